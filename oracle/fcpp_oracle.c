@@ -1,0 +1,774 @@
+/*
+ * fcpp_oracle.c -- TEST INFRASTRUCTURE ONLY (see fcpp_oracle.h).
+ *
+ * Sequential float64 restatement of the reference's hot path with the
+ * reference's operation order.  Citations "MLP:a-b" are line ranges of
+ * /root/reference/multi_layer_planner_v3.py, "GA:a-b" of
+ * /root/reference/genetic_algorithm_solver.py (reference @ 2025-10-24).
+ *
+ * Build with -ffp-contract=off: numpy evaluates a*b+c with two roundings.
+ */
+#include "fcpp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* numpy.linspace(a, b, n) (endpoint=True): i*step + a, last element := b     */
+/* ------------------------------------------------------------------------- */
+void orc_linspace(double a, double b, int64_t n, double *out)
+{
+    if (n <= 0) return;
+    if (n == 1) { out[0] = 0.0 * (b - a) + a; return; }
+    double div = (double)(n - 1);
+    double delta = b - a;
+    double step = delta / div;
+    if (step == 0.0) {
+        for (int64_t i = 0; i < n; ++i) out[i] = ((double)i / div) * delta + a;
+    } else {
+        for (int64_t i = 0; i < n; ++i) out[i] = (double)i * step + a;
+    }
+    out[n - 1] = b;
+}
+
+/* MLP:513-536 */
+double orc_curvature(const double *p1, const double *p2, const double *p3)
+{
+    double dx1 = p2[0] - p1[0], dy1 = p2[1] - p1[1];
+    double dx2 = p3[0] - p2[0], dy2 = p3[1] - p2[1];
+    double ds1 = sqrt(dx1 * dx1 + dy1 * dy1);
+    double ds2 = sqrt(dx2 * dx2 + dy2 * dy2);
+    if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
+    double theta1 = atan2(dy1, dx1);
+    double theta2 = atan2(dy2, dx2);
+    double dtheta = theta2 - theta1;
+    dtheta = atan2(sin(dtheta), cos(dtheta));
+    return fabs(2 * dtheta / (ds1 + ds2));
+}
+
+/* MLP:538-589: forward (accel) sweep then backward (decel) sweep, km/h in/out */
+void orc_smooth_speed_profile(const double *xy, double *v, int64_t n, double a_lon)
+{
+    if (n < 2) return;
+    for (int64_t i = 1; i < n; ++i) {                      /* MLP:558-571 */
+        double dx = xy[2 * i] - xy[2 * (i - 1)], dy = xy[2 * i + 1] - xy[2 * (i - 1) + 1];
+        double dist = sqrt(dx * dx + dy * dy);
+        if (dist < 1e-6) continue;
+        double v1 = v[i - 1] / 3.6;
+        double vmax_ms = sqrt(v1 * v1 + 2 * a_lon * dist);
+        double vmax_kmh = vmax_ms * 3.6;
+        if (v[i] > vmax_kmh) v[i] = vmax_kmh;
+    }
+    for (int64_t i = n - 2; i >= 0; --i) {                 /* MLP:574-587 */
+        double dx = xy[2 * (i + 1)] - xy[2 * i], dy = xy[2 * (i + 1) + 1] - xy[2 * i + 1];
+        double dist = sqrt(dx * dx + dy * dy);
+        if (dist < 1e-6) continue;
+        double v2 = v[i + 1] / 3.6;
+        double vmax_ms = sqrt(v2 * v2 + 2 * a_lon * dist);
+        double vmax_kmh = vmax_ms * 3.6;
+        if (v[i] > vmax_kmh) v[i] = vmax_kmh;
+    }
+}
+
+/* MLP:467-511; returns the number of clamped points ("speed_adjustments") */
+int64_t orc_speed_limit(const double *xy, const double *v_in, double *v_out, int64_t n,
+                        const orc_vehicle *veh)
+{
+    memcpy(v_out, v_in, (size_t)n * sizeof(double));
+    if (n < 3) return 0;                                   /* MLP:480-481 (no smoothing either) */
+    int64_t adj = 0;
+    for (int64_t i = 1; i < n - 1; ++i) {
+        double kappa = orc_curvature(xy + 2 * (i - 1), xy + 2 * i, xy + 2 * (i + 1));
+        if (kappa > 1e-6) {
+            double vmax_ms = sqrt(veh->max_lateral_accel / kappa) * veh->safety_factor;
+            double vmax_kmh = vmax_ms * 3.6;
+            if (v_out[i] > vmax_kmh) { v_out[i] = vmax_kmh; ++adj; }
+        }
+    }
+    orc_smooth_speed_profile(xy, v_out, n, veh->max_longitudinal_accel);
+    return adj;
+}
+
+/* MLP:1373-1424 */
+void orc_verify(const double *xy, const double *v, int64_t n, const orc_vehicle *veh, double *o)
+{
+    if (n < 3) { o[0] = 0; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 0; o[5] = 1; return; }
+    double maxk = 0, maxa = 0, maxj = 0, prevk = 0;
+    int64_t viol = 0;
+    int first = 1;
+    for (int64_t i = 1; i < n - 1; ++i) {
+        double k = orc_curvature(xy + 2 * (i - 1), xy + 2 * i, xy + 2 * (i + 1));
+        double vms = v[i] / 3.6;
+        double alat = vms * vms * k;
+        if (first || k > maxk) maxk = k;
+        if (first || alat > maxa) maxa = alat;
+        if (alat > veh->max_lateral_accel) ++viol;
+        if (!first) { double j = fabs(k - prevk); if (j > maxj) maxj = j; }
+        prevk = k;
+        first = 0;
+    }
+    int64_t m = n - 2;
+    o[0] = maxk; o[1] = maxa; o[2] = (double)viol;
+    o[3] = m > 0 ? ((double)viol / (double)m * 100) : 0;
+    o[4] = maxj;
+    o[5] = o[3] < 5 ? 1 : 0;
+}
+
+/* MLP:1290-1296 (numpy sums pairwise; this sums left to right: compare to ~1e-12 relative) */
+double orc_path_length(const double *xy, int64_t n)
+{
+    if (n < 2) return 0.0;
+    double s = 0;
+    for (int64_t i = 1; i < n; ++i) {
+        double dx = xy[2 * i] - xy[2 * (i - 1)], dy = xy[2 * i + 1] - xy[2 * (i - 1) + 1];
+        s += sqrt(dx * dx + dy * dy);
+    }
+    return s;
+}
+
+/* MLP:1298-1311 */
+double orc_work_time(const double *xy, const double *v, int64_t n)
+{
+    if (n < 2) return 0.0;
+    double s = 0;
+    for (int64_t i = 1; i < n; ++i) {
+        double dx = xy[2 * i] - xy[2 * (i - 1)], dy = xy[2 * i + 1] - xy[2 * (i - 1) + 1];
+        double d = sqrt(dx * dx + dy * dy);
+        double avg = (v[i - 1] + v[i]) / 2;
+        double ms = avg / 3.6;
+        if (!(ms >= 0.1)) ms = 0.1;   /* np.maximum(avg, 0.1) */
+        s += d / ms;
+    }
+    return s;
+}
+
+/* MLP:1013-1022 */
+void orc_straight(double x0, double y0, double x1, double y1, int64_t n, double *xy)
+{
+    double *t = (double *)malloc((size_t)n * sizeof(double));
+    orc_linspace(x0, x1, n, t);
+    for (int64_t i = 0; i < n; ++i) xy[2 * i] = t[i];
+    orc_linspace(y0, y1, n, t);
+    for (int64_t i = 0; i < n; ++i) xy[2 * i + 1] = t[i];
+    free(t);
+}
+
+/* MLP:791-830 generalised to n points (reference: n = 20) */
+static void arc_uturn(double y, int turn_right, double min_x, double max_x, double R, int64_t n,
+                      double *xy)
+{
+    double *ang = (double *)malloc((size_t)n * sizeof(double));
+    orc_linspace(0.0, M_PI, n, ang);
+    for (int64_t i = 0; i < n; ++i) {
+        if (turn_right) {
+            xy[2 * i] = max_x - R * cos(ang[i]);
+            xy[2 * i + 1] = y + R * sin(ang[i]);
+        } else {
+            xy[2 * i] = min_x + R * cos(ang[i]);
+            xy[2 * i + 1] = y + R * sin(ang[i]);
+        }
+    }
+    free(ang);
+}
+
+void orc_safe_arc_turn(double y, int turn_right, double min_x, double max_x, double R, double *xy20)
+{
+    arc_uturn(y, turn_right, min_x, max_x, R, 20, xy20);
+}
+
+/* MLP:1580-1608 (and the identical block MLP:1046-1062); reference n = 15 */
+void orc_corner_arc(double x, double y, int ci, double R, int n, double *xy)
+{
+    double *ang = (double *)malloc((size_t)n * sizeof(double));
+    orc_linspace(0.0, M_PI / 2, n, ang);
+    for (int i = 0; i < n; ++i) {
+        double c = cos(ang[i]), s = sin(ang[i]);
+        if (ci == 0)      { xy[2 * i] = x + R * (1 - c); xy[2 * i + 1] = y + R * s; }
+        else if (ci == 1) { xy[2 * i] = x - R * s;       xy[2 * i + 1] = y + R * (1 - c); }
+        else if (ci == 2) { xy[2 * i] = x - R * (1 - c); xy[2 * i + 1] = y - R * s; }
+        else              { xy[2 * i] = x + R * s;       xy[2 * i + 1] = y - R * (1 - c); }
+    }
+    free(ang);
+}
+
+/* MLP:265-284 */
+void orc_rotate_point(double x, double y, double ang, double cx, double cy, double *out)
+{
+    x -= cx; y -= cy;
+    double ca = cos(ang), sa = sin(ang);
+    double xn = x * ca - y * sa;
+    double yn = x * sa + y * ca;
+    out[0] = xn + cx; out[1] = yn + cy;
+}
+
+/* MLP:1220-1288 (field boundary = bbox anchored at the origin, MLP:1241-1242) */
+double orc_distance_to_boundary(double x, double y, double dx, double dy, double L, double H, double R)
+{
+    double best = 0; int have = 0;
+    double cand[4]; int nc = 0;
+    if (fabs(dx) > 1e-6) { double t = (0 - x) / dx; if (t > 0) cand[nc++] = t; }
+    if (fabs(dx) > 1e-6) { double t = (L - x) / dx; if (t > 0) cand[nc++] = t; }
+    if (fabs(dy) > 1e-6) { double t = (0 - y) / dy; if (t > 0) cand[nc++] = t; }
+    if (fabs(dy) > 1e-6) { double t = (H - y) / dy; if (t > 0) cand[nc++] = t; }
+    for (int i = 0; i < nc; ++i) if (!have || cand[i] < best) { best = cand[i]; have = 1; }
+    if (!have) return 2.0 * R;
+    double maxd = 3.0 * R;
+    return best < maxd ? best : maxd;
+}
+
+static int64_t n_for_length(double len, double ds)
+{
+    int64_t n = (int64_t)ceil(len / ds) + 1;
+    return n < 2 ? 2 : n;
+}
+
+/* MLP:1154-1218.  spacing == 0 -> reference count max(10, int(len/0.5)); >0 -> dense (BUILD-DEFINED) */
+int64_t orc_reverse_path(const double *end, const double *second_last, double L, double H, double R,
+                         double spacing, double *len_out, double *xy)
+{
+    double tx = end[0] - second_last[0], ty = end[1] - second_last[1];
+    double nrm = sqrt(tx * tx + ty * ty);
+    double dx, dy;
+    if (nrm > 1e-6) { dx = -tx / nrm; dy = -ty / nrm; }
+    else { dx = -1.0; dy = 0.0; }  /* MLP:1195-1206 needs gap.centroid (GEOS); unreachable for arcs */
+    double len = orc_distance_to_boundary(end[0], end[1], dx, dy, L, H, R);
+    int64_t n;
+    if (spacing > 0) n = n_for_length(len, spacing);
+    else { n = (int64_t)(len / 0.5); if (n < 10) n = 10; }
+    if (len_out) *len_out = len;
+    if (xy) {
+        double *t = (double *)malloc((size_t)n * sizeof(double));
+        orc_linspace(0.0, len, n, t);
+        for (int64_t i = 0; i < n; ++i) {
+            xy[2 * i] = end[0] + t[i] * dx;
+            xy[2 * i + 1] = end[1] + t[i] * dy;
+        }
+        free(t);
+    }
+    return n;
+}
+
+/* GA:174-181 */
+double orc_ga_distance(const int32_t *route, int32_t n, const double *D)
+{
+    double total = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t a = route[i], b = route[(i + 1) % n];
+        total += D[(int64_t)a * n + b];
+    }
+    return total;
+}
+
+/* GA:168-172 */
+double orc_ga_fitness(const int32_t *route, int32_t n, const double *D)
+{
+    return 1.0 / (orc_ga_distance(route, n, D) + 1e-6);
+}
+
+/* ------------------------------------------------------------------------- */
+/* BUILD-DEFINED: Fresnel integrals by composite Gauss-Legendre in long double */
+/* ------------------------------------------------------------------------- */
+#define GLN 16
+static long double gl_x[GLN], gl_w[GLN];
+static int gl_ready = 0;
+
+static void gl_init(void)
+{
+    if (gl_ready) return;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int i = 0; i < GLN; ++i) {
+        long double x = cosl(pi * (i + 0.75L) / (GLN + 0.5L));
+        long double dp = 1;
+        for (int it = 0; it < 100; ++it) {
+            long double p0 = 1, p1 = x;
+            for (int k = 2; k <= GLN; ++k) {
+                long double p2 = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+                p0 = p1; p1 = p2;
+            }
+            dp = GLN * (x * p1 - p0) / (x * x - 1);
+            long double dx = p1 / dp;
+            x -= dx;
+            if (fabsl(dx) < 1e-21L) break;
+        }
+        gl_x[i] = x;
+        gl_w[i] = 2 / ((1 - x * x) * dp * dp);
+    }
+    gl_ready = 1;
+}
+
+void orc_fresnel(double t, double *C, double *S)
+{
+    gl_init();
+    const long double pi = 3.14159265358979323846264338327950288L;
+    long double at = fabsl((long double)t);
+    int64_t m = (int64_t)ceill(at / 0.125L);
+    if (m < 1) m = 1;
+    long double h = at / m, c = 0, s = 0;
+    for (int64_t p = 0; p < m; ++p) {
+        long double a = p * h, mid = a + h / 2;
+        for (int i = 0; i < GLN; ++i) {
+            long double u = mid + gl_x[i] * h / 2;
+            long double ph = pi * u * u / 2;
+            c += gl_w[i] * cosl(ph);
+            s += gl_w[i] * sinl(ph);
+        }
+    }
+    c *= h / 2; s *= h / 2;
+    if (t < 0) { c = -c; s = -s; }
+    *C = (double)c; *S = (double)s;
+}
+
+/* unit CAC (kappa_max = 1), total heading change D > 0 (CCW), clothoid share f.
+ * Entry clothoid length Lc = f*D (turns f*D/2), arc length La = (1-f)*D, exit clothoid Lc. */
+static void cac_unit_point(double D, double f, double s, double *X, double *Y)
+{
+    double Lc = f * D, La = (1 - f) * D, T = 2 * Lc + La;
+    double a = sqrt(M_PI * Lc);
+    if (s < 0) s = 0;
+    if (s > T) s = T;
+    if (Lc > 0 && s <= Lc) {
+        double c, sn;
+        orc_fresnel(s / a, &c, &sn);
+        *X = a * c; *Y = a * sn;
+        return;
+    }
+    double x1 = 0, y1 = 0, th1 = Lc / 2;
+    if (Lc > 0) { double c, sn; orc_fresnel(Lc / a, &c, &sn); x1 = a * c; y1 = a * sn; }
+    double cx = x1 - sin(th1), cy = y1 + cos(th1);
+    if (s <= Lc + La || Lc == 0) {
+        double th = th1 + (s - Lc);
+        *X = cx + sin(th); *Y = cy - cos(th);
+        return;
+    }
+    /* exit clothoid = entry clothoid mirrored about the turn's axis of symmetry */
+    double th2 = th1 + La;
+    double x2 = cx + sin(th2), y2 = cy - cos(th2);
+    double ex = x2 + (cos(D) * x1 + sin(D) * y1);   /* E = P2 + Rot(D) * (x1, -y1) */
+    double ey = y2 + (sin(D) * x1 - cos(D) * y1);
+    double ss = T - s, c, sn;
+    orc_fresnel(ss / a, &c, &sn);
+    double qx = a * c, qy = a * sn;
+    *X = ex - (cos(D) * qx + sin(D) * qy);          /* P = E - Rot(D) * (qx, -qy) */
+    *Y = ey - (sin(D) * qx - cos(D) * qy);
+}
+
+double orc_cac_length(double dth, double Re, double f)
+{
+    return (1 + f) * fabs(dth) * Re;
+}
+
+double orc_cac_fit_radius(double dth, double R, double f, int fit)
+{
+    if (!fit) return R;
+    double D = fabs(dth), X, Y;
+    cac_unit_point(D, f, (1 + f) * D, &X, &Y);
+    double chord_unit = sqrt(X * X + Y * Y);
+    return R * (2 * sin(D / 2)) / chord_unit;
+}
+
+void orc_cac_point(double x0, double y0, double th0, double dth, double Re, double f, double s,
+                   double *out)
+{
+    double D = fabs(dth), sg = dth < 0 ? -1.0 : 1.0, X, Y;
+    cac_unit_point(D, f, s / Re, &X, &Y);
+    Y *= sg;
+    out[0] = x0 + Re * (cos(th0) * X - sin(th0) * Y);
+    out[1] = y0 + Re * (sin(th0) * X + cos(th0) * Y);
+}
+
+/* even-odd crossing rule; points exactly on an edge are not specified */
+int orc_point_in_polygon(double px, double py, const double *xy, int64_t nv)
+{
+    int in = 0;
+    for (int64_t i = 0, j = nv - 1; i < nv; j = i++) {
+        double xi = xy[2 * i], yi = xy[2 * i + 1], xj = xy[2 * j], yj = xy[2 * j + 1];
+        if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
+    }
+    return in;
+}
+
+/* convex polygon, either orientation: outside if beyond any edge by more than tol */
+int orc_outside_convex(double px, double py, const double *vx, const double *vy, int nv, double tol)
+{
+    double a2 = 0;
+    for (int i = 0; i < nv; ++i) { int j = (i + 1) % nv; a2 += vx[i] * vy[j] - vx[j] * vy[i]; }
+    double sg = a2 >= 0 ? 1.0 : -1.0;
+    for (int i = 0; i < nv; ++i) {
+        int j = (i + 1) % nv;
+        double ex = vx[j] - vx[i], ey = vy[j] - vy[i];
+        double ln = sqrt(ex * ex + ey * ey);
+        double d = sg * (ex * (py - vy[i]) - ey * (px - vx[i])) / ln;  /* >0 inside */
+        if (d < -tol) return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* geometry the reference delegates to Shapely, for convex quadrilaterals only */
+/* (identical arithmetic to tools/_shapely_standin.py; GEOS itself unpinned)   */
+/* ------------------------------------------------------------------------- */
+static double poly_area_centroid(const double *vx, const double *vy, int n, double *cx, double *cy)
+{
+    double a = 0, sx = 0, sy = 0;
+    for (int i = 0; i < n; ++i) {
+        int j = (i + 1) % n;
+        double cr = vx[i] * vy[j] - vx[j] * vy[i];
+        a += cr;
+        sx += (vx[i] + vx[j]) * cr;
+        sy += (vy[i] + vy[j]) * cr;
+    }
+    a *= 0.5;
+    if (fabs(a) < 1e-300) { *cx = vx[0]; *cy = vy[0]; return 0.0; }
+    *cx = sx / (6.0 * a); *cy = sy / (6.0 * a);
+    return a;
+}
+
+/* sharp inset by d; returns 0 if empty */
+static int inset_convex(const double *vx, const double *vy, int n, double d, double *ox, double *oy)
+{
+    double cx, cy;
+    double a = poly_area_centroid(vx, vy, n, &cx, &cy);
+    double sgn = a > 0 ? 1.0 : -1.0;
+    double nx[8], ny[8];
+    for (int i = 0; i < n; ++i) {
+        int j = (i + 1) % n;
+        double ex = vx[j] - vx[i], ey = vy[j] - vy[i];
+        double ln = hypot(ex, ey);
+        nx[i] = -ey / ln * sgn; ny[i] = ex / ln * sgn;
+    }
+    for (int i = 0; i < n; ++i) {
+        int p = (i + n - 1) % n;
+        double den = 1.0 + (nx[p] * nx[i] + ny[p] * ny[i]);
+        ox[i] = vx[i] + d * (nx[p] + nx[i]) / den;
+        oy[i] = vy[i] + d * (ny[p] + ny[i]) / den;
+    }
+    for (int i = 0; i < n; ++i) {
+        int j = (i + 1) % n;
+        double ex = vx[j] - vx[i], ey = vy[j] - vy[i];
+        if ((ox[j] - ox[i]) * ex + (oy[j] - oy[i]) * ey <= 0) return 0;
+    }
+    return 1;
+}
+
+static double poly_abs_area(const double *vx, const double *vy, int n)
+{
+    double cx, cy;
+    return fabs(poly_area_centroid(vx, vy, n, &cx, &cy));
+}
+
+/* MLP:165-192 */
+static double corner_angle(const double *vx, const double *vy, int n, int i)
+{
+    int p = (i + n - 1) % n, q = (i + 1) % n;
+    double v1x = vx[p] - vx[i], v1y = vy[p] - vy[i];
+    double v2x = vx[q] - vx[i], v2y = vy[q] - vy[i];
+    double dot = v1x * v2x + v1y * v2y;
+    double n1 = sqrt(v1x * v1x + v1y * v1y), n2 = sqrt(v2x * v2x + v2y * v2y);
+    double c = dot / (n1 * n2);
+    if (c < -1.0) c = -1.0;
+    if (c > 1.0) c = 1.0;
+    return acos(c) * (180.0 / M_PI);
+}
+
+/* MLP:194-222 */
+static int is_parallelogram(const double *vx, const double *vy)
+{
+    double ex[4], ey[4];
+    for (int i = 0; i < 4; ++i) { int j = (i + 1) % 4; ex[i] = vx[j] - vx[i]; ey[i] = vy[j] - vy[i]; }
+    int ok = 1;
+    for (int k = 0; k < 2; ++k) {
+        int a = k, b = k + 2;
+        double cross = fabs(ex[a] * ey[b] - ey[a] * ex[b]);
+        double na = sqrt(ex[a] * ex[a] + ey[a] * ey[a]), nb = sqrt(ex[b] * ex[b] + ey[b] * ey[b]);
+        if (!(cross < 0.01 * (na * nb))) ok = 0;
+    }
+    return ok;
+}
+
+/* growable AoS path with speeds and flag words */
+typedef struct { double *xy, *v; uint32_t *fs; int64_t n, cap; } pbuf;
+static void pb_reserve(pbuf *b, int64_t extra)
+{
+    if (b->n + extra <= b->cap) return;
+    int64_t c = b->cap ? b->cap : 1024;
+    while (c < b->n + extra) c *= 2;
+    b->xy = (double *)realloc(b->xy, (size_t)c * 2 * sizeof(double));
+    b->v = (double *)realloc(b->v, (size_t)c * sizeof(double));
+    b->fs = (uint32_t *)realloc(b->fs, (size_t)c * sizeof(uint32_t));
+    b->cap = c;
+}
+static void pb_push(pbuf *b, const double *xy, int64_t n, double v, uint32_t fs)
+{
+    pb_reserve(b, n);
+    memcpy(b->xy + 2 * b->n, xy, (size_t)n * 2 * sizeof(double));
+    for (int64_t i = 0; i < n; ++i) { b->v[b->n + i] = v; b->fs[b->n + i] = fs; }
+    b->n += n;
+}
+
+/* a turn primitive of either model, n points (BUILD-DEFINED for model 1 / n != reference) */
+static void cac_sample(double x0, double y0, double th0, double dth, double R, const orc_options *o,
+                       int64_t n, double *xy)
+{
+    double Re = orc_cac_fit_radius(dth, R, o->clothoid_frac, o->clothoid_fit);
+    double T = orc_cac_length(dth, Re, o->clothoid_frac);
+    double *s = (double *)malloc((size_t)n * sizeof(double));
+    orc_linspace(0.0, T, n, s);
+    for (int64_t i = 0; i < n; ++i) orc_cac_point(x0, y0, th0, dth, Re, o->clothoid_frac, s[i], xy + 2 * i);
+    free(s);
+}
+static double turn_length(double dth, double R, const orc_options *o)
+{
+    if (o->turn_model == 0) return fabs(dth) * R;
+    double Re = orc_cac_fit_radius(dth, R, o->clothoid_frac, o->clothoid_fit);
+    return orc_cac_length(dth, Re, o->clothoid_frac);
+}
+
+/* MLP:720-789 with the reference's 2-point lines / 20-point arcs */
+int64_t orc_u_pattern(double min_x, double min_y, double max_x, double max_y, int reverse_order,
+                      int start_from_right, const orc_vehicle *veh, double *xy, double *v, int64_t cap)
+{
+    double R = veh->min_turn_radius, W = veh->working_width;
+    double lsx = min_x + R, lex = max_x - R;
+    int64_t P = (int64_t)((max_y - min_y) / W) + 1;
+    int64_t n = 0;
+    for (int64_t idx = 0; idx < P; ++idx) {
+        int64_t i = reverse_order ? (P - 1 - idx) : idx;
+        double y = min_y + (double)i * W;
+        int go_left = start_from_right ? (idx % 2 == 0) : (idx % 2 == 1);
+        if (n + 22 > cap) return -1;
+        if (go_left) { xy[2 * n] = lex; xy[2 * n + 1] = y; xy[2 * n + 2] = lsx; xy[2 * n + 3] = y; }
+        else         { xy[2 * n] = lsx; xy[2 * n + 1] = y; xy[2 * n + 2] = lex; xy[2 * n + 3] = y; }
+        v[n] = v[n + 1] = veh->max_work_speed_kmh;
+        n += 2;
+        if (idx < P - 1) {
+            orc_safe_arc_turn(y, !go_left, min_x, max_x, R, xy + 2 * n);
+            for (int k = 0; k < 20; ++k) v[n + k] = veh->headland_turn_speed_kmh;
+            n += 20;
+        }
+    }
+    return n;
+}
+
+static const double CORNER_TH0[4] = { M_PI / 2, M_PI, -M_PI / 2, 0.0 };
+
+int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options *opt, orc_plan *out)
+{
+    memset(out, 0, sizeof(*out));
+    const double W = veh->working_width, R = veh->min_turn_radius;
+    const double ds = opt->sample_spacing;
+    const double *vx = f->vx, *vy = f->vy;
+
+    /* ---- __init__, MLP:63-107 ---- */
+    double bminx = vx[0], bmaxx = vx[0], bminy = vy[0], bmaxy = vy[0];
+    for (int i = 1; i < 4; ++i) {
+        if (vx[i] < bminx) bminx = vx[i];
+        if (vx[i] > bmaxx) bmaxx = vx[i];
+        if (vy[i] < bminy) bminy = vy[i];
+        if (vy[i] > bmaxy) bmaxy = vy[i];
+    }
+    /* MLP:120-126: vertices -> bbox extents; length/width input -> as given (= vx[1], vy[2]) */
+    double L = f->from_vertices ? (bmaxx - bminx) : vx[1];
+    double H = f->from_vertices ? (bmaxy - bminy) : vy[2];
+    out->field_length = L; out->field_width = H;
+    int all90 = 1;
+    for (int i = 0; i < 4; ++i) {
+        out->corner_angles[i] = corner_angle(vx, vy, 4, i);
+        if (!(fabs(out->corner_angles[i] - 90) < 1.0)) all90 = 0;
+    }
+    out->shape = all90 ? 0 : (is_parallelogram(vx, vy) ? 1 : 2);                 /* MLP:137-163 */
+    out->headland_width = R;                                                     /* MLP:310 */
+    double hw = R;
+    int has_start = f->has_start && (0 <= f->start_x && f->start_x <= L && 0 <= f->start_y && f->start_y <= H);
+    int has_end = f->has_end && (0 <= f->end_x && f->end_x <= L && 0 <= f->end_y && f->end_y <= H);
+    out->start_kept = has_start; out->end_kept = has_end;                        /* MLP:322-343 */
+
+    /* ---- start corner, MLP:345-385, 396-399 ---- */
+    int sci = 0;
+    if (has_start) {
+        double cxs[4] = { hw / 2, L - hw / 2, L - hw / 2, hw / 2 };
+        double cys[4] = { hw / 2, hw / 2, H - hw / 2, H - hw / 2 };
+        double best = 0;
+        for (int i = 0; i < 4; ++i) {
+            double dx = cxs[i] - f->start_x, dy = cys[i] - f->start_y;
+            double d = sqrt(dx * dx + dy * dy);
+            if (i == 0 || d < best) { best = d; sci = i; }
+        }
+    }
+    out->start_corner = sci;
+
+    /* ---- layer 1, MLP:591-718 ---- */
+    double mx[4], my[4];
+    if (!inset_convex(vx, vy, 4, hw, mx, my) || poly_abs_area(mx, my, 4) < 1.0) return -1; /* MLP:597-598 */
+    double rot = atan2(vy[1] - vy[0], vx[1] - vx[0]);                            /* MLP:255-261 */
+    out->rotation_angle = rot;
+    int rotated = fabs(rot) > 0.01;                                              /* MLP:686 */
+    out->rotated = rotated;
+    double ccx = 0, ccy = 0, rx[4], ry[4], sx = f->start_x, sy = f->start_y;
+    if (rotated) {
+        poly_area_centroid(mx, my, 4, &ccx, &ccy);
+        for (int i = 0; i < 4; ++i) {
+            double o[2];
+            orc_rotate_point(mx[i], my[i], -rot, ccx, ccy, o);
+            rx[i] = o[0]; ry[i] = o[1];
+        }
+        if (has_start) { double o[2]; orc_rotate_point(sx, sy, -rot, ccx, ccy, o); sx = o[0]; sy = o[1]; }
+    } else {
+        for (int i = 0; i < 4; ++i) { rx[i] = mx[i]; ry[i] = my[i]; }
+    }
+    double min_x = rx[0], max_x = rx[0], min_y = ry[0], max_y = ry[0];
+    for (int i = 1; i < 4; ++i) {
+        if (rx[i] < min_x) min_x = rx[i];
+        if (rx[i] > max_x) max_x = rx[i];
+        if (ry[i] < min_y) min_y = ry[i];
+        if (ry[i] > max_y) max_y = ry[i];
+    }
+    int reverse_order = 0, start_from_right = 0;                                 /* MLP:631-668 */
+    if (has_start) {
+        if (sy > (min_y + max_y) / 2) reverse_order = 1;
+        if (sx > (min_x + max_x) / 2) start_from_right = 1;
+    }
+    out->reverse_order = reverse_order; out->start_from_right = start_from_right;
+
+    pbuf pb; memset(&pb, 0, sizeof(pb));
+    {   /* MLP:720-789 */
+        double lsx = min_x + R, lex = max_x - R;
+        int64_t P = (int64_t)((max_y - min_y) / W) + 1;
+        out->n_swaths = (int32_t)P;
+        int64_t n_line = ds > 0 ? n_for_length(fabs(lex - lsx), ds) : 2;
+        int64_t n_turn = ds > 0 ? n_for_length(turn_length(M_PI, R, opt), ds) : 20;
+        double *lb = (double *)malloc((size_t)(n_line > n_turn ? n_line : n_turn) * 2 * sizeof(double));
+        for (int64_t idx = 0; idx < P; ++idx) {
+            int64_t i = reverse_order ? (P - 1 - idx) : idx;
+            double y = min_y + (double)i * W;
+            int go_left = start_from_right ? (idx % 2 == 0) : (idx % 2 == 1);
+            if (go_left) orc_straight(lex, y, lsx, y, n_line, lb);
+            else orc_straight(lsx, y, lex, y, n_line, lb);
+            if (n_line == 2) { lb[1] = y; lb[3] = y; }
+            pb_push(&pb, lb, n_line, veh->max_work_speed_kmh, ORC_KIND_SWATH | ((uint32_t)i << ORC_INDEX_SHIFT));
+            if (idx < P - 1) {
+                int turn_right = !go_left;
+                if (opt->turn_model == 0) arc_uturn(y, turn_right, min_x, max_x, R, n_turn, lb);
+                else if (turn_right) cac_sample(max_x - R, y, M_PI / 2, -M_PI, R, opt, n_turn, lb);
+                else cac_sample(min_x + R, y, M_PI / 2, M_PI, R, opt, n_turn, lb);
+                pb_push(&pb, lb, n_turn, veh->headland_turn_speed_kmh,
+                        ORC_KIND_UTURN | ((uint32_t)i << ORC_INDEX_SHIFT));
+            }
+        }
+        free(lb);
+    }
+    if (rotated)                                                                 /* MLP:709-714 */
+        for (int64_t i = 0; i < pb.n; ++i)
+            orc_rotate_point(pb.xy[2 * i], pb.xy[2 * i + 1], rot, ccx, ccy, pb.xy + 2 * i);
+    int64_t n_main = pb.n;
+    out->n_main = n_main;
+
+    /* ---- layer 2, MLP:860-1084 ---- */
+    int num_loops = (int)ceil(hw / W);                                           /* MLP:916 */
+    out->n_loops = num_loops;
+    for (int loop = 0; loop < num_loops; ++loop) {
+        double offset = W / 2 + loop * W;                                        /* MLP:924 */
+        double cx4[4], cy4[4];
+        if (!inset_convex(vx, vy, 4, offset, cx4, cy4) || poly_abs_area(cx4, cy4, 4) < 1.0) {
+            free(pb.xy); free(pb.v); free(pb.fs);
+            return -2;                                                           /* MLP:967-969 then :939 */
+        }
+        uint32_t lp = ORC_FLAG_HEADLAND | ((uint32_t)(loop * 8) << ORC_INDEX_SHIFT);
+        double p0[2] = { cx4[sci], cy4[sci] };
+        pb_push(&pb, p0, 1, veh->max_headland_speed_kmh, ORC_KIND_HEAD_START | lp | ((uint32_t)sci << ORC_INDEX_SHIFT));
+        for (int i = 0; i < 4; ++i) {
+            int cur = (sci + i) % 4, nxt = (sci + i + 1) % 4;
+            double len = hypot(cx4[nxt] - cx4[cur], cy4[nxt] - cy4[cur]);
+            int64_t ns = ds > 0 ? n_for_length(len, ds) : 20;
+            double *sb = (double *)malloc((size_t)ns * 2 * sizeof(double));
+            orc_straight(cx4[cur], cy4[cur], cx4[nxt], cy4[nxt], ns, sb);
+            pb_push(&pb, sb, ns, veh->max_headland_speed_kmh,
+                    ORC_KIND_HEAD_STRAIGHT | lp | ((uint32_t)cur << ORC_INDEX_SHIFT));
+            free(sb);
+            if (i < 3) {
+                int64_t nt = ds > 0 ? n_for_length(turn_length(M_PI / 2, R, opt), ds) : 15;
+                double *tb = (double *)malloc((size_t)nt * 2 * sizeof(double));
+                if (opt->turn_model == 0) orc_corner_arc(cx4[nxt], cy4[nxt], nxt, R, (int)nt, tb);
+                else cac_sample(cx4[nxt], cy4[nxt], CORNER_TH0[nxt], -M_PI / 2, R, opt, nt, tb);
+                pb_push(&pb, tb, nt, veh->headland_turn_speed_kmh,
+                        ORC_KIND_CORNER | lp | ((uint32_t)nxt << ORC_INDEX_SHIFT));
+                /* MLP:1043, 224-242, 1066-1082 */
+                int add_rev = (loop == 0) && (out->corner_angles[nxt] >= 60);
+                /* gap.area > 0.1 (MLP:1070): lower bound 4R^2 - (pi R W/2 + pi W^2/4), GEOS unpinned */
+                double gap_lb = 4 * R * R - (M_PI * R / 2 * W + M_PI * W * W / 4);
+                if (add_rev && gap_lb > 0.1 && nt >= 2) {
+                    double rl;
+                    int64_t nr = orc_reverse_path(tb + 2 * (nt - 1), tb + 2 * (nt - 2), L, H, R, ds, &rl, NULL);
+                    double *rb = (double *)malloc((size_t)nr * 2 * sizeof(double));
+                    orc_reverse_path(tb + 2 * (nt - 1), tb + 2 * (nt - 2), L, H, R, ds, &rl, rb);
+                    pb_push(&pb, rb, nr, 2.5, ORC_KIND_REVERSE | lp | ((uint32_t)nxt << ORC_INDEX_SHIFT));
+                    out->n_reverse[nxt] = (int32_t)nr;
+                    free(rb);
+                }
+                free(tb);
+            }
+        }
+    }
+    int64_t N = pb.n, n_head = N - n_main;
+    out->n_head = n_head;
+
+    /* ---- stats before clamp, MLP:616-628, 882-895 ---- */
+    out->main_len_m = orc_path_length(pb.xy, n_main);
+    out->main_time_pre_s = orc_work_time(pb.xy, pb.v, n_main);
+    out->head_len_m = orc_path_length(pb.xy + 2 * n_main, n_head);
+    out->head_time_pre_s = orc_work_time(pb.xy + 2 * n_main, pb.v + n_main, n_head);
+
+    /* ---- speed plan on the concatenation, MLP:411-431 ---- */
+    double *vout = (double *)malloc((size_t)N * sizeof(double));
+    out->n_adjusted = orc_speed_limit(pb.xy, pb.v, vout, N, veh);
+    out->main_time_s = orc_work_time(pb.xy, vout, n_main);
+    out->head_time_s = orc_work_time(pb.xy + 2 * n_main, vout + n_main, n_head);
+
+    /* ---- verifier over the concatenation (as test/test_multi-layer_planner_v3.py:41-43) ---- */
+    double ver[6];
+    orc_verify(pb.xy, vout, N, veh, ver);
+    out->max_kappa = ver[0]; out->max_alat = ver[1]; out->n_viol = (int64_t)ver[2];
+    out->viol_rate = ver[3]; out->max_jump = ver[4]; out->pass = (int32_t)ver[5];
+
+    double *kap = (double *)calloc((size_t)N, sizeof(double));
+    for (int64_t i = 1; i < N - 1; ++i) {
+        kap[i] = orc_curvature(pb.xy + 2 * (i - 1), pb.xy + 2 * i, pb.xy + 2 * (i + 1));
+        double vms = vout[i] / 3.6;
+        if (vms * vms * kap[i] > veh->max_lateral_accel) pb.fs[i] |= ORC_FLAG_ALAT;
+    }
+    /* BUILD-DEFINED geofence / obstacle flags */
+    for (int64_t i = 0; i < N; ++i) {
+        double px = pb.xy[2 * i], py = pb.xy[2 * i + 1];
+        if (orc_outside_convex(px, py, vx, vy, 4, opt->geofence_tol)) { pb.fs[i] |= ORC_FLAG_OUTSIDE; out->n_outside++; }
+        for (int32_t k = 0; k < f->n_obstacles; ++k) {
+            int64_t a = f->obs_offsets[k], b = f->obs_offsets[k + 1];
+            if (orc_point_in_polygon(px, py, f->obs_xy + 2 * a, b - a)) {
+                pb.fs[i] |= ORC_FLAG_OBSTACLE; out->n_in_obstacle++;
+                break;
+            }
+        }
+    }
+
+    /* ---- connectors, MLP:437-447, 1313-1355 ---- */
+    if (has_start && n_head > 0) {
+        out->has_approach = 1;
+        orc_straight(f->start_x, f->start_y, pb.xy[2 * n_main], pb.xy[2 * n_main + 1], 50, out->approach);
+    }
+    if (has_end && n_head > 0) {
+        out->has_departure = 1;
+        orc_straight(pb.xy[2 * (N - 1)], pb.xy[2 * (N - 1) + 1], f->end_x, f->end_y, 50, out->departure);
+    }
+    out->xy = pb.xy; out->v = vout; out->kappa = kap; out->flagseg = pb.fs;
+    free(pb.v);
+    return 0;
+}
+
+void orc_plan_free(orc_plan *p)
+{
+    free(p->xy); free(p->v); free(p->kappa); free(p->flagseg);
+    p->xy = p->v = p->kappa = NULL; p->flagseg = NULL;
+}

@@ -1,0 +1,180 @@
+"""Pins the CPU oracle (oracle/fcpp_oracle.c) to the reference.
+
+Golden vectors in tests/golden/*.npz were produced by tools/gen_golden.py, which runs the
+reference's own Python code (multi_layer_planner_v3.py / genetic_algorithm_solver.py).
+Tolerances: numpy's libm/SIMD transcendental kernels and glibc's differ by <= 1-2 ulp, so
+coordinates are compared at 1e-11 m (tier A kernels mostly come out bit-equal); integer
+quantities (point counts, swath counts, violation counts) must be exactly equal.
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+XY_TOL = 1e-11
+V_TOL = 1e-10
+
+
+def test_curvature(golden_kernels):
+    g = golden_kernels
+    k = np.array([orc.curvature(t[0], t[1], t[2]) for t in g['curv_tri']])
+    np.testing.assert_allclose(k, g['curv_kappa'], rtol=1e-13, atol=1e-15)
+    assert k[0] == 0 and k[1] == 0 and k[4] == 0      # degenerate stencils -> exactly 0
+
+
+def test_speed_planner(golden_kernels):
+    g = golden_kernels
+    veh = orc.Vehicle.make(g['vp_default'])
+    veh2 = orc.Vehicle.make(g['vp2'])
+    offs = g['sp_offsets']
+    for k in range(len(offs) - 1):
+        a, b = offs[k], offs[k + 1]
+        xy, v = g['sp_path'][a:b], g['sp_v_in'][a:b]
+        out, _ = orc.speed_limit(xy, v, veh)
+        np.testing.assert_allclose(out, g['sp_v_out'][a:b], rtol=0, atol=V_TOL)
+        out2, _ = orc.speed_limit(xy, v, veh2)
+        np.testing.assert_allclose(out2, g['sp2_v_out'][a:b], rtol=0, atol=V_TOL)
+        sm = orc.smooth_speed_profile(xy, v, veh.max_longitudinal_accel)
+        np.testing.assert_allclose(sm, g['sp_v_smooth_only'][a:b], rtol=0, atol=V_TOL)
+
+
+def test_verifier_and_metrics(golden_kernels):
+    g = golden_kernels
+    veh = orc.Vehicle.make(g['vp_default'])
+    offs = g['sp_offsets']
+    for k in range(len(offs) - 1):
+        a, b = offs[k], offs[k + 1]
+        xy, v = g['sp_path'][a:b], g['sp_v_out'][a:b]
+        st = orc.verify(xy, v, veh)
+        ref = g['ver_stats'][k]
+        np.testing.assert_allclose(st[[0, 1, 3, 4]], ref[[0, 1, 3, 4]], rtol=1e-12, atol=1e-13)
+        assert st[2] == ref[2] and st[5] == ref[5]
+        np.testing.assert_allclose(orc.path_length(xy), g['len_m'][k], rtol=1e-13)
+        np.testing.assert_allclose(orc.work_time(xy, v), g['time_s'][k], rtol=1e-13)
+        if k >= 1:
+            st15 = orc.verify(xy, np.full(len(xy), 15.0), veh)
+            ref15 = g['ver15_stats'][k - 1]
+            assert st15[2] == ref15[2] and st15[5] == ref15[5]
+            np.testing.assert_allclose(st15[[0, 1, 3, 4]], ref15[[0, 1, 3, 4]], rtol=1e-12, atol=1e-13)
+    assert g['ver15_stats'][:, 2].max() > 0  # the violating case is really exercised
+
+
+def test_samplers(golden_kernels):
+    g = golden_kernels
+    R = 8.0
+    for args, pts in zip(g['uturn_args'], g['uturn_pts']):
+        got = orc.safe_arc_turn(args[1], bool(args[2]), args[3], args[4], R)
+        np.testing.assert_allclose(got, pts, rtol=0, atol=XY_TOL)
+    for ci in range(4):
+        got = orc.corner_arc(100.25 + ci, 50.5 - ci, ci, R)
+        np.testing.assert_allclose(got, g['corner_arc_pts'][ci], rtol=0, atol=XY_TOL)
+    assert np.array_equal(orc.straight(1.6, 1.6, 498.4, 1.6, 20), g['straight_pts'])      # linspace: bit-equal
+    assert np.array_equal(orc.straight(498.4, 1.6, 498.4, 198.4, 20), g['straight2_pts'])
+    assert np.array_equal(orc.straight(10.0, 10.0, 1.6, 1.6, 50), g['approach_pts'])
+    for r_in, r_out in zip(g['rot_in'], g['rot_out']):
+        np.testing.assert_allclose(orc.rotate_point(*r_in), r_out, rtol=0, atol=1e-12)
+
+
+def test_reverse_fill(golden_kernels):
+    g = golden_kernels
+    W, R = 3.2, 8.0
+    cs = [(W / 2, W / 2), (500 - W / 2, W / 2), (500 - W / 2, 200 - W / 2), (W / 2, 200 - W / 2)]
+    offs = g['rev_offsets']
+    for ci in range(4):
+        arc = orc.corner_arc(cs[ci][0], cs[ci][1], ci, R)
+        pts, ln = orc.reverse_path(arc[-1], arc[-2], 500.0, 200.0, R)
+        ref = g['rev_pts'][offs[ci]:offs[ci + 1]]
+        assert len(pts) == len(ref)                       # int(len/0.5): exact
+        np.testing.assert_allclose(pts, ref, rtol=0, atol=XY_TOL)
+        np.testing.assert_allclose(ln, g['rev_len'][ci], rtol=1e-13)
+
+
+def test_u_pattern(golden_kernels):
+    g = golden_kernels
+    veh = orc.Vehicle.make(g['vp_default'])
+    offs = g['upat_offsets']
+    for k, a in enumerate(g['upat_args']):
+        xy, v = orc.u_pattern(a[:4], bool(a[4]), bool(a[5]), veh)
+        ref = g['upat_pts'][offs[k]:offs[k + 1]]
+        assert len(xy) == len(ref)
+        np.testing.assert_allclose(xy, ref, rtol=0, atol=XY_TOL)
+        assert np.array_equal(v, g['upat_v'][offs[k]:offs[k + 1]])
+
+
+def test_ga_tour_length(golden_ga):
+    g = golden_ga
+    for tag in ('n10', 'n128', 'n129', 'n33'):
+        D, routes = g[f'{tag}_D'], g[f'{tag}_routes']
+        assert np.array_equal(orc.ga_distance(routes, D), g[f'{tag}_dist'])   # sequential sum: bit-equal
+        assert np.array_equal(orc.ga_fitness(routes, D), g[f'{tag}_fit'])
+
+
+def _field_from_golden(g, name):
+    verts = g[f'{name}/verts']
+    start = g[f'{name}/start']
+    end = g[f'{name}/end']
+    obstacles = None
+    if f'{name}/obs_offsets' in g:
+        o, xy = g[f'{name}/obs_offsets'], g[f'{name}/obs_xy']
+        obstacles = [xy[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+    kw = dict(start=None if np.isnan(start[0]) else start, end=None if np.isnan(end[0]) else end,
+              obstacles=obstacles)
+    if int(g[f'{name}/is_verts_input']):
+        return orc.make_field(verts=verts, **kw)
+    return orc.make_field(L=float(verts[1][0]), H=float(verts[2][1]), **kw)
+
+
+def test_full_plans(golden_plans):
+    g = golden_plans
+    shapes = {'rectangle': 0, 'parallelogram': 1, 'other': 2}
+    for name in g['names']:
+        f = _field_from_golden(g, name)
+        veh = orc.Vehicle.make(g[f'{name}/vp'])
+        rc, p = orc.plan_field(f, veh)
+        assert rc == 0, name
+        mp, hp = g[f'{name}/main_path'], g[f'{name}/head_path']
+        assert p.n_main == len(mp) and p.n_head == len(hp), name             # counts: exact
+        assert p.shape == shapes[str(g[f'{name}/shape'])], name
+        assert p.start_kept == int(g[f'{name}/start_kept']) and p.end_kept == int(g[f'{name}/end_kept'])
+        np.testing.assert_allclose(p.corner_angles, g[f'{name}/corner_angles'], rtol=1e-13, err_msg=name)
+        np.testing.assert_allclose([p.field_length, p.field_width], g[f'{name}/field_LH'], rtol=1e-15)
+        np.testing.assert_allclose(p.xy[:p.n_main], mp, rtol=0, atol=2e-10, err_msg=name)
+        np.testing.assert_allclose(p.xy[p.n_main:], hp, rtol=0, atol=2e-10, err_msg=name)
+        np.testing.assert_allclose(p.v[:p.n_main], g[f'{name}/main_v'], rtol=0, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(p.v[p.n_main:], g[f'{name}/head_v'], rtol=0, atol=1e-9, err_msg=name)
+        ms, hs = g[f'{name}/main_stats'], g[f'{name}/head_stats']
+        np.testing.assert_allclose(p.main_len_m / 1000, ms[0], rtol=1e-12)
+        np.testing.assert_allclose(p.main_time_s / 3600, ms[1], rtol=1e-11)
+        np.testing.assert_allclose((p.main_len_m / 1000) / (p.main_time_pre_s / 3600), ms[2], rtol=1e-11)
+        np.testing.assert_allclose(p.head_len_m / 1000, hs[0], rtol=1e-12)
+        np.testing.assert_allclose(p.head_time_s / 3600, hs[1], rtol=1e-11)
+        ver = g[f'{name}/ver']
+        np.testing.assert_allclose([p.max_kappa, p.max_alat, p.viol_rate, p.max_jump], ver[[0, 1, 3, 4]],
+                                   rtol=1e-9, atol=1e-12, err_msg=name)
+        assert p.n_viol == ver[2] and p.passed == bool(ver[5]), name
+        ap, dp = g[f'{name}/approach'], g[f'{name}/departure']
+        assert (p.approach is None) == (len(ap) == 0) and (p.departure is None) == (len(dp) == 0)
+        if p.approach is not None:
+            np.testing.assert_allclose(p.approach, ap, rtol=0, atol=2e-10)
+        if p.departure is not None:
+            np.testing.assert_allclose(p.departure, dp, rtol=0, atol=2e-10)
+
+
+def test_published_pins(golden_plans):
+    """Numbers the reference's docs publish (README_en.md:199-215)."""
+    rc, p = orc.plan_field(orc.make_field(L=500.0, H=200.0))
+    assert rc == 0
+    assert (p.n_swaths, p.n_main, p.n_head, p.n_loops) == (58, 1256, 435, 3)
+    assert p.headland_width == 8.0 and p.n_viol == 0 and p.viol_rate == 0.0 and p.n_outside == 0
+    assert abs(p.main_len_m / 1000 - 29.504996) < 1e-6 and abs(p.head_len_m / 1000 - 4.326508) < 1e-6
+    assert abs(p.main_time_s / 3600 - 3.516820) < 1e-6 and abs(p.head_time_s / 3600 - 0.327350) < 1e-6
+    assert abs(p.max_kappa - 0.42278406271172153) < 1e-12
+    assert len(np.unique(p.v)) == 13 and len(np.unique(np.round(p.v, 9))) == 11
+    # fp-fragile swath counts (SURVEY.md 7 "hard parts"): (H-2R)/W = 8.999...98 -> 9 ; 3.000...04 -> 4
+    assert orc.plan_field(orc.make_field(L=500.0, H=44.8))[1].n_swaths == 9
+    assert orc.plan_field(orc.make_field(L=500.0, H=25.6))[1].n_swaths == 4
+
+
+def test_error_cases():
+    assert orc.plan_field(orc.make_field(L=15.0, H=200.0))[0] == -1     # MLP:597-598 ValueError
+    assert orc.plan_field(orc.make_field(L=500.0, H=16.5))[0] == -1     # inset area < 1

@@ -119,26 +119,29 @@ class Polygon:
 
 
 def _inset_convex(vs, d):
-    """Sharp inset of a convex polygon by distance d (same vertex order)."""
+    """Sharp inset of a convex polygon by distance d (same vertex order).
+
+    Vertex i moves along the mitre of its two edges:
+        v_i + d * (n_a + n_b) / (1 + n_a . n_b)
+    with n_a, n_b the inward unit normals of edge (i-1) and edge i.  For an
+    axis-aligned rectangle this is exactly (x +- d, y +- d).
+    """
     n = len(vs)
     a, _ = _area_centroid(vs)
     sgn = 1.0 if a > 0 else -1.0  # CCW -> inward normal is left of edge
-    lines = []
+    normals = []
     for i in range(n):
         x0, y0 = vs[i]
         x1, y1 = vs[(i + 1) % n]
         ex, ey = x1 - x0, y1 - y0
         ln = math.hypot(ex, ey)
-        nx, ny = -ey / ln * sgn, ex / ln * sgn  # inward normal
-        lines.append((x0 + nx * d, y0 + ny * d, ex, ey))
+        normals.append((-ey / ln * sgn, ex / ln * sgn))
     out = []
     for i in range(n):
-        # vertex i = intersection of offset edge (i-1) and offset edge i
-        px, py, pdx, pdy = lines[(i - 1) % n]
-        qx, qy, qdx, qdy = lines[i]
-        den = pdx * qdy - pdy * qdx
-        t = ((qx - px) * qdy - (qy - py) * qdx) / den
-        out.append((px + t * pdx, py + t * pdy))
+        ax, ay = normals[(i - 1) % n]
+        bx, by = normals[i]
+        den = 1.0 + (ax * bx + ay * by)
+        out.append((vs[i][0] + d * (ax + bx) / den, vs[i][1] + d * (ay + by) / den))
     # validity: every inset edge must keep the direction of its source edge
     for i in range(n):
         x0, y0 = out[i]
