@@ -177,4 +177,4 @@ def test_published_pins(golden_plans):
 
 def test_error_cases():
     assert orc.plan_field(orc.make_field(L=15.0, H=200.0))[0] == -1     # MLP:597-598 ValueError
-    assert orc.plan_field(orc.make_field(L=500.0, H=16.5))[0] == -1     # inset area < 1
+    assert orc.plan_field(orc.make_field(L=500.0, H=16.002))[0] == -1   # inset area 484*0.002 < 1
