@@ -1,0 +1,140 @@
+"""ctypes binding of libfcpp.so (the C ABI declared in include/fcpp.h).
+
+There is no Python or CPU implementation behind these calls: if the shared library is missing, or no
+HIP device is usable, the operators raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfcpp.so')
+
+OK, EINVAL, EHEADLAND, EUNSUPPORTED, EHIP, ENOMEM, ESIZE = 0, -1, -2, -3, -4, -5, -6
+TURN_ARC, TURN_CLOTHOID = 0, 1
+KIND_SWATH, KIND_UTURN, KIND_HEAD_START, KIND_HEAD_STRAIGHT, KIND_CORNER, KIND_REVERSE = range(6)
+KIND_MASK, FLAG_HEADLAND, FLAG_ALAT, FLAG_OUTSIDE, FLAG_OBSTACLE, INDEX_SHIFT = 7, 8, 16, 32, 64, 8
+
+c_double_p = C.POINTER(C.c_double)
+c_i64_p = C.POINTER(C.c_int64)
+
+
+class FcppError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libfcpp error {code}: {msg}')
+        self.code = code
+
+
+class Vehicle(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        'working_width', 'min_turn_radius', 'max_work_speed_kmh', 'max_headland_speed_kmh',
+        'headland_turn_speed_kmh', 'max_lateral_accel', 'max_longitudinal_accel', 'safety_factor')]
+
+
+class Options(C.Structure):
+    _fields_ = [('turn_model', C.c_int32), ('clothoid_fit', C.c_int32), ('sample_spacing', C.c_double),
+                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double)]
+
+
+class Field(C.Structure):
+    _fields_ = [('vx', C.c_double * 4), ('vy', C.c_double * 4), ('from_vertices', C.c_int32),
+                ('has_start', C.c_int32), ('has_end', C.c_int32),
+                ('start_x', C.c_double), ('start_y', C.c_double), ('end_x', C.c_double), ('end_y', C.c_double),
+                ('n_obstacles', C.c_int32), ('_pad', C.c_int32), ('obstacle_first', C.c_int64)]
+
+
+class Polys(C.Structure):
+    _fields_ = [('n_polys', C.c_int64), ('offsets', c_i64_p), ('x', c_double_p), ('y', c_double_p)]
+
+
+class FieldInfo(C.Structure):
+    _fields_ = [('point_offset', C.c_int64), ('n_main', C.c_int64), ('n_head', C.c_int64),
+                ('n_swaths', C.c_int32), ('n_loops', C.c_int32), ('start_corner', C.c_int32),
+                ('reverse_order', C.c_int32), ('start_from_right', C.c_int32), ('rotated', C.c_int32),
+                ('start_kept', C.c_int32), ('end_kept', C.c_int32), ('shape', C.c_int32),
+                ('n_reverse', C.c_int32 * 4), ('status', C.c_int32),
+                ('corner_angles', C.c_double * 4), ('field_length', C.c_double), ('field_width', C.c_double),
+                ('headland_width', C.c_double), ('rotation_angle', C.c_double),
+                ('approach_from', C.c_double * 2), ('approach_to', C.c_double * 2),
+                ('departure_from', C.c_double * 2), ('departure_to', C.c_double * 2)]
+
+
+class FieldStats(C.Structure):
+    _fields_ = [('main_len_m', C.c_double), ('main_time_pre_s', C.c_double), ('main_time_s', C.c_double),
+                ('head_len_m', C.c_double), ('head_time_pre_s', C.c_double), ('head_time_s', C.c_double),
+                ('max_kappa', C.c_double), ('max_alat', C.c_double), ('max_jump', C.c_double),
+                ('n_viol', C.c_int64), ('n_outside', C.c_int64), ('n_in_obstacle', C.c_int64),
+                ('n_adjusted', C.c_int64)]
+
+
+STATS_DOUBLES = 9   # leading float64 members of FieldStats
+STATS_WORDS = 13    # 8-byte words per FieldStats
+
+# every symbol include/fcpp.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+PROTOTYPES = [
+    ('fcpp_last_error', C.c_char_p, []),
+    ('fcpp_abi_version', C.c_int, []),
+    ('fcpp_vehicle_default', None, [C.POINTER(Vehicle)]),
+    ('fcpp_options_default', None, [C.POINTER(Options)]),
+    ('fcpp_ctx_create', C.c_int, [C.c_int, C.POINTER(_VP)]),
+    ('fcpp_ctx_destroy', C.c_int, [_VP]),
+    ('fcpp_ctx_set_stream', C.c_int, [_VP, _VP]),
+    ('fcpp_ctx_synchronize', C.c_int, [_VP]),
+    ('fcpp_malloc', C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
+    ('fcpp_free', C.c_int, [_VP, _VP]),
+    ('fcpp_memcpy_h2d', C.c_int, [_VP, _VP, _VP, C.c_int64]),
+    ('fcpp_memcpy_d2h', C.c_int, [_VP, _VP, _VP, C.c_int64]),
+    ('fcpp_plan_count', C.c_int, [C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field),
+                                  C.POINTER(FieldInfo)]),
+    ('fcpp_batch_create', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field),
+                                    C.POINTER(Polys), C.POINTER(_VP)]),
+    ('fcpp_batch_info', C.c_int, [_VP, C.POINTER(FieldInfo), c_i64_p]),
+    ('fcpp_batch_run', C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int]),
+    ('fcpp_batch_connectors', C.c_int, [_VP, _VP, _VP]),
+    ('fcpp_batch_destroy', C.c_int, [_VP]),
+    ('fcpp_curvature', C.c_int, [_VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP]),
+    ('fcpp_speed_plan', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP,
+                                  _VP, _VP]),
+    ('fcpp_verify', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
+    ('fcpp_straight_segments', C.c_int, [_VP, C.c_int64, _VP, C.c_int32, _VP]),
+    ('fcpp_fresnel', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
+    ('fcpp_ga_fitness', C.c_int, [_VP, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_int]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libfcpp.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C {os.path.join(_HERE, "csrc")}`; there is no CPU fallback')
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in PROTOTYPES:
+            fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.fcpp_abi_version() != 1:
+            raise ImportError('libfcpp.so ABI version mismatch')
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise FcppError(rc, load().fcpp_last_error().decode('utf-8', 'replace'))
+
+
+def default_vehicle():
+    v = Vehicle()
+    load().fcpp_vehicle_default(C.byref(v))
+    return v
+
+
+def default_options():
+    o = Options()
+    load().fcpp_options_default(C.byref(o))
+    return o

@@ -1,0 +1,475 @@
+// fcpp_api.cpp -- the C ABI declared in include/fcpp.h: argument checking, device buffers, launches.
+// No CPU compute path exists here: every operator ends in a HIP kernel launch or fails with FCPP_EHIP.
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fcpp_device.h"
+#include "fcpp_internal.h"
+
+using namespace fcpp;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(FCPP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+#define LAUNCHCHK(expr)                                                                                  \
+    do {                                                                                                 \
+        int e_ = (expr);                                                                                 \
+        if (e_ != 0)                                                                                     \
+            return fail(FCPP_EHIP, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e_));       \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h, hipStream_t st)
+    {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st);
+    }
+};
+
+DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
+{
+    DevConst c;
+    c.a_lat = veh.max_lateral_accel; c.a_lon = veh.max_longitudinal_accel; c.sf = veh.safety_factor;
+    c.geofence_tol = opt.geofence_tol;
+    c.v_work = veh.max_work_speed_kmh; c.v_turn = veh.headland_turn_speed_kmh; c.v_head = veh.max_headland_speed_kmh;
+    c.sh_pi = make_cac_shape(kPi, opt.clothoid_frac);
+    c.sh_half = make_cac_shape(kHalfPi, opt.clothoid_frac);
+    return c;
+}
+
+// tile table of a set of paths
+struct Tiling {
+    std::vector<DevPath> paths;
+    std::vector<DevTile> tiles;
+    std::vector<int64_t> tile_first;
+    void build(int64_t n_paths, const int64_t *offsets)
+    {
+        paths.resize((size_t)n_paths);
+        tile_first.assign((size_t)n_paths + 1, 0);
+        tiles.clear();
+        for (int64_t p = 0; p < n_paths; ++p) {
+            const int64_t n = offsets[p + 1] - offsets[p];
+            paths[(size_t)p] = { offsets[p], n };
+            tile_first[(size_t)p] = (int64_t)tiles.size();
+            for (int64_t s = 0; s < n; s += TILE_POINTS) {
+                DevTile t;
+                t.field = (int32_t)p; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, n - s);
+                tiles.push_back(t);
+            }
+        }
+        tile_first[(size_t)n_paths] = (int64_t)tiles.size();
+    }
+};
+
+struct DevTiling {
+    DevBuf<DevPath> paths;
+    DevBuf<DevTile> tiles;
+    DevBuf<int64_t> tile_first;
+    DevBuf<char> agg_f, agg_b;   // Agg = 2 doubles
+    DevBuf<double> carry_f, carry_b;
+    DevBuf<TilePartial> partial;
+    DevBuf<unsigned long long> n_adj;
+    int64_t n_tiles = 0, n_paths = 0;
+    hipError_t upload(const Tiling &t, hipStream_t st)
+    {
+        n_tiles = (int64_t)t.tiles.size(); n_paths = (int64_t)t.paths.size();
+        hipError_t e;
+        if ((e = paths.upload(t.paths, st)) != hipSuccess) return e;
+        if ((e = tiles.upload(t.tiles, st)) != hipSuccess) return e;
+        if ((e = tile_first.upload(t.tile_first, st)) != hipSuccess) return e;
+        if ((e = agg_f.alloc((size_t)n_tiles * 16)) != hipSuccess) return e;
+        if ((e = agg_b.alloc((size_t)n_tiles * 16)) != hipSuccess) return e;
+        if ((e = carry_f.alloc((size_t)n_tiles)) != hipSuccess) return e;
+        if ((e = carry_b.alloc((size_t)n_tiles)) != hipSuccess) return e;
+        if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
+        if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+};
+}  // namespace
+
+struct fcpp_ctx {
+    int device = 0;
+    hipStream_t own = nullptr, stream = nullptr;
+};
+
+struct fcpp_batch {
+    fcpp_ctx *ctx = nullptr;
+    fcpp_vehicle veh;
+    fcpp_options opt;
+    int64_t n_fields = 0;
+    HostPlan hp;
+    DevConst cst;
+    DevBuf<DevField> fields;
+    DevBuf<DevPrim> prims;
+    DevTiling til;
+    DevBuf<int64_t> obs_off;
+    DevBuf<double> obs_x, obs_y;
+    DevBuf<double> seg;        // connector segments
+    DevBuf<int32_t> seg_mask;
+};
+
+extern "C" {
+
+const char *fcpp_last_error(void) { return g_err.c_str(); }
+int fcpp_abi_version(void) { return FCPP_ABI_VERSION; }
+
+void fcpp_vehicle_default(fcpp_vehicle *v)
+{
+    v->working_width = 3.2; v->min_turn_radius = 8.0; v->max_work_speed_kmh = 9.0;
+    v->max_headland_speed_kmh = 15.0; v->headland_turn_speed_kmh = 4.0; v->max_lateral_accel = 2.0;
+    v->max_longitudinal_accel = 1.5; v->safety_factor = 0.85;
+}
+
+void fcpp_options_default(fcpp_options *o)
+{
+    o->turn_model = FCPP_TURN_ARC; o->clothoid_fit = 1; o->sample_spacing = 0.0; o->clothoid_frac = 0.5;
+    o->geofence_tol = 1e-6;
+}
+
+int fcpp_ctx_create(int device_id, fcpp_ctx **out)
+{
+    if (!out) return fail(FCPP_EINVAL, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(FCPP_EHIP, "no HIP device available: libfcpp has no CPU fallback");
+    if (device_id < 0 || device_id >= n) return fail(FCPP_EINVAL, "device_id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    fcpp_ctx *c = new (std::nothrow) fcpp_ctx();
+    if (!c) return fail(FCPP_ENOMEM, "out of host memory");
+    c->device = device_id;
+    e = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(FCPP_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    c->stream = c->own;
+    *out = c;
+    return FCPP_OK;
+}
+
+int fcpp_ctx_destroy(fcpp_ctx *c)
+{
+    if (!c) return FCPP_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own) { (void)hipStreamSynchronize(c->own); (void)hipStreamDestroy(c->own); }
+    delete c;
+    return FCPP_OK;
+}
+
+int fcpp_ctx_set_stream(fcpp_ctx *c, void *s)
+{
+    if (!c) return fail(FCPP_EINVAL, "ctx is NULL");
+    c->stream = (hipStream_t)s;   // NULL = HIP's default stream
+    return FCPP_OK;
+}
+
+int fcpp_ctx_synchronize(fcpp_ctx *c)
+{
+    if (!c) return fail(FCPP_EINVAL, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPP_OK;
+}
+
+int fcpp_malloc(fcpp_ctx *c, int64_t bytes, void **p)
+{
+    if (!c || !p || bytes < 0) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    *p = nullptr;
+    if (bytes == 0) return FCPP_OK;
+    HIPCHK(hipMalloc(p, (size_t)bytes));
+    return FCPP_OK;
+}
+
+int fcpp_free(fcpp_ctx *c, void *p)
+{
+    if (!c) return fail(FCPP_EINVAL, "ctx is NULL");
+    if (p) HIPCHK(hipFree(p));
+    return FCPP_OK;
+}
+
+int fcpp_memcpy_h2d(fcpp_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    if (!c || bytes < 0) return fail(FCPP_EINVAL, "bad arguments");
+    if (bytes == 0) return FCPP_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPP_OK;
+}
+
+int fcpp_memcpy_d2h(fcpp_ctx *c, void *dst, const void *src, int64_t bytes)
+{
+    if (!c || bytes < 0) return fail(FCPP_EINVAL, "bad arguments");
+    if (bytes == 0) return FCPP_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPP_OK;
+}
+
+int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
+                    fcpp_field_info *info_out)
+{
+    if (!veh || !opt || n_fields < 0 || (n_fields > 0 && (!fields || !info_out)))
+        return fail(FCPP_EINVAL, "bad arguments");
+    HostPlan hp;
+    std::string err;
+    int rc = build_host_plan(*veh, *opt, n_fields, fields, false, hp, err);
+    if (rc != FCPP_OK) return fail(rc, err);
+    if (n_fields) memcpy(info_out, hp.info.data(), (size_t)n_fields * sizeof(fcpp_field_info));
+    return FCPP_OK;
+}
+
+int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
+                      const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **out)
+{
+    if (!c || !veh || !opt || !out || n_fields < 0 || (n_fields > 0 && !fields))
+        return fail(FCPP_EINVAL, "bad arguments");
+    if (n_fields > INT32_MAX) return fail(FCPP_ESIZE, "too many fields");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(c->device));
+    fcpp_batch *b = new (std::nothrow) fcpp_batch();
+    if (!b) return fail(FCPP_ENOMEM, "out of host memory");
+    b->ctx = c; b->veh = *veh; b->opt = *opt; b->n_fields = n_fields;
+    std::string err;
+    int rc = build_host_plan(*veh, *opt, n_fields, fields, true, b->hp, err);
+    if (rc != FCPP_OK) { delete b; return fail(rc, err); }
+    // obstacle references must stay inside the polygon table
+    const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
+    for (int64_t i = 0; i < n_fields; ++i) {
+        if (fields[i].n_obstacles < 0 || fields[i].obstacle_first < 0 ||
+            (fields[i].n_obstacles > 0 && fields[i].obstacle_first + fields[i].n_obstacles > n_polys)) {
+            delete b;
+            return fail(FCPP_ESIZE, "field obstacle range outside the polygon table");
+        }
+    }
+    b->cst = make_const(*veh, *opt);
+    hipStream_t st = c->stream;
+    Tiling til;
+    std::vector<int64_t> offs((size_t)n_fields + 1, 0);
+    for (int64_t i = 0; i < n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
+    til.build(n_fields, offs.data());
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
+    ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st));
+    if (e == hipSuccess && n_polys > 0) {
+        std::vector<int64_t> po(obstacles->offsets, obstacles->offsets + n_polys + 1);
+        const int64_t nv = po.back();
+        std::vector<double> px(obstacles->x, obstacles->x + nv), py(obstacles->y, obstacles->y + nv);
+        ok(b->obs_off.upload(po, st)) && ok(b->obs_x.upload(px, st)) && ok(b->obs_y.upload(py, st));
+    }
+    if (e == hipSuccess) {
+        std::vector<double> seg((size_t)n_fields * 8, 0.0);
+        std::vector<int32_t> mask((size_t)n_fields * 2, 0);
+        for (int64_t i = 0; i < n_fields; ++i) {
+            const fcpp_field_info &in = b->hp.info[(size_t)i];
+            const bool okf = in.status == FCPP_OK;
+            double *s = &seg[(size_t)i * 4];
+            s[0] = in.approach_from[0]; s[1] = in.approach_from[1]; s[2] = in.approach_to[0]; s[3] = in.approach_to[1];
+            mask[(size_t)i] = okf && in.start_kept;
+            double *d = &seg[(size_t)(n_fields + i) * 4];
+            d[0] = in.departure_from[0]; d[1] = in.departure_from[1]; d[2] = in.departure_to[0]; d[3] = in.departure_to[1];
+            mask[(size_t)(n_fields + i)] = okf && in.end_kept;
+        }
+        ok(b->seg.upload(seg, st)) && ok(b->seg_mask.upload(mask, st));
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);   // host vectors above die at scope exit
+    if (e != hipSuccess) {
+        delete b;
+        return fail(FCPP_EHIP, std::string("batch upload: ") + hipGetErrorString(e));
+    }
+    *out = b;
+    return FCPP_OK;
+}
+
+int fcpp_batch_info(const fcpp_batch *b, fcpp_field_info *info_out, int64_t *total_points)
+{
+    if (!b) return fail(FCPP_EINVAL, "batch is NULL");
+    if (info_out && b->n_fields) memcpy(info_out, b->hp.info.data(), (size_t)b->n_fields * sizeof(fcpp_field_info));
+    if (total_points) *total_points = b->hp.total_points;
+    return FCPP_OK;
+}
+
+int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v, uint32_t *fs,
+                   fcpp_field_stats *stats, int mode)
+{
+    if (!b) return fail(FCPP_EINVAL, "batch is NULL");
+    if (mode != 0) return fail(FCPP_EINVAL, "unknown pipeline mode");
+    if (b->n_fields == 0) return FCPP_OK;
+    if (b->hp.total_points > 0 && (!x || !y || !kappa || !v || !fs)) return fail(FCPP_EINVAL, "output pointer is NULL");
+    if (!stats) return fail(FCPP_EINVAL, "stats pointer is NULL");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    DevTiling &t = b->til;
+    DevObstacles obs = { b->obs_off.p, b->obs_x.p, b->obs_y.p };
+    HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
+    LAUNCHCHK(launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
+    LAUNCHCHK(launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
+    LAUNCHCHK(launch_sweeps(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 3, x, y, v, v, t.agg_f.p, t.agg_b.p,
+                            t.carry_f.p, t.carry_b.p));
+    LAUNCHCHK(launch_validate(st, t.n_tiles, t.n_paths, t.tiles.p, t.paths.p, b->fields.p, b->cst, obs, x, y, kappa, v,
+                              fs, t.partial.p, t.tile_first.p, t.n_adj.p, stats));
+    return FCPP_OK;
+}
+
+int fcpp_batch_connectors(fcpp_batch *b, double *approach_xy, double *departure_xy)
+{
+    if (!b) return fail(FCPP_EINVAL, "batch is NULL");
+    if (b->n_fields == 0) return FCPP_OK;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    hipStream_t st = b->ctx->stream;
+    if (approach_xy) LAUNCHCHK(launch_straight(st, b->n_fields, b->seg.p, 50, b->seg_mask.p, approach_xy));
+    if (departure_xy)
+        LAUNCHCHK(launch_straight(st, b->n_fields, b->seg.p + 4 * b->n_fields, 50, b->seg_mask.p + b->n_fields, departure_xy));
+    return FCPP_OK;
+}
+
+int fcpp_batch_destroy(fcpp_batch *b)
+{
+    if (!b) return FCPP_OK;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    delete b;
+    return FCPP_OK;
+}
+
+// ---- standalone operators -------------------------------------------------------------------
+namespace {
+// pulls the CSR offsets to the host (they size the launch), builds and uploads the tile table
+int make_tiling(fcpp_ctx *c, int64_t n_paths, const int64_t *offsets_dev, int64_t total, Tiling &til, DevTiling &dt)
+{
+    if (n_paths < 0 || total < 0 || n_paths > INT32_MAX) return fail(FCPP_ESIZE, "bad sizes");
+    std::vector<int64_t> offs((size_t)n_paths + 1, 0);
+    HIPCHK(hipMemcpyAsync(offs.data(), offsets_dev, offs.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (offs[0] != 0 || offs.back() != total) return fail(FCPP_ESIZE, "offsets do not span [0, total_points]");
+    for (int64_t p = 0; p < n_paths; ++p)
+        if (offs[(size_t)p + 1] < offs[(size_t)p]) return fail(FCPP_ESIZE, "offsets must be non-decreasing");
+    til.build(n_paths, offs.data());
+    HIPCHK(dt.upload(til, c->stream));
+    return FCPP_OK;
+}
+
+DevConst const_from_vehicle(const fcpp_vehicle &veh)
+{
+    fcpp_options o;
+    fcpp_options_default(&o);
+    return make_const(veh, o);
+}
+}  // namespace
+
+int fcpp_curvature(fcpp_ctx *c, int64_t n_paths, const int64_t *offsets, int64_t total, const double *x,
+                   const double *y, double *kappa)
+{
+    if (!c || !offsets || (total > 0 && (!x || !y || !kappa))) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    Tiling til; DevTiling dt;
+    int rc = make_tiling(c, n_paths, offsets, total, til, dt);
+    if (rc) return rc;
+    fcpp_vehicle veh;
+    fcpp_vehicle_default(&veh);
+    DevConst cst = const_from_vehicle(veh);
+    DevBuf<double> vtmp;
+    HIPCHK(vtmp.alloc((size_t)total));
+    HIPCHK(hipMemsetAsync(vtmp.p, 0, (size_t)total * sizeof(double), c->stream));
+    LAUNCHCHK(launch_curv_clamp(c->stream, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, 0, x, y, vtmp.p, vtmp.p, kappa, nullptr));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPP_OK;
+}
+
+int fcpp_speed_plan(fcpp_ctx *c, const fcpp_vehicle *veh, int clamp, int64_t n_paths, const int64_t *offsets,
+                    int64_t total, const double *x, const double *y, const double *v_in, double *v_out, double *kappa,
+                    int64_t *n_adjusted)
+{
+    if (!c || !veh || !offsets || (total > 0 && (!x || !y || !v_in || !v_out))) return fail(FCPP_EINVAL, "bad arguments");
+    if (!(veh->max_longitudinal_accel > 0) || !(veh->max_lateral_accel > 0)) return fail(FCPP_EINVAL, "accelerations must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    Tiling til; DevTiling dt;
+    int rc = make_tiling(c, n_paths, offsets, total, til, dt);
+    if (rc) return rc;
+    DevConst cst = const_from_vehicle(*veh);
+    hipStream_t st = c->stream;
+    if (n_paths) HIPCHK(hipMemsetAsync(dt.n_adj.p, 0, (size_t)n_paths * sizeof(unsigned long long), st));
+    LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, clamp ? 1 : 0, x, y, v_in, v_out, kappa, dt.n_adj.p));
+    LAUNCHCHK(launch_sweeps(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, clamp ? 3 : 2, x, y, v_out, v_out, dt.agg_f.p,
+                            dt.agg_b.p, dt.carry_f.p, dt.carry_b.p));
+    if (n_adjusted && n_paths)
+        HIPCHK(hipMemcpyAsync(n_adjusted, dt.n_adj.p, (size_t)n_paths * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return FCPP_OK;
+}
+
+int fcpp_verify(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n_paths, const int64_t *offsets, int64_t total,
+                const double *x, const double *y, const double *v, fcpp_field_stats *stats)
+{
+    if (!c || !veh || !offsets || !stats || (total > 0 && (!x || !y || !v))) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    Tiling til; DevTiling dt;
+    int rc = make_tiling(c, n_paths, offsets, total, til, dt);
+    if (rc) return rc;
+    DevConst cst = const_from_vehicle(*veh);
+    hipStream_t st = c->stream;
+    DevBuf<double> kap, vtmp;
+    HIPCHK(kap.alloc((size_t)total));
+    HIPCHK(vtmp.alloc((size_t)total));
+    LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, 0, x, y, v, vtmp.p, kap.p, nullptr));
+    DevObstacles obs = { nullptr, nullptr, nullptr };
+    LAUNCHCHK(launch_validate(st, dt.n_tiles, dt.n_paths, dt.tiles.p, dt.paths.p, nullptr, cst, obs, x, y, kap.p, v, nullptr,
+                              dt.partial.p, dt.tile_first.p, nullptr, stats));
+    HIPCHK(hipStreamSynchronize(st));
+    return FCPP_OK;
+}
+
+int fcpp_straight_segments(fcpp_ctx *c, int64_t n_seg, const double *seg, int32_t n_points, double *out)
+{
+    if (!c || n_seg < 0 || n_points < 1 || (n_seg > 0 && (!seg || !out))) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    LAUNCHCHK(launch_straight(c->stream, n_seg, seg, n_points, nullptr, out));
+    return FCPP_OK;
+}
+
+int fcpp_fresnel(fcpp_ctx *c, int64_t n, const double *t, double *cc, double *ss)
+{
+    if (!c || n < 0 || (n > 0 && (!t || !cc || !ss))) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    LAUNCHCHK(launch_fresnel(c->stream, n, t, cc, ss));
+    return FCPP_OK;
+}
+
+int fcpp_ga_fitness(fcpp_ctx *c, int32_t n_nodes, int64_t pop, const double *D, const int32_t *routes, double *dist,
+                    double *fit, int order_mode)
+{
+    if (!c || n_nodes < 1 || pop < 0 || (pop > 0 && (!D || !routes)) || (order_mode != 0 && order_mode != 1))
+        return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    LAUNCHCHK(launch_ga_fitness(c->stream, n_nodes, pop, D, routes, dist, fit, order_mode));
+    return FCPP_OK;
+}
+
+}  // extern "C"

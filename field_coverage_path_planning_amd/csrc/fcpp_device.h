@@ -1,0 +1,43 @@
+// fcpp_device.h -- interface between the C-ABI glue (fcpp_api.cpp) and the kernels (fcpp_kernels.hip)
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "fcpp_geom.h"
+#include "fcpp_internal.h"
+
+namespace fcpp {
+
+struct DevPath { int64_t off, n; };   // one path = points [off, off + n) of the SoA arrays
+
+struct DevObstacles {                 // batch obstacle polygons, CSR, device pointers
+    const int64_t *offsets;
+    const double *x, *y;
+};
+
+// by-value kernel argument: scalars + the two clothoid-arc-clothoid unit shapes (180 and 90 degrees)
+struct DevConst {
+    double a_lat, a_lon, sf, geofence_tol;
+    double v_work, v_turn, v_head;
+    CacShape sh_pi, sh_half;
+};
+
+// every launcher returns 0 or a hipError_t value
+int launch_generate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
+                    const DevPrim *prims, const DevConst &cst, double *x, double *y, double *v, uint32_t *fs);
+int launch_curv_clamp(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
+                      const DevConst &cst, int do_clamp, const double *x, const double *y, const double *v_in,
+                      double *v_out, double *kappa, unsigned long long *n_adjusted);
+int launch_sweeps(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
+                  int min_n, const double *x, const double *y, const double *v_in, double *v_out, void *agg_f,
+                  void *agg_b, double *carry_f, double *carry_b);
+int launch_validate(hipStream_t st, int64_t n_tiles, int64_t n_paths, const DevTile *tiles, const DevPath *paths,
+                    const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
+                    const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial,
+                    const int64_t *tile_first, const unsigned long long *n_adjusted, fcpp_field_stats *stats);
+int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts, const int32_t *mask, double *out);
+int launch_fresnel(hipStream_t st, int64_t n, const double *t, double *c, double *s);
+int launch_ga_fitness(hipStream_t st, int n, int64_t pop, const double *D, const int32_t *routes, double *dist,
+                      double *fit, int order_mode);
+
+}  // namespace fcpp

@@ -1,0 +1,148 @@
+// fcpp_geom.h -- point-level geometry shared by host setup and HIP kernels (compiled with
+// -ffp-contract=off: the reference's numpy arithmetic rounds every product and sum separately,
+// so a*b+c must NOT be fused; fma() is written out where fusing is wanted).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "fcpp_fresnel_coeffs.h"
+
+#if defined(__HIPCC__)
+#define FCPP_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define FCPP_HD inline
+#endif
+
+namespace fcpp {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kHalfPi = 1.57079632679489661923;
+
+// unit-curvature clothoid-arc-clothoid shape for one heading change D (pi or pi/2) and clothoid share f
+struct CacShape {
+    double D, Lc, La, T;  // heading change, clothoid length, arc length, total (all at kappa_max = 1)
+    double a;             // sqrt(pi * Lc): Fresnel scaling
+    double x1, y1, th1;   // end of the entry clothoid
+    double cx, cy;        // arc centre
+    double ex, ey;        // end point of the whole turn
+    double cosD, sinD;
+};
+
+// numpy.linspace(a, b, n)[k] with step = (b - a)/(n - 1) precomputed (IEEE division, same on host)
+FCPP_HD double linspace_at(double a, double b, double step, int64_t n, int64_t k)
+{
+    if (n > 1 && k == n - 1) return b;
+    if (step == 0.0) {
+        if (n <= 1) return 0.0 * (b - a) + a;
+        return ((double)k / (double)(n - 1)) * (b - a) + a;
+    }
+    return (double)k * step + a;
+}
+
+namespace detail {
+constexpr double kCser[FCPP_FRESNEL_NSER] = FCPP_FRESNEL_CSER_INIT;
+constexpr double kSser[FCPP_FRESNEL_NSER] = FCPP_FRESNEL_SSER_INIT;
+constexpr double kFcheb[FCPP_FRESNEL_NCHEB] = FCPP_FRESNEL_FCHEB_INIT;
+constexpr double kGcheb[FCPP_FRESNEL_NCHEB] = FCPP_FRESNEL_GCHEB_INIT;
+}  // namespace detail
+
+// Fresnel integrals C(t) = int_0^t cos(pi u^2/2) du, S(t) likewise with sin.
+// |t| <= 1.6: Maclaurin series in t^4 (20 terms); beyond: auxiliary functions f, g (Chebyshev in (1.6/t)^4).
+FCPP_HD void fresnel_cs(double t, double &C, double &S)
+{
+    const double at = fabs(t);
+    if (at <= FCPP_FRESNEL_T0) {
+        const double t2 = t * t, z = t2 * t2;
+        double pc = detail::kCser[FCPP_FRESNEL_NSER - 1], ps = detail::kSser[FCPP_FRESNEL_NSER - 1];
+#pragma unroll
+        for (int i = FCPP_FRESNEL_NSER - 2; i >= 0; --i) {
+            pc = fma(pc, z, detail::kCser[i]);
+            ps = fma(ps, z, detail::kSser[i]);
+        }
+        C = t * pc;
+        S = t * t2 * ps;
+        return;
+    }
+    const double q = FCPP_FRESNEL_T0 / at, q2 = q * q, y = q2 * q2, x2 = 2.0 * (2.0 * y - 1.0);
+    double f1 = 0, f2 = 0, g1 = 0, g2 = 0;  // Clenshaw
+#pragma unroll
+    for (int i = FCPP_FRESNEL_NCHEB - 1; i >= 1; --i) {
+        double f0 = fma(x2, f1, detail::kFcheb[i]) - f2;
+        double g0 = fma(x2, g1, detail::kGcheb[i]) - g2;
+        f2 = f1; f1 = f0; g2 = g1; g1 = g0;
+    }
+    const double F = fma(0.5 * x2, f1, detail::kFcheb[0]) - f2;
+    const double G = fma(0.5 * x2, g1, detail::kGcheb[0]) - g2;
+    const double f = F / (kPi * at), g = G / (kPi * kPi * at * at * at);
+    const double tt = at * at, lo = fma(at, at, -tt);
+    const double ph = (fmod(tt, 4.0) + lo) * kHalfPi;
+    const double sn = sin(ph), cs = cos(ph);
+    double c = 0.5 + (f * sn - g * cs), s = 0.5 - (f * cs + g * sn);
+    if (t < 0) { c = -c; s = -s; }
+    C = c; S = s;
+}
+
+FCPP_HD void cac_unit_point(const CacShape &sh, double u, double &X, double &Y)
+{
+    if (u < 0) u = 0;
+    if (u > sh.T) u = sh.T;
+    if (sh.Lc > 0 && u <= sh.Lc) {
+        double c, s;
+        fresnel_cs(u / sh.a, c, s);
+        X = sh.a * c; Y = sh.a * s;
+    } else if (u <= sh.Lc + sh.La || sh.Lc == 0) {
+        const double th = sh.th1 + (u - sh.Lc);
+        X = sh.cx + sin(th); Y = sh.cy - cos(th);
+    } else {
+        double c, s;
+        fresnel_cs((sh.T - u) / sh.a, c, s);
+        const double qx = sh.a * c, qy = sh.a * s;
+        X = sh.ex - (sh.cosD * qx + sh.sinD * qy);
+        Y = sh.ey - (sh.sinD * qx - sh.cosD * qy);
+    }
+}
+
+inline CacShape make_cac_shape(double D, double f)
+{
+    CacShape sh;
+    sh.D = D; sh.Lc = f * D; sh.La = (1 - f) * D; sh.T = 2 * sh.Lc + sh.La;
+    sh.a = sqrt(kPi * sh.Lc);
+    sh.x1 = 0; sh.y1 = 0; sh.th1 = sh.Lc / 2;
+    if (sh.Lc > 0) { double c, s; fresnel_cs(sh.Lc / sh.a, c, s); sh.x1 = sh.a * c; sh.y1 = sh.a * s; }
+    sh.cx = sh.x1 - sin(sh.th1); sh.cy = sh.y1 + cos(sh.th1);
+    const double th2 = sh.th1 + sh.La;
+    const double x2 = sh.cx + sin(th2), y2 = sh.cy - cos(th2);
+    sh.cosD = cos(D); sh.sinD = sin(D);
+    sh.ex = x2 + (sh.cosD * sh.x1 + sh.sinD * sh.y1);
+    sh.ey = y2 + (sh.sinD * sh.x1 - sh.cosD * sh.y1);
+    return sh;
+}
+
+// world point of a CAC turn: start (x0,y0), heading quadrant q (heading = q*pi/2), turn sign sg (+1 CCW)
+FCPP_HD void cac_world_point(const CacShape &sh, double x0, double y0, int q, double sg, double Re, double s,
+                             double &x, double &y)
+{
+    double X, Y;
+    cac_unit_point(sh, s / Re, X, Y);
+    Y *= sg;
+    double rx, ry;  // Rot(q*pi/2) * (X, Y), exact
+    switch (q & 3) {
+        case 0: rx = X; ry = Y; break;
+        case 1: rx = -Y; ry = X; break;
+        case 2: rx = -X; ry = -Y; break;
+        default: rx = Y; ry = -X; break;
+    }
+    x = x0 + Re * rx;
+    y = y0 + Re * ry;
+}
+
+// 90-degree corner arc, quadrant formulas MLP:1049-1060 / 1592-1603
+FCPP_HD void corner_arc_point(int ci, double cx, double cy, double R, double c, double s, double &x, double &y)
+{
+    if (ci == 0)      { x = cx + R * (1 - c); y = cy + R * s; }
+    else if (ci == 1) { x = cx - R * s;       y = cy + R * (1 - c); }
+    else if (ci == 2) { x = cx - R * (1 - c); y = cy - R * s; }
+    else              { x = cx + R * s;       y = cy - R * (1 - c); }
+}
+
+}  // namespace fcpp

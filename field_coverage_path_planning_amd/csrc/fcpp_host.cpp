@@ -1,0 +1,390 @@
+// fcpp_host.cpp -- host-side mirror of TwoLayerPathPlannerV37.__init__ and of the O(1)-per-field
+// decisions of plan_complete_coverage() (reference: multi_layer_planner_v3.py = "MLP").
+//
+// Nothing here touches path points: it turns each field into (a) the integer facts the reference
+// derives with Python floats (swath count, loop count, start corner, pass order, reverse-fill
+// counts) using the same float64 operation order, and (b) a closed-form device descriptor
+// (DevField + a few DevPrim) from which the HIP kernels compute any path point from its index.
+//
+// Shapely is replaced by exact formulas for convex quadrilaterals (the only shapes the reference's
+// generator handles meaningfully): mitre inset, area centroid, bounds.  GEOS-specific values are
+// not reproducible here (DESIGN.md "parity unpinned").
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "fcpp_geom.h"
+#include "fcpp_internal.h"
+
+namespace fcpp {
+namespace {
+
+struct Quad { double x[4], y[4]; };
+
+double area_centroid(const Quad &q, double &cx, double &cy)
+{
+    double a = 0, sx = 0, sy = 0;
+    for (int i = 0; i < 4; ++i) {
+        int j = (i + 1) & 3;
+        double cr = q.x[i] * q.y[j] - q.x[j] * q.y[i];
+        a += cr;
+        sx += (q.x[i] + q.x[j]) * cr;
+        sy += (q.y[i] + q.y[j]) * cr;
+    }
+    a *= 0.5;
+    if (fabs(a) < 1e-300) { cx = q.x[0]; cy = q.y[0]; return 0.0; }
+    cx = sx / (6.0 * a); cy = sy / (6.0 * a);
+    return a;
+}
+
+// Polygon.buffer(-d) for a convex quadrilateral: mitre inset, vertex order kept.  false = empty.
+bool inset(const Quad &q, double d, Quad &o)
+{
+    double cx, cy;
+    const double sgn = area_centroid(q, cx, cy) > 0 ? 1.0 : -1.0;
+    double nx[4], ny[4];
+    for (int i = 0; i < 4; ++i) {
+        int j = (i + 1) & 3;
+        double ex = q.x[j] - q.x[i], ey = q.y[j] - q.y[i];
+        double ln = hypot(ex, ey);
+        nx[i] = -ey / ln * sgn; ny[i] = ex / ln * sgn;
+    }
+    for (int i = 0; i < 4; ++i) {
+        int p = (i + 3) & 3;
+        double den = 1.0 + (nx[p] * nx[i] + ny[p] * ny[i]);
+        o.x[i] = q.x[i] + d * (nx[p] + nx[i]) / den;
+        o.y[i] = q.y[i] + d * (ny[p] + ny[i]) / den;
+    }
+    for (int i = 0; i < 4; ++i) {
+        int j = (i + 1) & 3;
+        double ex = q.x[j] - q.x[i], ey = q.y[j] - q.y[i];
+        if ((o.x[j] - o.x[i]) * ex + (o.y[j] - o.y[i]) * ey <= 0) return false;
+    }
+    return true;
+}
+
+double abs_area(const Quad &q) { double cx, cy; return fabs(area_centroid(q, cx, cy)); }
+
+bool is_convex(const Quad &q)
+{
+    int pos = 0, neg = 0;
+    for (int i = 0; i < 4; ++i) {
+        int j = (i + 1) & 3, k = (i + 2) & 3;
+        double cr = (q.x[j] - q.x[i]) * (q.y[k] - q.y[j]) - (q.y[j] - q.y[i]) * (q.x[k] - q.x[j]);
+        if (cr > 0) ++pos; else if (cr < 0) ++neg;
+    }
+    return (pos == 0 || neg == 0) && (pos + neg) > 0;
+}
+
+// MLP:165-192
+double corner_angle(const Quad &q, int i)
+{
+    int p = (i + 3) & 3, n = (i + 1) & 3;
+    double v1x = q.x[p] - q.x[i], v1y = q.y[p] - q.y[i];
+    double v2x = q.x[n] - q.x[i], v2y = q.y[n] - q.y[i];
+    double c = (v1x * v2x + v1y * v2y) / (sqrt(v1x * v1x + v1y * v1y) * sqrt(v2x * v2x + v2y * v2y));
+    c = std::min(1.0, std::max(-1.0, c));
+    return acos(c) * (180.0 / kPi);
+}
+
+// MLP:194-222
+bool is_parallelogram(const Quad &q)
+{
+    double ex[4], ey[4];
+    for (int i = 0; i < 4; ++i) { int j = (i + 1) & 3; ex[i] = q.x[j] - q.x[i]; ey[i] = q.y[j] - q.y[i]; }
+    for (int k = 0; k < 2; ++k) {
+        double cross = fabs(ex[k] * ey[k + 2] - ey[k] * ex[k + 2]);
+        double na = sqrt(ex[k] * ex[k] + ey[k] * ey[k]), nb = sqrt(ex[k + 2] * ex[k + 2] + ey[k + 2] * ey[k + 2]);
+        if (!(cross < 0.01 * (na * nb))) return false;
+    }
+    return true;
+}
+
+// MLP:265-284
+void rotate_point(double x, double y, double ca, double sa, double cx, double cy, double &ox, double &oy)
+{
+    x -= cx; y -= cy;
+    double xn = x * ca - y * sa;
+    double yn = x * sa + y * ca;
+    ox = xn + cx; oy = yn + cy;
+}
+
+int64_t n_for_length(double len, double ds)
+{
+    int64_t n = (int64_t)ceil(len / ds) + 1;
+    return n < 2 ? 2 : n;
+}
+
+double lin_step(double a, double b, int64_t n) { return n > 1 ? (b - a) / (double)(n - 1) : 0.0; }
+
+// MLP:1220-1288: distance along (dx,dy) to the bbox-at-origin boundary, capped at 3R, default 2R
+double distance_to_boundary(double x, double y, double dx, double dy, double L, double H, double R)
+{
+    double best = 0; bool have = false;
+    auto take = [&](double t) { if (t > 0 && (!have || t < best)) { best = t; have = true; } };
+    if (fabs(dx) > 1e-6) { take((0 - x) / dx); take((L - x) / dx); }
+    if (fabs(dy) > 1e-6) { take((0 - y) / dy); take((H - y) / dy); }
+    if (!have) return 2.0 * R;
+    return std::min(best, 3.0 * R);
+}
+
+const int kCornerQuadrant[4] = { 1, 2, 3, 0 };  // start heading of the corner arcs = q * pi/2 (MLP:1049-1060)
+
+}  // namespace
+
+int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields,
+                    bool want_device, HostPlan &out, std::string &err)
+{
+    const double W = veh.working_width, R = veh.min_turn_radius, ds = opt.sample_spacing;
+    if (!(W > 0) || !(R > 0) || !(ds >= 0) || !(opt.clothoid_frac >= 0 && opt.clothoid_frac <= 1) ||
+        (opt.turn_model != FCPP_TURN_ARC && opt.turn_model != FCPP_TURN_CLOTHOID)) {
+        err = "invalid vehicle parameters or options";
+        return FCPP_EINVAL;
+    }
+    if (!(veh.max_longitudinal_accel > 0) || !(veh.max_lateral_accel > 0)) {
+        err = "accelerations must be positive";
+        return FCPP_EINVAL;
+    }
+    const bool cloth = opt.turn_model == FCPP_TURN_CLOTHOID;
+    CacShape sh_pi = make_cac_shape(kPi, opt.clothoid_frac), sh_half = make_cac_shape(kHalfPi, opt.clothoid_frac);
+    auto fit_radius = [&](const CacShape &sh) {
+        if (!opt.clothoid_fit) return R;
+        return R * (2 * sin(sh.D / 2)) / sqrt(sh.ex * sh.ex + sh.ey * sh.ey);
+    };
+    const double Re_pi = cloth ? fit_radius(sh_pi) : R, Re_half = cloth ? fit_radius(sh_half) : R;
+    const double len_uturn = cloth ? sh_pi.T * Re_pi : kPi * R;
+    const double len_corner = cloth ? sh_half.T * Re_half : kHalfPi * R;
+    // gap.area > 0.1 (MLP:1070): 2R x 2R square minus the arc buffered by W/2.  The buffer's area is at
+    // most (pi R/2) W + pi W^2/4, so the decision is certain when this lower bound exceeds 0.1.
+    const double gap_lb = 4 * R * R - (kPi * R / 2 * W + kPi * W * W / 4);
+
+    out.info.assign((size_t)n, fcpp_field_info());
+    out.fields.clear(); out.prims.clear(); out.tiles.clear();
+    if (want_device) out.fields.reserve((size_t)n);
+    int64_t pt_off = 0;
+
+    for (int64_t fi = 0; fi < n; ++fi) {
+        const fcpp_field &f = fields[fi];
+        fcpp_field_info &in = out.info[(size_t)fi];
+        memset(&in, 0, sizeof(in));
+        in.point_offset = pt_off;
+        DevField df;
+        memset(&df, 0, sizeof(df));
+        df.pt_off = pt_off;
+        auto fail = [&](int code) {
+            in.status = code; in.n_main = in.n_head = 0;
+            if (want_device) { df.n_main = df.n_total = 0; out.fields.push_back(df); }
+        };
+        Quad q;
+        bool finite = true;
+        for (int i = 0; i < 4; ++i) { q.x[i] = f.vx[i]; q.y[i] = f.vy[i]; finite = finite && isfinite(q.x[i]) && isfinite(q.y[i]); }
+        if (!finite || !is_convex(q)) { fail(FCPP_EUNSUPPORTED); continue; }
+
+        // ---- __init__ (MLP:109-135, 137-163, 310, 322-343)
+        double bminx = q.x[0], bmaxx = q.x[0], bminy = q.y[0], bmaxy = q.y[0];
+        for (int i = 1; i < 4; ++i) {
+            bminx = std::min(bminx, q.x[i]); bmaxx = std::max(bmaxx, q.x[i]);
+            bminy = std::min(bminy, q.y[i]); bmaxy = std::max(bmaxy, q.y[i]);
+        }
+        const double L = f.from_vertices ? (bmaxx - bminx) : q.x[1];
+        const double H = f.from_vertices ? (bmaxy - bminy) : q.y[2];
+        in.field_length = L; in.field_width = H;
+        bool all90 = true;
+        for (int i = 0; i < 4; ++i) {
+            in.corner_angles[i] = corner_angle(q, i);
+            if (!(fabs(in.corner_angles[i] - 90) < 1.0)) all90 = false;
+        }
+        in.shape = all90 ? 0 : (is_parallelogram(q) ? 1 : 2);
+        const double hw = R;
+        in.headland_width = hw;
+        const bool has_start = f.has_start && (0 <= f.start_x && f.start_x <= L && 0 <= f.start_y && f.start_y <= H);
+        const bool has_end = f.has_end && (0 <= f.end_x && f.end_x <= L && 0 <= f.end_y && f.end_y <= H);
+        in.start_kept = has_start; in.end_kept = has_end;
+
+        // ---- start corner (MLP:345-385)
+        int sci = 0;
+        if (has_start) {
+            const double cxs[4] = { hw / 2, L - hw / 2, L - hw / 2, hw / 2 };
+            const double cys[4] = { hw / 2, hw / 2, H - hw / 2, H - hw / 2 };
+            double best = 0;
+            for (int i = 0; i < 4; ++i) {
+                double dx = cxs[i] - f.start_x, dy = cys[i] - f.start_y;
+                double d = sqrt(dx * dx + dy * dy);
+                if (i == 0 || d < best) { best = d; sci = i; }
+            }
+        }
+        in.start_corner = sci;
+
+        // ---- layer 1 frame (MLP:591-611, 670-718)
+        Quad mq;
+        if (!inset(q, hw, mq) || abs_area(mq) < 1.0) { fail(FCPP_EINVAL); continue; }
+        const double rot = atan2(q.y[1] - q.y[0], q.x[1] - q.x[0]);
+        in.rotation_angle = rot;
+        const bool rotated = fabs(rot) > 0.01;
+        in.rotated = rotated;
+        double ccx = 0, ccy = 0, sx = f.start_x, sy = f.start_y;
+        Quad rq = mq;
+        if (rotated) {
+            area_centroid(mq, ccx, ccy);
+            const double ca = cos(-rot), sa = sin(-rot);
+            for (int i = 0; i < 4; ++i) rotate_point(mq.x[i], mq.y[i], ca, sa, ccx, ccy, rq.x[i], rq.y[i]);
+            if (has_start) rotate_point(sx, sy, ca, sa, ccx, ccy, sx, sy);
+        }
+        double min_x = rq.x[0], max_x = rq.x[0], min_y = rq.y[0], max_y = rq.y[0];
+        for (int i = 1; i < 4; ++i) {
+            min_x = std::min(min_x, rq.x[i]); max_x = std::max(max_x, rq.x[i]);
+            min_y = std::min(min_y, rq.y[i]); max_y = std::max(max_y, rq.y[i]);
+        }
+        int reverse_order = 0, start_from_right = 0;   // MLP:631-668
+        if (has_start) {
+            if (sy > (min_y + max_y) / 2) reverse_order = 1;
+            if (sx > (min_x + max_x) / 2) start_from_right = 1;
+        }
+        in.reverse_order = reverse_order; in.start_from_right = start_from_right;
+
+        // ---- layer 1 sizes (MLP:736-739)
+        const double lsx = min_x + R, lex = max_x - R;
+        const int64_t P = (int64_t)((max_y - min_y) / W) + 1;
+        const int64_t n_line = ds > 0 ? n_for_length(fabs(lex - lsx), ds) : 2;
+        const int64_t n_turn = ds > 0 ? n_for_length(len_uturn, ds) : 20;
+        if (P > INT32_MAX || n_line > INT32_MAX || n_turn > INT32_MAX) { fail(FCPP_ESIZE); continue; }
+        in.n_swaths = (int32_t)P;
+        const int64_t n_main = P * n_line + (P - 1) * n_turn;
+        in.n_main = n_main;
+
+        df.n_main = n_main;
+        df.lsx = lsx; df.lex = lex; df.line_step = lin_step(lsx, lex, n_line);
+        df.min_x = min_x; df.max_x = max_x; df.min_y = min_y; df.W = W; df.R = R;
+        df.turn_end = cloth ? sh_pi.T * Re_pi : kPi;
+        df.turn_step = lin_step(0.0, df.turn_end, n_turn);
+        df.turn_Re = Re_pi;
+        df.rot_cos = cos(rot); df.rot_sin = sin(rot); df.rot_cx = ccx; df.rot_cy = ccy;
+        df.v_work = veh.max_work_speed_kmh; df.v_turn = veh.headland_turn_speed_kmh;
+        df.P = (int32_t)P; df.n_line = (int32_t)n_line; df.n_turn = (int32_t)n_turn;
+        df.reverse_order = reverse_order; df.start_from_right = start_from_right; df.rotated = rotated;
+        df.turn_model = opt.turn_model;
+        df.prim_first = (int32_t)out.prims.size();
+
+        // ---- layer 2 (MLP:898-1084)
+        const int num_loops = (int)ceil(hw / W);
+        in.n_loops = num_loops;
+        int64_t pos = n_main;
+        bool bad = false;
+        double first_head[2] = { 0, 0 }, last_head[2] = { 0, 0 };
+        auto push = [&](DevPrim &p) { p.start = pos; pos += p.n; if (want_device) out.prims.push_back(p); };
+        for (int loop = 0; loop < num_loops && !bad; ++loop) {
+            const double offset = W / 2 + loop * W;
+            Quad c;
+            if (!inset(q, offset, c) || abs_area(c) < 1.0) { bad = true; break; }
+            const uint32_t lp = FCPP_FLAG_HEADLAND | ((uint32_t)(loop * 8) << FCPP_INDEX_SHIFT);
+            DevPrim p;
+            memset(&p, 0, sizeof(p));
+            p.kind = PRIM_POINT; p.n = 1; p.v_nom = veh.max_headland_speed_kmh;
+            p.fs = FCPP_KIND_HEAD_START | lp | ((uint32_t)sci << FCPP_INDEX_SHIFT);
+            p.a[0] = c.x[sci]; p.a[1] = c.y[sci];
+            push(p);
+            if (loop == 0) { first_head[0] = c.x[sci]; first_head[1] = c.y[sci]; }
+            for (int i = 0; i < 4; ++i) {
+                const int cur = (sci + i) & 3, nxt = (sci + i + 1) & 3;
+                const double seg_len = hypot(c.x[nxt] - c.x[cur], c.y[nxt] - c.y[cur]);
+                const int64_t ns = ds > 0 ? n_for_length(seg_len, ds) : 20;
+                const int64_t nt = ds > 0 ? n_for_length(len_corner, ds) : 15;
+                if (ns > INT32_MAX || nt > INT32_MAX) { bad = true; break; }
+                memset(&p, 0, sizeof(p));
+                p.kind = PRIM_LINSPACE; p.n = (int32_t)ns; p.v_nom = veh.max_headland_speed_kmh;
+                p.fs = FCPP_KIND_HEAD_STRAIGHT | lp | ((uint32_t)cur << FCPP_INDEX_SHIFT);
+                p.a[0] = c.x[cur]; p.a[1] = c.y[cur]; p.a[2] = c.x[nxt]; p.a[3] = c.y[nxt];
+                p.a[4] = lin_step(c.x[cur], c.x[nxt], ns); p.a[5] = lin_step(c.y[cur], c.y[nxt], ns);
+                push(p);
+                last_head[0] = c.x[nxt]; last_head[1] = c.y[nxt];
+                if (i == 3) break;
+                // corner turn at `nxt` (MLP:1024-1063 / 1580-1608)
+                double e1[2], e2[2];  // last and second-to-last point of the turn (for the reverse direction)
+                memset(&p, 0, sizeof(p));
+                p.n = (int32_t)nt; p.v_nom = veh.headland_turn_speed_kmh;
+                p.fs = FCPP_KIND_CORNER | lp | ((uint32_t)nxt << FCPP_INDEX_SHIFT);
+                if (!cloth) {
+                    p.kind = PRIM_ARC; p.form = nxt;
+                    p.a[0] = c.x[nxt]; p.a[1] = c.y[nxt]; p.a[2] = R; p.a[3] = kHalfPi;
+                    p.a[4] = lin_step(0.0, kHalfPi, nt);
+                    const double th1 = linspace_at(0.0, kHalfPi, p.a[4], nt, nt - 1);
+                    const double th2 = linspace_at(0.0, kHalfPi, p.a[4], nt, nt - 2);
+                    corner_arc_point(nxt, c.x[nxt], c.y[nxt], R, cos(th1), sin(th1), e1[0], e1[1]);
+                    corner_arc_point(nxt, c.x[nxt], c.y[nxt], R, cos(th2), sin(th2), e2[0], e2[1]);
+                } else {
+                    p.kind = PRIM_CAC; p.form = kCornerQuadrant[nxt];
+                    const double T = sh_half.T * Re_half;
+                    p.a[0] = c.x[nxt]; p.a[1] = c.y[nxt]; p.a[2] = kCornerQuadrant[nxt] * kHalfPi; p.a[3] = -kHalfPi;
+                    p.a[4] = Re_half; p.a[5] = lin_step(0.0, T, nt); p.a[6] = T;
+                    const double s1 = linspace_at(0.0, T, p.a[5], nt, nt - 1), s2 = linspace_at(0.0, T, p.a[5], nt, nt - 2);
+                    cac_world_point(sh_half, c.x[nxt], c.y[nxt], p.form, -1.0, Re_half, s1, e1[0], e1[1]);
+                    cac_world_point(sh_half, c.x[nxt], c.y[nxt], p.form, -1.0, Re_half, s2, e2[0], e2[1]);
+                }
+                push(p);
+                // reverse fill (MLP:1043, 224-242, 1066-1082, 1154-1218)
+                const bool add_rev = (loop == 0) && (in.corner_angles[nxt] >= 60);
+                if (add_rev) {
+                    if (!(gap_lb > 0.1)) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
+                    const double tx = e1[0] - e2[0], ty = e1[1] - e2[1];
+                    const double nrm = sqrt(tx * tx + ty * ty);
+                    double dx = -1.0, dy = 0.0;
+                    if (nrm > 1e-6) { dx = -tx / nrm; dy = -ty / nrm; }
+                    const double len = distance_to_boundary(e1[0], e1[1], dx, dy, L, H, R);
+                    int64_t nr;
+                    if (ds > 0) nr = n_for_length(len, ds);
+                    else { nr = (int64_t)(len / 0.5); if (nr < 10) nr = 10; }
+                    memset(&p, 0, sizeof(p));
+                    p.kind = PRIM_RAY; p.n = (int32_t)nr; p.v_nom = 2.5;   // MLP:1080
+                    p.fs = FCPP_KIND_REVERSE | lp | ((uint32_t)nxt << FCPP_INDEX_SHIFT);
+                    p.a[0] = e1[0]; p.a[1] = e1[1]; p.a[2] = dx; p.a[3] = dy; p.a[4] = len;
+                    p.a[5] = lin_step(0.0, len, nr);
+                    push(p);
+                    in.n_reverse[nxt] = (int32_t)nr;
+                }
+            }
+        }
+        if (bad) {
+            if (want_device) out.prims.resize((size_t)df.prim_first);
+            int code = in.status ? in.status : FCPP_EHEADLAND;
+            memset(in.n_reverse, 0, sizeof(in.n_reverse));
+            fail(code);
+            continue;
+        }
+        in.n_head = pos - n_main;
+        if (has_start) {   // MLP:437-441
+            in.approach_from[0] = f.start_x; in.approach_from[1] = f.start_y;
+            in.approach_to[0] = first_head[0]; in.approach_to[1] = first_head[1];
+        }
+        if (has_end) {     // MLP:443-447
+            in.departure_from[0] = last_head[0]; in.departure_from[1] = last_head[1];
+            in.departure_to[0] = f.end_x; in.departure_to[1] = f.end_y;
+        }
+        if (want_device) {
+            df.n_total = pos;
+            df.prim_count = (int32_t)out.prims.size() - df.prim_first;
+            df.obs_first = (int32_t)f.obstacle_first; df.obs_count = f.n_obstacles;
+            // geofence half-planes: inside <=> ex*px + ey*py + eo >= -tol
+            double cx, cy;
+            const double sgn = area_centroid(q, cx, cy) > 0 ? 1.0 : -1.0;
+            for (int i = 0; i < 4; ++i) {
+                int j = (i + 1) & 3;
+                double ex = q.x[j] - q.x[i], ey = q.y[j] - q.y[i];
+                double ln = sqrt(ex * ex + ey * ey);
+                df.ex[i] = -ey / ln * sgn; df.ey[i] = ex / ln * sgn;
+                df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
+            }
+            out.fields.push_back(df);
+            for (int64_t s = 0; s < pos; s += TILE_POINTS) {
+                DevTile t;
+                t.field = (int32_t)fi; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, pos - s);
+                out.tiles.push_back(t);
+            }
+        }
+        pt_off += pos;
+    }
+    out.total_points = pt_off;
+    return FCPP_OK;
+}
+
+}  // namespace fcpp

@@ -1,0 +1,102 @@
+// fcpp_internal.h -- structures shared by the host-side setup (fcpp_host.cpp) and the HIP kernels.
+//
+// Data layout in HBM:
+//   * outputs: SoA float64 x[], y[], kappa[], v[] and uint32 flagseg[], one element per path point,
+//     fields laid out back to back (field f owns [pt_off, pt_off + n_total)).
+//   * per-field descriptor DevField (O(1) per field: the boustrophedon layer is decoded in closed
+//     form from the point index) and a short list of DevPrim primitives for the headland layer.
+//   * tile table: one entry per workgroup = (field, first point, count); tiles never straddle fields.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/fcpp.h"
+
+namespace fcpp {
+
+constexpr int TILE_POINTS = 2048;  // points per workgroup tile (256 threads x 8)
+
+enum PrimKind : int32_t { PRIM_POINT = 0, PRIM_LINSPACE = 1, PRIM_ARC = 2, PRIM_RAY = 3, PRIM_CAC = 4 };
+
+// one headland primitive (MLP:943-1084): a run of `n` points starting at path index `start`
+struct DevPrim {
+    int64_t start;   // index in the field's concatenated path (>= n_main)
+    int32_t n;
+    int32_t kind;    // PrimKind
+    int32_t form;    // PRIM_ARC: corner index 0..3 selecting the quadrant formula (MLP:1049-1060)
+    uint32_t fs;     // flag/segment base word
+    double v_nom;    // nominal speed of the run [km/h]
+    // PRIM_POINT    a0,a1 = x,y
+    // PRIM_LINSPACE a0..a3 = x0,y0,x1,y1 ; a4,a5 = step_x, step_y (numpy.linspace step)
+    // PRIM_ARC      a0,a1 = corner x,y ; a2 = R ; a3 = theta_end ; a4 = theta step
+    // PRIM_RAY      a0,a1 = origin ; a2,a3 = unit direction ; a4 = length ; a5 = t step
+    // PRIM_CAC      a0,a1 = start ; a2 = heading ; a3 = signed heading change ; a4 = Re ; a5 = s step ; a6 = total length
+    double a[7];
+};
+
+// closed-form description of one field's plan
+struct DevField {
+    int64_t pt_off;      // first point in the batch arrays
+    int64_t n_main;      // points of layer 1
+    int64_t n_total;     // n_main + n_head
+    // layer 1 (MLP:720-789) in the rotated frame
+    double lsx, lex;     // line_start_x, line_end_x (MLP:736-737)
+    double line_step;    // numpy.linspace step lsx -> lex over n_line points
+    double min_x, max_x, min_y;
+    double W, R;
+    double turn_step;    // arcs: pi/(n_turn-1) ; CAC: T/(n_turn-1)
+    double turn_end;     // arcs: pi ; CAC: total length T
+    double turn_Re;      // CAC effective radius
+    double rot_cos, rot_sin, rot_cx, rot_cy;  // rotate-back (MLP:709-714)
+    double v_work, v_turn;
+    int32_t P;           // num_passes
+    int32_t n_line, n_turn;
+    int32_t reverse_order, start_from_right, rotated;
+    int32_t turn_model;
+    int32_t prim_first, prim_count;   // headland primitives
+    // validator
+    int32_t obs_first, obs_count;     // obstacle polygons (batch polygon table)
+    int32_t _pad;
+    double ex[4], ey[4], eo[4];       // field edges as inward unit normals: inside <=> ex*px + ey*py + eo >= -tol
+};
+
+struct DevTile {
+    int32_t field;
+    int32_t count;       // <= TILE_POINTS
+    int64_t start;       // first point of the tile inside the field's path
+};
+
+// scalar parameters every kernel needs
+struct DevParams {
+    double a_lat, a_lon, sf;   // max_lateral_accel, max_longitudinal_accel, safety_factor
+    double clothoid_frac;
+    double geofence_tol;
+    double u_cap;              // (max nominal speed / 3.6)^2: above this no sweep constraint can bind
+};
+
+// per-tile partial statistics (reduced per field in a fixed order => run-to-run identical sums)
+struct TilePartial {
+    double main_len, main_time_pre, main_time, head_len, head_time_pre, head_time;
+    double max_kappa, max_alat, max_jump;
+    int64_t n_viol, n_outside, n_in_obstacle, n_adjusted;
+};
+
+}  // namespace fcpp
+
+// ---- host-side plan of a batch (fcpp_host.cpp) ----------------------------------------------
+#ifdef __cplusplus
+#include <string>
+#include <vector>
+namespace fcpp {
+struct HostPlan {
+    std::vector<fcpp_field_info> info;
+    std::vector<DevField> fields;
+    std::vector<DevPrim> prims;
+    std::vector<DevTile> tiles;
+    int64_t total_points = 0;
+};
+// Builds info (+ device descriptors when want_device) for n fields; returns FCPP_OK or FCPP_E*.
+int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields,
+                    bool want_device, HostPlan &out, std::string &err);
+// host+device Fresnel / CAC helpers live in fcpp_geom.h
+}  // namespace fcpp
+#endif

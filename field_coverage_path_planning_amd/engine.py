@@ -1,0 +1,333 @@
+"""Batch engine: device buffers (torch tensors), contexts, and the batched planner over libfcpp.so.
+
+torch is used for device memory and streams only; all arithmetic happens in the HIP library.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+_contexts = {}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Context:
+    """One fcpp_ctx per device, bound to torch's current stream at every call."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError('no GPU visible: the fcpp operators have no CPU fallback')
+        self.device = int(device)
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.check(self.lib.fcpp_ctx_create(self.device, C.byref(h)))
+        self.handle = h
+
+    def bind_stream(self):
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.fcpp_ctx_set_stream(self.handle, C.c_void_p(s)))
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.fcpp_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def get_context(device=None):
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    device = int(device)
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def make_vehicle(vp=None, **kw):
+    """fcpp_vehicle from a VehicleParams-like object (attributes named as MLP:31-38) or keywords."""
+    v = L.default_vehicle()
+    if vp is not None:
+        for n, _ in L.Vehicle._fields_:
+            setattr(v, n, float(getattr(vp, n)))
+    for k, val in kw.items():
+        setattr(v, k, float(val))
+    return v
+
+
+def make_options(turn_model=L.TURN_ARC, sample_spacing=0.0, clothoid_frac=0.5, clothoid_fit=1, geofence_tol=1e-6):
+    o = L.default_options()
+    o.turn_model = int(turn_model)
+    o.sample_spacing = float(sample_spacing)
+    o.clothoid_frac = float(clothoid_frac)
+    o.clothoid_fit = int(clothoid_fit)
+    o.geofence_tol = float(geofence_tol)
+    return o
+
+
+@dataclass
+class FieldSpec:
+    """Constructor arguments of one planner (MLP:63-72)."""
+    field_length: float = None
+    field_width: float = None
+    field_vertices: list = None
+    obstacles: list = None
+    start_point: tuple = None
+    end_point: tuple = None
+
+
+def pack_fields(specs):
+    """-> (Field array, Polys, keep-alive list).  Raises ValueError like MLP:135 when no field is given."""
+    n = len(specs)
+    arr = (L.Field * max(n, 1))()
+    offs, px, py = [0], [], []
+    for i, s in enumerate(specs):
+        f = arr[i]
+        if s.field_vertices is not None:
+            vs = list(s.field_vertices)
+            if len(vs) != 4:
+                raise ValueError('only quadrilateral fields are supported (4 vertices)')
+            f.from_vertices = 1
+        elif s.field_length is not None and s.field_width is not None:
+            vs = [(0.0, 0.0), (s.field_length, 0.0), (s.field_length, s.field_width), (0.0, s.field_width)]
+            f.from_vertices = 0
+        else:
+            raise ValueError('必须提供 field_vertices 或 (field_length, field_width)')
+        for k, (x, y) in enumerate(vs):
+            f.vx[k], f.vy[k] = float(x), float(y)
+        if s.start_point is not None:
+            f.has_start, f.start_x, f.start_y = 1, float(s.start_point[0]), float(s.start_point[1])
+        if s.end_point is not None:
+            f.has_end, f.end_x, f.end_y = 1, float(s.end_point[0]), float(s.end_point[1])
+        obs = s.obstacles or []
+        f.obstacle_first = len(offs) - 1
+        f.n_obstacles = len(obs)
+        for poly in obs:
+            for (x, y) in poly:
+                px.append(float(x))
+                py.append(float(y))
+            offs.append(len(px))
+    offs_a = np.asarray(offs, dtype=np.int64)
+    px_a = np.asarray(px, dtype=np.float64)
+    py_a = np.asarray(py, dtype=np.float64)
+    polys = L.Polys(len(offs) - 1, offs_a.ctypes.data_as(L.c_i64_p), px_a.ctypes.data_as(L.c_double_p),
+                    py_a.ctypes.data_as(L.c_double_p))
+    return arr, polys, [offs_a, px_a, py_a]
+
+
+def plan_count(specs, vehicle, options):
+    """Host-only sizing/decisions (fcpp_plan_count); needs no GPU."""
+    lib = L.load()
+    arr, _, _keep = pack_fields(specs)
+    info = (L.FieldInfo * max(len(specs), 1))()
+    L.check(lib.fcpp_plan_count(C.byref(vehicle), C.byref(options), len(specs), arr, info))
+    return [info[i] for i in range(len(specs))]
+
+
+class BatchResult:
+    """Device-resident result of one batch: SoA tensors + per-field stats."""
+
+    def __init__(self, batch, x, y, kappa, v, flagseg, stats_raw):
+        self.batch, self.x, self.y, self.kappa, self.v, self.flagseg = batch, x, y, kappa, v, flagseg
+        self.stats_raw = stats_raw   # (n_fields, 13) int64 view of fcpp_field_stats
+
+    def stats(self):
+        """-> dict of numpy arrays, one entry per field."""
+        raw = self.stats_raw.cpu().numpy()
+        names = [n for n, _ in L.FieldStats._fields_]
+        out = {}
+        for k, n in enumerate(names):
+            col = raw[:, k]
+            out[n] = col.view(np.float64).copy() if k < L.STATS_DOUBLES else col.copy()
+        return out
+
+    def field_slice(self, i):
+        info = self.batch.info[i]
+        return slice(info.point_offset, info.point_offset + info.n_main + info.n_head)
+
+
+class Batch:
+    """n independent fields planned together on one GPU (fcpp_batch_*)."""
+
+    def __init__(self, specs, vehicle, options=None, device=None):
+        self.ctx = get_context(device)
+        self.lib = self.ctx.lib
+        self.vehicle = vehicle
+        self.options = options or make_options()
+        self.n_fields = len(specs)
+        arr, polys, _keep = pack_fields(specs)
+        self.ctx.bind_stream()
+        h = C.c_void_p()
+        L.check(self.lib.fcpp_batch_create(self.ctx.handle, C.byref(self.vehicle), C.byref(self.options),
+                                           self.n_fields, arr, C.byref(polys), C.byref(h)))
+        self.handle = h
+        info = (L.FieldInfo * max(self.n_fields, 1))()
+        tot = C.c_int64()
+        L.check(self.lib.fcpp_batch_info(self.handle, info, C.byref(tot)))
+        self.info = [info[i] for i in range(self.n_fields)]
+        self.total_points = tot.value
+
+    def alloc(self):
+        torch = _torch()
+        dev = torch.device('cuda', self.ctx.device)
+        n = self.total_points
+        x = torch.empty(n, dtype=torch.float64, device=dev)
+        y = torch.empty(n, dtype=torch.float64, device=dev)
+        kappa = torch.empty(n, dtype=torch.float64, device=dev)
+        v = torch.empty(n, dtype=torch.float64, device=dev)
+        fs = torch.empty(n, dtype=torch.int32, device=dev)
+        stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
+        return x, y, kappa, v, fs, stats
+
+    def run(self, buffers=None, mode=0):
+        """Enqueue the hot path on torch's current stream; returns a BatchResult (asynchronous)."""
+        if buffers is None:
+            buffers = self.alloc()
+        x, y, kappa, v, fs, stats = buffers
+        self.ctx.bind_stream()
+        L.check(self.lib.fcpp_batch_run(self.handle, _ptr(x), _ptr(y), _ptr(kappa), _ptr(v), _ptr(fs), _ptr(stats),
+                                        int(mode)))
+        return BatchResult(self, x, y, kappa, v, fs, stats)
+
+    def connectors(self):
+        """-> (approach, departure) tensors of shape (n_fields, 50, 2); rows of fields without a kept
+        start/end point are NaN."""
+        torch = _torch()
+        dev = torch.device('cuda', self.ctx.device)
+        ap = torch.full((self.n_fields, 50, 2), float('nan'), dtype=torch.float64, device=dev)
+        dp = torch.full((self.n_fields, 50, 2), float('nan'), dtype=torch.float64, device=dev)
+        self.ctx.bind_stream()
+        L.check(self.lib.fcpp_batch_connectors(self.handle, _ptr(ap), _ptr(dp)))
+        return ap, dp
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.fcpp_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- standalone operators on device tensors -------------------------------------------------------
+def _dev_f64(a, device):
+    torch = _torch()
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=device)
+
+
+def _offsets(offsets, n, device):
+    torch = _torch()
+    if offsets is None:
+        offsets = [0, n]
+    if isinstance(offsets, torch.Tensor):
+        return offsets.to(device=device, dtype=torch.int64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(offsets, dtype=np.int64), device=device)
+
+
+def curvature(x, y, offsets=None, device=None):
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    x, y = _dev_f64(x, dev), _dev_f64(y, dev)
+    off = _offsets(offsets, x.numel(), dev)
+    k = torch.empty_like(x)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_curvature(ctx.handle, off.numel() - 1, _ptr(off), x.numel(), _ptr(x), _ptr(y), _ptr(k)))
+    return k
+
+
+def speed_plan(x, y, v, vehicle, clamp=True, offsets=None, device=None, want_kappa=False):
+    """_apply_curvature_based_speed_limit (clamp=True) or _smooth_speed_profile only (clamp=False)."""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    x, y, v = _dev_f64(x, dev), _dev_f64(y, dev), _dev_f64(v, dev)
+    off = _offsets(offsets, x.numel(), dev)
+    out = torch.empty_like(v)
+    kap = torch.empty_like(v) if want_kappa else None
+    nadj = torch.zeros(off.numel() - 1, dtype=torch.int64, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_speed_plan(ctx.handle, C.byref(vehicle), int(bool(clamp)), off.numel() - 1, _ptr(off),
+                                    x.numel(), _ptr(x), _ptr(y), _ptr(v), _ptr(out), _ptr(kap), _ptr(nadj)))
+    return (out, nadj, kap) if want_kappa else (out, nadj)
+
+
+def verify(x, y, v, vehicle, offsets=None, device=None):
+    """-> dict of numpy arrays per path (fcpp_verify)."""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    x, y, v = _dev_f64(x, dev), _dev_f64(y, dev), _dev_f64(v, dev)
+    off = _offsets(offsets, x.numel(), dev)
+    n_paths = off.numel() - 1
+    stats = torch.zeros((n_paths, L.STATS_WORDS), dtype=torch.int64, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_verify(ctx.handle, C.byref(vehicle), n_paths, _ptr(off), x.numel(), _ptr(x), _ptr(y),
+                                _ptr(v), _ptr(stats)))
+    raw = stats.cpu().numpy()
+    out = {}
+    for k, (n, _) in enumerate(L.FieldStats._fields_):
+        col = raw[:, k]
+        out[n] = col.view(np.float64).copy() if k < L.STATS_DOUBLES else col.copy()
+    return out
+
+
+def straight_segments(segs, n_points, device=None):
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    segs = _dev_f64(segs, dev).reshape(-1, 4)
+    out = torch.empty((segs.shape[0], int(n_points), 2), dtype=torch.float64, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_straight_segments(ctx.handle, segs.shape[0], _ptr(segs), int(n_points), _ptr(out)))
+    return out
+
+
+def fresnel(t, device=None):
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    t = _dev_f64(t, dev)
+    c, s = torch.empty_like(t), torch.empty_like(t)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_fresnel(ctx.handle, t.numel(), _ptr(t), _ptr(c), _ptr(s)))
+    return c, s
+
+
+def ga_fitness(routes, D, order_mode=0, device=None):
+    """-> (distance, fitness) tensors for a population of tours (GA:168-181)."""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    D = _dev_f64(D, dev)
+    n = D.shape[0]
+    if isinstance(routes, torch.Tensor):
+        r = routes.to(device=dev, dtype=torch.int32).contiguous()
+    else:
+        r = torch.as_tensor(np.ascontiguousarray(routes, dtype=np.int32), device=dev)
+    r = r.reshape(-1, n)
+    dist = torch.empty(r.shape[0], dtype=torch.float64, device=dev)
+    fit = torch.empty_like(dist)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_ga_fitness(ctx.handle, n, r.shape[0], _ptr(D), _ptr(r), _ptr(dist), _ptr(fit),
+                                    int(order_mode)))
+    return dist, fit

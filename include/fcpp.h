@@ -1,0 +1,198 @@
+/*
+ * fcpp.h -- C ABI of libfcpp.so, the MI355X (gfx950) coverage-path geometry engine.
+ *
+ * The reference (qwagrox/field-coverage-path-planning @ 2025-10-24) is pure Python and has no
+ * FFI: its boundary is the class surface of multi_layer_planner_v3.py ("MLP") and
+ * genetic_algorithm_solver.py ("GA").  Each entry point below names the reference
+ * method(s) it replaces; the Python mirror of that surface
+ * (field_coverage_path_planning_amd/multi_layer_planner_v3.py) binds them through ctypes, and
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns FCPP_OK (0) or a negative FCPP_E* code and
+ *     records a message retrievable with fcpp_last_error() (thread-local).
+ *   - pointers named *_dev are DEVICE pointers (hipMalloc / torch CUDA tensors); all others
+ *     are host pointers.  Path arrays are SoA float64: x[], y[], kappa[], v[] (km/h) plus
+ *     one uint32 flag/segment word per point.
+ *   - work is enqueued on the context's HIP stream (fcpp_ctx_set_stream); calls that return
+ *     host data synchronise that stream themselves, the others are asynchronous.
+ *   - a context is not thread-safe; distinct contexts are independent.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry fails with
+ *     FCPP_EHIP.
+ */
+#ifndef FCPP_H
+#define FCPP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCPP_ABI_VERSION 1
+
+enum {
+    FCPP_OK = 0,
+    FCPP_EINVAL = -1,       /* the reference's ValueError: no field given / headland wider than field (MLP:135,597-598) */
+    FCPP_EHEADLAND = -2,    /* a headland loop's inset polygon is empty (MLP:967-969 followed by the vstack at :939) */
+    FCPP_EUNSUPPORTED = -3, /* not a convex quadrilateral, or a regime only GEOS could decide */
+    FCPP_EHIP = -4,         /* HIP runtime failure / no device */
+    FCPP_ENOMEM = -5,
+    FCPP_ESIZE = -6         /* negative / inconsistent sizes */
+};
+
+/* ---- VehicleParams (MLP:29-39), same field order and defaults ------------------------ */
+typedef struct fcpp_vehicle {
+    double working_width;          /* 3.2  */
+    double min_turn_radius;        /* 8.0  */
+    double max_work_speed_kmh;     /* 9.0  */
+    double max_headland_speed_kmh; /* 15.0 */
+    double headland_turn_speed_kmh;/* 4.0  */
+    double max_lateral_accel;      /* 2.0  */
+    double max_longitudinal_accel; /* 1.5  */
+    double safety_factor;          /* 0.85 */
+} fcpp_vehicle;
+
+/* ---- sampling / validation options (build-defined; all-zero + geofence_tol = reference) -- */
+enum { FCPP_TURN_ARC = 0, FCPP_TURN_CLOTHOID = 1 };
+typedef struct fcpp_options {
+    int32_t turn_model;     /* FCPP_TURN_ARC: circular arcs as MLP:807-825,1046-1062; _CLOTHOID: line->clothoid->arc->clothoid->line */
+    int32_t clothoid_fit;   /* 0: kappa_max = 1/R ; 1: scale so the turn ends where the reference arc ends */
+    double sample_spacing;  /* 0: the reference's fixed counts (2/20/15/20, reverse 0.5 m); >0: uniform arc-length spacing [m] */
+    double clothoid_frac;   /* share of a turn's heading change spent in its two clothoids, in [0,1] */
+    double geofence_tol;    /* a point further than this outside the field polygon is flagged [m] */
+} fcpp_options;
+
+/* ---- one field = one planner instance (ctor arguments, MLP:63-72) ---------------------- */
+typedef struct fcpp_field {
+    double vx[4], vy[4];        /* field_vertices; for field_length/field_width: (0,0),(L,0),(L,H),(0,H) (MLP:127-132) */
+    int32_t from_vertices;      /* 1 = field_vertices=..., 0 = field_length/field_width */
+    int32_t has_start, has_end; /* start_point / end_point given */
+    double start_x, start_y, end_x, end_y;
+    int32_t n_obstacles;        /* obstacles=[...] : polygons obstacle_first .. +n_obstacles of the batch polygon table */
+    int32_t _pad;
+    int64_t obstacle_first;
+} fcpp_field;
+
+/* obstacle polygons of a whole batch, CSR layout, host pointers */
+typedef struct fcpp_polys {
+    int64_t n_polys;
+    const int64_t *offsets;     /* n_polys + 1 */
+    const double *x, *y;        /* offsets[n_polys] vertices */
+} fcpp_polys;
+
+/* ---- what the host-side setup decides per field (integers: bit-exact parity) ------------ */
+typedef struct fcpp_field_info {
+    int64_t point_offset;       /* first point of this field in the batch arrays */
+    int64_t n_main, n_head;     /* len(main_work['path']), len(headland['path']) */
+    int32_t n_swaths;           /* num_passes, MLP:739 */
+    int32_t n_loops;            /* ceil(R / W), MLP:916 */
+    int32_t start_corner;       /* MLP:360-385 */
+    int32_t reverse_order, start_from_right; /* MLP:631-668 */
+    int32_t rotated;            /* |rotation_angle| > 0.01, MLP:686 */
+    int32_t start_kept, end_kept; /* after _validate_point, MLP:322-343 */
+    int32_t shape;              /* 0 rectangle, 1 parallelogram, 2 other (MLP:137-163) */
+    int32_t n_reverse[4];       /* reverse-fill points appended at corner c of the outer loop */
+    int32_t status;             /* FCPP_OK or the error this field raises (its n_main = n_head = 0) */
+    double corner_angles[4];    /* degrees, MLP:165-192 */
+    double field_length, field_width, headland_width, rotation_angle;
+    double approach_from[2], approach_to[2];    /* MLP:437-441 (valid if start_kept) */
+    double departure_from[2], departure_to[2];  /* MLP:443-447 (valid if end_kept) */
+} fcpp_field_info;
+
+/* ---- per-field results reduced on the device ---------------------------------------- */
+typedef struct fcpp_field_stats {
+    double main_len_m, main_time_pre_s, main_time_s;   /* MLP:616-628 and :423-426 */
+    double head_len_m, head_time_pre_s, head_time_s;   /* MLP:882-895 and :428-431 */
+    double max_kappa, max_alat, max_jump;              /* verify_curvature_constraints over main||headland, MLP:1396-1408 */
+    int64_t n_viol;          /* a_lat > max_lateral_accel, MLP:1401 */
+    int64_t n_outside;       /* geofence: points outside the field polygon */
+    int64_t n_in_obstacle;   /* points inside an obstacle polygon */
+    int64_t n_adjusted;      /* points slowed by the curvature clamp, MLP:502-504 */
+} fcpp_field_stats;
+
+/* ---- flag / segment word -------------------------------------------------------------- */
+enum {
+    FCPP_KIND_SWATH = 0, FCPP_KIND_UTURN = 1, FCPP_KIND_HEAD_START = 2, FCPP_KIND_HEAD_STRAIGHT = 3,
+    FCPP_KIND_CORNER = 4, FCPP_KIND_REVERSE = 5
+};
+#define FCPP_KIND_MASK 7u
+#define FCPP_FLAG_HEADLAND 8u     /* layer 2 */
+#define FCPP_FLAG_ALAT 16u        /* lateral acceleration above max_lateral_accel at this point */
+#define FCPP_FLAG_OUTSIDE 32u     /* outside the field polygon (geofence) */
+#define FCPP_FLAG_OBSTACLE 64u    /* inside an obstacle polygon */
+#define FCPP_INDEX_SHIFT 8        /* bits 8..31: swath index i (layer 1) or loop*8 + corner/side (layer 2) */
+
+typedef struct fcpp_ctx fcpp_ctx;
+typedef struct fcpp_batch fcpp_batch;
+
+/* ---- library / context ---------------------------------------------------------------- */
+const char *fcpp_last_error(void);
+int fcpp_abi_version(void);
+void fcpp_vehicle_default(fcpp_vehicle *v);   /* VehicleParams() defaults, MLP:31-38 */
+void fcpp_options_default(fcpp_options *o);   /* reference behaviour, geofence_tol = 1e-6 */
+int fcpp_ctx_create(int device_id, fcpp_ctx **ctx);
+int fcpp_ctx_destroy(fcpp_ctx *ctx);
+int fcpp_ctx_set_stream(fcpp_ctx *ctx, void *hip_stream); /* a hipStream_t; NULL = HIP's default stream.  A new context starts on a private non-blocking stream */
+int fcpp_ctx_synchronize(fcpp_ctx *ctx);
+/* device memory for hosts without their own allocator (torch users pass tensor pointers instead) */
+int fcpp_malloc(fcpp_ctx *ctx, int64_t bytes, void **dev_ptr);
+int fcpp_free(fcpp_ctx *ctx, void *dev_ptr);
+int fcpp_memcpy_h2d(fcpp_ctx *ctx, void *dst_dev, const void *src, int64_t bytes);
+int fcpp_memcpy_d2h(fcpp_ctx *ctx, void *dst, const void *src_dev, int64_t bytes);
+
+/* ---- planner: TwoLayerPathPlannerV37.__init__ + plan_complete_coverage (MLP:63-107, 387-465) ---- */
+/* Host-only sizing and decisions for n_fields planners (no GPU needed): __init__ (MLP:63-107),
+ * _select_best_start_corner (:360-385), _determine_optimal_pass_order (:631-668), num_passes (:739),
+ * num_loops (:916), reverse-fill lengths (:1154-1288).  Fields that raise get info[i].status < 0. */
+int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
+                    const fcpp_field *fields, fcpp_field_info *info_out);
+/* Same setup, plus upload of the per-field descriptors to the device. */
+int fcpp_batch_create(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
+                      const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **batch);
+int fcpp_batch_info(const fcpp_batch *batch, fcpp_field_info *info_out /* n_fields, may be NULL */,
+                    int64_t *total_points);
+/* The hot path: sample every path point (MLP:720-830, 898-1084, 1154-1218, 1580-1608), curvature
+ * (MLP:513-536), curvature clamp (MLP:467-511), forward/backward sweeps (MLP:538-589), validator
+ * (MLP:1373-1424 + geofence / obstacle flags) and metrics (MLP:1290-1311).  Outputs are device
+ * arrays of total_points elements; stats_dev has n_fields entries.  mode: 0 = default pipeline. */
+int fcpp_batch_run(fcpp_batch *batch, double *x_dev, double *y_dev, double *kappa_dev, double *v_dev,
+                   uint32_t *flagseg_dev, fcpp_field_stats *stats_dev, int mode);
+/* _generate_approach_path / _generate_departure_path (MLP:1313-1355): 50 points each, AoS (x,y) per
+ * field at [field*100 .. +100); rows of fields without a kept start/end point are left untouched. */
+int fcpp_batch_connectors(fcpp_batch *batch, double *approach_xy_dev, double *departure_xy_dev);
+int fcpp_batch_destroy(fcpp_batch *batch);
+
+/* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) ------- */
+/* _calculate_curvature for every interior point (MLP:513-536); end points get 0 */
+int fcpp_curvature(fcpp_ctx *ctx, int64_t n_paths, const int64_t *offsets_dev, int64_t total_points,
+                   const double *x_dev, const double *y_dev, double *kappa_dev);
+/* _apply_curvature_based_speed_limit incl. _smooth_speed_profile (MLP:467-589); paths with fewer
+ * than 3 points are returned unchanged (MLP:480-481).  clamp=0 runs _smooth_speed_profile only.
+ * v_out_dev may alias v_in_dev; kappa_dev and n_adjusted_dev (int64[n_paths]) may be NULL. */
+int fcpp_speed_plan(fcpp_ctx *ctx, const fcpp_vehicle *veh, int clamp, int64_t n_paths,
+                    const int64_t *offsets_dev, int64_t total_points, const double *x_dev,
+                    const double *y_dev, const double *v_in_dev, double *v_out_dev, double *kappa_dev,
+                    int64_t *n_adjusted_dev);
+/* verify_curvature_constraints (MLP:1373-1424) + _calculate_path_length/_calculate_work_time
+ * (MLP:1290-1311) per path; stats_dev[n_paths] uses the main_* members for the whole path. */
+int fcpp_verify(fcpp_ctx *ctx, const fcpp_vehicle *veh, int64_t n_paths, const int64_t *offsets_dev,
+                int64_t total_points, const double *x_dev, const double *y_dev, const double *v_dev,
+                fcpp_field_stats *stats_dev);
+/* numpy.linspace straight segments (MLP:1013-1022, 1313-1355): seg_dev = n_seg x (x0,y0,x1,y1),
+ * out_xy_dev = n_seg x n_points x 2 */
+int fcpp_straight_segments(fcpp_ctx *ctx, int64_t n_seg, const double *seg_dev, int32_t n_points,
+                           double *out_xy_dev);
+/* Fresnel integrals C(t), S(t) = int_0^t cos|sin(pi u^2/2) du (README_en.md:111-120 promises the
+ * clothoid; the reference has no code for it) */
+int fcpp_fresnel(fcpp_ctx *ctx, int64_t n, const double *t_dev, double *c_dev, double *s_dev);
+
+/* ---- GeneticAlgorithmSolver._calculate_distance / _calculate_fitness (GA:168-181) ---------- */
+/* routes_dev: pop x n_nodes int32 permutations; D_dev: n_nodes x n_nodes float64 row-major.
+ * order_mode 0 = left-to-right summation (bit-exact with the reference), 1 = tree reduction. */
+int fcpp_ga_fitness(fcpp_ctx *ctx, int32_t n_nodes, int64_t pop, const double *D_dev,
+                    const int32_t *routes_dev, double *dist_dev, double *fit_dev, int order_mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCPP_H */
