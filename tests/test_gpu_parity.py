@@ -1,0 +1,292 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP library, called through its C ABI, against
+(a) the reference's golden vectors and (b) the CPU oracle on seeded inputs.
+
+Tolerances (float64): coordinates 1e-9 m (the bar in BASELINE.json is 1e-6 m), curvature 1e-9 1/m,
+speeds 1e-9 km/h at the reference's sampling; integers (counts, swath indices, flags) exact.
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+from field_coverage_path_planning_amd import _lib as L
+from field_coverage_path_planning_amd import engine as E
+from tests.test_abi_and_host import _specs_from_golden
+from tests.test_oracle_vs_golden import _field_from_golden
+
+pytestmark = pytest.mark.gpu
+
+XY_TOL, K_TOL, V_TOL = 1e-9, 1e-9, 1e-9
+VP_NAMES = [n for n, _ in L.Vehicle._fields_]
+
+
+def _veh(arr):
+    return E.make_vehicle(**dict(zip(VP_NAMES, arr)))
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def test_native_library_is_loaded():
+    import torch
+    assert torch.cuda.is_available()
+    E.get_context()
+    maps = open('/proc/self/maps').read()
+    assert 'libfcpp.so' in maps
+
+
+def test_batch_vs_golden_plans(golden_plans):
+    """All golden scenarios sharing a vehicle are planned as ONE batch; every array is compared."""
+    g = golden_plans
+    groups = {}
+    for name in g['names']:
+        groups.setdefault(tuple(g[f'{name}/vp']), []).append(str(name))
+    for vp, names in groups.items():
+        specs = [_specs_from_golden(g, n) for n in names]
+        batch = E.Batch(specs, _veh(vp))
+        res = batch.run()
+        ap, dp = batch.connectors()
+        x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
+        st = res.stats()
+        ap, dp = _np(ap), _np(dp)
+        for i, n in enumerate(names):
+            info = batch.info[i]
+            sl = res.field_slice(i)
+            mp, hp = g[f'{n}/main_path'], g[f'{n}/head_path']
+            assert info.n_main == len(mp) and info.n_head == len(hp), n
+            xy = np.column_stack([x[sl], y[sl]])
+            np.testing.assert_allclose(xy[:info.n_main], mp, rtol=0, atol=XY_TOL, err_msg=n)
+            np.testing.assert_allclose(xy[info.n_main:], hp, rtol=0, atol=XY_TOL, err_msg=n)
+            np.testing.assert_allclose(v[sl][:info.n_main], g[f'{n}/main_v'], rtol=0, atol=V_TOL, err_msg=n)
+            np.testing.assert_allclose(v[sl][info.n_main:], g[f'{n}/head_v'], rtol=0, atol=V_TOL, err_msg=n)
+            ms, hs, ver = g[f'{n}/main_stats'], g[f'{n}/head_stats'], g[f'{n}/ver']
+            np.testing.assert_allclose(st['main_len_m'][i] / 1000, ms[0], rtol=1e-12)
+            np.testing.assert_allclose(st['main_time_s'][i] / 3600, ms[1], rtol=1e-10)
+            np.testing.assert_allclose((st['main_len_m'][i] / 1000) / (st['main_time_pre_s'][i] / 3600), ms[2], rtol=1e-10)
+            np.testing.assert_allclose(st['head_len_m'][i] / 1000, hs[0], rtol=1e-12)
+            np.testing.assert_allclose(st['head_time_s'][i] / 3600, hs[1], rtol=1e-10)
+            np.testing.assert_allclose([st['max_kappa'][i], st['max_alat'][i], st['max_jump'][i]], ver[[0, 1, 4]],
+                                       rtol=1e-8, atol=1e-11, err_msg=n)
+            assert st['n_viol'][i] == ver[2], n
+            ga, gd = g[f'{n}/approach'], g[f'{n}/departure']
+            if len(ga):
+                np.testing.assert_allclose(ap[i], ga, rtol=0, atol=XY_TOL)
+            else:
+                assert np.isnan(ap[i]).all()
+            if len(gd):
+                np.testing.assert_allclose(dp[i], gd, rtol=0, atol=XY_TOL)
+            else:
+                assert np.isnan(dp[i]).all()
+        batch.close()
+
+
+def _compare_with_oracle(specs, ofields, veh_arr, opt_kw, xy_tol=XY_TOL, k_tol=K_TOL, v_tol=V_TOL):
+    o = E.make_options(**opt_kw)
+    batch = E.Batch(specs, _veh(veh_arr), o)
+    res = batch.run()
+    x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
+    st = res.stats()
+    oopt = orc.Options.make(o.turn_model, o.clothoid_fit, o.sample_spacing, o.clothoid_frac, o.geofence_tol)
+    for i, of in enumerate(ofields):
+        rc, p = orc.plan_field(of, orc.Vehicle.make(veh_arr), oopt)
+        info = batch.info[i]
+        assert rc == info.status
+        if rc != 0:
+            assert info.n_main == 0 and info.n_head == 0
+            continue
+        sl = res.field_slice(i)
+        assert (info.n_main, info.n_head) == (p.n_main, p.n_head)
+        np.testing.assert_allclose(np.column_stack([x[sl], y[sl]]), p.xy, rtol=0, atol=xy_tol)
+        np.testing.assert_allclose(k[sl], p.kappa, rtol=0, atol=k_tol)
+        np.testing.assert_allclose(v[sl], p.v, rtol=0, atol=v_tol)
+        assert np.array_equal(fs[sl], p.flagseg), i          # kinds, swath indices, validity flags: bit-exact
+        for a, b in (('main_len_m', p.main_len_m), ('main_time_pre_s', p.main_time_pre_s), ('main_time_s', p.main_time_s),
+                     ('head_len_m', p.head_len_m), ('head_time_pre_s', p.head_time_pre_s), ('head_time_s', p.head_time_s)):
+            np.testing.assert_allclose(st[a][i], b, rtol=1e-10, err_msg=a)
+        np.testing.assert_allclose([st['max_kappa'][i], st['max_alat'][i], st['max_jump'][i]],
+                                   [p.max_kappa, p.max_alat, p.max_jump], rtol=1e-7, atol=max(k_tol, 1e-11))
+        assert (st['n_viol'][i], st['n_outside'][i], st['n_in_obstacle'][i], st['n_adjusted'][i]) == \
+            (p.n_viol, p.n_outside, p.n_in_obstacle, p.n_adjusted), i
+    batch.close()
+
+
+def _random_fields(seed, n, para=False, with_obstacles=False, with_points=True):
+    rng = np.random.default_rng(seed)
+    specs, ofs = [], []
+    for i in range(n):
+        Lx, Hy = rng.uniform(100, 1000, 2)
+        start = end = None
+        if with_points and i % 2 == 0:
+            start = (float(rng.uniform(0, Lx)), float(rng.uniform(0, Hy)))
+        if with_points and i % 3 == 0:
+            end = (float(rng.uniform(0, Lx)), float(rng.uniform(0, Hy)))
+        obstacles = None
+        if with_obstacles:
+            obstacles = []
+            for _ in range(int(rng.integers(1, 5))):
+                cx, cy, r = rng.uniform(0.2 * Lx, 0.8 * Lx), rng.uniform(0.2 * Hy, 0.8 * Hy), rng.uniform(5, 30)
+                a = np.sort(rng.uniform(0, 2 * np.pi, int(rng.integers(3, 9))))
+                obstacles.append([(float(cx + r * np.cos(t)), float(cy + r * np.sin(t))) for t in a])
+        if para:
+            ang, rot = np.radians(rng.uniform(60, 120)), rng.uniform(-np.pi / 4, np.pi / 4)
+            sx = Hy / np.tan(ang)
+            vv = np.array([[0, 0], [Lx, 0], [Lx + sx, Hy], [sx, Hy]]) @ np.array([[np.cos(rot), np.sin(rot)], [-np.sin(rot), np.cos(rot)]])
+            verts = [(float(a), float(b)) for a, b in vv]
+            specs.append(E.FieldSpec(field_vertices=verts, obstacles=obstacles, start_point=start, end_point=end))
+            ofs.append(orc.make_field(verts=verts, start=start, end=end, obstacles=obstacles))
+        else:
+            specs.append(E.FieldSpec(field_length=float(Lx), field_width=float(Hy), obstacles=obstacles,
+                                     start_point=start, end_point=end))
+            ofs.append(orc.make_field(L=float(Lx), H=float(Hy), start=start, end=end, obstacles=obstacles))
+    return specs, ofs
+
+
+DEFAULT_VP = [3.2, 8.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85]
+
+
+def test_reference_sampling_random_rectangles_vs_oracle():
+    specs, ofs = _random_fields(1024, 48)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, {})
+
+
+def test_reference_sampling_parallelograms_vs_oracle():
+    specs, ofs = _random_fields(65536, 48, para=True)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, {})
+
+
+def test_obstacles_and_geofence_flags_vs_oracle():
+    specs, ofs = _random_fields(32, 24, with_obstacles=True)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, {})
+    # densely sampled swaths really cross the obstacles -> the flag must be set and match the oracle
+    _compare_with_oracle(specs[:8], ofs[:8], DEFAULT_VP, dict(sample_spacing=1.0), k_tol=1e-8, v_tol=1e-6)
+    b = E.Batch(specs[:8], _veh(DEFAULT_VP), E.make_options(sample_spacing=1.0))
+    assert b.run().stats()['n_in_obstacle'].sum() > 0
+    b.close()
+
+
+def test_error_fields_inside_a_batch():
+    specs = [E.FieldSpec(field_length=500.0, field_width=200.0), E.FieldSpec(field_length=15.0, field_width=200.0),
+             E.FieldSpec(field_length=100.0, field_width=80.0)]
+    ofs = [orc.make_field(L=500.0, H=200.0), orc.make_field(L=15.0, H=200.0), orc.make_field(L=100.0, H=80.0)]
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, {})
+
+
+@pytest.mark.parametrize('opt', [
+    dict(sample_spacing=0.5), dict(sample_spacing=0.1), dict(turn_model=1, sample_spacing=0.25),
+    dict(turn_model=1, sample_spacing=0.1, clothoid_frac=1.0), dict(turn_model=1, sample_spacing=0.2, clothoid_frac=0.0),
+    dict(turn_model=1, sample_spacing=0.3, clothoid_frac=0.4, clothoid_fit=0), dict(turn_model=1)])
+def test_dense_and_clothoid_sampling_vs_oracle(opt):
+    """Build-defined modes (no reference counterpart): oracle = independent long-double Fresnel quadrature.
+    Curvature from a 3-point stencil amplifies coordinate rounding by ~4/ds^2, hence the scaled tolerances."""
+    specs, ofs = _random_fields(7, 6, with_points=True)
+    specs2, ofs2 = _random_fields(8, 3, para=True)
+    ds = opt.get('sample_spacing', 0.0) or 0.5
+    k_tol = max(K_TOL, 4e-12 / ds ** 2)
+    _compare_with_oracle(specs + specs2, ofs + ofs2, DEFAULT_VP, opt, xy_tol=1e-9, k_tol=k_tol, v_tol=max(V_TOL, 200 * k_tol))
+
+
+def test_other_vehicles_vs_oracle():
+    specs, ofs = _random_fields(99, 12)
+    _compare_with_oracle(specs, ofs, [2.5, 6.0, 12.0, 14.0, 5.0, 1.2, 0.7, 0.9], {})
+    _compare_with_oracle(specs, ofs, [4.0, 5.0, 9.0, 20.0, 3.0, 2.5, 3.0, 0.8], dict(sample_spacing=0.4))
+
+
+def test_standalone_speed_planner_vs_golden(golden_kernels):
+    g = golden_kernels
+    offs = g['sp_offsets']
+    x, y = g['sp_path'][:, 0], g['sp_path'][:, 1]
+    out, nadj = E.speed_plan(x, y, g['sp_v_in'], _veh(g['vp_default']), clamp=True, offsets=offs)
+    np.testing.assert_allclose(_np(out), g['sp_v_out'], rtol=0, atol=V_TOL)
+    out2, _ = E.speed_plan(x, y, g['sp_v_in'], _veh(g['vp2']), clamp=True, offsets=offs)
+    np.testing.assert_allclose(_np(out2), g['sp2_v_out'], rtol=0, atol=V_TOL)
+    sm, _ = E.speed_plan(x, y, g['sp_v_in'], _veh(g['vp_default']), clamp=False, offsets=offs)
+    np.testing.assert_allclose(_np(sm), g['sp_v_smooth_only'], rtol=0, atol=V_TOL)
+    # path 0 has 3 points; a 2-point path must come back untouched by clamp=True (MLP:480-481)
+    o2, _ = E.speed_plan([0.0, 1.0], [0.0, 0.0], [0.1, 15.0], _veh(g['vp_default']), clamp=True)
+    assert _np(o2).tolist() == [0.1, 15.0]
+    o3, _ = E.speed_plan([0.0, 1.0], [0.0, 0.0], [0.1, 15.0], _veh(g['vp_default']), clamp=False)
+    assert _np(o3)[1] < 15.0
+    # adjusted counts equal the oracle's
+    veh = orc.Vehicle.make(g['vp_default'])
+    want = [orc.speed_limit(g['sp_path'][offs[k]:offs[k + 1]], g['sp_v_in'][offs[k]:offs[k + 1]], veh)[1]
+            for k in range(len(offs) - 1)]
+    assert _np(nadj).tolist() == want
+
+
+def test_standalone_curvature_and_verify_vs_golden(golden_kernels):
+    g = golden_kernels
+    tri = g['curv_tri']
+    offs = np.arange(0, 3 * len(tri) + 1, 3)
+    k = _np(E.curvature(tri[:, :, 0].ravel(), tri[:, :, 1].ravel(), offsets=offs)).reshape(-1, 3)
+    np.testing.assert_allclose(k[:, 1], g['curv_kappa'], rtol=1e-11, atol=1e-13)
+    assert (k[:, 0] == 0).all() and (k[:, 2] == 0).all()
+    so = g['sp_offsets']
+    st = E.verify(g['sp_path'][:, 0], g['sp_path'][:, 1], g['sp_v_out'], _veh(g['vp_default']), offsets=so)
+    ref = g['ver_stats']
+    np.testing.assert_allclose(st['max_kappa'], ref[:, 0], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(st['max_alat'], ref[:, 1], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(st['max_jump'], ref[:, 4], rtol=1e-10, atol=1e-12)
+    assert st['n_viol'].tolist() == ref[:, 2].astype(int).tolist()
+    np.testing.assert_allclose(st['main_len_m'], g['len_m'], rtol=1e-12)
+    np.testing.assert_allclose(st['main_time_s'], g['time_s'], rtol=1e-12)
+    st15 = E.verify(g['sp_path'][:, 0], g['sp_path'][:, 1], np.full(len(g['sp_path']), 15.0), _veh(g['vp_default']), offsets=so)
+    assert st15['n_viol'][1:].tolist() == g['ver15_stats'][:, 2].astype(int).tolist()
+
+
+def test_long_single_path_sweeps_vs_oracle():
+    """One path of 300k points (147 tiles): exercises the cross-tile spine of the min-plus scan."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    th = np.cumsum(rng.normal(0, 0.05, n))
+    seg = rng.uniform(0.01, 0.06, n)                   # ~3.5 cm steps: constraints reach across many tiles
+    xy = np.cumsum(np.column_stack([seg * np.cos(th), seg * np.sin(th)]), axis=0)
+    for j in rng.integers(1, n, size=50):
+        xy[j] = xy[j - 1]
+    v = rng.choice([0.5, 2.5, 4.0, 9.0, 15.0, 40.0], size=n, p=[0.01, 0.04, 0.1, 0.4, 0.4, 0.05])
+    veh = orc.Vehicle.make(max_longitudinal_accel=0.05)
+    want, _ = orc.speed_limit(xy, v, veh)
+    got, _ = E.speed_plan(xy[:, 0], xy[:, 1], v, _veh([3.2, 8.0, 9.0, 15.0, 4.0, 2.0, 0.05, 0.85]), clamp=True)
+    np.testing.assert_allclose(_np(got), want, rtol=0, atol=1e-9)
+
+
+def test_fresnel_vs_mpmath_table():
+    import os
+    tab = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'fresnel_table.npz'))
+    c, s = E.fresnel(tab['t'])
+    np.testing.assert_allclose(_np(c), tab['C'], rtol=0, atol=2e-15)
+    np.testing.assert_allclose(_np(s), tab['S'], rtol=0, atol=2e-15)
+
+
+def test_ga_fitness_bit_exact(golden_ga):
+    g = golden_ga
+    for tag in ('n10', 'n128', 'n129', 'n33'):
+        d, f = E.ga_fitness(g[f'{tag}_routes'], g[f'{tag}_D'], order_mode=0)
+        assert np.array_equal(_np(d), g[f'{tag}_dist']), tag       # left-to-right sum: bit-exact
+        assert np.array_equal(_np(f), g[f'{tag}_fit']), tag
+        d1, _ = E.ga_fitness(g[f'{tag}_routes'], g[f'{tag}_D'], order_mode=1)
+        np.testing.assert_allclose(_np(d1), g[f'{tag}_dist'], rtol=1e-13)
+
+
+def test_planner_class_end_to_end(golden_plans):
+    from field_coverage_path_planning_amd.multi_layer_planner_v3 import TwoLayerPathPlannerV37, VehicleParams
+    g = golden_plans
+    pl = TwoLayerPathPlannerV37(VehicleParams(max_headland_speed_kmh=14.0), field_length=500, field_width=200,
+                                start_point=(10, 10), end_point=(490, 190))
+    r = pl.plan_complete_coverage()
+    n = 'v351_start_end'
+    assert r['version'] == 'V3.5.1' and len(r['features']) == 5
+    np.testing.assert_allclose(r['main_work']['path'], g[f'{n}/main_path'], rtol=0, atol=XY_TOL)
+    np.testing.assert_allclose(r['headland']['speeds'], g[f'{n}/head_v'], rtol=0, atol=V_TOL)
+    np.testing.assert_allclose(r['approach_path'], g[f'{n}/approach'], rtol=0, atol=XY_TOL)
+    np.testing.assert_allclose(r['departure_path'], g[f'{n}/departure'], rtol=0, atol=XY_TOL)
+    np.testing.assert_allclose([r['main_work']['stats'][k] for k in ('path_length_km', 'time_hours', 'avg_speed_kmh')],
+                               g[f'{n}/main_stats'], rtol=1e-10)
+    allp = np.vstack([r['main_work']['path'], r['headland']['path']])
+    alls = np.concatenate([r['main_work']['speeds'], r['headland']['speeds']])
+    ver = pl.verify_curvature_constraints(allp, alls)
+    gv = g[f'{n}/ver']
+    assert ver['accel_violations'] == gv[2] and ver['pass'] == bool(gv[5])
+    np.testing.assert_allclose([ver['max_curvature'], ver['max_lateral_accel'], ver['max_jump']], gv[[0, 1, 4]], rtol=1e-9)
+    assert abs(pl._calculate_path_length(r['approach_path']) - 11.9) < 0.05           # doc/V3.5.1:109-111
+    with pytest.raises(ValueError):
+        TwoLayerPathPlannerV37(VehicleParams(), field_length=15, field_width=200).plan_complete_coverage()
