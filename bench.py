@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- validated path points/sec of the HIP hot path on MI355X.
+
+One "step" = one pass of the whole hot path (sample every path point, curvature, curvature clamp,
+forward/backward speed sweeps, a_lat/geofence/obstacle validation, per-field metrics) over one batch
+of synthetic fields whose descriptors are already resident in HBM.
+
+Workload (BASELINE.json configs[1]): 1024 random rectangular fields, edges U[100,1000) m, seed 1024,
+default VehicleParams, clothoid turn model, uniform 0.1 m sample spacing  ->  1.01e9 path points and
+36.5 GB of output per step per GPU.  With --gpus N every rank plans its own 1024-field batch
+(seed 1024 + rank; weak scaling), and the per-field stats are gathered to rank 0 over RCCL each step.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+BYTES_PER_POINT = 36          # x, y, kappa, v as float64 + one uint32 flag/segment word
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def make_specs(E, n_fields, seed):
+    rng = np.random.default_rng(seed)
+    LH = rng.uniform(100.0, 1000.0, size=(n_fields, 2))
+    return [E.FieldSpec(field_length=float(a), field_width=float(b)) for a, b in LH], LH
+
+
+def cpu_baseline(LH, spacing, turn_model, budget_s=12.0):
+    """The CPU oracle (plain C restatement of the reference algorithm, one core) on the first fields of
+    the same workload, until ~budget_s seconds of CPU work have been spent."""
+    import oracle as orc
+    veh, opt = orc.Vehicle.make(), orc.Options.make(turn_model, 1, spacing, 0.5)
+    pts, t_used, k = 0, 0.0, 0
+    while k < len(LH) and t_used < budget_s:
+        f = orc.make_field(L=float(LH[k, 0]), H=float(LH[k, 1]))
+        t0 = time.perf_counter()
+        rc, p = orc.plan_field(f, veh, opt)
+        t_used += time.perf_counter() - t0
+        assert rc == 0
+        pts += p.n
+        k += 1
+    return {'value': pts / t_used, 'unit': 'points/s', 'cores': 1, 'kind': 'port',
+            'sample': f'first {k} of the batch\'s fields ({pts} points, {t_used:.1f} s) through oracle/fcpp_oracle.c '
+                      f'(sequential C restatement of the reference loops, gcc -O2, 1 thread)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--fields', type=int, default=1024)
+    ap.add_argument('--spacing', type=float, default=0.1)
+    ap.add_argument('--turn-model', type=int, default=1, help='1 = clothoid (default), 0 = arcs')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from field_coverage_path_planning_amd import engine as E
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    specs, LH = make_specs(E, args.fields, 1024 + rank)
+    batch = E.Batch(specs, E.make_vehicle(), E.make_options(args.turn_model, args.spacing), device=local)
+    bufs = batch.alloc()
+    n_points = batch.total_points
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty_like(bufs[5]) for _ in range(world)]
+
+    def step():
+        res = batch.run(bufs)
+        if world > 1:   # the only collective of the path: final gather of the per-field stats
+            dist.gather(res.stats_raw, gather_list, dst=0)
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    batch.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    stage_ms, prof_runs = batch.stage_times()
+    batch.set_profiling(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    pts = torch.tensor([float(n_points)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total_points = float(pts.item())
+
+    if rank == 0:
+        # sanity on the produced data (outside the timed region)
+        st = res.stats()
+        assert int(st['n_viol'].sum()) == 0 and np.isfinite(st['main_len_m']).all()
+        dom = max(stage_ms, key=stage_ms.get)
+        dom_ms = stage_ms[dom]
+        achieved = BYTES_PER_POINT * n_points / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        pipe_ms = sum(stage_ms.values())
+        traffic = None
+        tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            key = f'{dom}|fields={args.fields}|spacing={args.spacing}|turn={args.turn_model}'
+            traffic = tj.get(key)
+        out = {
+            'metric': 'validated path points/sec (Clothoid+speed+geofence) on field batch',
+            'value': total_points * args.steps / dt,
+            'unit': 'points/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': f'cfg2: {args.fields} random rectangular fields per GPU (edges U[100,1000) m, seed 1024+rank), '
+                            f'{"clothoid" if args.turn_model else "arc"} turns, {args.spacing} m sample spacing, '
+                            f'default VehicleParams',
+                'points_per_gpu_step': n_points, 'fields_per_gpu': args.fields,
+                'pipeline': 'staged (7 kernels)',
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * n_points,
+                'all_kernels_ms': stage_ms, 'pipeline_ms': pipe_ms,
+                'pipeline_frac': (BYTES_PER_POINT * n_points / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pipe_ms > 0 else 0.0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(LH, args.spacing, args.turn_model)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -134,7 +134,19 @@ struct fcpp_batch {
     DevBuf<double> obs_x, obs_y;
     DevBuf<double> seg;        // connector segments
     DevBuf<int32_t> seg_mask;
+    // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
+    bool profiling = false;
+    std::vector<hipEvent_t> events;   // kProfRuns x (kStages + 1)
+    int prof_runs = 0;
+    ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
+
+namespace {
+constexpr int kStages = 7;
+constexpr int kProfRuns = 64;
+const char *const kStageNames[kStages] = { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine",
+                                            "k_scan_apply", "k_validate", "k_reduce_stats" };
+}
 
 extern "C" {
 
@@ -329,13 +341,62 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     DevTiling &t = b->til;
     DevObstacles obs = { b->obs_off.p, b->obs_x.p, b->obs_y.p };
     HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
-    LAUNCHCHK(launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
-    LAUNCHCHK(launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
-    LAUNCHCHK(launch_sweeps(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 3, x, y, v, v, t.agg_f.p, t.agg_b.p,
-                            t.carry_f.p, t.carry_b.p));
-    LAUNCHCHK(launch_validate(st, t.n_tiles, t.n_paths, t.tiles.p, t.paths.p, b->fields.p, b->cst, obs, x, y, kappa, v,
-                              fs, t.partial.p, t.tile_first.p, t.n_adj.p, stats));
+    hipEvent_t *ev = nullptr;
+    if (b->profiling && b->prof_runs < kProfRuns) ev = &b->events[(size_t)b->prof_runs * (kStages + 1)];
+#define STAGE(k, call)                                     \
+    do {                                                   \
+        LAUNCHCHK(call);                                   \
+        if (ev) HIPCHK(hipEventRecord(ev[(k) + 1], st));   \
+    } while (0)
+    if (ev) HIPCHK(hipEventRecord(ev[0], st));
+    STAGE(0, launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
+    STAGE(1, launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
+    STAGE(2, launch_scan_tiles(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, x, y, v, t.agg_f.p, t.agg_b.p));
+    STAGE(3, launch_scan_spine(st, t.n_tiles, t.agg_f.p, t.agg_b.p, t.carry_f.p, t.carry_b.p));
+    STAGE(4, launch_scan_apply(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 3, x, y, v, v, t.carry_f.p, t.carry_b.p));
+    STAGE(5, launch_validate(st, t.n_tiles, t.tiles.p, t.paths.p, b->fields.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+    STAGE(6, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, t.n_adj.p, stats));
+#undef STAGE
+    if (ev) ++b->prof_runs;
     return FCPP_OK;
+}
+
+int fcpp_batch_set_profiling(fcpp_batch *b, int enable)
+{
+    if (!b) return fail(FCPP_EINVAL, "batch is NULL");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if (enable && b->events.empty()) {
+        b->events.resize((size_t)kProfRuns * (kStages + 1));
+        for (hipEvent_t &e : b->events) HIPCHK(hipEventCreate(&e));
+    }
+    b->profiling = enable != 0;
+    b->prof_runs = 0;
+    return FCPP_OK;
+}
+
+int fcpp_batch_stage_times(fcpp_batch *b, int max_stages, double *ms_sum, int *n_stages, int *n_runs)
+{
+    if (!b || !ms_sum || max_stages < kStages) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    for (int k = 0; k < kStages; ++k) ms_sum[k] = 0.0;
+    for (int r = 0; r < b->prof_runs; ++r) {
+        hipEvent_t *ev = &b->events[(size_t)r * (kStages + 1)];
+        for (int k = 0; k < kStages; ++k) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            ms_sum[k] += ms;
+        }
+    }
+    if (n_stages) *n_stages = kStages;
+    if (n_runs) *n_runs = b->prof_runs;
+    b->prof_runs = 0;
+    return FCPP_OK;
+}
+
+const char *fcpp_batch_stage_name(int stage)
+{
+    return (stage >= 0 && stage < kStages) ? kStageNames[stage] : "";
 }
 
 int fcpp_batch_connectors(fcpp_batch *b, double *approach_xy, double *departure_xy)
@@ -417,8 +478,10 @@ int fcpp_speed_plan(fcpp_ctx *c, const fcpp_vehicle *veh, int clamp, int64_t n_p
     hipStream_t st = c->stream;
     if (n_paths) HIPCHK(hipMemsetAsync(dt.n_adj.p, 0, (size_t)n_paths * sizeof(unsigned long long), st));
     LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, clamp ? 1 : 0, x, y, v_in, v_out, kappa, dt.n_adj.p));
-    LAUNCHCHK(launch_sweeps(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, clamp ? 3 : 2, x, y, v_out, v_out, dt.agg_f.p,
-                            dt.agg_b.p, dt.carry_f.p, dt.carry_b.p));
+    LAUNCHCHK(launch_scan_tiles(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, x, y, v_out, dt.agg_f.p, dt.agg_b.p));
+    LAUNCHCHK(launch_scan_spine(st, dt.n_tiles, dt.agg_f.p, dt.agg_b.p, dt.carry_f.p, dt.carry_b.p));
+    LAUNCHCHK(launch_scan_apply(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, clamp ? 3 : 2, x, y, v_out, v_out,
+                                dt.carry_f.p, dt.carry_b.p));
     if (n_adjusted && n_paths)
         HIPCHK(hipMemcpyAsync(n_adjusted, dt.n_adj.p, (size_t)n_paths * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -440,8 +503,8 @@ int fcpp_verify(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n_paths, const int
     HIPCHK(vtmp.alloc((size_t)total));
     LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, 0, x, y, v, vtmp.p, kap.p, nullptr));
     DevObstacles obs = { nullptr, nullptr, nullptr };
-    LAUNCHCHK(launch_validate(st, dt.n_tiles, dt.n_paths, dt.tiles.p, dt.paths.p, nullptr, cst, obs, x, y, kap.p, v, nullptr,
-                              dt.partial.p, dt.tile_first.p, nullptr, stats));
+    LAUNCHCHK(launch_validate(st, dt.n_tiles, dt.tiles.p, dt.paths.p, nullptr, cst, obs, x, y, kap.p, v, nullptr, dt.partial.p));
+    LAUNCHCHK(launch_reduce_stats(st, dt.n_paths, dt.partial.p, dt.tile_first.p, nullptr, stats));
     HIPCHK(hipStreamSynchronize(st));
     return FCPP_OK;
 }

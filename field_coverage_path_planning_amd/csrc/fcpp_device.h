@@ -28,13 +28,18 @@ int launch_generate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
 int launch_curv_clamp(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
                       const DevConst &cst, int do_clamp, const double *x, const double *y, const double *v_in,
                       double *v_out, double *kappa, unsigned long long *n_adjusted);
-int launch_sweeps(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
-                  int min_n, const double *x, const double *y, const double *v_in, double *v_out, void *agg_f,
-                  void *agg_b, double *carry_f, double *carry_b);
-int launch_validate(hipStream_t st, int64_t n_tiles, int64_t n_paths, const DevTile *tiles, const DevPath *paths,
+int launch_scan_tiles(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
+                      const double *x, const double *y, const double *v_in, void *agg_f, void *agg_b);
+int launch_scan_spine(hipStream_t st, int64_t n_tiles, const void *agg_f, const void *agg_b, double *carry_f,
+                      double *carry_b);
+int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
+                      int min_n, const double *x, const double *y, const double *v_in, double *v_out,
+                      const double *carry_f, const double *carry_b);
+int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
                     const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
-                    const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial,
-                    const int64_t *tile_first, const unsigned long long *n_adjusted, fcpp_field_stats *stats);
+                    const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
+int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats);
 int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts, const int32_t *mask, double *out);
 int launch_fresnel(hipStream_t st, int64_t n, const double *t, double *c, double *s);
 int launch_ga_fitness(hipStream_t st, int n, int64_t pop, const double *D, const int32_t *routes, double *dist,

@@ -624,34 +624,52 @@ int launch_curv_clamp(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
     return 0;
 }
 
-int launch_sweeps(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
-                  int min_n, const double *x, const double *y, const double *v_in, double *v_out, void *agg_f,
-                  void *agg_b, double *carry_f, double *carry_b)
+int launch_scan_tiles(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
+                      const double *x, const double *y, const double *v_in, void *agg_f, void *agg_b)
 {
     if (n_tiles <= 0) return 0;
     hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, x, y, v_in,
                        (Agg *)agg_f, (Agg *)agg_b);
     FCPP_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_scan_spine(hipStream_t st, int64_t n_tiles, const void *agg_f, const void *agg_b, double *carry_f,
+                      double *carry_b)
+{
+    if (n_tiles <= 0) return 0;
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(BLOCK), 0, st, n_tiles, (const Agg *)agg_f, (const Agg *)agg_b,
                        carry_f, carry_b);
     FCPP_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
+                      int min_n, const double *x, const double *y, const double *v_in, double *v_out,
+                      const double *carry_f, const double *carry_b)
+{
+    if (n_tiles <= 0) return 0;
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, min_n, x, y, v_in,
                        v_out, carry_f, carry_b);
     FCPP_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_validate(hipStream_t st, int64_t n_tiles, int64_t n_paths, const DevTile *tiles, const DevPath *paths,
+int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
                     const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
-                    const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial,
-                    const int64_t *tile_first, const unsigned long long *n_adjusted, fcpp_field_stats *stats)
+                    const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial)
+{
+    if (n_tiles <= 0) return 0;
+    hipLaunchKernelGGL(k_validate, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, fields, cst, obs, x, y,
+                       kappa, v, fs, partial);
+    FCPP_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats)
 {
     if (n_paths <= 0) return 0;
-    if (n_tiles > 0) {
-        hipLaunchKernelGGL(k_validate, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, fields, cst, obs, x, y,
-                           kappa, v, fs, partial);
-        FCPP_LAUNCH_CHECK();
-    }
     hipLaunchKernelGGL(k_reduce_stats, dim3((unsigned)n_paths), dim3(64), 0, st, n_paths, tile_first, partial,
                        n_adjusted, stats);
     FCPP_LAUNCH_CHECK();

@@ -214,6 +214,17 @@ class Batch:
         L.check(self.lib.fcpp_batch_connectors(self.handle, _ptr(ap), _ptr(dp)))
         return ap, dp
 
+    def set_profiling(self, on=True):
+        L.check(self.lib.fcpp_batch_set_profiling(self.handle, int(bool(on))))
+
+    def stage_times(self):
+        """-> ({kernel name: mean ms per run}, runs) from the HIP events recorded since the last call."""
+        ms = (C.c_double * 16)()
+        ns, nr = C.c_int(), C.c_int()
+        L.check(self.lib.fcpp_batch_stage_times(self.handle, 16, ms, C.byref(ns), C.byref(nr)))
+        runs = max(nr.value, 1)
+        return {self.lib.fcpp_batch_stage_name(k).decode(): ms[k] / runs for k in range(ns.value)}, nr.value
+
     def close(self):
         if getattr(self, 'handle', None):
             self.lib.fcpp_batch_destroy(self.handle)

@@ -161,6 +161,13 @@ int fcpp_batch_run(fcpp_batch *batch, double *x_dev, double *y_dev, double *kapp
  * field at [field*100 .. +100); rows of fields without a kept start/end point are left untouched. */
 int fcpp_batch_connectors(fcpp_batch *batch, double *approach_xy_dev, double *departure_xy_dev);
 int fcpp_batch_destroy(fcpp_batch *batch);
+/* Per-kernel device timing with HIP events on the context's stream (bench.py's roofline leg).  While
+ * enabled, each fcpp_batch_run records one event per kernel (up to 64 runs are kept).
+ * fcpp_batch_stage_times synchronises, returns the summed milliseconds per stage over the recorded
+ * runs and clears the record. */
+int fcpp_batch_set_profiling(fcpp_batch *batch, int enable);
+int fcpp_batch_stage_times(fcpp_batch *batch, int max_stages, double *ms_sum_out, int *n_stages_out, int *n_runs_out);
+const char *fcpp_batch_stage_name(int stage);
 
 /* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) ------- */
 /* _calculate_curvature for every interior point (MLP:513-536); end points get 0 */
