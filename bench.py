@@ -61,6 +61,7 @@ def main():
     ap.add_argument('--fields', type=int, default=1024)
     ap.add_argument('--spacing', type=float, default=0.1)
     ap.add_argument('--turn-model', type=int, default=1, help='1 = clothoid (default), 0 = arcs')
+    ap.add_argument('--mode', type=int, default=1, help='1 = fused single-pass kernel (default), 0 = staged pipeline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -88,7 +89,7 @@ def main():
         gather_list = [torch.empty_like(bufs[5]) for _ in range(world)]
 
     def step():
-        res = batch.run(bufs)
+        res = batch.run(bufs, mode=args.mode)
         if world > 1:   # the only collective of the path: final gather of the per-field stats
             dist.gather(res.stats_raw, gather_list, dst=0)
         return res
@@ -145,7 +146,7 @@ def main():
                             f'{"clothoid" if args.turn_model else "arc"} turns, {args.spacing} m sample spacing, '
                             f'default VehicleParams',
                 'points_per_gpu_step': n_points, 'fields_per_gpu': args.fields,
-                'pipeline': 'staged (7 kernels)',
+                'pipeline': 'fused single-pass kernel' if args.mode == 1 else 'staged (7 kernels)',
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -59,8 +59,10 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     c.a_lat = veh.max_lateral_accel; c.a_lon = veh.max_longitudinal_accel; c.sf = veh.safety_factor;
     c.geofence_tol = opt.geofence_tol;
     c.v_work = veh.max_work_speed_kmh; c.v_turn = veh.headland_turn_speed_kmh; c.v_head = veh.max_headland_speed_kmh;
-    c.sh_pi = make_cac_shape(kPi, opt.clothoid_frac);
-    c.sh_half = make_cac_shape(kHalfPi, opt.clothoid_frac);
+    const double vm = std::max(std::max(veh.max_work_speed_kmh, veh.max_headland_speed_kmh),
+                               std::max(veh.headland_turn_speed_kmh, 2.5)) / 3.6;
+    c.u_cap = vm * vm;
+    c.shapes = nullptr;
     return c;
 }
 
@@ -132,20 +134,24 @@ struct fcpp_batch {
     DevTiling til;
     DevBuf<int64_t> obs_off;
     DevBuf<double> obs_x, obs_y;
+    DevBuf<CacShape> shapes;   // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
     DevBuf<double> seg;        // connector segments
     DevBuf<int32_t> seg_mask;
     // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
     bool profiling = false;
     std::vector<hipEvent_t> events;   // kProfRuns x (kStages + 1)
     int prof_runs = 0;
+    int last_mode = 0;
     ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 
 namespace {
 constexpr int kStages = 7;
 constexpr int kProfRuns = 64;
-const char *const kStageNames[kStages] = { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine",
-                                            "k_scan_apply", "k_validate", "k_reduce_stats" };
+const char *const kStageNames[2][kStages] = {
+    { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine", "k_scan_apply", "k_validate", "k_reduce_stats" },
+    { "k_plan_fused", "k_reduce_stats", "", "", "", "", "" } };
+const int kStageCount[2] = { 7, 2 };
 }
 
 extern "C" {
@@ -283,13 +289,16 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     }
     b->cst = make_const(*veh, *opt);
     hipStream_t st = c->stream;
+    std::vector<CacShape> shp = { make_cac_shape(kPi, opt->clothoid_frac), make_cac_shape(kHalfPi, opt->clothoid_frac) };
     Tiling til;
     std::vector<int64_t> offs((size_t)n_fields + 1, 0);
     for (int64_t i = 0; i < n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
     til.build(n_fields, offs.data());
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
-    ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st));
+    ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st)) &&
+        ok(b->shapes.upload(shp, st));
+    b->cst.shapes = b->shapes.p;
     if (e == hipSuccess && n_polys > 0) {
         std::vector<int64_t> po(obstacles->offsets, obstacles->offsets + n_polys + 1);
         const int64_t nv = po.back();
@@ -332,7 +341,8 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
                    fcpp_field_stats *stats, int mode)
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
-    if (mode != 0) return fail(FCPP_EINVAL, "unknown pipeline mode");
+    if (mode != 0 && mode != 1) return fail(FCPP_EINVAL, "unknown pipeline mode");
+    if (mode != b->last_mode) { b->prof_runs = 0; b->last_mode = mode; }
     if (b->n_fields == 0) return FCPP_OK;
     if (b->hp.total_points > 0 && (!x || !y || !kappa || !v || !fs)) return fail(FCPP_EINVAL, "output pointer is NULL");
     if (!stats) return fail(FCPP_EINVAL, "stats pointer is NULL");
@@ -349,6 +359,12 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         if (ev) HIPCHK(hipEventRecord(ev[(k) + 1], st));   \
     } while (0)
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
+    if (mode == 1) {
+        STAGE(0, launch_plan_fused(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(1, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, nullptr, stats));
+        if (ev) ++b->prof_runs;
+        return FCPP_OK;
+    }
     STAGE(0, launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
     STAGE(1, launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
     STAGE(2, launch_scan_tiles(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, x, y, v, t.agg_f.p, t.agg_b.p));
@@ -379,24 +395,25 @@ int fcpp_batch_stage_times(fcpp_batch *b, int max_stages, double *ms_sum, int *n
     if (!b || !ms_sum || max_stages < kStages) return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(b->ctx->device));
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    const int ns = kStageCount[b->last_mode];
     for (int k = 0; k < kStages; ++k) ms_sum[k] = 0.0;
     for (int r = 0; r < b->prof_runs; ++r) {
         hipEvent_t *ev = &b->events[(size_t)r * (kStages + 1)];
-        for (int k = 0; k < kStages; ++k) {
+        for (int k = 0; k < ns; ++k) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
             ms_sum[k] += ms;
         }
     }
-    if (n_stages) *n_stages = kStages;
+    if (n_stages) *n_stages = ns;
     if (n_runs) *n_runs = b->prof_runs;
     b->prof_runs = 0;
     return FCPP_OK;
 }
 
-const char *fcpp_batch_stage_name(int stage)
+const char *fcpp_batch_stage_name(int mode, int stage)
 {
-    return (stage >= 0 && stage < kStages) ? kStageNames[stage] : "";
+    return (mode >= 0 && mode < 2 && stage >= 0 && stage < kStages) ? kStageNames[mode][stage] : "";
 }
 
 int fcpp_batch_connectors(fcpp_batch *b, double *approach_xy, double *departure_xy)

@@ -15,11 +15,13 @@ struct DevObstacles {                 // batch obstacle polygons, CSR, device po
     const double *x, *y;
 };
 
-// by-value kernel argument: scalars + the two clothoid-arc-clothoid unit shapes (180 and 90 degrees)
+// by-value kernel argument: scalars + pointer to the two clothoid-arc-clothoid unit shapes
+// (shapes[0]: 180 degrees, shapes[1]: 90 degrees; device memory, NULL for the standalone operators)
 struct DevConst {
     double a_lat, a_lon, sf, geofence_tol;
     double v_work, v_turn, v_head;
-    CacShape sh_pi, sh_half;
+    double u_cap;              // (max nominal speed / 3.6)^2: no sweep constraint can bind above this
+    const CacShape *shapes;
 };
 
 // every launcher returns 0 or a hipError_t value
@@ -40,6 +42,9 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
 int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats);
+int launch_plan_fused(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
+                      const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y,
+                      double *kappa, double *v, uint32_t *fs, TilePartial *partial);
 int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts, const int32_t *mask, double *out);
 int launch_fresnel(hipStream_t st, int64_t n, const double *t, double *c, double *s);
 int launch_ga_fitness(hipStream_t st, int n, int64_t pop, const double *D, const int32_t *routes, double *dist,

@@ -65,14 +65,6 @@ struct DevTile {
     int64_t start;       // first point of the tile inside the field's path
 };
 
-// scalar parameters every kernel needs
-struct DevParams {
-    double a_lat, a_lon, sf;   // max_lateral_accel, max_longitudinal_accel, safety_factor
-    double clothoid_frac;
-    double geofence_tol;
-    double u_cap;              // (max nominal speed / 3.6)^2: above this no sweep constraint can bind
-};
-
 // per-tile partial statistics (reduced per field in a fixed order => run-to-run identical sums)
 struct TilePartial {
     double main_len, main_time_pre, main_time, head_len, head_time_pre, head_time;

@@ -193,11 +193,12 @@ class Batch:
         stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
         return x, y, kappa, v, fs, stats
 
-    def run(self, buffers=None, mode=0):
+    def run(self, buffers=None, mode=1):
         """Enqueue the hot path on torch's current stream; returns a BatchResult (asynchronous)."""
         if buffers is None:
             buffers = self.alloc()
         x, y, kappa, v, fs, stats = buffers
+        self._last_mode = int(mode)
         self.ctx.bind_stream()
         L.check(self.lib.fcpp_batch_run(self.handle, _ptr(x), _ptr(y), _ptr(kappa), _ptr(v), _ptr(fs), _ptr(stats),
                                         int(mode)))
@@ -223,7 +224,7 @@ class Batch:
         ns, nr = C.c_int(), C.c_int()
         L.check(self.lib.fcpp_batch_stage_times(self.handle, 16, ms, C.byref(ns), C.byref(nr)))
         runs = max(nr.value, 1)
-        return {self.lib.fcpp_batch_stage_name(k).decode(): ms[k] / runs for k in range(ns.value)}, nr.value
+        return {self.lib.fcpp_batch_stage_name(self._last_mode, k).decode(): ms[k] / runs for k in range(ns.value)}, nr.value
 
     def close(self):
         if getattr(self, 'handle', None):

@@ -154,7 +154,9 @@ int fcpp_batch_info(const fcpp_batch *batch, fcpp_field_info *info_out /* n_fiel
 /* The hot path: sample every path point (MLP:720-830, 898-1084, 1154-1218, 1580-1608), curvature
  * (MLP:513-536), curvature clamp (MLP:467-511), forward/backward sweeps (MLP:538-589), validator
  * (MLP:1373-1424 + geofence / obstacle flags) and metrics (MLP:1290-1311).  Outputs are device
- * arrays of total_points elements; stats_dev has n_fields entries.  mode: 0 = default pipeline. */
+ * arrays of total_points elements; stats_dev has n_fields entries.
+ * mode 0: staged pipeline (one kernel per operator, 7 launches); mode 1: fused single-pass kernel
+ * (each point is written once, nothing is read back) -- same results. */
 int fcpp_batch_run(fcpp_batch *batch, double *x_dev, double *y_dev, double *kappa_dev, double *v_dev,
                    uint32_t *flagseg_dev, fcpp_field_stats *stats_dev, int mode);
 /* _generate_approach_path / _generate_departure_path (MLP:1313-1355): 50 points each, AoS (x,y) per
@@ -167,7 +169,7 @@ int fcpp_batch_destroy(fcpp_batch *batch);
  * runs and clears the record. */
 int fcpp_batch_set_profiling(fcpp_batch *batch, int enable);
 int fcpp_batch_stage_times(fcpp_batch *batch, int max_stages, double *ms_sum_out, int *n_stages_out, int *n_runs_out);
-const char *fcpp_batch_stage_name(int stage);
+const char *fcpp_batch_stage_name(int mode, int stage);
 
 /* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) ------- */
 /* _calculate_curvature for every interior point (MLP:513-536); end points get 0 */

@@ -35,8 +35,10 @@ def test_native_library_is_loaded():
     assert 'libfcpp.so' in maps
 
 
-def test_batch_vs_golden_plans(golden_plans):
-    """All golden scenarios sharing a vehicle are planned as ONE batch; every array is compared."""
+@pytest.mark.parametrize('mode', [1, 0])
+def test_batch_vs_golden_plans(golden_plans, mode):
+    """All golden scenarios sharing a vehicle are planned as ONE batch; every array is compared.
+    mode 1 = fused single-pass kernel, mode 0 = staged pipeline."""
     g = golden_plans
     groups = {}
     for name in g['names']:
@@ -44,7 +46,7 @@ def test_batch_vs_golden_plans(golden_plans):
     for vp, names in groups.items():
         specs = [_specs_from_golden(g, n) for n in names]
         batch = E.Batch(specs, _veh(vp))
-        res = batch.run()
+        res = batch.run(mode=mode)
         ap, dp = batch.connectors()
         x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
         st = res.stats()
@@ -81,9 +83,14 @@ def test_batch_vs_golden_plans(golden_plans):
 
 
 def _compare_with_oracle(specs, ofields, veh_arr, opt_kw, xy_tol=XY_TOL, k_tol=K_TOL, v_tol=V_TOL):
+    for mode in (1, 0):     # 1 = fused single-pass kernel (default), 0 = staged pipeline
+        _compare_with_oracle_mode(mode, specs, ofields, veh_arr, opt_kw, xy_tol, k_tol, v_tol)
+
+
+def _compare_with_oracle_mode(mode, specs, ofields, veh_arr, opt_kw, xy_tol, k_tol, v_tol):
     o = E.make_options(**opt_kw)
     batch = E.Batch(specs, _veh(veh_arr), o)
-    res = batch.run()
+    res = batch.run(mode=mode)
     x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
     st = res.stats()
     oopt = orc.Options.make(o.turn_model, o.clothoid_fit, o.sample_spacing, o.clothoid_frac, o.geofence_tol)
