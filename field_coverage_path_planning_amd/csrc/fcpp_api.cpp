@@ -62,6 +62,7 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     const double vm = std::max(std::max(veh.max_work_speed_kmh, veh.max_headland_speed_kmh),
                                std::max(veh.headland_turn_speed_kmh, 2.5)) / 3.6;
     c.u_cap = vm * vm;
+    c.ms_work = c.v_work / 3.6; c.ms_turn = c.v_turn / 3.6; c.ms_head = c.v_head / 3.6; c.ms_rev = 2.5 / 3.6;
     c.shapes = nullptr;
     return c;
 }
@@ -71,7 +72,8 @@ struct Tiling {
     std::vector<DevPath> paths;
     std::vector<DevTile> tiles;
     std::vector<int64_t> tile_first;
-    void build(int64_t n_paths, const int64_t *offsets)
+    // per (optional): points per pass (n_line + n_turn) of each field, for the fused kernel's layer-1 decode
+    void build(int64_t n_paths, const int64_t *offsets, const int64_t *per = nullptr)
     {
         paths.resize((size_t)n_paths);
         tile_first.assign((size_t)n_paths + 1, 0);
@@ -83,6 +85,8 @@ struct Tiling {
             for (int64_t s = 0; s < n; s += TILE_POINTS) {
                 DevTile t;
                 t.field = (int32_t)p; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, n - s);
+                t.idx0 = 0; t.off0 = 0;
+                if (per && per[p] > 0) { t.idx0 = (int32_t)(s / per[p]); t.off0 = (int32_t)(s % per[p]); }
                 tiles.push_back(t);
             }
         }
@@ -293,7 +297,9 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     Tiling til;
     std::vector<int64_t> offs((size_t)n_fields + 1, 0);
     for (int64_t i = 0; i < n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
-    til.build(n_fields, offs.data());
+    std::vector<int64_t> per((size_t)n_fields, 0);
+    for (int64_t i = 0; i < n_fields; ++i) per[(size_t)i] = (int64_t)b->hp.fields[(size_t)i].n_line + b->hp.fields[(size_t)i].n_turn;
+    til.build(n_fields, offs.data(), per.data());
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
     ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st)) &&

@@ -215,4 +215,25 @@ __device__ __forceinline__ double nominal_speed(uint32_t fs, const DevConst &c)
     }
 }
 
+// out-of-line variants for the rare cases of the fused kernel (turn points, primitive boundaries):
+// keeping them out of the unrolled per-item loops is what keeps that kernel's register budget sane
+__device__ __noinline__ GenOut gen_point_slow(const DevField *f, const DevPrim *prims, int64_t i, const DevConst *cst)
+{
+    GenOut o;
+    gen_point(*f, prims, i, *cst, o);
+    return o;
+}
+
+__device__ __noinline__ double atan2_slow(double y, double x) { return atan2(y, x); }
+
+__device__ __forceinline__ double nominal_ms(uint32_t fs, const DevConst &c)
+{
+    switch (fs & FCPP_KIND_MASK) {
+        case FCPP_KIND_SWATH: return c.ms_work;
+        case FCPP_KIND_UTURN: case FCPP_KIND_CORNER: return c.ms_turn;
+        case FCPP_KIND_REVERSE: return c.ms_rev;
+        default: return c.ms_head;
+    }
+}
+
 }  // namespace fcpp

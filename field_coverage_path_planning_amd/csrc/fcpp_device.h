@@ -21,6 +21,7 @@ struct DevConst {
     double a_lat, a_lon, sf, geofence_tol;
     double v_work, v_turn, v_head;
     double u_cap;              // (max nominal speed / 3.6)^2: no sweep constraint can bind above this
+    double ms_work, ms_turn, ms_head, ms_rev;   // the four nominal speeds in m/s (v / 3.6, IEEE division on the host)
     const CacShape *shapes;
 };
 

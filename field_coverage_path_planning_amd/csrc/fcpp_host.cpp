@@ -248,7 +248,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         const int64_t P = (int64_t)((max_y - min_y) / W) + 1;
         const int64_t n_line = ds > 0 ? n_for_length(fabs(lex - lsx), ds) : 2;
         const int64_t n_turn = ds > 0 ? n_for_length(len_uturn, ds) : 20;
-        if (P > INT32_MAX || n_line > INT32_MAX || n_turn > INT32_MAX) { fail(FCPP_ESIZE); continue; }
+        if (P > INT32_MAX || n_line + n_turn > INT32_MAX - 2 * TILE_POINTS) { fail(FCPP_ESIZE); continue; }
         in.n_swaths = (int32_t)P;
         const int64_t n_main = P * n_line + (P - 1) * n_turn;
         in.n_main = n_main;
@@ -378,6 +378,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
             for (int64_t s = 0; s < pos; s += TILE_POINTS) {
                 DevTile t;
                 t.field = (int32_t)fi; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, pos - s);
+                t.idx0 = 0; t.off0 = 0;
                 out.tiles.push_back(t);
             }
         }

@@ -63,6 +63,7 @@ struct DevTile {
     int32_t field;
     int32_t count;       // <= TILE_POINTS
     int64_t start;       // first point of the tile inside the field's path
+    int32_t idx0, off0;  // layer 1 only: pass position idx and offset inside the pass of `start` (start = idx0*per + off0)
 };
 
 // per-tile partial statistics (reduced per field in a fixed order => run-to-run identical sums)
