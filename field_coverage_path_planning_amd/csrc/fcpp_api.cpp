@@ -347,6 +347,9 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
                    fcpp_field_stats *stats, int mode)
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
+    // modes 12/13/14: the fused kernel compiled for a minimum of 2/3/4 waves per SIMD (tuning only)
+    int variant = 3;
+    if (mode >= 12 && mode <= 14) { variant = mode - 10; mode = 1; }
     if (mode != 0 && mode != 1) return fail(FCPP_EINVAL, "unknown pipeline mode");
     if (mode != b->last_mode) { b->prof_runs = 0; b->last_mode = mode; }
     if (b->n_fields == 0) return FCPP_OK;
@@ -366,7 +369,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     } while (0)
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (mode == 1) {
-        STAGE(0, launch_plan_fused(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(0, launch_plan_fused(st, variant, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         STAGE(1, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, nullptr, stats));
         if (ev) ++b->prof_runs;
         return FCPP_OK;

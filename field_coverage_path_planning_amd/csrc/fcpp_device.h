@@ -43,7 +43,7 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
 int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats);
-int launch_plan_fused(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
+int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
                       const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y,
                       double *kappa, double *v, uint32_t *fs, TilePartial *partial);
 int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts, const int32_t *mask, double *out);

@@ -241,7 +241,8 @@ __device__ __forceinline__ long long wave_sum_i(int v)
     return v;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_plan_fused(const DevTile *__restrict__ tiles,
+template <int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__restrict__ tiles,
                                                       const DevField *__restrict__ fields,
                                                       const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                       double *__restrict__ xo, double *__restrict__ yo,
@@ -578,13 +579,21 @@ __global__ __launch_bounds__(BLOCK) void k_plan_fused(const DevTile *__restrict_
     }
 }
 
-int launch_plan_fused(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
+int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
                       const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y,
                       double *kappa, double *v, uint32_t *fs, TilePartial *partial)
 {
     if (n_tiles <= 0) return 0;
-    hipLaunchKernelGGL(k_plan_fused, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
-                       kappa, v, fs, partial);
+    // variant = register budget: minimum waves per SIMD the compiler must allow (3 -> <=168 VGPRs, 4 -> <=128, 2 -> <=256)
+    if (variant == 4)
+        hipLaunchKernelGGL(k_plan_fused<4>, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+                           kappa, v, fs, partial);
+    else if (variant == 2)
+        hipLaunchKernelGGL(k_plan_fused<2>, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+                           kappa, v, fs, partial);
+    else
+        hipLaunchKernelGGL(k_plan_fused<3>, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+                           kappa, v, fs, partial);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -82,21 +82,37 @@ FCPP_HD void fresnel_cs(double t, double &C, double &S)
     C = c; S = s;
 }
 
+// the Maclaurin branch alone: valid for |t| <= 1.6.  Turn shapes only ever need |t| <= sqrt(f*D/pi) <= 1.
+FCPP_HD void fresnel_series(double t, double &C, double &S)
+{
+    const double t2 = t * t, z = t2 * t2;
+    double pc = detail::kCser[FCPP_FRESNEL_NSER - 1], ps = detail::kSser[FCPP_FRESNEL_NSER - 1];
+#pragma unroll
+    for (int i = FCPP_FRESNEL_NSER - 2; i >= 0; --i) {
+        pc = fma(pc, z, detail::kCser[i]);
+        ps = fma(ps, z, detail::kSser[i]);
+    }
+    C = t * pc;
+    S = t * t2 * ps;
+}
+
 FCPP_HD void cac_unit_point(const CacShape &sh, double u, double &X, double &Y)
 {
     if (u < 0) u = 0;
     if (u > sh.T) u = sh.T;
-    if (sh.Lc > 0 && u <= sh.Lc) {
-        double c, s;
-        fresnel_cs(u / sh.a, c, s);
-        X = sh.a * c; Y = sh.a * s;
-    } else if (u <= sh.Lc + sh.La || sh.Lc == 0) {
+    // entry clothoid (u <= Lc) and exit clothoid (mirrored) share ONE Fresnel evaluation
+    const bool entry = sh.Lc > 0 && u <= sh.Lc;
+    const bool arc = !entry && (u <= sh.Lc + sh.La || sh.Lc == 0);
+    if (arc) {
         const double th = sh.th1 + (u - sh.Lc);
         X = sh.cx + sin(th); Y = sh.cy - cos(th);
-    } else {
-        double c, s;
-        fresnel_cs((sh.T - u) / sh.a, c, s);
-        const double qx = sh.a * c, qy = sh.a * s;
+        return;
+    }
+    double c, s;
+    fresnel_series((entry ? u : (sh.T - u)) / sh.a, c, s);
+    const double qx = sh.a * c, qy = sh.a * s;
+    if (entry) { X = qx; Y = qy; }
+    else {
         X = sh.ex - (sh.cosD * qx + sh.sinD * qy);
         Y = sh.ey - (sh.sinD * qx - sh.cosD * qy);
     }
