@@ -63,7 +63,7 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
                                std::max(veh.headland_turn_speed_kmh, 2.5)) / 3.6;
     c.u_cap = vm * vm;
     c.ms_work = c.v_work / 3.6; c.ms_turn = c.v_turn / 3.6; c.ms_head = c.v_head / 3.6; c.ms_rev = 2.5 / 3.6;
-    c.shapes = nullptr;
+    c.shapes = nullptr; c.tmpl_u = nullptr; c.tmpl_c = nullptr;
     return c;
 }
 
@@ -139,6 +139,7 @@ struct fcpp_batch {
     DevBuf<int64_t> obs_off;
     DevBuf<double> obs_x, obs_y;
     DevBuf<CacShape> shapes;   // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
+    DevBuf<double2> tmpl_u, tmpl_c;   // sampled turn templates (fcpp_fused.hip)
     DevBuf<double> seg;        // connector segments
     DevBuf<int32_t> seg_mask;
     // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
@@ -305,6 +306,14 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st)) &&
         ok(b->shapes.upload(shp, st));
     b->cst.shapes = b->shapes.p;
+    if (e == hipSuccess) {
+        ok(b->tmpl_u.alloc((size_t)b->hp.tt.nu)) && ok(b->tmpl_c.alloc((size_t)b->hp.tt.nc));
+        if (e == hipSuccess) {
+            int le = launch_build_templates(st, b->hp.tt, b->shapes.p, b->tmpl_u.p, b->tmpl_c.p);
+            if (le != 0) e = (hipError_t)le;
+        }
+        b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p;
+    }
     if (e == hipSuccess && n_polys > 0) {
         std::vector<int64_t> po(obstacles->offsets, obstacles->offsets + n_polys + 1);
         const int64_t nv = po.back();

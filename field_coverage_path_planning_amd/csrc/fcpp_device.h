@@ -1,6 +1,7 @@
 // fcpp_device.h -- interface between the C-ABI glue (fcpp_api.cpp) and the kernels (fcpp_kernels.hip)
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 #include <stdint.h>
 
 #include "fcpp_geom.h"
@@ -23,6 +24,7 @@ struct DevConst {
     double u_cap;              // (max nominal speed / 3.6)^2: no sweep constraint can bind above this
     double ms_work, ms_turn, ms_head, ms_rev;   // the four nominal speeds in m/s (v / 3.6, IEEE division on the host)
     const CacShape *shapes;
+    const double2 *tmpl_u, *tmpl_c;   // turn templates of the batch (fused kernel), see TurnTemplates
 };
 
 // every launcher returns 0 or a hipError_t value
@@ -43,6 +45,7 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
 int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats);
+int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc);
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
                       const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y,
                       double *kappa, double *v, uint32_t *fs, TilePartial *partial);

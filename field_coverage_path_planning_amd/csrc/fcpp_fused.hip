@@ -1,19 +1,26 @@
 // fcpp_fused.hip -- pipeline B: the whole hot path in ONE pass over HBM (36 B written per point, nothing read
-// back): generate -> curvature -> clamp -> forward/backward sweeps -> validate -> metrics.
+// back): generate -> curvature -> geofence -> clamp -> forward/backward sweeps -> a_lat check -> metrics.
 //
 // Work decomposition (gfx950: 64-wide waves, 256 CUs): one 256-thread workgroup per 2048-point tile of one
 // field's path; thread t owns the 8 CONSECUTIVE points 8t..8t+7, so
 //   * the 3-point curvature stencil and the segment lengths live in registers; only the two end
-//     neighbours of a thread come from the adjacent lane (DPP shuffle) or, at wave edges, from 64 bytes of LDS;
+//     neighbours of a thread come from the adjacent lane (shuffle) or, at wave edges, from 64 bytes of LDS;
 //   * the min-plus scans of the sweeps run over registers: 8 serial steps per thread, one 6-step wave scan
 //     of the per-thread maps, 4 wave aggregates through LDS;
 //   * results are transposed through a 4.5 KB per-wave LDS buffer so that every global store instruction
 //     writes 512 contiguous bytes per wave (SoA arrays, coalesced).
+//
+// Turn geometry comes from two small per-batch TEMPLATES (k_build_templates, run once at batch creation): every
+// U-turn of a batch is a translate/mirror of one sampled shape and every corner turn a quadrant rotation of
+// another, so the kernel never evaluates sincos or Fresnel series: a turn point is one 16-byte load and two adds,
+// bit-identical to the direct formula.
+//
 // No workgroup ever waits for another one: what the sweeps need from outside the tile is RECOMPUTED.
 // A constraint at point j can only bind at point i while u0_j + 2a*dist(i,j) < u_cap = (v_max/3.6)^2, i.e.
-// within u_cap/(2a) metres (5.8 m for the default vehicle), so wave 0 re-generates 64-point chunks before the
-// tile (and wave 3 after it) until the accumulated 2a*distance exceeds u_cap or the path ends; usually one
-// chunk.  The recomputation is exact (same arithmetic as the owning tile), so results do not depend on tiling.
+// within u_cap/(2a) metres (5.8 m for the default vehicle).  If that stretch next to the tile is one straight
+// primitive the carried value is its nominal u0 (closed form); otherwise wave 0 (wave 3) re-generates 64-point
+// chunks before (after) the tile until the accumulated 2a*distance exceeds u_cap or the path ends.  The
+// recomputation uses the same arithmetic as the owning tile, so results do not depend on the tiling.
 #include "fcpp_devfn.h"
 
 namespace fcpp {
@@ -21,7 +28,8 @@ namespace fcpp {
 struct HaloInfo {
     double px, py;       // the neighbouring path point (index s-1 or s+count)
     double carry;        // value the forward (backward) sweep carries into the tile; +inf if none
-    double kappa, v0, vnom, u0;
+    double kappa, v0, u0;
+    uint32_t fs;
     int valid;
 };
 
@@ -72,94 +80,147 @@ __device__ __forceinline__ double clamped_speed(double v_nom, double kappa, cons
     return v_nom;
 }
 
-__device__ __forceinline__ double clamp_speed(double v, double kappa, const DevConst &cst, int &adj)
+// sqrt(fl(t*t)) == |t| exactly in IEEE arithmetic: axis-aligned steps need no square root
+__device__ __forceinline__ double seg_len(double dx, double dy)
 {
-    bool cl;
-    const double r = clamped_speed(v, kappa, cst, cl);
-    adj += cl ? 1 : 0;
-    return r;
+    return (dy == 0.0) ? fabs(dx) : ((dx == 0.0) ? fabs(dy) : sqrt(dx * dx + dy * dy));
 }
 
-// Straight-primitive lookup shared by the fast paths: is the index range [i_lo, i_hi] (inclusive) inside ONE
-// straight primitive (a swath line or a headland straight)?  Returns its linspace description.
-struct StraightRun {
-    double ax, ay, bx, by, sx, sy;   // start, stop, step of numpy.linspace (x and y)
-    int64_t r0, n;                   // position of i_lo inside the primitive, samples of the primitive
-    uint32_t fs;
-    bool rot;
-};
-
-__device__ __forceinline__ bool find_straight(const DevField &f, const DevPrim *__restrict__ prims, int64_t i_lo,
-                                              int64_t i_hi, StraightRun &o)
+// ---- template-based point evaluation ---------------------------------------------------------------------
+__device__ __forceinline__ void rotate_back(const DevField &f, double &px, double &py)   // MLP:271-282, angle = +rotation
 {
-    if (i_lo < 0 || i_hi >= f.n_total) return false;
-    if (i_hi < f.n_main) {
-        const int64_t per = (int64_t)f.n_line + f.n_turn;
-        const int64_t idx = i_lo / per;
-        o.r0 = i_lo - idx * per;
-        if (o.r0 + (i_hi - i_lo) >= f.n_line) return false;
-        const int64_t pi = f.reverse_order ? (f.P - 1 - idx) : idx;
-        const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
-        o.ax = go_left ? f.lex : f.lsx; o.bx = go_left ? f.lsx : f.lex; o.sx = go_left ? -f.line_step : f.line_step;
-        o.ay = o.by = f.min_y + (double)pi * f.W; o.sy = 0.0;
-        o.n = f.n_line; o.rot = f.rotated != 0;
-        o.fs = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
-        return true;
+    const double tx = px - f.rot_cx, ty = py - f.rot_cy;
+    px = (tx * f.rot_cos - ty * f.rot_sin) + f.rot_cx;
+    py = (tx * f.rot_sin + ty * f.rot_cos) + f.rot_cy;
+}
+
+// layer 1 (MLP:750-780): pass position idx, offset off inside the pass
+__device__ __forceinline__ void eval_main(const DevField &f, const DevConst &cst, int idx, int off, double &px, double &py,
+                                          uint32_t &fw)
+{
+    const int pi = f.reverse_order ? (f.P - 1 - idx) : idx;
+    const double y = f.min_y + (double)pi * f.W;
+    const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+    if (off < f.n_line) {
+        px = go_left ? linspace_at(f.lex, f.lsx, -f.line_step, f.n_line, off) : linspace_at(f.lsx, f.lex, f.line_step, f.n_line, off);
+        py = y;
+        fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+    } else {
+        const double2 t = cst.tmpl_u[off - f.n_line];
+        const bool turn_right = !go_left;                              // MLP:776
+        if (f.turn_model == FCPP_TURN_ARC) px = turn_right ? (f.max_x - t.x) : (f.min_x + t.x);   // MLP:815, 822
+        else px = turn_right ? ((f.max_x - f.R) + t.x) : ((f.min_x + f.R) - t.x);
+        py = y + t.y;
+        fw = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
     }
-    if (i_lo < f.n_main) return false;
+    if (f.rotated) rotate_back(f, px, py);
+}
+
+// layer 2 (MLP:943-1084): sample r of primitive p
+__device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst, int r, double &px, double &py)
+{
+    if (p.kind == PRIM_LINSPACE) {
+        px = linspace_at(p.a[0], p.a[2], p.a[4], p.n, r);
+        py = linspace_at(p.a[1], p.a[3], p.a[5], p.n, r);
+    } else if (p.kind == PRIM_POINT) { px = p.a[0]; py = p.a[1]; }
+    else if (p.kind == PRIM_RAY) {
+        const double t = linspace_at(0.0, p.a[4], p.a[5], p.n, r);
+        px = p.a[0] + t * p.a[2];
+        py = p.a[1] + t * p.a[3];
+    } else {   // corner turn: quadrant formulas MLP:1049-1060 on the template (t1, t2) = (R(1-cos), R sin) or its clothoid analogue
+        const double2 t = cst.tmpl_c[r];
+        const int ci = p.kind == PRIM_ARC ? p.form : ((p.form + 3) & 3);
+        if (ci == 0)      { px = p.a[0] + t.x; py = p.a[1] + t.y; }
+        else if (ci == 1) { px = p.a[0] - t.y; py = p.a[1] + t.x; }
+        else if (ci == 2) { px = p.a[0] - t.x; py = p.a[1] - t.y; }
+        else              { px = p.a[0] + t.y; py = p.a[1] - t.x; }
+    }
+}
+
+__device__ __forceinline__ int find_prim(const DevField &f, const DevPrim *__restrict__ prims, int64_t i)
+{
     int a = f.prim_first, b = f.prim_first + f.prim_count - 1;
     while (a < b) {
         const int m = (a + b + 1) >> 1;
-        if (prims[m].start <= i_lo) a = m; else b = m - 1;
+        if (prims[m].start <= i) a = m; else b = m - 1;
     }
-    const DevPrim &p = prims[a];
-    o.r0 = i_lo - p.start;
-    if (p.kind != PRIM_LINSPACE || o.r0 + (i_hi - i_lo) >= p.n) return false;
-    o.ax = p.a[0]; o.bx = p.a[2]; o.sx = p.a[4]; o.ay = p.a[1]; o.by = p.a[3]; o.sy = p.a[5];
-    o.n = p.n; o.fs = p.fs; o.rot = false;
-    return true;
+    return a;
 }
 
-__device__ __forceinline__ void straight_point(const DevField &f, const StraightRun &r, int64_t rk, double &px, double &py)
+// random access (halo recomputation only): point i of the field's path
+__device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const DevPrim *prims, const DevConst *cst, int64_t i)
 {
-    px = (double)rk * r.sx + r.ax; py = (double)rk * r.sy + r.ay;     // numpy.linspace: k*step + start
-    if (rk == r.n - 1) { px = r.bx; py = r.by; }                       // ... and the last sample is `stop`
-    if (r.rot) {
-        const double tx = px - f.rot_cx, ty = py - f.rot_cy;
-        px = (tx * f.rot_cos - ty * f.rot_sin) + f.rot_cx;
-        py = (tx * f.rot_sin + ty * f.rot_cos) + f.rot_cy;
+    GenOut o;
+    o.v = 0;
+    if (i < f->n_main) {
+        const int64_t per = (int64_t)f->n_line + f->n_turn;
+        const int64_t idx = i / per;
+        eval_main(*f, *cst, (int)idx, (int)(i - idx * per), o.x, o.y, o.fs);
+    } else {
+        const DevPrim &p = prims[find_prim(*f, prims, i)];
+        eval_prim(p, *cst, (int)(i - p.start), o.x, o.y);
+        o.fs = p.fs;
     }
+    return o;
 }
 
-// One wave recomputes what the sweeps carry across the tile edge (see the header comment).
+// One wave computes what the sweeps carry across the tile edge (see the header comment).
 template <bool BACK>
-__device__ void halo_wave(const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
+__device__ void halo_wave(const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst, const DevTile &tl,
                           int64_t edge, HaloInfo *out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = f.n_total;
     const double two_a = 2 * cst.a_lon;
     if (BACK ? (edge <= 0) : (edge >= n)) {
-        if (lane == 0) { out->valid = 0; out->carry = FCPP_INF; out->px = out->py = 0; out->kappa = out->v0 = out->vnom = out->u0 = 0; }
+        if (lane == 0) { out->valid = 0; out->carry = FCPP_INF; out->px = out->py = 0; out->kappa = out->v0 = out->u0 = 0; out->fs = 0; }
         return;
     }
-    // Fast case (most tiles at fine sampling): the point next to the edge lies on a straight primitive that extends at
-    // least u_cap / (2a) metres away from the tile.  Every point on that stretch has curvature 0 and the same u0, and
-    // nothing farther away can bind, so the carried value is that u0 and no point needs generating.
+    // Fast case: the point next to the edge lies on a straight primitive that extends at least u_cap / (2a) metres
+    // away from the tile.  Every point on that stretch has curvature 0 and the same u0, and nothing farther away can
+    // bind, so the carried value is that u0 and no point needs generating.
     {
-        StraightRun r;
-        if (BACK ? find_straight(f, prims, edge - 2, edge - 1, r) : find_straight(f, prims, edge, edge + 1, r)) {
-            const double step_len = sqrt(r.sx * r.sx + r.sy * r.sy);
+        const int64_t nb = BACK ? edge - 1 : edge;      // the neighbouring point
+        double ax = 0, ay = 0, bx = 0, by = 0, sx = 0, sy = 0;
+        int pos = -1, np = 0;
+        uint32_t fw = 0;
+        bool rot = false;
+        if (nb < f.n_main) {
+            if (tl.start < f.n_main) {
+                const int per = f.n_line + f.n_turn;
+                int off = tl.off0 + (int)(nb - tl.start), idx = tl.idx0;
+                if (off >= 0) {
+                    if (off >= per) { const int q = off / per; off -= q * per; idx += q; }
+                    if (off < f.n_line) {
+                        const int pi = f.reverse_order ? (f.P - 1 - idx) : idx;
+                        const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+                        ax = go_left ? f.lex : f.lsx; bx = go_left ? f.lsx : f.lex; sx = go_left ? -f.line_step : f.line_step;
+                        ay = by = f.min_y + (double)pi * f.W; sy = 0.0;
+                        pos = off; np = f.n_line; rot = f.rotated != 0;
+                        fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+                    }
+                }
+            }
+        } else {
+            const DevPrim &p = prims[find_prim(f, prims, nb)];
+            if (p.kind == PRIM_LINSPACE) {
+                ax = p.a[0]; bx = p.a[2]; sx = p.a[4]; ay = p.a[1]; by = p.a[3]; sy = p.a[5];
+                pos = (int)(nb - p.start); np = p.n; fw = p.fs;
+            }
+        }
+        if (pos >= 0) {
+            const double step_len = sqrt(sx * sx + sy * sy);
             if (step_len >= 1e-6) {
-                const int64_t need = (int64_t)(cst.u_cap / (two_a * step_len)) + 3;
-                const int64_t pos = BACK ? r.r0 + 1 : r.r0;   // position of the neighbouring point in the primitive
-                if (BACK ? (pos - need >= 0) : (pos + need <= r.n - 1)) {
+                const double needd = cst.u_cap / (two_a * step_len) + 3.0;
+                const bool ok = BACK ? ((double)pos - needd >= 0.0) : ((double)pos + needd <= (double)(np - 1));
+                if (ok) {
                     if (lane == 0) {
-                        const double ms = nominal_ms(r.fs, cst);
-                        double px, py;
-                        straight_point(f, r, pos, px, py);
-                        out->valid = 1; out->px = px; out->py = py; out->kappa = 0.0;
-                        out->v0 = out->vnom = nominal_speed(r.fs, cst); out->u0 = ms * ms; out->carry = ms * ms;
+                        const double ms = nominal_ms(fw, cst);
+                        double px = (double)pos * sx + ax, py = (double)pos * sy + ay;
+                        if (pos == np - 1) { px = bx; py = by; }
+                        if (rot) rotate_back(f, px, py);
+                        out->valid = 1; out->px = px; out->py = py; out->kappa = 0.0; out->fs = fw;
+                        out->v0 = nominal_speed(fw, cst); out->u0 = ms * ms; out->carry = ms * ms;
                     }
                     return;
                 }
@@ -173,21 +234,21 @@ __device__ void halo_wave(const DevField &f, const DevPrim *__restrict__ prims, 
         const int64_t i = b + lane;
         const bool act = i >= 0 && i < n;
         GenOut g; g.x = g.y = g.v = 0; g.fs = 0;
-        if (act) g = gen_point_slow(&f, prims, i, &cst);
+        if (act) g = gen_point_tmpl(&f, prims, &cst, i);
         double xm = __shfl_up(g.x, 1), ym = __shfl_up(g.y, 1), xp = __shfl_down(g.x, 1), yp = __shfl_down(g.y, 1);
         const int64_t ei = lane == 0 ? i - 1 : i + 1;
         if ((lane == 0 || lane == 63) && ei >= 0 && ei < n) {   // the chunk's two outer neighbours
-            const GenOut e = gen_point_slow(&f, prims, ei, &cst);
+            const GenOut e = gen_point_tmpl(&f, prims, &cst, ei);
             if (lane == 0) { xm = e.x; ym = e.y; } else { xp = e.x; yp = e.y; }
         }
         double kappa = 0, dprev = 0, dnext = 0;
         const double dx1 = g.x - xm, dy1 = g.y - ym, dx2 = xp - g.x, dy2 = yp - g.y;
-        if (act && i > 0) dprev = sqrt(dx1 * dx1 + dy1 * dy1);
-        if (act && i < n - 1) dnext = sqrt(dx2 * dx2 + dy2 * dy2);
+        if (act && i > 0) dprev = seg_len(dx1, dy1);
+        if (act && i < n - 1) dnext = seg_len(dx2, dy2);
         if (act && i > 0 && i < n - 1) kappa = curv_chords(dx1, dy1, dprev, dx2, dy2, dnext);
-        int adj = 0;
-        const double v0 = clamp_speed(g.v, kappa, cst, adj);
-        const double ms = v0 / 3.6;
+        bool cl;
+        const double v0 = clamped_speed(nominal_speed(g.fs, cst), kappa, cst, cl);
+        const double ms = cl ? v0 / 3.6 : nominal_ms(g.fs, cst);
         Agg me;
         me.c = act ? ms * ms : FCPP_INF;
         if (BACK) me.w = !act ? 0.0 : ((i == 0 || dprev < 1e-6) ? FCPP_INF : two_a * dprev);
@@ -207,7 +268,7 @@ __device__ void halo_wave(const DevField &f, const DevPrim *__restrict__ prims, 
         Agg chunk = { __shfl(inc.c, src), __shfl(inc.w, src) };
         total = first ? chunk : combine_after(chunk, total);   // the farther chunk acts first
         if (first && lane == src) {
-            out->valid = 1; out->px = g.x; out->py = g.y; out->kappa = kappa; out->v0 = v0; out->vnom = g.v; out->u0 = me.c;
+            out->valid = 1; out->px = g.x; out->py = g.y; out->kappa = kappa; out->v0 = v0; out->fs = g.fs; out->u0 = me.c;
         }
         first = false;
         const bool done = (total.w >= cst.u_cap) || (BACK ? (b <= 0) : (b + 64 >= n));
@@ -243,11 +304,11 @@ __device__ __forceinline__ long long wave_sum_i(int v)
 
 template <int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__restrict__ tiles,
-                                                      const DevField *__restrict__ fields,
-                                                      const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
-                                                      double *__restrict__ xo, double *__restrict__ yo,
-                                                      double *__restrict__ ko, double *__restrict__ vo,
-                                                      uint32_t *__restrict__ fso, TilePartial *__restrict__ partial)
+                                                            const DevField *__restrict__ fields,
+                                                            const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
+                                                            double *__restrict__ xo, double *__restrict__ yo,
+                                                            double *__restrict__ ko, double *__restrict__ vo,
+                                                            uint32_t *__restrict__ fso, TilePartial *__restrict__ partial)
 {
     __shared__ FusedShared S;
     const DevTile tl = tiles[blockIdx.x];
@@ -257,8 +318,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     const int cnt = tl.count;
     const double two_a = 2 * cst.a_lon;
 
-    if (wave == 0) halo_wave<true>(f, prims, cst, s, &S.back);
-    else if (wave == NWAVE - 1) halo_wave<false>(f, prims, cst, s + cnt, &S.fwd);
+    if (wave == 0) halo_wave<true>(f, prims, cst, tl, s, &S.back);
+    else if (wave == NWAVE - 1) halo_wave<false>(f, prims, cst, tl, s + cnt, &S.fwd);
 
     // ---- 0. where this thread's run sits relative to the path's special indices (small ints from here on) ----
     const int j0 = tid * IPT;
@@ -268,43 +329,60 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     const int64_t rem_end = (n - 1) - i0, rem_seam = f.n_main - i0;
     const int k_end = (rem_end >= 0 && rem_end < IPT) ? (int)rem_end : 1000;     // item that is the path's last point
     const int k_seam = rem_seam < 0 ? -1 : (rem_seam >= IPT ? 1000 : (int)rem_seam);  // item with index n_main (first of layer 2)
+    double *buf = S.tr[wave];
+    const int64_t g0 = f.pt_off + s + wave * (64 * IPT);
+    const int cw = min(max(cnt - wave * (64 * IPT), 0), 64 * IPT);
+    // coalesced SoA store of one per-item array through the per-wave transposition buffer
+    auto put = [&](double *__restrict__ dst, const double *vals) {
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) buf[lidx(lane * IPT + k)] = vals[k];
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < IPT; ++m) {
+            const int p = lane + 64 * m;
+            if (p < cw) dst[g0 + p] = buf[lidx(p)];
+        }
+        wave_sync();
+    };
 
     // ---- 1. generate this thread's 8 consecutive points -------------------------------------------
-    // Fast path: the whole run lies on one straight primitive (a swath line or a headland straight), which is
-    // the case for ~95 % of the threads at fine sampling: 8 x (cvt, mul, add).  Everything else -- turn points,
-    // primitive boundaries, partial tiles -- goes through the out-of-line generic generator.
+    // Position of the first item: layer 1 = (pass idx, offset in the pass) from the tile's host-precomputed decode,
+    // layer 2 = (primitive, offset) by binary search.  Fast path: the whole run lies on one straight primitive
+    // (~95 % of the threads at fine sampling): 8 x (cvt, mul, add).  Otherwise a cursor walks the run item by item
+    // through whatever primitives it crosses (line -> turn -> line ..).
     double X[IPT + 2], Y[IPT + 2];
     uint32_t fs[IPT];
+    const bool in_main0 = k_seam > 0;            // item 0 belongs to layer 1
+    const int per = f.n_line + f.n_turn;
+    int c_idx = 0, c_off = 0, c_a = f.prim_first, c_r = 0;
+    if (in_main0) {
+        c_off = tl.off0 + j0; c_idx = tl.idx0;
+        if (c_off >= per) { const int q = c_off / per; c_off -= q * per; c_idx += q; }
+    } else if (nvalid > 0) {
+        c_a = find_prim(f, prims, i0);
+        c_r = (int)(i0 - prims[c_a].start);
+    }
     bool straight = false;
     uint32_t run_fs = 0;
     if (nvalid == IPT) {
         double ax = 0, ay = 0, bx = 0, by = 0, sx = 0, sy = 0;
         int r0 = 0, nl = 0;
         bool rot = false;
-        if (k_seam >= IPT) {                       // whole run in layer 1: decode from the tile's precomputed pass position
-            const int per = f.n_line + f.n_turn;
-            int off = tl.off0 + j0, idx = tl.idx0;
-            if (off >= per) { const int q = off / per; off -= q * per; idx += q; }
-            if (off + IPT <= f.n_line) {
-                const int pi = f.reverse_order ? (f.P - 1 - idx) : idx;
-                const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+        if (in_main0) {
+            if (c_off + IPT <= f.n_line) {          // (a line never runs into layer 2: the seam follows a line END)
+                const int pi = f.reverse_order ? (f.P - 1 - c_idx) : c_idx;
+                const bool go_left = f.start_from_right ? ((c_idx & 1) == 0) : ((c_idx & 1) == 1);
                 ax = go_left ? f.lex : f.lsx; bx = go_left ? f.lsx : f.lex; sx = go_left ? -f.line_step : f.line_step;
                 ay = by = f.min_y + (double)pi * f.W; sy = 0.0;
-                r0 = off; nl = f.n_line; rot = f.rotated != 0;
+                r0 = c_off; nl = f.n_line; rot = f.rotated != 0;
                 run_fs = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
                 straight = true;
             }
-        } else if (k_seam < 0 || k_seam == 0) {    // whole run in layer 2
-            int a = f.prim_first, b = f.prim_first + f.prim_count - 1;
-            while (a < b) {
-                const int m = (a + b + 1) >> 1;
-                if (prims[m].start <= i0) a = m; else b = m - 1;
-            }
-            const DevPrim &p = prims[a];
-            const int64_t rr = i0 - p.start;
-            if (p.kind == PRIM_LINSPACE && rr + IPT <= p.n) {
+        } else {
+            const DevPrim &p = prims[c_a];
+            if (p.kind == PRIM_LINSPACE && c_r + IPT <= p.n) {
                 ax = p.a[0]; bx = p.a[2]; sx = p.a[4]; ay = p.a[1]; by = p.a[3]; sy = p.a[5];
-                r0 = (int)rr; nl = p.n; run_fs = p.fs;
+                r0 = c_r; nl = p.n; run_fs = p.fs;
                 straight = true;
             }
         }
@@ -314,23 +392,36 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
                 const int rk = r0 + k;
                 double px = (double)rk * sx + ax, py = (double)rk * sy + ay;   // numpy.linspace: k*step + start
                 if (rk == nl - 1) { px = bx; py = by; }                        // ... and the last sample is `stop`
-                if (rot) {
-                    const double tx = px - f.rot_cx, ty = py - f.rot_cy;
-                    px = (tx * f.rot_cos - ty * f.rot_sin) + f.rot_cx;
-                    py = (tx * f.rot_sin + ty * f.rot_cos) + f.rot_cy;
-                }
+                if (rot) rotate_back(f, px, py);
                 X[k + 1] = px; Y[k + 1] = py; fs[k] = run_fs;
             }
         }
     }
     if (!straight) {
+        bool in_main = in_main0;
 #pragma unroll 1
         for (int k = 0; k < IPT; ++k) {
-            GenOut g; g.x = g.y = 0; g.fs = 0;
-            if (k < nvalid) g = gen_point_slow(&f, prims, i0 + k, &cst);
+            double px = 0.0, py = 0.0;
+            uint32_t fw = 0;
+            if (k < nvalid) {
+                if (in_main) {
+                    eval_main(f, cst, c_idx, c_off, px, py, fw);
+                    ++c_off;
+                    if (c_off == per || (c_idx == f.P - 1 && c_off == f.n_line)) {
+                        c_off = 0; ++c_idx;
+                        if (c_idx == f.P) { in_main = false; c_a = f.prim_first; c_r = 0; }
+                    }
+                } else {
+                    const DevPrim &p = prims[c_a];
+                    fw = p.fs;
+                    eval_prim(p, cst, c_r, px, py);
+                    ++c_r;
+                    if (c_r == p.n) { ++c_a; c_r = 0; }
+                }
+            }
             // compile-time indices only (runtime-indexed register arrays would go to scratch)
 #pragma unroll
-            for (int q = 0; q < IPT; ++q) if (q == k) { X[q + 1] = g.x; Y[q + 1] = g.y; fs[q] = g.fs; }
+            for (int q = 0; q < IPT; ++q) if (q == k) { X[q + 1] = px; Y[q + 1] = py; fs[q] = fw; }
         }
     }
     // end neighbours: previous thread's last point, next thread's first point
@@ -348,44 +439,91 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         else { X[IPT + 1] = S.fwd.px; Y[IPT + 1] = S.fwd.py; }
     }
 
-    // ---- 2. segment lengths, couplings, curvature, clamp ---------------------------------------------
-    // d[k] = |P(item k) - P(item k-1)|, w[k] = coupling of the sweeps across that segment; item -1 / item IPT are
-    // the end neighbours.  Skipped steps (d < 1e-6, MLP:560-561 / 576-577) and the path ends cut the propagation.
-    double d[IPT + 1], w[IPT + 1];
+    // ---- 2. segment lengths, curvature; everything that needs coordinates; then the coordinates leave --------
+    // d[k] = |P(item k) - P(item k-1)|; item -1 / item IPT are the end neighbours.  Bit k of `cut` = the sweeps do
+    // not propagate across segment k: skipped steps (d < 1e-6, MLP:560-561 / 576-577) and the path ends.
+    double d[IPT + 1];
+    unsigned cut = 0;
 #pragma unroll
     for (int k = 0; k <= IPT; ++k) {
-        const double dx = X[k + 1] - X[k], dy = Y[k + 1] - Y[k];
-        // sqrt(fl(t*t)) == |t| exactly in IEEE arithmetic: axis-aligned steps need no square root
-        d[k] = (dy == 0.0) ? fabs(dx) : ((dx == 0.0) ? fabs(dy) : sqrt(dx * dx + dy * dy));
-        const bool cut = (d[k] < 1e-6) || (k == 0 && at_start) || (k == k_end + 1);
-        w[k] = cut ? FCPP_INF : two_a * d[k];
+        d[k] = seg_len(X[k + 1] - X[k], Y[k + 1] - Y[k]);
+        if ((d[k] < 1e-6) || (k == 0 && at_start) || (k == k_end + 1)) cut |= 1u << k;
     }
-    double kap[IPT], c[IPT];
-    int adj = 0;
-    unsigned clmask = 0;    // items slowed by the curvature clamp
-    const double ms_run = nominal_ms(run_fs, cst);
+    double kap[IPT];
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
         double kk = 0.0;
         if (k < nvalid && !(k == 0 && at_start) && k != k_end)
             kk = curv_chords(X[k + 1] - X[k], Y[k + 1] - Y[k], d[k], X[k + 2] - X[k + 1], Y[k + 2] - Y[k + 1], d[k + 1]);
         kap[k] = kk;
+    }
+    int nout = 0, nobs = 0;
+    {
+        // geofence; convexity: a straight run whose two end points pass it lies inside as a whole
+        bool run_inside = false;
+        if (straight) {
+            bool out = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                out = out || (f.ex[e] * X[1] + f.ey[e] * Y[1] + f.eo[e] < -cst.geofence_tol)
+                          || (f.ex[e] * X[IPT] + f.ey[e] * Y[IPT] + f.eo[e] < -cst.geofence_tol);
+            run_inside = !out;
+        }
+        const int ob0 = f.obs_first, ob1 = f.obs_first + f.obs_count;
+        if (!run_inside || ob1 > ob0) {
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                if (k < nvalid) {
+                    const double px = X[k + 1], py = Y[k + 1];
+                    if (!run_inside) {
+                        bool out = false;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) out = out || (f.ex[e] * px + f.ey[e] * py + f.eo[e] < -cst.geofence_tol);
+                        if (out) { ++nout; fs[k] |= FCPP_FLAG_OUTSIDE; }
+                    }
+                    bool inside_any = false;
+                    for (int b = ob0; b < ob1 && !inside_any; ++b) {
+                        const int64_t a0 = obs.offsets[b], a1 = obs.offsets[b + 1];
+                        bool in = false;
+                        for (int64_t q = a0, r = a1 - 1; q < a1; r = q++) {
+                            const double xi = obs.x[q], yi = obs.y[q], xj = obs.x[r], yj = obs.y[r];
+                            if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
+                        }
+                        inside_any = in;
+                    }
+                    if (inside_any) { ++nobs; fs[k] |= FCPP_FLAG_OBSTACLE; }
+                }
+            }
+        }
+    }
+    put(xo, &X[1]);
+    put(yo, &Y[1]);
+    put(ko, kap);
+
+    // ---- 3. curvature clamp (MLP:490-504) -> u0 = (v/3.6)^2 ---------------------------------------------------
+    double c[IPT];
+    int adj = 0;
+    unsigned clmask = 0;    // items slowed by the clamp
+    const double ms_run = nominal_ms(run_fs, cst), vn_run = nominal_speed(run_fs, cst);
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
         double ms = straight ? ms_run : nominal_ms(fs[k], cst);
-        if (kk > 1e-6) {
+        if (kap[k] > 1e-6) {
             bool cl;
-            const double vc = clamped_speed(nominal_speed(fs[k], cst), kk, cst, cl);
+            const double vc = clamped_speed(nominal_speed(fs[k], cst), kap[k], cst, cl);
             if (cl) { ms = vc / 3.6; clmask |= 1u << k; ++adj; }
         }
         c[k] = (k < nvalid) ? ms * ms : FCPP_INF;
     }
 
-    // ---- 3. forward / backward sweeps as min-plus scans over registers ----------------------------
+    // ---- 4. forward / backward sweeps as min-plus scans over registers ----------------------------
     // (items beyond a partial tile have c = +inf; they sit at the path end, where nothing propagates)
+    auto wk = [&](int k) -> double { return ((cut >> k) & 1u) ? FCPP_INF : two_a * d[k]; };   // coupling across segment k
     Agg fa = { FCPP_INF, 0.0 }, ba = { FCPP_INF, 0.0 };
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) { fa.c = fmin(c[k], fa.c + w[k]); fa.w += w[k]; }
+    for (int k = 0; k < IPT; ++k) { const double w = wk(k); fa.c = fmin(c[k], fa.c + w); fa.w += w; }
 #pragma unroll
-    for (int k = IPT - 1; k >= 0; --k) { ba.c = fmin(c[k], ba.c + w[k + 1]); ba.w += w[k + 1]; }
+    for (int k = IPT - 1; k >= 0; --k) { const double w = wk(k + 1); ba.c = fmin(c[k], ba.c + w); ba.w += w; }
     Agg fi = fa, bi = ba;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -410,11 +548,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     double uf = fmin(ef.c, carry_f + ef.w), ub = fmin(eb.c, carry_b + eb.w);
     double vf[IPT];   // first the swept u = (v/3.6)^2, then the final speed in km/h
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) { uf = fmin(c[k], uf + w[k]); vf[k] = uf; }
+    for (int k = 0; k < IPT; ++k) { uf = fmin(c[k], uf + wk(k)); vf[k] = uf; }
 #pragma unroll
-    for (int k = IPT - 1; k >= 0; --k) { ub = fmin(c[k], ub + w[k + 1]); vf[k] = fmin(vf[k], ub); }
+    for (int k = IPT - 1; k >= 0; --k) { ub = fmin(c[k], ub + wk(k + 1)); vf[k] = fmin(vf[k], ub); }
     const double b_first = ub;   // backward value at this thread's first item
-    const double vn_run = nominal_speed(run_fs, cst);
     bool uniform = straight;     // every item (and the previous point) still runs at the run's nominal speed
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
@@ -426,25 +563,25 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         } else vf[k] = straight ? vn_run : nominal_speed(fs[k], cst);          // untouched: exactly the nominal value
     }
 
-    // ---- 4. previous point's final v / kappa / nominal v (for the segment metrics) ------------------
+    // ---- 5. previous point's final v / kappa / nominal v (for the segment metrics) ------------------
     double vprev = __shfl_up(vf[IPT - 1], 1), kprev = __shfl_up(kap[IPT - 1], 1);
     uint32_t fsprev = __shfl_up(fs[IPT - 1], 1);
     if (lane == 63) { S.ev[wave] = vf[IPT - 1]; S.ek[wave] = kap[IPT - 1]; S.efs[wave] = fs[IPT - 1]; }
     __syncthreads();
-    double vnprev = nominal_speed(fsprev, cst);
     if (lane == 0) {
-        if (wave > 0) { vprev = S.ev[wave - 1]; kprev = S.ek[wave - 1]; vnprev = nominal_speed(S.efs[wave - 1], cst); }
+        if (wave > 0) { vprev = S.ev[wave - 1]; kprev = S.ek[wave - 1]; fsprev = S.efs[wave - 1]; }
         else if (S.back.valid) {
             // final value at s-1: forward part = carry_f, backward part = B(s) + w(s-1,s)
-            const double up = fmin(carry_f, b_first + w[0]);
+            const double up = fmin(carry_f, b_first + wk(0));
             vprev = (up < S.back.u0) ? sqrt(up) * 3.6 : S.back.v0;
-            kprev = S.back.kappa; vnprev = S.back.vnom;
+            kprev = S.back.kappa; fsprev = S.back.fs;
         }
     }
+    const double vnprev = nominal_speed(fsprev, cst);
 
-    // ---- 5. validator + metrics (MLP:1290-1311, 1373-1424; geofence / obstacles) --------------------
+    // ---- 6. metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) ---------------------------------
     double s_len[2] = { 0, 0 }, s_tpre[2] = { 0, 0 }, s_t[2] = { 0, 0 }, mk = 0, ma = 0, mj = 0;
-    int nv = 0, nout = 0, nobs = 0;
+    int nv = 0;
     uniform = uniform && (vprev == vn_run) && (vnprev == vn_run);
     if (uniform) {
         // one layer, one speed, before and after the speed plan: sum the lengths, divide once
@@ -470,73 +607,21 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
             }
         }
     }
-    const int ob0 = f.obs_first, ob1 = f.obs_first + f.obs_count;
-    // convexity: a straight run whose two end points pass the geofence lies inside as a whole
-    bool run_inside = false;
-    if (straight) {
-        bool out = false;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            out = out || (f.ex[e] * X[1] + f.ey[e] * Y[1] + f.eo[e] < -cst.geofence_tol)
-                      || (f.ex[e] * X[IPT] + f.ey[e] * Y[IPT] + f.eo[e] < -cst.geofence_tol);
-        run_inside = !out;
-    }
 #pragma unroll
     for (int k = 0; k < IPT; ++k) {
-        if (k < nvalid) {
-            const double px = X[k + 1], py = Y[k + 1];
+        if (k < nvalid && !(k == 0 && at_start) && k != k_end) {     // interior points of the path
             const double kp = k == 0 ? kprev : kap[k - 1];
-            if (!(k == 0 && at_start) && k != k_end) {           // interior points of the path, MLP:1383-1391
-                if (kap[k] > 0.0) {            // kappa == 0 contributes a_lat = 0: neither a maximum nor a violation
-                    const double ms = vf[k] / 3.6, alat = ms * ms * kap[k];
-                    mk = fmax(mk, kap[k]); ma = fmax(ma, alat);
-                    if (alat > cst.a_lat) { ++nv; fs[k] |= FCPP_FLAG_ALAT; }
-                }
-                // |kappa_i - kappa_(i-1)| for i >= 2 (MLP:1404-1406)
-                if (kap[k] != kp && !(i0 + k == 1)) mj = fmax(mj, fabs(kap[k] - kp));
+            if (kap[k] > 0.0) {            // kappa == 0 contributes a_lat = 0: neither a maximum nor a violation
+                const double ms = vf[k] / 3.6, alat = ms * ms * kap[k];
+                mk = fmax(mk, kap[k]); ma = fmax(ma, alat);
+                if (alat > cst.a_lat) { ++nv; fs[k] |= FCPP_FLAG_ALAT; }
             }
-            if (!run_inside) {
-                bool out = false;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out = out || (f.ex[e] * px + f.ey[e] * py + f.eo[e] < -cst.geofence_tol);
-                if (out) { ++nout; fs[k] |= FCPP_FLAG_OUTSIDE; }
-            }
-            if (ob1 > ob0) {
-                bool inside_any = false;
-                for (int b = ob0; b < ob1 && !inside_any; ++b) {
-                    const int64_t a0 = obs.offsets[b], a1 = obs.offsets[b + 1];
-                    bool in = false;
-                    for (int64_t q = a0, r = a1 - 1; q < a1; r = q++) {
-                        const double xi = obs.x[q], yi = obs.y[q], xj = obs.x[r], yj = obs.y[r];
-                        if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
-                    }
-                    inside_any = in;
-                }
-                if (inside_any) { ++nobs; fs[k] |= FCPP_FLAG_OBSTACLE; }
-            }
+            // |kappa_i - kappa_(i-1)| for i >= 2 (MLP:1404-1406)
+            if (kap[k] != kp && !(i0 + k == 1)) mj = fmax(mj, fabs(kap[k] - kp));
         }
     }
-
-    // ---- 6. coalesced SoA stores through the per-wave transposition buffer --------------------------
+    put(vo, vf);
     {
-        double *buf = S.tr[wave];
-        const int64_t g0 = f.pt_off + s + wave * (64 * IPT);
-        const int cw = min(max(cnt - wave * (64 * IPT), 0), 64 * IPT);
-        auto put = [&](double *__restrict__ dst, const double *vals) {
-#pragma unroll
-            for (int k = 0; k < IPT; ++k) buf[lidx(lane * IPT + k)] = vals[k];
-            wave_sync();
-#pragma unroll
-            for (int m = 0; m < IPT; ++m) {
-                const int p = lane + 64 * m;
-                if (p < cw) dst[g0 + p] = buf[lidx(p)];
-            }
-            wave_sync();
-        };
-        put(xo, &X[1]);
-        put(yo, &Y[1]);
-        put(ko, kap);
-        put(vo, vf);
         uint32_t *b32 = reinterpret_cast<uint32_t *>(buf);
 #pragma unroll
         for (int k = 0; k < IPT; ++k) b32[2 * lidx(lane * IPT + k)] = fs[k];
@@ -577,6 +662,54 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         tp.n_viol = b[0]; tp.n_outside = b[1]; tp.n_in_obstacle = b[2]; tp.n_adjusted = b[3];
         partial[blockIdx.x] = tp;
     }
+}
+
+// ---- turn templates (once per batch) -----------------------------------------------------------------------
+// tmpl_u[k]: U-turn sample k.  Arcs (MLP:815-823): (R cos th_k, R sin th_k).  Clothoid: (Re * Y_k, Re * X_k) of the
+// unit clothoid-arc-clothoid shape, i.e. the world offsets of cac_world_point for the start heading +y.
+// tmpl_c[k]: corner sample k = (t1, t2).  Arcs (MLP:1049-1060): (R (1 - cos th_k), R sin th_k); clothoid: (Re * Y_k, Re * X_k).
+__global__ void k_build_templates(TurnTemplates tt, const CacShape *__restrict__ shapes, double2 *__restrict__ tu,
+                                  double2 *__restrict__ tc)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < tt.nu) {
+        const double sv = linspace_at(0.0, tt.u_end, tt.u_step, tt.nu, k);
+        double2 o;
+        if (tt.turn_model == FCPP_TURN_ARC) {
+            double sn, cs;
+            sincos(sv, &sn, &cs);
+            o.x = tt.R * cs; o.y = tt.R * sn;
+        } else {
+            double X, Y;
+            cac_unit_point(shapes[0], sv / tt.u_Re, X, Y);
+            o.x = tt.u_Re * Y; o.y = tt.u_Re * X;
+        }
+        tu[k] = o;
+    }
+    if (k < tt.nc) {
+        const double sv = linspace_at(0.0, tt.c_end, tt.c_step, tt.nc, k);
+        double2 o;
+        if (tt.turn_model == FCPP_TURN_ARC) {
+            double sn, cs;
+            sincos(sv, &sn, &cs);
+            o.x = tt.R * (1 - cs); o.y = tt.R * sn;
+        } else {
+            double X, Y;
+            cac_unit_point(shapes[1], sv / tt.c_Re, X, Y);
+            o.x = tt.c_Re * Y; o.y = tt.c_Re * X;
+        }
+        tc[k] = o;
+    }
+}
+
+int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc)
+{
+    const int n = tt.nu > tt.nc ? tt.nu : tt.nc;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_build_templates, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tt, shapes, (double2 *)tu,
+                       (double2 *)tc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const DevTile *tiles, const DevField *fields,

@@ -159,6 +159,15 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
     // most (pi R/2) W + pi W^2/4, so the decision is certain when this lower bound exceeds 0.1.
     const double gap_lb = 4 * R * R - (kPi * R / 2 * W + kPi * W * W / 4);
 
+    {   // turn templates (same sample counts as every field computes below)
+        TurnTemplates &tt = out.tt;
+        memset(&tt, 0, sizeof(tt));
+        tt.turn_model = opt.turn_model; tt.R = R;
+        tt.nu = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(len_uturn, ds) : 20, INT32_MAX);
+        tt.nc = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(len_corner, ds) : 15, INT32_MAX);
+        tt.u_end = cloth ? sh_pi.T * Re_pi : kPi; tt.u_step = lin_step(0.0, tt.u_end, tt.nu); tt.u_Re = Re_pi;
+        tt.c_end = cloth ? sh_half.T * Re_half : kHalfPi; tt.c_step = lin_step(0.0, tt.c_end, tt.nc); tt.c_Re = Re_half;
+    }
     out.info.assign((size_t)n, fcpp_field_info());
     out.fields.clear(); out.prims.clear(); out.tiles.clear();
     if (want_device) out.fields.reserve((size_t)n);

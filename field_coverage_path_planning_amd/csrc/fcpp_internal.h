@@ -66,6 +66,15 @@ struct DevTile {
     int32_t idx0, off0;  // layer 1 only: pass position idx and offset inside the pass of `start` (start = idx0*per + off0)
 };
 
+// batch-wide turn templates: every field of a batch shares the vehicle and the sampling options, hence the number of
+// samples and the shape of its U-turns (nu) and corner turns (nc)
+struct TurnTemplates {
+    int32_t turn_model, nu, nc, _pad;
+    double R;
+    double u_end, u_step, u_Re;   // U-turn: arcs end = pi (angle), clothoid end = total length
+    double c_end, c_step, c_Re;   // corner turn: arcs end = pi/2, clothoid end = total length
+};
+
 // per-tile partial statistics (reduced per field in a fixed order => run-to-run identical sums)
 struct TilePartial {
     double main_len, main_time_pre, main_time, head_len, head_time_pre, head_time;
@@ -85,6 +94,7 @@ struct HostPlan {
     std::vector<DevField> fields;
     std::vector<DevPrim> prims;
     std::vector<DevTile> tiles;
+    TurnTemplates tt;
     int64_t total_points = 0;
 };
 // Builds info (+ device descriptors when want_device) for n fields; returns FCPP_OK or FCPP_E*.
