@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfcpp.so')
+LIB_PATH = os.environ.get('FCPP_LIBRARY') or os.path.join(_HERE, 'libfcpp.so')   # FCPP_LIBRARY: diagnostic builds only
 
 OK, EINVAL, EHEADLAND, EUNSUPPORTED, EHIP, ENOMEM, ESIZE = 0, -1, -2, -3, -4, -5, -6
 TURN_ARC, TURN_CLOTHOID = 0, 1

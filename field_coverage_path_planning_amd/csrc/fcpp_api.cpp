@@ -1,6 +1,7 @@
 // fcpp_api.cpp -- the C ABI declared in include/fcpp.h: argument checking, device buffers, launches.
 // No CPU compute path exists here: every operator ends in a HIP kernel launch or fails with FCPP_EHIP.
 #include <hip/hip_runtime_api.h>
+#include <math.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -72,8 +73,9 @@ struct Tiling {
     std::vector<DevPath> paths;
     std::vector<DevTile> tiles;
     std::vector<int64_t> tile_first;
+    struct QuietInfo { int64_t need, n_line, n_main; };   // need < 0: never quiet
     // per (optional): points per pass (n_line + n_turn) of each field, for the fused kernel's layer-1 decode
-    void build(int64_t n_paths, const int64_t *offsets, const int64_t *per = nullptr)
+    void build(int64_t n_paths, const int64_t *offsets, const int64_t *per = nullptr, const QuietInfo *quiet = nullptr)
     {
         paths.resize((size_t)n_paths);
         tile_first.assign((size_t)n_paths + 1, 0);
@@ -85,8 +87,16 @@ struct Tiling {
             for (int64_t s = 0; s < n; s += TILE_POINTS) {
                 DevTile t;
                 t.field = (int32_t)p; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, n - s);
-                t.idx0 = 0; t.off0 = 0;
+                t.idx0 = 0; t.off0 = 0; t.quiet = 0; t._pad = 0;
                 if (per && per[p] > 0) { t.idx0 = (int32_t)(s / per[p]); t.off0 = (int32_t)(s % per[p]); }
+                if (quiet) {
+                    // whole tile + `need` samples on either side inside one swath line of layer 1 (need = samples that
+                    // span u_cap / (2a) metres: nothing farther away can influence the speeds inside the tile)
+                    const QuietInfo &q = quiet[p];
+                    if (q.need >= 0 && s + t.count <= q.n_main && t.count == TILE_POINTS && t.off0 >= q.need &&
+                        (int64_t)t.off0 + t.count + q.need <= q.n_line)
+                        t.quiet = 1;
+                }
                 tiles.push_back(t);
             }
         }
@@ -300,7 +310,16 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     for (int64_t i = 0; i < n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
     std::vector<int64_t> per((size_t)n_fields, 0);
     for (int64_t i = 0; i < n_fields; ++i) per[(size_t)i] = (int64_t)b->hp.fields[(size_t)i].n_line + b->hp.fields[(size_t)i].n_turn;
-    til.build(n_fields, offs.data(), per.data());
+    std::vector<Tiling::QuietInfo> qi((size_t)n_fields);
+    for (int64_t i = 0; i < n_fields; ++i) {
+        const DevField &df = b->hp.fields[(size_t)i];
+        const double step = fabs(df.line_step);
+        Tiling::QuietInfo q = { -1, df.n_line, df.n_main };
+        if (df.n_total > 0 && step >= 1e-6 && df.n_line > 2)
+            q.need = (int64_t)(b->cst.u_cap / (2 * b->cst.a_lon * step)) + 3;
+        qi[(size_t)i] = q;
+    }
+    til.build(n_fields, offs.data(), per.data(), qi.data());
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
     ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st)) &&

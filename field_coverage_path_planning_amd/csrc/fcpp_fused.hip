@@ -37,7 +37,11 @@ struct RedSharedF { double d[NWAVE][9]; long long i[NWAVE][4]; };
 
 static constexpr int TR_WORDS = 64 * IPT + 64;   // padded per-wave transposition buffer (doubles)
 
+struct FieldWords { uint32_t w[sizeof(DevField) / 4]; };
+static_assert(sizeof(DevField) % 4 == 0 && sizeof(DevField) / 4 <= BLOCK, "DevField staging");
+
 struct FusedShared {
+    FieldWords fw;       // the tile's field descriptor, staged by ONE coalesced load
     HaloInfo back, fwd;
     double efx[NWAVE], efy[NWAVE], elx[NWAVE], ely[NWAVE];   // first / last point of each wave
     Agg wf[NWAVE], wb[NWAVE];
@@ -166,7 +170,7 @@ __device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const DevPrim *
 
 // One wave computes what the sweeps carry across the tile edge (see the header comment).
 template <bool BACK>
-__device__ void halo_wave(const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst, const DevTile &tl,
+__device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *__restrict__ prims, const DevConst &cst, const DevTile &tl,
                           int64_t edge, HaloInfo *out)
 {
     const int lane = threadIdx.x & 63;
@@ -234,11 +238,11 @@ __device__ void halo_wave(const DevField &f, const DevPrim *__restrict__ prims, 
         const int64_t i = b + lane;
         const bool act = i >= 0 && i < n;
         GenOut g; g.x = g.y = g.v = 0; g.fs = 0;
-        if (act) g = gen_point_tmpl(&f, prims, &cst, i);
+        if (act) g = gen_point_tmpl(fg, prims, &cst, i);
         double xm = __shfl_up(g.x, 1), ym = __shfl_up(g.y, 1), xp = __shfl_down(g.x, 1), yp = __shfl_down(g.y, 1);
         const int64_t ei = lane == 0 ? i - 1 : i + 1;
         if ((lane == 0 || lane == 63) && ei >= 0 && ei < n) {   // the chunk's two outer neighbours
-            const GenOut e = gen_point_tmpl(&f, prims, &cst, ei);
+            const GenOut e = gen_point_tmpl(fg, prims, &cst, ei);
             if (lane == 0) { xm = e.x; ym = e.y; } else { xp = e.x; yp = e.y; }
         }
         double kappa = 0, dprev = 0, dnext = 0;
@@ -302,6 +306,13 @@ __device__ __forceinline__ long long wave_sum_i(int v)
     return v;
 }
 
+// Diagnostic build only (-DFCPP_DIAG_STAMPS, never shipped): phase time stamps of wave 1 replace the tile's metrics.
+#ifdef FCPP_DIAG_STAMPS
+#define FCPP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FCPP_STAMP(i) do { } while (0)
+#endif
+
 template <int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__restrict__ tiles,
                                                             const DevField *__restrict__ fields,
@@ -311,16 +322,98 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
                                                             uint32_t *__restrict__ fso, TilePartial *__restrict__ partial)
 {
     __shared__ FusedShared S;
+#ifdef FCPP_DIAG_STAMPS
+    unsigned long long stamp[10];
+#endif
+    FCPP_STAMP(0);
     const DevTile tl = tiles[blockIdx.x];
-    const DevField &f = fields[tl.field];
+    const DevField *fg = &fields[tl.field];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tl.quiet) {
+        // ---- quiet tile (flagged by the host): all 2048 points and everything within reach of the sweeps lie on one
+        // swath line.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere, so the results are closed-form:
+        // no neighbours, no scan, no LDS -- striped point order, every store instruction writes 512 contiguous bytes.
+        const DevField &q = *fg;
+        const int idx = tl.idx0;
+        const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
+        const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+        const double ax = go_left ? q.lex : q.lsx, sx = go_left ? -q.line_step : q.line_step;
+        const double y = q.min_y + (double)pi * q.W;
+        const bool rot = q.rotated != 0;
+        const uint32_t fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+        // geofence by convexity: both end points inside => the whole segment is inside
+        double ex0 = (double)tl.off0 * sx + ax, ey0 = y, ex1 = (double)(tl.off0 + TILE_POINTS - 1) * sx + ax, ey1 = y;
+        if (rot) { rotate_back(q, ex0, ey0); rotate_back(q, ex1, ey1); }
+        bool ends_out = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            ends_out = ends_out || (q.ex[e] * ex0 + q.ey[e] * ey0 + q.eo[e] < -cst.geofence_tol)
+                                || (q.ex[e] * ex1 + q.ey[e] * ey1 + q.eo[e] < -cst.geofence_tol);
+        const bool per_point = ends_out || q.obs_count > 0;
+        const int64_t g0 = q.pt_off + tl.start;
+        int nout = 0, nobs = 0;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) {
+            const int j = tid + BLOCK * k;
+            double px = (double)(tl.off0 + j) * sx + ax, py = y;     // numpy.linspace: k*step + start
+            if (rot) rotate_back(q, px, py);
+            uint32_t fsw = fw;
+            if (per_point) {
+                bool out = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out = out || (q.ex[e] * px + q.ey[e] * py + q.eo[e] < -cst.geofence_tol);
+                if (out) { ++nout; fsw |= FCPP_FLAG_OUTSIDE; }
+                bool inside_any = false;
+                for (int b = q.obs_first; b < q.obs_first + q.obs_count && !inside_any; ++b) {
+                    const int64_t a0 = obs.offsets[b], a1 = obs.offsets[b + 1];
+                    bool in = false;
+                    for (int64_t u = a0, r = a1 - 1; u < a1; r = u++) {
+                        const double xi = obs.x[u], yi = obs.y[u], xj = obs.x[r], yj = obs.y[r];
+                        if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
+                    }
+                    inside_any = in;
+                }
+                if (inside_any) { ++nobs; fsw |= FCPP_FLAG_OBSTACLE; }
+            }
+            xo[g0 + j] = px; yo[g0 + j] = py; ko[g0 + j] = 0.0; vo[g0 + j] = cst.v_work; fso[g0 + j] = fsw;
+        }
+        long long io = 0, ib = 0;
+        if (per_point) {   // block-uniform
+            io = wave_sum_i(nout); ib = wave_sum_i(nobs);
+            if (lane == 0) { S.R.i[wave][0] = io; S.R.i[wave][1] = ib; }
+            __syncthreads();
+            io = S.R.i[0][0] + S.R.i[1][0] + S.R.i[2][0] + S.R.i[3][0];
+            ib = S.R.i[0][1] + S.R.i[1][1] + S.R.i[2][1] + S.R.i[3][1];
+        }
+        if (tid == 0) {
+            // 2048 segments of |line_step| each (the tile's first segment comes from its left neighbour on the same line)
+            TilePartial tp;
+            const double len = (double)TILE_POINTS * fabs(sx), t = len / fmax(cst.ms_work, 0.1);
+            tp.main_len = len; tp.main_time_pre = t; tp.main_time = t;
+            tp.head_len = tp.head_time_pre = tp.head_time = 0.0;
+            tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
+            tp.n_viol = 0; tp.n_outside = io; tp.n_in_obstacle = ib; tp.n_adjusted = 0;
+            partial[blockIdx.x] = tp;
+        }
+        return;
+    }
+    // The field descriptor is block-uniform and used all over the kernel.  Read lazily it costs dozens of dependent
+    // scalar-load round trips per wave; instead: one coalesced vector load into LDS, one barrier, then every word is
+    // broadcast-read and moved to a scalar register (readfirstlane) in one go.
+    if (tid < (int)(sizeof(DevField) / 4)) S.fw.w[tid] = reinterpret_cast<const uint32_t *>(fg)[tid];
+    __syncthreads();
+    FieldWords fwl;
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(DevField) / 4); ++q) fwl.w[q] = __builtin_amdgcn_readfirstlane(S.fw.w[q]);
+    const DevField f = __builtin_bit_cast(DevField, fwl);
     const int64_t n = f.n_total, s = tl.start;
     const int cnt = tl.count;
     const double two_a = 2 * cst.a_lon;
 
-    if (wave == 0) halo_wave<true>(f, prims, cst, tl, s, &S.back);
-    else if (wave == NWAVE - 1) halo_wave<false>(f, prims, cst, tl, s + cnt, &S.fwd);
+    if (wave == 0) halo_wave<true>(f, fg, prims, cst, tl, s, &S.back);
+    else if (wave == NWAVE - 1) halo_wave<false>(f, fg, prims, cst, tl, s + cnt, &S.fwd);
 
+    FCPP_STAMP(1);
     // ---- 0. where this thread's run sits relative to the path's special indices (small ints from here on) ----
     const int j0 = tid * IPT;
     const int64_t i0 = s + j0;
@@ -424,6 +517,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
             for (int q = 0; q < IPT; ++q) if (q == k) { X[q + 1] = px; Y[q + 1] = py; fs[q] = fw; }
         }
     }
+    FCPP_STAMP(2);
     // end neighbours: previous thread's last point, next thread's first point
     X[0] = __shfl_up(X[IPT], 1); Y[0] = __shfl_up(Y[IPT], 1);
     X[IPT + 1] = __shfl_down(X[1], 1); Y[IPT + 1] = __shfl_down(Y[1], 1);
@@ -439,6 +533,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         else { X[IPT + 1] = S.fwd.px; Y[IPT + 1] = S.fwd.py; }
     }
 
+    FCPP_STAMP(3);
     // ---- 2. segment lengths, curvature; everything that needs coordinates; then the coordinates leave --------
     // d[k] = |P(item k) - P(item k-1)|; item -1 / item IPT are the end neighbours.  Bit k of `cut` = the sweeps do
     // not propagate across segment k: skipped steps (d < 1e-6, MLP:560-561 / 576-577) and the path ends.
@@ -496,9 +591,11 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
             }
         }
     }
+    FCPP_STAMP(4);
     put(xo, &X[1]);
     put(yo, &Y[1]);
     put(ko, kap);
+    FCPP_STAMP(5);
 
     // ---- 3. curvature clamp (MLP:490-504) -> u0 = (v/3.6)^2 ---------------------------------------------------
     double c[IPT];
@@ -563,6 +660,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         } else vf[k] = straight ? vn_run : nominal_speed(fs[k], cst);          // untouched: exactly the nominal value
     }
 
+    FCPP_STAMP(6);
     // ---- 5. previous point's final v / kappa / nominal v (for the segment metrics) ------------------
     double vprev = __shfl_up(vf[IPT - 1], 1), kprev = __shfl_up(kap[IPT - 1], 1);
     uint32_t fsprev = __shfl_up(fs[IPT - 1], 1);
@@ -579,6 +677,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     }
     const double vnprev = nominal_speed(fsprev, cst);
 
+    FCPP_STAMP(7);
     // ---- 6. metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) ---------------------------------
     double s_len[2] = { 0, 0 }, s_tpre[2] = { 0, 0 }, s_t[2] = { 0, 0 }, mk = 0, ma = 0, mj = 0;
     int nv = 0;
@@ -633,6 +732,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         }
     }
 
+    FCPP_STAMP(8);
     // ---- 7. fixed-shape block reduction of the metrics ---------------------------------------------
     double dv[9] = { s_len[0], s_tpre[0], s_t[0], s_len[1], s_tpre[1], s_t[1], mk, ma, mj };
     long long iv[4];
@@ -660,8 +760,23 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         tp.head_len = a[3]; tp.head_time_pre = a[4]; tp.head_time = a[5];
         tp.max_kappa = a[6]; tp.max_alat = a[7]; tp.max_jump = a[8];
         tp.n_viol = b[0]; tp.n_outside = b[1]; tp.n_in_obstacle = b[2]; tp.n_adjusted = b[3];
+#ifndef FCPP_DIAG_STAMPS
+        partial[blockIdx.x] = tp;
+#endif
+    }
+#ifdef FCPP_DIAG_STAMPS
+    FCPP_STAMP(9);
+    if (tid == FCPP_DIAG_STAMPS * 64) {   // lane 0 of the chosen wave: phase durations in shader cycles
+        TilePartial tp;
+        tp.main_len = (double)(stamp[1] - stamp[0]); tp.main_time_pre = (double)(stamp[2] - stamp[1]);
+        tp.main_time = (double)(stamp[3] - stamp[2]); tp.head_len = (double)(stamp[4] - stamp[3]);
+        tp.head_time_pre = (double)(stamp[5] - stamp[4]); tp.head_time = (double)(stamp[6] - stamp[5]);
+        tp.max_kappa = 0; tp.max_alat = 0; tp.max_jump = 0;
+        tp.n_viol = (long long)(stamp[7] - stamp[6]); tp.n_outside = (long long)(stamp[8] - stamp[7]);
+        tp.n_in_obstacle = (long long)(stamp[9] - stamp[8]); tp.n_adjusted = (long long)(stamp[9] - stamp[0]);
         partial[blockIdx.x] = tp;
     }
+#endif
 }
 
 // ---- turn templates (once per batch) -----------------------------------------------------------------------

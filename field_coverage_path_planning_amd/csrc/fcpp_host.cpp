@@ -387,7 +387,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
             for (int64_t s = 0; s < pos; s += TILE_POINTS) {
                 DevTile t;
                 t.field = (int32_t)fi; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, pos - s);
-                t.idx0 = 0; t.off0 = 0;
+                t.idx0 = 0; t.off0 = 0; t.quiet = 0; t._pad = 0;
                 out.tiles.push_back(t);
             }
         }

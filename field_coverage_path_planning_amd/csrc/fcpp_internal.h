@@ -64,6 +64,8 @@ struct DevTile {
     int32_t count;       // <= TILE_POINTS
     int64_t start;       // first point of the tile inside the field's path
     int32_t idx0, off0;  // layer 1 only: pass position idx and offset inside the pass of `start` (start = idx0*per + off0)
+    int32_t quiet;       // 1: the tile and its sweep neighbourhood lie on ONE swath line (closed-form results, see fcpp_fused.hip)
+    int32_t _pad;
 };
 
 // batch-wide turn templates: every field of a batch shares the vehicle and the sampling options, hence the number of
