@@ -112,7 +112,8 @@ struct DevTiling {
     DevBuf<double> carry_f, carry_b;
     DevBuf<TilePartial> partial;
     DevBuf<unsigned long long> n_adj;
-    int64_t n_tiles = 0, n_paths = 0;
+    DevBuf<int32_t> quiet_ids, general_ids;   // fused pipeline: tiles by kernel
+    int64_t n_tiles = 0, n_paths = 0, n_quiet = 0, n_general = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
     {
         n_tiles = (int64_t)t.tiles.size(); n_paths = (int64_t)t.paths.size();
@@ -126,6 +127,12 @@ struct DevTiling {
         if ((e = carry_b.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
+        std::vector<int32_t> qv, gv;
+        for (size_t i = 0; i < t.tiles.size(); ++i) (t.tiles[i].quiet ? qv : gv).push_back((int32_t)i);
+        n_quiet = (int64_t)qv.size(); n_general = (int64_t)gv.size();
+        if ((e = quiet_ids.upload(qv, st)) != hipSuccess) return e;
+        if ((e = general_ids.upload(gv, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // qv / gv die here
         return hipSuccess;
     }
 };
@@ -165,8 +172,8 @@ constexpr int kStages = 7;
 constexpr int kProfRuns = 64;
 const char *const kStageNames[2][kStages] = {
     { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine", "k_scan_apply", "k_validate", "k_reduce_stats" },
-    { "k_plan_fused", "k_reduce_stats", "", "", "", "", "" } };
-const int kStageCount[2] = { 7, 2 };
+    { "k_plan_quiet", "k_plan_fused", "k_reduce_stats", "", "", "", "" } };
+const int kStageCount[2] = { 7, 3 };
 }
 
 extern "C" {
@@ -397,8 +404,10 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     } while (0)
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (mode == 1) {
-        STAGE(0, launch_plan_fused(st, variant, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
-        STAGE(1, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, nullptr, stats));
+        STAGE(0, launch_plan_quiet(st, t.n_quiet, t.quiet_ids.p, t.tiles.p, b->fields.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y,
+                                   kappa, v, fs, t.partial.p));
+        STAGE(2, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, nullptr, stats));
         if (ev) ++b->prof_runs;
         return FCPP_OK;
     }
@@ -445,6 +454,15 @@ int fcpp_batch_stage_times(fcpp_batch *b, int max_stages, double *ms_sum, int *n
     if (n_stages) *n_stages = ns;
     if (n_runs) *n_runs = b->prof_runs;
     b->prof_runs = 0;
+    return FCPP_OK;
+}
+
+int fcpp_batch_point_split(const fcpp_batch *b, int64_t *quiet_points, int64_t *general_points)
+{
+    if (!b) return fail(FCPP_EINVAL, "batch is NULL");
+    const int64_t q = b->til.n_quiet * TILE_POINTS;
+    if (quiet_points) *quiet_points = q;
+    if (general_points) *general_points = b->hp.total_points - q;
     return FCPP_OK;
 }
 

@@ -25,6 +25,11 @@
 
 namespace fcpp {
 
+// the fused kernel runs ONE wavefront per 512-point tile: no workgroup barrier anywhere, waves never wait for each other
+static constexpr int FBLOCK = 64;
+static constexpr int FIPT = TILE_POINTS / FBLOCK;   // 8 consecutive points per lane
+static constexpr int FNWAVE = 1;
+
 struct HaloInfo {
     double px, py;       // the neighbouring path point (index s-1 or s+count)
     double carry;        // value the forward (backward) sweep carries into the tile; +inf if none
@@ -33,21 +38,21 @@ struct HaloInfo {
     int valid;
 };
 
-struct RedSharedF { double d[NWAVE][9]; long long i[NWAVE][4]; };
+struct RedSharedF { double d[FNWAVE][9]; long long i[FNWAVE][4]; };
 
-static constexpr int TR_WORDS = 64 * IPT + 64;   // padded per-wave transposition buffer (doubles)
+static constexpr int TR_WORDS = 64 * FIPT + 64;   // padded per-wave transposition buffer (doubles)
 
 struct FieldWords { uint32_t w[sizeof(DevField) / 4]; };
-static_assert(sizeof(DevField) % 4 == 0 && sizeof(DevField) / 4 <= BLOCK, "DevField staging");
+static_assert(sizeof(DevField) % 4 == 0 && sizeof(DevField) / 4 <= 2 * FBLOCK, "DevField staging");
 
 struct FusedShared {
     FieldWords fw;       // the tile's field descriptor, staged by ONE coalesced load
     HaloInfo back, fwd;
-    double efx[NWAVE], efy[NWAVE], elx[NWAVE], ely[NWAVE];   // first / last point of each wave
-    Agg wf[NWAVE], wb[NWAVE];
-    double ev[NWAVE], ek[NWAVE];                                // last item of each wave: final v, kappa
-    uint32_t efs[NWAVE];                                         // ... and its segment word
-    double tr[NWAVE][TR_WORDS];
+    double efx[FNWAVE], efy[FNWAVE], elx[FNWAVE], ely[FNWAVE];   // first / last point of each wave
+    Agg wf[FNWAVE], wb[FNWAVE];
+    double ev[FNWAVE], ek[FNWAVE];                                // last item of each wave: final v, kappa
+    uint32_t efs[FNWAVE];                                         // ... and its segment word
+    double tr[FNWAVE][TR_WORDS];
     RedSharedF R;
 };
 
@@ -306,6 +311,101 @@ __device__ __forceinline__ long long wave_sum_i(int v)
     return v;
 }
 
+// ---- quiet tiles (flagged by the host): all 2048 points and everything within reach of the sweeps lie on one swath
+// line.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere, so the results are closed-form: no neighbours,
+// no scan, no LDS -- striped point order, every store instruction writes 512 contiguous bytes per wave.  A separate
+// kernel so that it runs at full occupancy: it is pure HBM streaming.
+__global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ tiles, const DevField *__restrict__ fields,
+                                                      DevConst cst, DevObstacles obs, double *__restrict__ xo,
+                                                      double *__restrict__ yo, double *__restrict__ ko,
+                                                      double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                                      TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
+                                                      int64_t n_ids)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one tile per wavefront
+    if (slot >= n_ids) return;
+    const int tile_id = ids[slot];
+    const DevTile tl = tiles[tile_id];
+    const DevField *fg = &fields[tl.field];
+    const DevField &q = *fg;
+    const int idx = tl.idx0;
+    const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
+    const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+    const double ax = go_left ? q.lex : q.lsx, sx = go_left ? -q.line_step : q.line_step;
+    const double y = q.min_y + (double)pi * q.W;
+    const bool rot = q.rotated != 0;
+    const uint32_t fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+    // geofence by convexity: both end points inside => the whole segment is inside
+    double ex0 = (double)tl.off0 * sx + ax, ey0 = y, ex1 = (double)(tl.off0 + TILE_POINTS - 1) * sx + ax, ey1 = y;
+    if (rot) { rotate_back(q, ex0, ey0); rotate_back(q, ex1, ey1); }
+    bool ends_out = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        ends_out = ends_out || (q.ex[e] * ex0 + q.ey[e] * ey0 + q.eo[e] < -cst.geofence_tol)
+                            || (q.ex[e] * ex1 + q.ey[e] * ey1 + q.eo[e] < -cst.geofence_tol);
+    const bool per_point = ends_out || q.obs_count > 0;
+    const int64_t g0 = q.pt_off + tl.start;
+    int nout = 0, nobs = 0;
+    // each lane owns pairs of consecutive points: 16-byte stores, 1 KiB per wave instruction
+#pragma unroll
+    for (int k = 0; k < TILE_POINTS / 128; ++k) {
+        const int j = 2 * lane + 128 * k;
+        double px[2], py[2];
+        uint32_t fsw[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            px[h] = (double)(tl.off0 + j + h) * sx + ax; py[h] = y;     // numpy.linspace: k*step + start
+            if (rot) rotate_back(q, px[h], py[h]);
+            fsw[h] = fw;
+            if (per_point) {
+                bool out = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out = out || (q.ex[e] * px[h] + q.ey[e] * py[h] + q.eo[e] < -cst.geofence_tol);
+                if (out) { ++nout; fsw[h] |= FCPP_FLAG_OUTSIDE; }
+                bool inside_any = false;
+                for (int b = q.obs_first; b < q.obs_first + q.obs_count && !inside_any; ++b) {
+                    const int64_t a0 = obs.offsets[b], a1 = obs.offsets[b + 1];
+                    bool in = false;
+                    for (int64_t u = a0, r = a1 - 1; u < a1; r = u++) {
+                        const double xi = obs.x[u], yi = obs.y[u], xj = obs.x[r], yj = obs.y[r];
+                        if (((yi > py[h]) != (yj > py[h])) && (px[h] < (xj - xi) * (py[h] - yi) / (yj - yi) + xi)) in = !in;
+                    }
+                    inside_any = in;
+                }
+                if (inside_any) { ++nobs; fsw[h] |= FCPP_FLAG_OBSTACLE; }
+            }
+        }
+        // (tile starts are multiples of 512 points from 16-byte aligned bases: pt_off of every field is even? no -- only
+        // 8-byte alignment is guaranteed, so the pair is stored as two 8-byte halves when the address is odd)
+        const int64_t g = g0 + j;
+        if ((g & 1) == 0) {
+            *reinterpret_cast<double2 *>(xo + g) = make_double2(px[0], px[1]);
+            *reinterpret_cast<double2 *>(yo + g) = make_double2(py[0], py[1]);
+            *reinterpret_cast<double2 *>(ko + g) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2 *>(vo + g) = make_double2(cst.v_work, cst.v_work);
+            *reinterpret_cast<uint2 *>(fso + g) = make_uint2(fsw[0], fsw[1]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                xo[g + h] = px[h]; yo[g + h] = py[h]; ko[g + h] = 0.0; vo[g + h] = cst.v_work; fso[g + h] = fsw[h];
+            }
+        }
+    }
+    long long io = 0, ib = 0;
+    if (per_point) { io = wave_sum_i(nout); ib = wave_sum_i(nobs); }   // wave-uniform
+    if (lane == 0) {
+        // TILE_POINTS segments of |line_step| each (the tile's first segment comes from its left neighbour on the same line)
+        TilePartial tp;
+        const double len = (double)TILE_POINTS * fabs(sx), t = len / fmax(cst.ms_work, 0.1);
+        tp.main_len = len; tp.main_time_pre = t; tp.main_time = t;
+        tp.head_len = tp.head_time_pre = tp.head_time = 0.0;
+        tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
+        tp.n_viol = 0; tp.n_outside = io; tp.n_in_obstacle = ib; tp.n_adjusted = 0;
+        partial[tile_id] = tp;
+    }
+}
+
 // Diagnostic build only (-DFCPP_DIAG_STAMPS, never shipped): phase time stamps of wave 1 replace the tile's metrics.
 #ifdef FCPP_DIAG_STAMPS
 #define FCPP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -314,93 +414,27 @@ __device__ __forceinline__ long long wave_sum_i(int v)
 #endif
 
 template <int MINW>
-__global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__restrict__ tiles,
+__global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__restrict__ tiles,
                                                             const DevField *__restrict__ fields,
                                                             const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                             double *__restrict__ xo, double *__restrict__ yo,
                                                             double *__restrict__ ko, double *__restrict__ vo,
-                                                            uint32_t *__restrict__ fso, TilePartial *__restrict__ partial)
+                                                            uint32_t *__restrict__ fso, TilePartial *__restrict__ partial,
+                                                            const int32_t *__restrict__ ids)
 {
     __shared__ FusedShared S;
 #ifdef FCPP_DIAG_STAMPS
     unsigned long long stamp[10];
 #endif
     FCPP_STAMP(0);
-    const DevTile tl = tiles[blockIdx.x];
+    const int tile_id = ids ? ids[blockIdx.x] : (int)blockIdx.x;
+    const DevTile tl = tiles[tile_id];
     const DevField *fg = &fields[tl.field];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tl.quiet) {
-        // ---- quiet tile (flagged by the host): all 2048 points and everything within reach of the sweeps lie on one
-        // swath line.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere, so the results are closed-form:
-        // no neighbours, no scan, no LDS -- striped point order, every store instruction writes 512 contiguous bytes.
-        const DevField &q = *fg;
-        const int idx = tl.idx0;
-        const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
-        const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
-        const double ax = go_left ? q.lex : q.lsx, sx = go_left ? -q.line_step : q.line_step;
-        const double y = q.min_y + (double)pi * q.W;
-        const bool rot = q.rotated != 0;
-        const uint32_t fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
-        // geofence by convexity: both end points inside => the whole segment is inside
-        double ex0 = (double)tl.off0 * sx + ax, ey0 = y, ex1 = (double)(tl.off0 + TILE_POINTS - 1) * sx + ax, ey1 = y;
-        if (rot) { rotate_back(q, ex0, ey0); rotate_back(q, ex1, ey1); }
-        bool ends_out = false;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            ends_out = ends_out || (q.ex[e] * ex0 + q.ey[e] * ey0 + q.eo[e] < -cst.geofence_tol)
-                                || (q.ex[e] * ex1 + q.ey[e] * ey1 + q.eo[e] < -cst.geofence_tol);
-        const bool per_point = ends_out || q.obs_count > 0;
-        const int64_t g0 = q.pt_off + tl.start;
-        int nout = 0, nobs = 0;
-#pragma unroll
-        for (int k = 0; k < IPT; ++k) {
-            const int j = tid + BLOCK * k;
-            double px = (double)(tl.off0 + j) * sx + ax, py = y;     // numpy.linspace: k*step + start
-            if (rot) rotate_back(q, px, py);
-            uint32_t fsw = fw;
-            if (per_point) {
-                bool out = false;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out = out || (q.ex[e] * px + q.ey[e] * py + q.eo[e] < -cst.geofence_tol);
-                if (out) { ++nout; fsw |= FCPP_FLAG_OUTSIDE; }
-                bool inside_any = false;
-                for (int b = q.obs_first; b < q.obs_first + q.obs_count && !inside_any; ++b) {
-                    const int64_t a0 = obs.offsets[b], a1 = obs.offsets[b + 1];
-                    bool in = false;
-                    for (int64_t u = a0, r = a1 - 1; u < a1; r = u++) {
-                        const double xi = obs.x[u], yi = obs.y[u], xj = obs.x[r], yj = obs.y[r];
-                        if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
-                    }
-                    inside_any = in;
-                }
-                if (inside_any) { ++nobs; fsw |= FCPP_FLAG_OBSTACLE; }
-            }
-            xo[g0 + j] = px; yo[g0 + j] = py; ko[g0 + j] = 0.0; vo[g0 + j] = cst.v_work; fso[g0 + j] = fsw;
-        }
-        long long io = 0, ib = 0;
-        if (per_point) {   // block-uniform
-            io = wave_sum_i(nout); ib = wave_sum_i(nobs);
-            if (lane == 0) { S.R.i[wave][0] = io; S.R.i[wave][1] = ib; }
-            __syncthreads();
-            io = S.R.i[0][0] + S.R.i[1][0] + S.R.i[2][0] + S.R.i[3][0];
-            ib = S.R.i[0][1] + S.R.i[1][1] + S.R.i[2][1] + S.R.i[3][1];
-        }
-        if (tid == 0) {
-            // 2048 segments of |line_step| each (the tile's first segment comes from its left neighbour on the same line)
-            TilePartial tp;
-            const double len = (double)TILE_POINTS * fabs(sx), t = len / fmax(cst.ms_work, 0.1);
-            tp.main_len = len; tp.main_time_pre = t; tp.main_time = t;
-            tp.head_len = tp.head_time_pre = tp.head_time = 0.0;
-            tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
-            tp.n_viol = 0; tp.n_outside = io; tp.n_in_obstacle = ib; tp.n_adjusted = 0;
-            partial[blockIdx.x] = tp;
-        }
-        return;
-    }
     // The field descriptor is block-uniform and used all over the kernel.  Read lazily it costs dozens of dependent
     // scalar-load round trips per wave; instead: one coalesced vector load into LDS, one barrier, then every word is
     // broadcast-read and moved to a scalar register (readfirstlane) in one go.
-    if (tid < (int)(sizeof(DevField) / 4)) S.fw.w[tid] = reinterpret_cast<const uint32_t *>(fg)[tid];
+    for (int q = tid; q < (int)(sizeof(DevField) / 4); q += FBLOCK) S.fw.w[q] = reinterpret_cast<const uint32_t *>(fg)[q];
     __syncthreads();
     FieldWords fwl;
 #pragma unroll
@@ -410,28 +444,28 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     const int cnt = tl.count;
     const double two_a = 2 * cst.a_lon;
 
-    if (wave == 0) halo_wave<true>(f, fg, prims, cst, tl, s, &S.back);
-    else if (wave == NWAVE - 1) halo_wave<false>(f, fg, prims, cst, tl, s + cnt, &S.fwd);
+    halo_wave<true>(f, fg, prims, cst, tl, s, &S.back);          // one wave per tile: it computes both carries itself
+    halo_wave<false>(f, fg, prims, cst, tl, s + cnt, &S.fwd);
 
     FCPP_STAMP(1);
     // ---- 0. where this thread's run sits relative to the path's special indices (small ints from here on) ----
-    const int j0 = tid * IPT;
+    const int j0 = tid * FIPT;
     const int64_t i0 = s + j0;
-    const int nvalid = min(max(cnt - j0, 0), IPT);
+    const int nvalid = min(max(cnt - j0, 0), FIPT);
     const bool at_start = (i0 == 0);                                  // item 0 is the path's first point
     const int64_t rem_end = (n - 1) - i0, rem_seam = f.n_main - i0;
-    const int k_end = (rem_end >= 0 && rem_end < IPT) ? (int)rem_end : 1000;     // item that is the path's last point
-    const int k_seam = rem_seam < 0 ? -1 : (rem_seam >= IPT ? 1000 : (int)rem_seam);  // item with index n_main (first of layer 2)
+    const int k_end = (rem_end >= 0 && rem_end < FIPT) ? (int)rem_end : 1000;     // item that is the path's last point
+    const int k_seam = rem_seam < 0 ? -1 : (rem_seam >= FIPT ? 1000 : (int)rem_seam);  // item with index n_main (first of layer 2)
     double *buf = S.tr[wave];
-    const int64_t g0 = f.pt_off + s + wave * (64 * IPT);
-    const int cw = min(max(cnt - wave * (64 * IPT), 0), 64 * IPT);
+    const int64_t g0 = f.pt_off + s + wave * (64 * FIPT);
+    const int cw = min(max(cnt - wave * (64 * FIPT), 0), 64 * FIPT);
     // coalesced SoA store of one per-item array through the per-wave transposition buffer
     auto put = [&](double *__restrict__ dst, const double *vals) {
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) buf[lidx(lane * IPT + k)] = vals[k];
+        for (int k = 0; k < FIPT; ++k) buf[lidx(lane * FIPT + k)] = vals[k];
         wave_sync();
 #pragma unroll
-        for (int m = 0; m < IPT; ++m) {
+        for (int m = 0; m < FIPT; ++m) {
             const int p = lane + 64 * m;
             if (p < cw) dst[g0 + p] = buf[lidx(p)];
         }
@@ -443,8 +477,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     // layer 2 = (primitive, offset) by binary search.  Fast path: the whole run lies on one straight primitive
     // (~95 % of the threads at fine sampling): 8 x (cvt, mul, add).  Otherwise a cursor walks the run item by item
     // through whatever primitives it crosses (line -> turn -> line ..).
-    double X[IPT + 2], Y[IPT + 2];
-    uint32_t fs[IPT];
+    double X[FIPT + 2], Y[FIPT + 2];
+    uint32_t fs[FIPT];
     const bool in_main0 = k_seam > 0;            // item 0 belongs to layer 1
     const int per = f.n_line + f.n_turn;
     int c_idx = 0, c_off = 0, c_a = f.prim_first, c_r = 0;
@@ -457,12 +491,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     }
     bool straight = false;
     uint32_t run_fs = 0;
-    if (nvalid == IPT) {
+    if (nvalid == FIPT) {
         double ax = 0, ay = 0, bx = 0, by = 0, sx = 0, sy = 0;
         int r0 = 0, nl = 0;
         bool rot = false;
         if (in_main0) {
-            if (c_off + IPT <= f.n_line) {          // (a line never runs into layer 2: the seam follows a line END)
+            if (c_off + FIPT <= f.n_line) {          // (a line never runs into layer 2: the seam follows a line END)
                 const int pi = f.reverse_order ? (f.P - 1 - c_idx) : c_idx;
                 const bool go_left = f.start_from_right ? ((c_idx & 1) == 0) : ((c_idx & 1) == 1);
                 ax = go_left ? f.lex : f.lsx; bx = go_left ? f.lsx : f.lex; sx = go_left ? -f.line_step : f.line_step;
@@ -473,7 +507,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
             }
         } else {
             const DevPrim &p = prims[c_a];
-            if (p.kind == PRIM_LINSPACE && c_r + IPT <= p.n) {
+            if (p.kind == PRIM_LINSPACE && c_r + FIPT <= p.n) {
                 ax = p.a[0]; bx = p.a[2]; sx = p.a[4]; ay = p.a[1]; by = p.a[3]; sy = p.a[5];
                 r0 = c_r; nl = p.n; run_fs = p.fs;
                 straight = true;
@@ -481,7 +515,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         }
         if (straight) {
 #pragma unroll
-            for (int k = 0; k < IPT; ++k) {
+            for (int k = 0; k < FIPT; ++k) {
                 const int rk = r0 + k;
                 double px = (double)rk * sx + ax, py = (double)rk * sy + ay;   // numpy.linspace: k*step + start
                 if (rk == nl - 1) { px = bx; py = by; }                        // ... and the last sample is `stop`
@@ -493,7 +527,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     if (!straight) {
         bool in_main = in_main0;
 #pragma unroll 1
-        for (int k = 0; k < IPT; ++k) {
+        for (int k = 0; k < FIPT; ++k) {
             double px = 0.0, py = 0.0;
             uint32_t fw = 0;
             if (k < nvalid) {
@@ -514,39 +548,39 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
             }
             // compile-time indices only (runtime-indexed register arrays would go to scratch)
 #pragma unroll
-            for (int q = 0; q < IPT; ++q) if (q == k) { X[q + 1] = px; Y[q + 1] = py; fs[q] = fw; }
+            for (int q = 0; q < FIPT; ++q) if (q == k) { X[q + 1] = px; Y[q + 1] = py; fs[q] = fw; }
         }
     }
     FCPP_STAMP(2);
     // end neighbours: previous thread's last point, next thread's first point
-    X[0] = __shfl_up(X[IPT], 1); Y[0] = __shfl_up(Y[IPT], 1);
-    X[IPT + 1] = __shfl_down(X[1], 1); Y[IPT + 1] = __shfl_down(Y[1], 1);
+    X[0] = __shfl_up(X[FIPT], 1); Y[0] = __shfl_up(Y[FIPT], 1);
+    X[FIPT + 1] = __shfl_down(X[1], 1); Y[FIPT + 1] = __shfl_down(Y[1], 1);
     if (lane == 0) { S.efx[wave] = X[1]; S.efy[wave] = Y[1]; }
-    if (lane == 63) { S.elx[wave] = X[IPT]; S.ely[wave] = Y[IPT]; }
+    if (lane == 63) { S.elx[wave] = X[FIPT]; S.ely[wave] = Y[FIPT]; }
     __syncthreads();
     if (lane == 0) {
         if (wave > 0) { X[0] = S.elx[wave - 1]; Y[0] = S.ely[wave - 1]; }
         else { X[0] = S.back.px; Y[0] = S.back.py; }
     }
     if (lane == 63) {
-        if (wave < NWAVE - 1) { X[IPT + 1] = S.efx[wave + 1]; Y[IPT + 1] = S.efy[wave + 1]; }
-        else { X[IPT + 1] = S.fwd.px; Y[IPT + 1] = S.fwd.py; }
+        if (wave < FNWAVE - 1) { X[FIPT + 1] = S.efx[wave + 1]; Y[FIPT + 1] = S.efy[wave + 1]; }
+        else { X[FIPT + 1] = S.fwd.px; Y[FIPT + 1] = S.fwd.py; }
     }
 
     FCPP_STAMP(3);
     // ---- 2. segment lengths, curvature; everything that needs coordinates; then the coordinates leave --------
-    // d[k] = |P(item k) - P(item k-1)|; item -1 / item IPT are the end neighbours.  Bit k of `cut` = the sweeps do
+    // d[k] = |P(item k) - P(item k-1)|; item -1 / item FIPT are the end neighbours.  Bit k of `cut` = the sweeps do
     // not propagate across segment k: skipped steps (d < 1e-6, MLP:560-561 / 576-577) and the path ends.
-    double d[IPT + 1];
+    double d[FIPT + 1];
     unsigned cut = 0;
 #pragma unroll
-    for (int k = 0; k <= IPT; ++k) {
+    for (int k = 0; k <= FIPT; ++k) {
         d[k] = seg_len(X[k + 1] - X[k], Y[k + 1] - Y[k]);
         if ((d[k] < 1e-6) || (k == 0 && at_start) || (k == k_end + 1)) cut |= 1u << k;
     }
-    double kap[IPT];
+    double kap[FIPT];
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
+    for (int k = 0; k < FIPT; ++k) {
         double kk = 0.0;
         if (k < nvalid && !(k == 0 && at_start) && k != k_end)
             kk = curv_chords(X[k + 1] - X[k], Y[k + 1] - Y[k], d[k], X[k + 2] - X[k + 1], Y[k + 2] - Y[k + 1], d[k + 1]);
@@ -561,13 +595,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 out = out || (f.ex[e] * X[1] + f.ey[e] * Y[1] + f.eo[e] < -cst.geofence_tol)
-                          || (f.ex[e] * X[IPT] + f.ey[e] * Y[IPT] + f.eo[e] < -cst.geofence_tol);
+                          || (f.ex[e] * X[FIPT] + f.ey[e] * Y[FIPT] + f.eo[e] < -cst.geofence_tol);
             run_inside = !out;
         }
         const int ob0 = f.obs_first, ob1 = f.obs_first + f.obs_count;
         if (!run_inside || ob1 > ob0) {
 #pragma unroll
-            for (int k = 0; k < IPT; ++k) {
+            for (int k = 0; k < FIPT; ++k) {
                 if (k < nvalid) {
                     const double px = X[k + 1], py = Y[k + 1];
                     if (!run_inside) {
@@ -598,12 +632,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     FCPP_STAMP(5);
 
     // ---- 3. curvature clamp (MLP:490-504) -> u0 = (v/3.6)^2 ---------------------------------------------------
-    double c[IPT];
+    double c[FIPT];
     int adj = 0;
     unsigned clmask = 0;    // items slowed by the clamp
     const double ms_run = nominal_ms(run_fs, cst), vn_run = nominal_speed(run_fs, cst);
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
+    for (int k = 0; k < FIPT; ++k) {
         double ms = straight ? ms_run : nominal_ms(fs[k], cst);
         if (kap[k] > 1e-6) {
             bool cl;
@@ -618,9 +652,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     auto wk = [&](int k) -> double { return ((cut >> k) & 1u) ? FCPP_INF : two_a * d[k]; };   // coupling across segment k
     Agg fa = { FCPP_INF, 0.0 }, ba = { FCPP_INF, 0.0 };
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) { const double w = wk(k); fa.c = fmin(c[k], fa.c + w); fa.w += w; }
+    for (int k = 0; k < FIPT; ++k) { const double w = wk(k); fa.c = fmin(c[k], fa.c + w); fa.w += w; }
 #pragma unroll
-    for (int k = IPT - 1; k >= 0; --k) { const double w = wk(k + 1); ba.c = fmin(c[k], ba.c + w); ba.w += w; }
+    for (int k = FIPT - 1; k >= 0; --k) { const double w = wk(k + 1); ba.c = fmin(c[k], ba.c + w); ba.w += w; }
     Agg fi = fa, bi = ba;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -638,20 +672,20 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     if (lane == 63) eb = { FCPP_INF, 0.0 };
     Agg pre = { FCPP_INF, 0.0 }, suf = { FCPP_INF, 0.0 };
     for (int q = 0; q < wave; ++q) pre = combine_after(pre, S.wf[q]);
-    for (int q = NWAVE - 1; q > wave; --q) suf = combine_after(suf, S.wb[q]);
+    for (int q = FNWAVE - 1; q > wave; --q) suf = combine_after(suf, S.wb[q]);
     ef = combine_after(pre, ef);
     eb = combine_after(suf, eb);
     const double carry_f = S.back.carry, carry_b = S.fwd.carry;
     double uf = fmin(ef.c, carry_f + ef.w), ub = fmin(eb.c, carry_b + eb.w);
-    double vf[IPT];   // first the swept u = (v/3.6)^2, then the final speed in km/h
+    double vf[FIPT];   // first the swept u = (v/3.6)^2, then the final speed in km/h
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) { uf = fmin(c[k], uf + wk(k)); vf[k] = uf; }
+    for (int k = 0; k < FIPT; ++k) { uf = fmin(c[k], uf + wk(k)); vf[k] = uf; }
 #pragma unroll
-    for (int k = IPT - 1; k >= 0; --k) { ub = fmin(c[k], ub + wk(k + 1)); vf[k] = fmin(vf[k], ub); }
+    for (int k = FIPT - 1; k >= 0; --k) { ub = fmin(c[k], ub + wk(k + 1)); vf[k] = fmin(vf[k], ub); }
     const double b_first = ub;   // backward value at this thread's first item
     bool uniform = straight;     // every item (and the previous point) still runs at the run's nominal speed
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
+    for (int k = 0; k < FIPT; ++k) {
         if (vf[k] < c[k]) { vf[k] = sqrt(vf[k]) * 3.6; uniform = false; }     // slowed by a sweep
         else if ((clmask >> k) & 1u) {                                         // untouched: exactly the clamped value
             bool cl;
@@ -662,9 +696,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
 
     FCPP_STAMP(6);
     // ---- 5. previous point's final v / kappa / nominal v (for the segment metrics) ------------------
-    double vprev = __shfl_up(vf[IPT - 1], 1), kprev = __shfl_up(kap[IPT - 1], 1);
-    uint32_t fsprev = __shfl_up(fs[IPT - 1], 1);
-    if (lane == 63) { S.ev[wave] = vf[IPT - 1]; S.ek[wave] = kap[IPT - 1]; S.efs[wave] = fs[IPT - 1]; }
+    double vprev = __shfl_up(vf[FIPT - 1], 1), kprev = __shfl_up(kap[FIPT - 1], 1);
+    uint32_t fsprev = __shfl_up(fs[FIPT - 1], 1);
+    if (lane == 63) { S.ev[wave] = vf[FIPT - 1]; S.ek[wave] = kap[FIPT - 1]; S.efs[wave] = fs[FIPT - 1]; }
     __syncthreads();
     if (lane == 0) {
         if (wave > 0) { vprev = S.ev[wave - 1]; kprev = S.ek[wave - 1]; fsprev = S.efs[wave - 1]; }
@@ -687,13 +721,13 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         // (item 0's segment does not count if it starts the path or the headland layer)
         double sd = (at_start || k_seam == 0) ? 0.0 : d[0];
 #pragma unroll
-        for (int k = 1; k < IPT; ++k) sd += d[k];
+        for (int k = 1; k < FIPT; ++k) sd += d[k];
         const int layer = k_seam <= 0 ? 1 : 0;
         const double t = sd / fmax(ms_run, 0.1);
         s_len[layer] = sd; s_tpre[layer] = t; s_t[layer] = t;
     } else {
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) {
+        for (int k = 0; k < FIPT; ++k) {
             if (k < nvalid && !(k == 0 && at_start) && k != k_seam) {      // the seam main|headland belongs to neither layer
                 const int layer = k > k_seam ? 1 : 0;
                 const double vn_k = nominal_speed(fs[k], cst);
@@ -707,7 +741,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         }
     }
 #pragma unroll
-    for (int k = 0; k < IPT; ++k) {
+    for (int k = 0; k < FIPT; ++k) {
         if (k < nvalid && !(k == 0 && at_start) && k != k_end) {     // interior points of the path
             const double kp = k == 0 ? kprev : kap[k - 1];
             if (kap[k] > 0.0) {            // kappa == 0 contributes a_lat = 0: neither a maximum nor a violation
@@ -723,10 +757,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
     {
         uint32_t *b32 = reinterpret_cast<uint32_t *>(buf);
 #pragma unroll
-        for (int k = 0; k < IPT; ++k) b32[2 * lidx(lane * IPT + k)] = fs[k];
+        for (int k = 0; k < FIPT; ++k) b32[2 * lidx(lane * FIPT + k)] = fs[k];
         wave_sync();
 #pragma unroll
-        for (int m = 0; m < IPT; ++m) {
+        for (int m = 0; m < FIPT; ++m) {
             const int p = lane + 64 * m;
             if (p < cw) fso[g0 + p] = b32[2 * lidx(p)];
         }
@@ -750,7 +784,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         double a[9]; long long b[4];
         for (int k = 0; k < 9; ++k) a[k] = S.R.d[0][k];
         for (int k = 0; k < 4; ++k) b[k] = S.R.i[0][k];
-        for (int wv = 1; wv < NWAVE; ++wv) {
+        for (int wv = 1; wv < FNWAVE; ++wv) {
             for (int k = 0; k < 6; ++k) a[k] += S.R.d[wv][k];
             for (int k = 6; k < 9; ++k) a[k] = fmax(a[k], S.R.d[wv][k]);
             for (int k = 0; k < 4; ++k) b[k] += S.R.i[wv][k];
@@ -761,12 +795,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         tp.max_kappa = a[6]; tp.max_alat = a[7]; tp.max_jump = a[8];
         tp.n_viol = b[0]; tp.n_outside = b[1]; tp.n_in_obstacle = b[2]; tp.n_adjusted = b[3];
 #ifndef FCPP_DIAG_STAMPS
-        partial[blockIdx.x] = tp;
+        partial[tile_id] = tp;
 #endif
     }
 #ifdef FCPP_DIAG_STAMPS
     FCPP_STAMP(9);
-    if (tid == FCPP_DIAG_STAMPS * 64) {   // lane 0 of the chosen wave: phase durations in shader cycles
+    if (tid == 0) {   // lane 0 of the chosen wave: phase durations in shader cycles
         TilePartial tp;
         tp.main_len = (double)(stamp[1] - stamp[0]); tp.main_time_pre = (double)(stamp[2] - stamp[1]);
         tp.main_time = (double)(stamp[3] - stamp[2]); tp.head_len = (double)(stamp[4] - stamp[3]);
@@ -774,7 +808,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_plan_fused(const DevTile *__res
         tp.max_kappa = 0; tp.max_alat = 0; tp.max_jump = 0;
         tp.n_viol = (long long)(stamp[7] - stamp[6]); tp.n_outside = (long long)(stamp[8] - stamp[7]);
         tp.n_in_obstacle = (long long)(stamp[9] - stamp[8]); tp.n_adjusted = (long long)(stamp[9] - stamp[0]);
-        partial[blockIdx.x] = tp;
+        partial[tile_id] = tp;
     }
 #endif
 }
@@ -827,21 +861,32 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
-                      const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y,
-                      double *kappa, double *v, uint32_t *fs, TilePartial *partial)
+int launch_plan_quiet(hipStream_t st, int64_t n_ids, const int32_t *ids, const DevTile *tiles, const DevField *fields,
+                      const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
+                      uint32_t *fs, TilePartial *partial)
+{
+    if (n_ids <= 0) return 0;
+    hipLaunchKernelGGL(k_plan_quiet, dim3((unsigned)((n_ids + 3) / 4)), dim3(256), 0, st, tiles, fields, cst, obs, x, y, kappa, v,
+                       fs, partial, ids, n_ids);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,
+                      const DevField *fields, const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x,
+                      double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial)
 {
     if (n_tiles <= 0) return 0;
     // variant = register budget: minimum waves per SIMD the compiler must allow (3 -> <=168 VGPRs, 4 -> <=128, 2 -> <=256)
     if (variant == 4)
-        hipLaunchKernelGGL(k_plan_fused<4>, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
-                           kappa, v, fs, partial);
+        hipLaunchKernelGGL(k_plan_fused<4>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+                           kappa, v, fs, partial, ids);
     else if (variant == 2)
-        hipLaunchKernelGGL(k_plan_fused<2>, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
-                           kappa, v, fs, partial);
+        hipLaunchKernelGGL(k_plan_fused<2>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+                           kappa, v, fs, partial, ids);
     else
-        hipLaunchKernelGGL(k_plan_fused<3>, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
-                           kappa, v, fs, partial);
+        hipLaunchKernelGGL(k_plan_fused<3>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+                           kappa, v, fs, partial, ids);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -13,7 +13,7 @@
 
 namespace fcpp {
 
-constexpr int TILE_POINTS = 2048;  // points per workgroup tile (256 threads x 8)
+constexpr int TILE_POINTS = 512;   // points per tile: one wavefront x 8 points in the fused kernel, 256 threads x 2 in the staged ones
 
 enum PrimKind : int32_t { PRIM_POINT = 0, PRIM_LINSPACE = 1, PRIM_ARC = 2, PRIM_RAY = 3, PRIM_CAC = 4 };
 

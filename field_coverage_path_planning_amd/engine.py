@@ -226,6 +226,12 @@ class Batch:
         runs = max(nr.value, 1)
         return {self.lib.fcpp_batch_stage_name(self._last_mode, k).decode(): ms[k] / runs for k in range(ns.value)}, nr.value
 
+    def point_split(self):
+        """-> (points handled by k_plan_quiet, points handled by k_plan_fused) in the fused pipeline."""
+        q, g = C.c_int64(), C.c_int64()
+        L.check(self.lib.fcpp_batch_point_split(self.handle, C.byref(q), C.byref(g)))
+        return q.value, g.value
+
     def close(self):
         if getattr(self, 'handle', None):
             self.lib.fcpp_batch_destroy(self.handle)

@@ -170,6 +170,8 @@ int fcpp_batch_destroy(fcpp_batch *batch);
 int fcpp_batch_set_profiling(fcpp_batch *batch, int enable);
 int fcpp_batch_stage_times(fcpp_batch *batch, int max_stages, double *ms_sum_out, int *n_stages_out, int *n_runs_out);
 const char *fcpp_batch_stage_name(int mode, int stage);
+/* how the fused pipeline (mode 1) splits the batch: points handled by k_plan_quiet / by k_plan_fused */
+int fcpp_batch_point_split(const fcpp_batch *batch, int64_t *quiet_points, int64_t *general_points);
 
 /* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) ------- */
 /* _calculate_curvature for every interior point (MLP:513-536); end points get 0 */
