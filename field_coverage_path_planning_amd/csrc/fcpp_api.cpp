@@ -383,7 +383,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
     // modes 12/13/14: the fused kernel compiled for a minimum of 2/3/4 waves per SIMD (tuning only)
-    int variant = 3;
+    int variant = 4;
     if (mode >= 12 && mode <= 14) { variant = mode - 10; mode = 1; }
     if (mode != 0 && mode != 1) return fail(FCPP_EINVAL, "unknown pipeline mode");
     if (mode != b->last_mode) { b->prof_runs = 0; b->last_mode = mode; }
