@@ -1,0 +1,120 @@
+"""One process per GPU: shard a batch of independent fields over the ranks of a torch.distributed job.
+
+Fields never interact, so there is no data-path collective: each rank plans a contiguous block of fields,
+cut on the analytic point counts so that every GPU gets about the same number of POINTS (not fields).  The only
+communication is the final gather of the per-field stats (104 B per field) and, on request, of the point arrays, over RCCL
+(`torch.distributed` backend "nccl" on ROCm) -- or gloo for the CPU tests, which exercise exactly this file.
+
+Results do not depend on the shard count: tiles are anchored at field starts and every reduction runs in a fixed order.
+"""
+import numpy as np
+
+from . import _lib as L
+from . import engine as E
+
+
+def partition_by_points(point_counts, world_size):
+    """Contiguous blocks [lo, hi) of fields, one per rank, cut where the running point total crosses k/world of the total.
+
+    Deterministic, every field in exactly one block, blocks in rank order (some may be empty when fields are few)."""
+    counts = np.asarray(point_counts, dtype=np.int64)
+    n = len(counts)
+    if world_size <= 0:
+        raise ValueError('world_size must be positive')
+    csum = np.concatenate([[0], np.cumsum(counts)])
+    total = int(csum[-1])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        # first field boundary whose running total reaches the target, never before the previous cut
+        k = int(np.searchsorted(csum, target, side='left'))
+        k = min(max(k, cuts[-1]), n)
+        cuts.append(k)
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world():
+    """(rank, world_size) of the default process group, (0, 1) when torch.distributed is not initialised."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_rows(local_rows, rows_per_rank, dst=0):
+    """Gather 2-D tensors with a different number of rows per rank to `dst` (None elsewhere).
+
+    rows_per_rank is known to every rank (it follows from the host-side partition), so no size exchange is needed: ranks
+    send their block straight to the root (point-to-point over xGMI with the nccl backend: every peer uses its own link)."""
+    import torch
+    dist = _dist()
+    rank, ws = world()
+    if ws == 1:
+        return local_rows
+    if rank == dst:
+        parts, reqs = [], []
+        for r in range(ws):
+            if r == dst:
+                parts.append(local_rows)
+                continue
+            buf = torch.empty((rows_per_rank[r],) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype,
+                              device=local_rows.device)
+            parts.append(buf)
+            if rows_per_rank[r] > 0:
+                reqs.append(dist.irecv(buf, src=r))
+        for q in reqs:
+            q.wait()
+        return torch.cat(parts, dim=0)
+    if local_rows.shape[0] > 0:
+        dist.send(local_rows.contiguous(), dst=dst)
+    return None
+
+
+class ShardedResult:
+    def __init__(self, block, local, stats_all, infos):
+        self.block = block            # (lo, hi) fields of this rank
+        self.local = local            # engine.BatchResult of this rank's block (device tensors), None if the block is empty
+        self.stats_all = stats_all    # rank 0: (n_fields, 13) int64 tensor of fcpp_field_stats for ALL fields; else None
+        self.infos = infos            # fcpp_field_info of every field of the whole batch (host-side, same on every rank)
+
+    def stats(self):
+        """rank 0: dict of numpy arrays over all fields (same layout as BatchResult.stats())."""
+        if self.stats_all is None:
+            return None
+        raw = self.stats_all.cpu().numpy()
+        out = {}
+        for k, (n, _) in enumerate(L.FieldStats._fields_):
+            col = raw[:, k]
+            out[n] = col.view(np.float64).copy() if k < L.STATS_DOUBLES else col.copy()
+        return out
+
+
+def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1):
+    """Plan `specs` across all ranks of the current process group; per-field stats are gathered to rank 0.
+
+    compute(specs_block, vehicle, options) -> (n_block, 13) int64 tensor replaces the GPU batch in the CPU (gloo) tests."""
+    import torch
+    options = options or E.make_options()
+    rank, ws = world()
+    infos = E.plan_count(specs, vehicle, options)                       # host only, identical on every rank
+    counts = [i.n_main + i.n_head for i in infos]
+    blocks = partition_by_points(counts, ws)
+    lo, hi = blocks[rank]
+    local = None
+    if compute is not None:
+        stats_local = compute(specs[lo:hi], vehicle, options)
+    elif hi > lo:
+        batch = E.Batch(specs[lo:hi], vehicle, options, device=device)
+        local = batch.run(mode=mode)
+        stats_local = local.stats_raw
+    else:
+        dev = torch.device('cuda', device if device is not None else torch.cuda.current_device())
+        stats_local = torch.zeros((0, L.STATS_WORDS), dtype=torch.int64, device=dev)
+    stats_all = gather_rows(stats_local, [b[1] - b[0] for b in blocks], dst=0)
+    return ShardedResult((lo, hi), local, stats_all, infos)

@@ -297,3 +297,45 @@ def test_planner_class_end_to_end(golden_plans):
     assert abs(pl._calculate_path_length(r['approach_path']) - 11.9) < 0.05           # doc/V3.5.1:109-111
     with pytest.raises(ValueError):
         TwoLayerPathPlannerV37(VehicleParams(), field_length=15, field_width=200).plan_complete_coverage()
+
+
+def test_ga_solver_end_to_end():
+    from field_coverage_path_planning_amd.genetic_algorithm_solver import GAConfig, GeneticAlgorithmSolver
+    rng = np.random.default_rng(42)
+    pts = rng.uniform(0, 100, size=(24, 2))
+    D = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    s = GeneticAlgorithmSolver(GAConfig(population_size=120, max_generations=150, convergence_threshold=40), seed=3)
+    route, stats = s.solve(D, verbose=False)
+    assert sorted(route) == list(range(24)) and route[0] == 0                 # GA:118-120
+    assert stats['best_distance'] == pytest.approx(orc.ga_distance([route], D)[0], rel=1e-12)
+    random_mean = np.mean(orc.ga_distance(np.array([rng.permutation(24) for _ in range(200)]), D))
+    assert stats['best_distance'] < 0.6 * random_mean                          # it optimises
+    assert s._calculate_distance(route, D) == orc.ga_distance([route], D)[0]   # bit-exact single-tour entry point
+    assert s._calculate_fitness(route, D) == orc.ga_fitness([route], D)[0]
+
+
+def test_sharded_api_single_rank_matches_batch():
+    from field_coverage_path_planning_amd import sharding as S
+    specs, _ = _random_fields(11, 9)
+    res = S.plan_sharded(specs, _veh(DEFAULT_VP), E.make_options(1, 0.5))
+    assert res.block == (0, 9) and res.stats_all.shape == (9, 13)
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(1, 0.5))
+    assert np.array_equal(_np(b.run().stats_raw), _np(res.stats_all))          # deterministic reductions
+    b.close()
+
+
+def test_results_do_not_depend_on_batch_composition():
+    """A field planned alone or inside a batch (= on another rank of a sharded job) gives bit-identical arrays."""
+    specs, _ = _random_fields(21, 5, para=True)
+    o = E.make_options(1, 0.2)
+    b = E.Batch(specs, _veh(DEFAULT_VP), o)
+    r = b.run()
+    for i in (0, 3):
+        b1 = E.Batch([specs[i]], _veh(DEFAULT_VP), o)
+        r1 = b1.run()
+        sl = r.field_slice(i)
+        for name in ('x', 'y', 'kappa', 'v', 'flagseg'):
+            assert np.array_equal(_np(getattr(r, name))[sl], _np(getattr(r1, name))), (i, name)
+        assert np.array_equal(_np(r.stats_raw)[i], _np(r1.stats_raw)[0])
+        b1.close()
+    b.close()
