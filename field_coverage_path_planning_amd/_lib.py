@@ -116,6 +116,13 @@ def load():
             raise ImportError(
                 f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 f'or `make -C {os.path.join(_HERE, "csrc")}`; there is no CPU fallback')
+        # One HIP runtime per process: PyTorch's ROCm wheels bundle their own libamdhip64 (same SONAME as the system's).
+        # Imported first, torch's copy is the one libfcpp's DT_NEEDED resolves to, so streams and allocations are shared;
+        # loaded the other way round the process would end up with two runtimes that cannot see each other's streams.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in PROTOTYPES:
             fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol

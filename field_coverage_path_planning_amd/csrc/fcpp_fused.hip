@@ -221,7 +221,10 @@ __device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *
             const double step_len = sqrt(sx * sx + sy * sy);
             if (step_len >= 1e-6) {
                 const double needd = cst.u_cap / (two_a * step_len) + 3.0;
-                const bool ok = BACK ? ((double)pos - needd >= 0.0) : ((double)pos + needd <= (double)(np - 1));
+                // the neighbour's own curvature stencil must lie on the primitive too: it may not be the sample that
+                // faces the tile's side of the primitive's end (its kappa would see the next primitive)
+                const bool stencil_ok = BACK ? (pos <= np - 2) : (pos >= 1);
+                const bool ok = stencil_ok && (BACK ? ((double)pos - needd >= 0.0) : ((double)pos + needd <= (double)(np - 1)));
                 if (ok) {
                     if (lane == 0) {
                         const double ms = nominal_ms(fw, cst);

@@ -339,3 +339,31 @@ def test_results_do_not_depend_on_batch_composition():
         assert np.array_equal(_np(r.stats_raw)[i], _np(r1.stats_raw)[0])
         b1.close()
     b.close()
+
+
+@pytest.mark.parametrize('opt', [dict(sample_spacing=0.25), dict(turn_model=1, sample_spacing=0.1), dict()])
+def test_fused_equals_staged_over_many_tile_alignments(opt):
+    """The fused kernel takes shortcuts at tile edges (closed-form halos, quiet tiles); the staged pipeline has none.
+    600 fields whose sizes shift every primitive boundary through all alignments relative to the 512-point tiles."""
+    specs = [E.FieldSpec(field_length=100.0 + 0.37 * i, field_width=60.0 + 0.11 * i,
+                         start_point=(5.0, 5.0) if i % 4 == 0 else None) for i in range(600)]
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**opt))
+    r1 = b.run(mode=1)
+    keep = [t.clone() for t in (r1.x, r1.y, r1.kappa, r1.v, r1.flagseg, r1.stats_raw)]
+    r0 = b.run(mode=0)
+    assert torch_max_abs(keep[0], r0.x) == 0 and torch_max_abs(keep[1], r0.y) == 0     # same arithmetic: bit-equal
+    assert torch_max_abs(keep[2], r0.kappa) <= 1e-9
+    assert torch_max_abs(keep[3], r0.v) <= 1e-9
+    assert bool((keep[4] == r0.flagseg).all())
+    s1, s0 = E.BatchResult(b, *keep).stats(), r0.stats()
+    for k in ('main_len_m', 'main_time_s', 'main_time_pre_s', 'head_len_m', 'head_time_s', 'head_time_pre_s'):
+        np.testing.assert_allclose(s1[k], s0[k], rtol=1e-11, err_msg=k)
+    for k in ('max_kappa', 'max_alat', 'max_jump'):
+        np.testing.assert_allclose(s1[k], s0[k], rtol=1e-8, atol=1e-11, err_msg=k)
+    for k in ('n_viol', 'n_outside', 'n_in_obstacle', 'n_adjusted'):
+        assert np.array_equal(s1[k], s0[k]), k
+    b.close()
+
+
+def torch_max_abs(a, b):
+    return float((a - b).abs().max())
