@@ -154,7 +154,7 @@ struct fcpp_batch {
     DevBuf<DevPrim> prims;
     DevTiling til;
     DevBuf<int64_t> obs_off;
-    DevBuf<double> obs_x, obs_y;
+    DevBuf<double> obs_x, obs_y, obs_bbox;
     DevBuf<CacShape> shapes;   // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
     DevBuf<double2> tmpl_u, tmpl_c;   // sampled turn templates (fcpp_fused.hip)
     DevBuf<double> seg;        // connector segments
@@ -344,7 +344,16 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         std::vector<int64_t> po(obstacles->offsets, obstacles->offsets + n_polys + 1);
         const int64_t nv = po.back();
         std::vector<double> px(obstacles->x, obstacles->x + nv), py(obstacles->y, obstacles->y + nv);
-        ok(b->obs_off.upload(po, st)) && ok(b->obs_x.upload(px, st)) && ok(b->obs_y.upload(py, st));
+        std::vector<double> bb((size_t)n_polys * 4);
+        for (int64_t k = 0; k < n_polys; ++k) {
+            double mnx = HUGE_VAL, mny = HUGE_VAL, mxx = -HUGE_VAL, mxy = -HUGE_VAL;
+            for (int64_t q = po[(size_t)k]; q < po[(size_t)k + 1]; ++q) {
+                mnx = std::min(mnx, px[(size_t)q]); mxx = std::max(mxx, px[(size_t)q]);
+                mny = std::min(mny, py[(size_t)q]); mxy = std::max(mxy, py[(size_t)q]);
+            }
+            bb[(size_t)k * 4] = mnx; bb[(size_t)k * 4 + 1] = mny; bb[(size_t)k * 4 + 2] = mxx; bb[(size_t)k * 4 + 3] = mxy;
+        }
+        ok(b->obs_off.upload(po, st)) && ok(b->obs_x.upload(px, st)) && ok(b->obs_y.upload(py, st)) && ok(b->obs_bbox.upload(bb, st));
     }
     if (e == hipSuccess) {
         std::vector<double> seg((size_t)n_fields * 8, 0.0);
@@ -393,7 +402,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
     DevTiling &t = b->til;
-    DevObstacles obs = { b->obs_off.p, b->obs_x.p, b->obs_y.p };
+    DevObstacles obs = { b->obs_off.p, b->obs_x.p, b->obs_y.p, b->obs_bbox.p };
     HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
     hipEvent_t *ev = nullptr;
     if (b->profiling && b->prof_runs < kProfRuns) ev = &b->events[(size_t)b->prof_runs * (kStages + 1)];
@@ -574,7 +583,7 @@ int fcpp_verify(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n_paths, const int
     HIPCHK(kap.alloc((size_t)total));
     HIPCHK(vtmp.alloc((size_t)total));
     LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, 0, x, y, v, vtmp.p, kap.p, nullptr));
-    DevObstacles obs = { nullptr, nullptr, nullptr };
+    DevObstacles obs = { nullptr, nullptr, nullptr, nullptr };
     LAUNCHCHK(launch_validate(st, dt.n_tiles, dt.tiles.p, dt.paths.p, nullptr, cst, obs, x, y, kap.p, v, nullptr, dt.partial.p));
     LAUNCHCHK(launch_reduce_stats(st, dt.n_paths, dt.partial.p, dt.tile_first.p, nullptr, stats));
     HIPCHK(hipStreamSynchronize(st));

@@ -14,6 +14,7 @@ struct DevPath { int64_t off, n; };   // one path = points [off, off + n) of the
 struct DevObstacles {                 // batch obstacle polygons, CSR, device pointers
     const int64_t *offsets;
     const double *x, *y;
+    const double *bbox;               // 4 doubles per polygon: min_x, min_y, max_x, max_y (fused kernels: tile-level culling)
 };
 
 // by-value kernel argument: scalars + pointer to the two clothoid-arc-clothoid unit shapes

@@ -314,6 +314,56 @@ __device__ __forceinline__ long long wave_sum_i(int v)
     return v;
 }
 
+// ---- obstacle flags (build-defined validator): even-odd crossing test of the wave's points against the field's
+// obstacle polygons.  Culling first: lane b compares polygon b's bounding box with the bounding box of the wave's
+// points, a ballot collects the few candidates, and each candidate's vertices are staged in LDS (coalesced load, then
+// broadcast reads) before every lane tests its own points against all its edges.
+static constexpr int OBS_LDS_VERTS = 256;    // polygons with more vertices are read from global memory
+
+// returns the bit mask of the points (bit p = point p of this lane) that lie inside an obstacle
+template <int NP>
+__device__ __forceinline__ unsigned obstacle_mask(const DevObstacles &obs, int ob0, int ob1, double *lds /* 2*OBS_LDS_VERTS */,
+                                                  double bminx, double bminy, double bmaxx, double bmaxy,
+                                                  const double (&px)[NP], const double (&py)[NP], int nvalid)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned inside = 0;    // bit k: point k is inside some obstacle
+    for (int base = ob0; base < ob1; base += 64) {
+        const int b = base + lane;
+        bool hit = false;
+        if (b < ob1) {
+            const double *bb = obs.bbox + 4 * (int64_t)b;
+            hit = !(bb[0] > bmaxx || bb[2] < bminx || bb[1] > bmaxy || bb[3] < bminy);
+        }
+        unsigned long long cand = __ballot(hit);
+        while (cand) {
+            const int k = __ffsll((long long)cand) - 1;
+            cand &= cand - 1;
+            const int64_t a0 = obs.offsets[base + k], a1 = obs.offsets[base + k + 1];
+            const int nv = (int)(a1 - a0);
+            const bool staged = nv <= OBS_LDS_VERTS;
+            if (staged) {
+                wave_sync();
+                for (int q = lane; q < nv; q += 64) { lds[2 * q] = obs.x[a0 + q]; lds[2 * q + 1] = obs.y[a0 + q]; }
+                wave_sync();
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (p < nvalid && !((inside >> p) & 1u)) {
+                    bool in = false;
+                    for (int q = 0, r = nv - 1; q < nv; r = q++) {
+                        const double xi = staged ? lds[2 * q] : obs.x[a0 + q], yi = staged ? lds[2 * q + 1] : obs.y[a0 + q];
+                        const double xj = staged ? lds[2 * r] : obs.x[a0 + r], yj = staged ? lds[2 * r + 1] : obs.y[a0 + r];
+                        if (((yi > py[p]) != (yj > py[p])) && (px[p] < (xj - xi) * (py[p] - yi) / (yj - yi) + xi)) in = !in;
+                    }
+                    if (in) inside |= 1u << p;
+                }
+            }
+        }
+    }
+    return inside;
+}
+
 // ---- quiet tiles (flagged by the host): all 2048 points and everything within reach of the sweeps lie on one swath
 // line.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere, so the results are closed-form: no neighbours,
 // no scan, no LDS -- striped point order, every store instruction writes 512 contiguous bytes per wave.  A separate
@@ -349,50 +399,50 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
                             || (q.ex[e] * ex1 + q.ey[e] * ey1 + q.eo[e] < -cst.geofence_tol);
     const bool per_point = ends_out || q.obs_count > 0;
     const int64_t g0 = q.pt_off + tl.start;
+    __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
+    double *my_lds = obs_lds[threadIdx.x >> 6];
+    const double bminx = fmin(ex0, ex1), bmaxx = fmax(ex0, ex1), bminy = fmin(ey0, ey1), bmaxy = fmax(ey0, ey1);
     int nout = 0, nobs = 0;
     // each lane owns pairs of consecutive points: 16-byte stores, 1 KiB per wave instruction
+    auto outside = [&](double px, double py) -> bool {
+        bool out = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out = out || (q.ex[e] * px + q.ey[e] * py + q.eo[e] < -cst.geofence_tol);
+        return out;
+    };
 #pragma unroll
     for (int k = 0; k < TILE_POINTS / 128; ++k) {
         const int j = 2 * lane + 128 * k;
-        double px[2], py[2];
-        uint32_t fsw[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            px[h] = (double)(tl.off0 + j + h) * sx + ax; py[h] = y;     // numpy.linspace: k*step + start
-            if (rot) rotate_back(q, px[h], py[h]);
-            fsw[h] = fw;
-            if (per_point) {
-                bool out = false;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) out = out || (q.ex[e] * px[h] + q.ey[e] * py[h] + q.eo[e] < -cst.geofence_tol);
-                if (out) { ++nout; fsw[h] |= FCPP_FLAG_OUTSIDE; }
-                bool inside_any = false;
-                for (int b = q.obs_first; b < q.obs_first + q.obs_count && !inside_any; ++b) {
-                    const int64_t a0 = obs.offsets[b], a1 = obs.offsets[b + 1];
-                    bool in = false;
-                    for (int64_t u = a0, r = a1 - 1; u < a1; r = u++) {
-                        const double xi = obs.x[u], yi = obs.y[u], xj = obs.x[r], yj = obs.y[r];
-                        if (((yi > py[h]) != (yj > py[h])) && (px[h] < (xj - xi) * (py[h] - yi) / (yj - yi) + xi)) in = !in;
-                    }
-                    inside_any = in;
-                }
-                if (inside_any) { ++nobs; fsw[h] |= FCPP_FLAG_OBSTACLE; }
-            }
+        double px0 = (double)(tl.off0 + j) * sx + ax, py0 = y;          // numpy.linspace: k*step + start
+        double px1 = (double)(tl.off0 + j + 1) * sx + ax, py1 = y;
+        if (rot) { rotate_back(q, px0, py0); rotate_back(q, px1, py1); }
+        uint32_t f0 = fw, f1 = fw;
+        if (ends_out) {      // wave-uniform
+            const bool o0 = outside(px0, py0), o1 = outside(px1, py1);
+            nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
+            f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
+            f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
         }
-        // (tile starts are multiples of 512 points from 16-byte aligned bases: pt_off of every field is even? no -- only
-        // 8-byte alignment is guaranteed, so the pair is stored as two 8-byte halves when the address is odd)
+        if (q.obs_count > 0) {
+            const double ox[2] = { px0, px1 }, oy[2] = { py0, py1 };
+            const unsigned m = obstacle_mask<2>(obs, q.obs_first, q.obs_first + q.obs_count, my_lds, bminx, bminy, bmaxx, bmaxy,
+                                                ox, oy, 2);
+            nobs += (int)(m & 1u) + (int)((m >> 1) & 1u);
+            f0 |= (m & 1u) ? FCPP_FLAG_OBSTACLE : 0u;
+            f1 |= (m & 2u) ? FCPP_FLAG_OBSTACLE : 0u;
+        }
+        // pt_off of a field need not be even: only 8-byte alignment is guaranteed, so the pair is stored as two 8-byte
+        // halves when the address is odd
         const int64_t g = g0 + j;
         if ((g & 1) == 0) {
-            *reinterpret_cast<double2 *>(xo + g) = make_double2(px[0], px[1]);
-            *reinterpret_cast<double2 *>(yo + g) = make_double2(py[0], py[1]);
+            *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
+            *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
             *reinterpret_cast<double2 *>(ko + g) = make_double2(0.0, 0.0);
             *reinterpret_cast<double2 *>(vo + g) = make_double2(cst.v_work, cst.v_work);
-            *reinterpret_cast<uint2 *>(fso + g) = make_uint2(fsw[0], fsw[1]);
+            *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
         } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                xo[g + h] = px[h]; yo[g + h] = py[h]; ko[g + h] = 0.0; vo[g + h] = cst.v_work; fso[g + h] = fsw[h];
-            }
+            xo[g] = px0; yo[g] = py0; ko[g] = 0.0; vo[g] = cst.v_work; fso[g] = f0;
+            xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = 0.0; vo[g + 1] = cst.v_work; fso[g + 1] = f1;
         }
     }
     long long io = 0, ib = 0;
@@ -602,30 +652,36 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
             run_inside = !out;
         }
         const int ob0 = f.obs_first, ob1 = f.obs_first + f.obs_count;
-        if (!run_inside || ob1 > ob0) {
+        if (!run_inside) {
 #pragma unroll
             for (int k = 0; k < FIPT; ++k) {
                 if (k < nvalid) {
                     const double px = X[k + 1], py = Y[k + 1];
-                    if (!run_inside) {
-                        bool out = false;
+                    bool out = false;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) out = out || (f.ex[e] * px + f.ey[e] * py + f.eo[e] < -cst.geofence_tol);
-                        if (out) { ++nout; fs[k] |= FCPP_FLAG_OUTSIDE; }
-                    }
-                    bool inside_any = false;
-                    for (int b = ob0; b < ob1 && !inside_any; ++b) {
-                        const int64_t a0 = obs.offsets[b], a1 = obs.offsets[b + 1];
-                        bool in = false;
-                        for (int64_t q = a0, r = a1 - 1; q < a1; r = q++) {
-                            const double xi = obs.x[q], yi = obs.y[q], xj = obs.x[r], yj = obs.y[r];
-                            if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
-                        }
-                        inside_any = in;
-                    }
-                    if (inside_any) { ++nobs; fs[k] |= FCPP_FLAG_OBSTACLE; }
+                    for (int e = 0; e < 4; ++e) out = out || (f.ex[e] * px + f.ey[e] * py + f.eo[e] < -cst.geofence_tol);
+                    if (out) { ++nout; fs[k] |= FCPP_FLAG_OUTSIDE; }
                 }
             }
+        }
+        if (ob1 > ob0) {     // wave-uniform: bounding box of the wave's points, then culled + LDS-staged polygon tests
+            double mnx = FCPP_INF, mny = FCPP_INF, mxx = -FCPP_INF, mxy = -FCPP_INF;
+#pragma unroll
+            for (int k = 0; k < FIPT; ++k)
+                if (k < nvalid) { mnx = fmin(mnx, X[k + 1]); mxx = fmax(mxx, X[k + 1]); mny = fmin(mny, Y[k + 1]); mxy = fmax(mxy, Y[k + 1]); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mnx = fmin(mnx, __shfl_xor(mnx, o)); mny = fmin(mny, __shfl_xor(mny, o));
+                mxx = fmax(mxx, __shfl_xor(mxx, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+            }
+            double ox[FIPT], oy[FIPT];
+#pragma unroll
+            for (int k = 0; k < FIPT; ++k) { ox[k] = X[k + 1]; oy[k] = Y[k + 1]; }
+            const unsigned m = obstacle_mask<FIPT>(obs, ob0, ob1, buf, mnx, mny, mxx, mxy, ox, oy, nvalid);
+#pragma unroll
+            for (int k = 0; k < FIPT; ++k)
+                if ((m >> k) & 1u) { ++nobs; fs[k] |= FCPP_FLAG_OBSTACLE; }
+            wave_sync();
         }
     }
     FCPP_STAMP(4);
