@@ -73,9 +73,16 @@ struct Tiling {
     std::vector<DevPath> paths;
     std::vector<DevTile> tiles;
     std::vector<int64_t> tile_first;
-    struct QuietInfo { int64_t need, n_line, n_main; };   // need < 0: never quiet
-    // per (optional): points per pass (n_line + n_turn) of each field, for the fused kernel's layer-1 decode
-    void build(int64_t n_paths, const int64_t *offsets, const int64_t *per = nullptr, const QuietInfo *quiet = nullptr)
+    // layer-1 structure of a field, for the fused pipeline's tiling (need < 0: no quiet tiles)
+    struct QuietInfo { int64_t need, n_line, n_turn, P, n_main; };
+
+    // Tiles never straddle paths and hold at most TILE_POINTS points.  Without layer-1 information (standalone operators)
+    // a path is cut into near-equal tiles.  With it (planner batches) every swath line is cut as
+    //     [ need | quiet zone ............................. | need ] turn [ need | quiet zone ...
+    // quiet zone = samples whose sweep neighbourhood (need samples = u_cap / (2a) metres on either side) stays on the line:
+    // they become "quiet" tiles (closed-form kernel); everything else -- turns, their margins, the headland layer --
+    // becomes general tiles.  The cut depends only on the field itself, never on its position in the batch.
+    void build(int64_t n_paths, const int64_t *offsets, const QuietInfo *quiet = nullptr)
     {
         paths.resize((size_t)n_paths);
         tile_first.assign((size_t)n_paths + 1, 0);
@@ -84,21 +91,36 @@ struct Tiling {
             const int64_t n = offsets[p + 1] - offsets[p];
             paths[(size_t)p] = { offsets[p], n };
             tile_first[(size_t)p] = (int64_t)tiles.size();
-            for (int64_t s = 0; s < n; s += TILE_POINTS) {
+            const QuietInfo *q = quiet ? &quiet[p] : nullptr;
+            const int64_t per = q ? q->n_line + q->n_turn : 0;
+            auto emit = [&](int64_t s, int64_t cnt, int is_quiet) {
                 DevTile t;
-                t.field = (int32_t)p; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, n - s);
-                t.idx0 = 0; t.off0 = 0; t.quiet = 0; t._pad = 0;
-                if (per && per[p] > 0) { t.idx0 = (int32_t)(s / per[p]); t.off0 = (int32_t)(s % per[p]); }
-                if (quiet) {
-                    // whole tile + `need` samples on either side inside one swath line of layer 1 (need = samples that
-                    // span u_cap / (2a) metres: nothing farther away can influence the speeds inside the tile)
-                    const QuietInfo &q = quiet[p];
-                    if (q.need >= 0 && s + t.count <= q.n_main && t.count == TILE_POINTS && t.off0 >= q.need &&
-                        (int64_t)t.off0 + t.count + q.need <= q.n_line)
-                        t.quiet = 1;
-                }
+                t.field = (int32_t)p; t.start = s; t.count = (int32_t)cnt; t.quiet = is_quiet; t._pad = 0;
+                t.idx0 = 0; t.off0 = 0;
+                if (per > 0 && s < q->n_main) { t.idx0 = (int32_t)(s / per); t.off0 = (int32_t)(s % per); }
                 tiles.push_back(t);
+            };
+            auto emit_general = [&](int64_t a, int64_t b) {
+                const int64_t len = b - a;
+                if (len <= 0) return;
+                const int64_t k = (len + TILE_POINTS - 1) / TILE_POINTS, base = len / k, rem = len % k;
+                for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(a, c, 0); a += c; }
+            };
+            int64_t pos = 0;
+            if (q && q->need >= 0 && per > 0) {
+                for (int64_t idx = 0; idx < q->P; ++idx) {
+                    const int64_t L0 = idx * per;
+                    const int64_t zs = L0 + q->need, ze = L0 + q->n_line - q->need, Z = ze - zs;
+                    if (Z < 64) continue;
+                    emit_general(pos, zs);
+                    // near-equal quiet tiles of at most TILE_POINTS - 2 points (the kernel stores aligned PAIRS; a tile that
+                    // starts on an odd global index needs one pair more than half its points)
+                    const int64_t cap = TILE_POINTS - 2, k = (Z + cap - 1) / cap, base = Z / k, rem = Z % k;
+                    for (int64_t i = 0, s0 = zs; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(s0, c, 1); s0 += c; }
+                    pos = ze;
+                }
             }
+            emit_general(pos, n);
         }
         tile_first[(size_t)n_paths] = (int64_t)tiles.size();
     }
@@ -113,7 +135,7 @@ struct DevTiling {
     DevBuf<TilePartial> partial;
     DevBuf<unsigned long long> n_adj;
     DevBuf<int32_t> quiet_ids, general_ids;   // fused pipeline: tiles by kernel
-    int64_t n_tiles = 0, n_paths = 0, n_quiet = 0, n_general = 0;
+    int64_t n_tiles = 0, n_paths = 0, n_quiet = 0, n_general = 0, quiet_points = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
     {
         n_tiles = (int64_t)t.tiles.size(); n_paths = (int64_t)t.paths.size();
@@ -128,7 +150,11 @@ struct DevTiling {
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
         std::vector<int32_t> qv, gv;
-        for (size_t i = 0; i < t.tiles.size(); ++i) (t.tiles[i].quiet ? qv : gv).push_back((int32_t)i);
+        quiet_points = 0;
+        for (size_t i = 0; i < t.tiles.size(); ++i) {
+            (t.tiles[i].quiet ? qv : gv).push_back((int32_t)i);
+            if (t.tiles[i].quiet) quiet_points += t.tiles[i].count;
+        }
         n_quiet = (int64_t)qv.size(); n_general = (int64_t)gv.size();
         if ((e = quiet_ids.upload(qv, st)) != hipSuccess) return e;
         if ((e = general_ids.upload(gv, st)) != hipSuccess) return e;
@@ -315,18 +341,16 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     Tiling til;
     std::vector<int64_t> offs((size_t)n_fields + 1, 0);
     for (int64_t i = 0; i < n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
-    std::vector<int64_t> per((size_t)n_fields, 0);
-    for (int64_t i = 0; i < n_fields; ++i) per[(size_t)i] = (int64_t)b->hp.fields[(size_t)i].n_line + b->hp.fields[(size_t)i].n_turn;
     std::vector<Tiling::QuietInfo> qi((size_t)n_fields);
     for (int64_t i = 0; i < n_fields; ++i) {
         const DevField &df = b->hp.fields[(size_t)i];
         const double step = fabs(df.line_step);
-        Tiling::QuietInfo q = { -1, df.n_line, df.n_main };
+        Tiling::QuietInfo q = { -1, df.n_line, df.n_turn, df.P, df.n_main };
         if (df.n_total > 0 && step >= 1e-6 && df.n_line > 2)
             q.need = (int64_t)(b->cst.u_cap / (2 * b->cst.a_lon * step)) + 3;
         qi[(size_t)i] = q;
     }
-    til.build(n_fields, offs.data(), per.data(), qi.data());
+    til.build(n_fields, offs.data(), qi.data());
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
     ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st)) &&
@@ -469,7 +493,7 @@ int fcpp_batch_stage_times(fcpp_batch *b, int max_stages, double *ms_sum, int *n
 int fcpp_batch_point_split(const fcpp_batch *b, int64_t *quiet_points, int64_t *general_points)
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
-    const int64_t q = b->til.n_quiet * TILE_POINTS;
+    const int64_t q = b->til.quiet_points;
     if (quiet_points) *quiet_points = q;
     if (general_points) *general_points = b->hp.total_points - q;
     return FCPP_OK;

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
     const bool rot = q.rotated != 0;
     const uint32_t fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
     // geofence by convexity: both end points inside => the whole segment is inside
-    double ex0 = (double)tl.off0 * sx + ax, ey0 = y, ex1 = (double)(tl.off0 + TILE_POINTS - 1) * sx + ax, ey1 = y;
+    const int cnt = tl.count;    // <= TILE_POINTS, even except possibly for the last tile of a line
+    double ex0 = (double)tl.off0 * sx + ax, ey0 = y, ex1 = (double)(tl.off0 + cnt - 1) * sx + ax, ey1 = y;
     if (rot) { rotate_back(q, ex0, ey0); rotate_back(q, ex1, ey1); }
     bool ends_out = false;
 #pragma unroll
@@ -410,47 +411,52 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
         for (int e = 0; e < 4; ++e) out = out || (q.ex[e] * px + q.ey[e] * py + q.eo[e] < -cst.geofence_tol);
         return out;
     };
+    // Aligned pairs: pair m covers the tile-local points (2m - odd, 2m - odd + 1), whose global index is even whatever the
+    // parity of the tile's first global index (odd = 1: the tile's first point is the second half of pair 0).
+    const int odd = (int)(g0 & 1);
 #pragma unroll
     for (int k = 0; k < TILE_POINTS / 128; ++k) {
-        const int j = 2 * lane + 128 * k;
+        const int j = 2 * (lane + 64 * k) - odd;
+        const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;     // (no early exit: the obstacle test below is wave-wide)
         double px0 = (double)(tl.off0 + j) * sx + ax, py0 = y;          // numpy.linspace: k*step + start
         double px1 = (double)(tl.off0 + j + 1) * sx + ax, py1 = y;
         if (rot) { rotate_back(q, px0, py0); rotate_back(q, px1, py1); }
         uint32_t f0 = fw, f1 = fw;
         if (ends_out) {      // wave-uniform
-            const bool o0 = outside(px0, py0), o1 = outside(px1, py1);
+            const bool o0 = has0 && outside(px0, py0), o1 = has1 && outside(px1, py1);
             nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
             f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
             f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
         }
         if (q.obs_count > 0) {
-            const double ox[2] = { px0, px1 }, oy[2] = { py0, py1 };
+            // lanes without a valid first point test only their second one (or nothing)
+            const double ox[2] = { has0 ? px0 : px1, px1 }, oy[2] = { has0 ? py0 : py1, py1 };
             const unsigned m = obstacle_mask<2>(obs, q.obs_first, q.obs_first + q.obs_count, my_lds, bminx, bminy, bmaxx, bmaxy,
-                                                ox, oy, 2);
-            nobs += (int)(m & 1u) + (int)((m >> 1) & 1u);
-            f0 |= (m & 1u) ? FCPP_FLAG_OBSTACLE : 0u;
-            f1 |= (m & 2u) ? FCPP_FLAG_OBSTACLE : 0u;
+                                                ox, oy, has1 ? 2 : (has0 ? 1 : 0));
+            const bool b0 = has0 && (m & 1u), b1 = has1 && (m & 2u);
+            nobs += (b0 ? 1 : 0) + (b1 ? 1 : 0);
+            f0 |= b0 ? FCPP_FLAG_OBSTACLE : 0u;
+            f1 |= b1 ? FCPP_FLAG_OBSTACLE : 0u;
         }
-        // pt_off of a field need not be even: only 8-byte alignment is guaranteed, so the pair is stored as two 8-byte
-        // halves when the address is odd
-        const int64_t g = g0 + j;
-        if ((g & 1) == 0) {
+        const int64_t g = g0 + j;      // even
+        if (has0 && has1) {
             *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
             *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
             *reinterpret_cast<double2 *>(ko + g) = make_double2(0.0, 0.0);
             *reinterpret_cast<double2 *>(vo + g) = make_double2(cst.v_work, cst.v_work);
             *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
-        } else {
+        } else if (has0) {
             xo[g] = px0; yo[g] = py0; ko[g] = 0.0; vo[g] = cst.v_work; fso[g] = f0;
+        } else if (has1) {
             xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = 0.0; vo[g + 1] = cst.v_work; fso[g + 1] = f1;
         }
     }
     long long io = 0, ib = 0;
     if (per_point) { io = wave_sum_i(nout); ib = wave_sum_i(nobs); }   // wave-uniform
     if (lane == 0) {
-        // TILE_POINTS segments of |line_step| each (the tile's first segment comes from its left neighbour on the same line)
+        // cnt segments of |line_step| each (the tile's first segment comes from its left neighbour on the same line)
         TilePartial tp;
-        const double len = (double)TILE_POINTS * fabs(sx), t = len / fmax(cst.ms_work, 0.1);
+        const double len = (double)cnt * fabs(sx), t = len / fmax(cst.ms_work, 0.1);
         tp.main_len = len; tp.main_time_pre = t; tp.main_time = t;
         tp.head_len = tp.head_time_pre = tp.head_time = 0.0;
         tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
@@ -619,17 +625,24 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         if (wave < FNWAVE - 1) { X[FIPT + 1] = S.efx[wave + 1]; Y[FIPT + 1] = S.efy[wave + 1]; }
         else { X[FIPT + 1] = S.fwd.px; Y[FIPT + 1] = S.fwd.py; }
     }
+    // a tile may hold fewer than 512 points anywhere on the path: the successor of its last point is the forward halo point
+    if (nvalid > 0 && j0 + nvalid == cnt) {
+#pragma unroll
+        for (int q = 1; q <= FIPT; ++q) if (q == nvalid) { X[q + 1] = S.fwd.px; Y[q + 1] = S.fwd.py; }
+    }
 
     FCPP_STAMP(3);
     // ---- 2. segment lengths, curvature; everything that needs coordinates; then the coordinates leave --------
     // d[k] = |P(item k) - P(item k-1)|; item -1 / item FIPT are the end neighbours.  Bit k of `cut` = the sweeps do
     // not propagate across segment k: skipped steps (d < 1e-6, MLP:560-561 / 576-577) and the path ends.
+    // Bit k of `nocouple` = segment k lies beyond the tile's last point (both ends are padding): coupling 0, the identity.
     double d[FIPT + 1];
-    unsigned cut = 0;
+    unsigned cut = 0, nocouple = 0;
 #pragma unroll
     for (int k = 0; k <= FIPT; ++k) {
         d[k] = seg_len(X[k + 1] - X[k], Y[k + 1] - Y[k]);
         if ((d[k] < 1e-6) || (k == 0 && at_start) || (k == k_end + 1)) cut |= 1u << k;
+        if (k > nvalid || nvalid == 0) nocouple |= 1u << k;
     }
     double kap[FIPT];
 #pragma unroll
@@ -707,8 +720,10 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     }
 
     // ---- 4. forward / backward sweeps as min-plus scans over registers ----------------------------
-    // (items beyond a partial tile have c = +inf; they sit at the path end, where nothing propagates)
-    auto wk = [&](int k) -> double { return ((cut >> k) & 1u) ? FCPP_INF : two_a * d[k]; };   // coupling across segment k
+    // (lanes / items beyond the tile's last point are identities: c = +inf, coupling 0)
+    auto wk = [&](int k) -> double {   // coupling across segment k
+        return ((nocouple >> k) & 1u) ? 0.0 : (((cut >> k) & 1u) ? FCPP_INF : two_a * d[k]);
+    };
     Agg fa = { FCPP_INF, 0.0 }, ba = { FCPP_INF, 0.0 };
 #pragma unroll
     for (int k = 0; k < FIPT; ++k) { const double w = wk(k); fa.c = fmin(c[k], fa.c + w); fa.w += w; }
