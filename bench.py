@@ -61,7 +61,8 @@ def main():
     ap.add_argument('--fields', type=int, default=1024)
     ap.add_argument('--spacing', type=float, default=0.1)
     ap.add_argument('--turn-model', type=int, default=1, help='1 = clothoid (default), 0 = arcs')
-    ap.add_argument('--mode', type=int, default=1, help='1 = fused single-pass kernel (default), 0 = staged pipeline')
+    ap.add_argument('--mode', type=int, default=1,
+                    help='1 = fused single pass (default), 0 = staged pipeline; 2 / 3 / 12-14: tuning variants, see fcpp_batch_run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -127,7 +128,10 @@ def main():
         dom_ms = stage_ms[dom]
         # points the dominant kernel itself processes per launch (the fused pipeline splits the tiles over two kernels)
         q_pts, g_pts = batch.point_split()
-        dom_points = {'k_plan_quiet': q_pts, 'k_plan_fused': g_pts}.get(dom, n_points) if args.mode >= 1 else n_points
+        if args.mode in (1, 12, 13, 14):      # quiet and general tiles as two launches
+            dom_points = {'k_plan_quiet': q_pts, 'k_plan_fused': g_pts}.get(dom, n_points)
+        else:                   # one launch covers every tile (fused) / every kernel sees every point (staged)
+            dom_points = n_points
         achieved = BYTES_PER_POINT * dom_points / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         pipe_ms = sum(stage_ms.values())
         traffic = None
@@ -149,8 +153,11 @@ def main():
                             f'{"clothoid" if args.turn_model else "arc"} turns, {args.spacing} m sample spacing, '
                             f'default VehicleParams',
                 'points_per_gpu_step': n_points, 'fields_per_gpu': args.fields,
-                'pipeline': ('fused single pass: k_plan_quiet (tiles on one swath line, closed form) + k_plan_fused (the rest)'
-                             if args.mode >= 1 else 'staged (7 kernels)'),
+                'pipeline': ('staged (7 kernels)' if args.mode == 0 else
+                             'fused single pass, one launch (quiet and general tiles mixed)' if args.mode == 2 else
+                             'fused single pass, two launches on two streams' if args.mode == 3 else
+                             'fused single pass: k_plan_quiet (closed-form tiles on swath lines) + k_plan_fused (all other tiles)'),
+                'quiet_points': q_pts, 'general_points': g_pts,
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -415,9 +415,13 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
                    fcpp_field_stats *stats, int mode)
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
-    // modes 12/13/14: the fused kernel compiled for a minimum of 2/3/4 waves per SIMD (tuning only)
+    // mode 1 (default): quiet tiles (k_plan_quiet, streaming) and general tiles (k_plan_fused) as two launches.
+    // Tuning only: mode 2 = one launch with both tile kinds mixed in the grid (measured: no faster, the two kinds do not
+    // overlap usefully); modes 12/13/14 = mode 1 with k_plan_fused compiled for a minimum of 2/3/4 waves per SIMD.
     int variant = 4;
+    bool split = true;
     if (mode >= 12 && mode <= 14) { variant = mode - 10; mode = 1; }
+    if (mode == 2) { split = false; mode = 1; }
     if (mode != 0 && mode != 1) return fail(FCPP_EINVAL, "unknown pipeline mode");
     if (mode != b->last_mode) { b->prof_runs = 0; b->last_mode = mode; }
     if (b->n_fields == 0) return FCPP_OK;
@@ -437,9 +441,15 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     } while (0)
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (mode == 1) {
-        STAGE(0, launch_plan_quiet(st, t.n_quiet, t.quiet_ids.p, t.tiles.p, b->fields.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
-        STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y,
-                                   kappa, v, fs, t.partial.p));
+        if (split) {
+            STAGE(0, launch_plan_quiet(st, t.n_quiet, t.quiet_ids.p, t.tiles.p, b->fields.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+            STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
+                                       y, kappa, v, fs, t.partial.p));
+        } else {
+            if (ev) HIPCHK(hipEventRecord(ev[1], st));   // (no separate quiet launch: stage 0 has zero duration)
+            STAGE(1, launch_plan_fused(st, variant, t.n_tiles, nullptr, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa,
+                                       v, fs, t.partial.p));
+        }
         STAGE(2, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, nullptr, stats));
         if (ev) ++b->prof_runs;
         return FCPP_OK;

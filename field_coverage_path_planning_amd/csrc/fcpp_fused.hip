@@ -368,19 +368,13 @@ __device__ __forceinline__ unsigned obstacle_mask(const DevObstacles &obs, int o
 // line.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere, so the results are closed-form: no neighbours,
 // no scan, no LDS -- striped point order, every store instruction writes 512 contiguous bytes per wave.  A separate
 // kernel so that it runs at full occupancy: it is pure HBM streaming.
-__global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ tiles, const DevField *__restrict__ fields,
-                                                      DevConst cst, DevObstacles obs, double *__restrict__ xo,
-                                                      double *__restrict__ yo, double *__restrict__ ko,
-                                                      double *__restrict__ vo, uint32_t *__restrict__ fso,
-                                                      TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
-                                                      int64_t n_ids)
+__device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const DevField *fg, const DevConst &cst,
+                                           const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
+                                           double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
+                                           double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                           TilePartial *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one tile per wavefront
-    if (slot >= n_ids) return;
-    const int tile_id = ids[slot];
-    const DevTile tl = tiles[tile_id];
-    const DevField *fg = &fields[tl.field];
     const DevField &q = *fg;
     const int idx = tl.idx0;
     const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
@@ -400,8 +394,6 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
                             || (q.ex[e] * ex1 + q.ey[e] * ey1 + q.eo[e] < -cst.geofence_tol);
     const bool per_point = ends_out || q.obs_count > 0;
     const int64_t g0 = q.pt_off + tl.start;
-    __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
-    double *my_lds = obs_lds[threadIdx.x >> 6];
     const double bminx = fmin(ex0, ex1), bmaxx = fmax(ex0, ex1), bminy = fmin(ey0, ey1), bmaxy = fmax(ey0, ey1);
     int nout = 0, nobs = 0;
     // each lane owns pairs of consecutive points: 16-byte stores, 1 KiB per wave instruction
@@ -465,6 +457,22 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
     }
 }
 
+// stand-alone launch of the quiet path (tuning / profiling; the default pipeline runs it inside k_plan_fused)
+__global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ tiles, const DevField *__restrict__ fields,
+                                                      DevConst cst, DevObstacles obs, double *__restrict__ xo,
+                                                      double *__restrict__ yo, double *__restrict__ ko,
+                                                      double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                                      TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
+                                                      int64_t n_ids)
+{
+    __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one tile per wavefront
+    if (slot >= n_ids) return;
+    const int tile_id = ids[slot];
+    const DevTile tl = tiles[tile_id];
+    quiet_tile(tl, tile_id, &fields[tl.field], cst, obs, obs_lds[threadIdx.x >> 6], xo, yo, ko, vo, fso, partial);
+}
+
 // Diagnostic build only (-DFCPP_DIAG_STAMPS, never shipped): phase time stamps of wave 1 replace the tile's metrics.
 #ifdef FCPP_DIAG_STAMPS
 #define FCPP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); stamp[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -490,6 +498,10 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     const DevTile tl = tiles[tile_id];
     const DevField *fg = &fields[tl.field];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tl.quiet) {     // closed-form tile: pure streaming; mixed into the same grid so that it overlaps the ALU-bound tiles
+        quiet_tile(tl, tile_id, fg, cst, obs, S.tr[0], xo, yo, ko, vo, fso, partial);
+        return;
+    }
     // The field descriptor is block-uniform and used all over the kernel.  Read lazily it costs dozens of dependent
     // scalar-load round trips per wave; instead: one coalesced vector load into LDS, one barrier, then every word is
     // broadcast-read and moved to a scalar register (readfirstlane) in one go.

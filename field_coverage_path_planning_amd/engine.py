@@ -198,7 +198,7 @@ class Batch:
         if buffers is None:
             buffers = self.alloc()
         x, y, kappa, v, fs, stats = buffers
-        self._last_mode = 1 if int(mode) >= 12 else int(mode)
+        self._last_mode = 1 if int(mode) >= 1 else 0
         self.ctx.bind_stream()
         L.check(self.lib.fcpp_batch_run(self.handle, _ptr(x), _ptr(y), _ptr(kappa), _ptr(v), _ptr(fs), _ptr(stats),
                                         int(mode)))

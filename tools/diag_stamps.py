@@ -17,7 +17,7 @@ specs = [E.FieldSpec(field_length=float(x), field_width=float(y)) for x, y in LH
 b = E.Batch(specs, E.make_vehicle(), E.make_options(1, 0.1))
 bufs = b.alloc()
 for _ in range(2):
-    res = b.run(bufs, mode=int(os.environ.get('FCPP_MODE', '14')))
+    res = b.run(bufs, mode=int(os.environ.get('FCPP_MODE', '2')))
 torch.cuda.synchronize()
 st = res.stats()
 q, g = b.point_split()
