@@ -63,6 +63,7 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     const double vm = std::max(std::max(veh.max_work_speed_kmh, veh.max_headland_speed_kmh),
                                std::max(veh.headland_turn_speed_kmh, 2.5)) / 3.6;
     c.u_cap = vm * vm;
+    c.inv_sf36 = 1.0 / (c.sf * 3.6);
     c.ms_work = c.v_work / 3.6; c.ms_turn = c.v_turn / 3.6; c.ms_head = c.v_head / 3.6; c.ms_rev = 2.5 / 3.6;
     c.shapes = nullptr; c.tmpl_u = nullptr; c.tmpl_c = nullptr;
     return c;

@@ -215,15 +215,8 @@ __device__ __forceinline__ double nominal_speed(uint32_t fs, const DevConst &c)
     }
 }
 
-// out-of-line variants for the rare cases of the fused kernel (turn points, primitive boundaries):
-// keeping them out of the unrolled per-item loops is what keeps that kernel's register budget sane
-__device__ __noinline__ GenOut gen_point_slow(const DevField *f, const DevPrim *prims, int64_t i, const DevConst *cst)
-{
-    GenOut o;
-    gen_point(*f, prims, i, *cst, o);
-    return o;
-}
-
+// out-of-line atan2 for the fused kernel: only turn points reach it, and keeping it out of the unrolled per-item loops keeps
+// that kernel's register budget sane
 __device__ __noinline__ double atan2_slow(double y, double x) { return atan2(y, x); }
 
 __device__ __forceinline__ double nominal_ms(uint32_t fs, const DevConst &c)

@@ -24,6 +24,7 @@ struct DevConst {
     double v_work, v_turn, v_head;
     double u_cap;              // (max nominal speed / 3.6)^2: no sweep constraint can bind above this
     double ms_work, ms_turn, ms_head, ms_rev;   // the four nominal speeds in m/s (v / 3.6, IEEE division on the host)
+    double inv_sf36;           // 1 / (safety_factor * 3.6), for the clamp pre-test
     const CacShape *shapes;
     const double2 *tmpl_u, *tmpl_c;   // turn templates of the batch (fused kernel), see TurnTemplates
 };

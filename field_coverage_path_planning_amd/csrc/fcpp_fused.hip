@@ -77,11 +77,15 @@ __device__ __forceinline__ double curv_chords(double dx1, double dy1, double ds1
     return fabs(2 * dth / (ds1 + ds2));
 }
 
-// speed after the curvature clamp (MLP:496-504); nominal = the primitive's nominal speed
+// speed after the curvature clamp (MLP:496-504); nominal = the primitive's nominal speed.
+// v_nom > sqrt(a_lat / kappa) * sf * 3.6  <=>  kappa * (v_nom / (sf * 3.6))^2 > a_lat: points that are clearly not clamped
+// (the vast majority of turn points) are decided by that product, without the square root and the division.
 __device__ __forceinline__ double clamped_speed(double v_nom, double kappa, const DevConst &cst, bool &clamped)
 {
     clamped = false;
     if (kappa > 1e-6) {
+        const double q = v_nom * cst.inv_sf36;
+        if (kappa * q * q < cst.a_lat * (1.0 - 1e-9)) return v_nom;
         const double vmax_ms = sqrt(cst.a_lat / kappa) * cst.sf;
         const double vmax_kmh = vmax_ms * 3.6;
         if (v_nom > vmax_kmh) { clamped = true; return vmax_kmh; }
@@ -598,7 +602,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     if (!straight) {
         bool in_main = in_main0;
 #pragma unroll 1
-        for (int k = 0; k < FIPT; ++k) {
+        for (int k = 0; k < FIPT; ++k) {      // rolled: one copy of the evaluators (unrolling costs more in registers than it saves)
             double px = 0.0, py = 0.0;
             uint32_t fw = 0;
             if (k < nvalid) {
@@ -820,7 +824,9 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
                 const double vp = k == 0 ? vprev : vf[k - 1];
                 const double vnp = k == 0 ? vnprev : nominal_speed(fs[k - 1], cst);
                 s_len[layer] += d[k];
-                const double tpre = d[k] / fmax(((vnp + vn_k) / 2) / 3.6, 0.1);
+                // (v + v) / 2 / 3.6 == v / 3.6: equal nominal speeds on both ends take the tabulated m/s value
+                const double ms_pre = (vnp == vn_k) ? nominal_ms(fs[k], cst) : ((vnp + vn_k) / 2) / 3.6;
+                const double tpre = d[k] / fmax(ms_pre, 0.1);
                 s_tpre[layer] += tpre;
                 s_t[layer] += (vp == vnp && vf[k] == vn_k) ? tpre : d[k] / fmax(((vp + vf[k]) / 2) / 3.6, 0.1);
             }

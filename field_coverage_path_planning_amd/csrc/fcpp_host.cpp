@@ -169,7 +169,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         tt.c_end = cloth ? sh_half.T * Re_half : kHalfPi; tt.c_step = lin_step(0.0, tt.c_end, tt.nc); tt.c_Re = Re_half;
     }
     out.info.assign((size_t)n, fcpp_field_info());
-    out.fields.clear(); out.prims.clear(); out.tiles.clear();
+    out.fields.clear(); out.prims.clear();
     if (want_device) out.fields.reserve((size_t)n);
     int64_t pt_off = 0;
 
@@ -384,12 +384,6 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
                 df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
             }
             out.fields.push_back(df);
-            for (int64_t s = 0; s < pos; s += TILE_POINTS) {
-                DevTile t;
-                t.field = (int32_t)fi; t.start = s; t.count = (int32_t)std::min<int64_t>(TILE_POINTS, pos - s);
-                t.idx0 = 0; t.off0 = 0; t.quiet = 0; t._pad = 0;
-                out.tiles.push_back(t);
-            }
         }
         pt_off += pos;
     }

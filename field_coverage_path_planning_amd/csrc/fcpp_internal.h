@@ -95,7 +95,6 @@ struct HostPlan {
     std::vector<fcpp_field_info> info;
     std::vector<DevField> fields;
     std::vector<DevPrim> prims;
-    std::vector<DevTile> tiles;
     TurnTemplates tt;
     int64_t total_points = 0;
 };

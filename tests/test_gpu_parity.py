@@ -367,3 +367,66 @@ def test_fused_equals_staged_over_many_tile_alignments(opt):
 
 def torch_max_abs(a, b):
     return float((a - b).abs().max())
+
+
+def test_edge_case_fields_vs_oracle():
+    """Tiny / degenerate geometries: reversed swath lines (line_end_x < line_start_x), single pass, fields barely larger
+    than the headland, one headland loop (W > R), start point on the centre lines (tie-breaks), points out of bounds."""
+    cases = [dict(L=33.0, H=40.0), dict(L=40.0, H=17.5), dict(L=17.2, H=300.0), dict(L=60.0, H=18.5),
+             dict(L=200.0, H=100.0, start=(100.0, 50.0)), dict(L=200.0, H=100.0, start=(100.0, 50.0000001)),
+             dict(L=120.0, H=80.0, start=(500.0, 10.0), end=(-1.0, 5.0)), dict(L=120.0, H=80.0, start=(0.0, 0.0), end=(120.0, 80.0)),
+             dict(L=1000.0, H=16.1)]
+    specs = [E.FieldSpec(field_length=c['L'], field_width=c['H'], start_point=c.get('start'), end_point=c.get('end')) for c in cases]
+    ofs = [orc.make_field(L=c['L'], H=c['H'], start=c.get('start'), end=c.get('end')) for c in cases]
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, {})
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(sample_spacing=0.3), k_tol=1e-7, v_tol=1e-5)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(turn_model=1, sample_spacing=50.0))         # spacing >> every primitive
+    _compare_with_oracle(specs[4:8], ofs[4:8], [5.0, 4.5, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85], {})     # W > R: one headland loop
+    _compare_with_oracle(specs[:5], ofs[:5], [0.8, 8.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85], {})       # 10 headland loops
+
+
+def test_empty_and_all_error_batches():
+    b = E.Batch([], _veh(DEFAULT_VP))
+    r = b.run()
+    assert b.total_points == 0 and r.x.numel() == 0 and r.stats_raw.shape == (0, 13)
+    b.close()
+    b = E.Batch([E.FieldSpec(field_length=10.0, field_width=10.0), E.FieldSpec(field_length=15.9, field_width=500.0)], _veh(DEFAULT_VP))
+    assert [i.status for i in b.info] == [L.EINVAL, L.EINVAL] and b.total_points == 0
+    r = b.run()
+    assert r.x.numel() == 0 and int(_np(r.stats_raw).sum()) == 0
+    ap, dp = b.connectors()
+    assert np.isnan(_np(ap)).all()
+    b.close()
+
+
+def test_standalone_operators_on_ragged_paths():
+    """CSR with empty, 1-point, 2-point paths between ordinary ones; duplicates at path ends; v_out aliasing v_in."""
+    rng = np.random.default_rng(11)
+    lens = [0, 1, 2, 3, 700, 0, 513, 1, 512, 1025]
+    offs = np.cumsum([0] + lens)
+    xy = np.cumsum(rng.normal(0, 0.4, size=(offs[-1], 2)), axis=0)
+    xy[7] = xy[6]
+    xy[offs[-1] - 1] = xy[offs[-1] - 2]
+    v = rng.choice([2.5, 4.0, 9.0, 15.0], size=offs[-1])
+    veh = orc.Vehicle.make()
+    want = np.concatenate([orc.speed_limit(xy[a:b], v[a:b], veh)[0] if b - a >= 1 else np.zeros(0)
+                           for a, b in zip(offs[:-1], offs[1:])])
+    got, nadj = E.speed_plan(xy[:, 0], xy[:, 1], v, _veh(DEFAULT_VP), clamp=True, offsets=offs)
+    np.testing.assert_allclose(_np(got), want, rtol=0, atol=1e-9)
+    want_sm = np.concatenate([orc.smooth_speed_profile(xy[a:b], v[a:b], 1.5) for a, b in zip(offs[:-1], offs[1:])])
+    got_sm, _ = E.speed_plan(xy[:, 0], xy[:, 1], v, _veh(DEFAULT_VP), clamp=False, offsets=offs)
+    np.testing.assert_allclose(_np(got_sm), want_sm, rtol=0, atol=1e-9)
+    st = E.verify(xy[:, 0], xy[:, 1], want, _veh(DEFAULT_VP), offsets=offs)
+    for k, (a, b) in enumerate(zip(offs[:-1], offs[1:])):
+        ref = orc.verify(xy[a:b], want[a:b], veh) if b - a >= 1 else np.array([0, 0, 0, 0, 0, 1.0])
+        assert st['n_viol'][k] == ref[2]
+        np.testing.assert_allclose([st['max_kappa'][k], st['max_alat'][k], st['max_jump'][k]], ref[[0, 1, 4]], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(st['main_len_m'][k], orc.path_length(xy[a:b]) if b - a >= 2 else 0.0, rtol=1e-12, atol=0)
+    k = _np(E.curvature(xy[:, 0], xy[:, 1], offsets=offs))
+    for a, b in zip(offs[:-1], offs[1:]):
+        if b - a >= 1:
+            assert k[a] == 0 and k[b - 1] == 0
+    with pytest.raises(L.FcppError):
+        E.speed_plan(xy[:, 0], xy[:, 1], v, _veh(DEFAULT_VP), offsets=[0, 5, 3, offs[-1]])     # decreasing offsets
+    d, f = E.ga_fitness(np.zeros((3, 1), dtype=np.int32), np.zeros((1, 1)))
+    assert _np(d).tolist() == [0.0, 0.0, 0.0] and np.allclose(_np(f), 1e6)

@@ -17,11 +17,11 @@ specs = [E.FieldSpec(field_length=float(x), field_width=float(y)) for x, y in LH
 b = E.Batch(specs, E.make_vehicle(), E.make_options(1, 0.1))
 bufs = b.alloc()
 for _ in range(2):
-    res = b.run(bufs, mode=int(os.environ.get('FCPP_MODE', '2')))
+    res = b.run(bufs, mode=int(os.environ.get('FCPP_MODE', '1')))
 torch.cuda.synchronize()
 st = res.stats()
 q, g = b.point_split()
-ntiles = sum((i.n_main + i.n_head + 511) // 512 for i in b.info) - q // 512   # general tiles only
+ntiles = int(os.environ.get('FCPP_GENERAL_TILES', '0')) or max(1, g // 440)   # general tiles (approx. if not given)
 names = [('main_len_m', 'load tile+field, both halos'), ('main_time_pre_s', 'decode+generate'), ('main_time_s', 'neighbour exchange'),
          ('head_len_m', 'd/kappa/geofence'), ('head_time_pre_s', 'store x,y,kappa'), ('head_time_s', 'clamp+scan'),
          ('n_viol', 'prev exchange'), ('n_outside', 'metrics'), ('n_in_obstacle', 'store v,fs + reduce'),
