@@ -74,15 +74,23 @@ struct Tiling {
     std::vector<DevPath> paths;
     std::vector<DevTile> tiles;
     std::vector<int64_t> tile_first;
-    // layer-1 structure of a field, for the fused pipeline's tiling (need < 0: no quiet tiles)
-    struct QuietInfo { int64_t need, n_line, n_turn, P, n_main; };
+    // structure of a field's path, for the fused pipeline's tiling
+    struct QuietInfo {
+        int64_t n_line, n_turn, P, n_main;
+        double line_step_len, c_line;          // |numpy step| of the swath lines, their nominal u = (v/3.6)^2
+        const DevPrim *prims; int prim_count, prim_index0;  // layer 2: the field's primitives, index of the first one in the batch
+        double two_a;
+        bool enable;
+    };
 
-    // Tiles never straddle paths and hold at most TILE_POINTS points.  Without layer-1 information (standalone operators)
-    // a path is cut into near-equal tiles.  With it (planner batches) every swath line is cut as
-    //     [ need | quiet zone ............................. | need ] turn [ need | quiet zone ...
-    // quiet zone = samples whose sweep neighbourhood (need samples = u_cap / (2a) metres on either side) stays on the line:
-    // they become "quiet" tiles (closed-form kernel); everything else -- turns, their margins, the headland layer --
-    // becomes general tiles.  The cut depends only on the field itself, never on its position in the batch.
+    // Tiles never straddle paths and hold at most TILE_POINTS points.  Without structure information (standalone operators)
+    // a path is cut into near-equal tiles.  With it (planner batches) every straight primitive -- swath lines of layer 1,
+    // headland straights of layer 2 -- is cut as
+    //     [ need | quiet zone ............................. | need ]
+    // quiet zone = samples whose sweep neighbourhood stays on the straight: `need` samples span u_nominal / (2a) metres, the
+    // farthest a slower point can lower speeds that are nominal for this straight.  Quiet zones become "quiet" tiles
+    // (closed-form kernel); everything else -- turns, corner arcs, reverse fills and the margins around them -- becomes
+    // general tiles.  The cut depends only on the field itself, never on its position in the batch.
     void build(int64_t n_paths, const int64_t *offsets, const QuietInfo *quiet = nullptr)
     {
         paths.resize((size_t)n_paths);
@@ -92,33 +100,58 @@ struct Tiling {
             const int64_t n = offsets[p + 1] - offsets[p];
             paths[(size_t)p] = { offsets[p], n };
             tile_first[(size_t)p] = (int64_t)tiles.size();
-            const QuietInfo *q = quiet ? &quiet[p] : nullptr;
+            const QuietInfo *q = (quiet && quiet[p].enable) ? &quiet[p] : nullptr;
             const int64_t per = q ? q->n_line + q->n_turn : 0;
-            auto emit = [&](int64_t s, int64_t cnt, int is_quiet) {
+            auto emit = [&](int64_t s, int64_t cnt, int kind, int64_t i0, int64_t o0) {
                 DevTile t;
-                t.field = (int32_t)p; t.start = s; t.count = (int32_t)cnt; t.quiet = is_quiet; t._pad = 0;
-                t.idx0 = 0; t.off0 = 0;
-                if (per > 0 && s < q->n_main) { t.idx0 = (int32_t)(s / per); t.off0 = (int32_t)(s % per); }
+                t.field = (int32_t)p; t.start = s; t.count = (int32_t)cnt; t.quiet = kind; t._pad = 0;
+                t.idx0 = (int32_t)i0; t.off0 = (int32_t)o0;
                 tiles.push_back(t);
             };
             auto emit_general = [&](int64_t a, int64_t b) {
                 const int64_t len = b - a;
                 if (len <= 0) return;
                 const int64_t k = (len + TILE_POINTS - 1) / TILE_POINTS, base = len / k, rem = len % k;
-                for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(a, c, 0); a += c; }
+                for (int64_t i = 0; i < k; ++i) {
+                    const int64_t c = base + (i < rem ? 1 : 0);
+                    const bool in1 = per > 0 && a < q->n_main;        // layer-1 decode of the tile start for the general kernel
+                    emit(a, c, 0, in1 ? a / per : 0, in1 ? a % per : 0);
+                    a += c;
+                }
+            };
+            // near-equal quiet tiles of at most TILE_POINTS - 2 points (the kernel stores aligned PAIRS; a tile that starts on an
+            // odd global index needs one pair more than half its points)
+            auto emit_quiet = [&](int64_t zs, int64_t Z, int kind, int64_t i0, int64_t o0) {
+                const int64_t cap = TILE_POINTS - 2, k = (Z + cap - 1) / cap, base = Z / k, rem = Z % k;
+                for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(zs, c, kind, i0, o0); zs += c; o0 += c; }
+            };
+            auto need_for = [&](double c_nom, double step_len) -> int64_t {
+                if (!(step_len >= 1e-6)) return -1;
+                return (int64_t)(c_nom / (q->two_a * step_len)) + 3;
             };
             int64_t pos = 0;
-            if (q && q->need >= 0 && per > 0) {
-                for (int64_t idx = 0; idx < q->P; ++idx) {
-                    const int64_t L0 = idx * per;
-                    const int64_t zs = L0 + q->need, ze = L0 + q->n_line - q->need, Z = ze - zs;
-                    if (Z < 64) continue;
+            if (q) {
+                const int64_t need1 = need_for(q->c_line, q->line_step_len);
+                if (need1 >= 0 && per > 0) {
+                    for (int64_t idx = 0; idx < q->P; ++idx) {
+                        const int64_t L0 = idx * per, zs = L0 + need1, Z = q->n_line - 2 * need1;
+                        if (Z < 64) break;
+                        emit_general(pos, zs);
+                        emit_quiet(zs, Z, 1, idx, need1);
+                        pos = zs + Z;
+                    }
+                }
+                for (int k = 0; k < q->prim_count; ++k) {
+                    const DevPrim &pr = q->prims[k];
+                    if (pr.kind != PRIM_LINSPACE) continue;
+                    const double ms = pr.v_nom / 3.6;
+                    const int64_t need2 = need_for(ms * ms, sqrt(pr.a[4] * pr.a[4] + pr.a[5] * pr.a[5]));
+                    if (need2 < 0) continue;
+                    const int64_t zs = pr.start + need2, Z = (int64_t)pr.n - 2 * need2;
+                    if (Z < 64 || zs < pos) continue;
                     emit_general(pos, zs);
-                    // near-equal quiet tiles of at most TILE_POINTS - 2 points (the kernel stores aligned PAIRS; a tile that
-                    // starts on an odd global index needs one pair more than half its points)
-                    const int64_t cap = TILE_POINTS - 2, k = (Z + cap - 1) / cap, base = Z / k, rem = Z % k;
-                    for (int64_t i = 0, s0 = zs; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(s0, c, 1); s0 += c; }
-                    pos = ze;
+                    emit_quiet(zs, Z, 2, q->prim_index0 + k, need2);
+                    pos = zs + Z;
                 }
             }
             emit_general(pos, n);
@@ -345,10 +378,12 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     std::vector<Tiling::QuietInfo> qi((size_t)n_fields);
     for (int64_t i = 0; i < n_fields; ++i) {
         const DevField &df = b->hp.fields[(size_t)i];
-        const double step = fabs(df.line_step);
-        Tiling::QuietInfo q = { -1, df.n_line, df.n_turn, df.P, df.n_main };
-        if (df.n_total > 0 && step >= 1e-6 && df.n_line > 2)
-            q.need = (int64_t)(b->cst.u_cap / (2 * b->cst.a_lon * step)) + 3;
+        Tiling::QuietInfo q;
+        q.n_line = df.n_line; q.n_turn = df.n_turn; q.P = df.P; q.n_main = df.n_main;
+        q.line_step_len = fabs(df.line_step); q.c_line = b->cst.ms_work * b->cst.ms_work;
+        q.prims = b->hp.prims.data() + df.prim_first; q.prim_count = df.prim_count; q.prim_index0 = df.prim_first;
+        q.two_a = 2 * b->cst.a_lon;
+        q.enable = df.n_total > 0;
         qi[(size_t)i] = q;
     }
     til.build(n_fields, offs.data(), qi.data());
@@ -443,7 +478,8 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (mode == 1) {
         if (split) {
-            STAGE(0, launch_plan_quiet(st, t.n_quiet, t.quiet_ids.p, t.tiles.p, b->fields.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+            STAGE(0, launch_plan_quiet(st, t.n_quiet, t.quiet_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs,
+                                       t.partial.p));
             STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
                                        y, kappa, v, fs, t.partial.p));
         } else {

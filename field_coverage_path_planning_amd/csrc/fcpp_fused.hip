@@ -224,7 +224,9 @@ __device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *
         if (pos >= 0) {
             const double step_len = sqrt(sx * sx + sy * sy);
             if (step_len >= 1e-6) {
-                const double needd = cst.u_cap / (two_a * step_len) + 3.0;
+                // nothing farther than u_nominal / (2a) can lower the speeds ON this straight below its nominal value
+                const double msn = nominal_ms(fw, cst);
+                const double needd = (msn * msn) / (two_a * step_len) + 3.0;
                 // the neighbour's own curvature stencil must lie on the primitive too: it may not be the sample that
                 // faces the tile's side of the primitive's end (its kappa would see the next primitive)
                 const bool stencil_ok = BACK ? (pos <= np - 2) : (pos >= 1);
@@ -372,24 +374,37 @@ __device__ __forceinline__ unsigned obstacle_mask(const DevObstacles &obs, int o
 // line.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere, so the results are closed-form: no neighbours,
 // no scan, no LDS -- striped point order, every store instruction writes 512 contiguous bytes per wave.  A separate
 // kernel so that it runs at full occupancy: it is pure HBM streaming.
-__device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const DevField *fg, const DevConst &cst,
-                                           const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
+__device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const DevField *fg, const DevPrim *__restrict__ prims,
+                                           const DevConst &cst, const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
                                            double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
                                            double *__restrict__ vo, uint32_t *__restrict__ fso,
                                            TilePartial *__restrict__ partial)
 {
     const int lane = threadIdx.x & 63;
     const DevField &q = *fg;
-    const int idx = tl.idx0;
-    const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
-    const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
-    const double ax = go_left ? q.lex : q.lsx, sx = go_left ? -q.line_step : q.line_step;
-    const double y = q.min_y + (double)pi * q.W;
-    const bool rot = q.rotated != 0;
-    const uint32_t fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+    double ax, ay, sx, sy, vnom, msnom;
+    uint32_t fw;
+    bool rot;
+    int layer;
+    if (tl.quiet == 1) {        // swath line of layer 1: idx0 = pass position, off0 = offset in the pass
+        const int idx = tl.idx0;
+        const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
+        const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+        ax = go_left ? q.lex : q.lsx; sx = go_left ? -q.line_step : q.line_step;
+        ay = q.min_y + (double)pi * q.W; sy = 0.0;
+        rot = q.rotated != 0; layer = 0;
+        fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+        vnom = cst.v_work; msnom = cst.ms_work;
+    } else {                    // headland straight: idx0 = primitive, off0 = offset in it
+        const DevPrim &p = prims[tl.idx0];
+        ax = p.a[0]; ay = p.a[1]; sx = p.a[4]; sy = p.a[5];
+        rot = false; layer = 1;
+        fw = p.fs; vnom = p.v_nom; msnom = nominal_ms(p.fs, cst);
+    }
     // geofence by convexity: both end points inside => the whole segment is inside
     const int cnt = tl.count;    // <= TILE_POINTS, even except possibly for the last tile of a line
-    double ex0 = (double)tl.off0 * sx + ax, ey0 = y, ex1 = (double)(tl.off0 + cnt - 1) * sx + ax, ey1 = y;
+    double ex0 = (double)tl.off0 * sx + ax, ey0 = (double)tl.off0 * sy + ay;
+    double ex1 = (double)(tl.off0 + cnt - 1) * sx + ax, ey1 = (double)(tl.off0 + cnt - 1) * sy + ay;
     if (rot) { rotate_back(q, ex0, ey0); rotate_back(q, ex1, ey1); }
     bool ends_out = false;
 #pragma unroll
@@ -414,8 +429,8 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const
     for (int k = 0; k < TILE_POINTS / 128; ++k) {
         const int j = 2 * (lane + 64 * k) - odd;
         const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;     // (no early exit: the obstacle test below is wave-wide)
-        double px0 = (double)(tl.off0 + j) * sx + ax, py0 = y;          // numpy.linspace: k*step + start
-        double px1 = (double)(tl.off0 + j + 1) * sx + ax, py1 = y;
+        double px0 = (double)(tl.off0 + j) * sx + ax, py0 = (double)(tl.off0 + j) * sy + ay;   // numpy.linspace: k*step + start
+        double px1 = (double)(tl.off0 + j + 1) * sx + ax, py1 = (double)(tl.off0 + j + 1) * sy + ay;
         if (rot) { rotate_back(q, px0, py0); rotate_back(q, px1, py1); }
         uint32_t f0 = fw, f1 = fw;
         if (ends_out) {      // wave-uniform
@@ -439,22 +454,23 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const
             *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
             *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
             *reinterpret_cast<double2 *>(ko + g) = make_double2(0.0, 0.0);
-            *reinterpret_cast<double2 *>(vo + g) = make_double2(cst.v_work, cst.v_work);
+            *reinterpret_cast<double2 *>(vo + g) = make_double2(vnom, vnom);
             *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
         } else if (has0) {
-            xo[g] = px0; yo[g] = py0; ko[g] = 0.0; vo[g] = cst.v_work; fso[g] = f0;
+            xo[g] = px0; yo[g] = py0; ko[g] = 0.0; vo[g] = vnom; fso[g] = f0;
         } else if (has1) {
-            xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = 0.0; vo[g + 1] = cst.v_work; fso[g + 1] = f1;
+            xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = 0.0; vo[g + 1] = vnom; fso[g + 1] = f1;
         }
     }
     long long io = 0, ib = 0;
     if (per_point) { io = wave_sum_i(nout); ib = wave_sum_i(nobs); }   // wave-uniform
     if (lane == 0) {
-        // cnt segments of |line_step| each (the tile's first segment comes from its left neighbour on the same line)
+        // cnt segments of one step each (the tile's first segment comes from its left neighbour on the same straight)
         TilePartial tp;
-        const double len = (double)cnt * fabs(sx), t = len / fmax(cst.ms_work, 0.1);
-        tp.main_len = len; tp.main_time_pre = t; tp.main_time = t;
-        tp.head_len = tp.head_time_pre = tp.head_time = 0.0;
+        const double step_len = (sy == 0.0) ? fabs(sx) : ((sx == 0.0) ? fabs(sy) : sqrt(sx * sx + sy * sy));
+        const double len = (double)cnt * step_len, t = len / fmax(msnom, 0.1);
+        tp.main_len = layer ? 0.0 : len; tp.main_time_pre = layer ? 0.0 : t; tp.main_time = layer ? 0.0 : t;
+        tp.head_len = layer ? len : 0.0; tp.head_time_pre = layer ? t : 0.0; tp.head_time = layer ? t : 0.0;
         tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
         tp.n_viol = 0; tp.n_outside = io; tp.n_in_obstacle = ib; tp.n_adjusted = 0;
         partial[tile_id] = tp;
@@ -463,7 +479,8 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const
 
 // stand-alone launch of the quiet path (tuning / profiling; the default pipeline runs it inside k_plan_fused)
 __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ tiles, const DevField *__restrict__ fields,
-                                                      DevConst cst, DevObstacles obs, double *__restrict__ xo,
+                                                      const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
+                                                      double *__restrict__ xo,
                                                       double *__restrict__ yo, double *__restrict__ ko,
                                                       double *__restrict__ vo, uint32_t *__restrict__ fso,
                                                       TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
@@ -474,7 +491,7 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
     if (slot >= n_ids) return;
     const int tile_id = ids[slot];
     const DevTile tl = tiles[tile_id];
-    quiet_tile(tl, tile_id, &fields[tl.field], cst, obs, obs_lds[threadIdx.x >> 6], xo, yo, ko, vo, fso, partial);
+    quiet_tile(tl, tile_id, &fields[tl.field], prims, cst, obs, obs_lds[threadIdx.x >> 6], xo, yo, ko, vo, fso, partial);
 }
 
 // Diagnostic build only (-DFCPP_DIAG_STAMPS, never shipped): phase time stamps of wave 1 replace the tile's metrics.
@@ -503,7 +520,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     const DevField *fg = &fields[tl.field];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tl.quiet) {     // closed-form tile: pure streaming; mixed into the same grid so that it overlaps the ALU-bound tiles
-        quiet_tile(tl, tile_id, fg, cst, obs, S.tr[0], xo, yo, ko, vo, fso, partial);
+        quiet_tile(tl, tile_id, fg, prims, cst, obs, S.tr[0], xo, yo, ko, vo, fso, partial);
         return;
     }
     // The field descriptor is block-uniform and used all over the kernel.  Read lazily it costs dozens of dependent
@@ -954,11 +971,11 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
 }
 
 int launch_plan_quiet(hipStream_t st, int64_t n_ids, const int32_t *ids, const DevTile *tiles, const DevField *fields,
-                      const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
+                      const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
                       uint32_t *fs, TilePartial *partial)
 {
     if (n_ids <= 0) return 0;
-    hipLaunchKernelGGL(k_plan_quiet, dim3((unsigned)((n_ids + 3) / 4)), dim3(256), 0, st, tiles, fields, cst, obs, x, y, kappa, v,
+    hipLaunchKernelGGL(k_plan_quiet, dim3((unsigned)((n_ids + 3) / 4)), dim3(256), 0, st, tiles, fields, prims, cst, obs, x, y, kappa, v,
                        fs, partial, ids, n_ids);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
