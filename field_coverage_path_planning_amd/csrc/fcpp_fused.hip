@@ -73,7 +73,14 @@ __device__ __forceinline__ double curv_chords(double dx1, double dy1, double ds1
     if (cr == 0.0 && dt > 0.0) return 0.0;
     double dth;
     if (dt > 0.0 && fabs(cr) <= 1e-8 * dt) dth = cr / dt;     // atan(x) = x (1 - x^2/3 + ..): exact to < 1e-16 relative
-    else dth = atan2_slow(cr, dt);
+    else if (dt > 0.0 && fabs(cr) <= 0.125 * dt) {
+        // consecutive samples of a turn: |angle| <= 0.124 rad.  atan(x) = x - x^3/3 + x^5/5 - ... ; 10 terms leave < 3e-20 at x = 1/8
+        const double x = cr / dt, z = x * x;
+        double p = -1.0 / 19.0;
+        p = fma(p, z, 1.0 / 17.0); p = fma(p, z, -1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0);
+        p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
+        dth = fma(x * z, p, x);
+    } else dth = atan2_slow(cr, dt);
     return fabs(2 * dth / (ds1 + ds2));
 }
 
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         c_a = find_prim(f, prims, i0);
         c_r = (int)(i0 - prims[c_a].start);
     }
-    bool straight = false;
+    bool straight = false, turn_run = false;   // fast generation paths: one straight primitive / one U-turn
     uint32_t run_fs = 0;
     if (nvalid == FIPT) {
         double ax = 0, ay = 0, bx = 0, by = 0, sx = 0, sy = 0;
@@ -605,6 +612,25 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
                 straight = true;
             }
         }
+        if (!straight && in_main0 && k_seam >= FIPT && c_off >= f.n_line && c_off + FIPT <= per) {
+            // the whole run lies inside ONE U-turn: 8 template samples, translated / mirrored (MLP:815-823 or the clothoid form)
+            const int pi = f.reverse_order ? (f.P - 1 - c_idx) : c_idx;
+            const double y = f.min_y + (double)pi * f.W;
+            const bool go_left = f.start_from_right ? ((c_idx & 1) == 0) : ((c_idx & 1) == 1);
+            const bool turn_right = !go_left;
+            const bool arc = f.turn_model == FCPP_TURN_ARC;
+            run_fs = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+            const double xr = arc ? f.max_x : (f.max_x - f.R), xl = arc ? f.min_x : (f.min_x + f.R);
+#pragma unroll
+            for (int k = 0; k < FIPT; ++k) {
+                const double2 t = cst.tmpl_u[c_off - f.n_line + k];
+                double px = arc ? (turn_right ? (xr - t.x) : (xl + t.x)) : (turn_right ? (xr + t.x) : (xl - t.x));
+                double py = y + t.y;
+                if (f.rotated) rotate_back(f, px, py);
+                X[k + 1] = px; Y[k + 1] = py; fs[k] = run_fs;
+            }
+            turn_run = true;
+        }
         if (straight) {
 #pragma unroll
             for (int k = 0; k < FIPT; ++k) {
@@ -616,7 +642,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
             }
         }
     }
-    if (!straight) {
+    if (!straight && !turn_run) {
         bool in_main = in_main0;
 #pragma unroll 1
         for (int k = 0; k < FIPT; ++k) {      // rolled: one copy of the evaluators (unrolling costs more in registers than it saves)
@@ -743,7 +769,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     const double ms_run = nominal_ms(run_fs, cst), vn_run = nominal_speed(run_fs, cst);
 #pragma unroll
     for (int k = 0; k < FIPT; ++k) {
-        double ms = straight ? ms_run : nominal_ms(fs[k], cst);
+        double ms = (straight || turn_run) ? ms_run : nominal_ms(fs[k], cst);
         if (kap[k] > 1e-6) {
             bool cl;
             const double vc = clamped_speed(nominal_speed(fs[k], cst), kap[k], cst, cl);
@@ -790,7 +816,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
 #pragma unroll
     for (int k = FIPT - 1; k >= 0; --k) { ub = fmin(c[k], ub + wk(k + 1)); vf[k] = fmin(vf[k], ub); }
     const double b_first = ub;   // backward value at this thread's first item
-    bool uniform = straight;     // every item (and the previous point) still runs at the run's nominal speed
+    bool uniform = straight || turn_run;   // one primitive kind; every item (and the previous point) still at its nominal speed
 #pragma unroll
     for (int k = 0; k < FIPT; ++k) {
         if (vf[k] < c[k]) { vf[k] = sqrt(vf[k]) * 3.6; uniform = false; }     // slowed by a sweep
@@ -798,7 +824,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
             bool cl;
             vf[k] = clamped_speed(nominal_speed(fs[k], cst), kap[k], cst, cl);
             uniform = false;
-        } else vf[k] = straight ? vn_run : nominal_speed(fs[k], cst);          // untouched: exactly the nominal value
+        } else vf[k] = (straight || turn_run) ? vn_run : nominal_speed(fs[k], cst);   // untouched: exactly the nominal value
     }
 
     FCPP_STAMP(6);
