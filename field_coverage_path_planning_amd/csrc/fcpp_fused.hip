@@ -45,8 +45,21 @@ static constexpr int TR_WORDS = 64 * FIPT + 64;   // padded per-wave transpositi
 struct FieldWords { uint32_t w[sizeof(DevField) / 4]; };
 static_assert(sizeof(DevField) % 4 == 0 && sizeof(DevField) / 4 <= 2 * FBLOCK, "DevField staging");
 
+// nominal speeds by primitive kind (fs & FCPP_KIND_MASK): a per-lane LDS lookup instead of a divergent switch over scalars
+struct NomTable { double v[8], ms[8]; };
+__device__ __forceinline__ double nom_v(const NomTable &t, uint32_t fs) { return t.v[fs & FCPP_KIND_MASK]; }
+__device__ __forceinline__ double nom_ms(const NomTable &t, uint32_t fs) { return t.ms[fs & FCPP_KIND_MASK]; }
+
 struct FusedShared {
     FieldWords fw;       // the tile's field descriptor, staged by ONE coalesced load
+    NomTable nom;
+    double cd[6];        // a_lat, a_lon, sf, geofence_tol, u_cap, inv_sf36
+    // double number q of the staged descriptor, as a wave-uniform (scalar) value
+    __device__ __forceinline__ double fw_d(int q) const
+    {
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(fw.w[2 * q]), hi = __builtin_amdgcn_readfirstlane(fw.w[2 * q + 1]);
+        return __hiloint2double((int)hi, (int)lo);
+    }
     HaloInfo back, fwd;
     double efx[FNWAVE], efy[FNWAVE], elx[FNWAVE], ely[FNWAVE];   // first / last point of each wave
     Agg wf[FNWAVE], wb[FNWAVE];
@@ -81,6 +94,25 @@ __device__ __forceinline__ double curv_chords(double dx1, double dy1, double ds1
         p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
         dth = fma(x * z, p, x);
     } else dth = atan2_slow(cr, dt);
+    return fabs(2 * dth / (ds1 + ds2));
+}
+
+// the same without the atan2 call: `slow` = the caller must evaluate atan2(cross, dot) itself
+__device__ __forceinline__ double curv_chords_fast(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2, bool &slow)
+{
+    slow = false;
+    if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
+    const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
+    if (cr == 0.0 && dt > 0.0) return 0.0;
+    double dth;
+    if (dt > 0.0 && fabs(cr) <= 1e-8 * dt) dth = cr / dt;
+    else if (dt > 0.0 && fabs(cr) <= 0.125 * dt) {
+        const double x = cr / dt, z = x * x;
+        double p = -1.0 / 19.0;
+        p = fma(p, z, 1.0 / 17.0); p = fma(p, z, -1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0);
+        p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
+        dth = fma(x * z, p, x);
+    } else { slow = true; return 0.0; }
     return fabs(2 * dth / (ds1 + ds2));
 }
 
@@ -186,8 +218,8 @@ __device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const DevPrim *
 
 // One wave computes what the sweeps carry across the tile edge (see the header comment).
 template <bool BACK>
-__device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *__restrict__ prims, const DevConst &cst, const DevTile &tl,
-                          int64_t edge, HaloInfo *out)
+__device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *__restrict__ prims, const DevConst &cst, const NomTable &nom,
+                          const DevTile &tl, int64_t edge, HaloInfo *out)
 {
     const int lane = threadIdx.x & 63;
     const int64_t n = f.n_total;
@@ -232,7 +264,7 @@ __device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *
             const double step_len = sqrt(sx * sx + sy * sy);
             if (step_len >= 1e-6) {
                 // nothing farther than u_nominal / (2a) can lower the speeds ON this straight below its nominal value
-                const double msn = nominal_ms(fw, cst);
+                const double msn = nom_ms(nom, fw);
                 const double needd = (msn * msn) / (two_a * step_len) + 3.0;
                 // the neighbour's own curvature stencil must lie on the primitive too: it may not be the sample that
                 // faces the tile's side of the primitive's end (its kappa would see the next primitive)
@@ -240,12 +272,12 @@ __device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *
                 const bool ok = stencil_ok && (BACK ? ((double)pos - needd >= 0.0) : ((double)pos + needd <= (double)(np - 1)));
                 if (ok) {
                     if (lane == 0) {
-                        const double ms = nominal_ms(fw, cst);
+                        const double ms = msn;
                         double px = (double)pos * sx + ax, py = (double)pos * sy + ay;
                         if (pos == np - 1) { px = bx; py = by; }
                         if (rot) rotate_back(f, px, py);
                         out->valid = 1; out->px = px; out->py = py; out->kappa = 0.0; out->fs = fw;
-                        out->v0 = nominal_speed(fw, cst); out->u0 = ms * ms; out->carry = ms * ms;
+                        out->v0 = nom_v(nom, fw); out->u0 = ms * ms; out->carry = ms * ms;
                     }
                     return;
                 }
@@ -272,8 +304,8 @@ __device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *
         if (act && i < n - 1) dnext = seg_len(dx2, dy2);
         if (act && i > 0 && i < n - 1) kappa = curv_chords(dx1, dy1, dprev, dx2, dy2, dnext);
         bool cl;
-        const double v0 = clamped_speed(nominal_speed(g.fs, cst), kappa, cst, cl);
-        const double ms = cl ? v0 / 3.6 : nominal_ms(g.fs, cst);
+        const double v0 = clamped_speed(nom_v(nom, g.fs), kappa, cst, cl);
+        const double ms = cl ? v0 / 3.6 : nom_ms(nom, g.fs);
         Agg me;
         me.c = act ? ms * ms : FCPP_INF;
         if (BACK) me.w = !act ? 0.0 : ((i == 0 || dprev < 1e-6) ? FCPP_INF : two_a * dprev);
@@ -508,10 +540,19 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
 #define FCPP_STAMP(i) do { } while (0)
 #endif
 
+// A kernel-argument struct arrives as ONE wide scalar-register tuple, and under register pressure the compiler spills and
+// reloads the whole tuple around every use of one member.  The few constants the kernel needs therefore take the same
+// route as the field descriptor: through LDS, each one becoming an independent scalar value.
+__device__ __forceinline__ double uniform_d(const double *lds)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(lds);
+    return __hiloint2double((int)__builtin_amdgcn_readfirstlane(w[1]), (int)__builtin_amdgcn_readfirstlane(w[0]));
+}
+
 template <int MINW>
 __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__restrict__ tiles,
                                                             const DevField *__restrict__ fields,
-                                                            const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
+                                                            const DevPrim *__restrict__ prims, DevConst cst_arg, DevObstacles obs,
                                                             double *__restrict__ xo, double *__restrict__ yo,
                                                             double *__restrict__ ko, double *__restrict__ vo,
                                                             uint32_t *__restrict__ fso, TilePartial *__restrict__ partial,
@@ -527,24 +568,35 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     const DevField *fg = &fields[tl.field];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tl.quiet) {     // closed-form tile: pure streaming; mixed into the same grid so that it overlaps the ALU-bound tiles
-        quiet_tile(tl, tile_id, fg, prims, cst, obs, S.tr[0], xo, yo, ko, vo, fso, partial);
+        quiet_tile(tl, tile_id, fg, prims, cst_arg, obs, S.tr[0], xo, yo, ko, vo, fso, partial);
         return;
+    }
+    if (tid < 8) { S.nom.v[tid] = nominal_speed((uint32_t)tid, cst_arg); S.nom.ms[tid] = nominal_ms((uint32_t)tid, cst_arg); }
+    if (tid == 8) {
+        S.cd[0] = cst_arg.a_lat; S.cd[1] = cst_arg.a_lon; S.cd[2] = cst_arg.sf; S.cd[3] = cst_arg.geofence_tol;
+        S.cd[4] = cst_arg.u_cap; S.cd[5] = cst_arg.inv_sf36;
     }
     // The field descriptor is block-uniform and used all over the kernel.  Read lazily it costs dozens of dependent
     // scalar-load round trips per wave; instead: one coalesced vector load into LDS, one barrier, then every word is
     // broadcast-read and moved to a scalar register (readfirstlane) in one go.
     for (int q = tid; q < (int)(sizeof(DevField) / 4); q += FBLOCK) S.fw.w[q] = reinterpret_cast<const uint32_t *>(fg)[q];
     __syncthreads();
+    // everything but the geofence edges (fetched where they are used: 24 scalar registers less across the kernel)
+    static constexpr int FW_HEAD = (int)(offsetof(DevField, ex) / 4);
     FieldWords fwl;
 #pragma unroll
-    for (int q = 0; q < (int)(sizeof(DevField) / 4); ++q) fwl.w[q] = __builtin_amdgcn_readfirstlane(S.fw.w[q]);
+    for (int q = 0; q < (int)(sizeof(DevField) / 4); ++q) fwl.w[q] = q < FW_HEAD ? __builtin_amdgcn_readfirstlane(S.fw.w[q]) : 0u;
     const DevField f = __builtin_bit_cast(DevField, fwl);
+    const NomTable &nom = S.nom;
+    DevConst cst = cst_arg;
+    cst.a_lat = uniform_d(&S.cd[0]); cst.a_lon = uniform_d(&S.cd[1]); cst.sf = uniform_d(&S.cd[2]);
+    cst.geofence_tol = uniform_d(&S.cd[3]); cst.u_cap = uniform_d(&S.cd[4]); cst.inv_sf36 = uniform_d(&S.cd[5]);
     const int64_t n = f.n_total, s = tl.start;
     const int cnt = tl.count;
     const double two_a = 2 * cst.a_lon;
 
-    halo_wave<true>(f, fg, prims, cst, tl, s, &S.back);          // one wave per tile: it computes both carries itself
-    halo_wave<false>(f, fg, prims, cst, tl, s + cnt, &S.fwd);
+    halo_wave<true>(f, fg, prims, cst, nom, tl, s, &S.back);          // one wave per tile: it computes both carries itself
+    halo_wave<false>(f, fg, prims, cst, nom, tl, s + cnt, &S.fwd);
 
     FCPP_STAMP(1);
     // ---- 0. where this thread's run sits relative to the path's special indices (small ints from here on) ----
@@ -573,9 +625,11 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
 
     // ---- 1. generate this thread's 8 consecutive points -------------------------------------------
     // Position of the first item: layer 1 = (pass idx, offset in the pass) from the tile's host-precomputed decode,
-    // layer 2 = (primitive, offset) by binary search.  Fast path: the whole run lies on one straight primitive
-    // (~95 % of the threads at fine sampling): 8 x (cvt, mul, add).  Otherwise a cursor walks the run item by item
-    // through whatever primitives it crosses (line -> turn -> line ..).
+    // layer 2 = (primitive, offset) by binary search.  Three generators:
+    //   A. all 8 items in layer 1: branch-free (line sample or U-turn template sample, selected per item; a pass has
+    //      at least 8 points, so the run crosses at most one pass boundary) -- the lanes of a wave do not diverge over line / turn / mixed runs;
+    //   B. all 8 items on one headland straight: 8 x (cvt, mul, add);
+    //   C. everything else (the seam, corners, reverse fills, the path's end): a cursor walks the run item by item.
     double X[FIPT + 2], Y[FIPT + 2];
     uint32_t fs[FIPT];
     const bool in_main0 = k_seam > 0;            // item 0 belongs to layer 1
@@ -588,61 +642,60 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         c_a = find_prim(f, prims, i0);
         c_r = (int)(i0 - prims[c_a].start);
     }
-    bool straight = false, turn_run = false;   // fast generation paths: one straight primitive / one U-turn
+    bool straight = false, turn_run = false;   // uniform runs: one straight primitive / one U-turn (shortcuts further down)
+    bool generated = false;
     uint32_t run_fs = 0;
-    if (nvalid == FIPT) {
-        double ax = 0, ay = 0, bx = 0, by = 0, sx = 0, sy = 0;
-        int r0 = 0, nl = 0;
-        bool rot = false;
-        if (in_main0) {
-            if (c_off + FIPT <= f.n_line) {          // (a line never runs into layer 2: the seam follows a line END)
-                const int pi = f.reverse_order ? (f.P - 1 - c_idx) : c_idx;
-                const bool go_left = f.start_from_right ? ((c_idx & 1) == 0) : ((c_idx & 1) == 1);
-                ax = go_left ? f.lex : f.lsx; bx = go_left ? f.lsx : f.lex; sx = go_left ? -f.line_step : f.line_step;
-                ay = by = f.min_y + (double)pi * f.W; sy = 0.0;
-                r0 = c_off; nl = f.n_line; rot = f.rotated != 0;
-                run_fs = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
-                straight = true;
-            }
-        } else {
-            const DevPrim &p = prims[c_a];
-            if (p.kind == PRIM_LINSPACE && c_r + FIPT <= p.n) {
-                ax = p.a[0]; bx = p.a[2]; sx = p.a[4]; ay = p.a[1]; by = p.a[3]; sy = p.a[5];
-                r0 = c_r; nl = p.n; run_fs = p.fs;
-                straight = true;
-            }
-        }
-        if (!straight && in_main0 && k_seam >= FIPT && c_off >= f.n_line && c_off + FIPT <= per) {
-            // the whole run lies inside ONE U-turn: 8 template samples, translated / mirrored (MLP:815-823 or the clothoid form)
-            const int pi = f.reverse_order ? (f.P - 1 - c_idx) : c_idx;
-            const double y = f.min_y + (double)pi * f.W;
-            const bool go_left = f.start_from_right ? ((c_idx & 1) == 0) : ((c_idx & 1) == 1);
+    if (k_seam >= FIPT && per >= FIPT) {       // A: items 0..7 all have indices < n_main (padding items beyond the tile's count included)
+        const int idx1 = c_idx + 1;
+        const int pi0 = f.reverse_order ? (f.P - 1 - c_idx) : c_idx, pi1 = f.reverse_order ? (f.P - 1 - idx1) : idx1;
+        const double y0 = f.min_y + (double)pi0 * f.W, y1 = f.min_y + (double)pi1 * f.W;
+        const bool gl0 = f.start_from_right ? ((c_idx & 1) == 0) : ((c_idx & 1) == 1);    // go_left of pass c_idx; the next pass is the opposite
+        const bool arc = f.turn_model == FCPP_TURN_ARC;
+        const double xr = arc ? f.max_x : (f.max_x - f.R), xl = arc ? f.min_x : (f.min_x + f.R);
+        const int nl = f.n_line;
+#pragma unroll
+        for (int k = 0; k < FIPT; ++k) {
+            int off = c_off + k;
+            const bool nxt = off >= per;
+            off = nxt ? off - per : off;
+            const bool go_left = gl0 != nxt;
+            const double y = nxt ? y1 : y0;
+            const bool is_line = off < nl;
+            // line sample (numpy.linspace: k*step + start, the last one is `stop`)
+            double lx = go_left ? ((double)off * -f.line_step + f.lex) : ((double)off * f.line_step + f.lsx);
+            if (off == nl - 1) lx = go_left ? f.lsx : f.lex;
+            // turn sample: translate / mirror of the template (MLP:815-823 or the clothoid form)
+            const double2 t = cst.tmpl_u[is_line ? 0 : off - nl];
             const bool turn_right = !go_left;
-            const bool arc = f.turn_model == FCPP_TURN_ARC;
-            run_fs = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
-            const double xr = arc ? f.max_x : (f.max_x - f.R), xl = arc ? f.min_x : (f.min_x + f.R);
-#pragma unroll
-            for (int k = 0; k < FIPT; ++k) {
-                const double2 t = cst.tmpl_u[c_off - f.n_line + k];
-                double px = arc ? (turn_right ? (xr - t.x) : (xl + t.x)) : (turn_right ? (xr + t.x) : (xl - t.x));
-                double py = y + t.y;
-                if (f.rotated) rotate_back(f, px, py);
-                X[k + 1] = px; Y[k + 1] = py; fs[k] = run_fs;
-            }
-            turn_run = true;
+            const double tx = arc ? (turn_right ? (xr - t.x) : (xl + t.x)) : (turn_right ? (xr + t.x) : (xl - t.x));
+            double px = is_line ? lx : tx, py = is_line ? y : (y + t.y);
+            if (f.rotated) rotate_back(f, px, py);
+            X[k + 1] = px; Y[k + 1] = py;
+            fs[k] = (is_line ? (uint32_t)FCPP_KIND_SWATH : (uint32_t)FCPP_KIND_UTURN) | ((uint32_t)(nxt ? pi1 : pi0) << FCPP_INDEX_SHIFT);
         }
-        if (straight) {
+        generated = true;
+        if (nvalid == FIPT) {
+            straight = c_off + FIPT <= nl;
+            turn_run = c_off >= nl && c_off + FIPT <= per;
+            run_fs = (straight ? (uint32_t)FCPP_KIND_SWATH : (uint32_t)FCPP_KIND_UTURN) | ((uint32_t)pi0 << FCPP_INDEX_SHIFT);
+        }
+    } else if (nvalid == FIPT && !in_main0) {   // B
+        const DevPrim &p = prims[c_a];
+        if (p.kind == PRIM_LINSPACE && c_r + FIPT <= p.n) {
+            const double ax = p.a[0], bx = p.a[2], sx = p.a[4], ay = p.a[1], by = p.a[3], sy = p.a[5];
+            const int nl = p.n;
+            run_fs = p.fs;
 #pragma unroll
             for (int k = 0; k < FIPT; ++k) {
-                const int rk = r0 + k;
+                const int rk = c_r + k;
                 double px = (double)rk * sx + ax, py = (double)rk * sy + ay;   // numpy.linspace: k*step + start
                 if (rk == nl - 1) { px = bx; py = by; }                        // ... and the last sample is `stop`
-                if (rot) rotate_back(f, px, py);
                 X[k + 1] = px; Y[k + 1] = py; fs[k] = run_fs;
             }
+            straight = true; generated = true;
         }
     }
-    if (!straight && !turn_run) {
+    if (!generated) {           // C
         bool in_main = in_main0;
 #pragma unroll 1
         for (int k = 0; k < FIPT; ++k) {      // rolled: one copy of the evaluators (unrolling costs more in registers than it saves)
@@ -673,17 +726,9 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     // end neighbours: previous thread's last point, next thread's first point
     X[0] = __shfl_up(X[FIPT], 1); Y[0] = __shfl_up(Y[FIPT], 1);
     X[FIPT + 1] = __shfl_down(X[1], 1); Y[FIPT + 1] = __shfl_down(Y[1], 1);
-    if (lane == 0) { S.efx[wave] = X[1]; S.efy[wave] = Y[1]; }
-    if (lane == 63) { S.elx[wave] = X[FIPT]; S.ely[wave] = Y[FIPT]; }
-    __syncthreads();
-    if (lane == 0) {
-        if (wave > 0) { X[0] = S.elx[wave - 1]; Y[0] = S.ely[wave - 1]; }
-        else { X[0] = S.back.px; Y[0] = S.back.py; }
-    }
-    if (lane == 63) {
-        if (wave < FNWAVE - 1) { X[FIPT + 1] = S.efx[wave + 1]; Y[FIPT + 1] = S.efy[wave + 1]; }
-        else { X[FIPT + 1] = S.fwd.px; Y[FIPT + 1] = S.fwd.py; }
-    }
+    __syncthreads();            // (the halos in LDS)
+    if (lane == 0) { X[0] = S.back.px; Y[0] = S.back.py; }
+    if (lane == 63) { X[FIPT + 1] = S.fwd.px; Y[FIPT + 1] = S.fwd.py; }
     // a tile may hold fewer than 512 points anywhere on the path: the successor of its last point is the forward halo point
     if (nvalid > 0 && j0 + nvalid == cnt) {
 #pragma unroll
@@ -703,37 +748,62 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         if ((d[k] < 1e-6) || (k == 0 && at_start) || (k == k_end + 1)) cut |= 1u << k;
         if (k > nvalid || nvalid == 0) nocouple |= 1u << k;
     }
+    // curvature: the unrolled loop handles the cheap cases (collinear, tiny and small turning angles); the rare large
+    // angles (junctions, coarse reference-sampled arcs) go through ONE copy of atan2 below, one item per lane per round
     double kap[FIPT];
+    unsigned hard = 0;
 #pragma unroll
     for (int k = 0; k < FIPT; ++k) {
         double kk = 0.0;
-        if (k < nvalid && !(k == 0 && at_start) && k != k_end)
-            kk = curv_chords(X[k + 1] - X[k], Y[k + 1] - Y[k], d[k], X[k + 2] - X[k + 1], Y[k + 2] - Y[k + 1], d[k + 1]);
+        if (k < nvalid && !(k == 0 && at_start) && k != k_end) {
+            bool slow;
+            kk = curv_chords_fast(X[k + 1] - X[k], Y[k + 1] - Y[k], d[k], X[k + 2] - X[k + 1], Y[k + 2] - Y[k + 1], d[k + 1], slow);
+            if (slow) hard |= 1u << k;
+        }
         kap[k] = kk;
+    }
+    while (__ballot(hard != 0u)) {
+        if (hard) {
+            const int kh = __ffs(hard) - 1;
+            hard &= hard - 1;
+            double x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0, dsum = 1;
+#pragma unroll
+            for (int q = 0; q < FIPT; ++q)
+                if (q == kh) { x0 = X[q]; y0 = Y[q]; x1 = X[q + 1]; y1 = Y[q + 1]; x2 = X[q + 2]; y2 = Y[q + 2]; dsum = d[q] + d[q + 1]; }
+            const double dx1 = x1 - x0, dy1 = y1 - y0, dx2 = x2 - x1, dy2 = y2 - y1;
+            const double kk = fabs(2 * atan2(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / dsum);
+#pragma unroll
+            for (int q = 0; q < FIPT; ++q) if (q == kh) kap[q] = kk;
+        }
     }
     int nout = 0, nobs = 0;
     {
         // geofence; convexity: a straight run whose two end points pass it lies inside as a whole
+        double ex[4], ey[4], eo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ex[e] = S.fw_d(offsetof(DevField, ex) / 8 + e); ey[e] = S.fw_d(offsetof(DevField, ey) / 8 + e); eo[e] = S.fw_d(offsetof(DevField, eo) / 8 + e);
+        }
         bool run_inside = false;
+        const double ntol = -cst.geofence_tol;
         if (straight) {
             bool out = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                out = out || (f.ex[e] * X[1] + f.ey[e] * Y[1] + f.eo[e] < -cst.geofence_tol)
-                          || (f.ex[e] * X[FIPT] + f.ey[e] * Y[FIPT] + f.eo[e] < -cst.geofence_tol);
+                out = out | (ex[e] * X[1] + ey[e] * Y[1] + eo[e] < ntol) | (ex[e] * X[FIPT] + ey[e] * Y[FIPT] + eo[e] < ntol);
             run_inside = !out;
         }
         const int ob0 = f.obs_first, ob1 = f.obs_first + f.obs_count;
         if (!run_inside) {
 #pragma unroll
-            for (int k = 0; k < FIPT; ++k) {
-                if (k < nvalid) {
-                    const double px = X[k + 1], py = Y[k + 1];
-                    bool out = false;
+            for (int k = 0; k < FIPT; ++k) {     // (branch-free: the tests are cheaper than the jumps around them)
+                const double px = X[k + 1], py = Y[k + 1];
+                bool out = false;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) out = out || (f.ex[e] * px + f.ey[e] * py + f.eo[e] < -cst.geofence_tol);
-                    if (out) { ++nout; fs[k] |= FCPP_FLAG_OUTSIDE; }
-                }
+                for (int e = 0; e < 4; ++e) out = out | (ex[e] * px + ey[e] * py + eo[e] < ntol);
+                out = out & (k < nvalid);
+                nout += out ? 1 : 0;
+                fs[k] |= out ? FCPP_FLAG_OUTSIDE : 0u;
             }
         }
         if (ob1 > ob0) {     // wave-uniform: bounding box of the wave's points, then culled + LDS-staged polygon tests
@@ -766,13 +836,13 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     double c[FIPT];
     int adj = 0;
     unsigned clmask = 0;    // items slowed by the clamp
-    const double ms_run = nominal_ms(run_fs, cst), vn_run = nominal_speed(run_fs, cst);
+    const double ms_run = nom_ms(nom, run_fs), vn_run = nom_v(nom, run_fs);
 #pragma unroll
     for (int k = 0; k < FIPT; ++k) {
-        double ms = (straight || turn_run) ? ms_run : nominal_ms(fs[k], cst);
+        double ms = (straight || turn_run) ? ms_run : nom_ms(nom, fs[k]);
         if (kap[k] > 1e-6) {
             bool cl;
-            const double vc = clamped_speed(nominal_speed(fs[k], cst), kap[k], cst, cl);
+            const double vc = clamped_speed((straight || turn_run) ? vn_run : nom_v(nom, fs[k]), kap[k], cst, cl);
             if (cl) { ms = vc / 3.6; clmask |= 1u << k; ++adj; }
         }
         c[k] = (k < nvalid) ? ms * ms : FCPP_INF;
@@ -822,9 +892,9 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         if (vf[k] < c[k]) { vf[k] = sqrt(vf[k]) * 3.6; uniform = false; }     // slowed by a sweep
         else if ((clmask >> k) & 1u) {                                         // untouched: exactly the clamped value
             bool cl;
-            vf[k] = clamped_speed(nominal_speed(fs[k], cst), kap[k], cst, cl);
+            vf[k] = clamped_speed(nom_v(nom, fs[k]), kap[k], cst, cl);
             uniform = false;
-        } else vf[k] = (straight || turn_run) ? vn_run : nominal_speed(fs[k], cst);   // untouched: exactly the nominal value
+        } else vf[k] = (straight || turn_run) ? vn_run : nom_v(nom, fs[k]);   // untouched: exactly the nominal value
     }
 
     FCPP_STAMP(6);
@@ -842,7 +912,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
             kprev = S.back.kappa; fsprev = S.back.fs;
         }
     }
-    const double vnprev = nominal_speed(fsprev, cst);
+    const double vnprev = nom_v(nom, fsprev);
 
     FCPP_STAMP(7);
     // ---- 6. metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) ---------------------------------
@@ -863,12 +933,12 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         for (int k = 0; k < FIPT; ++k) {
             if (k < nvalid && !(k == 0 && at_start) && k != k_seam) {      // the seam main|headland belongs to neither layer
                 const int layer = k > k_seam ? 1 : 0;
-                const double vn_k = nominal_speed(fs[k], cst);
+                const double vn_k = nom_v(nom, fs[k]);
                 const double vp = k == 0 ? vprev : vf[k - 1];
-                const double vnp = k == 0 ? vnprev : nominal_speed(fs[k - 1], cst);
+                const double vnp = k == 0 ? vnprev : nom_v(nom, fs[k - 1]);
                 s_len[layer] += d[k];
                 // (v + v) / 2 / 3.6 == v / 3.6: equal nominal speeds on both ends take the tabulated m/s value
-                const double ms_pre = (vnp == vn_k) ? nominal_ms(fs[k], cst) : ((vnp + vn_k) / 2) / 3.6;
+                const double ms_pre = (vnp == vn_k) ? nom_ms(nom, fs[k]) : ((vnp + vn_k) / 2) / 3.6;
                 const double tpre = d[k] / fmax(ms_pre, 0.1);
                 s_tpre[layer] += tpre;
                 s_t[layer] += (vp == vnp && vf[k] == vn_k) ? tpre : d[k] / fmax(((vp + vf[k]) / 2) / 3.6, 0.1);
