@@ -104,7 +104,7 @@ struct Tiling {
             const int64_t per = q ? q->n_line + q->n_turn : 0;
             auto emit = [&](int64_t s, int64_t cnt, int kind, int64_t i0, int64_t o0) {
                 DevTile t;
-                t.field = (int32_t)p; t.start = s; t.count = (int32_t)cnt; t.quiet = kind; t._pad = 0;
+                t.field = (int32_t)p; t.start = s; t.count = (int32_t)cnt; t.quiet = kind; t.stat_tile = 0;
                 t.idx0 = (int32_t)i0; t.off0 = (int32_t)o0;
                 tiles.push_back(t);
             };
@@ -168,8 +168,10 @@ struct DevTiling {
     DevBuf<double> carry_f, carry_b;
     DevBuf<TilePartial> partial;
     DevBuf<unsigned long long> n_adj;
-    DevBuf<int32_t> quiet_ids, general_ids;   // fused pipeline: tiles by kernel
-    int64_t n_tiles = 0, n_paths = 0, n_quiet = 0, n_general = 0, quiet_points = 0;
+    DevBuf<int32_t> general_ids;   // fused pipeline: the tiles of k_plan_fused
+    DevBuf<DevTile> chunks;        // ... the quiet runs cut on 512-point boundaries of the batch arrays (k_plan_quiet)
+    DevBuf<DevRun> runs;           // ... the quiet runs (k_quiet_run_stats)
+    int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_runs = 0, n_general = 0, quiet_points = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
     {
         n_tiles = (int64_t)t.tiles.size(); n_paths = (int64_t)t.paths.size();
@@ -183,16 +185,41 @@ struct DevTiling {
         if ((e = carry_b.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
-        std::vector<int32_t> qv, gv;
+        std::vector<int32_t> gv;
+        std::vector<DevTile> cv;
+        std::vector<DevRun> rv;
         quiet_points = 0;
-        for (size_t i = 0; i < t.tiles.size(); ++i) {
-            (t.tiles[i].quiet ? qv : gv).push_back((int32_t)i);
-            if (t.tiles[i].quiet) quiet_points += t.tiles[i].count;
+        for (size_t i = 0; i < t.tiles.size();) {
+            const DevTile &t0 = t.tiles[i];
+            if (!t0.quiet) { gv.push_back((int32_t)i); ++i; continue; }
+            // the run: quiet tiles that continue each other on the same straight
+            int64_t cnt = t0.count;
+            size_t j = i + 1;
+            for (; j < t.tiles.size(); ++j) {
+                const DevTile &tj = t.tiles[j];
+                if (!(tj.quiet == t0.quiet && tj.field == t0.field && tj.idx0 == t0.idx0 && tj.start == t0.start + cnt &&
+                      (int64_t)tj.off0 == (int64_t)t0.off0 + cnt))
+                    break;
+                cnt += tj.count;
+            }
+            rv.push_back({ (int32_t)i, 0, cnt });
+            quiet_points += cnt;
+            const int64_t g_run = t.paths[(size_t)t0.field].off + t0.start;    // index of the run's first point in the batch arrays
+            for (int64_t done = 0; done < cnt;) {
+                const int64_t g = g_run + done;
+                const int64_t c = std::min<int64_t>(cnt - done, TILE_POINTS - (g % TILE_POINTS));
+                DevTile ch = t0;
+                ch.start = t0.start + done; ch.off0 = (int32_t)(t0.off0 + done); ch.count = (int32_t)c; ch.stat_tile = (int32_t)i;
+                cv.push_back(ch);
+                done += c;
+            }
+            i = j;
         }
-        n_quiet = (int64_t)qv.size(); n_general = (int64_t)gv.size();
-        if ((e = quiet_ids.upload(qv, st)) != hipSuccess) return e;
+        n_chunks = (int64_t)cv.size(); n_runs = (int64_t)rv.size(); n_general = (int64_t)gv.size();
+        if ((e = chunks.upload(cv, st)) != hipSuccess) return e;
+        if ((e = runs.upload(rv, st)) != hipSuccess) return e;
         if ((e = general_ids.upload(gv, st)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // qv / gv die here
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the staging vectors die here
         return hipSuccess;
     }
 };
@@ -224,6 +251,7 @@ struct fcpp_batch {
     std::vector<hipEvent_t> events;   // kProfRuns x (kStages + 1)
     int prof_runs = 0;
     int last_mode = 0;
+    bool partial_dirty = true;   // the staged pipeline (or nobody yet) wrote the tile partials last
     ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 
@@ -452,12 +480,11 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
     // mode 1 (default): quiet tiles (k_plan_quiet, streaming) and general tiles (k_plan_fused) as two launches.
-    // Tuning only: mode 2 = one launch with both tile kinds mixed in the grid (measured: no faster, the two kinds do not
-    // overlap usefully); modes 12/13/14 = mode 1 with k_plan_fused compiled for a minimum of 2/3/4 waves per SIMD.
-    int variant = 4;
-    bool split = true;
+    // Tuning only: modes 12/13/14 = mode 1 with k_plan_fused compiled for a minimum of 2/3/4 waves per SIMD (default 3).
+    // (Measured and dropped: both tile kinds in one grid, and the two kernels on two streams -- the HBM-bound and the
+    // ALU-bound kernel do not overlap usefully, the sum of the two launches is the faster schedule.)
+    int variant = 3;
     if (mode >= 12 && mode <= 14) { variant = mode - 10; mode = 1; }
-    if (mode == 2) { split = false; mode = 1; }
     if (mode != 0 && mode != 1) return fail(FCPP_EINVAL, "unknown pipeline mode");
     if (mode != b->last_mode) { b->prof_runs = 0; b->last_mode = mode; }
     if (b->n_fields == 0) return FCPP_OK;
@@ -477,20 +504,19 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     } while (0)
     if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (mode == 1) {
-        if (split) {
-            STAGE(0, launch_plan_quiet(st, t.n_quiet, t.quiet_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs,
-                                       t.partial.p));
-            STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
-                                       y, kappa, v, fs, t.partial.p));
-        } else {
-            if (ev) HIPCHK(hipEventRecord(ev[1], st));   // (no separate quiet launch: stage 0 has zero duration)
-            STAGE(1, launch_plan_fused(st, variant, t.n_tiles, nullptr, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa,
-                                       v, fs, t.partial.p));
+        if (b->partial_dirty) {   // slots of quiet tiles that are not the first of their run stay zero from here on
+            HIPCHK(hipMemsetAsync(t.partial.p, 0, (size_t)t.n_tiles * sizeof(TilePartial), st));
+            b->partial_dirty = false;
         }
+        LAUNCHCHK(launch_quiet_run_stats(st, t.n_runs, t.runs.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, t.partial.p));
+        STAGE(0, launch_plan_quiet(st, t.n_chunks, t.chunks.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
+                                   y, kappa, v, fs, t.partial.p));
         STAGE(2, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, nullptr, stats));
         if (ev) ++b->prof_runs;
         return FCPP_OK;
     }
+    b->partial_dirty = true;
     STAGE(0, launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
     STAGE(1, launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
     STAGE(2, launch_scan_tiles(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, x, y, v, t.agg_f.p, t.agg_b.p));

@@ -52,9 +52,11 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,
                       const DevField *fields, const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x,
                       double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial);
-int launch_plan_quiet(hipStream_t st, int64_t n_ids, const int32_t *ids, const DevTile *tiles, const DevField *fields,
-                      const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
-                      uint32_t *fs, TilePartial *partial);
+int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, const DevField *fields, const DevPrim *prims,
+                      const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
+                      TilePartial *partial);
+int launch_quiet_run_stats(hipStream_t st, int64_t n_runs, const DevRun *runs, const DevTile *tiles, const DevField *fields,
+                           const DevPrim *prims, const DevConst &cst, TilePartial *partial);
 int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts, const int32_t *mask, double *out);
 int launch_fresnel(hipStream_t st, int64_t n, const double *t, double *c, double *s);
 int launch_ga_fitness(hipStream_t st, int n, int64_t pop, const double *D, const int32_t *routes, double *dist,

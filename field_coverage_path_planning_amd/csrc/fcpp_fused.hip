@@ -77,43 +77,32 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // curvature (MLP:513-536) from the two chords and their lengths.  dtheta = atan2(sin(t2-t1), cos(t2-t1)) is the
-// signed angle between the chords = atan2(cross, dot); exactly collinear chords (every interior point of an
-// axis-aligned straight run) and tiny angles never reach atan2.
-__device__ __forceinline__ double curv_chords(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)
-{
-    if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
-    const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
-    if (cr == 0.0 && dt > 0.0) return 0.0;
-    double dth;
-    if (dt > 0.0 && fabs(cr) <= 1e-8 * dt) dth = cr / dt;     // atan(x) = x (1 - x^2/3 + ..): exact to < 1e-16 relative
-    else if (dt > 0.0 && fabs(cr) <= 0.125 * dt) {
-        // consecutive samples of a turn: |angle| <= 0.124 rad.  atan(x) = x - x^3/3 + x^5/5 - ... ; 10 terms leave < 3e-20 at x = 1/8
-        const double x = cr / dt, z = x * x;
-        double p = -1.0 / 19.0;
-        p = fma(p, z, 1.0 / 17.0); p = fma(p, z, -1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0);
-        p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
-        dth = fma(x * z, p, x);
-    } else dth = atan2_slow(cr, dt);
-    return fabs(2 * dth / (ds1 + ds2));
-}
-
-// the same without the atan2 call: `slow` = the caller must evaluate atan2(cross, dot) itself
+// signed angle between the chords = atan2(cross, dot).  Exactly collinear chords (every interior point of an
+// axis-aligned straight run) give 0; turning angles up to 0.124 rad (consecutive samples of any turn at fine sampling)
+// take the odd series atan(x) = x - x^3/3 + x^5/5 - ..., 10 terms of which leave < 3e-20 at x = 1/8 (for |x| < 1e-8 the
+// series returns x itself, as atan2 does).  Larger angles set `slow`: the caller evaluates atan2(cross, dot).
 __device__ __forceinline__ double curv_chords_fast(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2, bool &slow)
 {
     slow = false;
     if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
     const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
     if (cr == 0.0 && dt > 0.0) return 0.0;
-    double dth;
-    if (dt > 0.0 && fabs(cr) <= 1e-8 * dt) dth = cr / dt;
-    else if (dt > 0.0 && fabs(cr) <= 0.125 * dt) {
-        const double x = cr / dt, z = x * x;
-        double p = -1.0 / 19.0;
-        p = fma(p, z, 1.0 / 17.0); p = fma(p, z, -1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0);
-        p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
-        dth = fma(x * z, p, x);
-    } else { slow = true; return 0.0; }
+    if (!(dt > 0.0 && fabs(cr) <= 0.125 * dt)) { slow = true; return 0.0; }
+    const double x = cr / dt, z = x * x;
+    double p = -1.0 / 19.0;
+    p = fma(p, z, 1.0 / 17.0); p = fma(p, z, -1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0);
+    p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
+    const double dth = fma(x * z, p, x);
     return fabs(2 * dth / (ds1 + ds2));
+}
+
+// the same with the atan2 fallback as an out-of-line call (halo recomputation: one call site, not eight)
+__device__ __forceinline__ double curv_chords(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)
+{
+    bool slow;
+    const double k = curv_chords_fast(dx1, dy1, ds1, dx2, dy2, ds2, slow);
+    if (!slow) return k;
+    return fabs(2 * atan2_slow(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / (ds1 + ds2));
 }
 
 // speed after the curvature clamp (MLP:496-504); nominal = the primitive's nominal speed.
@@ -409,11 +398,13 @@ __device__ __forceinline__ unsigned obstacle_mask(const DevObstacles &obs, int o
     return inside;
 }
 
-// ---- quiet tiles (flagged by the host): all 2048 points and everything within reach of the sweeps lie on one swath
-// line.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere, so the results are closed-form: no neighbours,
-// no scan, no LDS -- striped point order, every store instruction writes 512 contiguous bytes per wave.  A separate
-// kernel so that it runs at full occupancy: it is pure HBM streaming.
-__device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const DevField *fg, const DevPrim *__restrict__ prims,
+// ---- quiet runs (found by the host tiler): stretches of a straight primitive whose points, and everything within reach of
+// the sweeps, lie on that primitive.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere: closed-form results, no
+// neighbours, no scan, no LDS.  The kernel is pure HBM streaming, so what matters is the shape of its stores: a run is cut into
+// chunks on 512-point boundaries of the batch arrays, one chunk per wavefront, every store instruction of a full chunk writes
+// one ALIGNED KiB (16 bytes per lane) -- measured 15-25 % faster than the same bytes through tiles that start anywhere in a
+// cache line (tools/micro/stream_probe.hip), and far less sensitive to where the arrays happen to live in device memory.
+__device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg, const DevPrim *__restrict__ prims,
                                            const DevConst &cst, const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
                                            double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
                                            double *__restrict__ vo, uint32_t *__restrict__ fso,
@@ -421,27 +412,26 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const
 {
     const int lane = threadIdx.x & 63;
     const DevField &q = *fg;
-    double ax, ay, sx, sy, vnom, msnom;
+    double ax, ay, sx, sy, vnom;
     uint32_t fw;
     bool rot;
-    int layer;
     if (tl.quiet == 1) {        // swath line of layer 1: idx0 = pass position, off0 = offset in the pass
         const int idx = tl.idx0;
         const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
         const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
         ax = go_left ? q.lex : q.lsx; sx = go_left ? -q.line_step : q.line_step;
         ay = q.min_y + (double)pi * q.W; sy = 0.0;
-        rot = q.rotated != 0; layer = 0;
+        rot = q.rotated != 0;
         fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
-        vnom = cst.v_work; msnom = cst.ms_work;
+        vnom = cst.v_work;
     } else {                    // headland straight: idx0 = primitive, off0 = offset in it
         const DevPrim &p = prims[tl.idx0];
         ax = p.a[0]; ay = p.a[1]; sx = p.a[4]; sy = p.a[5];
-        rot = false; layer = 1;
-        fw = p.fs; vnom = p.v_nom; msnom = nominal_ms(p.fs, cst);
+        rot = false;
+        fw = p.fs; vnom = p.v_nom;
     }
     // geofence by convexity: both end points inside => the whole segment is inside
-    const int cnt = tl.count;    // <= TILE_POINTS, even except possibly for the last tile of a line
+    const int cnt = tl.count;    // <= TILE_POINTS; a chunk that starts on an odd index ends on a 512 boundary (<= 511 points)
     double ex0 = (double)tl.off0 * sx + ax, ey0 = (double)tl.off0 * sy + ay;
     double ex1 = (double)(tl.off0 + cnt - 1) * sx + ax, ey1 = (double)(tl.off0 + cnt - 1) * sy + ay;
     if (rot) { rotate_back(q, ex0, ey0); rotate_back(q, ex1, ey1); }
@@ -501,36 +491,55 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, int tile_id, const
             xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = 0.0; vo[g + 1] = vnom; fso[g + 1] = f1;
         }
     }
-    long long io = 0, ib = 0;
-    if (per_point) { io = wave_sum_i(nout); ib = wave_sum_i(nobs); }   // wave-uniform
-    if (lane == 0) {
-        // cnt segments of one step each (the tile's first segment comes from its left neighbour on the same straight)
-        TilePartial tp;
-        const double step_len = (sy == 0.0) ? fabs(sx) : ((sx == 0.0) ? fabs(sy) : sqrt(sx * sx + sy * sy));
-        const double len = (double)cnt * step_len, t = len / fmax(msnom, 0.1);
-        tp.main_len = layer ? 0.0 : len; tp.main_time_pre = layer ? 0.0 : t; tp.main_time = layer ? 0.0 : t;
-        tp.head_len = layer ? len : 0.0; tp.head_time_pre = layer ? t : 0.0; tp.head_time = layer ? t : 0.0;
-        tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
-        tp.n_viol = 0; tp.n_outside = io; tp.n_in_obstacle = ib; tp.n_adjusted = 0;
-        partial[tile_id] = tp;
+    if (per_point) {   // wave-uniform; integer counts: the order of the additions does not matter
+        const long long io = wave_sum_i(nout), ib = wave_sum_i(nobs);
+        if (lane == 0 && io) atomicAdd(reinterpret_cast<unsigned long long *>(&partial[tl.stat_tile].n_outside), (unsigned long long)io);
+        if (lane == 0 && ib) atomicAdd(reinterpret_cast<unsigned long long *>(&partial[tl.stat_tile].n_in_obstacle), (unsigned long long)ib);
     }
 }
 
-// stand-alone launch of the quiet path (tuning / profiling; the default pipeline runs it inside k_plan_fused)
-__global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ tiles, const DevField *__restrict__ fields,
+// length / time statistics of the quiet runs (closed form: count x step), one thread per run, credited to the run's first
+// tile; the flag counts of the run's points are added to the same slot by k_plan_quiet, which runs after this kernel
+__global__ __launch_bounds__(256) void k_quiet_run_stats(int64_t n_runs, const DevRun *__restrict__ runs, const DevTile *__restrict__ tiles,
+                                                           const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
+                                                           DevConst cst, TilePartial *__restrict__ partial)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_runs) return;
+    const DevRun run = runs[r];
+    const DevTile tl = tiles[run.tile];
+    double step_len, msnom;
+    int layer;
+    if (tl.quiet == 1) { step_len = fabs(fields[tl.field].line_step); msnom = cst.ms_work; layer = 0; }
+    else {
+        const DevPrim &p = prims[tl.idx0];
+        const double sx = p.a[4], sy = p.a[5];
+        step_len = (sy == 0.0) ? fabs(sx) : ((sx == 0.0) ? fabs(sy) : sqrt(sx * sx + sy * sy));
+        msnom = nominal_ms(p.fs, cst); layer = 1;
+    }
+    // one segment of one step per point (a run's first segment comes from its left neighbour on the same straight)
+    TilePartial tp;
+    const double len = (double)run.count * step_len, t = len / fmax(msnom, 0.1);
+    tp.main_len = layer ? 0.0 : len; tp.main_time_pre = layer ? 0.0 : t; tp.main_time = layer ? 0.0 : t;
+    tp.head_len = layer ? len : 0.0; tp.head_time_pre = layer ? t : 0.0; tp.head_time = layer ? t : 0.0;
+    tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
+    tp.n_viol = 0; tp.n_outside = 0; tp.n_in_obstacle = 0; tp.n_adjusted = 0;
+    partial[run.tile] = tp;
+}
+
+// the quiet path: one tile per wavefront, four per workgroup; pure HBM streaming at full occupancy
+__global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
                                                       const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                       double *__restrict__ xo,
                                                       double *__restrict__ yo, double *__restrict__ ko,
                                                       double *__restrict__ vo, uint32_t *__restrict__ fso,
-                                                      TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
-                                                      int64_t n_ids)
+                                                      TilePartial *__restrict__ partial, int64_t n_chunks)
 {
     __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
-    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one tile per wavefront
-    if (slot >= n_ids) return;
-    const int tile_id = ids[slot];
-    const DevTile tl = tiles[tile_id];
-    quiet_tile(tl, tile_id, &fields[tl.field], prims, cst, obs, obs_lds[threadIdx.x >> 6], xo, yo, ko, vo, fso, partial);
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one chunk per wavefront
+    if (slot >= n_chunks) return;
+    const DevTile tl = chunks[slot];
+    quiet_tile(tl, &fields[tl.field], prims, cst, obs, obs_lds[threadIdx.x >> 6], xo, yo, ko, vo, fso, partial);
 }
 
 // Diagnostic build only (-DFCPP_DIAG_STAMPS, never shipped): phase time stamps of wave 1 replace the tile's metrics.
@@ -560,17 +569,13 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
 {
     __shared__ FusedShared S;
 #ifdef FCPP_DIAG_STAMPS
-    unsigned long long stamp[10];
+    unsigned long long stamp[12];
 #endif
     FCPP_STAMP(0);
     const int tile_id = ids ? ids[blockIdx.x] : (int)blockIdx.x;
     const DevTile tl = tiles[tile_id];
     const DevField *fg = &fields[tl.field];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tl.quiet) {     // closed-form tile: pure streaming; mixed into the same grid so that it overlaps the ALU-bound tiles
-        quiet_tile(tl, tile_id, fg, prims, cst_arg, obs, S.tr[0], xo, yo, ko, vo, fso, partial);
-        return;
-    }
     if (tid < 8) { S.nom.v[tid] = nominal_speed((uint32_t)tid, cst_arg); S.nom.ms[tid] = nominal_ms((uint32_t)tid, cst_arg); }
     if (tid == 8) {
         S.cd[0] = cst_arg.a_lat; S.cd[1] = cst_arg.a_lon; S.cd[2] = cst_arg.sf; S.cd[3] = cst_arg.geofence_tol;
@@ -595,7 +600,9 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     const int cnt = tl.count;
     const double two_a = 2 * cst.a_lon;
 
+    FCPP_STAMP(10);
     halo_wave<true>(f, fg, prims, cst, nom, tl, s, &S.back);          // one wave per tile: it computes both carries itself
+    FCPP_STAMP(11);
     halo_wave<false>(f, fg, prims, cst, nom, tl, s + cnt, &S.fwd);
 
     FCPP_STAMP(1);
@@ -1010,7 +1017,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         tp.main_len = (double)(stamp[1] - stamp[0]); tp.main_time_pre = (double)(stamp[2] - stamp[1]);
         tp.main_time = (double)(stamp[3] - stamp[2]); tp.head_len = (double)(stamp[4] - stamp[3]);
         tp.head_time_pre = (double)(stamp[5] - stamp[4]); tp.head_time = (double)(stamp[6] - stamp[5]);
-        tp.max_kappa = 0; tp.max_alat = 0; tp.max_jump = 0;
+        tp.max_kappa = (double)(stamp[10] - stamp[0]); tp.max_alat = (double)(stamp[11] - stamp[10]); tp.max_jump = (double)(stamp[1] - stamp[11]);
         tp.n_viol = (long long)(stamp[7] - stamp[6]); tp.n_outside = (long long)(stamp[8] - stamp[7]);
         tp.n_in_obstacle = (long long)(stamp[9] - stamp[8]); tp.n_adjusted = (long long)(stamp[9] - stamp[0]);
         partial[tile_id] = tp;
@@ -1066,13 +1073,23 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_plan_quiet(hipStream_t st, int64_t n_ids, const int32_t *ids, const DevTile *tiles, const DevField *fields,
-                      const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
-                      uint32_t *fs, TilePartial *partial)
+int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, const DevField *fields, const DevPrim *prims,
+                      const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
+                      TilePartial *partial)
 {
-    if (n_ids <= 0) return 0;
-    hipLaunchKernelGGL(k_plan_quiet, dim3((unsigned)((n_ids + 3) / 4)), dim3(256), 0, st, tiles, fields, prims, cst, obs, x, y, kappa, v,
-                       fs, partial, ids, n_ids);
+    if (n_chunks <= 0) return 0;
+    hipLaunchKernelGGL(k_plan_quiet, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st, chunks, fields, prims, cst, obs, x, y, kappa,
+                       v, fs, partial, n_chunks);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int launch_quiet_run_stats(hipStream_t st, int64_t n_runs, const DevRun *runs, const DevTile *tiles, const DevField *fields,
+                           const DevPrim *prims, const DevConst &cst, TilePartial *partial)
+{
+    if (n_runs <= 0) return 0;
+    hipLaunchKernelGGL(k_quiet_run_stats, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, st, n_runs, runs, tiles, fields, prims, cst,
+                       partial);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -65,7 +65,16 @@ struct DevTile {
     int64_t start;       // first point of the tile inside the field's path
     int32_t idx0, off0;  // layer 1 only: pass position idx and offset inside the pass of `start` (start = idx0*per + off0)
     int32_t quiet;       // 1: the tile and its sweep neighbourhood lie on ONE swath line (closed-form results, see fcpp_fused.hip)
+    int32_t stat_tile;   // quiet chunks only: the tile whose partial statistics collect this chunk's flag counts
+};
+
+// A quiet run = one quiet zone of a straight primitive (consecutive quiet tiles).  Its points are STORED by chunks cut on
+// 512-point boundaries of the batch arrays (aligned 1 KiB stores), its length / time statistics are one closed form for the
+// whole run, credited to the run's first tile -- so the statistics do not depend on where the field sits in the batch.
+struct DevRun {
+    int32_t tile;        // first tile of the run (geometry: field, idx0, off0, kind)
     int32_t _pad;
+    int64_t count;       // points in the run
 };
 
 // batch-wide turn templates: every field of a batch shares the vehicle and the sampling options, hence the number of

@@ -22,10 +22,12 @@ torch.cuda.synchronize()
 st = res.stats()
 q, g = b.point_split()
 ntiles = int(os.environ.get('FCPP_GENERAL_TILES', '0')) or max(1, g // 440)   # general tiles (approx. if not given)
-names = [('main_len_m', 'load tile+field, both halos'), ('main_time_pre_s', 'decode+generate'), ('main_time_s', 'neighbour exchange'),
+names = [('max_kappa', '  load tile + field -> scalars'), ('max_alat', '  backward halo'), ('max_jump', '  forward halo'),
+         ('main_len_m', 'load tile+field, both halos'), ('main_time_pre_s', 'decode+generate'), ('main_time_s', 'neighbour exchange'),
          ('head_len_m', 'd/kappa/geofence'), ('head_time_pre_s', 'store x,y,kappa'), ('head_time_s', 'clamp+scan'),
          ('n_viol', 'prev exchange'), ('n_outside', 'metrics'), ('n_in_obstacle', 'store v,fs + reduce'),
          ('n_adjusted', 'TOTAL')]
 print(os.environ.get('FCPP_LIBRARY'), 'tiles', ntiles)
 for k, label in names:
-    print(f'{label:36s} {st[k].sum() / ntiles:10.0f} cycles')
+    val = st[k].mean() if k.startswith('max_') else st[k].sum() / ntiles     # max_* fields: per-field MAXIMUM over tiles, mean over fields
+    print(f'{label:36s} {val:10.0f} cycles')

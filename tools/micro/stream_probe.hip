@@ -1,0 +1,84 @@
+// Tuning microbenchmark: write streams advancing in lockstep (what k_plan_quiet does with its five output arrays).
+//   A: 5 x 8-byte streams, tiles of 512 elements, every store 1 KiB-aligned
+//   B: 4 x 8-byte + 1 x 4-byte stream (the real mix), aligned tiles
+//   C: B with tiles of 510 elements (tile boundaries fall anywhere in a cache line; lanes beyond the count are masked)
+//   S: A's bytes, one stream after the other
+// hipcc --offload-arch=gfx950 -O3 -o stream_probe stream_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int K8, int K4, int TILE>
+__global__ __launch_bounds__(256) void k_streams(double *base, size_t dist, size_t n_tiles)
+{
+    const size_t tile = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x & 63;
+    const size_t g0 = tile * TILE;
+    const int odd = (int)(g0 & 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = 2 * (lane + 64 * k) - odd;
+        const bool has0 = j >= 0 && j < TILE, has1 = j + 1 < TILE;
+        const size_t idx = g0 + j;
+        const double v = (double)idx;
+        if (has0 && has1) {
+#pragma unroll
+            for (int s = 0; s < K8; ++s) *reinterpret_cast<double2 *>(base + s * dist + idx) = make_double2(v, v + 1.0);
+#pragma unroll
+            for (int s = 0; s < K4; ++s)
+                *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned *>(base + (K8 + s) * dist) + idx) = make_uint2((unsigned)idx, 7u);
+        } else if (has0 || has1) {
+            const size_t i1 = has0 ? idx : idx + 1;
+#pragma unroll
+            for (int s = 0; s < K8; ++s) base[s * dist + i1] = v;
+#pragma unroll
+            for (int s = 0; s < K4; ++s) reinterpret_cast<unsigned *>(base + (K8 + s) * dist)[i1] = 7u;
+        }
+    }
+}
+
+template <int K8, int K4, int TILE>
+float run(double *base, size_t dist, size_t n, int reps)
+{
+    const size_t n_tiles = n / TILE;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_streams<K8, K4, TILE>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, base, dist, n_tiles);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL((k_streams<K8, K4, TILE>), dim3((unsigned)((n_tiles + 3) / 4)), dim3(256), 0, 0, base, dist, n_tiles);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    CHK(hipEventDestroy(e0)); CHK(hipEventDestroy(e1));
+    return ms / reps;
+}
+
+int main(int argc, char **argv)
+{
+    const size_t GiB = 1ull << 30;
+    const size_t slab_gib = argc > 1 ? atoi(argv[1]) : 72;
+    const size_t n = 1013583353ull / 512 * 512;
+    char *slab;
+    CHK(hipMalloc(&slab, slab_gib * GiB));
+    printf("slab %zu GiB at %p\n", slab_gib, (void *)slab);
+    const size_t dist = (size_t)(7.6 * GiB) / 4096 * 4096 / 8;   // elements
+    for (int rnd = 0; rnd < 2; ++rnd)
+        for (size_t base_gib : { 0, 8, 16, 24, 33 }) {
+            double *base = reinterpret_cast<double *>(slab + base_gib * GiB);
+            const float tA = run<5, 0, 512>(base, dist, n, 5);
+            const float tB = run<4, 1, 512>(base, dist, n, 5);
+            const float tC = run<4, 1, 510>(base, dist, n, 5);
+            float tS = 0;
+            for (int s = 0; s < 5; ++s) tS += run<1, 0, 512>(base + s * dist, 0, n, 5);
+            const double gA = 5.0 * n * 8 / 1e9, gB = 36.0 * n / 1e9;
+            printf("base %2zu GiB | A %.3f ms %.0f GB/s | B %.3f ms %.0f GB/s | C %.3f ms %.0f GB/s | S %.3f ms %.0f GB/s\n", base_gib, tA,
+                   gA / tA * 1e3, tB, gB / tB * 1e3, tC, gB / tC * 1e3, tS, gA / tS * 1e3);
+        }
+    return 0;
+}
