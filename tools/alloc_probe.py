@@ -37,7 +37,7 @@ def group(sizes_groups, oversize=0):
     out = [None] * 5
     keep = []
     for g in sizes_groups:
-        tot = sum(SZ[k] * n + 4096 for k in g) + oversize
+        tot = sum(SZ[k] * n + 4096 for k in g) + oversize if oversize >= 0 else (-oversize) << 30
         buf = torch.empty(tot, dtype=torch.uint8, device=dev)
         keep.append(buf)
         off = 0
@@ -48,10 +48,10 @@ def group(sizes_groups, oversize=0):
 
 
 for rnd in range(2):
-    for label, g, over in (('5 separate', [[0], [1], [2], [3], [4]], 0), ('1 slab', [[0, 1, 2, 3, 4]], 0),
-                           ('2 slabs (x y | k v fs)', [[0, 1], [2, 3, 4]], 0), ('3 slabs (x y | k v | fs)', [[0, 1], [2, 3], [4]], 0),
-                           ('5 separate, each 4 GiB oversized', [[0], [1], [2], [3], [4]], 4 << 30),
-                           ('5 separate, reverse order', [[4], [3], [2], [1], [0]], 0)):
+    for label, g, over in (('5 separate, exact', [[0], [1], [2], [3], [4]], 0), ('5 separate, +1 GiB each', [[0], [1], [2], [3], [4]], 1 << 30),
+                           ('5 separate, +2 GiB each', [[0], [1], [2], [3], [4]], 2 << 30), ('5 separate, +4 GiB each', [[0], [1], [2], [3], [4]], 4 << 30),
+                           ('5 separate, +8 GiB each', [[0], [1], [2], [3], [4]], 8 << 30),
+                           ('5 separate, 16 GiB each', [[0], [1], [2], [3], [4]], -16)):
         bufs, keep = group(g, over)
         timeit(bufs, label)
         del bufs, keep

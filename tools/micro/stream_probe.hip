@@ -67,6 +67,20 @@ int main(int argc, char **argv)
     char *slab;
     CHK(hipMalloc(&slab, slab_gib * GiB));
     printf("slab %zu GiB at %p\n", slab_gib, (void *)slab);
+    if (argc > 2) {   // map: a 8 GiB window (5 streams of 1.5 GiB, 1.6 GiB apart) slides over the slab
+        const size_t nm = (size_t)(1.5 * GiB) / 8 / 512 * 512, dm = (size_t)(1.6 * GiB) / 4096 * 4096 / 8;
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            printf("GB/s per 8 GiB window (B: 4x8+1x4 bytes aligned | S: one stream):");
+            for (size_t b = 0; b + 8 <= slab_gib; b += 8) {
+                double *base = reinterpret_cast<double *>(slab + b * GiB);
+                const float tB = run<4, 1, 512>(base, dm, nm, 3);
+                const float tS = run<1, 0, 512>(base, 0, nm * 4, 3);
+                printf(" %.0f|%.0f", 36.0 * nm / 1e9 / tB * 1e3, 8.0 * nm * 4 / 1e9 / tS * 1e3);
+            }
+            printf("\n");
+        }
+        return 0;
+    }
     const size_t dist = (size_t)(7.6 * GiB) / 4096 * 4096 / 8;   // elements
     for (int rnd = 0; rnd < 2; ++rnd)
         for (size_t base_gib : { 0, 8, 16, 24, 33 }) {
