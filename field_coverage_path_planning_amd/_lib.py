@@ -66,6 +66,14 @@ class FieldStats(C.Structure):
                 ('n_adjusted', C.c_int64)]
 
 
+class CoverJob(C.Structure):
+    """fcpp_cover_job (include/fcpp.h)"""
+    _fields_ = [('ox', C.c_double), ('oy', C.c_double), ('res', C.c_double), ('shift', C.c_double), ('radius', C.c_double),
+                ('nx', C.c_int32), ('ny', C.c_int32), ('n_a', C.c_int32), ('n_b', C.c_int32),
+                ('pts_first', C.c_int64), ('grid_first', C.c_int64), ('strict', C.c_int32), ('region', C.c_int32),
+                ('outer', C.c_double * 12), ('inner', C.c_double * 12)]
+
+
 STATS_DOUBLES = 9   # leading float64 members of FieldStats
 STATS_WORDS = 13    # 8-byte words per FieldStats
 
@@ -103,6 +111,7 @@ PROTOTYPES = [
     ('fcpp_straight_segments', C.c_int, [_VP, C.c_int64, _VP, C.c_int32, _VP]),
     ('fcpp_fresnel', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
     ('fcpp_ga_fitness', C.c_int, [_VP, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_int]),
+    ('fcpp_cover_grid', C.c_int, [_VP, C.c_int64, C.POINTER(CoverJob), C.c_int64, _VP, _VP, _VP, _VP]),
 ]
 
 _lib = None

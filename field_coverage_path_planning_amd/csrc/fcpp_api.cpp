@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "fcpp_cover.h"
 #include "fcpp_device.h"
 #include "fcpp_internal.h"
 
@@ -700,6 +701,38 @@ int fcpp_fresnel(fcpp_ctx *c, int64_t n, const double *t, double *cc, double *ss
     if (!c || n < 0 || (n > 0 && (!t || !cc || !ss))) return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     LAUNCHCHK(launch_fresnel(c->stream, n, t, cc, ss));
+    return FCPP_OK;
+}
+
+int fcpp_cover_grid(fcpp_ctx *c, int64_t n_jobs, const fcpp_cover_job *jobs, int64_t n_pts, const double *px, const double *py,
+                    uint8_t *grid, int64_t *counts)
+{
+    if (!c || n_jobs < 0 || (n_jobs > 0 && (!jobs || !counts))) return fail(FCPP_EINVAL, "bad arguments");
+    if (n_jobs == 0) return FCPP_OK;
+    std::vector<DevCoverJob> dj((size_t)n_jobs);
+    int64_t tiles = 0;
+    for (int64_t k = 0; k < n_jobs; ++k) {
+        const fcpp_cover_job &j = jobs[k];
+        if (j.nx < 0 || j.ny < 0 || j.n_a < 0 || j.n_b < 0 || !(j.res > 0) || !(j.radius >= 0) || j.pts_first < 0 ||
+            j.pts_first + j.n_a + j.n_b > n_pts || ((j.n_a > 0 || j.n_b > 0) && (!px || !py)) || (j.grid_first >= 0 && !grid))
+            return fail(FCPP_EINVAL, "bad coverage job");
+        DevCoverJob &d = dj[(size_t)k];
+        d.ox = j.ox; d.oy = j.oy; d.res = j.res; d.shift = j.shift; d.radius = j.radius;
+        d.nx = j.nx; d.ny = j.ny; d.n_a = j.n_a; d.n_b = j.n_b; d.pts_first = j.pts_first; d.grid_first = j.grid_first;
+        d.strict = j.strict; d.region = j.region;
+        memcpy(d.outer, j.outer, sizeof d.outer); memcpy(d.inner, j.inner, sizeof d.inner);
+        d.tiles_x = (j.nx + 63) / 64; d.tiles_y = (j.ny + 63) / 64;
+        d.tile_first = tiles;
+        tiles += (int64_t)d.tiles_x * d.tiles_y;
+    }
+    if (tiles > 0x7fffffffLL) return fail(FCPP_ESIZE, "coverage grids too large for one call");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    DevBuf<DevCoverJob> dev;
+    HIPCHK(dev.upload(dj, st));
+    HIPCHK(hipMemsetAsync(counts, 0, (size_t)n_jobs * 3 * sizeof(int64_t), st));
+    LAUNCHCHK(launch_cover(st, n_jobs, tiles, dev.p, px, py, grid, reinterpret_cast<unsigned long long *>(counts)));
+    HIPCHK(hipStreamSynchronize(st));      // the job table dies here
     return FCPP_OK;
 }
 

@@ -387,3 +387,54 @@ def ga_fitness(routes, D, order_mode=0, device=None):
     L.check(ctx.lib.fcpp_ga_fitness(ctx.handle, n, r.shape[0], _ptr(D), _ptr(r), _ptr(dist), _ptr(fit),
                                     int(order_mode)))
     return dist, fit
+
+
+# ---- coverage rasterisation (include/fcpp.h: fcpp_cover_grid; MLP:1357-1371, 1426-1509) ------------------------------
+def half_planes(vertices):
+    """12 doubles (a, b, c) x 4 for a convex quadrilateral: inside <=> a*x + b*y + c >= 0 for all four edges."""
+    v = [(float(x), float(y)) for x, y in vertices]
+    area2 = sum(v[i][0] * v[(i + 1) % 4][1] - v[(i + 1) % 4][0] * v[i][1] for i in range(4))
+    sgn = 1.0 if area2 > 0 else -1.0
+    out = []
+    for i in range(4):
+        (x0, y0), (x1, y1) = v[i], v[(i + 1) % 4]
+        a, b = -(y1 - y0) * sgn, (x1 - x0) * sgn            # inward normal (not normalised: only the sign is used)
+        out += [a, b, -(a * x0 + b * y0)]
+    return out
+
+
+NOWHERE = [0.0, 0.0, -1.0] * 4      # half-planes nobody is inside of (an empty inner polygon)
+
+
+def make_cover_job(ox, oy, res, nx, ny, radius, n_a, n_b=0, pts_first=0, grid_first=-1, shift=0.0, strict=True, outer=None,
+                   inner=None):
+    j = L.CoverJob()
+    j.ox, j.oy, j.res, j.shift, j.radius = float(ox), float(oy), float(res), float(shift), float(radius)
+    j.nx, j.ny, j.n_a, j.n_b = int(nx), int(ny), int(n_a), int(n_b)
+    j.pts_first, j.grid_first = int(pts_first), int(grid_first)
+    j.strict, j.region = int(bool(strict)), int(outer is not None)
+    j.outer[:] = list(outer) if outer is not None else [0.0] * 12
+    j.inner[:] = list(inner) if inner is not None else NOWHERE
+    return j
+
+
+def cover_grid(jobs, px, py, want_grid=False, device=None):
+    """Run a list of L.CoverJob over the device (or host) point arrays px, py.
+    -> (counts int64 tensor (n_jobs, 3), grid uint8 tensor or None); a job's grid is grid[j.grid_first : + nx*ny].view(ny, nx)."""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    px, py = _dev_f64(px, dev), _dev_f64(py, dev)
+    n = len(jobs)
+    total = 0
+    if want_grid:                       # (the jobs are updated in place: grid_first tells the caller where each grid starts)
+        for j in jobs:
+            j.grid_first = total
+            total += j.nx * j.ny
+    arr = (L.CoverJob * max(n, 1))(*jobs)
+    grid = torch.zeros(total, dtype=torch.uint8, device=dev) if want_grid else None
+    counts = torch.zeros((n, 3), dtype=torch.int64, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_cover_grid(ctx.handle, n, arr, px.numel(), _ptr(px), _ptr(py), _ptr(grid) if want_grid and total else None,
+                                    _ptr(counts)))
+    return counts, grid

@@ -16,8 +16,12 @@ converts arguments and assembles the result dictionary.  The names the reference
 README import but the reference never defines (TwoLayerPathPlannerV35/V36, TwoLayerPlannerV35/V36,
 `vehicle=`, `.plan()`) are provided as aliases so that those scripts resolve.
 
-Not reproduced: matplotlib plotting helpers, the Shapely objects under result['...']['area'] (a plain
-vertex-list polygon is returned instead) and `coverage_rate` (needs polygon clipping, SURVEY.md 8f -> NaN).
+        .verify_all_corners_coverage(result['headland']) / .verify_corner_coverage_grid_based(...)   MLP:1426-1578
+        ._calculate_coverage_rate(path, area)                               MLP:1357-1371
+
+Not reproduced: matplotlib plotting helpers and the Shapely objects under result['...']['area'] (a plain
+vertex-list polygon is returned instead).  `coverage_rate` is sampled on a 0.1 m grid (`coverage_resolution=`)
+instead of GEOS polygon clipping.
 """
 import math
 import time
@@ -59,9 +63,10 @@ class QuadPolygon:
         def __init__(self, vs):
             self.coords = list(vs) + [vs[0]]
 
-    def __init__(self, vertices, area=None):
+    def __init__(self, vertices, area=None, hole=None):
         self.vertices = [(float(x), float(y)) for x, y in vertices]
         self._area = area
+        self.hole = [(float(x), float(y)) for x, y in hole] if hole else None   # headland ring = field minus main-work polygon
 
     @property
     def area(self):
@@ -110,13 +115,14 @@ class TwoLayerPathPlannerV37:
                  obstacles: List[List[Tuple[float, float]]] = None, start_point: Tuple[float, float] = None,
                  end_point: Tuple[float, float] = None, *, vehicle: VehicleParams = None, verbose: bool = False,
                  turn_model: str = 'arc', sample_spacing: float = 0.0, clothoid_frac: float = 0.5,
-                 clothoid_fit: int = 1, geofence_tol: float = 1e-6, device: int = None):
+                 clothoid_fit: int = 1, geofence_tol: float = 1e-6, coverage_resolution: float = 0.1, device: int = None):
         if vehicle_params is None:
             vehicle_params = vehicle if vehicle is not None else VehicleParams()   # README_en.md:274-302 uses vehicle=
         self.vehicle = vehicle_params
         self.obstacles = obstacles or []
         self.verbose = verbose
         self._device = device
+        self.coverage_resolution = float(coverage_resolution)   # sample spacing of coverage_rate [m] (build-defined)
         self._spec = E.FieldSpec(field_length, field_width, field_vertices, self.obstacles, start_point, end_point)
         self._veh = E.make_vehicle(self.vehicle)
         self._opt = E.make_options(L.TURN_CLOTHOID if str(turn_model).lower().startswith('cloth') else L.TURN_ARC,
@@ -161,6 +167,8 @@ class TwoLayerPathPlannerV37:
             res = batch.run()
             ap, dp = batch.connectors()
             n_main, n_head = info.n_main, info.n_head
+            # coverage of the headland ring by the headland path, straight from the device arrays (MLP:884, 1357-1371)
+            coverage_rate = self._coverage_rate_dev(res.x[n_main:], res.y[n_main:], self._headland_area())
             x, y = res.x.cpu().numpy(), res.y.cpu().numpy()
             v, kappa, fs = res.v.cpu().numpy(), res.kappa.cpu().numpy(), res.flagseg.cpu().numpy().view(np.uint32)
             st = {k: a[0] for k, a in res.stats().items()}
@@ -172,7 +180,7 @@ class TwoLayerPathPlannerV37:
         main_pre, head_pre = st['main_time_pre_s'], st['head_time_pre_s']
         W, R = self.vehicle.working_width, self.vehicle.min_turn_radius
         main_area = QuadPolygon(_inset_for_area(self.field_vertices, R))
-        head_area = QuadPolygon(self.field_vertices, area=self.field_polygon.area - main_area.area)
+        head_area = self._headland_area()
         main_work = {
             'path': path[:n_main], 'speeds': v[:n_main], 'pattern': self.main_work_pattern, 'area': main_area,
             'stats': {
@@ -188,7 +196,7 @@ class TwoLayerPathPlannerV37:
                 'path_length_km': head_len / 1000,
                 'time_hours': st['head_time_s'] / 3600,                                      # MLP:428-431
                 'avg_speed_kmh': (head_len / 1000) / (head_pre / 3600) if head_pre > 0 else 0,
-                'coverage_rate': float('nan'),   # needs polygon clipping (MLP:1357-1371), SURVEY.md 8f
+                'coverage_rate': coverage_rate,   # MLP:884 (0..1), sampled at self.coverage_resolution
             },
             'kappa': kappa[n_main:], 'flagseg': fs[n_main:],
         }
@@ -278,6 +286,126 @@ class TwoLayerPathPlannerV37:
     def _generate_straight_segment(self, start, end, num_points: int = 20) -> np.ndarray:
         """MLP:1013-1022."""
         return self._generate_approach_path(start, end, num_points)
+
+    # ---- coverage (MLP:1357-1371, 1426-1578): sampled on the GPU by fcpp_cover_grid ----------------------------------
+    def _headland_area(self) -> QuadPolygon:
+        """field minus the polygon inset by headland_width (MLP:867-877); the whole field if the inset is empty."""
+        inner = _inset_for_area(self.field_vertices, self.headland_width)
+        main = QuadPolygon(inner)
+        if not _inset_is_valid(self.field_vertices, inner) or main.area < 1.0:
+            return QuadPolygon(self.field_vertices)
+        return QuadPolygon(self.field_vertices, area=self.field_polygon.area - main.area, hole=inner)
+
+    def _coverage_rate_dev(self, px, py, area) -> float:
+        n = int(px.shape[0])
+        if n < 2:
+            return 0.0                                                          # MLP:1359-1360
+        x0, y0, x1, y1 = area.bounds
+        res = self.coverage_resolution
+        nx, ny = max(1, int(math.ceil((x1 - x0) / res))), max(1, int(math.ceil((y1 - y0) / res)))
+        job = E.make_cover_job(x0, y0, res, nx, ny, self.vehicle.working_width / 2, n, shift=0.5, strict=False,
+                               outer=E.half_planes(area.vertices), inner=E.half_planes(area.hole) if area.hole else None)
+        counts, _ = E.cover_grid([job], px, py, device=self._device)
+        tot, cov = (int(c) for c in counts.cpu().numpy()[0, :2])
+        return cov / tot if tot > 0 else 0.0                                    # MLP:1368-1371 (0..1, not percent)
+
+    def _calculate_coverage_rate(self, path: np.ndarray, area) -> float:
+        """计算覆盖率 (MLP:1357-1371): share of `area` within working_width/2 of the path, sampled on a regular grid of
+        `coverage_resolution` metres (cell centres) instead of Shapely's buffer / intersection."""
+        path = np.asarray(path, dtype=np.float64)
+        if len(path) < 2:
+            return 0.0
+        if not isinstance(area, QuadPolygon):
+            area = QuadPolygon(list(area.exterior.coords)[:4])
+        return self._coverage_rate_dev(np.ascontiguousarray(path[:, 0]), np.ascontiguousarray(path[:, 1]), area)
+
+    def _generate_corner_turn_arc(self, corner, corner_index: int):
+        """15-point quarter arc of radius R leaving `corner` (MLP:1580-1608; quadrant formulas MLP:1049-1060)."""
+        R = self.vehicle.min_turn_radius
+        th = np.linspace(0, np.pi / 2, 15)
+        t1, t2 = R * (1 - np.cos(th)), R * np.sin(th)
+        x, y = corner
+        ax, ay = [(x + t1, y + t2), (x - t2, y + t1), (x - t1, y - t2), (x + t2, y - t1)][corner_index if corner_index in (0, 1, 2) else 3]
+        return np.column_stack([ax, ay]), [self.vehicle.headland_turn_speed_kmh] * 15
+
+    def _corner_reverse_path(self, turn: np.ndarray):
+        """Reverse fill after a corner turn (MLP:1154-1288): back up along the end tangent until the nearest side of the
+        [0, L] x [0, H] box, at most 3R (2R if no side lies ahead); max(10, int(len / 0.5)) points."""
+        R = self.vehicle.min_turn_radius
+        end, tang = turn[-1], turn[-1] - turn[-2]
+        nrm = float(np.linalg.norm(tang))
+        d = -tang / nrm if nrm > 1e-6 else np.array([-1.0, 0.0])
+        hits = []
+        for p, dp, lo, hi in ((end[0], d[0], 0.0, self.field_length), (end[1], d[1], 0.0, self.field_width)):
+            if abs(dp) > 1e-6:
+                hits += [t for t in ((lo - p) / dp, (hi - p) / dp) if t > 0]
+        length = min(min(hits), 3.0 * R) if hits else 2.0 * R
+        t = np.linspace(0, length, max(10, int(length / 0.5)))
+        return end + t[:, None] * d, length
+
+    def verify_corner_coverage_grid_based(self, corner, corner_index: int, turn_path: np.ndarray,
+                                          reverse_path: np.ndarray = None) -> Dict:
+        """网格化验证转角覆盖率 (MLP:1426-1509): 0.1 m grid over the 2R x 2R corner square; a cell is covered if its
+        corner point lies strictly within W/2 of the turn polyline, then (cells still open) of the reverse polyline."""
+        return self._corner_grids([(corner, corner_index, turn_path, reverse_path)])[0]
+
+    def _corner_grids(self, items):
+        R, W, res = self.vehicle.min_turn_radius, self.vehicle.working_width, 0.1
+        gs = int(2 * R / res)                                                   # MLP:1456
+        jobs, pts = [], []
+        first = 0
+        origins = []
+        for (cx, cy), ci, turn, rev in items:
+            origin = [(cx, cy), (cx - 2 * R, cy), (cx - 2 * R, cy - 2 * R), (cx, cy - 2 * R)][ci if ci in (0, 1, 2) else 3]   # MLP:1460-1467
+            turn = np.asarray(turn, dtype=np.float64).reshape(-1, 2)
+            rev = np.asarray(rev, dtype=np.float64).reshape(-1, 2) if rev is not None and len(rev) > 0 else np.zeros((0, 2))
+            jobs.append(E.make_cover_job(origin[0], origin[1], res, gs, gs, W / 2, len(turn), len(rev), pts_first=first))
+            pts += [turn, rev]
+            first += len(turn) + len(rev)
+            origins.append(origin)
+        xy = np.vstack(pts)
+        counts, grid = E.cover_grid(jobs, np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1]), want_grid=True,
+                                    device=self._device)
+        grid = grid.cpu().numpy().reshape(len(items), gs, gs)
+        counts = counts.cpu().numpy()
+        out = []
+        for k in range(len(items)):
+            before, after = counts[k, 1] / (gs * gs) * 100, counts[k, 2] / (gs * gs) * 100     # MLP:1485, 1499
+            out.append({'coverage_before': before, 'coverage_after': after, 'improvement': after - before,
+                        'grid': grid[k] != 0, 'grid_origin': origins[k], 'grid_resolution': res})
+        return out
+
+    def verify_all_corners_coverage(self, headland_result: Dict = None) -> Dict:
+        """验证所有4个角落的覆盖率 (MLP:1511-1578): the four corners of the rectangle inset by headland_width, each with its
+        quarter-arc turn and, where the corner gap is large enough, the reverse fill; one GPU call for all four."""
+        hw, Lf, Hf = self.headland_width, self.field_length, self.field_width
+        R, W = self.vehicle.min_turn_radius, self.vehicle.working_width
+        # gap.area > 0.1 (MLP:1557) by the same analytic bound libfcpp's host setup uses (fcpp_host.cpp)
+        reverse = 4 * R * R - (math.pi * R * W / 2 + math.pi * W * W / 4) > 0.1
+        items = []
+        for cx, cy, ci in ((hw, hw, 0), (Lf - hw, hw, 1), (Lf - hw, Hf - hw, 2), (hw, Hf - hw, 3)):
+            turn, _ = self._generate_corner_turn_arc((cx, cy), ci)
+            rev = self._corner_reverse_path(turn)[0] if reverse else None
+            items.append(((cx, cy), ci, turn, rev))
+        corners = self._corner_grids(items)
+        if self.verbose:
+            for ci, r in enumerate(corners):
+                print(f"  角落{ci}: 填充前={r['coverage_before']:.1f}%, 填充后={r['coverage_after']:.1f}%, "
+                      f"改进=+{r['improvement']:.1f}%")
+        b = float(np.mean([r['coverage_before'] for r in corners]))
+        a = float(np.mean([r['coverage_after'] for r in corners]))
+        return {'corners': corners, 'avg_coverage_before': b, 'avg_coverage_after': a, 'avg_improvement': a - b}
+
+
+def _inset_is_valid(vertices, inset):
+    """every inset edge keeps the direction of its source edge (otherwise the inset polygon is empty)"""
+    n = len(vertices)
+    for i in range(n):
+        ex, ey = vertices[(i + 1) % n][0] - vertices[i][0], vertices[(i + 1) % n][1] - vertices[i][1]
+        fx, fy = inset[(i + 1) % n][0] - inset[i][0], inset[(i + 1) % n][1] - inset[i][1]
+        if fx * ex + fy * ey <= 0:
+            return False
+    return True
 
 
 def _inset_for_area(vertices, d):

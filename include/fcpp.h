@@ -203,6 +203,40 @@ int fcpp_fresnel(fcpp_ctx *ctx, int64_t n, const double *t_dev, double *c_dev, d
 int fcpp_ga_fitness(fcpp_ctx *ctx, int32_t n_nodes, int64_t pop, const double *D_dev,
                     const int32_t *routes_dev, double *dist_dev, double *fit_dev, int order_mode);
 
+/* ---- coverage rasterisation -------------------------------------------------
+ * Replaces the Shapely calls of verify_corner_coverage_grid_based (MLP:1426-1509: `LineString(path).buffer(W/2)
+ * .contains(Point)` per 0.1 m grid cell of a 2R x 2R corner square, first for the turn, then for the reverse fill on
+ * the cells still open) and of _calculate_coverage_rate (MLP:1357-1371: area(path.buffer(W/2) & area) / area(area)),
+ * by one sampled operator: a job is a regular grid of sample points, a polyline A and an optional polyline B (stored
+ * right after A in px/py).  A sample is covered by a polyline iff its distance to one of the polyline's segments
+ * (consecutive point pairs, jumps included -- as in LineString(path)) is < radius (strict = 1, Shapely's `contains`)
+ * or <= radius (strict = 0).  The distance test is division-free and the same in the oracle and on the GPU: with
+ * a -> b the segment, p the sample, dot = (p-a).(b-a), len2 = |b-a|^2:
+ *     dot <= 0     : |p-a|^2              < radius^2
+ *     dot >= len2  : |p-b|^2              < radius^2
+ *     otherwise    : ((b-a) x (p-a))^2    < radius^2 * len2
+ * B is only evaluated on samples A left open (MLP:1489-1497).  counts (3 per job): samples in the region, of those
+ * covered by A, of those covered by A or B.  grid (optional): one byte per sample, row-major [j][i] like the
+ * reference's grid[j, i] (MLP:1483), bit 0 = A, bit 1 = B (and not A); samples outside the region stay 0. */
+typedef struct fcpp_cover_job {
+    double ox, oy;        /* sample (i, j) lies at (ox + (i + shift) * res, oy + (j + shift) * res) */
+    double res, shift;    /* MLP:1449, 1477-1478: res = 0.1, shift = 0 (cell corners); 0.5 = cell centres for area estimates */
+    double radius;        /* W / 2 (MLP:1471, 1363) */
+    int32_t nx, ny;       /* samples per row, rows */
+    int32_t n_a, n_b;     /* points of polyline A and of polyline B (0 = none) */
+    int64_t pts_first;    /* index of A's first point in px / py */
+    int64_t grid_first;   /* offset of this job's nx * ny bytes in `grid`, or -1: counts only */
+    int32_t strict;       /* 1: distance < radius, 0: distance <= radius */
+    int32_t region;       /* 0: every sample counts; 1: samples inside `outer` and not inside `inner` */
+    double outer[12];     /* 4 half-planes (a, b, c): inside <=> a*x + b*y + c >= 0 for all four */
+    double inner[12];
+} fcpp_cover_job;
+
+/* jobs: host array; px, py: device (n_pts points, e.g. the x / y arrays of fcpp_batch_run); grid_dev may be NULL when no job
+ * asks for it; counts_dev: 3 * n_jobs int64 (zeroed by the call).  Runs on the context's stream and synchronises it. */
+int fcpp_cover_grid(fcpp_ctx *ctx, int64_t n_jobs, const fcpp_cover_job *jobs, int64_t n_pts, const double *px_dev,
+                    const double *py_dev, uint8_t *grid_dev, int64_t *counts_dev);
+
 #ifdef __cplusplus
 }
 #endif

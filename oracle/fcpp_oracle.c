@@ -772,3 +772,54 @@ void orc_plan_free(orc_plan *p)
     free(p->xy); free(p->v); free(p->kappa); free(p->flagseg);
     p->xy = p->v = p->kappa = NULL; p->flagseg = NULL;
 }
+
+/* ---- coverage rasterisation (build-defined sampling of MLP:1357-1371, 1426-1509) ------------------------------------ */
+static int orc_seg_covers(double ax, double ay, double bx, double by, double X, double Y, double r2, int strict)
+{
+    const double abx = bx - ax, aby = by - ay, apx = X - ax, apy = Y - ay;
+    const double len2 = abx * abx + aby * aby, dot = apx * abx + apy * aby;
+    double lhs, rhs = r2;
+    if (dot <= 0.0) lhs = apx * apx + apy * apy;
+    else if (dot >= len2) { const double bpx = X - bx, bpy = Y - by; lhs = bpx * bpx + bpy * bpy; }
+    else { const double cr = abx * apy - aby * apx; lhs = cr * cr; rhs = r2 * len2; }
+    return strict ? (lhs < rhs) : (lhs <= rhs);
+}
+
+static int orc_line_covers(const double *x, const double *y, int32_t n, double X, double Y, double r2, int strict)
+{
+    for (int32_t s = 0; s + 1 < n; ++s)
+        if (orc_seg_covers(x[s], y[s], x[s + 1], y[s + 1], X, Y, r2, strict)) return 1;
+    return 0;
+}
+
+void orc_cover_grid(double ox, double oy, double res, double shift, double radius, int32_t nx, int32_t ny, const double *ax,
+                    const double *ay, int32_t n_a, const double *bx, const double *by, int32_t n_b, int strict,
+                    const double *region, uint8_t *grid, int64_t *counts)
+{
+    const double r2 = radius * radius;
+    counts[0] = counts[1] = counts[2] = 0;
+    for (int32_t j = 0; j < ny; ++j) {
+        const double Y = oy + ((double)j + shift) * res;
+        for (int32_t i = 0; i < nx; ++i) {
+            const double X = ox + ((double)i + shift) * res;      /* MLP:1477-1478 with shift = 0 */
+            int in = 1;
+            if (region) {
+                int io = 1, ii = 1;
+                for (int e = 0; e < 4; ++e) {
+                    io = io && (region[3 * e] * X + region[3 * e + 1] * Y + region[3 * e + 2] >= 0.0);
+                    ii = ii && (region[12 + 3 * e] * X + region[12 + 3 * e + 1] * Y + region[12 + 3 * e + 2] >= 0.0);
+                }
+                in = io && !ii;
+            }
+            uint8_t g = 0;
+            if (in) {
+                counts[0]++;
+                if (orc_line_covers(ax, ay, n_a, X, Y, r2, strict)) g = 1;                    /* MLP:1481-1483 */
+                else if (n_b > 1 && orc_line_covers(bx, by, n_b, X, Y, r2, strict)) g = 2;    /* MLP:1489-1497 */
+                counts[1] += (g == 1);
+                counts[2] += (g != 0);
+            }
+            if (grid) grid[(int64_t)j * nx + i] = g;
+        }
+    }
+}

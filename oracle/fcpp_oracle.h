@@ -119,6 +119,16 @@ double orc_cac_fit_radius(double dth, double R, double f, int fit);
 int orc_point_in_polygon(double px, double py, const double *poly_xy, int64_t nv);  /* even-odd */
 int orc_outside_convex(double px, double py, const double *vx, const double *vy, int nv, double tol);
 
+/* coverage rasterisation: the sampled restatement of MLP:1426-1509 (corner grids) and MLP:1357-1371 (coverage rate).
+ * Sample (i, j) = (ox + (i + shift) * res, oy + (j + shift) * res); covered by a polyline iff within `radius` of one of its
+ * segments (strict: <, else <=; division-free test, see include/fcpp.h); polyline B is tried only on samples A left open
+ * (MLP:1489-1497).  region: NULL, or 24 doubles = 4 outer + 4 inner half-planes (a, b, c), a sample counts iff inside all
+ * outer ones and not inside all inner ones.  grid (may be NULL): nx*ny bytes [j][i], bit 0 = A, bit 1 = B; counts[3] =
+ * samples in region, covered by A, covered by A or B. */
+void orc_cover_grid(double ox, double oy, double res, double shift, double radius, int32_t nx, int32_t ny, const double *ax,
+                    const double *ay, int32_t n_a, const double *bx, const double *by, int32_t n_b, int strict,
+                    const double *region, uint8_t *grid, int64_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,9 @@ def lib():
         L.orc_cac_fit_radius.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
         L.orc_point_in_polygon.restype = C.c_int
         L.orc_point_in_polygon.argtypes = [C.c_double, C.c_double, c_double_p, C.c_int64]
+        L.orc_cover_grid.restype = None
+        L.orc_cover_grid.argtypes = [C.c_double] * 5 + [C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p,
+                                     C.c_int32, C.c_int, c_double_p, C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
         L.orc_outside_convex.restype = C.c_int
         L.orc_outside_convex.argtypes = [C.c_double, C.c_double, c_double_p, c_double_p, C.c_int, C.c_double]
         _lib = L
@@ -262,6 +265,21 @@ def cac_points(x0, y0, th0, dth, R, f, fit, n):
 def point_in_polygon(px, py, poly):
     poly = _f64(poly)
     return bool(lib().orc_point_in_polygon(px, py, _dp(poly), len(poly)))
+
+
+def cover_grid(ox, oy, res, shift, radius, nx, ny, a_xy, b_xy=None, strict=True, region=None, want_grid=True):
+    """-> (counts[3], grid (ny, nx) uint8 or None); region = 24 doubles (4 outer + 4 inner half-planes) or None."""
+    a = _f64(np.asarray(a_xy, dtype=np.float64).reshape(-1, 2))
+    b = _f64(np.asarray(b_xy if b_xy is not None else np.zeros((0, 2)), dtype=np.float64).reshape(-1, 2))
+    ax, ay = _f64(a[:, 0].copy()), _f64(a[:, 1].copy())
+    bx, by = _f64(b[:, 0].copy()), _f64(b[:, 1].copy())
+    reg = _f64(np.asarray(region, dtype=np.float64)) if region is not None else None
+    grid = np.zeros((ny, nx), dtype=np.uint8) if want_grid else None
+    counts = np.zeros(3, dtype=np.int64)
+    lib().orc_cover_grid(ox, oy, res, shift, radius, nx, ny, _dp(ax), _dp(ay), len(ax), _dp(bx), _dp(by), len(bx), int(bool(strict)),
+                         _dp(reg) if reg is not None else None, grid.ctypes.data_as(C.POINTER(C.c_uint8)) if want_grid else None,
+                         counts.ctypes.data_as(C.POINTER(C.c_int64)))
+    return counts, grid
 
 
 class PlanResult:

@@ -27,6 +27,13 @@ def golden_ga():
 
 
 @pytest.fixture(scope='session')
+def golden_cover():
+    """corner grid verification run by the reference (tools/gen_golden.py tier_cover)"""
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, 'golden_cover.npz'))
+
+
+@pytest.fixture(scope='session')
 def golden_plans():
     import numpy as np
     return np.load(os.path.join(GOLDEN, 'golden_plans.npz'))

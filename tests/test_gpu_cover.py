@@ -1,0 +1,159 @@
+"""GPU parity of the coverage rasteriser (fcpp_cover_grid), through the C ABI: against the reference's
+corner grids (golden_cover.npz), against the CPU oracle on seeded jobs, and through the Python mirror of
+verify_all_corners_coverage / _calculate_coverage_rate.  Flags and counts are integers: everything is compared exactly."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from field_coverage_path_planning_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _box(x0, y0, x1, y1):
+    return [1, 0, -x0, 0, 1, -y0, -1, 0, x1, 0, -1, y1]
+
+
+def test_corner_grids_vs_reference_and_oracle(golden_cover):
+    """The reference's own corner grids (all corners of all scenarios in ONE call), cell for cell."""
+    g = golden_cover
+    jobs, pts, want, first = [], [], [], 0
+    for name in g['names']:
+        W, R = g[f'{name}/vp'][:2]
+        gs = int(2 * R / 0.1)
+        for ci in range(4):
+            k = f'{name}/c{ci}'
+            turn, rev = g[k + '/turn'], g[k + '/rev'].reshape(-1, 2)
+            ox, oy = g[k + '/origin']
+            jobs.append(E.make_cover_job(ox, oy, 0.1, gs, gs, W / 2, len(turn), len(rev), pts_first=first))
+            pts += [turn, rev]
+            first += len(turn) + len(rev)
+            want.append((np.unpackbits(g[k + '/grid_bits'])[:gs * gs].reshape(gs, gs).astype(bool), g[k + '/cov'], gs))
+    xy = np.vstack(pts)
+    counts, grid = E.cover_grid(jobs, xy[:, 0].copy(), xy[:, 1].copy(), want_grid=True)
+    counts, grid = _np(counts), _np(grid)
+    for k, (wgrid, cov, gs) in enumerate(want):
+        got = grid[jobs[k].grid_first:jobs[k].grid_first + gs * gs].reshape(gs, gs)
+        assert np.array_equal(got != 0, wgrid), k
+        assert counts[k, 0] == gs * gs and counts[k, 1] == (got == 1).sum() and counts[k, 2] == (got != 0).sum()
+        assert counts[k, 1] / (gs * gs) * 100 == cov[0] and counts[k, 2] / (gs * gs) * 100 == cov[1]
+
+
+def test_random_jobs_vs_oracle():
+    """Ragged grids (1 x n, 65 x 130, 200 x 33), cell corners and centres, strict and closed, with and without region,
+    polylines with repeated points / a single point / no B: flag bytes and counts equal the oracle's."""
+    rng = np.random.default_rng(77)
+    jobs, pts, spec, first = [], [], [], 0
+    shapes = [(1, 70), (65, 130), (200, 33), (64, 64), (129, 1), (300, 257)]
+    for n, (nx, ny) in enumerate(shapes * 2):
+        res = float(rng.choice([0.1, 0.25, 0.037]))
+        ox, oy = rng.uniform(-50, 50, 2)
+        w, h = nx * res, ny * res
+        na = int(rng.choice([1, 2, 7, 40, 300]))
+        nb = int(rng.choice([0, 0, 2, 25]))
+        a = np.column_stack([rng.uniform(ox - 0.2 * w, ox + 1.2 * w, na), rng.uniform(oy - 0.2 * h, oy + 1.2 * h, na)])
+        if na > 5:
+            a[3] = a[2]                                   # zero-length segment
+        b = np.column_stack([rng.uniform(ox, ox + w, nb), rng.uniform(oy, oy + h, nb)])
+        radius = float(rng.uniform(0.05, 0.3) * max(w, h))
+        shift = 0.5 if n % 2 else 0.0
+        strict = n % 3 != 0
+        region = None
+        if n % 4 == 1:
+            region = (_box(ox + 0.1 * w, oy + 0.1 * h, ox + 0.9 * w, oy + 0.8 * h), _box(ox + 0.3 * w, oy + 0.3 * h, ox + 0.6 * w, oy + 0.5 * h))
+        elif n % 4 == 3:
+            region = (E.half_planes([(ox, oy), (ox + w, oy + 0.2 * h), (ox + 0.8 * w, oy + h), (ox + 0.1 * w, oy + 0.7 * h)]), None)
+        jobs.append(E.make_cover_job(ox, oy, res, nx, ny, radius, na, nb, pts_first=first, shift=shift, strict=strict,
+                                     outer=region[0] if region else None, inner=region[1] if region else None))
+        pts += [a, b]
+        first += na + nb
+        spec.append((ox, oy, res, shift, radius, nx, ny, a, b, strict, (list(region[0]) + list(region[1] or E.NOWHERE)) if region else None))
+    xy = np.vstack(pts)
+    counts, grid = E.cover_grid(jobs, xy[:, 0].copy(), xy[:, 1].copy(), want_grid=True)
+    counts, grid = _np(counts), _np(grid)
+    for k, (ox, oy, res, shift, radius, nx, ny, a, b, strict, region) in enumerate(spec):
+        wc, wg = orc.cover_grid(ox, oy, res, shift, radius, nx, ny, a, b, strict=strict, region=region)
+        got = grid[jobs[k].grid_first:jobs[k].grid_first + nx * ny].reshape(ny, nx)
+        assert np.array_equal(got, wg), (k, int((got != wg).sum()))
+        assert np.array_equal(counts[k], wc), (k, counts[k], wc)
+    # counts-only call (no grid buffer) gives the same counts
+    for j in jobs:
+        j.grid_first = -1
+    c2, g2 = E.cover_grid(jobs, xy[:, 0].copy(), xy[:, 1].copy(), want_grid=False)
+    assert g2 is None and np.array_equal(_np(c2), counts)
+
+
+def test_mirror_corner_verification_vs_reference(golden_cover):
+    """planner.verify_all_corners_coverage(result['headland']) as the reference's test calls it (test_multi-layer_planner_v3.py:46)."""
+    from field_coverage_path_planning_amd.multi_layer_planner_v3 import TwoLayerPathPlannerV37, VehicleParams
+    g = golden_cover
+    names = ['working_width', 'min_turn_radius', 'max_work_speed_kmh', 'max_headland_speed_kmh', 'headland_turn_speed_kmh',
+             'max_lateral_accel', 'max_longitudinal_accel', 'safety_factor']
+    for name in g['names']:
+        Lf, Hf = g[f'{name}/LH']
+        pl = TwoLayerPathPlannerV37(VehicleParams(**dict(zip(names, g[f'{name}/vp']))), field_length=float(Lf), field_width=float(Hf))
+        res = pl.verify_all_corners_coverage(None)
+        np.testing.assert_allclose([res['avg_coverage_before'], res['avg_coverage_after'], res['avg_improvement']], g[f'{name}/avg'],
+                                   rtol=1e-12, atol=1e-12)
+        for ci, r in enumerate(res['corners']):
+            k = f'{name}/c{ci}'
+            gs = int(g[k + '/grid_shape'][0])
+            want = np.unpackbits(g[k + '/grid_bits'])[:gs * gs].reshape(gs, gs).astype(bool)
+            assert r['grid'].shape == (gs, gs) and r['grid'].dtype == bool
+            assert np.array_equal(r['grid'], want), (name, ci, int((r['grid'] != want).sum()))
+            assert (r['coverage_before'], r['coverage_after']) == tuple(g[k + '/cov'][:2])
+            np.testing.assert_allclose(r['grid_origin'], g[k + '/origin'], rtol=0, atol=0)
+            assert r['grid_resolution'] == 0.1
+        # the single-corner entry point with caller-supplied polylines
+        one = pl.verify_corner_coverage_grid_based(tuple(g[f'{name}/c2/corner']), 2, g[f'{name}/c2/turn'], g[f'{name}/c2/rev'])
+        assert one['coverage_after'] == g[f'{name}/c2/cov'][1]
+
+
+def test_coverage_rate_of_a_plan_vs_oracle():
+    """result['headland']['stats']['coverage_rate'] (MLP:884): the GPU's sample counts equal the oracle's on the same path; the
+    rate is a fraction in (0, 1]; a wider implement covers more."""
+    from field_coverage_path_planning_amd.multi_layer_planner_v3 import TwoLayerPathPlannerV37, VehicleParams
+    pl = TwoLayerPathPlannerV37(VehicleParams(), field_length=120.0, field_width=80.0, coverage_resolution=0.2)
+    r = pl.plan_complete_coverage()
+    rate = r['headland']['stats']['coverage_rate']
+    area = r['headland']['area']
+    assert area.hole is not None and 0.5 < rate <= 1.0
+    x0, y0, x1, y1 = area.bounds
+    nx, ny = int(np.ceil((x1 - x0) / 0.2)), int(np.ceil((y1 - y0) / 0.2))
+    wc, _ = orc.cover_grid(x0, y0, 0.2, 0.5, 1.6, nx, ny, r['headland']['path'], strict=False,
+                           region=E.half_planes(area.vertices) + E.half_planes(area.hole), want_grid=False)
+    assert rate == wc[1] / wc[0]
+    # ring area: samples x cell area -> the polygon area
+    assert abs(wc[0] * 0.04 - area.area) < 0.01 * area.area
+    assert pl._calculate_coverage_rate(r['headland']['path'], area) == rate
+    assert pl._calculate_coverage_rate(r['headland']['path'][:1], area) == 0.0
+    wide = TwoLayerPathPlannerV37(VehicleParams(working_width=4.0), field_length=120.0, field_width=80.0, coverage_resolution=0.2)
+    assert wide._calculate_coverage_rate(r['headland']['path'], area) > rate
+
+
+def test_coverage_of_a_dense_full_size_path():
+    """A 0.1 m-sampled clothoid headland path (tens of thousands of segments) on a 500 x 200 field at 0.1 m resolution (10^7
+    samples): size-independent properties -- the closed test covers at least what the strict one does, radius 0 covers nothing,
+    a radius larger than the ring covers all of it, and the count is monotone in the radius."""
+    specs = [E.FieldSpec(field_length=500.0, field_width=200.0)]
+    b = E.Batch(specs, E.make_vehicle(), E.make_options(1, 0.1))
+    res = b.run()
+    info = b.info[0]
+    hx, hy = res.x[info.n_main:], res.y[info.n_main:]
+    outer = E.half_planes([(0, 0), (500, 0), (500, 200), (0, 200)])
+    inner = E.half_planes([(8, 8), (492, 8), (492, 192), (8, 192)])
+    n = int(hx.shape[0])
+    assert n > 20000
+    jobs = [E.make_cover_job(0, 0, 0.1, 5000, 2000, r, n, shift=0.5, strict=s, outer=outer, inner=inner)
+            for r, s in ((0.0, True), (0.8, True), (1.6, True), (1.6, False), (3.2, False), (20.0, False))]
+    c = _np(E.cover_grid(jobs, hx, hy)[0])
+    ring = 500 * 200 * 100 - 484 * 184 * 100
+    assert (c[:, 0] == ring).all()
+    assert c[0, 1] == 0 and c[5, 1] == ring
+    assert c[1, 1] < c[2, 1] <= c[3, 1] < c[4, 1] <= ring
+    assert (c[:, 2] == c[:, 1]).all()          # no polyline B
+    b.close()

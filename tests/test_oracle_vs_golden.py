@@ -178,3 +178,39 @@ def test_published_pins(golden_plans):
 def test_error_cases():
     assert orc.plan_field(orc.make_field(L=15.0, H=200.0))[0] == -1     # MLP:597-598 ValueError
     assert orc.plan_field(orc.make_field(L=500.0, H=16.002))[0] == -1   # inset area 484*0.002 < 1
+
+
+# ---- corner grid verification (MLP:1426-1578), SURVEY.md 8f-1 -------------------------------------------------------
+def test_corner_cover_grids_match_the_reference(golden_cover):
+    """orc_cover_grid on the polylines the reference generated reproduces the reference's own grids cell for cell
+    (the reference ran verify_all_corners_coverage with the stand-in's exact `contains`, tools/gen_golden.py)."""
+    g = golden_cover
+    for name in g['names']:
+        vp = g[f'{name}/vp']
+        W, R = vp[0], vp[1]
+        gs = int(2 * R / 0.1)
+        befores, afters = [], []
+        for ci in range(4):
+            k = f'{name}/c{ci}'
+            assert tuple(g[k + '/grid_shape']) == (gs, gs)
+            want = np.unpackbits(g[k + '/grid_bits'])[:gs * gs].reshape(gs, gs).astype(bool)
+            ox, oy = g[k + '/origin']
+            counts, grid = orc.cover_grid(ox, oy, 0.1, 0.0, W / 2, gs, gs, g[k + '/turn'], g[k + '/rev'], strict=True)
+            assert np.array_equal(grid != 0, want), (name, ci, int(((grid != 0) != want).sum()))
+            before, after = counts[1] / (gs * gs) * 100, counts[2] / (gs * gs) * 100
+            assert before == g[k + '/cov'][0] and after == g[k + '/cov'][1]
+            assert counts[0] == gs * gs and np.array_equal(grid == 1, (grid != 0) & (grid != 2))
+            befores.append(before); afters.append(after)
+        np.testing.assert_allclose([np.mean(befores), np.mean(afters)], g[f'{name}/avg'][:2], rtol=1e-14)
+
+
+def test_cover_grid_area_of_a_capsule():
+    """sampled area of one buffered segment -> L * 2r + pi r^2 (what Shapely's buffer(...).area tends to)"""
+    counts, _ = orc.cover_grid(-2.0, -2.0, 0.01, 0.5, 1.0, 1400, 400, [[0.0, 0.0], [10.0, 0.0]], strict=False, want_grid=False)
+    assert abs(counts[1] * 1e-4 - (20 + np.pi)) < 5e-3
+    # a region (ring) restricts what counts: outer 14 x 4 box, inner 10 x 2 box around the segment
+    def box(x0, y0, x1, y1):
+        return [1, 0, -x0, 0, 1, -y0, -1, 0, x1, 0, -1, y1]
+    counts, _ = orc.cover_grid(-2.0, -2.0, 0.01, 0.5, 1.0, 1400, 400, [[0.0, 0.0], [10.0, 0.0]], strict=False,
+                               region=box(-2, -2, 12, 2) + box(0, -1, 10, 1), want_grid=False)
+    assert abs(counts[0] * 1e-4 - (56 - 20)) < 1e-9 and abs(counts[1] * 1e-4 - np.pi) < 5e-3

@@ -21,8 +21,11 @@ path generator reads from Shapely objects:
     a LOWER bound of the true gap area; the decision `gap.area > 0.1` is
     therefore exact whenever the bound itself exceeds 0.1.
 
-Everything that would need real polygon clipping (coverage_rate, corner grid
-verification) returns NaN and is excluded from the golden vectors.
+  * LineString.buffer(w).contains(Point) for the corner grid verification
+    (MLP:1471-1497): the exact distance test (GEOS would use a 32-gon per circle).
+
+What would need real polygon clipping (coverage_rate) returns NaN and is
+excluded from the golden vectors.
 """
 import math
 import sys
@@ -157,11 +160,33 @@ class _NaNArea:
 
 
 class _BufferedLine:
-    def __init__(self, length, w):
+    def __init__(self, length, w, pts=()):
         self.area = length * 2.0 * w + math.pi * w * w
+        self._pts, self._w = list(pts), w
 
     def intersection(self, other):   # coverage_rate (MLP:1365): needs real clipping
         return _NaNArea()
+
+    def contains(self, pt):
+        """Interior of the exact buffer (GEOS uses a polygonal approximation of the round parts: up to
+        w * (1 - cos(pi/32)) smaller there).  Point-to-segment test without division, the same one the oracle
+        and the HIP kernel use (include/fcpp.h, fcpp_cover_grid)."""
+        X, Y, r2 = pt.x, pt.y, self._w * self._w
+        for (ax, ay), (bx, by) in zip(self._pts[:-1], self._pts[1:]):
+            abx, aby, apx, apy = bx - ax, by - ay, X - ax, Y - ay
+            len2 = abx * abx + aby * aby
+            dot = apx * abx + apy * aby
+            if dot <= 0.0:
+                lhs, rhs = apx * apx + apy * apy, r2
+            elif dot >= len2:
+                bpx, bpy = X - bx, Y - by
+                lhs, rhs = bpx * bpx + bpy * bpy, r2
+            else:
+                cr = abx * apy - aby * apx
+                lhs, rhs = cr * cr, r2 * len2
+            if lhs < rhs:
+                return True
+        return False
 
 
 class LineString:
@@ -173,7 +198,7 @@ class LineString:
         for i in range(1, len(self._pts)):
             length += math.hypot(self._pts[i][0] - self._pts[i - 1][0],
                                  self._pts[i][1] - self._pts[i - 1][1])
-        return _BufferedLine(length, w)
+        return _BufferedLine(length, w, self._pts)
 
 
 class Point:

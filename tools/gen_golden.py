@@ -341,14 +341,54 @@ def tier_b():
     return out
 
 
+def tier_cover():
+    """Corner grid verification (MLP:1426-1578) run by the reference itself; `contains` comes from the stand-in."""
+    out, names = {}, []
+    for name, L, H, kw in (('500x200', 500.0, 200.0, {}), ('300x120_w2.4_r6', 300.0, 120.0, dict(working_width=2.4, min_turn_radius=6.0)),
+                           ('200x100_w5_r4.5', 200.0, 100.0, dict(working_width=5.0, min_turn_radius=4.5))):
+        vp = mlp.VehicleParams(**kw)
+        pl = quiet(mlp.TwoLayerPathPlannerV37, vp, field_length=L, field_width=H)
+        res = quiet(pl.verify_all_corners_coverage, None)
+        names.append(name)
+        out[f'{name}/LH'] = np.array([L, H])
+        out[f'{name}/vp'] = vp_array(vp)
+        out[f'{name}/avg'] = np.array([res['avg_coverage_before'], res['avg_coverage_after'], res['avg_improvement']])
+        hw = pl.headland_width
+        corners = [(hw, hw, 0), (L - hw, hw, 1), (L - hw, H - hw, 2), (hw, H - hw, 3)]
+        for (cx, cy, ci), r in zip(corners, res['corners']):
+            # the same generator calls verify_all_corners_coverage makes (MLP:1546-1558), to record the polylines
+            turn, _ = pl._generate_corner_turn_arc((cx, cy), ci)
+            gap = pl._calculate_corner_gap_precise((cx, cy), ci, vp.min_turn_radius, vp.working_width)
+            rev = np.zeros((0, 2))
+            if gap is not None and gap.area > 0.1:
+                rev, _ = quiet(pl._generate_optimal_reverse_path, gap, turn[-1], turn[-2], vp.working_width, ci)
+            k = f'{name}/c{ci}'
+            out[k + '/corner'] = np.array([cx, cy])
+            out[k + '/turn'] = np.asarray(turn, dtype=np.float64)
+            out[k + '/rev'] = np.asarray(rev, dtype=np.float64)
+            out[k + '/origin'] = np.array(r['grid_origin'], dtype=np.float64)
+            out[k + '/grid_shape'] = np.array(r['grid'].shape)
+            out[k + '/grid_bits'] = np.packbits(r['grid'])
+            out[k + '/cov'] = np.array([r['coverage_before'], r['coverage_after'], r['improvement']])
+    out['names'] = np.array(names)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if '--cover-only' in sys.argv:
+        c = tier_cover()
+        np.savez_compressed(os.path.join(OUT, 'golden_cover.npz'), **c)
+        for n in c['names']:
+            print(n, c[n + '/avg'], [c[f'{n}/c{k}/cov'].round(2).tolist() for k in range(4)])
+        return
     a = tier_a()
     np.savez_compressed(os.path.join(OUT, 'golden_kernels.npz'), **a)
     g = tier_ga()
     np.savez_compressed(os.path.join(OUT, 'golden_ga.npz'), **g)
     b = tier_b()
     np.savez_compressed(os.path.join(OUT, 'golden_plans.npz'), **b)
+    np.savez_compressed(os.path.join(OUT, 'golden_cover.npz'), **tier_cover())
 
     # --- the reference's own published pins (README_en.md:199-215, doc/V3.5.1:109-111)
     assert len(b['cfg1_500x200/main_path']) == 1256, len(b['cfg1_500x200/main_path'])
