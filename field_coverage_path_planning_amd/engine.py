@@ -427,10 +427,9 @@ def cover_grid(jobs, px, py, want_grid=False, device=None):
     px, py = _dev_f64(px, dev), _dev_f64(py, dev)
     n = len(jobs)
     total = 0
-    if want_grid:                       # (the jobs are updated in place: grid_first tells the caller where each grid starts)
-        for j in jobs:
-            j.grid_first = total
-            total += j.nx * j.ny
+    for j in jobs:                      # (updated in place: grid_first tells the caller where each job's grid starts)
+        j.grid_first = total if want_grid else -1
+        total += j.nx * j.ny if want_grid else 0
     arr = (L.CoverJob * max(n, 1))(*jobs)
     grid = torch.zeros(total, dtype=torch.uint8, device=dev) if want_grid else None
     counts = torch.zeros((n, 3), dtype=torch.int64, device=dev)

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Measurement of the coverage rasteriser (fcpp_cover_grid) -- a secondary figure; bench.py stays on the headline metric.
+
+  A. corner verification (MLP:1426-1578) of --fields rectangular fields: 4 corners x (2R/0.1)^2 cells, 15-point turn + reverse fill
+  B. coverage_rate (MLP:1357-1371) of the headland paths of --rate-fields fields (reference sampling) at 0.1 m, cell centres
+Prints one JSON line: samples/s of each, the kernel time from HIP events, and the CPU oracle on a bounded sample."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from field_coverage_path_planning_amd import engine as E  # noqa: E402
+from field_coverage_path_planning_amd.multi_layer_planner_v3 import TwoLayerPathPlannerV37, VehicleParams  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--fields', type=int, default=1024)
+ap.add_argument('--rate-fields', type=int, default=64)
+ap.add_argument('--reps', type=int, default=5)
+ap.add_argument('--no-cpu-baseline', action='store_true')
+a = ap.parse_args()
+rng = np.random.default_rng(1024)
+LH = rng.uniform(100.0, 1000.0, size=(max(a.fields, a.rate_fields), 2))
+vp = VehicleParams()
+R, W = vp.min_turn_radius, vp.working_width
+gs = int(2 * R / 0.1)
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+# ---- A: corner grids ---------------------------------------------------------------------------------------------------
+jobs, pts, first = [], [], 0
+for Lf, Hf in LH[:a.fields]:
+    pl = TwoLayerPathPlannerV37(vp, field_length=float(Lf), field_width=float(Hf))
+    hw = pl.headland_width
+    for cx, cy, ci in ((hw, hw, 0), (Lf - hw, hw, 1), (Lf - hw, Hf - hw, 2), (hw, Hf - hw, 3)):
+        turn, _ = pl._generate_corner_turn_arc((cx, cy), ci)
+        rev = pl._corner_reverse_path(turn)[0]
+        origin = [(cx, cy), (cx - 2 * R, cy), (cx - 2 * R, cy - 2 * R), (cx, cy - 2 * R)][ci]
+        jobs.append(E.make_cover_job(origin[0], origin[1], 0.1, gs, gs, W / 2, len(turn), len(rev), pts_first=first))
+        pts += [turn, rev]
+        first += len(turn) + len(rev)
+xy = np.vstack(pts)
+dev = torch.device('cuda', 0)
+px, py = torch.as_tensor(xy[:, 0].copy(), device=dev), torch.as_tensor(xy[:, 1].copy(), device=dev)
+ms_a = timed(lambda: E.cover_grid(jobs, px, py, want_grid=True), a.reps)
+samples_a = len(jobs) * gs * gs
+counts_a = E.cover_grid(jobs, px, py)[0].cpu().numpy()
+
+# ---- B: coverage rate of headland paths -----------------------------------------------------------------------------------
+specs = [E.FieldSpec(field_length=float(x), field_width=float(y)) for x, y in LH[:a.rate_fields]]
+b = E.Batch(specs, E.make_vehicle(), E.make_options())
+res = b.run()
+jobs_b = []
+for k, (Lf, Hf) in enumerate(LH[:a.rate_fields]):
+    info = b.info[k]
+    nx, ny = int(np.ceil(Lf / 0.1)), int(np.ceil(Hf / 0.1))
+    jobs_b.append(E.make_cover_job(0.0, 0.0, 0.1, nx, ny, W / 2, info.n_head, pts_first=info.point_offset + info.n_main, shift=0.5, strict=False,
+                                   outer=E.half_planes([(0, 0), (Lf, 0), (Lf, Hf), (0, Hf)]),
+                                   inner=E.half_planes([(R, R), (Lf - R, R), (Lf - R, Hf - R), (R, Hf - R)])))
+ms_b = timed(lambda: E.cover_grid(jobs_b, res.x, res.y), a.reps)
+samples_b = sum(j.nx * j.ny for j in jobs_b)
+counts_b = E.cover_grid(jobs_b, res.x, res.y)[0].cpu().numpy()
+out = {
+    'metric': 'coverage samples/s (fcpp_cover_grid)', 'unit': 'samples/s',
+    'corner_grids': {'jobs': len(jobs), 'samples': samples_a, 'ms': ms_a, 'samples_per_s': samples_a / (ms_a * 1e-3),
+                     'mean_coverage_before_after_pct': [float(counts_a[:, 1].mean() / gs / gs * 100), float(counts_a[:, 2].mean() / gs / gs * 100)]},
+    'coverage_rate': {'fields': a.rate_fields, 'samples': samples_b, 'ring_samples': int(counts_b[:, 0].sum()), 'ms': ms_b,
+                      'samples_per_s': samples_b / (ms_b * 1e-3), 'mean_rate': float((counts_b[:, 1] / counts_b[:, 0]).mean())},
+    'note': 'times include the call\'s job-table upload and its stream synchronisation (the operator is synchronous)',
+}
+if not a.no_cpu_baseline:
+    import oracle as orc
+    t0 = time.perf_counter()
+    nj = min(len(jobs), 2048)
+    for k in range(nj):
+        j = jobs[k]
+        t, r = pts[2 * k], pts[2 * k + 1]
+        orc.cover_grid(j.ox, j.oy, 0.1, 0.0, W / 2, gs, gs, t, r, strict=True)
+    dt = time.perf_counter() - t0
+    out['cpu_baseline'] = {'value': nj * gs * gs / dt, 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
+                           'sample': f'{nj} corner grids through oracle/fcpp_oracle.c orc_cover_grid ({dt:.2f} s)'}
+print(json.dumps(out))
