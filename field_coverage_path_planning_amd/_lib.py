@@ -66,6 +66,18 @@ class FieldStats(C.Structure):
                 ('n_adjusted', C.c_int64)]
 
 
+class GaConfig(C.Structure):
+    """fcpp_ga_config = GAConfig (GA:20-29) + seed"""
+    _fields_ = [('population_size', C.c_int32), ('max_generations', C.c_int32), ('crossover_rate', C.c_double),
+                ('mutation_rate', C.c_double), ('elite_size', C.c_int32), ('tournament_size', C.c_int32),
+                ('convergence_threshold', C.c_int32), ('_pad', C.c_int32), ('seed', C.c_uint64)]
+
+
+class GaResult(C.Structure):
+    _fields_ = [('generations', C.c_int32), ('convergence_gen', C.c_int32), ('best_distance', C.c_double),
+                ('best_fitness', C.c_double)]
+
+
 class CoverJob(C.Structure):
     """fcpp_cover_job (include/fcpp.h)"""
     _fields_ = [('ox', C.c_double), ('oy', C.c_double), ('res', C.c_double), ('shift', C.c_double), ('radius', C.c_double),
@@ -111,6 +123,7 @@ PROTOTYPES = [
     ('fcpp_straight_segments', C.c_int, [_VP, C.c_int64, _VP, C.c_int32, _VP]),
     ('fcpp_fresnel', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
     ('fcpp_ga_fitness', C.c_int, [_VP, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_int]),
+    ('fcpp_ga_evolve', C.c_int, [_VP, C.c_int32, C.POINTER(GaConfig), _VP, _VP, _VP, _VP, C.POINTER(GaResult)]),
     ('fcpp_cover_grid', C.c_int, [_VP, C.c_int64, C.POINTER(CoverJob), C.c_int64, _VP, _VP, _VP, _VP]),
 ]
 

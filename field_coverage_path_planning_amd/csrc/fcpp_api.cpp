@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "fcpp_cover.h"
+#include "fcpp_ga.h"
 #include "fcpp_device.h"
 #include "fcpp_internal.h"
 
@@ -701,6 +702,51 @@ int fcpp_fresnel(fcpp_ctx *c, int64_t n, const double *t, double *cc, double *ss
     if (!c || n < 0 || (n > 0 && (!t || !cc || !ss))) return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     LAUNCHCHK(launch_fresnel(c->stream, n, t, cc, ss));
+    return FCPP_OK;
+}
+
+int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const double *D, int32_t *routes, int32_t *best_route,
+                   double *hist, fcpp_ga_result *result)
+{
+    if (!c || !cfg || !D || !routes || !best_route || !result) return fail(FCPP_EINVAL, "bad arguments");
+    const int pop = cfg->population_size;
+    if (n < 2 || n > GA_MAX_NODES) return fail(FCPP_EUNSUPPORTED, "n_nodes must be in [2, 2048]");
+    if (pop < 2 || (pop & 1) || cfg->elite_size < 0 || cfg->elite_size >= pop || cfg->tournament_size < 1 ||
+        cfg->tournament_size > 64 || cfg->tournament_size > pop || cfg->max_generations < 0)
+        return fail(FCPP_EINVAL, "population_size must be even and > elite_size; 1 <= tournament_size <= min(64, population_size)");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    DevBuf<int32_t> scratch;
+    DevBuf<double> fd;             // fitness / distance of both buffers
+    DevBuf<GaState> state;
+    HIPCHK(scratch.alloc((size_t)pop * n));
+    HIPCHK(fd.alloc((size_t)pop * 4));
+    HIPCHK(state.alloc(1));
+    HIPCHK(hipMemsetAsync(state.p, 0, sizeof(GaState), st));
+    int32_t *buf[2] = { routes, scratch.p };
+    double *fit[2] = { fd.p, fd.p + 2 * (size_t)pop }, *dist[2] = { fd.p + pop, fd.p + 3 * (size_t)pop };
+    LAUNCHCHK(launch_ga_fitness(st, n, pop, D, routes, dist[0], fit[0], 0));                       // GA:64
+    LAUNCHCHK(launch_ga_stats_elite(st, n, pop, buf[0], fit[0], dist[0], buf[1], fit[1], dist[1], *cfg, -1, state.p, best_route, hist));
+    GaState h = {};
+    for (int g = 0; g < cfg->max_generations; ++g) {
+        const int a = g & 1, b = a ^ 1;               // generation g: buffer a -> buffer b
+        LAUNCHCHK(launch_ga_pairs(st, n, pop, D, buf[a], fit[a], buf[b], fit[b], dist[b], *cfg, g, state.p));
+        LAUNCHCHK(launch_ga_stats_elite(st, n, pop, buf[b], fit[b], dist[b], buf[a], fit[a], dist[a], *cfg, g, state.p, best_route, hist));
+        if ((g & 31) == 31) {                          // the kernels are no-ops once converged; stop launching them
+            HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (h.converged) break;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h.generations & 1)                             // the last completed generation wrote the scratch buffer
+        HIPCHK(hipMemcpyAsync(routes, scratch.p, (size_t)pop * n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    result->generations = h.generations;                               // GA:122-127 (generation + 1)
+    result->convergence_gen = h.generations - 1 - h.gwi;
+    result->best_distance = h.best_dist;
+    result->best_fitness = h.best_fit;
     return FCPP_OK;
 }
 

@@ -1,0 +1,27 @@
+// fcpp_ga.h -- device state and launchers of the GA evolution kernels (fcpp_ga.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "../../include/fcpp.h"
+
+namespace fcpp {
+
+struct GaState {
+    double best_fit, best_dist;
+    int32_t gwi;            // generations without improvement
+    int32_t generations;    // generation + 1 of the last completed generation
+    int32_t converged;
+    int32_t _pad;
+};
+
+constexpr int GA_MAX_NODES = 2048;
+
+int launch_ga_pairs(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, int32_t *nxt,
+                    double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, const GaState *state);
+// stats of the population `cur` (generation gen, -1 = the initial one), then the elites of `cur` into the tail of `nxt`
+int launch_ga_stats_elite(hipStream_t st, int n, int pop, const int32_t *cur, const double *cur_fit, const double *cur_dist, int32_t *nxt,
+                          double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, GaState *state, int32_t *best_route,
+                          double *hist);
+
+}  // namespace fcpp

@@ -1,0 +1,256 @@
+// fcpp_ga.hip -- the GA's evolution loop on the device (include/fcpp.h: fcpp_ga_evolve; GA:64-115, 183-268).
+//
+// Two launches per generation, no host round trip:
+//   k_ga_pairs        one wavefront per pair of offspring: two tournaments (GA:183-196), order crossover of the winners
+//                     (GA:212-242: the kept segment is marked in LDS, the donor's genes are ranked with ballots and
+//                     scattered to (b + rank) mod n), swap mutation (GA:244-252), and the children's tour length in the
+//                     reference's left-to-right order (GA:174-181), straight from LDS.  Rows that elitism overwrites
+//                     (the last elite_size ones, GA:266) are not written.
+//   k_ga_stats_elite  one workgroup: first-argmax and mean of the new fitness, best-so-far and convergence bookkeeping
+//                     (GA:90-113), then the elites of this population (GA:254-268) into the tail of the next buffer.
+// Every random decision is a pure function of (seed, generation, pair): Philox4x32-10, see include/fcpp.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fcpp_ga.h"
+
+namespace fcpp {
+
+struct U4 { uint32_t w[4]; };
+
+__device__ __forceinline__ U4 philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{ { c0, c1, c2, c3 } };
+}
+
+__device__ __forceinline__ double unit(uint32_t a, uint32_t b)
+{
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+__device__ __forceinline__ void two_positions(uint32_t r0, uint32_t r1, int n, int &i, int &j)
+{
+    i = (int)(r0 % (uint32_t)n);
+    j = (int)(r1 % (uint32_t)(n - 1));
+    if (j >= i) ++j;
+}
+
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// child = keep[a:b] in place, the other positions from b on (wrapping) take donor's genes in the order they appear from
+// position b on, skipping the genes already present (GA:225-237)
+__device__ __forceinline__ void ox_child(const int32_t *keep, const int32_t *donor, int n, int a, int b, int32_t *child,
+                                         unsigned char *present, int lane)
+{
+    for (int g = lane; g < n; g += 64) present[g] = 0;
+    wsync();
+    for (int i = a + lane; i < b; i += 64) { const int32_t g = keep[i]; child[i] = g; present[g] = 1; }
+    wsync();
+    int base = 0;
+    for (int q0 = 0; q0 < n; q0 += 64) {
+        const int q = q0 + lane;
+        int32_t gene = 0;
+        bool fr = false;
+        if (q < n) {
+            int src = b + q; if (src >= n) src -= n;
+            gene = donor[src];
+            fr = !present[gene];
+        }
+        const unsigned long long m = __ballot(fr);
+        if (fr) {
+            int pos = b + base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos >= n) pos -= n;
+            child[pos] = gene;
+        }
+        base += __popcll(m);
+    }
+    wsync();
+}
+
+__global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
+                                                 const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
+                                                 double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
+                                                 int gen, const GaState *__restrict__ state)
+{
+    __shared__ int32_t P[2][GA_MAX_NODES], Cc[2][GA_MAX_NODES];
+    __shared__ unsigned char present[GA_MAX_NODES];
+    __shared__ int s_w[2];
+    if (state->converged) return;
+    const int lane = threadIdx.x, pair = blockIdx.x;
+    const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
+    if (lane < 2) {      // the two tournaments (GA:189-194): k distinct candidates, the FIRST maximum wins (np.argmax)
+        int cand[64];
+        int nc = 0, w = 0;
+        double wf = 0.0;
+        U4 blk = { { 0, 0, 0, 0 } };
+        for (uint32_t j = 0; nc < cfg.tournament_size; ++j) {
+            if ((j & 3u) == 0u) blk = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(1 + lane), j >> 2, k0, k1);
+            const uint32_t word = (j & 3u) == 0u ? blk.w[0] : ((j & 3u) == 1u ? blk.w[1] : ((j & 3u) == 2u ? blk.w[2] : blk.w[3]));
+            const int c = (int)(word % (uint32_t)pop);
+            bool dup = false;
+            for (int q = 0; q < nc; ++q) dup |= cand[q] == c;
+            if (!dup) {
+                cand[nc] = c;
+                const double f = cur_fit[c];
+                if (nc == 0 || f > wf) { w = c; wf = f; }
+                ++nc;
+            }
+        }
+        s_w[lane] = w;
+    }
+    __syncthreads();
+    const int32_t *p1g = cur + (int64_t)s_w[0] * n, *p2g = cur + (int64_t)s_w[1] * n;
+    for (int i = lane; i < n; i += 64) { P[0][i] = p1g[i]; P[1][i] = p2g[i]; }
+    wsync();
+    const U4 X = philox((uint32_t)gen, (uint32_t)pair, 3u, 0u, k0, k1);
+    if (unit(X.w[0], X.w[1]) < cfg.crossover_rate) {      // GA:207
+        int i, j;
+        two_positions(X.w[2], X.w[3], n, i, j);
+        const int a = min(i, j), b = max(i, j);
+        ox_child(P[0], P[1], n, a, b, Cc[0], present, lane);
+        ox_child(P[1], P[0], n, a, b, Cc[1], present, lane);
+    } else {
+        for (int i = lane; i < n; i += 64) { Cc[0][i] = P[0][i]; Cc[1][i] = P[1][i]; }
+        wsync();
+    }
+    if (lane < 2) {      // GA:246-250
+        const U4 M = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(4 + lane), 0u, k0, k1);
+        if (unit(M.w[0], M.w[1]) < cfg.mutation_rate) {
+            int i, j;
+            two_positions(M.w[2], M.w[3], n, i, j);
+            const int32_t t = Cc[lane][i]; Cc[lane][i] = Cc[lane][j]; Cc[lane][j] = t;
+        }
+    }
+    wsync();
+    for (int c = 0; c < 2; ++c) {
+        const int row = 2 * pair + c;
+        if (row >= pop - cfg.elite_size) continue;     // an elite takes this row (GA:266)
+        const int32_t *ch = Cc[c];
+        for (int i = lane; i < n; i += 64) nxt[(int64_t)row * n + i] = ch[i];
+        double total = 0.0;                             // GA:174-181, left to right
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            double d = 0.0;
+            if (k < n) d = D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]];
+            const int m = min(64, n - base);
+            for (int l = 0; l < m; ++l) total += __shfl(d, l);
+        }
+        if (lane == 0) { nxt_dist[row] = total; nxt_fit[row] = 1.0 / (total + 1e-6); }
+    }
+}
+
+static constexpr int SB = 1024;
+
+__global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int32_t *__restrict__ cur, const double *__restrict__ cur_fit,
+                                                       const double *__restrict__ cur_dist, int32_t *__restrict__ nxt,
+                                                       double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
+                                                       int gen, GaState *__restrict__ state, int32_t *__restrict__ best_route,
+                                                       double *__restrict__ hist)
+{
+    __shared__ double s_f[SB], s_sum[SB];
+    __shared__ int s_i[SB];
+    __shared__ int s_copy, s_stop;
+    if (state->converged) return;
+    const int tid = threadIdx.x;
+    // first argmax (np.argmax, GA:66 / GA:91) and the mean (GA:107) in a fixed order
+    double bf = -1.0, acc = 0.0;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < pop; i += SB) {
+        const double f = cur_fit[i];
+        acc += f;
+        if (f > bf || (f == bf && i < bi)) { bf = f; bi = i; }
+    }
+    s_f[tid] = bf; s_i[tid] = bi; s_sum[tid] = acc;
+    __syncthreads();
+    for (int o = SB / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            s_sum[tid] += s_sum[tid + o];
+            const double f = s_f[tid + o];
+            const int i = s_i[tid + o];
+            if (f > s_f[tid] || (f == s_f[tid] && i < s_i[tid])) { s_f[tid] = f; s_i[tid] = i; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double f = s_f[0];
+        const int i = s_i[0];
+        int copy = -1, stop = 0;
+        if (gen < 0) {                                   // GA:66-70
+            state->best_fit = f; state->best_dist = cur_dist[i]; state->gwi = 0; state->generations = 0;
+            copy = i;
+        } else {
+            if (f > state->best_fit) { state->best_fit = f; state->best_dist = cur_dist[i]; state->gwi = 0; copy = i; }   // GA:94-98
+            else state->gwi += 1;
+            if (hist) { hist[gen] = state->best_fit; hist[cfg.max_generations + gen] = s_sum[0] / (double)pop; }          // GA:106-107
+            state->generations = gen + 1;
+            if (state->gwi >= cfg.convergence_threshold) { state->converged = 1; stop = 1; }                              // GA:110-113
+        }
+        s_copy = copy; s_stop = stop;
+    }
+    __syncthreads();
+    if (s_copy >= 0)
+        for (int k = tid; k < n; k += SB) best_route[k] = cur[(int64_t)s_copy * n + k];
+    if (s_stop || gen + 1 >= cfg.max_generations) return;
+    // elites of this population for the next generation (GA:254-268): the t-th best in the order (fitness, index) goes to row
+    // pop - 1 - t; each is the maximum among the entries below the previous pick
+    double pf = 0.0;
+    int pi = 0;
+    for (int t = 0; t < cfg.elite_size; ++t) {
+        double f = -1.0;
+        int idx = -1;
+        for (int i = tid; i < pop; i += SB) {
+            const double v = cur_fit[i];
+            if (t > 0 && !(v < pf || (v == pf && i < pi))) continue;
+            if (idx < 0 || v > f || (v == f && i > idx)) { f = v; idx = i; }
+        }
+        s_f[tid] = f; s_i[tid] = idx;
+        __syncthreads();
+        for (int o = SB / 2; o > 0; o >>= 1) {
+            if (tid < o) {
+                const double v = s_f[tid + o];
+                const int i = s_i[tid + o];
+                if (i >= 0 && (s_i[tid] < 0 || v > s_f[tid] || (v == s_f[tid] && i > s_i[tid]))) { s_f[tid] = v; s_i[tid] = i; }
+            }
+            __syncthreads();
+        }
+        pf = s_f[0]; pi = s_i[0];
+        __syncthreads();
+        const int row = pop - 1 - t;
+        for (int k = tid; k < n; k += SB) nxt[(int64_t)row * n + k] = cur[(int64_t)pi * n + k];
+        if (tid == 0) { nxt_fit[row] = pf; nxt_dist[row] = cur_dist[pi]; }
+    }
+}
+
+int launch_ga_pairs(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, int32_t *nxt,
+                    double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, const GaState *state)
+{
+    hipLaunchKernelGGL(k_ga_pairs, dim3((unsigned)(pop / 2)), dim3(64), 0, st, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen,
+                       state);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int launch_ga_stats_elite(hipStream_t st, int n, int pop, const int32_t *cur, const double *cur_fit, const double *cur_dist, int32_t *nxt,
+                          double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, GaState *state, int32_t *best_route,
+                          double *hist)
+{
+    hipLaunchKernelGGL(k_ga_stats_elite, dim3(1), dim3(SB), 0, st, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen, state,
+                       best_route, hist);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace fcpp

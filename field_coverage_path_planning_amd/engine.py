@@ -389,6 +389,31 @@ def ga_fitness(routes, D, order_mode=0, device=None):
     return dist, fit
 
 
+def ga_evolve(D, routes, cfg, seed=0, device=None):
+    """The GA's evolution loop on the device (fcpp_ga_evolve; GA:64-115, 183-268).  cfg: an object with GAConfig's attributes.
+    -> (final population tensor (pop, n) int32, best_route tensor, best_fitness_history, avg_fitness_history (numpy), L.GaResult)"""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    D = _dev_f64(D, dev)
+    n = D.shape[0]
+    if isinstance(routes, torch.Tensor):
+        r = routes.to(device=dev, dtype=torch.int32).contiguous().clone()
+    else:
+        r = torch.as_tensor(np.ascontiguousarray(routes, dtype=np.int32), device=dev)
+    r = r.reshape(-1, n)
+    c = L.GaConfig(int(r.shape[0]), int(cfg.max_generations), float(cfg.crossover_rate), float(cfg.mutation_rate), int(cfg.elite_size),
+                   int(cfg.tournament_size), int(cfg.convergence_threshold), 0, int(seed) & 0xffffffffffffffff)
+    best = torch.empty(n, dtype=torch.int32, device=dev)
+    hist = torch.zeros(2 * max(c.max_generations, 1), dtype=torch.float64, device=dev)
+    res = L.GaResult()
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_ga_evolve(ctx.handle, n, C.byref(c), _ptr(D), _ptr(r), _ptr(best), _ptr(hist), C.byref(res)))
+    h = hist.cpu().numpy()
+    g = res.generations
+    return r, best, h[:g].copy(), h[c.max_generations:c.max_generations + g].copy(), res
+
+
 # ---- coverage rasterisation (include/fcpp.h: fcpp_cover_grid; MLP:1357-1371, 1426-1509) ------------------------------
 def half_planes(vertices):
     """12 doubles (a, b, c) x 4 for a convex quadrilateral: inside <=> a*x + b*y + c >= 0 for all four edges."""

@@ -3,10 +3,11 @@ fitness on the GPU.
 
 Hot path: `_calculate_distance` / `_calculate_fitness` (GA:168-181) -> `fcpp_ga_fitness`, one
 wavefront per chromosome, left-to-right float64 summation (bit-exact with the reference) for the WHOLE population per call.
-The evolution loop around it (selection, order crossover, swap mutation, elitism; GA:183-268) is host-side control and not
-part of the accelerated path; it is restated here with vectorised numpy operators so that `solve()` works as in the
-reference.  The reference draws from the unseeded stdlib `random`, so evolved routes are not reproducible there either;
-this class takes an optional `seed`.
+The evolution loop around it (selection, order crossover, swap mutation, elitism, best tracking, convergence; GA:64-115,
+183-268) runs on the GPU as well (`fcpp_ga_evolve`: two launches per generation, no host round trip), its random decisions
+drawn from the counter-based generator Philox4x32-10.  The reference draws from the unseeded stdlib `random`, so evolved
+routes are not reproducible there; this class takes an optional `seed`, and a given seed reproduces a run bit for bit
+(and equals the CPU oracle's run).  population_size must be even.
 """
 from dataclasses import dataclass
 from typing import List, Tuple
@@ -55,52 +56,41 @@ class GeneticAlgorithmSolver:
         """GA:168-172"""
         return float(self.evaluate_population([list(route)], distance_matrix)[1][0])
 
-    # ---- host-side evolution loop (GA:44-135) ------------------------------------------------------------------
+    # ---- solve (GA:44-135): the whole evolution loop runs on the device -----------------------------------------------
     def solve(self, distance_matrix: np.ndarray, verbose: bool = True) -> Tuple[List[int], dict]:
         cfg, rng = self.config, self._rng
         D = np.ascontiguousarray(distance_matrix, dtype=np.float64)
         n = len(D)
         if verbose:
             print(f"\n[遗传算法] 开始优化...  节点数: {n}  种群大小: {cfg.population_size}  最大代数: {cfg.max_generations}")
-        half = cfg.population_size // 2
-        # GA:137-166: both halves are random permutations (the "greedy" half only fixes its first node)
-        pop = np.array([rng.permutation(n) for _ in range(2 * half)], dtype=np.int32)
-        for i in range(half):
-            row = pop[half + i]
-            j = int(np.where(row == i % n)[0][0])
-            row[0], row[j] = row[j], row[0]
-        dist, fit = self.evaluate_population(pop, D)
-        best_i = int(np.argmax(fit))
-        best_route, best_fit, best_dist = pop[best_i].copy(), float(fit[best_i]), float(dist[best_i])
-        stall, generation = 0, -1
-        for generation in range(cfg.max_generations):
-            sel = self._selection(pop, fit)
-            off = self._crossover(sel)
-            off = self._mutation(off)
-            pop = self._elitism(pop, off, fit)
-            dist, fit = self.evaluate_population(pop, D)
-            i = int(np.argmax(fit))
-            if fit[i] > best_fit:
-                best_fit, best_route, best_dist, stall = float(fit[i]), pop[i].copy(), float(dist[i]), 0
-                if verbose and generation % 50 == 0:
-                    print(f"  第 {generation} 代: 最优距离 = {best_dist:.1f}m")
-            else:
-                stall += 1
-            self.best_fitness_history.append(best_fit)
-            self.avg_fitness_history.append(float(np.mean(fit)))
-            if stall >= cfg.convergence_threshold:
-                if verbose:
-                    print(f"  第 {generation} 代: 收敛 (连续 {cfg.convergence_threshold} 代无改进)")
-                break
-        route = [int(g) for g in best_route]
+        pop = self._initialize_population(n)
+        # every random decision of the loop is drawn on the device from Philox4x32-10 keyed by this seed (include/fcpp.h)
+        seed = int(rng.integers(0, 2 ** 63))
+        _, best, hb, ha, res = E.ga_evolve(D, pop, cfg, seed=seed, device=self._device)
+        self.best_fitness_history.extend(float(v) for v in hb)           # GA:106-107
+        self.avg_fitness_history.extend(float(v) for v in ha)
+        route = [int(g) for g in best.cpu().numpy()]
         k = route.index(0)                         # GA:118-120: start from the depot
         final = route[k:] + route[:k]
-        stats = {'generations': generation + 1, 'best_distance': best_dist, 'best_fitness': best_fit,
-                 'convergence_gen': generation - stall}
+        stats = {'generations': res.generations, 'best_distance': res.best_distance, 'best_fitness': res.best_fitness,
+                 'convergence_gen': res.convergence_gen}
         if verbose:
-            print(f"[遗传算法] 优化完成! 总代数: {stats['generations']}  最优距离: {best_dist:.1f}m")
+            print(f"[遗传算法] 优化完成! 总代数: {stats['generations']}  最优距离: {res.best_distance:.1f}m  "
+                  f"收敛代数: {stats['convergence_gen']}")
         return final, stats
 
+    def _initialize_population(self, num_nodes: int) -> np.ndarray:
+        """GA:137-166: both halves are random permutations (the "greedy" half only fixes its first node, i % n)."""
+        half = self.config.population_size // 2
+        pop = np.array([self._rng.permutation(num_nodes) for _ in range(2 * half)], dtype=np.int32)
+        for i in range(half):
+            row = pop[half + i]
+            j = int(np.where(row == i % num_nodes)[0][0])
+            row[0], row[j] = row[j], row[0]
+        return pop
+
+    # ---- the operators as vectorised host functions (same semantics as the device kernels; kept for callers that drive their
+    # own loop).  solve() does not use them.
     # GA:183-196 tournament selection
     def _selection(self, pop, fit):
         m = len(pop)

@@ -203,6 +203,35 @@ int fcpp_fresnel(fcpp_ctx *ctx, int64_t n, const double *t_dev, double *c_dev, d
 int fcpp_ga_fitness(fcpp_ctx *ctx, int32_t n_nodes, int64_t pop, const double *D_dev,
                     const int32_t *routes_dev, double *dist_dev, double *fit_dev, int order_mode);
 
+/* ---- GeneticAlgorithmSolver.solve: the evolution loop on the device (GA:64-115, 183-268) --------------
+ * selection (GA:183-196), OX crossover (GA:198-242), swap mutation (GA:244-252), elitism (GA:254-268), fitness
+ * (GA:168-181), best tracking and the convergence test (GA:90-113) for up to max_generations, whole generations on the
+ * GPU.  The reference draws from the unseeded stdlib `random`; here every decision comes from the counter-based
+ * generator Philox4x32-10 with key = seed and counter = (generation, pair, stream, block):
+ *   stream 1 + s, word j : tournament candidate j of slot s = word % population_size, duplicates are redrawn
+ *   stream 3             : crossover iff unit(w0, w1) < crossover_rate; cut points i = w2 % n, j = w3 % (n-1), j += (j >= i)
+ *   stream 4 + c         : mutation of child c iff unit(w0, w1) < mutation_rate; positions as for the cut points
+ *   unit(a, b) = ((a >> 5) * 2^26 + (b >> 6)) / 2^53
+ * so a run is reproducible and identical to oracle/fcpp_oracle.c: orc_ga_evolve.  Ties in the elitism order go to the
+ * larger index.  population_size must be even (the reference grows an odd population by one per generation, GA:203),
+ * elite_size < population_size, tournament_size <= min(64, population_size), 2 <= n_nodes <= 2048. */
+typedef struct fcpp_ga_config {   /* GAConfig, GA:20-29, + seed */
+    int32_t population_size, max_generations;
+    double crossover_rate, mutation_rate;
+    int32_t elite_size, tournament_size, convergence_threshold, _pad;
+    uint64_t seed;
+} fcpp_ga_config;
+typedef struct fcpp_ga_result {   /* the `stats` of GA:122-127 */
+    int32_t generations;          /* generation + 1 */
+    int32_t convergence_gen;      /* generation - generations_without_improvement */
+    double best_distance, best_fitness;
+} fcpp_ga_result;
+/* routes_dev: pop x n int32, in = the initial population, out = the final one; best_route_dev: n int32 (as found, not yet
+ * rotated to start at node 0, GA:118-120); hist_dev: NULL or 2 * max_generations doubles = best_fitness_history then
+ * avg_fitness_history (GA:106-107; entries [0, generations) of each half are written).  Synchronises the stream. */
+int fcpp_ga_evolve(fcpp_ctx *ctx, int32_t n_nodes, const fcpp_ga_config *cfg, const double *D_dev, int32_t *routes_dev,
+                   int32_t *best_route_dev, double *hist_dev, fcpp_ga_result *result);
+
 /* ---- coverage rasterisation -------------------------------------------------
  * Replaces the Shapely calls of verify_corner_coverage_grid_based (MLP:1426-1509: `LineString(path).buffer(W/2)
  * .contains(Point)` per 0.1 m grid cell of a 2R x 2R corner square, first for the turn, then for the reverse fill on

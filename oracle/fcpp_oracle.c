@@ -823,3 +823,171 @@ void orc_cover_grid(double ox, double oy, double res, double shift, double radiu
         }
     }
 }
+
+/* ---- GA evolution (GA:64-115, 183-268) ----------------------------------------------------------------------------- */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static double orc_unit(uint32_t a, uint32_t b) { return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0; }
+
+void orc_ga_selection(const int32_t *population, const double *fitness, int32_t pop, int32_t n, const int32_t *cand, int32_t k,
+                      int32_t *selected)
+{
+    for (int32_t s = 0; s < pop; ++s) {
+        int32_t w = cand[(int64_t)s * k];
+        for (int32_t j = 1; j < k; ++j) {                      /* np.argmax: the FIRST maximum wins */
+            const int32_t c = cand[(int64_t)s * k + j];
+            if (fitness[c] > fitness[w]) w = c;
+        }
+        memcpy(selected + (int64_t)s * n, population + (int64_t)w * n, (size_t)n * sizeof(int32_t));
+    }
+}
+
+static void orc_ox_child(const int32_t *keep, const int32_t *donor, int32_t n, int32_t a, int32_t b, int32_t *child)
+{
+    unsigned char *present = (unsigned char *)calloc((size_t)n, 1);
+    for (int32_t i = a; i < b; ++i) { child[i] = keep[i]; present[keep[i]] = 1; }      /* GA:225-227 */
+    int32_t pos = b;
+    for (int32_t q = 0; q < n; ++q) {                                                  /* parent[cx2:] + parent[:cx2] */
+        const int32_t gene = donor[(b + q) % n];
+        if (!present[gene]) {
+            if (pos >= n) pos = 0;
+            child[pos++] = gene;
+        }
+    }
+    free(present);
+}
+
+void orc_ga_ox(const int32_t *p1, const int32_t *p2, int32_t n, int32_t a, int32_t b, int32_t *c1, int32_t *c2)
+{
+    orc_ox_child(p1, p2, n, a, b, c1);
+    orc_ox_child(p2, p1, n, a, b, c2);
+}
+
+/* the t-th best (t = 0: best) in the order (fitness, index) */
+static int32_t orc_next_best(const double *fit, int32_t pop, int have_prev, double pf, int32_t pi)
+{
+    int32_t best = -1;
+    for (int32_t i = 0; i < pop; ++i) {
+        if (have_prev && !(fit[i] < pf || (fit[i] == pf && i < pi))) continue;
+        if (best < 0 || fit[i] > fit[best] || (fit[i] == fit[best] && i > best)) best = i;
+    }
+    return best;
+}
+
+void orc_ga_elitism(const int32_t *old_population, const double *old_fitness, int32_t pop, int32_t n, int32_t e,
+                    int32_t *new_population)
+{
+    int32_t prev = -1;
+    for (int32_t t = 0; t < e; ++t) {
+        prev = orc_next_best(old_fitness, pop, t > 0, t > 0 ? old_fitness[prev] : 0.0, prev);
+        memcpy(new_population + (int64_t)(pop - 1 - t) * n, old_population + (int64_t)prev * n, (size_t)n * sizeof(int32_t));
+    }
+}
+
+static void orc_two_positions(uint32_t r0, uint32_t r1, int32_t n, int32_t *i, int32_t *j)
+{
+    *i = (int32_t)(r0 % (uint32_t)n);
+    *j = (int32_t)(r1 % (uint32_t)(n - 1));
+    if (*j >= *i) ++*j;
+}
+
+/* mean in the summation order of the HIP kernel: 1024 strided partial sums, then a binary tree */
+static double orc_tree_mean(const double *v, int32_t m)
+{
+    double part[1024];
+    for (int t = 0; t < 1024; ++t) { double a = 0.0; for (int32_t i = t; i < m; i += 1024) a += v[i]; part[t] = a; }
+    for (int o = 512; o > 0; o >>= 1) for (int t = 0; t < o; ++t) part[t] += part[t + o];
+    return part[0] / (double)m;
+}
+
+void orc_ga_evolve(int32_t n, const orc_ga_config *cfg, const double *D, int32_t *routes, int32_t *best_route, double *hist,
+                   orc_ga_result *res)
+{
+    const int32_t pop = cfg->population_size, k = cfg->tournament_size, e = cfg->elite_size, G = cfg->max_generations;
+    const uint32_t key[2] = { (uint32_t)cfg->seed, (uint32_t)(cfg->seed >> 32) };
+    int32_t *cur = routes, *nxt = (int32_t *)malloc((size_t)pop * n * sizeof(int32_t));
+    double *fit = (double *)malloc((size_t)pop * sizeof(double)), *dist = (double *)malloc((size_t)pop * sizeof(double));
+    double *nfit = (double *)malloc((size_t)pop * sizeof(double)), *ndist = (double *)malloc((size_t)pop * sizeof(double));
+    int32_t *c1 = (int32_t *)malloc((size_t)n * sizeof(int32_t)), *c2 = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    for (int32_t r = 0; r < pop; ++r) { dist[r] = orc_ga_distance(cur + (int64_t)r * n, n, D); fit[r] = 1.0 / (dist[r] + 1e-6); }
+    int32_t bi = 0;
+    for (int32_t r = 1; r < pop; ++r) if (fit[r] > fit[bi]) bi = r;                 /* GA:66 np.argmax */
+    double best_fit = fit[bi], best_dist = dist[bi];
+    memcpy(best_route, cur + (int64_t)bi * n, (size_t)n * sizeof(int32_t));
+    int32_t gwi = 0, gen = -1;
+    for (int32_t g = 0; g < G; ++g) {
+        gen = g;
+        for (int32_t p = 0; p < pop / 2; ++p) {
+            int32_t w[2];
+            for (int slot = 0; slot < 2; ++slot) {                                  /* GA:189-194 */
+                int32_t cand[64] = { 0 }, nc = 0;
+                for (uint32_t j = 0; nc < k; ++j) {
+                    const uint32_t ctr[4] = { (uint32_t)g, (uint32_t)p, (uint32_t)(1 + slot), j >> 2 };
+                    uint32_t o[4];
+                    orc_philox4x32(ctr, key, o);
+                    const int32_t c = (int32_t)(o[j & 3] % (uint32_t)pop);
+                    int dup = 0;
+                    for (int32_t q = 0; q < nc; ++q) dup |= cand[q] == c;
+                    if (!dup) cand[nc++] = c;
+                }
+                w[slot] = cand[0];
+                for (int32_t q = 1; q < k; ++q) if (fit[cand[q]] > fit[w[slot]]) w[slot] = cand[q];
+            }
+            const int32_t *p1 = cur + (int64_t)w[0] * n, *p2 = cur + (int64_t)w[1] * n;
+            uint32_t X[4];
+            { const uint32_t ctr[4] = { (uint32_t)g, (uint32_t)p, 3u, 0u }; orc_philox4x32(ctr, key, X); }
+            if (orc_unit(X[0], X[1]) < cfg->crossover_rate) {                         /* GA:207 */
+                int32_t i, j;
+                orc_two_positions(X[2], X[3], n, &i, &j);
+                orc_ga_ox(p1, p2, n, i < j ? i : j, i < j ? j : i, c1, c2);
+            } else { memcpy(c1, p1, (size_t)n * sizeof(int32_t)); memcpy(c2, p2, (size_t)n * sizeof(int32_t)); }
+            for (int c = 0; c < 2; ++c) {                                           /* GA:246-250 */
+                uint32_t M[4];
+                const uint32_t ctr[4] = { (uint32_t)g, (uint32_t)p, (uint32_t)(4 + c), 0u };
+                orc_philox4x32(ctr, key, M);
+                if (orc_unit(M[0], M[1]) < cfg->mutation_rate) {
+                    int32_t i, j, *ch = c ? c2 : c1;
+                    orc_two_positions(M[2], M[3], n, &i, &j);
+                    const int32_t t = ch[i]; ch[i] = ch[j]; ch[j] = t;
+                }
+                const int32_t row = 2 * p + c;
+                if (row < pop - e) {
+                    memcpy(nxt + (int64_t)row * n, c ? c2 : c1, (size_t)n * sizeof(int32_t));
+                    ndist[row] = orc_ga_distance(nxt + (int64_t)row * n, n, D);
+                    nfit[row] = 1.0 / (ndist[row] + 1e-6);
+                }
+            }
+        }
+        {   /* GA:254-268 */
+            int32_t prev = -1;
+            for (int32_t t = 0; t < e; ++t) {
+                prev = orc_next_best(fit, pop, t > 0, t > 0 ? fit[prev] : 0.0, prev);
+                memcpy(nxt + (int64_t)(pop - 1 - t) * n, cur + (int64_t)prev * n, (size_t)n * sizeof(int32_t));
+                nfit[pop - 1 - t] = fit[prev]; ndist[pop - 1 - t] = dist[prev];
+            }
+        }
+        { int32_t *t = cur; cur = nxt; nxt = t; double *u = fit; fit = nfit; nfit = u; u = dist; dist = ndist; ndist = u; }
+        bi = 0;
+        for (int32_t r = 1; r < pop; ++r) if (fit[r] > fit[bi]) bi = r;             /* GA:91 */
+        if (fit[bi] > best_fit) {                                                   /* GA:94-98 */
+            best_fit = fit[bi]; best_dist = dist[bi]; gwi = 0;
+            memcpy(best_route, cur + (int64_t)bi * n, (size_t)n * sizeof(int32_t));
+        } else ++gwi;
+        if (hist) { hist[g] = best_fit; hist[G + g] = orc_tree_mean(fit, pop); }    /* GA:106-107 */
+        if (gwi >= cfg->convergence_threshold) break;                               /* GA:110-113 */
+    }
+    res->generations = gen + 1; res->convergence_gen = gen - gwi;                   /* GA:122-127 */
+    res->best_distance = best_dist; res->best_fitness = best_fit;
+    if (cur != routes) memcpy(routes, cur, (size_t)pop * n * sizeof(int32_t));
+    free(cur == routes ? nxt : cur); free(fit); free(dist); free(nfit); free(ndist); free(c1); free(c2);
+}

@@ -119,6 +119,31 @@ double orc_cac_fit_radius(double dth, double R, double f, int fit);
 int orc_point_in_polygon(double px, double py, const double *poly_xy, int64_t nv);  /* even-odd */
 int orc_outside_convex(double px, double py, const double *vx, const double *vy, int nv, double tol);
 
+/* ---- GA evolution operators (GA:183-268) ------------------------------------------------------------------------------
+ * The reference draws from the unseeded stdlib `random`; here every random decision is an explicit input, so the
+ * operators are pure functions that the reference's own methods pin (tools/gen_golden.py replays the same decisions
+ * through `random.sample` / `random.random`).  orc_ga_evolve draws the decisions from Philox4x32-10 exactly as the HIP
+ * kernels do (include/fcpp.h, fcpp_ga_evolve), so whole runs are comparable bit for bit. */
+void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);   /* Salmon et al., SC'11: 10 rounds */
+/* GA:183-196: cand = pop x k tournament candidates (distinct per row); selected row s = population[first argmax of fitness] */
+void orc_ga_selection(const int32_t *population, const double *fitness, int32_t pop, int32_t n, const int32_t *cand, int32_t k,
+                      int32_t *selected);
+/* GA:212-242: children of one pair for the cut points a < b */
+void orc_ga_ox(const int32_t *p1, const int32_t *p2, int32_t n, int32_t a, int32_t b, int32_t *c1, int32_t *c2);
+/* GA:254-268: new_population[pop-e+j] = old_population[argsort(old_fitness)[pop-e+j]] (ties: the larger index is later) */
+void orc_ga_elitism(const int32_t *old_population, const double *old_fitness, int32_t pop, int32_t n, int32_t e,
+                    int32_t *new_population);
+typedef struct orc_ga_config {
+    int32_t population_size, max_generations;
+    double crossover_rate, mutation_rate;
+    int32_t elite_size, tournament_size, convergence_threshold, _pad;
+    uint64_t seed;
+} orc_ga_config;
+typedef struct orc_ga_result { int32_t generations, convergence_gen; double best_distance, best_fitness; } orc_ga_result;
+/* GA:64-115 with Philox decisions; routes: in = initial population, out = final; hist (may be NULL): 2 * max_generations */
+void orc_ga_evolve(int32_t n, const orc_ga_config *cfg, const double *D, int32_t *routes, int32_t *best_route, double *hist,
+                   orc_ga_result *res);
+
 /* coverage rasterisation: the sampled restatement of MLP:1426-1509 (corner grids) and MLP:1357-1371 (coverage rate).
  * Sample (i, j) = (ox + (i + shift) * res, oy + (j + shift) * res); covered by a polyline iff within `radius` of one of its
  * segments (strict: <, else <=; division-free test, see include/fcpp.h); polyline B is tried only on samples A left open

@@ -43,6 +43,16 @@ class Vehicle(C.Structure):
         return cls(**d)
 
 
+class GaConfig(C.Structure):
+    _fields_ = [('population_size', C.c_int32), ('max_generations', C.c_int32), ('crossover_rate', C.c_double),
+                ('mutation_rate', C.c_double), ('elite_size', C.c_int32), ('tournament_size', C.c_int32),
+                ('convergence_threshold', C.c_int32), ('_pad', C.c_int32), ('seed', C.c_uint64)]
+
+
+class GaResult(C.Structure):
+    _fields_ = [('generations', C.c_int32), ('convergence_gen', C.c_int32), ('best_distance', C.c_double), ('best_fitness', C.c_double)]
+
+
 class Options(C.Structure):
     _fields_ = [('turn_model', C.c_int32), ('clothoid_fit', C.c_int32), ('sample_spacing', C.c_double),
                 ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double)]
@@ -124,6 +134,17 @@ def lib():
         L.orc_cac_fit_radius.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
         L.orc_point_in_polygon.restype = C.c_int
         L.orc_point_in_polygon.argtypes = [C.c_double, C.c_double, c_double_p, C.c_int64]
+        c_u32_p = C.POINTER(C.c_uint32)
+        L.orc_philox4x32.restype = None
+        L.orc_philox4x32.argtypes = [c_u32_p, c_u32_p, c_u32_p]
+        L.orc_ga_selection.restype = None
+        L.orc_ga_selection.argtypes = [c_i32_p, c_double_p, C.c_int32, C.c_int32, c_i32_p, C.c_int32, c_i32_p]
+        L.orc_ga_ox.restype = None
+        L.orc_ga_ox.argtypes = [c_i32_p, c_i32_p, C.c_int32, C.c_int32, C.c_int32, c_i32_p, c_i32_p]
+        L.orc_ga_elitism.restype = None
+        L.orc_ga_elitism.argtypes = [c_i32_p, c_double_p, C.c_int32, C.c_int32, C.c_int32, c_i32_p]
+        L.orc_ga_evolve.restype = None
+        L.orc_ga_evolve.argtypes = [C.c_int32, C.POINTER(GaConfig), c_double_p, c_i32_p, c_i32_p, c_double_p, C.POINTER(GaResult)]
         L.orc_cover_grid.restype = None
         L.orc_cover_grid.argtypes = [C.c_double] * 5 + [C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p,
                                      C.c_int32, C.c_int, c_double_p, C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
@@ -265,6 +286,56 @@ def cac_points(x0, y0, th0, dth, R, f, fit, n):
 def point_in_polygon(px, py, poly):
     poly = _f64(poly)
     return bool(lib().orc_point_in_polygon(px, py, _dp(poly), len(poly)))
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_i32_p)
+
+
+def philox4x32(ctr, key):
+    c = (C.c_uint32 * 4)(*[int(v) & 0xffffffff for v in ctr])
+    k = (C.c_uint32 * 2)(*[int(v) & 0xffffffff for v in key])
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32(c, k, o)
+    return [int(v) for v in o]
+
+
+def ga_selection(population, fitness, cand):
+    population = np.ascontiguousarray(population, dtype=np.int32)
+    cand = np.ascontiguousarray(cand, dtype=np.int32)
+    fitness = _f64(fitness)
+    out = np.empty_like(population)
+    lib().orc_ga_selection(_ip(population), _dp(fitness), population.shape[0], population.shape[1], _ip(cand), cand.shape[1], _ip(out))
+    return out
+
+
+def ga_ox(p1, p2, a, b):
+    p1, p2 = np.ascontiguousarray(p1, dtype=np.int32), np.ascontiguousarray(p2, dtype=np.int32)
+    c1, c2 = np.empty_like(p1), np.empty_like(p2)
+    lib().orc_ga_ox(_ip(p1), _ip(p2), len(p1), int(a), int(b), _ip(c1), _ip(c2))
+    return c1, c2
+
+
+def ga_elitism(old_population, old_fitness, new_population, e):
+    old_population = np.ascontiguousarray(old_population, dtype=np.int32)
+    out = np.ascontiguousarray(new_population, dtype=np.int32).copy()
+    lib().orc_ga_elitism(_ip(old_population), _dp(_f64(old_fitness)), old_population.shape[0], old_population.shape[1], int(e), _ip(out))
+    return out
+
+
+def ga_evolve(D, routes, population_size=None, max_generations=500, crossover_rate=0.85, mutation_rate=0.02, elite_size=20,
+              tournament_size=5, convergence_threshold=50, seed=0):
+    """-> (final population, best_route, best_fitness_history, avg_fitness_history, GaResult)"""
+    D = _f64(D)
+    routes = np.ascontiguousarray(routes, dtype=np.int32).copy()
+    pop, n = routes.shape
+    cfg = GaConfig(pop, max_generations, crossover_rate, mutation_rate, elite_size, tournament_size, convergence_threshold, 0, seed)
+    best = np.empty(n, dtype=np.int32)
+    hist = np.zeros(2 * max_generations, dtype=np.float64)
+    res = GaResult()
+    lib().orc_ga_evolve(n, C.byref(cfg), _dp(D), _ip(routes), _ip(best), _dp(hist), C.byref(res))
+    g = res.generations
+    return routes, best, hist[:g].copy(), hist[max_generations:max_generations + g].copy(), res
 
 
 def cover_grid(ox, oy, res, shift, radius, nx, ny, a_xy, b_xy=None, strict=True, region=None, want_grid=True):

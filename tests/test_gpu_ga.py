@@ -1,0 +1,70 @@
+"""GPU parity of the GA evolution loop (fcpp_ga_evolve), through the C ABI: the same seed gives the oracle's run
+bit for bit -- final population, best route, histories, stats (routes are integers, fitness sums run in the reference's order)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from field_coverage_path_planning_amd import _lib as L
+from field_coverage_path_planning_amd import engine as E
+from field_coverage_path_planning_amd.genetic_algorithm_solver import GAConfig, GeneticAlgorithmSolver
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(seed, n, pop, asym=False):
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(0, 1000, size=(n, 2))
+    D = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+    if asym:
+        D = D + rng.uniform(0, 5, size=D.shape)
+    routes = np.array([rng.permutation(n) for _ in range(pop)], dtype=np.int32)
+    return D, routes
+
+
+@pytest.mark.parametrize('n,pop,cfg,seed', [
+    (12, 10, dict(max_generations=40, elite_size=2, tournament_size=3, convergence_threshold=50), 1),
+    (129, 64, dict(max_generations=70, elite_size=20, tournament_size=5, convergence_threshold=50), 2 ** 40 + 17),
+    (64, 200, dict(max_generations=120, elite_size=20, tournament_size=5, convergence_threshold=15, mutation_rate=0.3), 3),   # converges early
+    (200, 128, dict(max_generations=33, elite_size=0, tournament_size=64, convergence_threshold=50, crossover_rate=0.5), 4),
+    (2, 4, dict(max_generations=5, elite_size=1, tournament_size=1, convergence_threshold=50), 5),
+])
+def test_evolution_equals_oracle(n, pop, cfg, seed):
+    D, routes = _problem(seed % 1000, n, pop, asym=(n == 64))
+    c = GAConfig(population_size=pop, **cfg)
+    final, best, hb, ha, res = E.ga_evolve(D, routes, c, seed=seed)
+    ofinal, obest, ohb, oha, ores = orc.ga_evolve(D, routes, population_size=pop, seed=seed,
+                                                  **{k: getattr(c, k) for k in ('max_generations', 'crossover_rate', 'mutation_rate',
+                                                                               'elite_size', 'tournament_size', 'convergence_threshold')})
+    assert (res.generations, res.convergence_gen) == (ores.generations, ores.convergence_gen)
+    assert res.best_distance == ores.best_distance and res.best_fitness == ores.best_fitness
+    assert np.array_equal(final.cpu().numpy(), ofinal) and np.array_equal(best.cpu().numpy(), obest)
+    assert np.array_equal(hb, ohb) and np.array_equal(ha, oha)
+    assert all(sorted(r) == list(range(n)) for r in final.cpu().numpy())
+
+
+def test_bad_configurations_are_refused():
+    D, routes = _problem(1, 10, 9)
+    with pytest.raises(L.FcppError):
+        E.ga_evolve(D, routes, GAConfig(population_size=9))            # odd population
+    D, routes = _problem(1, 10, 8)
+    with pytest.raises(L.FcppError):
+        E.ga_evolve(D, routes, GAConfig(population_size=8, elite_size=8))
+    with pytest.raises(L.FcppError):
+        E.ga_evolve(D, routes, GAConfig(population_size=8, elite_size=2, tournament_size=9))
+
+
+def test_solver_solve_on_device():
+    """GeneticAlgorithmSolver(config).solve(D) as the reference's callers use it (multi_vehicle_planner.py): route from the depot,
+    stats keys, histories; a seed reproduces the run; the tour is much shorter than a random one."""
+    D, _ = _problem(8, 40, 2)
+    cfg = GAConfig(population_size=200, max_generations=150)
+    s1, s2 = GeneticAlgorithmSolver(cfg, seed=11), GeneticAlgorithmSolver(cfg, seed=11)
+    r1, st1 = s1.solve(D, verbose=False)
+    r2, st2 = s2.solve(D, verbose=False)
+    assert r1 == r2 and st1 == st2
+    assert r1[0] == 0 and sorted(r1) == list(range(40))
+    assert set(st1) == {'generations', 'best_distance', 'best_fitness', 'convergence_gen'}
+    assert len(s1.best_fitness_history) == len(s1.avg_fitness_history) == st1['generations']
+    assert abs(s1._calculate_distance(r1, D) - st1['best_distance']) < 1e-9 * st1['best_distance']
+    rnd = np.mean([s1._calculate_distance(list(np.random.default_rng(k).permutation(40)), D) for k in range(5)])
+    assert st1['best_distance'] < 0.5 * rnd

@@ -214,3 +214,61 @@ def test_cover_grid_area_of_a_capsule():
     counts, _ = orc.cover_grid(-2.0, -2.0, 0.01, 0.5, 1.0, 1400, 400, [[0.0, 0.0], [10.0, 0.0]], strict=False,
                                region=box(-2, -2, 12, 2) + box(0, -1, 10, 1), want_grid=False)
     assert abs(counts[0] * 1e-4 - (56 - 20)) < 1e-9 and abs(counts[1] * 1e-4 - np.pi) < 5e-3
+
+
+# ---- GA evolution operators (GA:183-268), SURVEY.md 8f-2 ------------------------------------------------------------
+def test_philox_known_answers():
+    """Random123's published vectors for philox4x32-10"""
+    assert orc.philox4x32([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox4x32([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox4x32([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+@pytest.mark.parametrize('tag', ['op_a', 'op_b', 'op_c'])
+def test_ga_operators_match_the_reference(golden_ga, tag):
+    """The reference's _selection / _crossover / _mutation / _elitism, replayed with the decisions they drew."""
+    g = golden_ga
+    n, pop, k, e = (int(v) for v in g[f'{tag}_cfg'])
+    cx_rate, mu_rate = g[f'{tag}_rates']
+    population, fitness = g[f'{tag}_population'], g[f'{tag}_fitness']
+    sel = orc.ga_selection(population, fitness, g[f'{tag}_cand'])
+    assert np.array_equal(sel, g[f'{tag}_selected'])
+    off = np.empty_like(sel)
+    for p in range(pop // 2):                                   # GA:198-210
+        p1, p2 = sel[2 * p], sel[2 * p + 1]
+        if g[f'{tag}_u_cx'][p] < cx_rate:
+            a, b = sorted(int(v) for v in g[f'{tag}_cuts'][p])
+            off[2 * p], off[2 * p + 1] = orc.ga_ox(p1, p2, a, b)
+        else:
+            off[2 * p], off[2 * p + 1] = p1, p2
+    assert np.array_equal(off, g[f'{tag}_offspring'])
+    mut = off.copy()
+    for r in range(pop):                                        # GA:244-252
+        if g[f'{tag}_u_mu'][r] < mu_rate:
+            i, j = (int(v) for v in g[f'{tag}_swaps'][r])
+            mut[r, i], mut[r, j] = mut[r, j], mut[r, i]
+    assert np.array_equal(mut, g[f'{tag}_mutated'])
+    assert np.array_equal(orc.ga_elitism(population, fitness, mut, e), g[f'{tag}_combined'])
+
+
+def test_ga_evolve_oracle_is_a_valid_ga():
+    """orc_ga_evolve (Philox decisions): permutations stay permutations, the best never gets worse, elites survive,
+    histories are consistent, convergence stops the loop."""
+    rng = np.random.default_rng(5)
+    n, pop = 24, 40
+    pts = rng.uniform(0, 100, size=(n, 2))
+    D = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+    routes = np.array([rng.permutation(n) for _ in range(pop)], dtype=np.int32)
+    final, best, hb, ha, res = orc.ga_evolve(D, routes, max_generations=300, elite_size=4, convergence_threshold=40, seed=99)
+    assert all(sorted(r) == list(range(n)) for r in final) and sorted(best) == list(range(n))
+    assert res.generations == len(hb) <= 300 and (np.diff(hb) >= 0).all() and (ha <= hb + 1e-15).all()
+    d0 = orc.ga_distance(routes, D).min()
+    assert res.best_distance < d0 and abs(res.best_fitness - 1 / (res.best_distance + 1e-6)) < 1e-18
+    assert abs(orc.ga_distance(best[None, :], D)[0] - res.best_distance) == 0
+    if res.generations < 300:
+        assert res.generations - 1 - res.convergence_gen == 40
+    # another seed gives another run; the same seed the same run
+    f2 = orc.ga_evolve(D, routes, max_generations=300, elite_size=4, convergence_threshold=40, seed=99)[0]
+    f3 = orc.ga_evolve(D, routes, max_generations=300, elite_size=4, convergence_threshold=40, seed=100)[0]
+    assert np.array_equal(final, f2) and not np.array_equal(final, f3)

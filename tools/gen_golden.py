@@ -221,6 +221,59 @@ def tier_ga():
         out[f'{tag}_routes'] = routes
         out[f'{tag}_dist'] = dist
         out[f'{tag}_fit'] = fit
+    out.update(tier_ga_operators(rng))
+    return out
+
+
+class _ScriptedRandom:
+    """Stands in for the stdlib `random` module inside the reference's GA module: every call returns the next scripted decision,
+    so that the operators' outputs can be stored next to the decisions that produced them."""
+
+    def __init__(self, samples, uniforms):
+        self.samples, self.uniforms = list(samples), list(uniforms)
+
+    def sample(self, population, k):
+        s = self.samples.pop(0)
+        assert len(s) == k and all(0 <= v < len(population) for v in s) and len(set(s)) == k
+        return list(s)
+
+    def random(self):
+        return self.uniforms.pop(0)
+
+
+def tier_ga_operators(rng):
+    """Reference `_selection`, `_crossover`, `_mutation`, `_elitism` (GA:183-268) on seeded populations with scripted draws."""
+    out = {}
+    real_random = gas.random
+    try:
+        for tag, n, pop, k, e in (('op_a', 12, 10, 3, 2), ('op_b', 129, 64, 5, 20), ('op_c', 40, 32, 5, 6)):
+            cfg = gas.GAConfig(population_size=pop, tournament_size=k, elite_size=e, crossover_rate=0.85, mutation_rate=0.3)
+            solver = gas.GeneticAlgorithmSolver(cfg)
+            pts = rng.uniform(0, 1000, size=(n, 2))
+            D = np.sqrt(((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1))
+            population = [list(map(int, rng.permutation(n))) for _ in range(pop)]
+            fitness = [solver._calculate_fitness(r, D) for r in population]
+            cand = np.array([rng.choice(pop, size=k, replace=False) for _ in range(pop)], dtype=np.int32)
+            gas.random = _ScriptedRandom([list(map(int, c)) for c in cand], [])
+            selected = solver._selection(population, fitness)
+            u_cx = rng.uniform(0, 1, size=pop // 2)
+            cuts = np.array([rng.choice(n, size=2, replace=False) for _ in range(pop // 2)], dtype=np.int32)
+            gas.random = _ScriptedRandom([list(map(int, c)) for c, u in zip(cuts, u_cx) if u < cfg.crossover_rate], list(u_cx))
+            offspring = solver._crossover([r.copy() for r in selected])
+            u_mu = rng.uniform(0, 1, size=pop)
+            swaps = np.array([rng.choice(n, size=2, replace=False) for _ in range(pop)], dtype=np.int32)
+            gas.random = _ScriptedRandom([list(map(int, c)) for c, u in zip(swaps, u_mu) if u < cfg.mutation_rate], list(u_mu))
+            mutated = solver._mutation([r.copy() for r in offspring])
+            combined = solver._elitism(population, mutated, fitness)
+            assert len(combined) == pop
+            out.update({f'{tag}_cfg': np.array([n, pop, k, e]), f'{tag}_rates': np.array([cfg.crossover_rate, cfg.mutation_rate]),
+                        f'{tag}_D': D, f'{tag}_population': np.array(population, dtype=np.int32), f'{tag}_fitness': np.array(fitness),
+                        f'{tag}_cand': cand, f'{tag}_selected': np.array(selected, dtype=np.int32), f'{tag}_u_cx': u_cx,
+                        f'{tag}_cuts': cuts, f'{tag}_offspring': np.array(offspring, dtype=np.int32), f'{tag}_u_mu': u_mu,
+                        f'{tag}_swaps': swaps, f'{tag}_mutated': np.array(mutated, dtype=np.int32),
+                        f'{tag}_combined': np.array(combined, dtype=np.int32)})
+    finally:
+        gas.random = real_random
     return out
 
 
@@ -376,6 +429,11 @@ def tier_cover():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if '--ga-only' in sys.argv:
+        g = tier_ga()
+        np.savez_compressed(os.path.join(OUT, 'golden_ga.npz'), **g)
+        print('golden_ga.npz:', len(g), 'arrays')
+        return
     if '--cover-only' in sys.argv:
         c = tier_cover()
         np.savez_compressed(os.path.join(OUT, 'golden_cover.npz'), **c)
