@@ -85,8 +85,9 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
                                                  double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
                                                  int gen, const GaState *__restrict__ state)
 {
-    __shared__ int32_t P[2][GA_MAX_NODES], Cc[2][GA_MAX_NODES];
-    __shared__ unsigned char present[GA_MAX_NODES];
+    extern __shared__ int32_t lds[];                    // 4 n genes + n presence bytes (sized by the launcher: small tours -> many waves per CU)
+    int32_t *const P[2] = { lds, lds + n }, *const Cc[2] = { lds + 2 * n, lds + 3 * n };
+    unsigned char *const present = reinterpret_cast<unsigned char *>(lds + 4 * n);
     __shared__ int s_w[2];
     if (state->converged) return;
     const int lane = threadIdx.x, pair = blockIdx.x;
@@ -152,7 +153,28 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
     }
 }
 
-static constexpr int SB = 1024;
+static constexpr int GA_LDS_POP = 6144;      // 48 KiB of fitness values cached in LDS
+static constexpr int SB = 1024, SW = SB / 64; // the bookkeeping kernel: one workgroup, a chain of ~20 dependent reductions
+
+// block-wide reduction of (value, index) pairs with a caller-supplied "a is better than b": shuffles inside the waves, one
+// LDS exchange across them.  Every thread returns the winner.
+template <class Better>
+__device__ __forceinline__ void block_best(double &f, int &i, double *s_f, int *s_i, Better better)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double of = __shfl_xor(f, o);
+        const int oi = __shfl_xor(i, o);
+        if (better(of, oi, f, i)) { f = of; i = oi; }
+    }
+    __syncthreads();                 // (previous users of s_f / s_i are done)
+    if (lane == 0) { s_f[wave] = f; s_i[wave] = i; }
+    __syncthreads();
+    f = s_f[0]; i = s_i[0];
+#pragma unroll
+    for (int w = 1; w < SW; ++w) if (better(s_f[w], s_i[w], f, i)) { f = s_f[w]; i = s_i[w]; }
+}
 
 __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int32_t *__restrict__ cur, const double *__restrict__ cur_fit,
                                                        const double *__restrict__ cur_dist, int32_t *__restrict__ nxt,
@@ -160,33 +182,39 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
                                                        int gen, GaState *__restrict__ state, int32_t *__restrict__ best_route,
                                                        double *__restrict__ hist)
 {
-    __shared__ double s_f[SB], s_sum[SB];
-    __shared__ int s_i[SB];
+    extern __shared__ double s_fit[];      // the population's fitness, read once (pop <= GA_LDS_POP; otherwise re-read from global)
+    __shared__ double s_f[SW], s_sum[SB];
+    __shared__ int s_i[SW], s_pick[64];
     __shared__ int s_copy, s_stop;
     if (state->converged) return;
     const int tid = threadIdx.x;
-    // first argmax (np.argmax, GA:66 / GA:91) and the mean (GA:107) in a fixed order
+    const bool cached = pop <= GA_LDS_POP;
+    const double *__restrict__ fitv = cached ? s_fit : cur_fit;
+    // first argmax (np.argmax, GA:66 / GA:91) and the mean (GA:107) in a fixed order: SB strided partial sums, then a binary tree
     double bf = -1.0, acc = 0.0;
     int bi = 0x7fffffff;
     for (int i = tid; i < pop; i += SB) {
         const double f = cur_fit[i];
+        if (cached) s_fit[i] = f;
         acc += f;
         if (f > bf || (f == bf && i < bi)) { bf = f; bi = i; }
     }
-    s_f[tid] = bf; s_i[tid] = bi; s_sum[tid] = acc;
+    s_sum[tid] = acc;
     __syncthreads();
-    for (int o = SB / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-            s_sum[tid] += s_sum[tid + o];
-            const double f = s_f[tid + o];
-            const int i = s_i[tid + o];
-            if (f > s_f[tid] || (f == s_f[tid] && i < s_i[tid])) { s_f[tid] = f; s_i[tid] = i; }
-        }
+    for (int o = SB / 2; o >= 64; o >>= 1) {
+        if (tid < o) s_sum[tid] += s_sum[tid + o];
         __syncthreads();
     }
+    double total = 0.0;
+    if (tid < 64) {                       // the last six levels of the same tree inside one wave
+        total = s_sum[tid];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o);
+    }
+    block_best(bf, bi, s_f, s_i, [](double af, int ai, double cf, int ci) { return af > cf || (af == cf && ai < ci); });
     if (tid == 0) {
-        const double f = s_f[0];
-        const int i = s_i[0];
+        const double f = bf;
+        const int i = bi;
         int copy = -1, stop = 0;
         if (gen < 0) {                                   // GA:66-70
             state->best_fit = f; state->best_dist = cur_dist[i]; state->gwi = 0; state->generations = 0;
@@ -194,7 +222,7 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
         } else {
             if (f > state->best_fit) { state->best_fit = f; state->best_dist = cur_dist[i]; state->gwi = 0; copy = i; }   // GA:94-98
             else state->gwi += 1;
-            if (hist) { hist[gen] = state->best_fit; hist[cfg.max_generations + gen] = s_sum[0] / (double)pop; }          // GA:106-107
+            if (hist) { hist[gen] = state->best_fit; hist[cfg.max_generations + gen] = total / (double)pop; }             // GA:106-107
             state->generations = gen + 1;
             if (state->gwi >= cfg.convergence_threshold) { state->converged = 1; stop = 1; }                              // GA:110-113
         }
@@ -208,36 +236,35 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
     // pop - 1 - t; each is the maximum among the entries below the previous pick
     double pf = 0.0;
     int pi = 0;
-    for (int t = 0; t < cfg.elite_size; ++t) {
-        double f = -1.0;
-        int idx = -1;
-        for (int i = tid; i < pop; i += SB) {
-            const double v = cur_fit[i];
-            if (t > 0 && !(v < pf || (v == pf && i < pi))) continue;
-            if (idx < 0 || v > f || (v == f && i > idx)) { f = v; idx = i; }
-        }
-        s_f[tid] = f; s_i[tid] = idx;
-        __syncthreads();
-        for (int o = SB / 2; o > 0; o >>= 1) {
-            if (tid < o) {
-                const double v = s_f[tid + o];
-                const int i = s_i[tid + o];
-                if (i >= 0 && (s_i[tid] < 0 || v > s_f[tid] || (v == s_f[tid] && i > s_i[tid]))) { s_f[tid] = v; s_i[tid] = i; }
+    for (int t0 = 0; t0 < cfg.elite_size; t0 += 64) {          // picks in batches of 64, their rows copied together
+        const int nt = min(64, cfg.elite_size - t0);
+        for (int t = t0; t < t0 + nt; ++t) {
+            double f = -1.0;
+            int idx = -1;
+            for (int i = tid; i < pop; i += SB) {
+                const double v = fitv[i];
+                if (t > 0 && !(v < pf || (v == pf && i < pi))) continue;
+                if (idx < 0 || v > f || (v == f && i > idx)) { f = v; idx = i; }
             }
-            __syncthreads();
+            block_best(f, idx, s_f, s_i, [](double af, int ai, double cf, int ci) { return ai >= 0 && (ci < 0 || af > cf || (af == cf && ai > ci)); });
+            pf = f; pi = idx;
+            if (tid == 0) s_pick[t - t0] = idx;
         }
-        pf = s_f[0]; pi = s_i[0];
         __syncthreads();
-        const int row = pop - 1 - t;
-        for (int k = tid; k < n; k += SB) nxt[(int64_t)row * n + k] = cur[(int64_t)pi * n + k];
-        if (tid == 0) { nxt_fit[row] = pf; nxt_dist[row] = cur_dist[pi]; }
+        for (int q = tid; q < nt * n; q += SB) {
+            const int t = q / n, k = q - t * n;
+            nxt[(int64_t)(pop - 1 - (t0 + t)) * n + k] = cur[(int64_t)s_pick[t] * n + k];
+        }
+        if (tid < nt) { const int src = s_pick[tid], row = pop - 1 - (t0 + tid); nxt_fit[row] = fitv[src]; nxt_dist[row] = cur_dist[src]; }
+        __syncthreads();
     }
 }
 
 int launch_ga_pairs(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, int32_t *nxt,
                     double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, const GaState *state)
 {
-    hipLaunchKernelGGL(k_ga_pairs, dim3((unsigned)(pop / 2)), dim3(64), 0, st, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen,
+    const size_t lds = (size_t)n * 4 * sizeof(int32_t) + (size_t)((n + 3) & ~3);
+    hipLaunchKernelGGL(k_ga_pairs, dim3((unsigned)(pop / 2)), dim3(64), lds, st, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen,
                        state);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -247,7 +274,8 @@ int launch_ga_stats_elite(hipStream_t st, int n, int pop, const int32_t *cur, co
                           double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, GaState *state, int32_t *best_route,
                           double *hist)
 {
-    hipLaunchKernelGGL(k_ga_stats_elite, dim3(1), dim3(SB), 0, st, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen, state,
+    const size_t lds = pop <= GA_LDS_POP ? (size_t)pop * sizeof(double) : 0;
+    hipLaunchKernelGGL(k_ga_stats_elite, dim3(1), dim3(SB), lds, st, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen, state,
                        best_route, hist);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
