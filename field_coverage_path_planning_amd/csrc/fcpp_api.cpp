@@ -67,7 +67,7 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     c.u_cap = vm * vm;
     c.inv_sf36 = 1.0 / (c.sf * 3.6);
     c.ms_work = c.v_work / 3.6; c.ms_turn = c.v_turn / 3.6; c.ms_head = c.v_head / 3.6; c.ms_rev = 2.5 / 3.6;
-    c.shapes = nullptr; c.tmpl_u = nullptr; c.tmpl_c = nullptr;
+    c.shapes = nullptr; c.tmpl_u = nullptr; c.tmpl_c = nullptr; c.tmpl_u_dk = nullptr;
     return c;
 }
 
@@ -245,7 +245,7 @@ struct fcpp_batch {
     DevBuf<int64_t> obs_off;
     DevBuf<double> obs_x, obs_y, obs_bbox;
     DevBuf<CacShape> shapes;   // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
-    DevBuf<double2> tmpl_u, tmpl_c;   // sampled turn templates (fcpp_fused.hip)
+    DevBuf<double2> tmpl_u, tmpl_c, tmpl_u_dk;   // sampled turn templates (fcpp_fused.hip)
     DevBuf<double> seg;        // connector segments
     DevBuf<int32_t> seg_mask;
     // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
@@ -423,12 +423,13 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         ok(b->shapes.upload(shp, st));
     b->cst.shapes = b->shapes.p;
     if (e == hipSuccess) {
-        ok(b->tmpl_u.alloc((size_t)b->hp.tt.nu)) && ok(b->tmpl_c.alloc((size_t)b->hp.tt.nc));
+        ok(b->tmpl_u.alloc((size_t)b->hp.tt.nu)) && ok(b->tmpl_c.alloc((size_t)b->hp.tt.nc)) && ok(b->tmpl_u_dk.alloc((size_t)b->hp.tt.nu));
         if (e == hipSuccess) {
             int le = launch_build_templates(st, b->hp.tt, b->shapes.p, b->tmpl_u.p, b->tmpl_c.p);
+            if (le == 0) le = launch_build_template_metrics(st, b->hp.tt.nu, b->tmpl_u.p, b->tmpl_u_dk.p);
             if (le != 0) e = (hipError_t)le;
         }
-        b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p;
+        b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p; b->cst.tmpl_u_dk = b->tmpl_u_dk.p;
     }
     if (e == hipSuccess && n_polys > 0) {
         std::vector<int64_t> po(obstacles->offsets, obstacles->offsets + n_polys + 1);

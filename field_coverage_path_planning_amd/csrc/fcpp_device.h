@@ -27,6 +27,7 @@ struct DevConst {
     double inv_sf36;           // 1 / (safety_factor * 3.6), for the clamp pre-test
     const CacShape *shapes;
     const double2 *tmpl_u, *tmpl_c;   // turn templates of the batch (fused kernel), see TurnTemplates
+    const double2 *tmpl_u_dk;         // per U-turn sample k: (|t_k - t_(k-1)|, curvature at t_k), the shape's own segment lengths / curvatures
 };
 
 // every launcher returns 0 or a hipError_t value
@@ -52,6 +53,7 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,
                       const DevField *fields, const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x,
                       double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial);
+int launch_build_template_metrics(hipStream_t st, int n, const void *tmpl, void *dk);
 int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, const DevField *fields, const DevPrim *prims,
                       const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
                       TilePartial *partial);

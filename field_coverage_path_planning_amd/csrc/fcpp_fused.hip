@@ -747,20 +747,38 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     // d[k] = |P(item k) - P(item k-1)|; item -1 / item FIPT are the end neighbours.  Bit k of `cut` = the sweeps do
     // not propagate across segment k: skipped steps (d < 1e-6, MLP:560-561 / 576-577) and the path ends.
     // Bit k of `nocouple` = segment k lies beyond the tile's last point (both ends are padding): coupling 0, the identity.
-    double d[FIPT + 1];
+    double d[FIPT + 1], kap[FIPT];
+    // Inside a U-turn both are properties of the turn's shape, the same for every turn of the batch (tmpl_u_dk): segment k
+    // lies inside a turn if item k is turn sample >= 1, the curvature stencil of item k if it is sample 1 .. n_turn - 2.
+    // (Layer 1 only; what remains for the generic code below are line samples -- axis-aligned: no square root, collinear:
+    // no angle -- and the junctions.)
+    unsigned tmpl_d = 0, tmpl_k = 0;
+    if (k_seam >= FIPT && per >= FIPT) {
+#pragma unroll
+        for (int k = 0; k <= FIPT; ++k) {
+            int off = c_off + k;
+            off = off >= per ? off - per : off;
+            const int tk = off - f.n_line;
+            if (tk >= 1) {
+                const double2 m = cst.tmpl_u_dk[tk];
+                d[k] = m.x; tmpl_d |= 1u << k;
+                if (k < FIPT && tk <= f.n_turn - 2) { kap[k] = m.y; tmpl_k |= 1u << k; }
+            }
+        }
+    }
     unsigned cut = 0, nocouple = 0;
 #pragma unroll
     for (int k = 0; k <= FIPT; ++k) {
-        d[k] = seg_len(X[k + 1] - X[k], Y[k + 1] - Y[k]);
+        if (!((tmpl_d >> k) & 1u)) d[k] = seg_len(X[k + 1] - X[k], Y[k + 1] - Y[k]);
         if ((d[k] < 1e-6) || (k == 0 && at_start) || (k == k_end + 1)) cut |= 1u << k;
         if (k > nvalid || nvalid == 0) nocouple |= 1u << k;
     }
     // curvature: the unrolled loop handles the cheap cases (collinear, tiny and small turning angles); the rare large
     // angles (junctions, coarse reference-sampled arcs) go through ONE copy of atan2 below, one item per lane per round
-    double kap[FIPT];
     unsigned hard = 0;
 #pragma unroll
     for (int k = 0; k < FIPT; ++k) {
+        if ((tmpl_k >> k) & 1u) { if (k >= nvalid) kap[k] = 0.0; continue; }
         double kk = 0.0;
         if (k < nvalid && !(k == 0 && at_start) && k != k_end) {
             bool slow;
@@ -1061,6 +1079,33 @@ __global__ void k_build_templates(TurnTemplates tt, const CacShape *__restrict__
         }
         tc[k] = o;
     }
+}
+
+// the U-turn shape's own metrics, once per batch: dk[k] = (segment length |t_k - t_(k-1)|, curvature of (t_(k-1), t_k, t_(k+1))).
+// Every U-turn of the batch is a translate / mirror (/ rotation, for tilted fields) of the template, under which both are
+// invariant; taken from the shape itself they carry none of the rounding noise of 1000 m coordinates.
+__global__ void k_build_template_metrics(int n, const double2 *__restrict__ t, double2 *__restrict__ dk)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double2 o = make_double2(0.0, 0.0);
+    if (k >= 1) {
+        const double dx1 = t[k].x - t[k - 1].x, dy1 = t[k].y - t[k - 1].y;
+        o.x = seg_len(dx1, dy1);
+        if (k + 1 < n) {
+            const double dx2 = t[k + 1].x - t[k].x, dy2 = t[k + 1].y - t[k].y;
+            o.y = curv_chords(dx1, dy1, o.x, dx2, dy2, seg_len(dx2, dy2));
+        }
+    }
+    dk[k] = o;
+}
+
+int launch_build_template_metrics(hipStream_t st, int n, const void *tmpl, void *dk)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_build_template_metrics, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const double2 *)tmpl, (double2 *)dk);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc)

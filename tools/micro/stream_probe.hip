@@ -40,6 +40,43 @@ __global__ __launch_bounds__(256) void k_streams(double *base, size_t dist, size
     }
 }
 
+// W: consecutive tiles per wavefront (fewer, longer waves)
+template <int W>
+__global__ __launch_bounds__(256) void k_multi(double *base, size_t dist, size_t n_tiles)
+{
+    const size_t t0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * W;
+    const int lane = threadIdx.x & 63;
+    for (int w = 0; w < W; ++w) {
+        const size_t tile = t0 + w;
+        if (tile >= n_tiles) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t idx = tile * 512 + 2 * (lane + 64 * k);
+            const double v = (double)idx;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<double2 *>(base + s * dist + idx) = make_double2(v, v + 1.0);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned *>(base + 4 * dist) + idx) = make_uint2((unsigned)idx, 7u);
+        }
+    }
+}
+
+template <int W>
+float run_multi(double *base, size_t dist, size_t n, int reps)
+{
+    const size_t n_tiles = n / 512, waves = (n_tiles + W - 1) / W;
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_multi<W>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, base, dist, n_tiles);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_multi<W>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, base, dist, n_tiles);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 template <int K8, int K4, int TILE>
 float run(double *base, size_t dist, size_t n, int reps)
 {
@@ -67,7 +104,7 @@ int main(int argc, char **argv)
     char *slab;
     CHK(hipMalloc(&slab, slab_gib * GiB));
     printf("slab %zu GiB at %p\n", slab_gib, (void *)slab);
-    if (argc > 2) {   // map: a 8 GiB window (5 streams of 1.5 GiB, 1.6 GiB apart) slides over the slab
+    if (argc > 2 && argv[2][0] == 'm') {   // map: a 8 GiB window (5 streams of 1.5 GiB, 1.6 GiB apart) slides over the slab
         const size_t nm = (size_t)(1.5 * GiB) / 8 / 512 * 512, dm = (size_t)(1.6 * GiB) / 4096 * 4096 / 8;
         for (int rnd = 0; rnd < 2; ++rnd) {
             printf("GB/s per 8 GiB window (B: 4x8+1x4 bytes aligned | S: one stream):");
@@ -82,6 +119,16 @@ int main(int argc, char **argv)
         return 0;
     }
     const size_t dist = (size_t)(7.6 * GiB) / 4096 * 4096 / 8;   // elements
+    if (argc > 2 && argv[2][0] == 'w') {   // tiles per wave
+        for (int rnd = 0; rnd < 2; ++rnd)
+            for (size_t base_gib : { 0, 33 }) {
+                double *base = reinterpret_cast<double *>(slab + base_gib * GiB);
+                const double gB = 36.0 * n / 1e9;
+                printf("base %2zu GiB | tiles per wave 1: %.3f ms  2: %.3f  4: %.3f  8: %.3f  (%.1f GB)\n", base_gib, run_multi<1>(base, dist, n, 5),
+                       run_multi<2>(base, dist, n, 5), run_multi<4>(base, dist, n, 5), run_multi<8>(base, dist, n, 5), gB);
+            }
+        return 0;
+    }
     for (int rnd = 0; rnd < 2; ++rnd)
         for (size_t base_gib : { 0, 8, 16, 24, 33 }) {
             double *base = reinterpret_cast<double *>(slab + base_gib * GiB);
