@@ -68,6 +68,8 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     c.inv_sf36 = 1.0 / (c.sf * 3.6);
     c.ms_work = c.v_work / 3.6; c.ms_turn = c.v_turn / 3.6; c.ms_head = c.v_head / 3.6; c.ms_rev = 2.5 / 3.6;
     c.shapes = nullptr; c.tmpl_u = nullptr; c.tmpl_c = nullptr; c.tmpl_u_dk = nullptr;
+    c.turn_kappa_last[0] = c.turn_kappa_last[1] = c.turn_len = c.turn_time = 0.0;
+    c.turn_max_kappa[0] = c.turn_max_kappa[1] = c.turn_max_jump[0] = c.turn_max_jump[1] = 0.0;
     return c;
 }
 
@@ -83,6 +85,7 @@ struct Tiling {
         const DevPrim *prims; int prim_count, prim_index0;  // layer 2: the field's primitives, index of the first one in the batch
         double two_a;
         bool enable;
+        bool turn_quiet;       // U-turns are closed form and swath lines are isolated by them (see fcpp_batch_create)
     };
 
     // Tiles never straddle paths and hold at most TILE_POINTS points.  Without structure information (standalone operators)
@@ -136,11 +139,18 @@ struct Tiling {
                 const int64_t need1 = need_for(q->c_line, q->line_step_len);
                 if (need1 >= 0 && per > 0) {
                     for (int64_t idx = 0; idx < q->P; ++idx) {
-                        const int64_t L0 = idx * per, zs = L0 + need1, Z = q->n_line - 2 * need1;
+                        // With closed-form U-turns nothing propagates into a swath line from the turns around it (the turn
+                        // starts on the line's last point: a skipped step; the jump back from the turn's end is too long to
+                        // bind): the whole line is a quiet run, and so is the turn after it.  The last line ends at the seam
+                        // to the headland layer and keeps its margin.
+                        const bool full = q->turn_quiet;
+                        const int64_t need_s = full ? 0 : need1, need_e = (full && idx < q->P - 1) ? 0 : need1;
+                        const int64_t L0 = idx * per, zs = L0 + need_s, Z = q->n_line - need_s - need_e;
                         if (Z < 64) break;
                         emit_general(pos, zs);
-                        emit_quiet(zs, Z, 1, idx, need1);
+                        emit_quiet(zs, Z, 1, idx, need_s);
                         pos = zs + Z;
+                        if (full && idx < q->P - 1) { emit_quiet(L0 + q->n_line, q->n_turn, 3, idx, 0); pos = L0 + per; }
                     }
                 }
                 for (int k = 0; k < q->prim_count; ++k) {
@@ -264,6 +274,52 @@ const char *const kStageNames[2][kStages] = {
     { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine", "k_scan_apply", "k_validate", "k_reduce_stats" },
     { "k_plan_quiet", "k_plan_fused", "k_reduce_stats", "", "", "", "" } };
 const int kStageCount[2] = { 7, 3 };
+}
+
+// Are the U-turns of this batch closed form?  A turn is a translate / mirror of the template t[0..nu); its neighbours are the
+// swath line it leaves (whose last point is the turn's first: a skipped step, nothing propagates across it) and the next
+// line, reached by a jump J from the turn's last sample.  If every sample keeps the nominal turn speed under the curvature
+// clamp, the next line's first point keeps the work speed, and 2a|J| is too long for the sweeps to bind across the jump, then
+// turn points are template + translation, curvature and segment lengths are the shape's own (dk), speeds are nominal.
+// Fills the per-batch constants the quiet kernel and the run statistics need.  Index 0 / 1: passes ascending / descending in y.
+static bool closed_form_turns(const fcpp_vehicle &veh, const TurnTemplates &tt, const std::vector<double2> &t,
+                              const std::vector<double2> &dk, DevConst &c)
+{
+    const int nu = tt.nu;
+    const double W = veh.working_width, R = veh.min_turn_radius;
+    if (nu < 3 || fabs(t[0].x) > 1e-9 || fabs(t[0].y) > 1e-9) return false;
+    const double q_t = c.v_turn * c.inv_sf36, q_w = c.v_work * c.inv_sf36, lim = c.a_lat * 0.999;
+    double len = 0.0, maxk = 0.0, maxj = 0.0;
+    for (int k = 1; k < nu; ++k) len += dk[(size_t)k].x;
+    for (int k = 1; k + 1 < nu; ++k) {
+        maxk = std::max(maxk, dk[(size_t)k].y);
+        maxj = std::max(maxj, fabs(dk[(size_t)k].y - dk[(size_t)k - 1].y));
+    }
+    if (maxk * q_t * q_t >= lim) return false;
+    // the turn's last chord in the frame of a right turn (world x grows to the right)
+    const bool arc = tt.turn_model == FCPP_TURN_ARC;
+    const double sx = arc ? -1.0 : 1.0;                    // arcs: px = max_x - t.x; clothoid: px = (max_x - R) + t.x
+    const double c1x = sx * (t[(size_t)nu - 1].x - t[(size_t)nu - 2].x), c1y = t[(size_t)nu - 1].y - t[(size_t)nu - 2].y;
+    const double d1 = sqrt(c1x * c1x + c1y * c1y);
+    const double u_t = c.ms_turn * c.ms_turn, u_w = c.ms_work * c.ms_work;
+    for (int v = 0; v < 2; ++v) {
+        // jump to the first point of the next line: x back to max_x - R, y to the next pass (+W, or -W in top-down order)
+        const double jx = arc ? (-R + t[(size_t)nu - 1].x) : -t[(size_t)nu - 1].x;
+        const double jy = (v == 0 ? W : -W) - t[(size_t)nu - 1].y;
+        const double dj = sqrt(jx * jx + jy * jy);
+        if (!(dj >= 1e-3) || d1 < 1e-6) return false;
+        if (u_t + 2 * c.a_lon * dj < u_w * (1.0 + 1e-9)) return false;          // the sweeps must not bind across the jump
+        const double k_last = fabs(2 * atan2(c1x * jy - c1y * jx, c1x * jx + c1y * jy) / (d1 + dj));
+        // first point of the next line: chords J and the line heading (-x after a right turn); its curvature is largest for step -> 0
+        const double k_first_max = fabs(2 * atan2(jx * 0.0 - jy * -1.0, jx * -1.0 + jy * 0.0) / dj);
+        if (k_last * q_t * q_t >= lim || k_first_max * q_w * q_w >= lim) return false;
+        c.turn_kappa_last[v] = k_last;
+        c.turn_max_kappa[v] = std::max(maxk, k_last);
+        c.turn_max_jump[v] = std::max(std::max(maxj, fabs(dk[(size_t)nu - 2].y - (nu >= 3 ? dk[(size_t)nu - 3].y : 0.0))), fabs(k_last - dk[(size_t)nu - 2].y));
+    }
+    c.turn_len = len;
+    c.turn_time = len / std::max(c.ms_turn, 0.1);
+    return true;
 }
 
 extern "C" {
@@ -402,6 +458,29 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     b->cst = make_const(*veh, *opt);
     hipStream_t st = c->stream;
     std::vector<CacShape> shp = { make_cac_shape(kPi, opt->clothoid_frac), make_cac_shape(kHalfPi, opt->clothoid_frac) };
+    // turn templates first: the tiler needs to know whether the U-turns of this batch are closed form
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
+    ok(b->shapes.upload(shp, st));
+    b->cst.shapes = b->shapes.p;
+    bool turn_quiet = false;
+    if (e == hipSuccess) {
+        const int nu = b->hp.tt.nu;
+        ok(b->tmpl_u.alloc((size_t)nu)) && ok(b->tmpl_c.alloc((size_t)b->hp.tt.nc)) && ok(b->tmpl_u_dk.alloc((size_t)nu));
+        if (e == hipSuccess) {
+            int le = launch_build_templates(st, b->hp.tt, b->shapes.p, b->tmpl_u.p, b->tmpl_c.p);
+            if (le == 0) le = launch_build_template_metrics(st, nu, b->tmpl_u.p, b->tmpl_u_dk.p);
+            if (le != 0) e = (hipError_t)le;
+        }
+        b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p; b->cst.tmpl_u_dk = b->tmpl_u_dk.p;
+        if (e == hipSuccess && nu >= 3) {
+            std::vector<double2> t((size_t)nu), dk((size_t)nu);
+            ok(hipMemcpyAsync(t.data(), b->tmpl_u.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st)) &&
+                ok(hipMemcpyAsync(dk.data(), b->tmpl_u_dk.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st)) &&
+                ok(hipStreamSynchronize(st));
+            if (e == hipSuccess) turn_quiet = closed_form_turns(*veh, b->hp.tt, t, dk, b->cst);
+        }
+    }
     Tiling til;
     std::vector<int64_t> offs((size_t)n_fields + 1, 0);
     for (int64_t i = 0; i < n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
@@ -414,23 +493,11 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         q.prims = b->hp.prims.data() + df.prim_first; q.prim_count = df.prim_count; q.prim_index0 = df.prim_first;
         q.two_a = 2 * b->cst.a_lon;
         q.enable = df.n_total > 0;
+        q.turn_quiet = turn_quiet && df.n_turn == b->hp.tt.nu;
         qi[(size_t)i] = q;
     }
     til.build(n_fields, offs.data(), qi.data());
-    hipError_t e = hipSuccess;
-    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
-    ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st)) &&
-        ok(b->shapes.upload(shp, st));
-    b->cst.shapes = b->shapes.p;
-    if (e == hipSuccess) {
-        ok(b->tmpl_u.alloc((size_t)b->hp.tt.nu)) && ok(b->tmpl_c.alloc((size_t)b->hp.tt.nc)) && ok(b->tmpl_u_dk.alloc((size_t)b->hp.tt.nu));
-        if (e == hipSuccess) {
-            int le = launch_build_templates(st, b->hp.tt, b->shapes.p, b->tmpl_u.p, b->tmpl_c.p);
-            if (le == 0) le = launch_build_template_metrics(st, b->hp.tt.nu, b->tmpl_u.p, b->tmpl_u_dk.p);
-            if (le != 0) e = (hipError_t)le;
-        }
-        b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p; b->cst.tmpl_u_dk = b->tmpl_u_dk.p;
-    }
+    ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st));
     if (e == hipSuccess && n_polys > 0) {
         std::vector<int64_t> po(obstacles->offsets, obstacles->offsets + n_polys + 1);
         const int64_t nv = po.back();
