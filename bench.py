@@ -157,7 +157,7 @@ def main():
                             f'default VehicleParams',
                 'points_per_gpu_step': n_points, 'fields_per_gpu': args.fields,
                 'pipeline': ('staged (7 kernels)' if args.mode == 0 else
-                             'fused single pass: k_plan_quiet (closed-form runs on straight primitives, aligned 512-point chunks) + '
+                             'fused single pass: k_plan_quiet (closed-form runs: swath lines, headland straights, U-turns; aligned 512-point chunks) + '
                              'k_plan_fused (all other tiles)'),
                 'quiet_points': q_pts, 'general_points': g_pts,
                 'output_placement': {'candidates_tried': len(getattr(batch, 'placement_ms', [])) or 1,

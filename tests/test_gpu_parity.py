@@ -192,6 +192,23 @@ def test_dense_and_clothoid_sampling_vs_oracle(opt):
     _compare_with_oracle(specs + specs2, ofs + ofs2, DEFAULT_VP, opt, xy_tol=1e-9, k_tol=k_tol, v_tol=max(V_TOL, 200 * k_tol))
 
 
+@pytest.mark.parametrize('vp', [
+    [3.2, 8.0, 9.0, 15.0, 15.0, 2.0, 1.5, 0.85],     # turn speed 15 km/h: the clamp binds on every turn sample
+    [3.2, 8.0, 9.0, 15.0, 4.0, 2.0, 0.1, 0.85],      # a_lon 0.1: the sweeps bind across the jump from a turn's end to the next line
+    [3.2, 8.0, 30.0, 15.0, 4.0, 2.0, 1.5, 0.85],     # work speed 30 km/h: the clamp binds on the first point of every line
+])
+def test_turns_that_are_not_closed_form_vs_oracle(vp):
+    """The closed-form U-turn path (quiet runs of kind 3, swath lines quiet end to end) is only taken when every turn sample and
+    the next line's first point keep their nominal speed and nothing propagates across the jump; otherwise the general kernel
+    plans the turns.  Same comparison against the oracle in both cases (dense clothoid and dense arcs)."""
+    specs, ofs = _random_fields(21, 5, with_points=True)
+    specs2, ofs2 = _random_fields(22, 2, para=True)
+    for opt in (dict(turn_model=1, sample_spacing=0.2), dict(sample_spacing=0.25)):
+        ds = opt['sample_spacing']
+        k_tol = max(K_TOL, 4e-12 / ds ** 2)
+        _compare_with_oracle(specs + specs2, ofs + ofs2, vp, opt, xy_tol=1e-9, k_tol=k_tol, v_tol=max(V_TOL, 200 * k_tol))
+
+
 def test_other_vehicles_vs_oracle():
     specs, ofs = _random_fields(99, 12)
     _compare_with_oracle(specs, ofs, [2.5, 6.0, 12.0, 14.0, 5.0, 1.2, 0.7, 0.9], {})
