@@ -78,6 +78,7 @@ struct Tiling {
     std::vector<DevPath> paths;
     std::vector<DevTile> tiles;
     std::vector<int64_t> tile_first;
+    std::vector<int64_t> pass_len;      // per path: points per pass of layer 1 (swath line + U-turn), 0 without structure
     // structure of a field's path, for the fused pipeline's tiling
     struct QuietInfo {
         int64_t n_line, n_turn, P, n_main;
@@ -100,6 +101,7 @@ struct Tiling {
     {
         paths.resize((size_t)n_paths);
         tile_first.assign((size_t)n_paths + 1, 0);
+        pass_len.assign((size_t)n_paths, 0);
         tiles.clear();
         for (int64_t p = 0; p < n_paths; ++p) {
             const int64_t n = offsets[p + 1] - offsets[p];
@@ -107,6 +109,7 @@ struct Tiling {
             tile_first[(size_t)p] = (int64_t)tiles.size();
             const QuietInfo *q = (quiet && quiet[p].enable) ? &quiet[p] : nullptr;
             const int64_t per = q ? q->n_line + q->n_turn : 0;
+            pass_len[(size_t)p] = per;
             auto emit = [&](int64_t s, int64_t cnt, int kind, int64_t i0, int64_t o0) {
                 DevTile t;
                 t.field = (int32_t)p; t.start = s; t.count = (int32_t)cnt; t.quiet = kind; t.stat_tile = 0;
@@ -138,13 +141,24 @@ struct Tiling {
             if (q) {
                 const int64_t need1 = need_for(q->c_line, q->line_step_len);
                 if (need1 >= 0 && per > 0) {
-                    for (int64_t idx = 0; idx < q->P; ++idx) {
-                        // With closed-form U-turns nothing propagates into a swath line from the turns around it (the turn
-                        // starts on the line's last point: a skipped step; the jump back from the turn's end is too long to
-                        // bind): the whole line is a quiet run, and so is the turn after it.  The last line ends at the seam
-                        // to the headland layer and keeps its margin.
-                        const bool full = q->turn_quiet;
-                        const int64_t need_s = full ? 0 : need1, need_e = (full && idx < q->P - 1) ? 0 : need1;
+                    // With closed-form U-turns nothing propagates into a swath line from the turns around it (a turn starts on
+                    // the line's last point: a skipped step; the jump back from the turn's end is too long to bind): all
+                    // complete passes (line + turn) form ONE quiet span, whatever the sampling.  The last line ends at the
+                    // seam to the headland layer: it is cut like any other straight, without a margin at its start.
+                    // Dense sampling keeps lines and turns as runs of their own (cheaper per point: no pass decode); the span is for
+                    // short lines -- the reference's own sampling has 2 points per line and 20 per turn.
+                    int64_t first_idx = 0;
+                    const bool span = q->turn_quiet && q->P >= 2 && q->n_line - need1 < 64 && (q->P - 1) * per < (int64_t)0x7fffffff;
+                    if (span) {
+                        const int64_t S = (q->P - 1) * per, cap = TILE_POINTS - 2, k = (S + cap - 1) / cap, base = S / k, rem = S % k;
+                        int64_t a = 0;
+                        for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(a, c, 4, a / per, a % per); a += c; }
+                        pos = S; first_idx = q->P - 1;
+                    }
+                    for (int64_t idx = first_idx; idx < q->P; ++idx) {
+                        // closed-form turns, dense sampling: the whole line is a quiet run, and so is the turn after it
+                        const bool full = q->turn_quiet && !span;
+                        const int64_t need_s = (full || (span && idx > 0)) ? 0 : need1, need_e = (full && idx < q->P - 1) ? 0 : need1;
                         const int64_t L0 = idx * per, zs = L0 + need_s, Z = q->n_line - need_s - need_e;
                         if (Z < 64) break;
                         emit_general(pos, zs);
@@ -209,9 +223,9 @@ struct DevTiling {
             size_t j = i + 1;
             for (; j < t.tiles.size(); ++j) {
                 const DevTile &tj = t.tiles[j];
-                if (!(tj.quiet == t0.quiet && tj.field == t0.field && tj.idx0 == t0.idx0 && tj.start == t0.start + cnt &&
-                      (int64_t)tj.off0 == (int64_t)t0.off0 + cnt))
-                    break;
+                const bool cont = tj.quiet == t0.quiet && tj.field == t0.field && tj.start == t0.start + cnt &&
+                                  (t0.quiet == 4 || (tj.idx0 == t0.idx0 && (int64_t)tj.off0 == (int64_t)t0.off0 + cnt));
+                if (!cont) break;
                 cnt += tj.count;
             }
             rv.push_back({ (int32_t)i, 0, cnt });
@@ -222,6 +236,10 @@ struct DevTiling {
                 const int64_t c = std::min<int64_t>(cnt - done, TILE_POINTS - (g % TILE_POINTS));
                 DevTile ch = t0;
                 ch.start = t0.start + done; ch.off0 = (int32_t)(t0.off0 + done); ch.count = (int32_t)c; ch.stat_tile = (int32_t)i;
+                if (t0.quiet == 4) {      // a span of layer 1: (pass, offset in the pass) of the chunk's first point
+                    const int64_t per = t.pass_len[(size_t)t0.field];
+                    ch.idx0 = (int32_t)(ch.start / per); ch.off0 = (int32_t)(ch.start % per);
+                }
                 cv.push_back(ch);
                 done += c;
             }
@@ -287,7 +305,8 @@ static bool closed_form_turns(const fcpp_vehicle &veh, const TurnTemplates &tt, 
 {
     const int nu = tt.nu;
     const double W = veh.working_width, R = veh.min_turn_radius;
-    if (nu < 3 || fabs(t[0].x) > 1e-9 || fabs(t[0].y) > 1e-9) return false;
+    // the turn's first sample must be the line's last point: template offset 0 (clothoid: x = (max_x - R) + t.x) or R (arcs: x = max_x - t.x)
+    if (nu < 3 || fabs(t[0].x - (tt.turn_model == FCPP_TURN_ARC ? R : 0.0)) > 1e-9 || fabs(t[0].y) > 1e-9) return false;
     const double q_t = c.v_turn * c.inv_sf36, q_w = c.v_work * c.inv_sf36, lim = c.a_lat * 0.999;
     double len = 0.0, maxk = 0.0, maxj = 0.0;
     for (int k = 1; k < nu; ++k) len += dk[(size_t)k].x;
@@ -493,7 +512,9 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         q.prims = b->hp.prims.data() + df.prim_first; q.prim_count = df.prim_count; q.prim_index0 = df.prim_first;
         q.two_a = 2 * b->cst.a_lon;
         q.enable = df.n_total > 0;
-        q.turn_quiet = turn_quiet && df.n_turn == b->hp.tt.nu;
+        // (fields narrower than 4R have line_end_x < line_start_x: their lines run against the jump from the previous turn, the
+        // first point of every line is clamped -- general kernel)
+        q.turn_quiet = turn_quiet && df.n_turn == b->hp.tt.nu && df.line_step > 0.0;
         qi[(size_t)i] = q;
     }
     til.build(n_fields, offs.data(), qi.data());

@@ -460,7 +460,90 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg
         return out;
     };
     int nout = 0, nobs = 0;
-    if (tl.quiet == 3) {
+    if (tl.quiet == 4) {
+        // ---- a span of layer 1 whose passes (swath line + U-turn) are all closed form.  Point i of the span is (pass i / per,
+        // offset i % per): a line sample k * step + start (kappa 0; the first point of a line after a turn has the curvature of
+        // the jump stencil), or a turn sample = template + translation (mirror), curvature = the shape's own, nominal speeds.
+        const int per = q.n_line + q.n_turn, nl = q.n_line, last = q.n_turn - 1;
+        const bool arc = q.turn_model == FCPP_TURN_ARC;
+        const double xr = arc ? q.max_x : (q.max_x - q.R), xl = arc ? q.min_x : (q.min_x + q.R);
+        const double k_last = cst.turn_kappa_last[q.reverse_order ? 1 : 0];
+        double k_start = 0.0;
+        if (tl.off0 == 0 || tl.off0 + cnt > per) {     // (wave-uniform) the chunk holds the first point of a line
+            double jl;
+            k_start = line_start_curvature(q, cst, tl.idx0 + 1, jl);    // the same for every line of the field (mirror images)
+        }
+        auto sample = [&](int j, double &px, double &py, double &kp, double &v, uint32_t &fw) {
+            const unsigned a = (unsigned)(tl.off0 + max(j, 0));
+            const unsigned dq = a / (unsigned)per;
+            const int off = (int)(a - dq * (unsigned)per), idx = tl.idx0 + (int)dq;
+            const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
+            const double y = q.min_y + (double)pi * q.W;
+            const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+            if (off < nl) {
+                px = go_left ? ((double)off * -q.line_step + q.lex) : ((double)off * q.line_step + q.lsx);
+                if (off == nl - 1) px = go_left ? q.lsx : q.lex;
+                py = y;
+                kp = (off == 0 && idx > 0) ? k_start : 0.0;
+                v = cst.v_work;
+                fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+            } else {
+                const int c = off - nl;
+                const double2 t = cst.tmpl_u[c];
+                const bool turn_right = !go_left;
+                px = arc ? (turn_right ? (xr - t.x) : (xl + t.x)) : (turn_right ? (xr + t.x) : (xl - t.x));
+                py = y + t.y;
+                kp = c == last ? k_last : cst.tmpl_u_dk[c].y;
+                v = cst.v_turn;
+                fw = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+            }
+            if (q.rotated) rotate_back(q, px, py);
+        };
+#pragma unroll
+        for (int k = 0; k < TILE_POINTS / 128; ++k) {
+            const int j = 2 * (lane + 64 * k) - odd;
+            const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;
+            double px0, py0, k0, v0, px1, py1, k1, v1;
+            uint32_t f0, f1;
+            sample(j, px0, py0, k0, v0, f0);
+            sample(min(j + 1, cnt - 1), px1, py1, k1, v1, f1);
+            const bool o0 = has0 && outside(px0, py0), o1 = has1 && outside(px1, py1);      // turns may leave the field: every point is tested
+            nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
+            f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
+            f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
+            if (q.obs_count > 0) {
+                // bounding box of the wave's points of this pass, then the culled polygon tests
+                double mnx = has0 ? px0 : (has1 ? px1 : FCPP_INF), mxx = has0 ? px0 : (has1 ? px1 : -FCPP_INF);
+                double mny = has0 ? py0 : (has1 ? py1 : FCPP_INF), mxy = has0 ? py0 : (has1 ? py1 : -FCPP_INF);
+                if (has1) { mnx = fmin(mnx, px1); mxx = fmax(mxx, px1); mny = fmin(mny, py1); mxy = fmax(mxy, py1); }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mnx = fmin(mnx, __shfl_xor(mnx, o)); mny = fmin(mny, __shfl_xor(mny, o));
+                    mxx = fmax(mxx, __shfl_xor(mxx, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+                }
+                const double ox[2] = { has0 ? px0 : px1, px1 }, oy[2] = { has0 ? py0 : py1, py1 };
+                const unsigned m = obstacle_mask<2>(obs, q.obs_first, q.obs_first + q.obs_count, my_lds, mnx, mny, mxx, mxy, ox, oy,
+                                                    has1 ? 2 : (has0 ? 1 : 0));
+                const bool b0 = has0 && (m & 1u), b1 = has1 && (m & 2u);
+                nobs += (b0 ? 1 : 0) + (b1 ? 1 : 0);
+                f0 |= b0 ? FCPP_FLAG_OBSTACLE : 0u;
+                f1 |= b1 ? FCPP_FLAG_OBSTACLE : 0u;
+            }
+            // (a pair may straddle a line / turn boundary: each point carries its own speed)
+            const int64_t g = g0 + j;
+            if (has0 && has1) {
+                *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
+                *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
+                *reinterpret_cast<double2 *>(ko + g) = make_double2(k0, k1);
+                *reinterpret_cast<double2 *>(vo + g) = make_double2(v0, v1);
+                *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
+            } else if (has0) {
+                xo[g] = px0; yo[g] = py0; ko[g] = k0; vo[g] = v0; fso[g] = f0;
+            } else if (has1) {
+                xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = k1; vo[g + 1] = v1; fso[g + 1] = f1;
+            }
+        }
+    } else     if (tl.quiet == 3) {
         // ---- U-turn in closed form: sample = template + translation (mirror), curvature = the shape's own, nominal turn speed ----
         const int idx = tl.idx0;
         const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
@@ -599,7 +682,23 @@ __global__ __launch_bounds__(256) void k_quiet_run_stats(int64_t n_runs, const D
     tp.main_len = tp.main_time_pre = tp.main_time = tp.head_len = tp.head_time_pre = tp.head_time = 0.0;
     tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
     tp.n_viol = 0; tp.n_outside = 0; tp.n_in_obstacle = 0; tp.n_adjusted = 0;
-    if (tl.quiet == 3) {            // a whole U-turn: the shape's own totals (its first segment has length 0: the turn starts on the line's end)
+    if (tl.quiet == 4) {
+        // a span of whole passes: per pass the line's n_line - 1 steps and the turn shape's own totals (the turn's first segment has
+        // length 0: it starts on the line's end); every pass but the path's first starts with the jump from the previous turn
+        const DevField &q = fields[tl.field];
+        const int v = q.reverse_order ? 1 : 0;
+        const int per = q.n_line + q.n_turn;
+        const double n_pass = (double)(run.count / per), n_jump = n_pass - (tl.idx0 == 0 ? 1.0 : 0.0);
+        const double line_len = (double)(q.n_line - 1) * fabs(q.line_step);
+        double jl = 0.0, k0 = 0.0;
+        if (n_jump > 0.0) k0 = line_start_curvature(q, cst, tl.idx0 + 1, jl);
+        tp.main_len = n_pass * (line_len + cst.turn_len) + n_jump * jl;
+        tp.main_time_pre = tp.main_time = n_pass * (line_len / fmax(cst.ms_work, 0.1) + cst.turn_time) +
+                                          n_jump * (jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1));     // MLP:1305-1309
+        tp.max_kappa = fmax(cst.turn_max_kappa[v], k0);
+        tp.max_alat = fmax(cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v], cst.ms_work * cst.ms_work * k0);
+        tp.max_jump = fmax(cst.turn_max_jump[v], n_jump > 0.0 ? fmax(fabs(k0 - cst.turn_kappa_last[v]), k0) : 0.0);
+    } else     if (tl.quiet == 3) {            // a whole U-turn: the shape's own totals (its first segment has length 0: the turn starts on the line's end)
         const int v = fields[tl.field].reverse_order ? 1 : 0;
         tp.main_len = cst.turn_len; tp.main_time_pre = tp.main_time = cst.turn_time;
         tp.max_kappa = cst.turn_max_kappa[v]; tp.max_alat = cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v];

@@ -397,6 +397,8 @@ def test_edge_case_fields_vs_oracle():
     ofs = [orc.make_field(L=c['L'], H=c['H'], start=c.get('start'), end=c.get('end')) for c in cases]
     _compare_with_oracle(specs, ofs, DEFAULT_VP, {})
     _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(sample_spacing=0.3), k_tol=1e-7, v_tol=1e-5)
+    # (the 17.2 m wide field: lines run against the jump from the previous turn, every line start is clamped -> no closed-form turns)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(turn_model=1, sample_spacing=0.3), k_tol=1e-7, v_tol=1e-5)
     _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(turn_model=1, sample_spacing=50.0))         # spacing >> every primitive
     _compare_with_oracle(specs[4:8], ofs[4:8], [5.0, 4.5, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85], {})     # W > R: one headland loop
     _compare_with_oracle(specs[:5], ofs[:5], [0.8, 8.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85], {})       # 10 headland loops
