@@ -197,6 +197,8 @@ struct DevTiling {
     DevBuf<int32_t> general_ids;   // fused pipeline: the tiles of k_plan_fused
     DevBuf<DevTile> chunks;        // ... the quiet runs cut on 512-point boundaries of the batch arrays (k_plan_quiet)
     DevBuf<DevRun> runs;           // ... the quiet runs (k_quiet_run_stats)
+    DevBuf<int32_t> stat_ids;      // ... the tiles that can hold statistics (general tiles, first tile of every run), path by path
+    DevBuf<int64_t> stat_first;    //     CSR offsets into stat_ids per path
     int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_runs = 0, n_general = 0, quiet_points = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
     {
@@ -211,12 +213,15 @@ struct DevTiling {
         if ((e = carry_b.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
-        std::vector<int32_t> gv;
+        std::vector<int32_t> gv, sv;
+        std::vector<int64_t> sf((size_t)n_paths + 1, 0);
         std::vector<DevTile> cv;
         std::vector<DevRun> rv;
         quiet_points = 0;
         for (size_t i = 0; i < t.tiles.size();) {
             const DevTile &t0 = t.tiles[i];
+            sv.push_back((int32_t)i);                 // a general tile, or the first tile of a run
+            sf[(size_t)t0.field + 1] = (int64_t)sv.size();
             if (!t0.quiet) { gv.push_back((int32_t)i); ++i; continue; }
             // the run: quiet tiles that continue each other on the same straight
             int64_t cnt = t0.count;
@@ -249,6 +254,9 @@ struct DevTiling {
         if ((e = chunks.upload(cv, st)) != hipSuccess) return e;
         if ((e = runs.upload(rv, st)) != hipSuccess) return e;
         if ((e = general_ids.upload(gv, st)) != hipSuccess) return e;
+        for (size_t p = 1; p < sf.size(); ++p) sf[p] = std::max(sf[p], sf[p - 1]);      // paths without tiles
+        if ((e = stat_ids.upload(sv, st)) != hipSuccess) return e;
+        if ((e = stat_first.upload(sf, st)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the staging vectors die here
         return hipSuccess;
     }
@@ -603,7 +611,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         STAGE(0, launch_plan_quiet(st, t.n_chunks, t.chunks.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
                                    y, kappa, v, fs, t.partial.p));
-        STAGE(2, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, nullptr, stats));
+        STAGE(2, launch_reduce_stats(st, t.n_paths, t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p));
         if (ev) ++b->prof_runs;
         return FCPP_OK;
     }

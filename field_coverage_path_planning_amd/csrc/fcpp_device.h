@@ -51,7 +51,7 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
                     const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
 int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
-                        const unsigned long long *n_adjusted, fcpp_field_stats *stats);
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr);
 int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc);
 // ids: tile indices the launch covers (NULL = all tiles in order)
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,

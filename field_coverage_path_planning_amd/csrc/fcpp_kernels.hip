@@ -294,10 +294,12 @@ __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ 
 }
 
 // one wave per path: lanes stride over the path's tiles in a fixed assignment, then a fixed butterfly
+// ids (optional): the reduction runs over partial[ids[k]], k in [tile_first[p], tile_first[p+1]) -- the fused pipeline lists only the
+// tiles that can hold statistics (general tiles and the first tile of every quiet run; the others stay zero)
 __global__ __launch_bounds__(64) void k_reduce_stats(int64_t n_paths, const int64_t *__restrict__ tile_first,
                                                      const TilePartial *__restrict__ partial,
                                                      const unsigned long long *__restrict__ n_adjusted,
-                                                     fcpp_field_stats *__restrict__ stats)
+                                                     fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids)
 {
     const int64_t pth = blockIdx.x;
     if (pth >= n_paths) return;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64) void k_reduce_stats(int64_t n_paths, const int6
     double a[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long b[4] = { 0, 0, 0, 0 };
     for (int64_t t = tile_first[pth] + lane; t < tile_first[pth + 1]; t += 64) {
-        const TilePartial tp = partial[t];
+        const TilePartial tp = partial[ids ? (int64_t)ids[t] : t];
         a[0] += tp.main_len; a[1] += tp.main_time_pre; a[2] += tp.main_time;
         a[3] += tp.head_len; a[4] += tp.head_time_pre; a[5] += tp.head_time;
         a[6] = fmax(a[6], tp.max_kappa); a[7] = fmax(a[7], tp.max_alat); a[8] = fmax(a[8], tp.max_jump);
@@ -461,11 +463,11 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
 }
 
 int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
-                        const unsigned long long *n_adjusted, fcpp_field_stats *stats)
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids)
 {
     if (n_paths <= 0) return 0;
     hipLaunchKernelGGL(k_reduce_stats, dim3((unsigned)n_paths), dim3(64), 0, st, n_paths, tile_first, partial,
-                       n_adjusted, stats);
+                       n_adjusted, stats, ids);
     FCPP_LAUNCH_CHECK();
     return 0;
 }

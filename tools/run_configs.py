@@ -61,8 +61,14 @@ def cfg5(n=65536):
     dt = timed(lambda: b.run(bufs))
     st = b.run(bufs).stats()
     bad = sum(1 for i in b.info if i.status != 0)
+    b.set_profiling(True)
+    for _ in range(5):
+        b.run(bufs)
+    kt, _ = b.stage_times()
+    q, g = b.point_split()
     print(f'cfg5 ({n} parallelograms, reference sampling): {b.total_points} points, batch_create {t_create:.2f} s, '
-          f'{dt*1e3:.2f} ms/run, {b.total_points/dt:.3e} pts/s, unsupported fields {bad}, viol={int(st["n_viol"].sum())}')
+          f'{dt*1e3:.2f} ms/run, {b.total_points/dt:.3e} pts/s, unsupported fields {bad}, viol={int(st["n_viol"].sum())}; '
+          f'kernels {{{", ".join(f"{k}: {v:.3f}" for k, v in kt.items())}}} ms, quiet points {q}, general {g}')
     b.close()
 
 
