@@ -86,7 +86,7 @@ def main():
     specs, LH = make_specs(E, args.fields, 1024 + rank)
     batch = E.Batch(specs, E.make_vehicle(), E.make_options(args.turn_model, args.spacing), device=local)
     # output buffers: the fastest of up to --placement candidate allocations (setup, outside the timed region; see Batch.alloc)
-    bufs = batch.alloc(best_of=args.placement, mode=args.mode) if args.mode != 0 else batch.alloc()
+    bufs = batch.alloc(best_of=args.placement, good_gbps=6800.0, mode=args.mode) if args.mode != 0 else batch.alloc()
     n_points = batch.total_points
     gather_list = None
     if world > 1 and rank == 0:
