@@ -123,6 +123,8 @@ PROTOTYPES = [
     ('fcpp_straight_segments', C.c_int, [_VP, C.c_int64, _VP, C.c_int32, _VP]),
     ('fcpp_fresnel', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
     ('fcpp_ga_fitness', C.c_int, [_VP, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_int]),
+    ('fcpp_distance_matrix', C.c_int, [_VP, C.c_int32, _VP, _VP, _VP]),
+    ('fcpp_best_connections', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ('fcpp_ga_evolve', C.c_int, [_VP, C.c_int32, C.POINTER(GaConfig), _VP, _VP, _VP, _VP, C.POINTER(GaResult)]),
     ('fcpp_cover_grid', C.c_int, [_VP, C.c_int64, C.POINTER(CoverJob), C.c_int64, _VP, _VP, _VP, _VP]),
 ]

@@ -802,6 +802,24 @@ int fcpp_fresnel(fcpp_ctx *c, int64_t n, const double *t, double *cc, double *ss
     return FCPP_OK;
 }
 
+int fcpp_distance_matrix(fcpp_ctx *c, int32_t n, const double *x, const double *y, double *D)
+{
+    if (!c || n < 0 || n > 65535 || (n > 0 && (!x || !y || !D))) return fail(FCPP_EINVAL, "bad arguments (0 <= n <= 65535)");
+    HIPCHK(hipSetDevice(c->device));
+    LAUNCHCHK(launch_distance_matrix(c->stream, n, x, y, D));
+    return FCPP_OK;
+}
+
+int fcpp_best_connections(fcpp_ctx *c, int64_t n_pairs, const int64_t *fo, const int64_t *to, const double *fx, const double *fy,
+                          const double *tx, const double *ty, int32_t *bf, int32_t *bt, double *bd)
+{
+    if (!c || n_pairs < 0 || n_pairs > 0x7fffffffLL || (n_pairs > 0 && (!fo || !to || !bf || !bt || !bd)))
+        return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    LAUNCHCHK(launch_best_connections(c->stream, n_pairs, fo, to, fx, fy, tx, ty, bf, bt, bd));
+    return FCPP_OK;
+}
+
 int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const double *D, int32_t *routes, int32_t *best_route,
                    double *hist, fcpp_ga_result *result)
 {

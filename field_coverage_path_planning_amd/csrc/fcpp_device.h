@@ -57,6 +57,9 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,
                       const DevField *fields, const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x,
                       double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial);
+int launch_distance_matrix(hipStream_t st, int n, const double *x, const double *y, double *D);
+int launch_best_connections(hipStream_t st, int64_t n_pairs, const int64_t *fo, const int64_t *to, const double *fx, const double *fy,
+                            const double *tx, const double *ty, int32_t *bf, int32_t *bt, double *bd);
 int launch_build_template_metrics(hipStream_t st, int n, const void *tmpl, void *dk);
 int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, const DevField *fields, const DevPrim *prims,
                       const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,

@@ -395,6 +395,47 @@ __global__ __launch_bounds__(BLOCK) void k_ga_fitness(int n, int64_t pop, const 
     }
 }
 
+// centroid distance matrix (MVP:229-259, MFP:263-288): one thread per entry, rows coalesced
+__global__ void k_distance_matrix(int n, const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    const double dx = x[i] - x[j], dy = y[i] - y[j];
+    D[(int64_t)i * n + j] = i == j ? 0.0 : sqrt(dx * dx + dy * dy);
+}
+
+// shortest exit -> entry connection per node pair (MFP:290-320): one wavefront per pair scans the candidate products in
+// order; ties go to the first pair in (exit-major, entry-minor) order
+__global__ __launch_bounds__(64) void k_best_connections(int64_t n_pairs, const int64_t *__restrict__ fo, const int64_t *__restrict__ to,
+                                                         const double *__restrict__ fx, const double *__restrict__ fy,
+                                                         const double *__restrict__ tx, const double *__restrict__ ty,
+                                                         int32_t *__restrict__ bf, int32_t *__restrict__ bt, double *__restrict__ bd)
+{
+    const int64_t p = blockIdx.x;
+    if (p >= n_pairs) return;
+    const int lane = threadIdx.x;
+    const int64_t f0 = fo[p], nf = fo[p + 1] - f0, t0 = to[p], nt = to[p + 1] - t0, total = nf * nt;
+    double best = FCPP_INF;
+    int64_t bk = -1;
+    for (int64_t k = lane; k < total; k += 64) {
+        const int64_t a = k / nt, b = k - a * nt;
+        const double dx = fx[f0 + a] - tx[t0 + b], dy = fy[f0 + a] - ty[t0 + b];
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d < best) { best = d; bk = k; }            // (k ascends per lane: the lane's first minimum)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int64_t ok = __shfl_xor(bk, o);
+        if (ok >= 0 && (bk < 0 || ob < best || (ob == best && ok < bk))) { best = ob; bk = ok; }
+    }
+    if (lane == 0) {
+        bf[p] = bk < 0 ? -1 : (int32_t)(f0 + bk / nt);
+        bt[p] = bk < 0 ? -1 : (int32_t)(t0 + bk % nt);
+        bd[p] = best;
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // launchers (called from fcpp_api.cpp)
 // --------------------------------------------------------------------------------------------
@@ -468,6 +509,23 @@ int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *part
     if (n_paths <= 0) return 0;
     hipLaunchKernelGGL(k_reduce_stats, dim3((unsigned)n_paths), dim3(64), 0, st, n_paths, tile_first, partial,
                        n_adjusted, stats, ids);
+    FCPP_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_distance_matrix(hipStream_t st, int n, const double *x, const double *y, double *D)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_distance_matrix, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, st, n, x, y, D);
+    FCPP_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_best_connections(hipStream_t st, int64_t n_pairs, const int64_t *fo, const int64_t *to, const double *fx, const double *fy,
+                            const double *tx, const double *ty, int32_t *bf, int32_t *bt, double *bd)
+{
+    if (n_pairs <= 0) return 0;
+    hipLaunchKernelGGL(k_best_connections, dim3((unsigned)n_pairs), dim3(64), 0, st, n_pairs, fo, to, fx, fy, tx, ty, bf, bt, bd);
     FCPP_LAUNCH_CHECK();
     return 0;
 }

@@ -389,6 +389,46 @@ def ga_fitness(routes, D, order_mode=0, device=None):
     return dist, fit
 
 
+def distance_matrix(xy, device=None):
+    """Centroid distance matrix (MVP:229-259, MFP:263-288) -> (n, n) float64 device tensor; row 0 = the depot by convention."""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    p = _dev_f64(xy, dev).reshape(-1, 2)
+    x, y = p[:, 0].contiguous(), p[:, 1].contiguous()
+    n = int(x.shape[0])
+    D = torch.empty((n, n), dtype=torch.float64, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_distance_matrix(ctx.handle, n, _ptr(x), _ptr(y), _ptr(D)))
+    return D
+
+
+def best_connections(from_lists, to_lists, device=None):
+    """Shortest exit -> entry connection for a batch of node pairs (MFP:290-320).  from_lists[p] / to_lists[p]: (k, 2) candidate
+    points of pair p.  -> (index into from_lists[p], index into to_lists[p], distance) as numpy arrays (-1, -1, inf for empty lists)."""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    n = len(from_lists)
+    f = [np.asarray(a, dtype=np.float64).reshape(-1, 2) for a in from_lists]
+    t = [np.asarray(a, dtype=np.float64).reshape(-1, 2) for a in to_lists]
+    fo = np.concatenate([[0], np.cumsum([len(a) for a in f])]).astype(np.int64)
+    to = np.concatenate([[0], np.cumsum([len(a) for a in t])]).astype(np.int64)
+    fxy = np.vstack(f) if n else np.zeros((0, 2))
+    txy = np.vstack(t) if n else np.zeros((0, 2))
+    d = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    fo_d, to_d, fx, fy, tx, ty = d(fo), d(to), d(fxy[:, 0]), d(fxy[:, 1]), d(txy[:, 0]), d(txy[:, 1])
+    bf = torch.empty(n, dtype=torch.int32, device=dev)
+    bt = torch.empty(n, dtype=torch.int32, device=dev)
+    bd = torch.empty(n, dtype=torch.float64, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_best_connections(ctx.handle, n, _ptr(fo_d), _ptr(to_d), _ptr(fx), _ptr(fy), _ptr(tx), _ptr(ty), _ptr(bf), _ptr(bt),
+                                          _ptr(bd)))
+    bf, bt = bf.cpu().numpy().astype(np.int64), bt.cpu().numpy().astype(np.int64)
+    ok = bf >= 0
+    return np.where(ok, bf - fo[:-1], -1), np.where(ok, bt - to[:-1], -1), bd.cpu().numpy()
+
+
 def ga_evolve(D, routes, cfg, seed=0, device=None):
     """The GA's evolution loop on the device (fcpp_ga_evolve; GA:64-115, 183-268).  cfg: an object with GAConfig's attributes.
     -> (final population tensor (pop, n) int32, best_route tensor, best_fitness_history, avg_fitness_history (numpy), L.GaResult)"""

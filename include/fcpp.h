@@ -232,6 +232,20 @@ typedef struct fcpp_ga_result {   /* the `stats` of GA:122-127 */
 int fcpp_ga_evolve(fcpp_ctx *ctx, int32_t n_nodes, const fcpp_ga_config *cfg, const double *D_dev, int32_t *routes_dev,
                    int32_t *best_route_dev, double *hist_dev, fcpp_ga_result *result);
 
+/* ---- scheduler inputs -----------------------------------------------------------
+ * MultiVehiclePlanner._build_distance_matrix (MVP:229-259) / MultiFieldPlanner._calculate_distance_matrix (MFP:263-288):
+ * D[i][j] = sqrt((x_i - x_j)^2 + (y_i - y_j)^2), 0 on the diagonal; node 0 is the depot, the others field centroids.
+ * D_dev: n x n float64 row-major (the layout fcpp_ga_fitness / fcpp_ga_evolve take). */
+int fcpp_distance_matrix(fcpp_ctx *ctx, int32_t n, const double *x_dev, const double *y_dev, double *D_dev);
+/* MultiFieldPlanner._find_best_connection (MFP:290-320) for a batch of consecutive node pairs: pair p connects one of the exit
+ * candidates [from_off[p], from_off[p+1]) of its first node with one of the entry candidates [to_off[p], to_off[p+1]) of its
+ * second node; the shortest pair wins, the FIRST one in (exit-major, entry-minor) order among equals (the reference's
+ * `distance < best_distance`).  Outputs per pair: the winning candidate indices (into fx/fy and tx/ty) and the distance
+ * (-1, -1, +inf when a candidate list is empty).  All arrays on the device. */
+int fcpp_best_connections(fcpp_ctx *ctx, int64_t n_pairs, const int64_t *from_off_dev, const int64_t *to_off_dev,
+                          const double *fx_dev, const double *fy_dev, const double *tx_dev, const double *ty_dev,
+                          int32_t *best_from_dev, int32_t *best_to_dev, double *best_dist_dev);
+
 /* ---- coverage rasterisation -------------------------------------------------
  * Replaces the Shapely calls of verify_corner_coverage_grid_based (MLP:1426-1509: `LineString(path).buffer(W/2)
  * .contains(Point)` per 0.1 m grid cell of a 2R x 2R corner square, first for the turn, then for the reverse fill on

@@ -991,3 +991,26 @@ void orc_ga_evolve(int32_t n, const orc_ga_config *cfg, const double *D, int32_t
     if (cur != routes) memcpy(routes, cur, (size_t)pop * n * sizeof(int32_t));
     free(cur == routes ? nxt : cur); free(fit); free(dist); free(nfit); free(ndist); free(c1); free(c2);
 }
+
+/* ---- scheduler inputs (MVP:229-259, MFP:263-320) ---------------------------------------------------------------------- */
+void orc_distance_matrix(int32_t n, const double *x, const double *y, double *D)
+{
+    for (int32_t i = 0; i < n; ++i)
+        for (int32_t j = 0; j < n; ++j) {
+            const double dx = x[i] - x[j], dy = y[i] - y[j];
+            D[(int64_t)i * n + j] = i == j ? 0.0 : sqrt(dx * dx + dy * dy);      /* np.linalg.norm of a 2-vector */
+        }
+}
+
+double orc_best_connection(const double *fx, const double *fy, int64_t nf, const double *tx, const double *ty, int64_t nt,
+                           int64_t *bf, int64_t *bt)
+{
+    double best = INFINITY;
+    *bf = *bt = -1;
+    for (int64_t a = 0; a < nf; ++a)
+        for (int64_t b = 0; b < nt; ++b) {
+            const double dx = fx[a] - tx[b], dy = fy[a] - ty[b], d = sqrt(dx * dx + dy * dy);
+            if (d < best) { best = d; *bf = a; *bt = b; }                         /* MFP:307-311 */
+        }
+    return best;
+}

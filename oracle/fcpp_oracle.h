@@ -144,6 +144,12 @@ typedef struct orc_ga_result { int32_t generations, convergence_gen; double best
 void orc_ga_evolve(int32_t n, const orc_ga_config *cfg, const double *D, int32_t *routes, int32_t *best_route, double *hist,
                    orc_ga_result *res);
 
+/* MVP:229-259 / MFP:263-288 */
+void orc_distance_matrix(int32_t n, const double *x, const double *y, double *D);
+/* MFP:290-320: first shortest (exit, entry) pair; returns the distance, indices in *bf / *bt (-1 if a list is empty) */
+double orc_best_connection(const double *fx, const double *fy, int64_t nf, const double *tx, const double *ty, int64_t nt,
+                           int64_t *bf, int64_t *bt);
+
 /* coverage rasterisation: the sampled restatement of MLP:1426-1509 (corner grids) and MLP:1357-1371 (coverage rate).
  * Sample (i, j) = (ox + (i + shift) * res, oy + (j + shift) * res); covered by a polyline iff within `radius` of one of its
  * segments (strict: <, else <=; division-free test, see include/fcpp.h); polyline B is tried only on samples A left open

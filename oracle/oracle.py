@@ -145,6 +145,11 @@ def lib():
         L.orc_ga_elitism.argtypes = [c_i32_p, c_double_p, C.c_int32, C.c_int32, C.c_int32, c_i32_p]
         L.orc_ga_evolve.restype = None
         L.orc_ga_evolve.argtypes = [C.c_int32, C.POINTER(GaConfig), c_double_p, c_i32_p, c_i32_p, c_double_p, C.POINTER(GaResult)]
+        L.orc_distance_matrix.restype = None
+        L.orc_distance_matrix.argtypes = [C.c_int32, c_double_p, c_double_p, c_double_p]
+        L.orc_best_connection.restype = C.c_double
+        L.orc_best_connection.argtypes = [c_double_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.POINTER(C.c_int64),
+                                          C.POINTER(C.c_int64)]
         L.orc_cover_grid.restype = None
         L.orc_cover_grid.argtypes = [C.c_double] * 5 + [C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_int32, c_double_p, c_double_p,
                                      C.c_int32, C.c_int, c_double_p, C.POINTER(C.c_uint8), C.POINTER(C.c_int64)]
@@ -336,6 +341,23 @@ def ga_evolve(D, routes, population_size=None, max_generations=500, crossover_ra
     lib().orc_ga_evolve(n, C.byref(cfg), _dp(D), _ip(routes), _ip(best), _dp(hist), C.byref(res))
     g = res.generations
     return routes, best, hist[:g].copy(), hist[max_generations:max_generations + g].copy(), res
+
+
+def distance_matrix(xy):
+    xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+    x, y = _f64(xy[:, 0].copy()), _f64(xy[:, 1].copy())
+    D = np.empty((len(x), len(x)), dtype=np.float64)
+    lib().orc_distance_matrix(len(x), _dp(x), _dp(y), _dp(D))
+    return D
+
+
+def best_connection(from_xy, to_xy):
+    """-> (index into from_xy, index into to_xy, distance)"""
+    f, t = np.asarray(from_xy, dtype=np.float64).reshape(-1, 2), np.asarray(to_xy, dtype=np.float64).reshape(-1, 2)
+    fx, fy, tx, ty = (_f64(a.copy()) for a in (f[:, 0], f[:, 1], t[:, 0], t[:, 1]))
+    bf, bt = C.c_int64(), C.c_int64()
+    d = lib().orc_best_connection(_dp(fx), _dp(fy), len(fx), _dp(tx), _dp(ty), len(tx), C.byref(bf), C.byref(bt))
+    return bf.value, bt.value, d
 
 
 def cover_grid(ox, oy, res, shift, radius, nx, ny, a_xy, b_xy=None, strict=True, region=None, want_grid=True):

@@ -68,3 +68,33 @@ def test_solver_solve_on_device():
     assert abs(s1._calculate_distance(r1, D) - st1['best_distance']) < 1e-9 * st1['best_distance']
     rnd = np.mean([s1._calculate_distance(list(np.random.default_rng(k).permutation(40)), D) for k in range(5)])
     assert st1['best_distance'] < 0.5 * rnd
+
+
+def test_distance_matrix_and_connections_vs_oracle(golden_ga):
+    """Scheduler inputs: the matrix the GA consumes (MVP:229-259) and the exit -> entry connection search (MFP:290-320)."""
+    nodes = golden_ga['dm_nodes']
+    D = E.distance_matrix(nodes).cpu().numpy()
+    assert np.array_equal(D, orc.distance_matrix(nodes))                       # same arithmetic: bit-equal with the oracle
+    np.testing.assert_allclose(D, golden_ga['dm_D'], rtol=4.5e-16, atol=0)     # 1 ulp of the reference (numpy's dot kernel)
+    # fed straight into the GA fitness: bit-exact tour lengths against the oracle on the same matrix
+    rng = np.random.default_rng(3)
+    routes = np.array([rng.permutation(len(nodes)) for _ in range(32)], dtype=np.int32)
+    dist, _ = E.ga_fitness(routes, D)
+    assert np.array_equal(dist.cpu().numpy(), orc.ga_distance(routes, D))
+    # connections: quadrilateral corners as exit / entry candidates (MFP:136-140), a depot with one candidate, an empty list, ties
+    fl, tl = [], []
+    for p in range(200):
+        a = rng.uniform(-500, 500, size=(4 if p % 7 else 1, 2))
+        b = rng.uniform(-500, 500, size=(4 if p % 5 else 1, 2))
+        if p % 11 == 0:
+            b = np.vstack([b, b[::-1]])              # every distance twice: the first pair must win
+        if p == 13:
+            a = np.zeros((0, 2))
+        fl.append(a); tl.append(b)
+    bf, bt, bd = E.best_connections(fl, tl)
+    for p in range(200):
+        want = orc.best_connection(fl[p], tl[p])
+        assert (int(bf[p]), int(bt[p])) == want[:2] and (bd[p] == want[2]), p
+    big_f, big_t = rng.uniform(0, 1, size=(300, 2)), rng.uniform(0, 1, size=(257, 2))      # more products than lanes
+    bf, bt, bd = E.best_connections([big_f], [big_t])
+    assert (int(bf[0]), int(bt[0]), float(bd[0])) == orc.best_connection(big_f, big_t)

@@ -272,3 +272,17 @@ def test_ga_evolve_oracle_is_a_valid_ga():
     f2 = orc.ga_evolve(D, routes, max_generations=300, elite_size=4, convergence_threshold=40, seed=99)[0]
     f3 = orc.ga_evolve(D, routes, max_generations=300, elite_size=4, convergence_threshold=40, seed=100)[0]
     assert np.array_equal(final, f2) and not np.array_equal(final, f3)
+
+
+# ---- scheduler inputs (MVP:229-259, MFP:290-320), SURVEY.md 8f-3 ------------------------------------------------------
+def test_distance_matrix_matches_the_reference(golden_ga):
+    D = orc.distance_matrix(golden_ga['dm_nodes'])
+    np.testing.assert_allclose(D, golden_ga['dm_D'], rtol=4.5e-16, atol=0)     # 1 ulp: numpy's norm sums the two squares through its dot kernel
+    assert (np.diag(D) == 0).all() and np.array_equal(D, D.T)
+
+
+def test_best_connection_picks_the_first_shortest_pair():
+    f = [[0, 0], [10, 0], [10, 0]]
+    t = [[20, 0], [13, 4], [13, -4], [7, 4]]          # distance 5 from f[1] to t[1], t[2], t[3] and from f[2] as well
+    assert orc.best_connection(f, t) == (1, 1, 5.0)
+    assert orc.best_connection([], t) == (-1, -1, float('inf'))

@@ -222,6 +222,14 @@ def tier_ga():
         out[f'{tag}_dist'] = dist
         out[f'{tag}_fit'] = fit
     out.update(tier_ga_operators(rng))
+    # MultiVehiclePlanner._build_distance_matrix (MVP:229-259), the matrix the GA consumes: depot + 60 field centroids
+    import multi_vehicle_planner as mvp  # the reference
+    cent = rng.uniform(-2000, 2000, size=(60, 2))
+    depot = (13.5, -7.25)
+    ids = [f'f{i}' for i in range(60)]
+    pl = object.__new__(mvp.MultiVehiclePlanner)
+    out['dm_nodes'] = np.vstack([np.array(depot)[None, :], cent])
+    out['dm_D'] = quiet(pl._build_distance_matrix, ids, {k: {'centroid': tuple(c)} for k, c in zip(ids, cent)}, depot)
     return out
 
 
