@@ -31,6 +31,7 @@ struct DevConst {
     double turn_kappa_last[2];        // curvature at the turn's last sample (its stencil spans the jump to the next swath line)
     double turn_len, turn_time;       // sum of the turn's segment lengths, and that over the nominal turn speed
     double turn_max_kappa[2], turn_max_jump[2];
+    const double2 *field_junc;        // per field: (curvature of the first point of a line that follows a U-turn, length of the jump from the turn's end)
     const double2 *tmpl_u_dk;         // per U-turn sample k: (|t_k - t_(k-1)|, curvature at t_k), the shape's own segment lengths / curvatures
 };
 
@@ -61,7 +62,8 @@ int launch_distance_matrix(hipStream_t st, int n, const double *x, const double 
 int launch_best_connections(hipStream_t st, int64_t n_pairs, const int64_t *fo, const int64_t *to, const double *fx, const double *fy,
                             const double *tx, const double *ty, int32_t *bf, int32_t *bt, double *bd);
 int launch_build_template_metrics(hipStream_t st, int n, const void *tmpl, void *dk);
-int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, const DevField *fields, const DevPrim *prims,
+int launch_field_junctions(hipStream_t st, int64_t n_fields, const DevField *fields, const DevConst &cst, void *junc);
+int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, int kinds, const DevField *fields, const DevPrim *prims,
                       const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
                       TilePartial *partial);
 int launch_quiet_run_stats(hipStream_t st, int64_t n_runs, const DevRun *runs, const DevTile *tiles, const DevField *fields,

@@ -439,6 +439,20 @@ __device__ __forceinline__ double line_start_curvature(const DevField &q, const 
     return curv_chords(dx1, dy1, jump_len, dx2, dy2, seg_len(dx2, dy2));
 }
 
+// per field, once per batch: the junction after a U-turn (all lines of a field are mirror images of each other)
+__global__ void k_field_junctions(int64_t n_fields, const DevField *__restrict__ fields, DevConst cst, double2 *__restrict__ junc)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_fields) return;
+    const DevField &q = fields[i];
+    double2 o = make_double2(0.0, 0.0);
+    if (q.n_total > 0 && q.P >= 2 && q.n_line >= 2 && q.n_turn >= 1) o.x = line_start_curvature(q, cst, 1, o.y);
+    junc[i] = o;
+}
+
+// KINDS: bit k set = chunks of kind k may occur in this instance (1 swath line, 2 headland straight, 3 U-turn, 4 layer-1 span).
+// The kinds are compiled into separate kernels where that saves registers (occupancy of a pure streaming kernel).
+template <int KINDS>
 __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg, const DevPrim *__restrict__ prims,
                                            const DevConst &cst, const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
                                            double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
@@ -460,7 +474,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg
         return out;
     };
     int nout = 0, nobs = 0;
-    if (tl.quiet == 4) {
+    if ((KINDS & 16) && (KINDS == 16 || tl.quiet == 4)) {
         // ---- a span of layer 1 whose passes (swath line + U-turn) are all closed form.  Point i of the span is (pass i / per,
         // offset i % per): a line sample k * step + start (kappa 0; the first point of a line after a turn has the curvature of
         // the jump stencil), or a turn sample = template + translation (mirror), curvature = the shape's own, nominal speeds.
@@ -468,11 +482,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg
         const bool arc = q.turn_model == FCPP_TURN_ARC;
         const double xr = arc ? q.max_x : (q.max_x - q.R), xl = arc ? q.min_x : (q.min_x + q.R);
         const double k_last = cst.turn_kappa_last[q.reverse_order ? 1 : 0];
-        double k_start = 0.0;
-        if (tl.off0 == 0 || tl.off0 + cnt > per) {     // (wave-uniform) the chunk holds the first point of a line
-            double jl;
-            k_start = line_start_curvature(q, cst, tl.idx0 + 1, jl);    // the same for every line of the field (mirror images)
-        }
+        const double k_start = cst.field_junc[tl.field].x;     // the same for every line of the field (mirror images)
         auto sample = [&](int j, double &px, double &py, double &kp, double &v, uint32_t &fw) {
             const unsigned a = (unsigned)(tl.off0 + max(j, 0));
             const unsigned dq = a / (unsigned)per;
@@ -543,7 +553,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg
                 xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = k1; vo[g + 1] = v1; fso[g + 1] = f1;
             }
         }
-    } else     if (tl.quiet == 3) {
+    } else if ((KINDS & 8) && (KINDS == 8 || tl.quiet == 3)) {
         // ---- U-turn in closed form: sample = template + translation (mirror), curvature = the shape's own, nominal turn speed ----
         const int idx = tl.idx0;
         const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
@@ -594,7 +604,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg
             }
             store_pair(has0, has1, g0 + j, px0, px1, py0, py1, k0, k1, cst.v_turn, f0, f1, xo, yo, ko, vo, fso);
         }
-    } else {
+    } else if (KINDS & 6) {
         double ax, ay, sx, sy, bx, by, vnom;      // numpy.linspace(a, b, n): sample k = k * step + a, the last one is b itself
         int n_lin;
         uint32_t fw;
@@ -621,9 +631,8 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg
             if (r == n_lin - 1) { px = bx; py = by; }
         };
         // a line that starts right after a quiet U-turn: its first point's curvature stencil spans the jump from the turn's end
-        double k_start = 0.0;
         const bool has_start = tl.quiet == 1 && tl.off0 == 0 && tl.idx0 > 0;     // wave-uniform
-        if (has_start) { double jl; k_start = line_start_curvature(q, cst, tl.idx0, jl); }
+        const double k_start = has_start ? cst.field_junc[tl.field].x : 0.0;
         // geofence by convexity: both end points inside => the whole segment is inside
         double ex0, ey0, ex1, ey1;
         lin(tl.off0, ex0, ey0);
@@ -690,8 +699,8 @@ __global__ __launch_bounds__(256) void k_quiet_run_stats(int64_t n_runs, const D
         const int per = q.n_line + q.n_turn;
         const double n_pass = (double)(run.count / per), n_jump = n_pass - (tl.idx0 == 0 ? 1.0 : 0.0);
         const double line_len = (double)(q.n_line - 1) * fabs(q.line_step);
-        double jl = 0.0, k0 = 0.0;
-        if (n_jump > 0.0) k0 = line_start_curvature(q, cst, tl.idx0 + 1, jl);
+        const double2 junc = cst.field_junc[tl.field];
+        const double jl = n_jump > 0.0 ? junc.y : 0.0, k0 = n_jump > 0.0 ? junc.x : 0.0;
         tp.main_len = n_pass * (line_len + cst.turn_len) + n_jump * jl;
         tp.main_time_pre = tp.main_time = n_pass * (line_len / fmax(cst.ms_work, 0.1) + cst.turn_time) +
                                           n_jump * (jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1));     // MLP:1305-1309
@@ -720,8 +729,7 @@ __global__ __launch_bounds__(256) void k_quiet_run_stats(int64_t n_runs, const D
         double len = (double)(at_line_start ? run.count - 1 : run.count) * step_len, t = len / fmax(msnom, 0.1);
         if (at_line_start && tl.idx0 > 0) {
             const DevField &q = fields[tl.field];
-            double jl;
-            const double k0 = line_start_curvature(q, cst, tl.idx0, jl);
+            const double k0 = cst.field_junc[tl.field].x, jl = cst.field_junc[tl.field].y;
             len += jl;
             t += jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1);        // MLP:1305-1309: mean of the two end speeds
             tp.max_kappa = k0; tp.max_alat = cst.ms_work * cst.ms_work * k0;
@@ -734,6 +742,7 @@ __global__ __launch_bounds__(256) void k_quiet_run_stats(int64_t n_runs, const D
 }
 
 // the quiet path: one tile per wavefront, four per workgroup; pure HBM streaming at full occupancy
+template <int KINDS>
 __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
                                                       const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                       double *__restrict__ xo,
@@ -742,10 +751,13 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
                                                       TilePartial *__restrict__ partial, int64_t n_chunks)
 {
     __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
-    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one chunk per wavefront
+    // the wave index as a scalar: the chunk and field descriptors are then fetched by scalar loads and live in scalar registers
+    // (as per-lane copies of the same values they cost ~40 vector registers, i.e. one wave per SIMD of occupancy)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t slot = (int64_t)blockIdx.x * 4 + wave;   // one chunk per wavefront
     if (slot >= n_chunks) return;
     const DevTile tl = chunks[slot];
-    quiet_tile(tl, &fields[tl.field], prims, cst, obs, obs_lds[threadIdx.x >> 6], xo, yo, ko, vo, fso, partial);
+    quiet_tile<KINDS>(tl, &fields[tl.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, partial);
 }
 
 // Diagnostic build only (-DFCPP_DIAG_STAMPS, never shipped): phase time stamps of wave 1 replace the tile's metrics.
@@ -1306,6 +1318,14 @@ __global__ void k_build_template_metrics(int n, const double2 *__restrict__ t, d
     dk[k] = o;
 }
 
+int launch_field_junctions(hipStream_t st, int64_t n_fields, const DevField *fields, const DevConst &cst, void *junc)
+{
+    if (n_fields <= 0) return 0;
+    hipLaunchKernelGGL(k_field_junctions, dim3((unsigned)((n_fields + 255) / 256)), dim3(256), 0, st, n_fields, fields, cst, (double2 *)junc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 int launch_build_template_metrics(hipStream_t st, int n, const void *tmpl, void *dk)
 {
     if (n <= 0) return 0;
@@ -1324,13 +1344,17 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, const DevField *fields, const DevPrim *prims,
+// kinds: which chunk kinds the list holds -- 14: straights and U-turns, 16: layer-1 spans
+int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, int kinds, const DevField *fields, const DevPrim *prims,
                       const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
                       TilePartial *partial)
 {
     if (n_chunks <= 0) return 0;
-    hipLaunchKernelGGL(k_plan_quiet, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st, chunks, fields, prims, cst, obs, x, y, kappa,
-                       v, fs, partial, n_chunks);
+    const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
+#define FCPP_QUIET(K) hipLaunchKernelGGL(k_plan_quiet<K>, grid, block, 0, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
+    if (kinds == 16) FCPP_QUIET(16);
+    else FCPP_QUIET(14);
+#undef FCPP_QUIET
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

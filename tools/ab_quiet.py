@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""A/B of k_plan_quiet build / tiling variants on IDENTICAL memory: one process, one set of output arrays, one batch per variant
+(environment variables read at batch creation), timings interleaved.  ab_quiet.py VAR=VALUE [VAR=VALUE ...] compares the
+default against each setting."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from field_coverage_path_planning_amd import engine as E  # noqa: E402
+
+rng = np.random.default_rng(1024)
+LH = rng.uniform(100.0, 1000.0, size=(1024, 2))
+specs = [E.FieldSpec(field_length=float(x), field_width=float(y)) for x, y in LH]
+variants = [('default', None)] + [(a, a.split('=', 1)) for a in sys.argv[1:]]
+batches = {}
+for name, kv in variants:
+    if kv:
+        os.environ[kv[0]] = kv[1]
+    batches[name] = E.Batch(specs, E.make_vehicle(), E.make_options(1, 0.1))
+    if kv:
+        del os.environ[kv[0]]
+bufs = next(iter(batches.values())).alloc(best_of=4)
+res = {n: [] for n in batches}
+for rnd in range(6):
+    for n, b in batches.items():
+        b.run(bufs)
+        torch.cuda.synchronize()
+        b.set_profiling(True)
+        for _ in range(10):
+            b.run(bufs)
+        t, _ = b.stage_times()
+        b.set_profiling(False)
+        res[n].append(t['k_plan_quiet'])
+for n, v in res.items():
+    print(f'{n:28s} k_plan_quiet min {min(v):.3f} median {float(np.median(v)):.3f} ms')
