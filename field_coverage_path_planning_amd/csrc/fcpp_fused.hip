@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void k_quiet_run_stats(int64_t n_runs, const D
 }
 
 // the quiet path: one tile per wavefront, four per workgroup; pure HBM streaming at full occupancy
-template <int KINDS>
+template <int KINDS, bool SCALAR_DESC>
 __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
                                                       const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                       double *__restrict__ xo,
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
     __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
     // the wave index as a scalar: the chunk and field descriptors are then fetched by scalar loads and live in scalar registers
     // (as per-lane copies of the same values they cost ~40 vector registers, i.e. one wave per SIMD of occupancy)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = SCALAR_DESC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
     const int64_t slot = (int64_t)blockIdx.x * 4 + wave;   // one chunk per wavefront
     if (slot >= n_chunks) return;
     const DevTile tl = chunks[slot];
@@ -1351,9 +1351,12 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
 {
     if (n_chunks <= 0) return 0;
     const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
-#define FCPP_QUIET(K) hipLaunchKernelGGL(k_plan_quiet<K>, grid, block, 0, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
-    if (kinds == 16) FCPP_QUIET(16);
-    else FCPP_QUIET(14);
+#define FCPP_QUIET(K, SD) hipLaunchKernelGGL((k_plan_quiet<K, SD>), grid, block, 0, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
+    // Descriptors by scalar loads: 55 instead of 116 vector registers, 7 instead of 4 waves per SIMD.  That nearly halves the time of
+    // the spans (latency-bound: pass decode, short runs) but costs the dense kernel 2-4 % on identical memory (tools/ab_quiet.py:
+    // 5.61 vs 5.49 ms; capping the occupancy below 4 waves costs more: 5.90 ms at 3, 6.70 ms at 2).
+    if (kinds == 16) FCPP_QUIET(16, true);
+    else FCPP_QUIET(14, false);
 #undef FCPP_QUIET
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of k_plan_quiet build / tiling variants on IDENTICAL memory: one process, one set of output arrays, one batch per variant
+"""A/B of k_plan_quiet tuning knobs (environment variables a build may read) on IDENTICAL memory: one process, one set of output arrays, one batch per variant
 (environment variables read at batch creation), timings interleaved.  ab_quiet.py VAR=VALUE [VAR=VALUE ...] compares the
 default against each setting."""
 import os
@@ -14,18 +14,24 @@ from field_coverage_path_planning_amd import engine as E  # noqa: E402
 rng = np.random.default_rng(1024)
 LH = rng.uniform(100.0, 1000.0, size=(1024, 2))
 specs = [E.FieldSpec(field_length=float(x), field_width=float(y)) for x, y in LH]
-variants = [('default', None)] + [(a, a.split('=', 1)) for a in sys.argv[1:]]
-batches = {}
+variants = [('default', None)] + [(a, a.split('=', 1)) for a in sys.argv[1:]]      # "run:VAR=VALUE": set while running, not at creation
+batches, runenv = {}, {}
 for name, kv in variants:
-    if kv:
+    at_run = bool(kv) and kv[0].startswith('run:')
+    if kv and not at_run:
         os.environ[kv[0]] = kv[1]
     batches[name] = E.Batch(specs, E.make_vehicle(), E.make_options(1, 0.1))
-    if kv:
+    if kv and not at_run:
         del os.environ[kv[0]]
+    runenv[name] = (kv[0][4:], kv[1]) if at_run else None
 bufs = next(iter(batches.values())).alloc(best_of=4)
 res = {n: [] for n in batches}
 for rnd in range(6):
     for n, b in batches.items():
+        for k, _ in filter(None, runenv.values()):
+            os.environ.pop(k, None)
+        if runenv[n]:
+            os.environ[runenv[n][0]] = runenv[n][1]
         b.run(bufs)
         torch.cuda.synchronize()
         b.set_profiling(True)
