@@ -61,7 +61,6 @@ struct FusedShared {
         return __hiloint2double((int)hi, (int)lo);
     }
     HaloInfo back, fwd;
-    double efx[FNWAVE], efy[FNWAVE], elx[FNWAVE], ely[FNWAVE];   // first / last point of each wave
     Agg wf[FNWAVE], wb[FNWAVE];
     double ev[FNWAVE], ek[FNWAVE];                                // last item of each wave: final v, kappa
     uint32_t efs[FNWAVE];                                         // ... and its segment word
