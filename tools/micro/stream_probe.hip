@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -77,6 +79,66 @@ float run_multi(double *base, size_t dist, size_t n, int reps)
     return ms / reps;
 }
 
+// runs: the index space is cut into alternating runs of len_a and len_b elements (a swath line and a U-turn); every run is cut into
+// chunks on 512-element boundaries, one chunk per wave -- the first and the last chunk of a run are partial (masked lanes)
+__global__ __launch_bounds__(256) void k_runs(double *base, size_t dist, const long long *chunk_start, const int *chunk_count, size_t n_chunks)
+{
+    const size_t c = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int lane = threadIdx.x & 63;
+    const size_t g0 = (size_t)chunk_start[c];
+    const int cnt = chunk_count[c], odd = (int)(g0 & 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = 2 * (lane + 64 * k) - odd;
+        const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;
+        const size_t idx = g0 + j;
+        const double v = (double)idx;
+        if (has0 && has1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<double2 *>(base + s * dist + idx) = make_double2(v, v + 1.0);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned *>(base + 4 * dist) + idx) = make_uint2((unsigned)idx, 7u);
+        } else if (has0 || has1) {
+            const size_t i1 = has0 ? idx : idx + 1;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) base[s * dist + i1] = v;
+            reinterpret_cast<unsigned *>(base + 4 * dist)[i1] = 7u;
+        }
+    }
+}
+
+float run_runs(double *base, size_t dist, size_t n, size_t len_a, size_t len_b, int reps)
+{
+    std::vector<long long> cs;
+    std::vector<int> cc;
+    size_t pos = 0;
+    for (int r = 0; pos < n; ++r) {
+        const size_t len = std::min(n - pos, (r & 1) ? len_b : len_a);
+        for (size_t done = 0; done < len;) {
+            const size_t g = pos + done, c = std::min(len - done, 512 - (g % 512));
+            cs.push_back((long long)g); cc.push_back((int)c);
+            done += c;
+        }
+        pos += len;
+    }
+    long long *dcs; int *dcc;
+    CHK(hipMalloc(&dcs, cs.size() * 8)); CHK(hipMalloc(&dcc, cc.size() * 4));
+    CHK(hipMemcpy(dcs, cs.data(), cs.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(dcc, cc.data(), cc.size() * 4, hipMemcpyHostToDevice));
+    const size_t nc = cs.size();
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_runs, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, 0, base, dist, dcs, dcc, nc);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_runs, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, 0, base, dist, dcs, dcc, nc);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    CHK(hipFree(dcs)); CHK(hipFree(dcc));
+    return ms / reps;
+}
+
 template <int K8, int K4, int TILE>
 float run(double *base, size_t dist, size_t n, int reps)
 {
@@ -119,6 +181,16 @@ int main(int argc, char **argv)
         return 0;
     }
     const size_t dist = (size_t)(7.6 * GiB) / 4096 * 4096 / 8;   // elements
+    if (argc > 2 && argv[2][0] == 'r') {   // runs with partial chunks at both ends vs one run (all chunks full)
+        for (int rnd = 0; rnd < 2; ++rnd)
+            for (size_t base_gib : { 0, 33 }) {
+                double *base = reinterpret_cast<double *>(slab + base_gib * GiB);
+                printf("base %2zu GiB | one run %.3f ms | runs 5500+398 %.3f ms | runs 1500+398 %.3f ms | runs 20000+398 %.3f ms\n", base_gib,
+                       run_runs(base, dist, n, n, n, 5), run_runs(base, dist, n, 5500, 398, 5), run_runs(base, dist, n, 1500, 398, 5),
+                       run_runs(base, dist, n, 20000, 398, 5));
+            }
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'w') {   // tiles per wave
         for (int rnd = 0; rnd < 2; ++rnd)
             for (size_t base_gib : { 0, 33 }) {
