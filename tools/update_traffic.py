@@ -14,12 +14,16 @@ fields, spacing, turn = (sys.argv[3:6] + ['1024', '0.1', '1'])[:3] if len(sys.ar
 
 
 def collect(path, counter):
+    """mean per launch of every kernel INSTANCE, then the instances of one kernel (k_plan_quiet<14,..> for straights / turns and
+    k_plan_quiet<16,..> for the mixed chunks run once each per step) added up under the kernel's base name"""
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] == counter:
-            name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('fcpp::', '').split('<')[0]
-            agg[name].append(float(r['Counter_Value']))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+            agg[r['Kernel_Name'].split('(')[0].replace('void ', '').replace('fcpp::', '')].append(float(r['Counter_Value']))
+    out = collections.defaultdict(float)
+    for k, v in agg.items():
+        out[k.split('<')[0]] += sum(v) / len(v)
+    return dict(out)
 
 
 w, f = collect(wcsv, 'WRITE_SIZE'), collect(fcsv, 'FETCH_SIZE')
