@@ -63,8 +63,8 @@ def main():
     ap.add_argument('--turn-model', type=int, default=1, help='1 = clothoid (default), 0 = arcs')
     ap.add_argument('--mode', type=int, default=1,
                     help='1 = fused single pass (default), 0 = staged pipeline; 12-14: register-budget variants, see fcpp_batch_run')
-    ap.add_argument('--placement', type=int, default=6,
-                    help='candidate allocations of the output arrays to choose the placement from (1 = take the first)')
+    ap.add_argument('--placement', type=int, default=3,
+                    help='candidate buffers per output array to choose the placement from (1 = take the first)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -85,8 +85,8 @@ def main():
 
     specs, LH = make_specs(E, args.fields, 1024 + rank)
     batch = E.Batch(specs, E.make_vehicle(), E.make_options(args.turn_model, args.spacing), device=local)
-    # output buffers: the fastest of up to --placement candidate allocations (setup, outside the timed region; see Batch.alloc)
-    bufs = batch.alloc(best_of=args.placement, good_gbps=6800.0, mode=args.mode) if args.mode != 0 else batch.alloc()
+    # output buffers: per array the fastest-to-fill of --placement candidate buffers (setup, outside the timed region; see Batch.alloc)
+    bufs = batch.alloc(best_of=args.placement)
     n_points = batch.total_points
     gather_list = None
     if world > 1 and rank == 0:
@@ -160,10 +160,9 @@ def main():
                              'fused single pass: k_plan_quiet (closed-form runs: swath lines, headland straights, U-turns; aligned 512-point chunks) + '
                              'k_plan_fused (all other tiles)'),
                 'quiet_points': q_pts, 'general_points': g_pts,
-                'output_placement': {'candidates_tried': len(getattr(batch, 'placement_ms', [])) or 1,
-                                     'k_plan_quiet_ms_per_candidate': [round(t, 3) for t in getattr(batch, 'placement_ms', [])],
-                                     'note': 'setup only: the output arrays are the fastest of the candidate allocations; the '
-                                             'allocator\'s placement changes the streaming rate (DESIGN.md section 4)'},
+                'output_placement': dict(getattr(batch, 'placement', {}), candidates_per_array=args.placement,
+                                         note='setup only: each output array is the fastest-to-fill of its candidate buffers; where '
+                                              'the allocator places a buffer changes its write rate (DESIGN.md section 4)'),
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

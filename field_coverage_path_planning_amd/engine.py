@@ -181,43 +181,58 @@ class Batch:
         self.info = [info[i] for i in range(self.n_fields)]
         self.total_points = tot.value
 
-    def alloc(self, best_of=1, good_gbps=6300.0, mode=1):
+    def alloc(self, best_of=1):
         """Output buffers (x, y, kappa, v, flagseg, stats) for run().
 
-        best_of > 1: placement calibration.  Where the allocator puts the five arrays in device memory changes what the
-        streaming kernel reaches (measured 5.1-6.9 ms on the same workload), and the draw is per
-        allocation.  Up to `best_of` candidate sets are allocated side by side, each is timed with two runs of the pipeline,
-        the search stops at the first set whose streaming kernel reaches `good_gbps`; the fastest set is kept, the others are
-        released.  The timings are left in `self.placement_ms` (ms of k_plan_quiet per candidate)."""
+        best_of > 1: placement calibration.  Where the allocator puts an array in device memory changes the rate at which it
+        can be written (a single-stream fill of the same 8 GB differs by ~5 % between buffers; five such streams written
+        together, as k_plan_quiet does, by up to 30 %: 5.2 vs 6.8 ms on the bench workload), and it is a
+        property of the buffer, not of the kernel.  `best_of` candidate buffers per output array are allocated side by side, each
+        is timed with a plain device fill, the fastest ones are kept and the others released.  The timings are left in
+        `self.placement` ({'fill_ms': per candidate, 'chosen': indices})."""
         if best_of <= 1 or self.total_points == 0:
             return self._alloc_once()
         torch = _torch()
-        q_pts, _ = self.point_split()
-        cands, times = [], []
-        for _ in range(int(best_of)):
-            try:
-                bufs = self._alloc_once()
-            except RuntimeError:          # out of device memory: choose among what we have
-                break
-            self.run(bufs, mode=mode)
-            torch.cuda.synchronize(self.ctx.device)
-            self.set_profiling(True)
-            for _ in range(2):
-                self.run(bufs, mode=mode)
-            st, _ = self.stage_times()
-            self.set_profiling(False)
-            ms = st.get('k_plan_quiet', sum(st.values()))
-            cands.append(bufs)
-            times.append(ms)
-            if ms > 0 and 36.0 * q_pts / (ms * 1e-3) / 1e9 >= good_gbps:
-                break
-        if not cands:
+        dev = torch.device('cuda', self.ctx.device)
+        n = self.total_points
+
+        def fill_ms(t):
+            t.fill_(0)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                t.fill_(0)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / 3
+
+        def candidates(count, dtype):
+            out = []
+            for _ in range(count):
+                try:
+                    out.append(torch.empty(n, dtype=dtype, device=dev))
+                except RuntimeError:          # out of device memory: choose among what we have
+                    break
+            return out
+
+        f64 = candidates(4 * int(best_of), torch.float64)
+        i32 = candidates(int(best_of), torch.int32)
+        if len(f64) < 4 or not i32:
+            del f64, i32
+            torch.cuda.empty_cache()
             return self._alloc_once()
-        self.placement_ms = times
-        best = cands[min(range(len(cands)), key=lambda i: times[i])]
-        del cands, bufs
+        t64, t32 = [fill_ms(t) for t in f64], [fill_ms(t) for t in i32]
+        pick = sorted(sorted(range(len(f64)), key=lambda k: t64[k])[:4])
+        pick_fs = min(range(len(i32)), key=lambda k: t32[k])
+        self.placement = {'fill_ms_f64': [round(v, 3) for v in t64], 'chosen_f64': pick,
+                          'fill_ms_i32': [round(v, 3) for v in t32], 'chosen_i32': pick_fs}
+        x, y, kappa, v = (f64[k] for k in pick)
+        fs = i32[pick_fs]
+        del f64, i32
         torch.cuda.empty_cache()
-        return best
+        stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
+        return x, y, kappa, v, fs, stats
 
     def _alloc_once(self):
         torch = _torch()

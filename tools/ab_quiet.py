@@ -24,7 +24,7 @@ for name, kv in variants:
     if kv and not at_run:
         del os.environ[kv[0]]
     runenv[name] = (kv[0][4:], kv[1]) if at_run else None
-bufs = next(iter(batches.values())).alloc(best_of=4)
+bufs = next(iter(batches.values())).alloc(best_of=3)
 res = {n: [] for n in batches}
 for rnd in range(6):
     for n, b in batches.items():
