@@ -449,3 +449,18 @@ def test_standalone_operators_on_ragged_paths():
         E.speed_plan(xy[:, 0], xy[:, 1], v, _veh(DEFAULT_VP), offsets=[0, 5, 3, offs[-1]])     # decreasing offsets
     d, f = E.ga_fitness(np.zeros((3, 1), dtype=np.int32), np.zeros((1, 1)))
     assert _np(d).tolist() == [0.0, 0.0, 0.0] and np.allclose(_np(f), 1e6)
+
+
+def test_placement_calibrated_buffers_give_the_same_plan():
+    """Batch.alloc(best_of=K) only chooses WHICH buffers receive the output (fill probe)."""
+    specs, _ = _random_fields(5, 6)
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(1, 0.2))
+    r0 = b.run()
+    keep = [t.clone() for t in (r0.x, r0.y, r0.kappa, r0.v, r0.flagseg, r0.stats_raw)]
+    bufs = b.alloc(best_of=3)
+    p = b.placement
+    assert len(p['fill_ms_f64']) == 12 and len(p['chosen_f64']) == 4 and len(p['fill_ms_i32']) == 3
+    r1 = b.run(bufs)
+    for a, c in zip(keep, (r1.x, r1.y, r1.kappa, r1.v, r1.flagseg, r1.stats_raw)):
+        assert bool((a == c).all())
+    b.close()
