@@ -50,8 +50,12 @@ struct NomTable { double v[8], ms[8]; };
 __device__ __forceinline__ double nom_v(const NomTable &t, uint32_t fs) { return t.v[fs & FCPP_KIND_MASK]; }
 __device__ __forceinline__ double nom_ms(const NomTable &t, uint32_t fs) { return t.ms[fs & FCPP_KIND_MASK]; }
 
+static constexpr int FPRIM_CAP = 48;     // headland primitives of one field staged in LDS (a field has <= 40)
+static_assert(sizeof(DevPrim) % 4 == 0, "DevPrim staging");
+
 struct FusedShared {
     FieldWords fw;       // the tile's field descriptor, staged by ONE coalesced load
+    uint32_t prims[FPRIM_CAP * sizeof(DevPrim) / 4];     // the field's headland primitives (tiles that touch layer 2)
     NomTable nom;
     double cd[6];        // a_lat, a_lon, sf, geofence_tol, u_cap, inv_sf36
     // double number q of the staged descriptor, as a wave-uniform (scalar) value
@@ -177,7 +181,14 @@ __device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst,
     }
 }
 
-__device__ __forceinline__ int find_prim(const DevField &f, const DevPrim *__restrict__ prims, int64_t i)
+// the batch's primitive table, or a field's primitives staged in LDS: indexed by the batch-wide primitive index either way
+struct PrimTable {
+    const DevPrim *p;
+    int first;
+    __device__ __forceinline__ const DevPrim &operator[](int i) const { return p[i - first]; }
+};
+
+__device__ __forceinline__ int find_prim(const DevField &f, const PrimTable prims, int64_t i)
 {
     int a = f.prim_first, b = f.prim_first + f.prim_count - 1;
     while (a < b) {
@@ -188,7 +199,7 @@ __device__ __forceinline__ int find_prim(const DevField &f, const DevPrim *__res
 }
 
 // random access (halo recomputation only): point i of the field's path
-__device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const DevPrim *prims, const DevConst *cst, int64_t i)
+__device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const PrimTable prims, const DevConst *cst, int64_t i)
 {
     GenOut o;
     o.v = 0;
@@ -206,7 +217,7 @@ __device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const DevPrim *
 
 // One wave computes what the sweeps carry across the tile edge (see the header comment).
 template <bool BACK>
-__device__ void halo_wave(const DevField &f, const DevField *fg, const DevPrim *__restrict__ prims, const DevConst &cst, const NomTable &nom,
+__device__ void halo_wave(const DevField &f, const DevField *fg, const PrimTable prims, const DevConst &cst, const NomTable &nom,
                           const DevTile &tl, int64_t edge, HaloInfo *out)
 {
     const int lane = threadIdx.x & 63;
@@ -778,7 +789,7 @@ __device__ __forceinline__ double uniform_d(const double *lds)
 template <int MINW>
 __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__restrict__ tiles,
                                                             const DevField *__restrict__ fields,
-                                                            const DevPrim *__restrict__ prims, DevConst cst_arg, DevObstacles obs,
+                                                            const DevPrim *__restrict__ prims_g, DevConst cst_arg, DevObstacles obs,
                                                             double *__restrict__ xo, double *__restrict__ yo,
                                                             double *__restrict__ ko, double *__restrict__ vo,
                                                             uint32_t *__restrict__ fso, TilePartial *__restrict__ partial,
@@ -816,6 +827,16 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     const int64_t n = f.n_total, s = tl.start;
     const int cnt = tl.count;
     const double two_a = 2 * cst.a_lon;
+    // A tile that reaches layer 2 looks primitives up all the time (binary searches in the halos and at the lane starts, one
+    // record per generated item): from global memory every one of those is a dependent ~1 us round trip.  The field's few
+    // primitives are staged in LDS once, by one coalesced load; `prims` is indexed by the batch-wide primitive index either way.
+    PrimTable prims = { prims_g, 0 };
+    if (s + cnt >= f.n_main && f.prim_count <= FPRIM_CAP) {     // (block-uniform)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(prims_g + f.prim_first);
+        for (int q = tid; q < f.prim_count * (int)(sizeof(DevPrim) / 4); q += FBLOCK) S.prims[q] = src[q];
+        __syncthreads();
+        prims = { reinterpret_cast<const DevPrim *>(S.prims), f.prim_first };
+    }
 
     FCPP_STAMP(10);
     halo_wave<true>(f, fg, prims, cst, nom, tl, s, &S.back);          // one wave per tile: it computes both carries itself

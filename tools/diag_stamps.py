@@ -14,7 +14,11 @@ from field_coverage_path_planning_amd import engine as E  # noqa: E402
 rng = np.random.default_rng(1024)
 LH = rng.uniform(100.0, 1000.0, size=(1024, 2))
 specs = [E.FieldSpec(field_length=float(x), field_width=float(y)) for x, y in LH]
-b = E.Batch(specs, E.make_vehicle(), E.make_options(1, 0.1))
+sparse = os.environ.get('FCPP_DIAG_SPARSE')          # the reference's sampling: every general tile is a headland
+if sparse:
+    LH = rng.uniform(100.0, 1000.0, size=(16384, 2))
+    specs = [E.FieldSpec(field_length=float(x), field_width=float(y)) for x, y in LH]
+b = E.Batch(specs, E.make_vehicle(), E.make_options() if sparse else E.make_options(1, 0.1))
 bufs = b.alloc()
 for _ in range(2):
     res = b.run(bufs, mode=int(os.environ.get('FCPP_MODE', '1')))
