@@ -296,14 +296,14 @@ __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ 
 // one wave per path: lanes stride over the path's tiles in a fixed assignment, then a fixed butterfly
 // ids (optional): the reduction runs over partial[ids[k]], k in [tile_first[p], tile_first[p+1]) -- the fused pipeline lists only the
 // tiles that can hold statistics (general tiles and the first tile of every quiet run; the others stay zero)
-__global__ __launch_bounds__(64) void k_reduce_stats(int64_t n_paths, const int64_t *__restrict__ tile_first,
+__global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_paths, const int64_t *__restrict__ tile_first,
                                                      const TilePartial *__restrict__ partial,
                                                      const unsigned long long *__restrict__ n_adjusted,
                                                      fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids)
 {
-    const int64_t pth = blockIdx.x;
+    const int64_t pth = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wavefront per path, four per workgroup
     if (pth >= n_paths) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     double a[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long b[4] = { 0, 0, 0, 0 };
     for (int64_t t = tile_first[pth] + lane; t < tile_first[pth + 1]; t += 64) {
@@ -507,7 +507,7 @@ int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *part
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids)
 {
     if (n_paths <= 0) return 0;
-    hipLaunchKernelGGL(k_reduce_stats, dim3((unsigned)n_paths), dim3(64), 0, st, n_paths, tile_first, partial,
+    hipLaunchKernelGGL(k_reduce_stats, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, n_paths, tile_first, partial,
                        n_adjusted, stats, ids);
     FCPP_LAUNCH_CHECK();
     return 0;
