@@ -341,10 +341,12 @@ def test_sharded_api_single_rank_matches_batch():
     b.close()
 
 
-def test_results_do_not_depend_on_batch_composition():
-    """A field planned alone or inside a batch (= on another rank of a sharded job) gives bit-identical arrays."""
+@pytest.mark.parametrize('opt', [dict(turn_model=1, sample_spacing=0.2), dict(), dict(sample_spacing=0.1)])
+def test_results_do_not_depend_on_batch_composition(opt):
+    """A field planned alone or inside a batch (= on another rank of a sharded job) gives bit-identical arrays and statistics:
+    the chunks of the quiet runs follow the position in the batch arrays, their results must not (dense runs, mixed chunks, spans)."""
     specs, _ = _random_fields(21, 5, para=True)
-    o = E.make_options(1, 0.2)
+    o = E.make_options(**opt)
     b = E.Batch(specs, _veh(DEFAULT_VP), o)
     r = b.run()
     for i in (0, 3):
