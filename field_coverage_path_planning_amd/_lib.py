@@ -121,6 +121,7 @@ PROTOTYPES = [
                                   _VP, _VP]),
     ('fcpp_verify', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     ('fcpp_straight_segments', C.c_int, [_VP, C.c_int64, _VP, C.c_int32, _VP]),
+    ('fcpp_corner_turns', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, _VP, _VP, C.c_double, C.c_double, C.c_int32, _VP, _VP]),
     ('fcpp_fresnel', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
     ('fcpp_ga_fitness', C.c_int, [_VP, C.c_int32, C.c_int64, _VP, _VP, _VP, _VP, C.c_int]),
     ('fcpp_distance_matrix', C.c_int, [_VP, C.c_int32, _VP, _VP, _VP]),

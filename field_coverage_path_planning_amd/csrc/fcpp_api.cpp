@@ -450,6 +450,7 @@ int fcpp_malloc(fcpp_ctx *c, int64_t bytes, void **p)
 int fcpp_free(fcpp_ctx *c, void *p)
 {
     if (!c) return fail(FCPP_EINVAL, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
     if (p) HIPCHK(hipFree(p));
     return FCPP_OK;
 }
@@ -501,6 +502,13 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     if (rc != FCPP_OK) { delete b; return fail(rc, err); }
     // obstacle references must stay inside the polygon table
     const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
+    if (n_polys < 0 || n_polys > INT32_MAX) { delete b; return fail(FCPP_ESIZE, "bad polygon count"); }
+    if (n_polys > 0) {      // CSR table: offsets[0] = 0, non-decreasing, coordinates present
+        if (!obstacles->offsets || obstacles->offsets[0] != 0) { delete b; return fail(FCPP_ESIZE, "polygon offsets must start at 0"); }
+        for (int64_t k = 0; k < n_polys; ++k)
+            if (obstacles->offsets[k + 1] < obstacles->offsets[k]) { delete b; return fail(FCPP_ESIZE, "polygon offsets must be non-decreasing"); }
+        if (obstacles->offsets[n_polys] > 0 && (!obstacles->x || !obstacles->y)) { delete b; return fail(FCPP_EINVAL, "polygon coordinates are NULL"); }
+    }
     for (int64_t i = 0; i < n_fields; ++i) {
         if (fields[i].n_obstacles < 0 || fields[i].obstacle_first < 0 ||
             (fields[i].n_obstacles > 0 && fields[i].obstacle_first + fields[i].n_obstacles > n_polys)) {
@@ -829,6 +837,19 @@ int fcpp_straight_segments(fcpp_ctx *c, int64_t n_seg, const double *seg, int32_
     return FCPP_OK;
 }
 
+int fcpp_corner_turns(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n, const double *corners, const int32_t *ci, const int32_t *rev,
+                      double L, double H, int32_t stride, double *out, int32_t *counts)
+{
+    if (!c || !veh || n < 0 || (n > 0 && (!corners || !ci || !rev || !out || !counts))) return fail(FCPP_EINVAL, "bad arguments");
+    const double R = veh->min_turn_radius;
+    if (!(R > 0)) return fail(FCPP_EINVAL, "min_turn_radius must be positive");
+    const int64_t need = 15 + std::max<int64_t>(10, (int64_t)(3.0 * R / 0.5));
+    if (stride < need) return fail(FCPP_ESIZE, "stride too small for 15 + max(10, int(3R / 0.5)) points");
+    HIPCHK(hipSetDevice(c->device));
+    LAUNCHCHK(launch_corner_turns(c->stream, n, corners, ci, rev, R, L, H, stride, out, counts));
+    return FCPP_OK;
+}
+
 int fcpp_fresnel(fcpp_ctx *c, int64_t n, const double *t, double *cc, double *ss)
 {
     if (!c || n < 0 || (n > 0 && (!t || !cc || !ss))) return fail(FCPP_EINVAL, "bad arguments");
@@ -873,6 +894,16 @@ int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const doub
     HIPCHK(fd.alloc((size_t)pop * 4));
     HIPCHK(state.alloc(1));
     HIPCHK(hipMemsetAsync(state.p, 0, sizeof(GaState), st));
+    {   // the initial population must consist of permutations: the kernels index D and their LDS marks by gene
+        DevBuf<int32_t> bad;
+        int32_t hb = 0;
+        HIPCHK(bad.alloc(1));
+        HIPCHK(hipMemsetAsync(bad.p, 0, sizeof(int32_t), st));
+        LAUNCHCHK(launch_ga_check_perm(st, n, pop, routes, bad.p));
+        HIPCHK(hipMemcpyAsync(&hb, bad.p, sizeof hb, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hb) return fail(FCPP_EINVAL, "routes must hold permutations of 0 .. n_nodes-1");
+    }
     int32_t *buf[2] = { routes, scratch.p };
     double *fit[2] = { fd.p, fd.p + 2 * (size_t)pop }, *dist[2] = { fd.p + pop, fd.p + 3 * (size_t)pop };
     LAUNCHCHK(launch_ga_fitness(st, n, pop, D, routes, dist[0], fit[0], 0));                       // GA:64

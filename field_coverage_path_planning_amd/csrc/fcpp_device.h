@@ -69,6 +69,8 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
 int launch_quiet_run_stats(hipStream_t st, int64_t n_runs, const DevRun *runs, const DevTile *tiles, const DevField *fields,
                            const DevPrim *prims, const DevConst &cst, TilePartial *partial);
 int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts, const int32_t *mask, double *out);
+int launch_corner_turns(hipStream_t st, int64_t n, const double *corners, const int32_t *ci, const int32_t *rev, double R, double L,
+                        double H, int stride, double *out, int32_t *counts);
 int launch_fresnel(hipStream_t st, int64_t n, const double *t, double *c, double *s);
 int launch_ga_fitness(hipStream_t st, int n, int64_t pop, const double *D, const int32_t *routes, double *dist,
                       double *fit, int order_mode);

@@ -17,6 +17,7 @@ struct GaState {
 
 constexpr int GA_MAX_NODES = 2048;
 
+int launch_ga_check_perm(hipStream_t st, int n, int pop, const int32_t *routes, int32_t *bad);   // *bad |= 1 unless every row is a permutation
 int launch_ga_pairs(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, int32_t *nxt,
                     double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, const GaState *state);
 // stats of the population `cur` (generation gen, -1 = the initial one), then the elites of `cur` into the tail of `nxt`

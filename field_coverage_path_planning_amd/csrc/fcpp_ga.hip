@@ -260,6 +260,39 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
     }
 }
 
+// precondition of fcpp_ga_evolve: every row of `routes` is a permutation of 0 .. n-1.  One wavefront per chromosome marks its genes
+// in LDS; a gene out of range or seen twice raises the flag.
+__global__ __launch_bounds__(64) void k_ga_check_perm(int n, int pop, const int32_t *__restrict__ routes, int32_t *__restrict__ bad)
+{
+    __shared__ unsigned char seen[GA_MAX_NODES];
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= pop) return;
+    for (int g = lane; g < n; g += 64) seen[g] = 0;
+    wsync();
+    bool wrong = false;
+    for (int k0 = 0; k0 < n; k0 += 64) {       // 64 genes at a time: duplicates inside one batch are caught by the count below
+        const int k = k0 + lane;
+        if (k < n) {
+            const int32_t g = routes[(int64_t)ch * n + k];
+            if ((unsigned)g >= (unsigned)n) wrong = true;
+            else seen[g] = 1;
+        }
+    }
+    wsync();
+    int cnt = 0;
+    for (int g = lane; g < n; g += 64) cnt += seen[g];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (__ballot(wrong) != 0ull || cnt != n) { if (lane == 0) atomicOr(bad, 1); }
+}
+
+int launch_ga_check_perm(hipStream_t st, int n, int pop, const int32_t *routes, int32_t *bad)
+{
+    hipLaunchKernelGGL(k_ga_check_perm, dim3((unsigned)pop), dim3(64), 0, st, n, pop, routes, bad);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 int launch_ga_pairs(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, int32_t *nxt,
                     double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, const GaState *state)
 {

@@ -350,6 +350,49 @@ __global__ void k_straight(int64_t n_seg, const double *__restrict__ seg, int n_
     out[2 * g + 1] = linspace_at(y0, y1, sy, n_pts, k);
 }
 
+// corner turns as a standalone operator (MLP:1580-1608, 1024-1084, 1154-1288): one thread per (corner, sample slot)
+__global__ void k_corner_turns(int64_t n, const double *__restrict__ corners, const int32_t *__restrict__ ci_arr,
+                               const int32_t *__restrict__ rev_arr, double R, double L, double H, int stride,
+                               double *__restrict__ out, int32_t *__restrict__ counts)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * stride) return;
+    const int64_t c = g / stride;
+    const int s = (int)(g - c * stride);
+    const double cx = corners[2 * c], cy = corners[2 * c + 1];
+    const int ci = (ci_arr[c] >= 0 && ci_arr[c] <= 2) ? ci_arr[c] : 3;
+    constexpr int NT = 15;
+    const double step = kHalfPi / (double)(NT - 1);
+    auto arc = [&](int k, double &x, double &y) {
+        double sn, cs;
+        sincos(linspace_at(0.0, kHalfPi, step, NT, k), &sn, &cs);
+        corner_arc_point(ci, cx, cy, R, cs, sn, x, y);
+    };
+    int n_rev = 0;
+    double e1x = 0, e1y = 0, dx = -1.0, dy = 0.0, len = 0;
+    if (rev_arr[c]) {
+        double e2x, e2y;
+        arc(NT - 1, e1x, e1y); arc(NT - 2, e2x, e2y);
+        const double tx = e1x - e2x, ty = e1y - e2y, nrm = sqrt(tx * tx + ty * ty);     // MLP:1188-1193
+        if (nrm > 1e-6) { dx = -tx / nrm; dy = -ty / nrm; }
+        double best = 0; bool have = false;                                               // MLP:1241-1281
+        auto take = [&](double t) { if (t > 0 && (!have || t < best)) { best = t; have = true; } };
+        if (fabs(dx) > 1e-6) { take((0 - e1x) / dx); take((L - e1x) / dx); }
+        if (fabs(dy) > 1e-6) { take((0 - e1y) / dy); take((H - e1y) / dy); }
+        len = have ? fmin(best, 3.0 * R) : 2.0 * R;
+        n_rev = max(10, (int)(len / 0.5));                                                // MLP:1214
+        if (NT + n_rev > stride) n_rev = stride - NT;
+    }
+    if (s == 0) { counts[2 * c] = NT; counts[2 * c + 1] = n_rev; }
+    double x, y;
+    if (s < NT) arc(s, x, y);
+    else if (s - NT < n_rev) {
+        const double t = linspace_at(0.0, len, n_rev > 1 ? len / (double)(n_rev - 1) : 0.0, n_rev, s - NT);
+        x = e1x + t * dx; y = e1y + t * dy;                                               // MLP:1215-1216
+    } else return;
+    out[2 * g] = x; out[2 * g + 1] = y;
+}
+
 __global__ void k_fresnel(int64_t n, const double *__restrict__ t, double *__restrict__ c, double *__restrict__ s)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -376,7 +419,7 @@ __global__ __launch_bounds__(BLOCK) void k_ga_fitness(int n, int64_t pop, const 
             double d = 0.0;
             if (k < n) {
                 const int a = r[k], b = r[k + 1 == n ? 0 : k + 1];
-                d = D[(int64_t)a * n + b];
+                d = ((unsigned)a < (unsigned)n && (unsigned)b < (unsigned)n) ? D[(int64_t)a * n + b] : __builtin_nan("");   // precondition, include/fcpp.h
             }
             const int m = min(64, n - base);
             for (int l = 0; l < m; ++l) total += __shfl(d, l);
@@ -384,7 +427,7 @@ __global__ __launch_bounds__(BLOCK) void k_ga_fitness(int n, int64_t pop, const 
     } else {
         for (int k = lane; k < n; k += 64) {
             const int a = r[k], b = r[k + 1 == n ? 0 : k + 1];
-            total += D[(int64_t)a * n + b];
+            total += ((unsigned)a < (unsigned)n && (unsigned)b < (unsigned)n) ? D[(int64_t)a * n + b] : __builtin_nan("");
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
@@ -537,6 +580,17 @@ int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts,
     hipLaunchKernelGGL(k_straight, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n_seg, seg, n_pts, mask, out);
     FCPP_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_corner_turns(hipStream_t st, int64_t n, const double *corners, const int32_t *ci, const int32_t *rev, double R, double L,
+                        double H, int stride, double *out, int32_t *counts)
+{
+    if (n <= 0) return 0;
+    const int64_t total = n * stride;
+    hipLaunchKernelGGL(k_corner_turns, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, n, corners, ci, rev, R, L, H, stride, out,
+                       counts);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 int launch_fresnel(hipStream_t st, int64_t n, const double *t, double *c, double *s)

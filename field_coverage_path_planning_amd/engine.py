@@ -246,10 +246,30 @@ class Batch:
         stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
         return x, y, kappa, v, fs, stats
 
+    def _check_buffers(self, buffers):
+        """The library writes total_points elements into each array without looking at it again: sizes, types, device and layout
+        are checked here (a short buffer would be an out-of-bounds device write)."""
+        torch = _torch()
+        x, y, kappa, v, fs, stats = buffers
+        want = [('x', x, torch.float64, self.total_points), ('y', y, torch.float64, self.total_points),
+                ('kappa', kappa, torch.float64, self.total_points), ('v', v, torch.float64, self.total_points),
+                ('flagseg', fs, None, self.total_points), ('stats', stats, torch.int64, self.n_fields * L.STATS_WORDS)]
+        for name, t, dtype, numel in want:
+            if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device.index != self.ctx.device:
+                raise ValueError(f'{name}: expected a tensor on cuda:{self.ctx.device}')
+            if dtype is None:
+                if t.dtype not in (torch.int32, torch.uint32):
+                    raise ValueError(f'{name}: expected int32 / uint32, got {t.dtype}')
+            elif t.dtype != dtype:
+                raise ValueError(f'{name}: expected {dtype}, got {t.dtype}')
+            if t.numel() < numel or not t.is_contiguous():
+                raise ValueError(f'{name}: needs {numel} contiguous elements, got {t.numel()}')
+
     def run(self, buffers=None, mode=1):
         """Enqueue the hot path on torch's current stream; returns a BatchResult (asynchronous)."""
         if buffers is None:
             buffers = self.alloc()
+        self._check_buffers(buffers)
         x, y, kappa, v, fs, stats = buffers
         self._last_mode = 1 if int(mode) >= 1 else 0
         self.ctx.bind_stream()
@@ -371,6 +391,31 @@ def straight_segments(segs, n_points, device=None):
     ctx.bind_stream()
     L.check(ctx.lib.fcpp_straight_segments(ctx.handle, segs.shape[0], _ptr(segs), int(n_points), _ptr(out)))
     return out
+
+
+def corner_turns(corners, corner_index, with_reverse, vehicle, field_length, field_width, device=None):
+    """Corner turns as a batch (fcpp_corner_turns; MLP:1580-1608 and 1024-1084 / 1154-1288): for every corner the 15-point
+    quarter arc and, where with_reverse is set, the tangent reverse fill toward the box [0, L] x [0, H].
+    -> list of (turn (15, 2), reverse (n, 2) or None) numpy arrays."""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    c = _dev_f64(corners, dev).reshape(-1, 2)
+    n = int(c.shape[0])
+    ci = torch.as_tensor(np.ascontiguousarray(corner_index, dtype=np.int32), device=dev)
+    rv = torch.as_tensor(np.ascontiguousarray(with_reverse, dtype=np.int32), device=dev)
+    stride = 15 + max(10, int(3.0 * vehicle.min_turn_radius / 0.5))
+    out = torch.empty((n, stride, 2), dtype=torch.float64, device=dev)
+    counts = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_corner_turns(ctx.handle, C.byref(vehicle), n, _ptr(c), _ptr(ci), _ptr(rv), float(field_length),
+                                      float(field_width), stride, _ptr(out), _ptr(counts)))
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    res = []
+    for k in range(n):
+        nt, nr = int(counts[k, 0]), int(counts[k, 1])
+        res.append((out[k, :nt].copy(), out[k, nt:nt + nr].copy() if nr else None))
+    return res
 
 
 def fresnel(t, device=None):

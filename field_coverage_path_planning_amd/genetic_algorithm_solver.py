@@ -88,70 +88,3 @@ class GeneticAlgorithmSolver:
             j = int(np.where(row == i % num_nodes)[0][0])
             row[0], row[j] = row[j], row[0]
         return pop
-
-    # ---- the operators as vectorised host functions (same semantics as the device kernels; kept for callers that drive their
-    # own loop).  solve() does not use them.
-    # GA:183-196 tournament selection
-    def _selection(self, pop, fit):
-        m = len(pop)
-        k = min(self.config.tournament_size, m)
-        # `k` distinct contestants per slot: rank random keys
-        cand = np.argsort(self._rng.random((m, m)), axis=1)[:, :k] if m <= 512 else \
-            np.stack([self._rng.choice(m, size=k, replace=False) for _ in range(m)])
-        win = cand[np.arange(m), np.argmax(fit[cand], axis=1)]
-        return pop[win].copy()
-
-    # GA:198-242 order crossover (OX) on consecutive pairs
-    def _crossover(self, sel):
-        m, n = sel.shape
-        p1 = sel[0::2]
-        p2 = sel[1::2] if m % 2 == 0 else np.vstack([sel[1::2], sel[:1]])
-        pairs = len(p1)
-        cuts = np.sort(np.argsort(self._rng.random((pairs, n)), axis=1)[:, :2], axis=1)   # two distinct cut points
-        do = self._rng.random(pairs) < self.config.crossover_rate
-        c1 = self._ox(p1, p2, cuts)
-        c2 = self._ox(p2, p1, cuts)
-        c1[~do], c2[~do] = p1[~do], p2[~do]
-        out = np.empty((2 * pairs, n), dtype=sel.dtype)
-        out[0::2], out[1::2] = c1, c2
-        return out
-
-    @staticmethod
-    def _ox(keep, fill, cuts):
-        """child[a:b] = keep[a:b]; the other positions, starting at b and wrapping, take fill's genes in the order they
-        appear from position b on, skipping genes already present (GA:225-237)."""
-        pairs, n = keep.shape
-        a, b = cuts[:, :1], cuts[:, 1:]
-        pos = np.arange(n)[None, :]
-        in_seg = (pos >= a) & (pos < b)
-        present = np.zeros((pairs, n), dtype=bool)
-        rows = np.repeat(np.arange(pairs), n).reshape(pairs, n)
-        present[rows[in_seg], keep[in_seg]] = True
-        order = (pos + b) % n                                  # positions b, b+1, ..., wrapping
-        donor = np.take_along_axis(fill, order, axis=1)        # fill's genes from b on
-        free = ~np.take_along_axis(present, donor, axis=1)     # ... that the child does not have yet
-        # stable partition: free genes first, in order
-        idx = np.argsort(~free, axis=1, kind='stable')
-        donor_sorted = np.take_along_axis(donor, idx, axis=1)
-        child = keep.copy()
-        n_free = n - (b - a)                                   # per pair
-        slot = np.arange(n)[None, :]
-        use = slot < n_free
-        tgt = np.take_along_axis(order, slot % n, axis=1)      # target positions b, b+1, ... (the segment comes last)
-        child[rows[use], tgt[use]] = donor_sorted[use]
-        return child
-
-    # GA:244-252 swap mutation
-    def _mutation(self, pop):
-        m, n = pop.shape
-        hit = np.where(self._rng.random(m) < self.config.mutation_rate)[0]
-        for r in hit:
-            i, j = self._rng.choice(n, size=2, replace=False)
-            pop[r, i], pop[r, j] = pop[r, j], pop[r, i]
-        return pop
-
-    # GA:254-268 elitism
-    def _elitism(self, old_pop, new_pop, old_fit):
-        e = self.config.elite_size
-        elite = np.argsort(old_fit)[-e:]
-        return np.vstack([new_pop[:-e], old_pop[elite]]) if e > 0 else new_pop

@@ -319,29 +319,16 @@ class TwoLayerPathPlannerV37:
             area = QuadPolygon(list(area.exterior.coords)[:4])
         return self._coverage_rate_dev(np.ascontiguousarray(path[:, 0]), np.ascontiguousarray(path[:, 1]), area)
 
+    def _corner_turns(self, corners, with_reverse):
+        """[(turn (15, 2), reverse (n, 2) | None)] for (corner, corner_index) pairs: fcpp_corner_turns, the library's own
+        generator of MLP:1580-1608 / 1024-1084 / 1154-1288 (no host restatement)."""
+        return E.corner_turns([c for c, _ in corners], [ci for _, ci in corners], with_reverse, self._veh,
+                              self.field_length, self.field_width, device=self._device)
+
     def _generate_corner_turn_arc(self, corner, corner_index: int):
         """15-point quarter arc of radius R leaving `corner` (MLP:1580-1608; quadrant formulas MLP:1049-1060)."""
-        R = self.vehicle.min_turn_radius
-        th = np.linspace(0, np.pi / 2, 15)
-        t1, t2 = R * (1 - np.cos(th)), R * np.sin(th)
-        x, y = corner
-        ax, ay = [(x + t1, y + t2), (x - t2, y + t1), (x - t1, y - t2), (x + t2, y - t1)][corner_index if corner_index in (0, 1, 2) else 3]
-        return np.column_stack([ax, ay]), [self.vehicle.headland_turn_speed_kmh] * 15
-
-    def _corner_reverse_path(self, turn: np.ndarray):
-        """Reverse fill after a corner turn (MLP:1154-1288): back up along the end tangent until the nearest side of the
-        [0, L] x [0, H] box, at most 3R (2R if no side lies ahead); max(10, int(len / 0.5)) points."""
-        R = self.vehicle.min_turn_radius
-        end, tang = turn[-1], turn[-1] - turn[-2]
-        nrm = float(np.linalg.norm(tang))
-        d = -tang / nrm if nrm > 1e-6 else np.array([-1.0, 0.0])
-        hits = []
-        for p, dp, lo, hi in ((end[0], d[0], 0.0, self.field_length), (end[1], d[1], 0.0, self.field_width)):
-            if abs(dp) > 1e-6:
-                hits += [t for t in ((lo - p) / dp, (hi - p) / dp) if t > 0]
-        length = min(min(hits), 3.0 * R) if hits else 2.0 * R
-        t = np.linspace(0, length, max(10, int(length / 0.5)))
-        return end + t[:, None] * d, length
+        turn, _ = self._corner_turns([(corner, corner_index)], [0])[0]
+        return turn, [self.vehicle.headland_turn_speed_kmh] * len(turn)
 
     def verify_corner_coverage_grid_based(self, corner, corner_index: int, turn_path: np.ndarray,
                                           reverse_path: np.ndarray = None) -> Dict:
@@ -382,11 +369,8 @@ class TwoLayerPathPlannerV37:
         R, W = self.vehicle.min_turn_radius, self.vehicle.working_width
         # gap.area > 0.1 (MLP:1557) by the same analytic bound libfcpp's host setup uses (fcpp_host.cpp)
         reverse = 4 * R * R - (math.pi * R * W / 2 + math.pi * W * W / 4) > 0.1
-        items = []
-        for cx, cy, ci in ((hw, hw, 0), (Lf - hw, hw, 1), (Lf - hw, Hf - hw, 2), (hw, Hf - hw, 3)):
-            turn, _ = self._generate_corner_turn_arc((cx, cy), ci)
-            rev = self._corner_reverse_path(turn)[0] if reverse else None
-            items.append(((cx, cy), ci, turn, rev))
+        cs = [((hw, hw), 0), ((Lf - hw, hw), 1), ((Lf - hw, Hf - hw), 2), ((hw, Hf - hw), 3)]
+        items = [(c, ci, turn, rev) for (c, ci), (turn, rev) in zip(cs, self._corner_turns(cs, [int(reverse)] * 4))]
         corners = self._corner_grids(items)
         if self.verbose:
             for ci, r in enumerate(corners):

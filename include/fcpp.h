@@ -193,13 +193,26 @@ int fcpp_verify(fcpp_ctx *ctx, const fcpp_vehicle *veh, int64_t n_paths, const i
  * out_xy_dev = n_seg x n_points x 2 */
 int fcpp_straight_segments(fcpp_ctx *ctx, int64_t n_seg, const double *seg_dev, int32_t n_points,
                            double *out_xy_dev);
+/* _generate_corner_turn_arc (MLP:1580-1608) and _generate_corner_turn_with_reverse (MLP:1024-1084 with
+ * _generate_optimal_reverse_path, MLP:1154-1218, and _calculate_distance_to_boundary, MLP:1220-1288) for n corners at once:
+ * corner k = corners_dev[2k .. 2k+1], quadrant formula corner_index_dev[k] (0 LL, 1 LR, 2 UR, else UL; MLP:1049-1060).
+ * The 15-point quarter arc of radius min_turn_radius goes to out_xy_dev[k * stride * 2 ..]; where with_reverse_dev[k] != 0
+ * the reverse fill follows it: backwards along the arc's end tangent to the nearest side of the box [0, field_length] x
+ * [0, field_width], at most 3R (2R when no side lies ahead), max(10, int(len / 0.5)) points.  counts_dev[2k], [2k+1] = points of
+ * the arc and of the reverse fill.  stride (points per corner in out_xy_dev) must be >= 15 + max(10, int(3R / 0.5)).
+ * The Shapely-dependent decision `gap.area > 0.1` (MLP:1070) stays with the caller (with_reverse_dev). */
+int fcpp_corner_turns(fcpp_ctx *ctx, const fcpp_vehicle *veh, int64_t n, const double *corners_dev,
+                      const int32_t *corner_index_dev, const int32_t *with_reverse_dev, double field_length,
+                      double field_width, int32_t stride, double *out_xy_dev, int32_t *counts_dev);
 /* Fresnel integrals C(t), S(t) = int_0^t cos|sin(pi u^2/2) du (README_en.md:111-120 promises the
  * clothoid; the reference has no code for it) */
 int fcpp_fresnel(fcpp_ctx *ctx, int64_t n, const double *t_dev, double *c_dev, double *s_dev);
 
 /* ---- GeneticAlgorithmSolver._calculate_distance / _calculate_fitness (GA:168-181) ---------- */
 /* routes_dev: pop x n_nodes int32 permutations; D_dev: n_nodes x n_nodes float64 row-major.
- * order_mode 0 = left-to-right summation (bit-exact with the reference), 1 = tree reduction. */
+ * order_mode 0 = left-to-right summation (bit-exact with the reference), 1 = tree reduction.
+ * Precondition: every gene lies in [0, n_nodes); a chromosome that violates it gets distance = fitness = NaN (no out-of-range
+ * read happens). */
 int fcpp_ga_fitness(fcpp_ctx *ctx, int32_t n_nodes, int64_t pop, const double *D_dev,
                     const int32_t *routes_dev, double *dist_dev, double *fit_dev, int order_mode);
 
@@ -213,7 +226,8 @@ int fcpp_ga_fitness(fcpp_ctx *ctx, int32_t n_nodes, int64_t pop, const double *D
  *   stream 4 + c         : mutation of child c iff unit(w0, w1) < mutation_rate; positions as for the cut points
  *   unit(a, b) = ((a >> 5) * 2^26 + (b >> 6)) / 2^53
  * so a run is reproducible and identical to oracle/fcpp_oracle.c: orc_ga_evolve.  Ties in the elitism order go to the
- * larger index.  population_size must be even (the reference grows an odd population by one per generation, GA:203),
+ * larger index.  routes_dev must hold permutations of 0 .. n_nodes-1 (checked on the device before the first generation:
+ * FCPP_EINVAL otherwise).  population_size must be even (the reference grows an odd population by one per generation, GA:203),
  * elite_size < population_size, tournament_size <= min(64, population_size), 2 <= n_nodes <= 2048. */
 typedef struct fcpp_ga_config {   /* GAConfig, GA:20-29, + seed */
     int32_t population_size, max_generations;

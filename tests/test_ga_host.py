@@ -1,6 +1,9 @@
-"""Host-side GA operators (CPU; the fitness kernel itself is covered by the -m gpu tests)."""
+"""Host-side surface of the GA mirror (CPU; the kernels themselves are covered by the -m gpu tests).  The evolution operators
+have no host implementation in the product: what is checked here is the oracle's order crossover against a plain restatement
+of GA:214-242, and the mirror's configuration record / initial population."""
 import numpy as np
 
+import oracle as orc
 from field_coverage_path_planning_amd.genetic_algorithm_solver import GAConfig, GeneticAlgorithmSolver
 
 
@@ -19,28 +22,23 @@ def _ox_reference_semantics(p1, p2, a, b):
     return child
 
 
-def test_order_crossover_matches_reference_semantics():
+def test_oracle_order_crossover_matches_reference_semantics():
     rng = np.random.default_rng(0)
     for n in (5, 10, 33, 128):
-        keep = np.array([rng.permutation(n) for _ in range(40)], dtype=np.int32)
-        fill = np.array([rng.permutation(n) for _ in range(40)], dtype=np.int32)
-        cuts = np.sort(np.array([rng.choice(n, size=2, replace=False) for _ in range(40)]), axis=1)
-        got = GeneticAlgorithmSolver._ox(keep, fill, cuts)
-        for r in range(40):
-            assert got[r].tolist() == _ox_reference_semantics(keep[r], fill[r], cuts[r, 0], cuts[r, 1])
+        for _ in range(40):
+            p1, p2 = rng.permutation(n).astype(np.int32), rng.permutation(n).astype(np.int32)
+            a, b = sorted(int(v) for v in rng.choice(n, size=2, replace=False))
+            c1, c2 = orc.ga_ox(p1, p2, a, b)
+            assert c1.tolist() == _ox_reference_semantics(p1, p2, a, b)
+            assert c2.tolist() == _ox_reference_semantics(p2, p1, a, b)
 
 
-def test_operators_keep_permutations():
+def test_config_defaults_and_initial_population():
+    assert GAConfig() == GAConfig(200, 500, 0.85, 0.02, 20, 5, 50)                 # GA:20-29
     s = GeneticAlgorithmSolver(GAConfig(population_size=64, elite_size=4), seed=1)
-    rng = np.random.default_rng(1)
-    n = 37
-    pop = np.array([rng.permutation(n) for _ in range(64)], dtype=np.int32)
-    fit = rng.random(64)
-    sel = s._selection(pop, fit)
-    off = s._mutation(s._crossover(sel))
-    new = s._elitism(pop, off, fit)
-    assert new.shape == pop.shape
-    assert all(sorted(r.tolist()) == list(range(n)) for r in new)
-    elite = np.argsort(fit)[-4:]
-    assert np.array_equal(new[-4:], pop[elite])          # GA:262-266
-    assert GAConfig() == GAConfig(200, 500, 0.85, 0.02, 20, 5, 50)
+    pop = s._initialize_population(37)
+    assert pop.shape == (64, 37) and pop.dtype == np.int32
+    assert all(sorted(r.tolist()) == list(range(37)) for r in pop)
+    assert [int(r[0]) for r in pop[32:]] == [i % 37 for i in range(32)]            # GA:160-164
+    for name in ('_selection', '_crossover', '_mutation', '_elitism'):             # device-only (fcpp_ga_evolve)
+        assert not hasattr(s, name)

@@ -113,6 +113,25 @@ def test_mirror_corner_verification_vs_reference(golden_cover):
         assert one['coverage_after'] == g[f'{name}/c2/cov'][1]
 
 
+def test_corner_turns_operator_vs_reference(golden_cover):
+    """fcpp_corner_turns against the polylines the reference's _generate_corner_turn_arc / _generate_optimal_reverse_path produced
+    (tools/gen_golden.py tier_cover: pure numpy code of the reference, no Shapely involved)."""
+    g = golden_cover
+    names = ['working_width', 'min_turn_radius', 'max_work_speed_kmh', 'max_headland_speed_kmh', 'headland_turn_speed_kmh',
+             'max_lateral_accel', 'max_longitudinal_accel', 'safety_factor']
+    for name in g['names']:
+        Lf, Hf = g[f'{name}/LH']
+        veh = E.make_vehicle(**dict(zip(names, g[f'{name}/vp'])))
+        corners = [tuple(g[f'{name}/c{ci}/corner']) for ci in range(4)]
+        got = E.corner_turns(corners + corners, [0, 1, 2, 3] * 2, [1] * 4 + [0] * 4, veh, float(Lf), float(Hf))
+        for ci in range(4):
+            turn, rev = got[ci]
+            np.testing.assert_allclose(turn, g[f'{name}/c{ci}/turn'], rtol=0, atol=1e-9)
+            assert rev.shape == g[f'{name}/c{ci}/rev'].shape
+            np.testing.assert_allclose(rev, g[f'{name}/c{ci}/rev'], rtol=0, atol=1e-9)
+            assert got[4 + ci][1] is None and np.array_equal(got[4 + ci][0], turn)
+
+
 def test_coverage_rate_of_a_plan_vs_oracle():
     """result['headland']['stats']['coverage_rate'] (MLP:884): the GPU's sample counts equal the oracle's on the same path; the
     rate is a fraction in (0, 1]; a wider implement covers more."""

@@ -47,9 +47,8 @@ jobs, pts, first = [], [], 0
 for Lf, Hf in LH[:a.fields]:
     pl = TwoLayerPathPlannerV37(vp, field_length=float(Lf), field_width=float(Hf))
     hw = pl.headland_width
-    for cx, cy, ci in ((hw, hw, 0), (Lf - hw, hw, 1), (Lf - hw, Hf - hw, 2), (hw, Hf - hw, 3)):
-        turn, _ = pl._generate_corner_turn_arc((cx, cy), ci)
-        rev = pl._corner_reverse_path(turn)[0]
+    cs = [((hw, hw), 0), ((Lf - hw, hw), 1), ((Lf - hw, Hf - hw), 2), ((hw, Hf - hw), 3)]
+    for ((cx, cy), ci), (turn, rev) in zip(cs, pl._corner_turns(cs, [1] * 4)):
         origin = [(cx, cy), (cx - 2 * R, cy), (cx - 2 * R, cy - 2 * R), (cx, cy - 2 * R)][ci]
         jobs.append(E.make_cover_job(origin[0], origin[1], 0.1, gs, gs, W / 2, len(turn), len(rev), pts_first=first))
         pts += [turn, rev]
