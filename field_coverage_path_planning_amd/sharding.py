@@ -76,12 +76,46 @@ def gather_rows(local_rows, rows_per_rank, dst=0):
     return None
 
 
+def gather_arrays(local_arrays, counts_per_rank, dst=0):
+    """Optional gather of the point arrays: every rank holds 1-D tensors of its own block (x, y, kappa, v,
+    flagseg, ...: the same list, in the same order, on every rank; counts_per_rank[r] elements each on rank r).  The root
+    allocates each full array once and receives every peer's block straight into its slice -- one batch of point-to-point
+    transfers (ncclGroupStart / ncclSend / ncclRecv with the nccl backend: each peer crosses its own xGMI link to the root,
+    no ring, no staging copy, no concatenation).  -> list of full tensors on `dst`, None elsewhere."""
+    import torch
+    dist = _dist()
+    rank, ws = world()
+    if ws == 1:
+        return list(local_arrays)
+    starts = np.concatenate([[0], np.cumsum(np.asarray(counts_per_rank, dtype=np.int64))])
+    ops, out = [], None
+    if rank == dst:
+        out = []
+        for a in local_arrays:
+            full = torch.empty(int(starts[-1]), dtype=a.dtype, device=a.device)
+            full[int(starts[dst]):int(starts[dst + 1])] = a[:int(counts_per_rank[dst])]
+            for r in range(ws):
+                if r != dst and counts_per_rank[r] > 0:
+                    ops.append(dist.P2POp(dist.irecv, full[int(starts[r]):int(starts[r + 1])], r))
+            out.append(full)
+    elif counts_per_rank[rank] > 0:
+        for a in local_arrays:
+            ops.append(dist.P2POp(dist.isend, a[:int(counts_per_rank[rank])].contiguous(), dst))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    return out
+
+
 class ShardedResult:
-    def __init__(self, block, local, stats_all, infos):
+    def __init__(self, block, local, stats_all, infos, blocks=None, points_all=None, batch=None):
         self.block = block            # (lo, hi) fields of this rank
         self.local = local            # engine.BatchResult of this rank's block (device tensors), None if the block is empty
         self.stats_all = stats_all    # rank 0: (n_fields, 13) int64 tensor of fcpp_field_stats for ALL fields; else None
         self.infos = infos            # fcpp_field_info of every field of the whole batch (host-side, same on every rank)
+        self.blocks = blocks          # [(lo, hi)] of every rank
+        self.points_all = points_all  # rank 0 with gather_points: (x, y, kappa, v, flagseg) of the WHOLE batch; else None
+        self.batch = batch            # this rank's engine.Batch (None for an empty block / the CPU tests)
 
     def stats(self):
         """rank 0: dict of numpy arrays over all fields (same layout as BatchResult.stats())."""
@@ -95,26 +129,45 @@ class ShardedResult:
         return out
 
 
-def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1):
-    """Plan `specs` across all ranks of the current process group; per-field stats are gathered to rank 0.
+def _comm_tensor(t):
+    """what the process group can carry: device tensors with nccl (RCCL), host tensors with gloo (the CPU tests, and the
+    one-GPU rehearsal of a multi-rank job)"""
+    return t.cpu() if _dist().is_initialized() and _dist().get_backend() == 'gloo' else t
 
-    compute(specs_block, vehicle, options) -> (n_block, 13) int64 tensor replaces the GPU batch in the CPU (gloo) tests."""
+
+def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1, gather_points=False, batch=None, buffers=None, infos=None):
+    """Plan `specs` across all ranks of the current process group; per-field stats are gathered to rank 0, and so are the point
+    arrays (x, y, kappa, v, flagseg) when gather_points is set.
+
+    compute(specs_block, vehicle, options) -> (n_block, 13) int64 tensor [, list of 1-D point arrays] replaces the GPU batch in
+    the CPU (gloo) tests.  batch / buffers: reuse this rank's engine.Batch (and output buffers) of an earlier call with the same
+    specs -- the setup (fcpp_batch_create) is then skipped, as a caller that plans the same fields repeatedly would; infos: the
+    fcpp_plan_count result of an earlier call (the host-side sizing is then skipped too)."""
     import torch
     options = options or E.make_options()
     rank, ws = world()
-    infos = E.plan_count(specs, vehicle, options)                       # host only, identical on every rank
+    if infos is None:
+        infos = E.plan_count(specs, vehicle, options)                   # host only, identical on every rank
     counts = [i.n_main + i.n_head for i in infos]
     blocks = partition_by_points(counts, ws)
     lo, hi = blocks[rank]
-    local = None
+    local, arrays = None, None
     if compute is not None:
-        stats_local = compute(specs[lo:hi], vehicle, options)
+        got = compute(specs[lo:hi], vehicle, options)
+        stats_local, arrays = got if isinstance(got, tuple) else (got, None)
     elif hi > lo:
-        batch = E.Batch(specs[lo:hi], vehicle, options, device=device)
-        local = batch.run(mode=mode)
+        if batch is None:
+            batch = E.Batch(specs[lo:hi], vehicle, options, device=device)
+        local = batch.run(buffers, mode=mode)
         stats_local = local.stats_raw
+        arrays = [local.x, local.y, local.kappa, local.v, local.flagseg]
     else:
         dev = torch.device('cuda', device if device is not None else torch.cuda.current_device())
         stats_local = torch.zeros((0, L.STATS_WORDS), dtype=torch.int64, device=dev)
-    stats_all = gather_rows(stats_local, [b[1] - b[0] for b in blocks], dst=0)
-    return ShardedResult((lo, hi), local, stats_all, infos)
+        arrays = [torch.empty(0, dtype=torch.float64, device=dev) for _ in range(4)] + [torch.empty(0, dtype=torch.int32, device=dev)]
+    stats_all = gather_rows(_comm_tensor(stats_local), [b[1] - b[0] for b in blocks], dst=0)
+    points_all = None
+    if gather_points:
+        per_rank = [int(sum(counts[a:b])) for a, b in blocks]
+        points_all = gather_arrays([_comm_tensor(a) for a in arrays], per_rank, dst=0)
+    return ShardedResult((lo, hi), local, stats_all, infos, blocks, points_all, batch)

@@ -1,0 +1,38 @@
+"""The N > 1 path with the real engine.Batch: a world-size-2 (and 3) job on the one GPU of the test box, process group over gloo
+(tests/_shard_gpu_worker.py).  The root's gathered stats and point arrays must be byte-identical to one process planning every field.
+The workers are started before this process initialises the GPU-side comparison run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_real_batch_sharded_equals_single_process(tmp_path, world):
+    n_fields = 96
+    out = str(tmp_path / 'sharded.npz')
+    port = 33500 + (os.getpid() % 2000) + world
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', '_shard_gpu_worker.py'), str(r), str(world), str(port),
+                               str(n_fields), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode(errors='replace') for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+    got = np.load(out)
+
+    from field_coverage_path_planning_amd import engine as E, workloads as WL
+    specs = WL.specs_from_vertices(E, WL.cfg5_parallelograms(n_fields, seed=65536))
+    batch = E.Batch(specs, E.make_vehicle(), E.make_options())
+    res = batch.run()
+    assert np.array_equal(got['stats'], res.stats_raw.cpu().numpy())              # byte-identical for any shard count
+    for k, a in enumerate((res.x, res.y, res.kappa, res.v, res.flagseg)):
+        assert np.array_equal(got[f'a{k}'], a.cpu().numpy()), k
+    blocks = got['blocks']
+    assert blocks[0, 0] == 0 and blocks[-1, 1] == n_fields and (blocks[1:, 0] == blocks[:-1, 1]).all()
+    loads = [sum(i.n_main + i.n_head for i in batch.info[lo:hi]) for lo, hi in blocks]
+    assert max(loads) <= batch.total_points / world + max(i.n_main + i.n_head for i in batch.info)
+    batch.close()
