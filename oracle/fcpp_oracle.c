@@ -119,15 +119,44 @@ void orc_verify(const double *xy, const double *v, int64_t n, const orc_vehicle 
     o[5] = o[3] < 5 ? 1 : 0;
 }
 
-/* MLP:1290-1296 (numpy sums pairwise; this sums left to right: compare to ~1e-12 relative) */
+/* numpy.sum over a contiguous float64 array = numpy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum;
+ * numpy is a dependency of the reference, not part of /root/reference: restated from its published algorithm, numpy 2.2):
+ * fewer than 8 elements are added left to right; up to 128 elements go through eight running sums combined as
+ * ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the remainder left to right; longer arrays are split in halves (the first one a multiple
+ * of 8) and the halves' sums added.  With it orc_path_length / orc_work_time equal np.sum(...) of MLP:1296 / 1311 bit for bit. */
+static double np_pairwise_sum(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* MLP:1290-1296 */
 double orc_path_length(const double *xy, int64_t n)
 {
     if (n < 2) return 0.0;
-    double s = 0;
+    double *d = (double *)malloc((size_t)(n - 1) * sizeof(double));
     for (int64_t i = 1; i < n; ++i) {
         double dx = xy[2 * i] - xy[2 * (i - 1)], dy = xy[2 * i + 1] - xy[2 * (i - 1) + 1];
-        s += sqrt(dx * dx + dy * dy);
+        d[i - 1] = sqrt(dx * dx + dy * dy);
     }
+    double s = np_pairwise_sum(d, n - 1);
+    free(d);
     return s;
 }
 
@@ -135,15 +164,17 @@ double orc_path_length(const double *xy, int64_t n)
 double orc_work_time(const double *xy, const double *v, int64_t n)
 {
     if (n < 2) return 0.0;
-    double s = 0;
+    double *t = (double *)malloc((size_t)(n - 1) * sizeof(double));
     for (int64_t i = 1; i < n; ++i) {
         double dx = xy[2 * i] - xy[2 * (i - 1)], dy = xy[2 * i + 1] - xy[2 * (i - 1) + 1];
         double d = sqrt(dx * dx + dy * dy);
         double avg = (v[i - 1] + v[i]) / 2;
         double ms = avg / 3.6;
         if (!(ms >= 0.1)) ms = 0.1;   /* np.maximum(avg, 0.1) */
-        s += d / ms;
+        t[i - 1] = d / ms;
     }
+    double s = np_pairwise_sum(t, n - 1);
+    free(t);
     return s;
 }
 

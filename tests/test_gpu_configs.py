@@ -101,6 +101,7 @@ def test_cfg3_full_size(turn_model):
     assert np.array_equal(got_fs, p.flagseg)
     assert (int(st['n_in_obstacle'][0]), int(st['n_outside'][0]), int(st['n_viol'][0]), int(st['n_adjusted'][0])) == \
         (p.n_in_obstacle, p.n_outside, p.n_viol, p.n_adjusted)
+    # (6e7 addends: the oracle follows numpy's pairwise summation, the device sums closed-form run lengths in a fixed tree)
     np.testing.assert_allclose([st['main_len_m'][0], st['head_len_m'][0]], [p.main_len_m, p.head_len_m], rtol=1e-10)
     np.testing.assert_allclose([st['main_time_s'][0], st['head_time_s'][0]], [p.main_time_s, p.head_time_s], rtol=1e-9)
     batch.close()
