@@ -128,8 +128,9 @@ def run_planner(E, torch, specs, opt, steps, warmup, mode=1, placement=1, fence=
     q_pts, g_pts = batch.point_split()
     n_points = batch.total_points
     dom = max(kernels, key=kernels.get)
-    dom_points = {'k_plan_quiet': q_pts, 'k_plan_fused': g_pts}.get(dom, n_points) if mode != 0 else n_points
-    return {'points': n_points, 'dt': dt, 'ms_per_step': dt / steps * 1e3, 'kernels': kernels, 'dominant': dom, 'dominant_points': dom_points,
+    stage_points = batch.stage_points()
+    dom_points = stage_points[dom]
+    return {'stage_points': stage_points,'points': n_points, 'dt': dt, 'ms_per_step': dt / steps * 1e3, 'kernels': kernels, 'dominant': dom, 'dominant_points': dom_points,
             'quiet_points': q_pts, 'general_points': g_pts, 'batch': batch, 'bufs': bufs, 'res': res, 'placement': getattr(batch, 'placement', None)}
 
 
@@ -143,7 +144,7 @@ def roofline_of(r, traffic_key=None):
         traffic = json.load(open(tpath)).get(f'{dom}|{traffic_key}')
     return {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
-            'kernel_points_per_launch': dom_points, 'all_kernels_ms': r['kernels'], 'pipeline_ms': pipe_ms,
+            'kernel_points_per_launch': dom_points, 'all_kernels_ms': r['kernels'], 'all_kernels_points': r['stage_points'], 'pipeline_ms': pipe_ms,
             'pipeline_frac': (BYTES_PER_POINT * r['points'] / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pipe_ms > 0 else 0.0,
             'step_frac': BYTES_PER_POINT * r['points'] / (r['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
@@ -243,7 +244,7 @@ def main():
                             f'(2 / 20 / 15 / 20 points per line / U-turn / corner / headland side), 1691 points per field -- the mode pinned to '
                             f'the reference\'s outputs; the clothoid variants of the same batch are configs[cfg1_clothoid*] below',
                 'points_per_gpu_step': r['points'], 'fields_per_gpu': args.fields,
-                'pipeline': 'staged (7 kernels)' if args.mode == 0 else 'fused: k_plan_quiet (closed-form runs and spans) + k_plan_fused (all other tiles) + k_reduce_stats',
+                'pipeline': 'staged (7 kernels)' if args.mode == 0 else 'fused: k_plan_quiet (closed-form runs and spans) + k_plan_sparse (wave tiles, one point per lane) + k_plan_fused (all other tiles) + k_reduce_stats',
                 'quiet_points': r['quiet_points'], 'general_points': r['general_points'],
             },
             'roofline': roofline_of(r),
@@ -435,7 +436,8 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, fence, allmax, steps, 
             assert all(int(a.numel()) == total for a in resg.points_all)
         q_pts, g_pts = batch.point_split()
         dom = max(kernels, key=kernels.get)
-        dom_points = {'k_plan_quiet': q_pts, 'k_plan_fused': g_pts}.get(dom, my_points)
+        stage_points = batch.stage_points()
+        dom_points = stage_points[dom]
         achieved = BYTES_PER_POINT * dom_points / (kernels[dom] * 1e-3) / 1e9
         pr = per_rank.cpu().numpy()
         entry = {'name': 'cfg5', 'workload': 'cfg5: 65 536 parallelograms (base / height U[100,1000) m, angle U[60,120) deg, rotation U[-pi/4,pi/4), seed 65536), '
@@ -451,7 +453,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, fence, allmax, steps, 
                                                 'the root\'s arrays (dist.batch_isend_irecv)'},
                  'quiet_points': q_pts, 'general_points': g_pts,
                  'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                              'traffic': None, 'kernel_ms': kernels[dom], 'kernel_points_per_launch': dom_points, 'all_kernels_ms': kernels,
+                              'traffic': None, 'kernel_ms': kernels[dom], 'kernel_points_per_launch': dom_points, 'all_kernels_ms': kernels, 'all_kernels_points': stage_points,
                               'rank': 0, 'step_frac': BYTES_PER_POINT * total / (dt_dev / steps) / 1e9 / HBM_PEAK_GBS / world},
                  'cpu_baseline': None}
         if cpu_on:

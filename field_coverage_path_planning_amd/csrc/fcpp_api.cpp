@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -16,6 +17,8 @@
 #include "fcpp_internal.h"
 
 using namespace fcpp;
+
+namespace fcpp { thread_local LaunchProf g_launch_prof; }
 
 namespace {
 thread_local std::string g_err;
@@ -87,7 +90,146 @@ struct Tiling {
         double two_a;
         bool enable;
         bool turn_quiet;       // U-turns are closed form and swath lines are isolated by them (see fcpp_batch_create)
+        // geometry for the wave tiles of the sparse kernel (fcpp_sparse.hip): the field, host copies of the batch's turn templates
+        const DevField *df = nullptr;
+        const double2 *tu = nullptr, *tc = nullptr;
+        double u_cap = 0.0;
+        bool wave_ok = false;  // sampling sparse enough for halos of a few lanes
     };
+
+    // Host evaluation of path point i of a field (same formulas as eval_main / eval_prim in fcpp_pointfn.h, from the host copies of
+    // the templates).  Only distances between consecutive points are taken from it, to size the halos of the wave tiles.
+    static void host_point(const QuietInfo &q, int64_t i, double &px, double &py)
+    {
+        const DevField &f = *q.df;
+        if (i < f.n_main) {
+            const int64_t per = (int64_t)f.n_line + f.n_turn;
+            const int64_t idx = i / per, off = i - idx * per;
+            const int64_t pi = f.reverse_order ? (f.P - 1 - idx) : idx;
+            const double y = f.min_y + (double)pi * f.W;
+            const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+            if (off < f.n_line) {
+                px = go_left ? linspace_at(f.lex, f.lsx, -f.line_step, f.n_line, off) : linspace_at(f.lsx, f.lex, f.line_step, f.n_line, off);
+                py = y;
+            } else {
+                const double2 t = q.tu[off - f.n_line];
+                const bool turn_right = !go_left;
+                if (f.turn_model == FCPP_TURN_ARC) px = turn_right ? (f.max_x - t.x) : (f.min_x + t.x);
+                else px = turn_right ? ((f.max_x - f.R) + t.x) : ((f.min_x + f.R) - t.x);
+                py = y + t.y;
+            }
+            if (f.rotated) {
+                const double tx = px - f.rot_cx, ty = py - f.rot_cy;
+                px = (tx * f.rot_cos - ty * f.rot_sin) + f.rot_cx;
+                py = (tx * f.rot_sin + ty * f.rot_cos) + f.rot_cy;
+            }
+            return;
+        }
+        const DevPrim &p = q.prims[prim_of(q, i)];
+        const int64_t r = i - p.start;
+        if (p.kind == PRIM_LINSPACE) { px = linspace_at(p.a[0], p.a[2], p.a[4], p.n, r); py = linspace_at(p.a[1], p.a[3], p.a[5], p.n, r); }
+        else if (p.kind == PRIM_POINT) { px = p.a[0]; py = p.a[1]; }
+        else if (p.kind == PRIM_RAY) { const double t = linspace_at(0.0, p.a[4], p.a[5], p.n, r); px = p.a[0] + t * p.a[2]; py = p.a[1] + t * p.a[3]; }
+        else {
+            const double2 t = q.tc[r];
+            const int ci = p.kind == PRIM_ARC ? p.form : ((p.form + 3) & 3);
+            if (ci == 0)      { px = p.a[0] + t.x; py = p.a[1] + t.y; }
+            else if (ci == 1) { px = p.a[0] - t.y; py = p.a[1] + t.x; }
+            else if (ci == 2) { px = p.a[0] - t.x; py = p.a[1] - t.y; }
+            else              { px = p.a[0] + t.y; py = p.a[1] - t.x; }
+        }
+    }
+    static int prim_of(const QuietInfo &q, int64_t i)      // index (within the field) of the headland primitive that holds point i
+    {
+        int a = 0, b = q.prim_count - 1;
+        while (a < b) { const int m = (a + b + 1) >> 1; if (q.prims[m].start <= i) a = m; else b = m - 1; }
+        return a;
+    }
+
+    // Wave tiles of the sparse kernel for the general stretch [a, b) of path p: [ Hb halo | count outputs | Hf halo ] <= 64 lanes.
+    // The halos are sized from the path's own step lengths (see fcpp_sparse.hip): backwards from the point before the first output
+    // (whose final speed the segment metrics need) until the couplings 2a|dp| add up to u_cap, a skipped step or the path's start,
+    // plus one lane for the stencil of the outermost point; forwards likewise from the last output.  Every tile takes as many
+    // outputs as fit.  false = some tile would hold fewer than 8 outputs (dense sampling): the stretch stays with k_plan_fused.
+    static constexpr int WAVE_HALO_MAX = 40;
+    mutable int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };   // diagnostics (FCPP_DEBUG_TILING): stretches that did not fit, by reason
+    mutable std::vector<double> wave_d;                  // scratch: step lengths of the stretch and its surroundings
+    bool wave_tiles(int64_t p, const QuietInfo &q, int64_t a, int64_t b, std::vector<DevTile> &out) const
+    {
+        const DevField &f = *q.df;
+        const int64_t n = f.n_total, per = (int64_t)f.n_line + f.n_turn;
+        const double cap = q.u_cap * (1.0 + 1e-9) + 1e-12;
+        // d[i - lo] = |p_i - p_(i-1)| for the stretch and WAVE_HALO_MAX + 2 points either side
+        const int64_t lo = std::max<int64_t>(a - WAVE_HALO_MAX - 2, 1), hi = std::min<int64_t>(b + WAVE_HALO_MAX + 2, n);   // i in [lo, hi)
+        if (hi - lo > (int64_t)1 << 22) { ++wave_fail[4]; return false; }
+        std::vector<double> &d = wave_d;
+        d.resize((size_t)std::max<int64_t>(hi - lo, 0));
+        {
+            double x0, y0, x1, y1;
+            if (hi > lo) host_point(q, lo - 1, x0, y0);
+            for (int64_t i = lo; i < hi; ++i) {
+                host_point(q, i, x1, y1);
+                const double dx = x1 - x0, dy = y1 - y0;
+                d[(size_t)(i - lo)] = sqrt(dx * dx + dy * dy);
+                x0 = x1; y0 = y1;
+            }
+        }
+        auto dist = [&](int64_t i) { return d[(size_t)(i - lo)]; };     // lo <= i < hi by the halo bound below
+        // (a step within 0.1 % of the 1e-6 threshold counts neither as skipped nor as a coupling)
+        auto back_halo = [&](int64_t s) -> int {
+            if (s == 0) return 0;
+            const int64_t j = s - 1;
+            int64_t m = j;
+            double acc = 0.0;
+            for (;;) {
+                if (m == 0) return (int)(j + 1);
+                const double dm = dist(m);
+                if (dm < 0.999e-6) return (int)(j - (m - 1) + 1);
+                if (dm > 1.001e-6) acc += q.two_a * dm;
+                --m;
+                if (acc >= cap) return (int)(j - m + 1);
+                if (j - m + 1 > WAVE_HALO_MAX) return -1;
+            }
+        };
+        auto fwd_halo = [&](int64_t e) -> int {
+            if (e == n - 1) return 0;
+            int64_t m = e;
+            double acc = 0.0;
+            for (;;) {
+                const double dm = dist(m + 1);
+                if (dm < 0.999e-6) return (int)(m + 1 - e);
+                if (dm > 1.001e-6) acc += q.two_a * dm;
+                ++m;
+                if (m == n - 1 || acc >= cap) return (int)(m - e);
+                if (m - e > WAVE_HALO_MAX) return -1;
+            }
+        };
+        const size_t mark = out.size();
+        for (int64_t s = a; s < b;) {
+            const int Hb = back_halo(s);
+            if (Hb < 0) { ++wave_fail[0]; out.resize(mark); return false; }
+            // the largest count whose forward halo still fits
+            int64_t c = std::min<int64_t>(b - s, 64 - Hb);
+            int Hf = -1;
+            for (; c >= 1; --c) {
+                Hf = fwd_halo(s + c - 1);
+                if (Hf >= 0 && Hb + c + Hf <= 64) break;
+            }
+            if (c < std::min<int64_t>(8, b - s)) { ++wave_fail[Hf < 0 ? 1 : 2]; out.resize(mark); return false; }
+            const int64_t first = s - Hb, last = s + c - 1 + Hf;
+            DevTile t;
+            t.field = (int32_t)p; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 8);
+            if (first < f.n_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
+            else { t.idx0 = q.prim_index0 + prim_of(q, first); t.off0 = 0; }
+            if (last >= f.n_main) {      // the kernel finds a lane's primitive among the tile's first one and the next 8
+                const int p0 = first >= f.n_main ? prim_of(q, first) : 0;
+                if (prim_of(q, last) - p0 > 8) { ++wave_fail[3]; out.resize(mark); return false; }
+            }
+            out.push_back(t);
+            s += c;
+        }
+        return true;
+    }
 
     // Tiles never straddle paths and hold at most TILE_POINTS points.  Without structure information (standalone operators)
     // a path is cut into near-equal tiles.  With it (planner batches) every straight primitive -- swath lines of layer 1,
@@ -119,6 +261,7 @@ struct Tiling {
             auto emit_general = [&](int64_t a, int64_t b) {
                 const int64_t len = b - a;
                 if (len <= 0) return;
+                if (q && q->wave_ok && wave_tiles(p, *q, a, b, tiles)) return;
                 const int64_t k = (len + TILE_POINTS - 1) / TILE_POINTS, base = len / k, rem = len % k;
                 for (int64_t i = 0; i < k; ++i) {
                     const int64_t c = base + (i < rem ? 1 : 0);
@@ -195,12 +338,14 @@ struct DevTiling {
     DevBuf<TilePartial> partial;
     DevBuf<unsigned long long> n_adj;
     DevBuf<int32_t> general_ids;   // fused pipeline: the tiles of k_plan_fused
+    DevBuf<int32_t> wave_ids;      // ... the wave tiles of k_plan_sparse
     DevBuf<DevTile> chunks;        // ... the quiet runs cut on 512-point boundaries of the batch arrays (k_plan_quiet)
     DevBuf<DevTile> span_chunks;   // ... the same for the layer-1 spans (their own kernel instance)
     DevBuf<DevRun> runs;           // ... the quiet runs (k_quiet_run_stats)
     DevBuf<int32_t> stat_ids;      // ... the tiles that can hold statistics (general tiles, first tile of every run), path by path
     DevBuf<int64_t> stat_first;    //     CSR offsets into stat_ids per path
-    int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_general = 0, quiet_points = 0;
+    int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_general = 0, n_wave = 0, quiet_points = 0;
+    int64_t span_points = 0, chunk_points = 0, wave_points = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
     {
         n_tiles = (int64_t)t.tiles.size(); n_paths = (int64_t)t.paths.size();
@@ -214,8 +359,9 @@ struct DevTiling {
         if ((e = carry_b.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
-        std::vector<int32_t> gv, sv;
+        std::vector<int32_t> gv, sv, wv;
         std::vector<int64_t> sf((size_t)n_paths + 1, 0);
+        wave_points = 0;
         std::vector<DevTile> cv, cs;
         std::vector<DevRun> rv;
         quiet_points = 0;
@@ -224,6 +370,7 @@ struct DevTiling {
             sv.push_back((int32_t)i);                 // a general tile, or the first tile of a run
             sf[(size_t)t0.field + 1] = (int64_t)sv.size();
             if (!t0.quiet) { gv.push_back((int32_t)i); ++i; continue; }
+            if (t0.quiet == 5) { wv.push_back((int32_t)i); wave_points += t0.count; ++i; continue; }
             // the run: quiet tiles that continue each other on the same straight
             int64_t cnt = t0.count;
             size_t j = i + 1;
@@ -275,6 +422,11 @@ struct DevTiling {
             r = r1;
         }
         n_chunks = (int64_t)cv.size(); n_span_chunks = (int64_t)cs.size(); n_runs = (int64_t)rv.size(); n_general = (int64_t)gv.size();
+        n_wave = (int64_t)wv.size();
+        span_points = chunk_points = 0;
+        for (const DevTile &c : cs) span_points += c.count;
+        for (const DevTile &c : cv) chunk_points += c.count;
+        if ((e = wave_ids.upload(wv, st)) != hipSuccess) return e;
         if ((e = chunks.upload(cv, st)) != hipSuccess) return e;
         if ((e = span_chunks.upload(cs, st)) != hipSuccess) return e;
         if ((e = runs.upload(rv, st)) != hipSuccess) return e;
@@ -302,7 +454,9 @@ struct fcpp_batch {
     DevConst cst;
     DevBuf<DevField> fields;
     DevBuf<DevPrim> prims;
-    DevTiling til;
+    DevTiling til;             // fused pipeline (mode 1): quiet runs, wave tiles, general tiles
+    DevTiling til0;            // staged pipeline (mode 0): plain near-equal tiles, built on its first run
+    bool til0_built = false;
     DevBuf<int64_t> obs_off;
     DevBuf<double> obs_x, obs_y, obs_bbox;
     DevBuf<CacShape> shapes;   // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
@@ -312,20 +466,21 @@ struct fcpp_batch {
     DevBuf<int32_t> seg_mask;
     // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
     bool profiling = false;
-    std::vector<hipEvent_t> events;   // kProfRuns x (kStages + 1)
+    std::vector<hipEvent_t> events;   // kProfRuns x kStages x (start, stop)
+    std::vector<unsigned char> ev_set; // kProfRuns x kStages: the stage launched a kernel in that run
     int prof_runs = 0;
     int last_mode = 0;
-    bool partial_dirty = true;   // the staged pipeline (or nobody yet) wrote the tile partials last
+    bool partial_dirty = true;   // the fused pipeline's tile partials have not been zeroed yet
     ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 
 namespace {
 constexpr int kStages = 7;
-constexpr int kProfRuns = 64;
+constexpr int kProfRuns = 256;
 const char *const kStageNames[2][kStages] = {
     { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine", "k_scan_apply", "k_validate", "k_reduce_stats" },
-    { "k_plan_quiet", "k_plan_fused", "k_reduce_stats", "", "", "", "" } };
-const int kStageCount[2] = { 7, 3 };
+    { "k_quiet_run_stats", "k_plan_quiet_spans", "k_plan_quiet", "k_plan_sparse", "k_plan_fused", "k_reduce_stats", "" } };
+const int kStageCount[2] = { 7, 6 };
 }
 
 // Are the U-turns of this batch closed form?  A turn is a translate / mirror of the template t[0..nu); its neighbours are the
@@ -525,6 +680,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     ok(b->shapes.upload(shp, st));
     b->cst.shapes = b->shapes.p;
     bool turn_quiet = false;
+    std::vector<double2> h_tu, h_tc;      // host copies of the turn templates (closed-form test, halos of the wave tiles)
     if (e == hipSuccess) {
         const int nu = b->hp.tt.nu;
         ok(b->tmpl_u.alloc((size_t)nu)) && ok(b->tmpl_c.alloc((size_t)b->hp.tt.nc)) && ok(b->tmpl_u_dk.alloc((size_t)nu));
@@ -534,12 +690,15 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
             if (le != 0) e = (hipError_t)le;
         }
         b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p; b->cst.tmpl_u_dk = b->tmpl_u_dk.p;
-        if (e == hipSuccess && nu >= 3) {
-            std::vector<double2> t((size_t)nu), dk((size_t)nu);
-            ok(hipMemcpyAsync(t.data(), b->tmpl_u.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st)) &&
-                ok(hipMemcpyAsync(dk.data(), b->tmpl_u_dk.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st)) &&
-                ok(hipStreamSynchronize(st));
-            if (e == hipSuccess) turn_quiet = closed_form_turns(*veh, b->hp.tt, t, dk, b->cst);
+        if (e == hipSuccess) {
+            const int nc = b->hp.tt.nc;
+            std::vector<double2> dk((size_t)nu);
+            h_tu.resize((size_t)nu); h_tc.resize((size_t)nc);
+            if (nu > 0) ok(hipMemcpyAsync(h_tu.data(), b->tmpl_u.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st)) &&
+                ok(hipMemcpyAsync(dk.data(), b->tmpl_u_dk.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st));
+            if (nc > 0) ok(hipMemcpyAsync(h_tc.data(), b->tmpl_c.p, (size_t)nc * sizeof(double2), hipMemcpyDeviceToHost, st));
+            ok(hipStreamSynchronize(st));
+            if (e == hipSuccess && nu >= 3) turn_quiet = closed_form_turns(*veh, b->hp.tt, h_tu, dk, b->cst);
         }
     }
     Tiling til;
@@ -557,9 +716,18 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         // (fields narrower than 4R have line_end_x < line_start_x: their lines run against the jump from the previous turn, the
         // first point of every line is clamped -- general kernel)
         q.turn_quiet = turn_quiet && df.n_turn == b->hp.tt.nu && df.line_step > 0.0;
+        // wave tiles (fcpp_sparse.hip) where eight steps of a swath line already exceed the reach of the sweeps: the reference's
+        // own sampling and coarse uniform spacings; dense sampling keeps the eight-points-per-lane kernel
+        q.df = &df; q.tu = h_tu.data(); q.tc = h_tc.data(); q.u_cap = b->cst.u_cap;
+        q.wave_ok = e == hipSuccess && df.n_turn == b->hp.tt.nu && (int)h_tc.size() == b->hp.tt.nc &&
+                    8.0 * q.two_a * q.line_step_len >= b->cst.u_cap;
         qi[(size_t)i] = q;
     }
     til.build(n_fields, offs.data(), qi.data());
+    if (getenv("FCPP_DEBUG_TILING"))
+        fprintf(stderr, "[fcpp] tiling: %zu tiles; wave-tile stretches refused: back halo %lld, forward halo %lld, too few outputs %lld, "
+                "primitive span %lld\n", til.tiles.size(), (long long)til.wave_fail[0], (long long)til.wave_fail[1],
+                (long long)til.wave_fail[2], (long long)til.wave_fail[3]);
     ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) && ok(b->til.upload(til, st)) &&
         ok(b->field_junc.alloc((size_t)n_fields));
     if (e == hipSuccess && n_fields > 0) {
@@ -632,33 +800,47 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     if (!stats) return fail(FCPP_EINVAL, "stats pointer is NULL");
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
-    DevTiling &t = b->til;
+    if (mode == 0 && !b->til0_built) {      // the staged pipeline's own tiling: plain tiles of at most TILE_POINTS points
+        Tiling t0;
+        std::vector<int64_t> offs((size_t)b->n_fields + 1, 0);
+        for (int64_t i = 0; i < b->n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
+        t0.build(b->n_fields, offs.data());
+        HIPCHK(b->til0.upload(t0, st));
+        b->til0_built = true;
+    }
+    DevTiling &t = mode == 0 ? b->til0 : b->til;
     DevObstacles obs = { b->obs_off.p, b->obs_x.p, b->obs_y.p, b->obs_bbox.p };
-    HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
+    if (mode == 0) HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
     hipEvent_t *ev = nullptr;
-    if (b->profiling && b->prof_runs < kProfRuns) ev = &b->events[(size_t)b->prof_runs * (kStages + 1)];
-#define STAGE(k, call)                                     \
-    do {                                                   \
-        LAUNCHCHK(call);                                   \
-        if (ev) HIPCHK(hipEventRecord(ev[(k) + 1], st));   \
+    unsigned char *evs = nullptr;
+    if (b->profiling && b->prof_runs < kProfRuns) {
+        ev = &b->events[(size_t)b->prof_runs * kStages * 2];
+        evs = &b->ev_set[(size_t)b->prof_runs * kStages];
+    }
+    // a stage = one kernel; profiled, its dispatch carries a start and a stop event (fcpp_device.h: LaunchProf)
+#define STAGE(k, call)                                                                  \
+    do {                                                                                \
+        if (ev) { g_launch_prof.start = ev[2 * (k)]; g_launch_prof.stop = ev[2 * (k) + 1]; } \
+        const int e_ = (call);                                                          \
+        if (ev) { evs[k] = g_launch_prof.start == nullptr; g_launch_prof = LaunchProf(); }   \
+        if (e_ != 0) return fail(FCPP_EHIP, std::string(#call) + ": " + hipGetErrorString((hipError_t)e_)); \
     } while (0)
-    if (ev) HIPCHK(hipEventRecord(ev[0], st));
     if (mode == 1) {
         if (b->partial_dirty) {   // slots of quiet tiles that are not the first of their run stay zero from here on
             HIPCHK(hipMemsetAsync(t.partial.p, 0, (size_t)t.n_tiles * sizeof(TilePartial), st));
             b->partial_dirty = false;
         }
-        LAUNCHCHK(launch_quiet_run_stats(st, t.n_runs, t.runs.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, t.partial.p));
-        LAUNCHCHK(launch_plan_quiet(st, t.n_span_chunks, t.span_chunks.p, 16, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(0, launch_quiet_run_stats(st, t.n_runs, t.runs.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, t.partial.p));
+        STAGE(1, launch_plan_quiet(st, t.n_span_chunks, t.span_chunks.p, 16, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
-        STAGE(0, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
-        STAGE(1, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
+        STAGE(2, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(3, launch_plan_sparse(st, t.n_wave, t.wave_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(4, launch_plan_fused(st, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
                                    y, kappa, v, fs, t.partial.p));
-        STAGE(2, launch_reduce_stats(st, t.n_paths, t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p));
+        STAGE(5, launch_reduce_stats(st, t.n_paths, t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p));
         if (ev) ++b->prof_runs;
         return FCPP_OK;
     }
-    b->partial_dirty = true;
     STAGE(0, launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
     STAGE(1, launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
     STAGE(2, launch_scan_tiles(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, x, y, v, t.agg_f.p, t.agg_b.p));
@@ -676,7 +858,8 @@ int fcpp_batch_set_profiling(fcpp_batch *b, int enable)
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
     HIPCHK(hipSetDevice(b->ctx->device));
     if (enable && b->events.empty()) {
-        b->events.resize((size_t)kProfRuns * (kStages + 1));
+        b->events.resize((size_t)kProfRuns * kStages * 2);
+        b->ev_set.assign((size_t)kProfRuns * kStages, 0);
         for (hipEvent_t &e : b->events) HIPCHK(hipEventCreate(&e));
     }
     b->profiling = enable != 0;
@@ -692,16 +875,28 @@ int fcpp_batch_stage_times(fcpp_batch *b, int max_stages, double *ms_sum, int *n
     const int ns = kStageCount[b->last_mode];
     for (int k = 0; k < kStages; ++k) ms_sum[k] = 0.0;
     for (int r = 0; r < b->prof_runs; ++r) {
-        hipEvent_t *ev = &b->events[(size_t)r * (kStages + 1)];
+        hipEvent_t *ev = &b->events[(size_t)r * kStages * 2];
         for (int k = 0; k < ns; ++k) {
+            if (!b->ev_set[(size_t)r * kStages + k]) continue;      // the stage had nothing to launch
             float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
             ms_sum[k] += ms;
         }
     }
     if (n_stages) *n_stages = ns;
     if (n_runs) *n_runs = b->prof_runs;
     b->prof_runs = 0;
+    return FCPP_OK;
+}
+
+int fcpp_batch_stage_points(const fcpp_batch *b, int mode, int stage, int64_t *points)
+{
+    if (!b || !points || mode < 0 || mode > 1 || stage < 0 || stage >= kStageCount[mode]) return fail(FCPP_EINVAL, "bad arguments");
+    const DevTiling &t = b->til;
+    const int64_t all = b->hp.total_points;
+    if (mode == 0) { *points = all; return FCPP_OK; }         // every staged kernel sees every point
+    const int64_t per_stage[6] = { t.quiet_points, t.span_points, t.chunk_points, t.wave_points, all - t.quiet_points - t.wave_points, all };
+    *points = per_stage[stage];
     return FCPP_OK;
 }
 

@@ -9,6 +9,17 @@
 #include "fcpp_geom.h"
 #include "fcpp_internal.h"
 
+#include <hip/hip_ext.h>
+
+// kernel launch of the planner pipelines: plain, or with the dispatch's start / stop events when profiling is armed (fcpp_device.h)
+#define FCPP_LAUNCH(kernel, grid, block, shmem, st, ...)                                                                         \
+    do {                                                                                                                         \
+        if (::fcpp::g_launch_prof.start) {                                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, ::fcpp::g_launch_prof.start, ::fcpp::g_launch_prof.stop, 0, __VA_ARGS__); \
+            ::fcpp::g_launch_prof = ::fcpp::LaunchProf();                                                                        \
+        } else hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                                                  \
+    } while (0)
+
 namespace fcpp {
 
 static constexpr int BLOCK = 256;

@@ -35,6 +35,12 @@ struct DevConst {
     const double2 *tmpl_u_dk;         // per U-turn sample k: (|t_k - t_(k-1)|, curvature at t_k), the shape's own segment lengths / curvatures
 };
 
+// Per-kernel device timing (fcpp_batch_set_profiling): when the caller has armed g_launch_prof, the next launcher call dispatches
+// its kernel with hipExtLaunchKernelGGL(start, stop): the two events take the dispatch's own begin / end time stamps -- no marker
+// packets between the kernels, so the timed step runs as it does unprofiled -- and the launcher disarms it.
+struct LaunchProf { hipEvent_t start = nullptr, stop = nullptr; };
+extern thread_local LaunchProf g_launch_prof;
+
 // every launcher returns 0 or a hipError_t value
 int launch_generate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevField *fields,
                     const DevPrim *prims, const DevConst &cst, double *x, double *y, double *v, uint32_t *fs);
@@ -58,6 +64,11 @@ int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacSha
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,
                       const DevField *fields, const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x,
                       double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial);
+// ids: the wave tiles (DevTile.quiet == 5: start / count = the output points, stat_tile = Hb | Hf << 8, idx0 / off0 = layer-1 decode or
+// first primitive of the tile's first lane)
+int launch_plan_sparse(hipStream_t st, int64_t n_ids, const int32_t *ids, const DevTile *tiles, const DevField *fields, const DevPrim *prims,
+                       const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
+                       TilePartial *partial);
 int launch_distance_matrix(hipStream_t st, int n, const double *x, const double *y, double *D);
 int launch_best_connections(hipStream_t st, int64_t n_pairs, const int64_t *fo, const int64_t *to, const double *fx, const double *fy,
                             const double *tx, const double *ty, int32_t *bf, int32_t *bt, double *bd);

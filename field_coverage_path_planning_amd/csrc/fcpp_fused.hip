@@ -21,7 +21,7 @@
 // primitive the carried value is its nominal u0 (closed form); otherwise wave 0 (wave 3) re-generates 64-point
 // chunks before (after) the tile until the accumulated 2a*distance exceeds u_cap or the path ends.  The
 // recomputation uses the same arithmetic as the owning tile, so results do not depend on the tiling.
-#include "fcpp_devfn.h"
+#include "fcpp_pointfn.h"
 
 namespace fcpp {
 
@@ -45,11 +45,6 @@ static constexpr int TR_WORDS = 64 * FIPT + 64;   // padded per-wave transpositi
 struct FieldWords { uint32_t w[sizeof(DevField) / 4]; };
 static_assert(sizeof(DevField) % 4 == 0 && sizeof(DevField) / 4 <= 2 * FBLOCK, "DevField staging");
 
-// nominal speeds by primitive kind (fs & FCPP_KIND_MASK): a per-lane LDS lookup instead of a divergent switch over scalars
-struct NomTable { double v[8], ms[8]; };
-__device__ __forceinline__ double nom_v(const NomTable &t, uint32_t fs) { return t.v[fs & FCPP_KIND_MASK]; }
-__device__ __forceinline__ double nom_ms(const NomTable &t, uint32_t fs) { return t.ms[fs & FCPP_KIND_MASK]; }
-
 static constexpr int FPRIM_CAP = 48;     // headland primitives of one field staged in LDS (a field has <= 40)
 static_assert(sizeof(DevPrim) % 4 == 0, "DevPrim staging");
 
@@ -71,132 +66,6 @@ struct FusedShared {
     double tr[FNWAVE][TR_WORDS];
     RedSharedF R;
 };
-
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// curvature (MLP:513-536) from the two chords and their lengths.  dtheta = atan2(sin(t2-t1), cos(t2-t1)) is the
-// signed angle between the chords = atan2(cross, dot).  Exactly collinear chords (every interior point of an
-// axis-aligned straight run) give 0; turning angles up to 0.124 rad (consecutive samples of any turn at fine sampling)
-// take the odd series atan(x) = x - x^3/3 + x^5/5 - ..., 10 terms of which leave < 3e-20 at x = 1/8 (for |x| < 1e-8 the
-// series returns x itself, as atan2 does).  Larger angles set `slow`: the caller evaluates atan2(cross, dot).
-__device__ __forceinline__ double curv_chords_fast(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2, bool &slow)
-{
-    slow = false;
-    if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
-    const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
-    if (cr == 0.0 && dt > 0.0) return 0.0;
-    if (!(dt > 0.0 && fabs(cr) <= 0.125 * dt)) { slow = true; return 0.0; }
-    const double x = cr / dt, z = x * x;
-    double p = -1.0 / 19.0;
-    p = fma(p, z, 1.0 / 17.0); p = fma(p, z, -1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, -1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0); p = fma(p, z, -1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, -1.0 / 3.0);
-    const double dth = fma(x * z, p, x);
-    return fabs(2 * dth / (ds1 + ds2));
-}
-
-// the same with the atan2 fallback as an out-of-line call (halo recomputation: one call site, not eight)
-__device__ __forceinline__ double curv_chords(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)
-{
-    bool slow;
-    const double k = curv_chords_fast(dx1, dy1, ds1, dx2, dy2, ds2, slow);
-    if (!slow) return k;
-    return fabs(2 * atan2_slow(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / (ds1 + ds2));
-}
-
-// speed after the curvature clamp (MLP:496-504); nominal = the primitive's nominal speed.
-// v_nom > sqrt(a_lat / kappa) * sf * 3.6  <=>  kappa * (v_nom / (sf * 3.6))^2 > a_lat: points that are clearly not clamped
-// (the vast majority of turn points) are decided by that product, without the square root and the division.
-__device__ __forceinline__ double clamped_speed(double v_nom, double kappa, const DevConst &cst, bool &clamped)
-{
-    clamped = false;
-    if (kappa > 1e-6) {
-        const double q = v_nom * cst.inv_sf36;
-        if (kappa * q * q < cst.a_lat * (1.0 - 1e-9)) return v_nom;
-        const double vmax_ms = sqrt(cst.a_lat / kappa) * cst.sf;
-        const double vmax_kmh = vmax_ms * 3.6;
-        if (v_nom > vmax_kmh) { clamped = true; return vmax_kmh; }
-    }
-    return v_nom;
-}
-
-// sqrt(fl(t*t)) == |t| exactly in IEEE arithmetic: axis-aligned steps need no square root
-__device__ __forceinline__ double seg_len(double dx, double dy)
-{
-    return (dy == 0.0) ? fabs(dx) : ((dx == 0.0) ? fabs(dy) : sqrt(dx * dx + dy * dy));
-}
-
-// ---- template-based point evaluation ---------------------------------------------------------------------
-__device__ __forceinline__ void rotate_back(const DevField &f, double &px, double &py)   // MLP:271-282, angle = +rotation
-{
-    const double tx = px - f.rot_cx, ty = py - f.rot_cy;
-    px = (tx * f.rot_cos - ty * f.rot_sin) + f.rot_cx;
-    py = (tx * f.rot_sin + ty * f.rot_cos) + f.rot_cy;
-}
-
-// layer 1 (MLP:750-780): pass position idx, offset off inside the pass
-__device__ __forceinline__ void eval_main(const DevField &f, const DevConst &cst, int idx, int off, double &px, double &py,
-                                          uint32_t &fw)
-{
-    const int pi = f.reverse_order ? (f.P - 1 - idx) : idx;
-    const double y = f.min_y + (double)pi * f.W;
-    const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
-    if (off < f.n_line) {
-        px = go_left ? linspace_at(f.lex, f.lsx, -f.line_step, f.n_line, off) : linspace_at(f.lsx, f.lex, f.line_step, f.n_line, off);
-        py = y;
-        fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
-    } else {
-        const double2 t = cst.tmpl_u[off - f.n_line];
-        const bool turn_right = !go_left;                              // MLP:776
-        if (f.turn_model == FCPP_TURN_ARC) px = turn_right ? (f.max_x - t.x) : (f.min_x + t.x);   // MLP:815, 822
-        else px = turn_right ? ((f.max_x - f.R) + t.x) : ((f.min_x + f.R) - t.x);
-        py = y + t.y;
-        fw = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
-    }
-    if (f.rotated) rotate_back(f, px, py);
-}
-
-// layer 2 (MLP:943-1084): sample r of primitive p
-__device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst, int r, double &px, double &py)
-{
-    if (p.kind == PRIM_LINSPACE) {
-        px = linspace_at(p.a[0], p.a[2], p.a[4], p.n, r);
-        py = linspace_at(p.a[1], p.a[3], p.a[5], p.n, r);
-    } else if (p.kind == PRIM_POINT) { px = p.a[0]; py = p.a[1]; }
-    else if (p.kind == PRIM_RAY) {
-        const double t = linspace_at(0.0, p.a[4], p.a[5], p.n, r);
-        px = p.a[0] + t * p.a[2];
-        py = p.a[1] + t * p.a[3];
-    } else {   // corner turn: quadrant formulas MLP:1049-1060 on the template (t1, t2) = (R(1-cos), R sin) or its clothoid analogue
-        const double2 t = cst.tmpl_c[r];
-        const int ci = p.kind == PRIM_ARC ? p.form : ((p.form + 3) & 3);
-        if (ci == 0)      { px = p.a[0] + t.x; py = p.a[1] + t.y; }
-        else if (ci == 1) { px = p.a[0] - t.y; py = p.a[1] + t.x; }
-        else if (ci == 2) { px = p.a[0] - t.x; py = p.a[1] - t.y; }
-        else              { px = p.a[0] + t.y; py = p.a[1] - t.x; }
-    }
-}
-
-// the batch's primitive table, or a field's primitives staged in LDS: indexed by the batch-wide primitive index either way
-struct PrimTable {
-    const DevPrim *p;
-    int first;
-    __device__ __forceinline__ const DevPrim &operator[](int i) const { return p[i - first]; }
-};
-
-__device__ __forceinline__ int find_prim(const DevField &f, const PrimTable prims, int64_t i)
-{
-    int a = f.prim_first, b = f.prim_first + f.prim_count - 1;
-    while (a < b) {
-        const int m = (a + b + 1) >> 1;
-        if (prims[m].start <= i) a = m; else b = m - 1;
-    }
-    return a;
-}
 
 // random access (halo recomputation only): point i of the field's path
 __device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const PrimTable prims, const DevConst *cst, int64_t i)
@@ -332,80 +201,6 @@ __device__ void halo_wave(const DevField &f, const DevField *fg, const PrimTable
         b += BACK ? -64 : 64;
     }
     if (lane == 0) out->carry = total.c;
-}
-
-// wave-wide reductions; a ballot skips the butterfly when every lane holds the neutral element (most tiles have
-// only one layer, no curvature and no flags)
-__device__ __forceinline__ double wave_sum(double v)
-{
-    if (__ballot(v != 0.0) == 0ull) return 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double wave_max0(double v)   // v >= 0
-{
-    if (__ballot(v != 0.0) == 0ull) return 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ long long wave_sum_i(int v)
-{
-    if (__ballot(v != 0) == 0ull) return 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// ---- obstacle flags (build-defined validator): even-odd crossing test of the wave's points against the field's
-// obstacle polygons.  Culling first: lane b compares polygon b's bounding box with the bounding box of the wave's
-// points, a ballot collects the few candidates, and each candidate's vertices are staged in LDS (coalesced load, then
-// broadcast reads) before every lane tests its own points against all its edges.
-static constexpr int OBS_LDS_VERTS = 256;    // polygons with more vertices are read from global memory
-
-// returns the bit mask of the points (bit p = point p of this lane) that lie inside an obstacle
-template <int NP>
-__device__ __forceinline__ unsigned obstacle_mask(const DevObstacles &obs, int ob0, int ob1, double *lds /* 2*OBS_LDS_VERTS */,
-                                                  double bminx, double bminy, double bmaxx, double bmaxy,
-                                                  const double (&px)[NP], const double (&py)[NP], int nvalid)
-{
-    const int lane = threadIdx.x & 63;
-    unsigned inside = 0;    // bit k: point k is inside some obstacle
-    for (int base = ob0; base < ob1; base += 64) {
-        const int b = base + lane;
-        bool hit = false;
-        if (b < ob1) {
-            const double *bb = obs.bbox + 4 * (int64_t)b;
-            hit = !(bb[0] > bmaxx || bb[2] < bminx || bb[1] > bmaxy || bb[3] < bminy);
-        }
-        unsigned long long cand = __ballot(hit);
-        while (cand) {
-            const int k = __ffsll((long long)cand) - 1;
-            cand &= cand - 1;
-            const int64_t a0 = obs.offsets[base + k], a1 = obs.offsets[base + k + 1];
-            const int nv = (int)(a1 - a0);
-            const bool staged = nv <= OBS_LDS_VERTS;
-            if (staged) {
-                wave_sync();
-                for (int q = lane; q < nv; q += 64) { lds[2 * q] = obs.x[a0 + q]; lds[2 * q + 1] = obs.y[a0 + q]; }
-                wave_sync();
-            }
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                if (p < nvalid && !((inside >> p) & 1u)) {
-                    bool in = false;
-                    for (int q = 0, r = nv - 1; q < nv; r = q++) {
-                        const double xi = staged ? lds[2 * q] : obs.x[a0 + q], yi = staged ? lds[2 * q + 1] : obs.y[a0 + q];
-                        const double xj = staged ? lds[2 * r] : obs.x[a0 + r], yj = staged ? lds[2 * r + 1] : obs.y[a0 + r];
-                        if (((yi > py[p]) != (yj > py[p])) && (px[p] < (xj - xi) * (py[p] - yi) / (yj - yi) + xi)) in = !in;
-                    }
-                    if (in) inside |= 1u << p;
-                }
-            }
-        }
-    }
-    return inside;
 }
 
 // ---- quiet runs (found by the host tiler): stretches of a straight primitive whose points, and everything within reach of
@@ -1371,7 +1166,7 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
 {
     if (n_chunks <= 0) return 0;
     const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
-#define FCPP_QUIET(K, SD) hipLaunchKernelGGL((k_plan_quiet<K, SD>), grid, block, 0, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
+#define FCPP_QUIET(K, SD) FCPP_LAUNCH((k_plan_quiet<K, SD>), grid, block, 0, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
     // Descriptors by scalar loads: 55 instead of 116 vector registers, 7 instead of 4 waves per SIMD.  That nearly halves the time of
     // the spans (latency-bound: pass decode, short runs) but costs the dense kernel 2-4 % on identical memory (tools/ab_quiet.py:
     // 5.61 vs 5.49 ms; capping the occupancy below 4 waves costs more: 5.90 ms at 3, 6.70 ms at 2).
@@ -1386,7 +1181,7 @@ int launch_quiet_run_stats(hipStream_t st, int64_t n_runs, const DevRun *runs, c
                            const DevPrim *prims, const DevConst &cst, TilePartial *partial)
 {
     if (n_runs <= 0) return 0;
-    hipLaunchKernelGGL(k_quiet_run_stats, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, st, n_runs, runs, tiles, fields, prims, cst,
+    FCPP_LAUNCH(k_quiet_run_stats, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, st, n_runs, runs, tiles, fields, prims, cst,
                        partial);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -1399,13 +1194,13 @@ int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_
     if (n_tiles <= 0) return 0;
     // variant = register budget: minimum waves per SIMD the compiler must allow (3 -> <=168 VGPRs, 4 -> <=128, 2 -> <=256)
     if (variant == 4)
-        hipLaunchKernelGGL(k_plan_fused<4>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+        FCPP_LAUNCH(k_plan_fused<4>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
                            kappa, v, fs, partial, ids);
     else if (variant == 2)
-        hipLaunchKernelGGL(k_plan_fused<2>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+        FCPP_LAUNCH(k_plan_fused<2>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
                            kappa, v, fs, partial, ids);
     else
-        hipLaunchKernelGGL(k_plan_fused<3>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
+        FCPP_LAUNCH(k_plan_fused<3>, dim3((unsigned)n_tiles), dim3(FBLOCK), 0, st, tiles, fields, prims, cst, obs, x, y,
                            kappa, v, fs, partial, ids);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

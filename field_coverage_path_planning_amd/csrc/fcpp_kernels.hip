@@ -488,7 +488,7 @@ int launch_generate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
                     const DevPrim *prims, const DevConst &cst, double *x, double *y, double *v, uint32_t *fs)
 {
     if (n_tiles <= 0) return 0;
-    hipLaunchKernelGGL(k_generate, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, x, y, v, fs);
+    FCPP_LAUNCH(k_generate, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, fields, prims, cst, x, y, v, fs);
     FCPP_LAUNCH_CHECK();
     return 0;
 }
@@ -498,7 +498,7 @@ int launch_curv_clamp(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
                       double *v_out, double *kappa, unsigned long long *n_adjusted)
 {
     if (n_tiles <= 0) return 0;
-    hipLaunchKernelGGL(k_curv_clamp, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, do_clamp, x, y,
+    FCPP_LAUNCH(k_curv_clamp, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, do_clamp, x, y,
                        v_in, v_out, kappa, n_adjusted);
     FCPP_LAUNCH_CHECK();
     return 0;
@@ -508,7 +508,7 @@ int launch_scan_tiles(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
                       const double *x, const double *y, const double *v_in, void *agg_f, void *agg_b)
 {
     if (n_tiles <= 0) return 0;
-    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, x, y, v_in,
+    FCPP_LAUNCH(k_scan_tiles, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, x, y, v_in,
                        (Agg *)agg_f, (Agg *)agg_b);
     FCPP_LAUNCH_CHECK();
     return 0;
@@ -518,7 +518,7 @@ int launch_scan_spine(hipStream_t st, int64_t n_tiles, const void *agg_f, const 
                       double *carry_b)
 {
     if (n_tiles <= 0) return 0;
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(BLOCK), 0, st, n_tiles, (const Agg *)agg_f, (const Agg *)agg_b,
+    FCPP_LAUNCH(k_scan_spine, dim3(1), dim3(BLOCK), 0, st, n_tiles, (const Agg *)agg_f, (const Agg *)agg_b,
                        carry_f, carry_b);
     FCPP_LAUNCH_CHECK();
     return 0;
@@ -529,7 +529,7 @@ int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
                       const double *carry_f, const double *carry_b)
 {
     if (n_tiles <= 0) return 0;
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, min_n, x, y, v_in,
+    FCPP_LAUNCH(k_scan_apply, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, cst, min_n, x, y, v_in,
                        v_out, carry_f, carry_b);
     FCPP_LAUNCH_CHECK();
     return 0;
@@ -540,7 +540,7 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial)
 {
     if (n_tiles <= 0) return 0;
-    hipLaunchKernelGGL(k_validate, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, fields, cst, obs, x, y,
+    FCPP_LAUNCH(k_validate, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, fields, cst, obs, x, y,
                        kappa, v, fs, partial);
     FCPP_LAUNCH_CHECK();
     return 0;
@@ -550,7 +550,7 @@ int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *part
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids)
 {
     if (n_paths <= 0) return 0;
-    hipLaunchKernelGGL(k_reduce_stats, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, n_paths, tile_first, partial,
+    FCPP_LAUNCH(k_reduce_stats, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, n_paths, tile_first, partial,
                        n_adjusted, stats, ids);
     FCPP_LAUNCH_CHECK();
     return 0;

@@ -299,6 +299,20 @@ class Batch:
         runs = max(nr.value, 1)
         return {self.lib.fcpp_batch_stage_name(self._last_mode, k).decode(): ms[k] / runs for k in range(ns.value)}, nr.value
 
+    def stage_points(self):
+        """-> {kernel name: points one launch of it processes} for the pipeline of the last run()."""
+        out = {}
+        k = 0
+        while True:
+            name = self.lib.fcpp_batch_stage_name(self._last_mode, k).decode()
+            if not name:
+                break
+            n = C.c_int64()
+            L.check(self.lib.fcpp_batch_stage_points(self.handle, self._last_mode, k, C.byref(n)))
+            out[name] = n.value
+            k += 1
+        return out
+
     def point_split(self):
         """-> (points handled by k_plan_quiet, points handled by k_plan_fused) in the fused pipeline."""
         q, g = C.c_int64(), C.c_int64()

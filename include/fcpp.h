@@ -155,8 +155,9 @@ int fcpp_batch_info(const fcpp_batch *batch, fcpp_field_info *info_out /* n_fiel
  * (MLP:513-536), curvature clamp (MLP:467-511), forward/backward sweeps (MLP:538-589), validator
  * (MLP:1373-1424 + geofence / obstacle flags) and metrics (MLP:1290-1311).  Outputs are device
  * arrays of total_points elements; stats_dev has n_fields entries.
- * mode 0: staged pipeline (one kernel per operator, 7 launches); mode 1: fused single-pass kernel
- * (each point is written once, nothing is read back) -- same results. */
+ * mode 0: staged pipeline (one kernel per operator, 7 launches); mode 1: fused single-pass kernels
+ * (each point is written once, nothing is read back: closed-form runs and spans, wave tiles at sparse sampling,
+ * general tiles) -- same results. */
 int fcpp_batch_run(fcpp_batch *batch, double *x_dev, double *y_dev, double *kappa_dev, double *v_dev,
                    uint32_t *flagseg_dev, fcpp_field_stats *stats_dev, int mode);
 /* _generate_approach_path / _generate_departure_path (MLP:1313-1355): 50 points each, AoS (x,y) per
@@ -170,7 +171,10 @@ int fcpp_batch_destroy(fcpp_batch *batch);
 int fcpp_batch_set_profiling(fcpp_batch *batch, int enable);
 int fcpp_batch_stage_times(fcpp_batch *batch, int max_stages, double *ms_sum_out, int *n_stages_out, int *n_runs_out);
 const char *fcpp_batch_stage_name(int mode, int stage);
-/* how the fused pipeline (mode 1) splits the batch: points handled by k_plan_quiet / by k_plan_fused */
+/* points one launch of stage `stage` of pipeline `mode` processes (the stages of fcpp_batch_stage_name; mode 1: the closed-form spans,
+ * the closed-form runs, the wave tiles of the sparse kernel, the general tiles, and all points for the reduction) */
+int fcpp_batch_stage_points(const fcpp_batch *batch, int mode, int stage, int64_t *points);
+/* how the fused pipeline (mode 1) splits the batch: points in closed-form runs and spans (k_plan_quiet) / all other points */
 int fcpp_batch_point_split(const fcpp_batch *batch, int64_t *quiet_points, int64_t *general_points);
 
 /* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) ------- */
