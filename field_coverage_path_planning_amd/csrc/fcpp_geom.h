@@ -33,6 +33,18 @@ FCPP_HD double linspace_at(double a, double b, double step, int64_t n, int64_t k
 {
     if (n > 1 && k == n - 1) return b;
     if (step == 0.0) {
+        if (b == a) return a;       // (k / (n-1)) * 0 + a: every axis-aligned straight has one coordinate like this
+        if (n <= 1) return 0.0 * (b - a) + a;
+        return ((double)k / (double)(n - 1)) * (b - a) + a;
+    }
+    return (double)k * step + a;
+}
+// the same for 32-bit counts (device code: int -> double is one instruction, int64 -> double is a sequence)
+FCPP_HD double linspace_at32(double a, double b, double step, int n, int k)
+{
+    if (n > 1 && k == n - 1) return b;
+    if (step == 0.0) {
+        if (b == a) return a;
         if (n <= 1) return 0.0 * (b - a) + a;
         return ((double)k / (double)(n - 1)) * (b - a) + a;
     }

@@ -77,6 +77,15 @@ struct DevRun {
     int64_t count;       // points in the run
 };
 
+// Work of one "simple" field (fcpp_field.hip: one workgroup plans the whole field): its span chunks, its wave tiles, its span run.
+struct DevFieldWork {
+    int32_t field;
+    int32_t n_chunks, chunk_first;   // chunks of the field's layer-1 span in the field-kernel's chunk list
+    int32_t n_wave, wave_first;      // its wave tiles in the field-kernel's wave-tile id list
+    int32_t run_tile;                // first tile of the span's run (closed-form statistics), -1: no span
+    int64_t run_count;               // points in that run
+};
+
 // batch-wide turn templates: every field of a batch shares the vehicle and the sampling options, hence the number of
 // samples and the shape of its U-turns (nu) and corner turns (nc)
 struct TurnTemplates {

@@ -85,7 +85,7 @@ __device__ __forceinline__ void eval_main(const DevField &f, const DevConst &cst
     const double y = f.min_y + (double)pi * f.W;
     const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
     if (off < f.n_line) {
-        px = go_left ? linspace_at(f.lex, f.lsx, -f.line_step, f.n_line, off) : linspace_at(f.lsx, f.lex, f.line_step, f.n_line, off);
+        px = go_left ? linspace_at32(f.lex, f.lsx, -f.line_step, f.n_line, off) : linspace_at32(f.lsx, f.lex, f.line_step, f.n_line, off);
         py = y;
         fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
     } else {
@@ -103,11 +103,11 @@ __device__ __forceinline__ void eval_main(const DevField &f, const DevConst &cst
 __device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst, int r, double &px, double &py)
 {
     if (p.kind == PRIM_LINSPACE) {
-        px = linspace_at(p.a[0], p.a[2], p.a[4], p.n, r);
-        py = linspace_at(p.a[1], p.a[3], p.a[5], p.n, r);
+        px = linspace_at32(p.a[0], p.a[2], p.a[4], p.n, r);
+        py = linspace_at32(p.a[1], p.a[3], p.a[5], p.n, r);
     } else if (p.kind == PRIM_POINT) { px = p.a[0]; py = p.a[1]; }
     else if (p.kind == PRIM_RAY) {
-        const double t = linspace_at(0.0, p.a[4], p.a[5], p.n, r);
+        const double t = linspace_at32(0.0, p.a[4], p.a[5], p.n, r);
         px = p.a[0] + t * p.a[2];
         py = p.a[1] + t * p.a[3];
     } else {   // corner turn: quadrant formulas MLP:1049-1060 on the template (t1, t2) = (R(1-cos), R sin) or its clothoid analogue

@@ -1,0 +1,336 @@
+// fcpp_quiet_fn.h -- closed-form ("quiet") runs as device functions: the chunk writer of k_plan_quiet and the run statistics, shared
+// by the streaming kernel (fcpp_fused.hip) and the one-workgroup-per-field kernel of sparse sampling (fcpp_field.hip).
+#pragma once
+#include "fcpp_pointfn.h"
+
+namespace fcpp {
+
+// ---- quiet runs (found by the host tiler): stretches of a straight primitive whose points, and everything within reach of
+// the sweeps, lie on that primitive.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere: closed-form results, no
+// neighbours, no scan, no LDS.  The kernel is pure HBM streaming, so what matters is the shape of its stores: a run is cut into
+// chunks on 512-point boundaries of the batch arrays, one chunk per wavefront, every store instruction of a full chunk writes
+// one ALIGNED KiB (16 bytes per lane) -- measured 15-25 % faster than the same bytes through tiles that start anywhere in a
+// cache line (tools/micro/stream_probe.hip), and far less sensitive to where the arrays happen to live in device memory.
+// aligned pair store of one lane: points (g, g + 1) of the batch arrays, g even
+__device__ __forceinline__ void store_pair(bool has0, bool has1, int64_t g, double px0, double px1, double py0, double py1, double k0,
+                                           double k1, double v, uint32_t f0, uint32_t f1, double *__restrict__ xo,
+                                           double *__restrict__ yo, double *__restrict__ ko, double *__restrict__ vo,
+                                           uint32_t *__restrict__ fso)
+{
+    if (has0 && has1) {
+        *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
+        *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
+        *reinterpret_cast<double2 *>(ko + g) = make_double2(k0, k1);
+        *reinterpret_cast<double2 *>(vo + g) = make_double2(v, v);
+        *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
+    } else if (has0) {
+        xo[g] = px0; yo[g] = py0; ko[g] = k0; vo[g] = v; fso[g] = f0;
+    } else if (has1) {
+        xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = k1; vo[g + 1] = v; fso[g + 1] = f1;
+    }
+}
+
+// Curvature of the first point of a swath line that follows a quiet U-turn: its stencil spans the jump back from the turn's
+// last sample (MLP:776-780: the reference's turn ends on the field edge, the next line starts R inside).  Same arithmetic
+// as the general kernel's stencil.  Also returns the length of the jump.
+__device__ __forceinline__ double line_start_curvature(const DevField &q, const DevConst &cst, int idx, double &jump_len)
+{
+    const int per = q.n_line + q.n_turn;
+    double tx, ty, x0, y0, x1, y1;
+    uint32_t fw;
+    eval_main(q, cst, idx - 1, per - 1, tx, ty, fw);
+    eval_main(q, cst, idx, 0, x0, y0, fw);
+    eval_main(q, cst, idx, 1, x1, y1, fw);
+    const double dx1 = x0 - tx, dy1 = y0 - ty, dx2 = x1 - x0, dy2 = y1 - y0;
+    jump_len = seg_len(dx1, dy1);
+    return curv_chords(dx1, dy1, jump_len, dx2, dy2, seg_len(dx2, dy2));
+}
+
+// KINDS: bit k set = chunks of kind k may occur in this instance (1 swath line, 2 headland straight, 3 U-turn, 4 layer-1 span).
+// The kinds are compiled into separate kernels where that saves registers (occupancy of a pure streaming kernel).
+template <int KINDS>
+__device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg, const DevPrim *__restrict__ prims,
+                                           const DevConst &cst, const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
+                                           double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
+                                           double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                           unsigned long long *sink_outside, unsigned long long *sink_obstacle)
+{
+    // sink_*: where the chunk's flag counts are added (integer atomics; global memory or LDS)
+    const int lane = threadIdx.x & 63;
+    const DevField &q = *fg;
+    const int cnt = tl.count;    // <= TILE_POINTS; a chunk that starts on an odd index ends on a 512 boundary (<= 511 points)
+    const int64_t g0 = q.pt_off + tl.start;
+    // Aligned pairs: pair m covers the chunk-local points (2m - odd, 2m - odd + 1), whose global index is even whatever the
+    // parity of the chunk's first global index (odd = 1: the chunk's first point is the second half of pair 0).
+    const int odd = (int)(g0 & 1);
+    const double ntol = -cst.geofence_tol;
+    auto outside = [&](double px, double py) -> bool {
+        bool out = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out = out | (q.ex[e] * px + q.ey[e] * py + q.eo[e] < ntol);
+        return out;
+    };
+    int nout = 0, nobs = 0;
+    if ((KINDS & 16) && (KINDS == 16 || tl.quiet == 4)) {
+        // ---- a span of layer 1 whose passes (swath line + U-turn) are all closed form.  Point i of the span is (pass i / per,
+        // offset i % per): a line sample k * step + start (kappa 0; the first point of a line after a turn has the curvature of
+        // the jump stencil), or a turn sample = template + translation (mirror), curvature = the shape's own, nominal speeds.
+        const int per = q.n_line + q.n_turn, nl = q.n_line, last = q.n_turn - 1;
+        const bool arc = q.turn_model == FCPP_TURN_ARC;
+        const double xr = arc ? q.max_x : (q.max_x - q.R), xl = arc ? q.min_x : (q.min_x + q.R);
+        const double k_last = cst.turn_kappa_last[q.reverse_order ? 1 : 0];
+        const double k_start = cst.field_junc[tl.field].x;     // the same for every line of the field (mirror images)
+        auto sample = [&](int j, double &px, double &py, double &kp, double &v, uint32_t &fw) {
+            const unsigned a = (unsigned)(tl.off0 + max(j, 0));
+            const unsigned dq = a / (unsigned)per;
+            const int off = (int)(a - dq * (unsigned)per), idx = tl.idx0 + (int)dq;
+            const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
+            const double y = q.min_y + (double)pi * q.W;
+            const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+            if (off < nl) {
+                px = go_left ? ((double)off * -q.line_step + q.lex) : ((double)off * q.line_step + q.lsx);
+                if (off == nl - 1) px = go_left ? q.lsx : q.lex;
+                py = y;
+                kp = (off == 0 && idx > 0) ? k_start : 0.0;
+                v = cst.v_work;
+                fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+            } else {
+                const int c = off - nl;
+                const double2 t = cst.tmpl_u[c];
+                const bool turn_right = !go_left;
+                px = arc ? (turn_right ? (xr - t.x) : (xl + t.x)) : (turn_right ? (xr + t.x) : (xl - t.x));
+                py = y + t.y;
+                kp = c == last ? k_last : cst.tmpl_u_dk[c].y;
+                v = cst.v_turn;
+                fw = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+            }
+            if (q.rotated) rotate_back(q, px, py);
+        };
+#pragma unroll
+        for (int k = 0; k < TILE_POINTS / 128; ++k) {
+            const int j = 2 * (lane + 64 * k) - odd;
+            const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;
+            double px0, py0, k0, v0, px1, py1, k1, v1;
+            uint32_t f0, f1;
+            sample(j, px0, py0, k0, v0, f0);
+            sample(min(j + 1, cnt - 1), px1, py1, k1, v1, f1);
+            const bool o0 = has0 && outside(px0, py0), o1 = has1 && outside(px1, py1);      // turns may leave the field: every point is tested
+            nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
+            f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
+            f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
+            if (q.obs_count > 0) {
+                // bounding box of the wave's points of this pass, then the culled polygon tests
+                double mnx = has0 ? px0 : (has1 ? px1 : FCPP_INF), mxx = has0 ? px0 : (has1 ? px1 : -FCPP_INF);
+                double mny = has0 ? py0 : (has1 ? py1 : FCPP_INF), mxy = has0 ? py0 : (has1 ? py1 : -FCPP_INF);
+                if (has1) { mnx = fmin(mnx, px1); mxx = fmax(mxx, px1); mny = fmin(mny, py1); mxy = fmax(mxy, py1); }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mnx = fmin(mnx, __shfl_xor(mnx, o)); mny = fmin(mny, __shfl_xor(mny, o));
+                    mxx = fmax(mxx, __shfl_xor(mxx, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+                }
+                const double ox[2] = { has0 ? px0 : px1, px1 }, oy[2] = { has0 ? py0 : py1, py1 };
+                const unsigned m = obstacle_mask<2>(obs, q.obs_first, q.obs_first + q.obs_count, my_lds, mnx, mny, mxx, mxy, ox, oy,
+                                                    has1 ? 2 : (has0 ? 1 : 0));
+                const bool b0 = has0 && (m & 1u), b1 = has1 && (m & 2u);
+                nobs += (b0 ? 1 : 0) + (b1 ? 1 : 0);
+                f0 |= b0 ? FCPP_FLAG_OBSTACLE : 0u;
+                f1 |= b1 ? FCPP_FLAG_OBSTACLE : 0u;
+            }
+            // (a pair may straddle a line / turn boundary: each point carries its own speed)
+            const int64_t g = g0 + j;
+            if (has0 && has1) {
+                *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
+                *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
+                *reinterpret_cast<double2 *>(ko + g) = make_double2(k0, k1);
+                *reinterpret_cast<double2 *>(vo + g) = make_double2(v0, v1);
+                *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
+            } else if (has0) {
+                xo[g] = px0; yo[g] = py0; ko[g] = k0; vo[g] = v0; fso[g] = f0;
+            } else if (has1) {
+                xo[g + 1] = px1; yo[g + 1] = py1; ko[g + 1] = k1; vo[g + 1] = v1; fso[g + 1] = f1;
+            }
+        }
+    } else if ((KINDS & 8) && (KINDS == 8 || tl.quiet == 3)) {
+        // ---- U-turn in closed form: sample = template + translation (mirror), curvature = the shape's own, nominal turn speed ----
+        const int idx = tl.idx0;
+        const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
+        const double y = q.min_y + (double)pi * q.W;
+        const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+        const bool turn_right = !go_left, arc = q.turn_model == FCPP_TURN_ARC;
+        const double xr = arc ? q.max_x : (q.max_x - q.R), xl = arc ? q.min_x : (q.min_x + q.R);
+        const uint32_t fw = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+        const double k_last = cst.turn_kappa_last[q.reverse_order ? 1 : 0];
+        const int last = q.n_turn - 1;
+        auto sample = [&](int tk, double &px, double &py, double &kp) {
+            const int c = min(max(tk, 0), last);
+            const double2 t = cst.tmpl_u[c];
+            px = arc ? (turn_right ? (xr - t.x) : (xl + t.x)) : (turn_right ? (xr + t.x) : (xl - t.x));
+            py = y + t.y;
+            if (q.rotated) rotate_back(q, px, py);
+            kp = c == last ? k_last : cst.tmpl_u_dk[c].y;
+        };
+#pragma unroll
+        for (int k = 0; k < TILE_POINTS / 128; ++k) {
+            const int j = 2 * (lane + 64 * k) - odd;
+            const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;
+            double px0, py0, k0, px1, py1, k1;
+            sample(tl.off0 + j, px0, py0, k0);
+            sample(tl.off0 + j + 1, px1, py1, k1);
+            uint32_t f0 = fw, f1 = fw;
+            const bool o0 = has0 && outside(px0, py0), o1 = has1 && outside(px1, py1);      // a turn may leave the field: every point is tested
+            nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
+            f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
+            f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
+            if (q.obs_count > 0) {
+                // bounding box of the wave's points of this pass, then the culled polygon tests
+                double mnx = has0 ? px0 : (has1 ? px1 : FCPP_INF), mxx = has0 ? px0 : (has1 ? px1 : -FCPP_INF);
+                double mny = has0 ? py0 : (has1 ? py1 : FCPP_INF), mxy = has0 ? py0 : (has1 ? py1 : -FCPP_INF);
+                if (has1) { mnx = fmin(mnx, px1); mxx = fmax(mxx, px1); mny = fmin(mny, py1); mxy = fmax(mxy, py1); }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mnx = fmin(mnx, __shfl_xor(mnx, o)); mny = fmin(mny, __shfl_xor(mny, o));
+                    mxx = fmax(mxx, __shfl_xor(mxx, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+                }
+                const double ox[2] = { has0 ? px0 : px1, px1 }, oy[2] = { has0 ? py0 : py1, py1 };
+                const unsigned m = obstacle_mask<2>(obs, q.obs_first, q.obs_first + q.obs_count, my_lds, mnx, mny, mxx, mxy, ox, oy,
+                                                    has1 ? 2 : (has0 ? 1 : 0));
+                const bool b0 = has0 && (m & 1u), b1 = has1 && (m & 2u);
+                nobs += (b0 ? 1 : 0) + (b1 ? 1 : 0);
+                f0 |= b0 ? FCPP_FLAG_OBSTACLE : 0u;
+                f1 |= b1 ? FCPP_FLAG_OBSTACLE : 0u;
+            }
+            store_pair(has0, has1, g0 + j, px0, px1, py0, py1, k0, k1, cst.v_turn, f0, f1, xo, yo, ko, vo, fso);
+        }
+    } else if (KINDS & 6) {
+        double ax, ay, sx, sy, bx, by, vnom;      // numpy.linspace(a, b, n): sample k = k * step + a, the last one is b itself
+        int n_lin;
+        uint32_t fw;
+        bool rot;
+        if (tl.quiet == 1) {        // swath line of layer 1: idx0 = pass position, off0 = offset in the pass
+            const int idx = tl.idx0;
+            const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
+            const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+            ax = go_left ? q.lex : q.lsx; bx = go_left ? q.lsx : q.lex; sx = go_left ? -q.line_step : q.line_step;
+            ay = by = q.min_y + (double)pi * q.W; sy = 0.0;
+            n_lin = q.n_line;
+            rot = q.rotated != 0;
+            fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+            vnom = cst.v_work;
+        } else {                    // headland straight: idx0 = primitive, off0 = offset in it
+            const DevPrim &p = prims[tl.idx0];
+            ax = p.a[0]; ay = p.a[1]; bx = p.a[2]; by = p.a[3]; sx = p.a[4]; sy = p.a[5];
+            n_lin = p.n;
+            rot = false;
+            fw = p.fs; vnom = p.v_nom;
+        }
+        auto lin = [&](int r, double &px, double &py) {
+            px = (double)r * sx + ax; py = (double)r * sy + ay;
+            if (r == n_lin - 1) { px = bx; py = by; }
+        };
+        // a line that starts right after a quiet U-turn: its first point's curvature stencil spans the jump from the turn's end
+        const bool has_start = tl.quiet == 1 && tl.off0 == 0 && tl.idx0 > 0;     // wave-uniform
+        const double k_start = has_start ? cst.field_junc[tl.field].x : 0.0;
+        // geofence by convexity: both end points inside => the whole segment is inside
+        double ex0, ey0, ex1, ey1;
+        lin(tl.off0, ex0, ey0);
+        lin(tl.off0 + cnt - 1, ex1, ey1);
+        if (rot) { rotate_back(q, ex0, ey0); rotate_back(q, ex1, ey1); }
+        const bool ends_out = outside(ex0, ey0) || outside(ex1, ey1);
+        const double bminx = fmin(ex0, ex1), bmaxx = fmax(ex0, ex1), bminy = fmin(ey0, ey1), bmaxy = fmax(ey0, ey1);
+#pragma unroll
+        for (int k = 0; k < TILE_POINTS / 128; ++k) {
+            const int j = 2 * (lane + 64 * k) - odd;
+            const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;     // (no early exit: the obstacle test below is wave-wide)
+            double px0, py0, px1, py1;
+            lin(tl.off0 + j, px0, py0);
+            lin(tl.off0 + j + 1, px1, py1);
+            if (rot) { rotate_back(q, px0, py0); rotate_back(q, px1, py1); }
+            uint32_t f0 = fw, f1 = fw;
+            if (ends_out) {      // wave-uniform
+                const bool o0 = has0 && outside(px0, py0), o1 = has1 && outside(px1, py1);
+                nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
+                f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
+                f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
+            }
+            if (q.obs_count > 0) {
+                // lanes without a valid first point test only their second one (or nothing)
+                const double ox[2] = { has0 ? px0 : px1, px1 }, oy[2] = { has0 ? py0 : py1, py1 };
+                const unsigned m = obstacle_mask<2>(obs, q.obs_first, q.obs_first + q.obs_count, my_lds, bminx, bminy, bmaxx, bmaxy,
+                                                    ox, oy, has1 ? 2 : (has0 ? 1 : 0));
+                const bool b0 = has0 && (m & 1u), b1 = has1 && (m & 2u);
+                nobs += (b0 ? 1 : 0) + (b1 ? 1 : 0);
+                f0 |= b0 ? FCPP_FLAG_OBSTACLE : 0u;
+                f1 |= b1 ? FCPP_FLAG_OBSTACLE : 0u;
+            }
+            // chunk-local point 0 is the line's first point only in the run's first chunk (has_start)
+            const double k0 = (has_start && j == 0) ? k_start : 0.0, k1 = (has_start && j + 1 == 0) ? k_start : 0.0;
+            store_pair(has0, has1, g0 + j, px0, px1, py0, py1, k0, k1, vnom, f0, f1, xo, yo, ko, vo, fso);
+        }
+    }
+    if (__ballot(nout | nobs)) {   // integer counts: the order of the additions does not matter
+        const long long io = wave_sum_i(nout), ib = wave_sum_i(nobs);
+        if (lane == 0 && io) atomicAdd(sink_outside, (unsigned long long)io);
+        if (lane == 0 && ib) atomicAdd(sink_obstacle, (unsigned long long)ib);
+    }
+}
+
+// length / time statistics of one quiet run in closed form (count x step; a span: per pass the line's steps and the turn shape's own
+// totals).  The flag counts of the run's points are not part of it (k_plan_quiet / k_plan_field count them while storing).
+__device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, const DevTile &tl, const DevField *__restrict__ fields,
+                                                         const DevPrim *__restrict__ prims, const DevConst &cst)
+{
+    TilePartial tp;
+    tp.main_len = tp.main_time_pre = tp.main_time = tp.head_len = tp.head_time_pre = tp.head_time = 0.0;
+    tp.max_kappa = tp.max_alat = tp.max_jump = 0.0;
+    tp.n_viol = 0; tp.n_outside = 0; tp.n_in_obstacle = 0; tp.n_adjusted = 0;
+    if (tl.quiet == 4) {
+        // a span of whole passes: per pass the line's n_line - 1 steps and the turn shape's own totals (the turn's first segment has
+        // length 0: it starts on the line's end); every pass but the path's first starts with the jump from the previous turn
+        const DevField &q = fields[tl.field];
+        const int v = q.reverse_order ? 1 : 0;
+        const int per = q.n_line + q.n_turn;
+        const double n_pass = (double)(run.count / per), n_jump = n_pass - (tl.idx0 == 0 ? 1.0 : 0.0);
+        const double line_len = (double)(q.n_line - 1) * fabs(q.line_step);
+        const double2 junc = cst.field_junc[tl.field];
+        const double jl = n_jump > 0.0 ? junc.y : 0.0, k0 = n_jump > 0.0 ? junc.x : 0.0;
+        tp.main_len = n_pass * (line_len + cst.turn_len) + n_jump * jl;
+        tp.main_time_pre = tp.main_time = n_pass * (line_len / fmax(cst.ms_work, 0.1) + cst.turn_time) +
+                                          n_jump * (jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1));     // MLP:1305-1309
+        tp.max_kappa = fmax(cst.turn_max_kappa[v], k0);
+        tp.max_alat = fmax(cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v], cst.ms_work * cst.ms_work * k0);
+        tp.max_jump = fmax(cst.turn_max_jump[v], n_jump > 0.0 ? fmax(fabs(k0 - cst.turn_kappa_last[v]), k0) : 0.0);
+    } else     if (tl.quiet == 3) {            // a whole U-turn: the shape's own totals (its first segment has length 0: the turn starts on the line's end)
+        const int v = fields[tl.field].reverse_order ? 1 : 0;
+        tp.main_len = cst.turn_len; tp.main_time_pre = tp.main_time = cst.turn_time;
+        tp.max_kappa = cst.turn_max_kappa[v]; tp.max_alat = cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v];
+        tp.max_jump = cst.turn_max_jump[v];
+    } else {
+        double step_len, msnom;
+        int layer;
+        if (tl.quiet == 1) { step_len = fabs(fields[tl.field].line_step); msnom = cst.ms_work; layer = 0; }
+        else {
+            const DevPrim &p = prims[tl.idx0];
+            const double sx = p.a[4], sy = p.a[5];
+            step_len = (sy == 0.0) ? fabs(sx) : ((sx == 0.0) ? fabs(sy) : sqrt(sx * sx + sy * sy));
+            msnom = nominal_ms(p.fs, cst); layer = 1;
+        }
+        // one segment of one step per point: a run's first segment comes from its left neighbour on the same straight -- unless the
+        // run starts the line (off0 = 0, swath lines between quiet U-turns): then it is the jump from the previous turn's end, or
+        // nothing at all for the path's first point
+        const bool at_line_start = tl.quiet == 1 && tl.off0 == 0;
+        double len = (double)(at_line_start ? run.count - 1 : run.count) * step_len, t = len / fmax(msnom, 0.1);
+        if (at_line_start && tl.idx0 > 0) {
+            const DevField &q = fields[tl.field];
+            const double k0 = cst.field_junc[tl.field].x, jl = cst.field_junc[tl.field].y;
+            len += jl;
+            t += jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1);        // MLP:1305-1309: mean of the two end speeds
+            tp.max_kappa = k0; tp.max_alat = cst.ms_work * cst.ms_work * k0;
+            tp.max_jump = fmax(fabs(k0 - cst.turn_kappa_last[q.reverse_order ? 1 : 0]), k0);
+        }
+        tp.main_len = layer ? 0.0 : len; tp.main_time_pre = layer ? 0.0 : t; tp.main_time = layer ? 0.0 : t;
+        tp.head_len = layer ? len : 0.0; tp.head_time_pre = layer ? t : 0.0; tp.head_time = layer ? t : 0.0;
+    }
+    return tp;
+}
+
+}  // namespace fcpp

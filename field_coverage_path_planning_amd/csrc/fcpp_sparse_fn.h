@@ -1,0 +1,147 @@
+// fcpp_sparse_fn.h -- one wave tile of the sparse-sampling path as a device function (see fcpp_sparse.hip for the method): used by
+// k_plan_sparse (one wave tile per wavefront, statistics per tile) and by k_plan_field (fcpp_field.hip: all the tiles of a field in
+// one workgroup, statistics per field).
+#pragma once
+#include "fcpp_pointfn.h"
+
+namespace fcpp {
+
+// per-lane running statistics of the tiles a wavefront has planned, and its flag counts (wave-uniform)
+struct SparseAcc {
+    double s_len[2], s_tpre[2], s_t[2], mk, ma, mj;
+    int c_viol, c_out, c_obs, c_adj;
+    __device__ __forceinline__ void clear()
+    {
+        s_len[0] = s_len[1] = s_tpre[0] = s_tpre[1] = s_t[0] = s_t[1] = mk = ma = mj = 0.0;
+        c_viol = c_out = c_obs = c_adj = 0;
+    }
+};
+
+// obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles)
+__device__ __forceinline__ void sparse_tile(const DevTile &tl, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
+                                            const DevObstacles &obs, double *obs_lds, double *__restrict__ xo, double *__restrict__ yo,
+                                            double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso, SparseAcc &acc)
+{
+    const int lane = threadIdx.x & 63;
+    const int Hb = tl.stat_tile & 0xffff, Hf = (tl.stat_tile >> 16) & 0xffff;
+    const int nl = Hb + tl.count + Hf;                       // active lanes
+    const int64_t n = f.n_total, n_main = f.n_main, first = tl.start - Hb;
+    const int64_t i = first + lane;
+    const bool act = lane < nl && i >= 0 && i < n;
+    const bool out = lane >= Hb && lane < Hb + tl.count;
+
+    // ---- 1. the lane's point --------------------------------------------------------------------------------------------------
+    double px = 0.0, py = 0.0;
+    uint32_t fw = 0;
+    if (act) {
+        if (i < n_main) {       // layer 1: (pass, offset) from the tile's host-side decode of its first lane
+            const unsigned per = (unsigned)(f.n_line + f.n_turn);
+            const unsigned off = (unsigned)tl.off0 + (unsigned)lane, q = off / per;
+            eval_main(f, cst, tl.idx0 + (int)q, (int)(off - q * per), px, py, fw);
+        } else {                // layer 2: the tile's first primitive is known, a wave tile spans at most 8 more
+            const int plast = f.prim_first + f.prim_count - 1;
+            const int p0 = first >= n_main ? tl.idx0 : f.prim_first;
+            int pi = p0;
+#pragma unroll
+            for (int k = 1; k <= 8; ++k) {
+                const int pk = min(p0 + k, plast);                                  // (wave-uniform: scalar loads)
+                pi += (p0 + k <= plast && i >= prims[pk].start) ? 1 : 0;
+            }
+            const DevPrim &p = prims[pi];
+            eval_prim(p, cst, (int)(i - p.start), px, py);
+            fw = p.fs;
+        }
+    }
+    const double vn = nominal_speed(fw, cst), msn = nominal_ms(fw, cst);
+
+    // ---- 2. chords, curvature (MLP:513-536), clamp (MLP:490-504) ----------------------------------------------------------------
+    const double xm = lane_prev(px), ym = lane_prev(py), xp = lane_next(px), yp = lane_next(py);
+    const bool has_prev = act && lane > 0 && i > 0;
+    const double dx1 = px - xm, dy1 = py - ym;
+    const double dprev = has_prev ? seg_len(dx1, dy1) : 0.0;                 // |p_i - p_(i-1)|
+    const double dnext = lane_next(dprev);
+    const bool interior = has_prev && lane < nl - 1 && i < n - 1;            // both neighbours are lanes of this wave
+    double kappa = 0.0;
+    if (interior) kappa = curv_chords(dx1, dy1, dprev, xp - px, yp - py, dnext);
+    bool cl = false;
+    double v0 = vn;
+    if (kappa > 1e-6) v0 = clamped_speed(vn, kappa, cst, cl);
+    const double ms0 = cl ? v0 / 3.6 : msn;
+    const double u0 = act ? ms0 * ms0 : FCPP_INF;
+
+    // ---- 3. sweeps (MLP:538-589) as min-plus scans over the lanes; skipped when no single step binds ----------------------------
+    // w = coupling of segment (i-1, i); +inf: nothing propagates (skipped step, the wave's first lane, the path's first point)
+    const double two_a = 2 * cst.a_lon;
+    const double w = !act ? 0.0 : ((!has_prev || dprev < 1e-6) ? FCPP_INF : two_a * dprev);
+    const double u0m = lane_prev(u0);
+    const bool binds = has_prev && w < FCPP_INF && (u0m + w < u0 || u0 + w < u0m);
+    double u = u0;
+    if (__ballot(binds) != 0ull) {
+        Agg fi = { u0, w };
+        double wn = lane_next(w);                      // coupling to the next lane
+        if (lane >= nl - 1) wn = act ? FCPP_INF : 0.0;
+        Agg bi = { u0, wn };
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            Agg pf = { __shfl_up(fi.c, o), __shfl_up(fi.w, o) };
+            Agg pb = { __shfl_down(bi.c, o), __shfl_down(bi.w, o) };
+            if (lane >= o) fi = combine_after(pf, fi);
+            if (lane + o < 64) bi = combine_after(pb, bi);
+        }
+        u = fmin(fi.c, bi.c);
+    }
+    // untouched points keep exactly their clamped / nominal value
+    const double vfin = (u < u0) ? sqrt(u) * 3.6 : (cl ? v0 : vn);
+
+    // ---- 4. validation flags ------------------------------------------------------------------------------------------------------
+    bool o_out = false, o_obs = false, o_viol = false;
+    if (out) {
+        const double ntol = -cst.geofence_tol;
+        bool o = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o = o | (f.ex[e] * px + f.ey[e] * py + f.eo[e] < ntol);
+        if (o) { fw |= FCPP_FLAG_OUTSIDE; o_out = true; }
+    }
+    if (f.obs_count > 0) {      // wave-uniform: bounding box of the wave's output points, then culled + LDS-staged polygon tests
+        double mnx = out ? px : FCPP_INF, mxx = out ? px : -FCPP_INF, mny = out ? py : FCPP_INF, mxy = out ? py : -FCPP_INF;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = fmin(mnx, __shfl_xor(mnx, o)); mny = fmin(mny, __shfl_xor(mny, o));
+            mxx = fmax(mxx, __shfl_xor(mxx, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+        }
+        const double ox[1] = { px }, oy[1] = { py };
+        const unsigned m = obstacle_mask<1>(obs, f.obs_first, f.obs_first + f.obs_count, obs_lds, mnx, mny, mxx, mxy, ox, oy, out ? 1 : 0);
+        if (out && (m & 1u)) { fw |= FCPP_FLAG_OBSTACLE; o_obs = true; }
+    }
+
+    // ---- 5. metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) on the output lanes ---------------------------------------
+    const double vprev = lane_prev(vfin), kprev = lane_prev(kappa), vnprev = lane_prev(vn);
+    if (out && i > 0 && i != n_main) {                      // the seam main|headland belongs to neither layer
+        const int layer = i > n_main ? 1 : 0;
+        const double ms_pre = (vnprev == vn) ? msn : ((vnprev + vn) / 2) / 3.6;
+        const double tpre = dprev / fmax(ms_pre, 0.1);
+        const double t = (vprev == vnprev && vfin == vn) ? tpre : dprev / fmax(((vprev + vfin) / 2) / 3.6, 0.1);
+        acc.s_len[layer] += dprev; acc.s_tpre[layer] += tpre; acc.s_t[layer] += t;
+    }
+    if (out && i > 0 && i < n - 1) {                        // interior points of the path
+        if (kappa > 0.0) {
+            // (v / 3.6)^2 kappa with the final speed: an untouched point's v / 3.6 is ms0 (the clamped value / 3.6, or the tabulated nominal one)
+            const double ms = (u < u0) ? vfin / 3.6 : ms0, alat = ms * ms * kappa;
+            acc.mk = fmax(acc.mk, kappa); acc.ma = fmax(acc.ma, alat);
+            if (alat > cst.a_lat) { o_viol = true; fw |= FCPP_FLAG_ALAT; }
+        }
+        if (kappa != kprev && i != 1) acc.mj = fmax(acc.mj, fabs(kappa - kprev));          // |kappa_i - kappa_(i-1)| for i >= 2 (MLP:1404-1406)
+    }
+
+    // ---- 6. stores: consecutive lanes, consecutive addresses ------------------------------------------------------------------------
+    if (out) {
+        const int64_t g = f.pt_off + i;
+        xo[g] = px; yo[g] = py; ko[g] = kappa; vo[g] = vfin; fso[g] = fw;
+    }
+
+    // the flag counts are one bit per lane: population counts of ballots
+    acc.c_viol += __popcll(__ballot(o_viol)); acc.c_out += __popcll(__ballot(o_out)); acc.c_obs += __popcll(__ballot(o_obs));
+    acc.c_adj += __popcll(__ballot(out && cl));
+}
+
+}  // namespace fcpp
