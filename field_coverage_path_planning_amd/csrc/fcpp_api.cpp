@@ -152,9 +152,10 @@ struct Tiling {
     // plus one lane for the stencil of the outermost point; forwards likewise from the last output.  Every tile takes as many
     // outputs as fit.  false = some tile would hold fewer than 8 outputs (dense sampling): the stretch stays with k_plan_fused.
     static constexpr int WAVE_HALO_MAX = 40;
-    static constexpr int WAVE_LANES = 64;                // fcpp_sparse.hip: one wavefront
+    static constexpr int WAVE_LANES = 64;                // fcpp_sparse.hip: one wavefront per wave tile
     mutable int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };   // diagnostics (FCPP_DEBUG_TILING): stretches that did not fit, by reason
     mutable std::vector<double> wave_d;                  // scratch: step lengths of the stretch and its surroundings
+    mutable std::vector<DevWaveTile> wtiles;             // the wave tiles' records, in the order of their DevTile entries
     bool wave_tiles(int64_t p, const QuietInfo &q, int64_t a, int64_t b, std::vector<DevTile> &out) const
     {
         const DevField &f = *q.df;
@@ -205,10 +206,10 @@ struct Tiling {
                 if (m - e > WAVE_HALO_MAX) return -1;
             }
         };
-        const size_t mark = out.size();
+        const size_t mark = out.size(), mark_w = wtiles.size();
         for (int64_t s = a; s < b;) {
             const int Hb = back_halo(s);
-            if (Hb < 0) { ++wave_fail[0]; out.resize(mark); return false; }
+            if (Hb < 0) { ++wave_fail[0]; out.resize(mark); wtiles.resize(mark_w); return false; }
             // the largest count whose forward halo still fits
             int64_t c = std::min<int64_t>(b - s, WAVE_LANES - Hb);
             int Hf = -1;
@@ -216,21 +217,30 @@ struct Tiling {
                 Hf = fwd_halo(s + c - 1);
                 if (Hf >= 0 && Hb + c + Hf <= WAVE_LANES) break;
             }
-            if (c < std::min<int64_t>(8, b - s)) { ++wave_fail[Hf < 0 ? 1 : 2]; out.resize(mark); return false; }
+            if (c < std::min<int64_t>(8, b - s)) { ++wave_fail[Hf < 0 ? 1 : 2]; out.resize(mark); wtiles.resize(mark_w); return false; }
             const int64_t first = s - Hb, last = s + c - 1 + Hf;
             DevTile t;
             t.field = (int32_t)p; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
             if (first < f.n_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
             else { t.idx0 = q.prim_index0 + prim_of(q, first); t.off0 = 0; }
-            // the kernel finds a lane's primitive among its 64-lane block's first one (that of the lane before the block) and the next 8
-            bool span_ok = true;
-            for (int64_t fk = first; fk <= last && span_ok; fk += 64) {
-                const int64_t lk = std::min<int64_t>(fk + 63, last);
-                if (lk < f.n_main) continue;
-                const int p0 = fk == first ? (first >= f.n_main ? prim_of(q, first) : 0) : (fk - 1 >= f.n_main ? prim_of(q, fk - 1) : 0);
-                span_ok = prim_of(q, lk) - p0 <= 8;
+            // the self-contained record: layer-1 decode of lane 0, and where the (at most 8) further primitives start among the lanes
+            DevWaveTile wt;
+            memset(&wt, 0, sizeof wt);
+            auto clampi = [](int64_t v) { return (int32_t)std::max<int64_t>(-2, std::min<int64_t>(v, (int64_t)1 << 30)); };
+            wt.out_base = f.pt_off + first; wt.field = (int32_t)p; wt.tile = (int32_t)out.size();
+            wt.count = (int32_t)c; wt.hb = Hb; wt.hf = Hf;
+            wt.rel_main = clampi(f.n_main - first); wt.rel_last = clampi(n - 1 - first); wt.first_is_0 = first == 0;
+            wt.idx0 = t.idx0; wt.off0 = t.off0;
+            for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
+            if (last >= f.n_main) {
+                const int64_t fl2 = std::max<int64_t>(first, f.n_main);        // first layer-2 point of the tile
+                const int pa = prim_of(q, fl2), pb = prim_of(q, last);
+                if (pb - pa > 8) { ++wave_fail[3]; out.resize(mark); wtiles.resize(mark_w); return false; }
+                wt.p0 = q.prim_index0 + pa;
+                wt.r0 = (int32_t)(first - q.prims[pa].start);
+                for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(q.prims[k].start - first);
             }
-            if (!span_ok) { ++wave_fail[3]; out.resize(mark); return false; }
+            wtiles.push_back(wt);
             out.push_back(t);
             s += c;
         }
@@ -251,6 +261,7 @@ struct Tiling {
         tile_first.assign((size_t)n_paths + 1, 0);
         pass_len.assign((size_t)n_paths, 0);
         tiles.clear();
+        wtiles.clear();
         for (int64_t p = 0; p < n_paths; ++p) {
             const int64_t n = offsets[p + 1] - offsets[p];
             paths[(size_t)p] = { offsets[p], n };
@@ -344,21 +355,15 @@ struct DevTiling {
     DevBuf<TilePartial> partial;
     DevBuf<unsigned long long> n_adj;
     DevBuf<int32_t> general_ids;   // fused pipeline: the tiles of k_plan_fused
-    DevBuf<int32_t> wave_ids;      // ... the wave tiles of k_plan_sparse
+    DevBuf<DevWaveTile> wave_tiles; // ... the wave tiles of k_plan_sparse (self-contained records)
     DevBuf<DevTile> chunks;        // ... the quiet runs cut on 512-point boundaries of the batch arrays (k_plan_quiet)
     DevBuf<DevTile> span_chunks;   // ... the same for the layer-1 spans (their own kernel instance)
     DevBuf<DevRun> runs;           // ... the quiet runs (k_quiet_run_stats)
     DevBuf<int32_t> stat_ids;      // ... the tiles that can hold statistics (general tiles, first tile of every run), path by path
     DevBuf<int64_t> stat_first;    //     CSR offsets into stat_ids per path
-    // simple fields (one span + wave tiles only): planned by k_plan_field, one workgroup per field, outside all the lists above
-    DevBuf<DevFieldWork> fwork;
-    DevBuf<DevTile> fchunks;       // their span chunks
-    DevBuf<int32_t> fwave_ids;     // their wave tiles
-    DevBuf<int32_t> path_list;     // the OTHER paths: the ones k_reduce_stats reduces
-    int64_t n_fwork = 0, n_path_list = 0, field_points = 0;
     int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_general = 0, n_wave = 0, quiet_points = 0;
     int64_t span_points = 0, chunk_points = 0, wave_points = 0;
-    hipError_t upload(const Tiling &t, hipStream_t st, bool field_kernel = false)
+    hipError_t upload(const Tiling &t, hipStream_t st)
     {
         n_tiles = (int64_t)t.tiles.size(); n_paths = (int64_t)t.paths.size();
         hipError_t e;
@@ -371,59 +376,18 @@ struct DevTiling {
         if ((e = carry_b.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
-        std::vector<int32_t> gv, sv, wv;
+        std::vector<int32_t> gv, sv;
         std::vector<int64_t> sf((size_t)n_paths + 1, 0);
         wave_points = 0;
-        std::vector<DevTile> cv, cs, fcs;
+        std::vector<DevTile> cv, cs;
         std::vector<DevRun> rv;
-        std::vector<DevFieldWork> fw;
-        std::vector<int32_t> fwv, plist;
-        quiet_points = 0; field_points = 0;
-        // simple paths: kind-4 tiles that continue each other from the path's start (one span), then wave tiles only
-        std::vector<unsigned char> simple((size_t)n_paths, 0);
-        for (int64_t p = 0; p < n_paths; ++p) {
-            const int64_t a0 = t.tile_first[(size_t)p], a1 = t.tile_first[(size_t)p + 1];
-            bool ok = field_kernel && a1 > a0;
-            bool in_span = true;
-            int64_t pos = 0, n_w = 0;
-            for (int64_t k = a0; k < a1 && ok; ++k) {
-                const DevTile &tk = t.tiles[(size_t)k];
-                if (tk.quiet == 4 && in_span && tk.start == pos) pos += tk.count;
-                else if (tk.quiet == 5) { in_span = false; ++n_w; }
-                else ok = false;
-            }
-            simple[(size_t)p] = ok && n_w > 0 && n_w < 32768;
-            if (!simple[(size_t)p]) plist.push_back((int32_t)p);
-        }
+        quiet_points = 0;
         for (size_t i = 0; i < t.tiles.size();) {
             const DevTile &t0 = t.tiles[i];
-            if (simple[(size_t)t0.field]) {
-                if (fw.empty() || fw.back().field != t0.field) fw.push_back({ t0.field, 0, (int32_t)fcs.size(), 0, (int32_t)fwv.size(), -1, 0 });
-                DevFieldWork &wk = fw.back();
-                if (t0.quiet == 5) { fwv.push_back((int32_t)i); ++wk.n_wave; field_points += t0.count; ++i; continue; }
-                // the span: its tiles continue each other; chunks on 512-point boundaries of the batch arrays
-                int64_t cnt = 0;
-                size_t j = i;
-                for (; j < t.tiles.size() && t.tiles[j].field == t0.field && t.tiles[j].quiet == 4; ++j) cnt += t.tiles[j].count;
-                wk.run_tile = (int32_t)i; wk.run_count = cnt;
-                const int64_t g0 = t.paths[(size_t)t0.field].off + t0.start, per = t.pass_len[(size_t)t0.field];
-                for (int64_t done = 0; done < cnt;) {
-                    const int64_t c = std::min<int64_t>(cnt - done, TILE_POINTS - ((g0 + done) % TILE_POINTS));
-                    DevTile ch = t0;
-                    ch.start = t0.start + done; ch.count = (int32_t)c; ch.stat_tile = (int32_t)i; ch.quiet = 4;
-                    ch.idx0 = (int32_t)(ch.start / per); ch.off0 = (int32_t)(ch.start % per);
-                    fcs.push_back(ch);
-                    ++wk.n_chunks;
-                    done += c;
-                }
-                field_points += cnt; quiet_points += cnt;
-                i = j;
-                continue;
-            }
-            sv.push_back((int32_t)i);                 // a general tile, or the first tile of a run
+            sv.push_back((int32_t)i);                 // a general tile, the first tile of a run, or the first wave tile of a workgroup
             sf[(size_t)t0.field + 1] = (int64_t)sv.size();
             if (!t0.quiet) { gv.push_back((int32_t)i); ++i; continue; }
-            if (t0.quiet == 5) { wv.push_back((int32_t)i); wave_points += t0.count; ++i; continue; }
+            if (t0.quiet == 5) { wave_points += t0.count; ++i; continue; }       // (its record: t.wtiles)
             // the run: quiet tiles that continue each other on the same straight
             int64_t cnt = t0.count;
             size_t j = i + 1;
@@ -475,16 +439,11 @@ struct DevTiling {
             r = r1;
         }
         n_chunks = (int64_t)cv.size(); n_span_chunks = (int64_t)cs.size(); n_runs = (int64_t)rv.size(); n_general = (int64_t)gv.size();
-        n_wave = (int64_t)wv.size();
+        n_wave = (int64_t)t.wtiles.size();
         span_points = chunk_points = 0;
         for (const DevTile &c : cs) span_points += c.count;
         for (const DevTile &c : cv) chunk_points += c.count;
-        n_fwork = (int64_t)fw.size(); n_path_list = (int64_t)plist.size();
-        if ((e = fwork.upload(fw, st)) != hipSuccess) return e;
-        if ((e = fchunks.upload(fcs, st)) != hipSuccess) return e;
-        if ((e = fwave_ids.upload(fwv, st)) != hipSuccess) return e;
-        if ((e = path_list.upload(plist, st)) != hipSuccess) return e;
-        if ((e = wave_ids.upload(wv, st)) != hipSuccess) return e;
+        if ((e = wave_tiles.upload(t.wtiles, st)) != hipSuccess) return e;
         if ((e = chunks.upload(cv, st)) != hipSuccess) return e;
         if ((e = span_chunks.upload(cs, st)) != hipSuccess) return e;
         if ((e = runs.upload(rv, st)) != hipSuccess) return e;
@@ -524,7 +483,6 @@ struct fcpp_batch {
     DevBuf<CacShape> shapes;   // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
     DevBuf<double2> tmpl_u, tmpl_c, tmpl_u_dk;   // sampled turn templates (fcpp_fused.hip)
     DevBuf<double2> field_junc;                  // per field: line-start curvature and jump length after a U-turn
-    DevBuf<DevConst> cst_dev;                    // device copy of `cst` (k_plan_field reads its members on demand)
     DevBuf<double> seg;        // connector segments
     DevBuf<int32_t> seg_mask;
     // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
@@ -543,8 +501,8 @@ constexpr int kStages = 7;
 constexpr int kProfRuns = 256;
 const char *const kStageNames[2][kStages] = {
     { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine", "k_scan_apply", "k_validate", "k_reduce_stats" },
-    { "k_plan_field", "k_quiet_run_stats", "k_plan_quiet_spans", "k_plan_quiet", "k_plan_sparse", "k_plan_fused", "k_reduce_stats" } };
-const int kStageCount[2] = { 7, 7 };
+    { "k_quiet_run_stats", "k_plan_quiet_spans", "k_plan_quiet", "k_plan_sparse", "k_plan_fused", "k_reduce_stats", "" } };
+const int kStageCount[2] = { 7, 6 };
 }
 
 // Are the U-turns of this batch closed form?  A turn is a translate / mirror of the template t[0..nu); its neighbours are the
@@ -581,9 +539,9 @@ static bool closed_form_turns(const fcpp_vehicle &veh, const TurnTemplates &tt, 
         const double dj = sqrt(jx * jx + jy * jy);
         if (!(dj >= 1e-3) || d1 < 1e-6) return false;
         if (u_t + 2 * c.a_lon * dj < u_w * (1.0 + 1e-9)) return false;          // the sweeps must not bind across the jump
-        const double k_last = fabs(2 * atan2(c1x * jy - c1y * jx, c1x * jx + c1y * jy) / (d1 + dj));
+        const double k_last = fabs(2 * atan2_fd(c1x * jy - c1y * jx, c1x * jx + c1y * jy) / (d1 + dj));
         // first point of the next line: chords J and the line heading (-x after a right turn); its curvature is largest for step -> 0
-        const double k_first_max = fabs(2 * atan2(jx * 0.0 - jy * -1.0, jx * -1.0 + jy * 0.0) / dj);
+        const double k_first_max = fabs(2 * atan2_fd(jx * 0.0 - jy * -1.0, jx * -1.0 + jy * 0.0) / dj);
         if (k_last * q_t * q_t >= lim || k_first_max * q_w * q_w >= lim) return false;
         c.turn_kappa_last[v] = k_last;
         c.turn_max_kappa[v] = std::max(maxk, k_last);
@@ -806,7 +764,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
                 "primitive span %lld\n", til.tiles.size(), (long long)til.wave_fail[0], (long long)til.wave_fail[1],
                 (long long)til.wave_fail[2], (long long)til.wave_fail[3]);
     ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) &&
-        ok(b->til.upload(til, st, getenv("FCPP_FIELD_KERNEL") != nullptr)) &&
+        ok(b->til.upload(til, st)) &&
         ok(b->field_junc.alloc((size_t)n_fields));
     if (e == hipSuccess && n_fields > 0) {
         b->cst.field_junc = b->field_junc.p;
@@ -843,10 +801,6 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
             mask[(size_t)(n_fields + i)] = okf && in.end_kept;
         }
         ok(b->seg.upload(seg, st)) && ok(b->seg_mask.upload(mask, st)) && ok(hipStreamSynchronize(st));
-    }
-    if (e == hipSuccess) {      // the constants are complete now (templates, junctions): their device copy
-        std::vector<DevConst> cv(1, b->cst);
-        ok(b->cst_dev.upload(cv, st)) && ok(hipStreamSynchronize(st));
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // host vectors above die at scope exit
     if (e != hipSuccess) {
@@ -912,29 +866,27 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
             HIPCHK(hipMemsetAsync(t.partial.p, 0, (size_t)t.n_tiles * sizeof(TilePartial), st));
             b->partial_dirty = false;
         }
-        // simple fields (sparse sampling): one workgroup each, statistics included
-        STAGE(0, launch_plan_field(st, t.n_fwork, t.fwork.p, t.fchunks.p, t.fwave_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst_dev.p, obs,
-                                   b->obs_off.n > 0, x, y, kappa, v, fs, stats));
-        // Two streams inside the step: the closed-form runs and spans are HBM-bound (k_plan_quiet), the wave tiles and general tiles
-        // ALU-bound (k_plan_sparse, k_plan_fused: ~97 % VALU utilisation, profiles/).  Side by side the two kinds fill each other's
-        // idle units; the reduction waits for both.  (Only when both kinds have enough work to pay for the two stream hand-offs.)
+        // Two streams inside the step where the general tiles are few and long-lived (dense sampling: a handful of tiles that walk
+        // long halos, e.g. cfg3's 5873 points in 0.37 ms): beside the HBM-bound streaming kernel they cost nothing (cfg3 0.87 -> 0.51
+        // ms).  Not at sparse sampling: k_plan_sparse and the span kernel both live on vector-instruction issue (profiles/: SQ
+        // counters) and only slow each other down side by side (measured: cfg5 2.66 vs 2.64 ms, cfg1 x 4096 0.134 vs 0.126 ms).
         hipStream_t sd = st;
-        const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_wave + t.n_general > 0;
+        const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_wave == 0;
         if (two) {
             sd = b->ctx->side;
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(sd, b->ctx->ev_fork, 0));
         }
-        STAGE(4, launch_plan_sparse(sd, t.n_wave, t.wave_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
-        STAGE(5, launch_plan_fused(sd, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
+        STAGE(3, launch_plan_sparse(sd, t.n_wave, t.wave_tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(4, launch_plan_fused(sd, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
                                    y, kappa, v, fs, t.partial.p));
         if (two) HIPCHK(hipEventRecord(b->ctx->ev_join, sd));
-        STAGE(1, launch_quiet_run_stats(st, t.n_runs, t.runs.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, t.partial.p));
-        STAGE(2, launch_plan_quiet(st, t.n_span_chunks, t.span_chunks.p, 16, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(0, launch_quiet_run_stats(st, t.n_runs, t.runs.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, t.partial.p));
+        STAGE(1, launch_plan_quiet(st, t.n_span_chunks, t.span_chunks.p, 16, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
-        STAGE(3, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(2, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
-        STAGE(6, launch_reduce_stats(st, t.n_path_list, t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.path_list.p));
+        STAGE(5, launch_reduce_stats(st, t.n_paths, t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p));
         if (ev) ++b->prof_runs;
         return FCPP_OK;
     }
@@ -992,8 +944,7 @@ int fcpp_batch_stage_points(const fcpp_batch *b, int mode, int stage, int64_t *p
     const DevTiling &t = b->til;
     const int64_t all = b->hp.total_points;
     if (mode == 0) { *points = all; return FCPP_OK; }         // every staged kernel sees every point
-    const int64_t per_stage[7] = { t.field_points, t.span_points + t.chunk_points, t.span_points, t.chunk_points, t.wave_points,
-                                   all - t.quiet_points - t.wave_points - (t.field_points - (t.quiet_points - t.span_points - t.chunk_points)), all - t.field_points };
+    const int64_t per_stage[6] = { t.quiet_points, t.span_points, t.chunk_points, t.wave_points, all - t.quiet_points - t.wave_points, all };
     *points = per_stage[stage];
     return FCPP_OK;
 }

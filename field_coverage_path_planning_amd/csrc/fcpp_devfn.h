@@ -120,7 +120,7 @@ __device__ __forceinline__ double curvature3(double x1, double y1, double x2, do
     if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
     // atan2(sin(t2 - t1), cos(t2 - t1)) of the two headings == signed angle between the two chords
     const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
-    const double dth = atan2(cr, dt);
+    const double dth = atan2_fd(cr, dt);
     return fabs(2 * dth / (ds1 + ds2));
 }
 
@@ -226,9 +226,9 @@ __device__ __forceinline__ double nominal_speed(uint32_t fs, const DevConst &c)
     }
 }
 
-// out-of-line atan2 for the fused kernel: only turn points reach it, and keeping it out of the unrolled per-item loops keeps
-// that kernel's register budget sane
-__device__ __noinline__ double atan2_slow(double y, double x) { return atan2(y, x); }
+// out-of-line copy of atan2_fd (fcpp_geom.h) for the eight-points-per-lane kernel's halo code: only turn points reach it, and keeping
+// it out of that kernel's unrolled per-item loops keeps its register budget sane
+__device__ __noinline__ double atan2_slow(double y, double x) { return atan2_fd(y, x); }
 
 __device__ __forceinline__ double nominal_ms(uint32_t fs, const DevConst &c)
 {

@@ -57,24 +57,17 @@ int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
 int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
                     const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
-// path_list (optional): the paths to reduce (n_paths of them); the others' stats records are left alone
 int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
-                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr,
-                        const int32_t *path_list = nullptr);
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr);
 int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc);
 // ids: tile indices the launch covers (NULL = all tiles in order)
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,
                       const DevField *fields, const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x,
                       double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial);
-// ids: the wave tiles (DevTile.quiet == 5: start / count = the output points, stat_tile = Hb | Hf << 16, idx0 / off0 = layer-1 decode or
-// first primitive of the tile's first lane)
-int launch_plan_sparse(hipStream_t st, int64_t n_ids, const int32_t *ids, const DevTile *tiles, const DevField *fields, const DevPrim *prims,
+// one wavefront per wave tile; statistics go to partial[wtiles[k].tile]
+int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtiles, const DevField *fields, const DevPrim *prims,
                        const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
                        TilePartial *partial);
-// one workgroup per simple field (fcpp_field.hip); writes stats[work[k].field] itself
-int launch_plan_field(hipStream_t st, int64_t n_work, const DevFieldWork *work, const DevTile *chunks, const int32_t *wave_ids,
-                      const DevTile *tiles, const DevField *fields, const DevPrim *prims, const DevConst *cst_dev, const DevObstacles &obs,
-                      bool any_obstacles, double *x, double *y, double *kappa, double *v, uint32_t *fs, fcpp_field_stats *stats);
 int launch_distance_matrix(hipStream_t st, int n, const double *x, const double *y, double *D);
 int launch_best_connections(hipStream_t st, int64_t n_pairs, const int64_t *fo, const int64_t *to, const double *fx, const double *fy,
                             const double *tx, const double *ty, int32_t *bf, int32_t *bt, double *bd);

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
             for (int q = 0; q < FIPT; ++q)
                 if (q == kh) { x0 = X[q]; y0 = Y[q]; x1 = X[q + 1]; y1 = Y[q + 1]; x2 = X[q + 2]; y2 = Y[q + 2]; dsum = d[q] + d[q + 1]; }
             const double dx1 = x1 - x0, dy1 = y1 - y0, dx2 = x2 - x1, dy2 = y2 - y1;
-            const double kk = fabs(2 * atan2(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / dsum);
+            const double kk = fabs(2 * atan2_fd(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / dsum);
 #pragma unroll
             for (int q = 0; q < FIPT; ++q) if (q == kh) kap[q] = kk;
         }

@@ -18,6 +18,36 @@ namespace fcpp {
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kHalfPi = 1.57079632679489661923;
 
+// atan2(y, x) for finite arguments that are not both zero, without the special-case ladder of a library routine: ONE division and an
+// odd polynomial.  Method of fdlibm's atan (Sun Microsystems' freely distributable math library; published algorithm and
+// coefficients): t = |y| / |x| is reduced at the break points 7/16, 11/16, 19/16, 39/16 to
+//     t' = (2t - 1)/(2 + t), (t - 1)/(t + 1), (t - 1.5)/(1 + 1.5 t), -1/t      with atan t = atan(c) + atan t', c = 1/2, 1, 3/2, inf,
+// here formed directly from |y| and |x| -- (2|y| - |x|) / (2|x| + |y|) and so on -- so that the quotient y/x itself is never taken;
+// |t'| <= 7/16 then goes through the degree-11 polynomial in t'^2.  Error < 1.5 ulp.  Every kernel takes curvature angles from this
+// one function (the turning angles of MLP:513-536 that are too large for the short series of curv_chords_fast), so results do not
+// depend on which kernel plans a point.
+FCPP_HD double atan2_fd(double y, double x)
+{
+    const double a = fabs(y), b = fabs(x);
+    // class of t = a / b (products instead of the quotient: a point within rounding of a break point may fall on either side, both
+    // sides being valid reductions)
+    const bool c0 = a < 0.4375 * b, c1 = a < 0.6875 * b, c2 = a < 1.1875 * b, c3 = a < 2.4375 * b;
+    double num, den, hi, lo;
+    if (c0)      { num = a;            den = b;            hi = 0.0;                          lo = 0.0; }
+    else if (c1) { num = 2.0 * a - b;  den = 2.0 * b + a;  hi = 4.63647609000806093515e-01;   lo = 2.26987774529616870924e-17; }
+    else if (c2) { num = a - b;        den = a + b;        hi = 7.85398163397448278999e-01;   lo = 3.06161699786838301793e-17; }
+    else if (c3) { num = a - 1.5 * b;  den = b + 1.5 * a;  hi = 9.82793723247329054082e-01;   lo = 1.39033110312309984516e-17; }
+    else         { num = -b;           den = a;            hi = 1.57079632679489655800e+00;   lo = 6.12323399573676603587e-17; }
+    const double t = num / den, z = t * t, w = z * z;
+    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                                                  9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
+    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                                        -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+    double r = hi - ((t * (s1 + s2) - lo) - t);                 // atan(|y| / |x|) in [0, pi/2]
+    if (x < 0.0) r = 3.14159265358979311600e+00 - (r - 1.22464679914735317720e-16);
+    return y < 0.0 ? -r : r;
+}
+
 // unit-curvature clothoid-arc-clothoid shape for one heading change D (pi or pi/2) and clothoid share f
 struct CacShape {
     double D, Lc, La, T;  // heading change, clothoid length, arc length, total (all at kappa_max = 1)

@@ -77,14 +77,24 @@ struct DevRun {
     int64_t count;       // points in the run
 };
 
-// Work of one "simple" field (fcpp_field.hip: one workgroup plans the whole field): its span chunks, its wave tiles, its span run.
-struct DevFieldWork {
+// A wave tile of the sparse kernel (fcpp_sparse.hip) as ONE self-contained 64-byte record: everything the wavefront needs to place
+// its 64 lanes on the path, so that after this single fetch the field's geofence, the primitives and the turn template samples are
+// all loaded side by side (the kernel is latency-bound on its dependent loads otherwise).  Lane l holds path point first + l.
+struct DevWaveTile {
+    int64_t out_base;        // index of lane 0's point in the batch arrays (pt_off + first)
     int32_t field;
-    int32_t n_chunks, chunk_first;   // chunks of the field's layer-1 span in the field-kernel's chunk list
-    int32_t n_wave, wave_first;      // its wave tiles in the field-kernel's wave-tile id list
-    int32_t run_tile;                // first tile of the span's run (closed-form statistics), -1: no span
-    int64_t run_count;               // points in that run
+    int32_t tile;            // the tile's index in the tile table = its slot in the partial statistics
+    int32_t count;           // output lanes ...
+    int32_t hb, hf;          // ... after hb halo lanes and before hf halo lanes (hb + count + hf <= 64)
+    int32_t rel_main;        // n_main - first: lanes below it lie in layer 1 (clamped to [-2, 1 << 30])
+    int32_t rel_last;        // (n_total - 1) - first: the lane of the path's last point (clamped likewise)
+    int32_t first_is_0;      // lane 0 is the path's first point
+    int32_t idx0, off0;      // layer 1: (pass position, offset in the pass) of lane 0
+    int32_t p0;              // layer 2: primitive (batch-wide index) of the first layer-2 lane ...
+    int32_t r0;              // ... and that lane's sample index in it is  lane + r0
+    uint8_t thr[8];          // lane at which primitive p0 + 1 + k starts (255 = not in this tile)
 };
+static_assert(sizeof(DevWaveTile) == 64, "DevWaveTile is fetched as one 64-byte record");
 
 // batch-wide turn templates: every field of a batch shares the vehicle and the sampling options, hence the number of
 // samples and the shape of its U-turns (nu) and corner turns (nc)

@@ -299,12 +299,10 @@ __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ 
 __global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_paths, const int64_t *__restrict__ tile_first,
                                                      const TilePartial *__restrict__ partial,
                                                      const unsigned long long *__restrict__ n_adjusted,
-                                                     fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids,
-                                                     const int32_t *__restrict__ path_list)
+                                                     fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids)
 {
-    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);    // one wavefront per path, four per workgroup
-    if (slot >= n_paths) return;
-    const int64_t pth = path_list ? (int64_t)path_list[slot] : slot;
+    const int64_t pth = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wavefront per path, four per workgroup
+    if (pth >= n_paths) return;
     const int lane = threadIdx.x & 63;
     double a[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long b[4] = { 0, 0, 0, 0 };
@@ -549,11 +547,11 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
 }
 
 int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
-                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids, const int32_t *path_list)
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids)
 {
     if (n_paths <= 0) return 0;
     FCPP_LAUNCH(k_reduce_stats, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, n_paths, tile_first, partial,
-                       n_adjusted, stats, ids, path_list);
+                       n_adjusted, stats, ids);
     FCPP_LAUNCH_CHECK();
     return 0;
 }

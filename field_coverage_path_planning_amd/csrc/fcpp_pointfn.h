@@ -38,7 +38,7 @@ __device__ __forceinline__ double curv_chords_fast(double dx1, double dy1, doubl
     return fabs(2 * dth / (ds1 + ds2));
 }
 
-// the same with the atan2 fallback as an out-of-line call (halo recomputation: one call site, not eight)
+// the same with the atan2 fallback as an out-of-line call (halo recomputation of k_plan_fused: one call site, not eight)
 __device__ __forceinline__ double curv_chords(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)
 {
     bool slow;
@@ -175,6 +175,15 @@ __device__ __forceinline__ double wave_max0_to63(double v)
     v = fmax(v, dpp_mov<0x142, 0xa>(0.0, v));
     v = fmax(v, dpp_mov<0x143, 0xc>(0.0, v));
     return v;
+}
+
+// ... and with the fallback in line (one point per lane: fcpp_sparse_fn.h)
+__device__ __forceinline__ double curv_chords_inline(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)
+{
+    bool slow;
+    const double k = curv_chords_fast(dx1, dy1, ds1, dx2, dy2, ds2, slow);
+    if (!slow) return k;
+    return fabs(2 * atan2_fd(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / (ds1 + ds2));
 }
 
 // wave-wide reductions; a ballot skips the butterfly when every lane holds the neutral element (most tiles have

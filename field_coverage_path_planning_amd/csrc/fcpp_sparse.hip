@@ -22,22 +22,20 @@ namespace fcpp {
 
 static constexpr int SP_WAVES = 4;     // wave tiles per workgroup (independent of each other: no barrier)
 
-__global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const int32_t *__restrict__ ids, int64_t n_ids,
-                                                               const DevTile *__restrict__ tiles, const DevField *__restrict__ fields,
-                                                               const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
-                                                               double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
-                                                               double *__restrict__ vo, uint32_t *__restrict__ fso,
+__global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile *__restrict__ wtiles, int64_t n_wtiles,
+                                                               const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
+                                                               DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
+                                                               double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
                                                                TilePartial *__restrict__ partial)
 {
     __shared__ double obs_lds[SP_WAVES][2 * OBS_LDS_VERTS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * SP_WAVES + wave;
-    if (slot >= n_ids) return;
-    const int tile_id = ids[slot];
-    const DevTile tl = tiles[tile_id];
+    if (slot >= n_wtiles) return;
+    const DevWaveTile wt = wtiles[slot];
     SparseAcc acc;
     acc.clear();
-    sparse_tile(tl, fields[tl.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
+    sparse_tile(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
 
     // the tile's partial statistics (fixed butterfly => run-to-run identical sums)
     double dv[9] = { acc.s_len[0], acc.s_tpre[0], acc.s_t[0], acc.s_len[1], acc.s_tpre[1], acc.s_t[1], acc.mk, acc.ma, acc.mj };
@@ -51,17 +49,17 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const int32_t *__
         tp.head_len = dv[3]; tp.head_time_pre = dv[4]; tp.head_time = dv[5];
         tp.max_kappa = dv[6]; tp.max_alat = dv[7]; tp.max_jump = dv[8];
         tp.n_viol = acc.c_viol; tp.n_outside = acc.c_out; tp.n_in_obstacle = acc.c_obs; tp.n_adjusted = acc.c_adj;
-        partial[tile_id] = tp;
+        partial[wt.tile] = tp;
     }
 }
 
-int launch_plan_sparse(hipStream_t st, int64_t n_ids, const int32_t *ids, const DevTile *tiles, const DevField *fields, const DevPrim *prims,
+int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtiles, const DevField *fields, const DevPrim *prims,
                        const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
                        TilePartial *partial)
 {
-    if (n_ids <= 0) return 0;
-    FCPP_LAUNCH(k_plan_sparse, dim3((unsigned)((n_ids + SP_WAVES - 1) / SP_WAVES)), dim3(64 * SP_WAVES), 0, st, ids, n_ids, tiles, fields,
-                       prims, cst, obs, x, y, kappa, v, fs, partial);
+    if (n_wtiles <= 0) return 0;
+    FCPP_LAUNCH(k_plan_sparse, dim3((unsigned)((n_wtiles + SP_WAVES - 1) / SP_WAVES)), dim3(64 * SP_WAVES), 0, st, wtiles, n_wtiles, fields,
+                prims, cst, obs, x, y, kappa, v, fs, partial);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

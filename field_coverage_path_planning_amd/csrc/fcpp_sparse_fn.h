@@ -18,51 +18,55 @@ struct SparseAcc {
 };
 
 // obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles)
-__device__ __forceinline__ void sparse_tile(const DevTile &tl, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
+__device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
                                             const DevObstacles &obs, double *obs_lds, double *__restrict__ xo, double *__restrict__ yo,
                                             double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso, SparseAcc &acc)
 {
     const int lane = threadIdx.x & 63;
-    const int Hb = tl.stat_tile & 0xffff, Hf = (tl.stat_tile >> 16) & 0xffff;
-    const int nl = Hb + tl.count + Hf;                       // active lanes
-    const int64_t n = f.n_total, n_main = f.n_main, first = tl.start - Hb;
-    const int64_t i = first + lane;
-    const bool act = lane < nl && i >= 0 && i < n;
-    const bool out = lane >= Hb && lane < Hb + tl.count;
+    const int Hb = wt.hb, nl = wt.hb + wt.count + wt.hf;     // active lanes
+    const bool act = lane < nl;
+    const bool out = lane >= Hb && lane < Hb + wt.count;
+    // the lane's position on the path, relative to the tile's first lane (32-bit throughout)
+    const bool in_main = lane < wt.rel_main;                 // layer 1
+    const bool is_first = wt.first_is_0 && lane == 0;        // the path's first point
+    const bool is_last = lane == wt.rel_last;                // the path's last point
+    const bool at_seam = lane == wt.rel_main;                // first point of layer 2
+    const bool is_second = wt.first_is_0 && lane == 1;       // path index 1
 
     // ---- 1. the lane's point --------------------------------------------------------------------------------------------------
+    // Everything needed to address the point's data is in the tile record: primitive records, turn template samples and the field's
+    // geofence are fetched side by side, not one after the other.
     double px = 0.0, py = 0.0;
     uint32_t fw = 0;
-    if (act) {
-        if (i < n_main) {       // layer 1: (pass, offset) from the tile's host-side decode of its first lane
+    if (__ballot(act && in_main) != 0ull) {                  // (wave-uniform) layer 1: (pass, offset) from the host's decode of lane 0
+        if (act && in_main) {
             const unsigned per = (unsigned)(f.n_line + f.n_turn);
-            const unsigned off = (unsigned)tl.off0 + (unsigned)lane, q = off / per;
-            eval_main(f, cst, tl.idx0 + (int)q, (int)(off - q * per), px, py, fw);
-        } else {                // layer 2: the tile's first primitive is known, a wave tile spans at most 8 more
-            const int plast = f.prim_first + f.prim_count - 1;
-            const int p0 = first >= n_main ? tl.idx0 : f.prim_first;
-            int pi = p0;
-#pragma unroll
-            for (int k = 1; k <= 8; ++k) {
-                const int pk = min(p0 + k, plast);                                  // (wave-uniform: scalar loads)
-                pi += (p0 + k <= plast && i >= prims[pk].start) ? 1 : 0;
-            }
-            const DevPrim &p = prims[pi];
-            eval_prim(p, cst, (int)(i - p.start), px, py);
-            fw = p.fs;
+            const unsigned off = (unsigned)wt.off0 + (unsigned)lane, q = off / per;
+            eval_main(f, cst, wt.idx0 + (int)q, (int)(off - q * per), px, py, fw);
         }
+    }
+    if (act && !in_main) {                                   // layer 2: primitive and sample index from the record's lane thresholds
+        int pi = wt.p0, r = lane + wt.r0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int th = wt.thr[k];
+            if (lane >= th) { ++pi; r = lane - th; }
+        }
+        const DevPrim &p = prims[pi];
+        eval_prim(p, cst, r, px, py);
+        fw = p.fs;
     }
     const double vn = nominal_speed(fw, cst), msn = nominal_ms(fw, cst);
 
     // ---- 2. chords, curvature (MLP:513-536), clamp (MLP:490-504) ----------------------------------------------------------------
     const double xm = lane_prev(px), ym = lane_prev(py), xp = lane_next(px), yp = lane_next(py);
-    const bool has_prev = act && lane > 0 && i > 0;
+    const bool has_prev = act && lane > 0;                                    // (lane > 0 => not the path's first point)
     const double dx1 = px - xm, dy1 = py - ym;
     const double dprev = has_prev ? seg_len(dx1, dy1) : 0.0;                 // |p_i - p_(i-1)|
     const double dnext = lane_next(dprev);
-    const bool interior = has_prev && lane < nl - 1 && i < n - 1;            // both neighbours are lanes of this wave
+    const bool interior = has_prev && lane < nl - 1 && !is_last;             // both neighbours are lanes of this wave
     double kappa = 0.0;
-    if (interior) kappa = curv_chords(dx1, dy1, dprev, xp - px, yp - py, dnext);
+    if (interior) kappa = curv_chords_inline(dx1, dy1, dprev, xp - px, yp - py, dnext);
     bool cl = false;
     double v0 = vn;
     if (kappa > 1e-6) v0 = clamped_speed(vn, kappa, cst, cl);
@@ -116,26 +120,26 @@ __device__ __forceinline__ void sparse_tile(const DevTile &tl, const DevField &f
 
     // ---- 5. metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) on the output lanes ---------------------------------------
     const double vprev = lane_prev(vfin), kprev = lane_prev(kappa), vnprev = lane_prev(vn);
-    if (out && i > 0 && i != n_main) {                      // the seam main|headland belongs to neither layer
-        const int layer = i > n_main ? 1 : 0;
+    if (out && !is_first && !at_seam) {                     // the seam main|headland belongs to neither layer
+        const int layer = in_main ? 0 : 1;
         const double ms_pre = (vnprev == vn) ? msn : ((vnprev + vn) / 2) / 3.6;
         const double tpre = dprev / fmax(ms_pre, 0.1);
         const double t = (vprev == vnprev && vfin == vn) ? tpre : dprev / fmax(((vprev + vfin) / 2) / 3.6, 0.1);
         acc.s_len[layer] += dprev; acc.s_tpre[layer] += tpre; acc.s_t[layer] += t;
     }
-    if (out && i > 0 && i < n - 1) {                        // interior points of the path
+    if (out && !is_first && !is_last) {                     // interior points of the path
         if (kappa > 0.0) {
             // (v / 3.6)^2 kappa with the final speed: an untouched point's v / 3.6 is ms0 (the clamped value / 3.6, or the tabulated nominal one)
             const double ms = (u < u0) ? vfin / 3.6 : ms0, alat = ms * ms * kappa;
             acc.mk = fmax(acc.mk, kappa); acc.ma = fmax(acc.ma, alat);
             if (alat > cst.a_lat) { o_viol = true; fw |= FCPP_FLAG_ALAT; }
         }
-        if (kappa != kprev && i != 1) acc.mj = fmax(acc.mj, fabs(kappa - kprev));          // |kappa_i - kappa_(i-1)| for i >= 2 (MLP:1404-1406)
+        if (kappa != kprev && !is_second) acc.mj = fmax(acc.mj, fabs(kappa - kprev));          // |kappa_i - kappa_(i-1)| for i >= 2 (MLP:1404-1406)
     }
 
     // ---- 6. stores: consecutive lanes, consecutive addresses ------------------------------------------------------------------------
     if (out) {
-        const int64_t g = f.pt_off + i;
+        const int64_t g = wt.out_base + lane;
         xo[g] = px; yo[g] = py; ko[g] = kappa; vo[g] = vfin; fso[g] = fw;
     }
 
