@@ -358,9 +358,9 @@ struct DevTiling {
     DevBuf<DevWaveTile> wave_tiles; // ... the wave tiles of k_plan_sparse (self-contained records)
     DevBuf<DevTile> chunks;        // ... the quiet runs cut on 512-point boundaries of the batch arrays (k_plan_quiet)
     DevBuf<DevTile> span_chunks;   // ... the same for the layer-1 spans (their own kernel instance)
-    DevBuf<DevRun> runs;           // ... the quiet runs (k_quiet_run_stats)
     DevBuf<int32_t> stat_ids;      // ... the tiles that can hold statistics (general tiles, first tile of every run), path by path
     DevBuf<int64_t> stat_first;    //     CSR offsets into stat_ids per path
+    DevBuf<int64_t> stat_run;      //     per entry of stat_ids: points of the quiet run that starts there (0: not a run)
     int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_general = 0, n_wave = 0, quiet_points = 0;
     int64_t span_points = 0, chunk_points = 0, wave_points = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
@@ -377,6 +377,7 @@ struct DevTiling {
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
         std::vector<int32_t> gv, sv;
+        std::vector<int64_t> srun;
         std::vector<int64_t> sf((size_t)n_paths + 1, 0);
         wave_points = 0;
         std::vector<DevTile> cv, cs;
@@ -384,7 +385,8 @@ struct DevTiling {
         quiet_points = 0;
         for (size_t i = 0; i < t.tiles.size();) {
             const DevTile &t0 = t.tiles[i];
-            sv.push_back((int32_t)i);                 // a general tile, the first tile of a run, or the first wave tile of a workgroup
+            sv.push_back((int32_t)i);                 // a general tile, a wave tile, or the first tile of a run
+            srun.push_back(0);
             sf[(size_t)t0.field + 1] = (int64_t)sv.size();
             if (!t0.quiet) { gv.push_back((int32_t)i); ++i; continue; }
             if (t0.quiet == 5) { wave_points += t0.count; ++i; continue; }       // (its record: t.wtiles)
@@ -399,6 +401,7 @@ struct DevTiling {
                 cnt += tj.count;
             }
             rv.push_back({ (int32_t)i, 0, cnt });
+            srun.back() = cnt;
             quiet_points += cnt;
             i = j;
         }
@@ -446,11 +449,11 @@ struct DevTiling {
         if ((e = wave_tiles.upload(t.wtiles, st)) != hipSuccess) return e;
         if ((e = chunks.upload(cv, st)) != hipSuccess) return e;
         if ((e = span_chunks.upload(cs, st)) != hipSuccess) return e;
-        if ((e = runs.upload(rv, st)) != hipSuccess) return e;
         if ((e = general_ids.upload(gv, st)) != hipSuccess) return e;
         for (size_t p = 1; p < sf.size(); ++p) sf[p] = std::max(sf[p], sf[p - 1]);      // paths without tiles
         if ((e = stat_ids.upload(sv, st)) != hipSuccess) return e;
         if ((e = stat_first.upload(sf, st)) != hipSuccess) return e;
+        if ((e = stat_run.upload(srun, st)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the staging vectors die here
         return hipSuccess;
     }
@@ -486,7 +489,8 @@ struct fcpp_batch {
     DevBuf<double> seg;        // connector segments
     DevBuf<int32_t> seg_mask;
     // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
-    bool profiling = false;
+    int profiling = 0;           // 0: off; k > 0: every k-th run carries the per-kernel events
+    int64_t run_counter = 0;
     std::vector<hipEvent_t> events;   // kProfRuns x kStages x (start, stop)
     std::vector<unsigned char> ev_set; // kProfRuns x kStages: the stage launched a kernel in that run
     int prof_runs = 0;
@@ -501,8 +505,8 @@ constexpr int kStages = 7;
 constexpr int kProfRuns = 256;
 const char *const kStageNames[2][kStages] = {
     { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine", "k_scan_apply", "k_validate", "k_reduce_stats" },
-    { "k_quiet_run_stats", "k_plan_quiet_spans", "k_plan_quiet", "k_plan_sparse", "k_plan_fused", "k_reduce_stats", "" } };
-const int kStageCount[2] = { 7, 6 };
+    { "k_plan_quiet_spans", "k_plan_quiet", "k_plan_sparse", "k_plan_fused", "k_reduce_stats", "", "" } };
+const int kStageCount[2] = { 7, 5 };
 }
 
 // Are the U-turns of this batch closed form?  A turn is a translate / mirror of the template t[0..nu); its neighbours are the
@@ -849,7 +853,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     if (mode == 0) HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
     hipEvent_t *ev = nullptr;
     unsigned char *evs = nullptr;
-    if (b->profiling && b->prof_runs < kProfRuns) {
+    if (b->profiling > 0 && b->prof_runs < kProfRuns && (b->run_counter++ % b->profiling) == 0) {
         ev = &b->events[(size_t)b->prof_runs * kStages * 2];
         evs = &b->ev_set[(size_t)b->prof_runs * kStages];
     }
@@ -877,16 +881,16 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(sd, b->ctx->ev_fork, 0));
         }
-        STAGE(3, launch_plan_sparse(sd, t.n_wave, t.wave_tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
-        STAGE(4, launch_plan_fused(sd, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
+        STAGE(2, launch_plan_sparse(sd, t.n_wave, t.wave_tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(3, launch_plan_fused(sd, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
                                    y, kappa, v, fs, t.partial.p));
         if (two) HIPCHK(hipEventRecord(b->ctx->ev_join, sd));
-        STAGE(0, launch_quiet_run_stats(st, t.n_runs, t.runs.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, t.partial.p));
-        STAGE(1, launch_plan_quiet(st, t.n_span_chunks, t.span_chunks.p, 16, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(0, launch_plan_quiet(st, t.n_span_chunks, t.span_chunks.p, 16, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
-        STAGE(2, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(1, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
-        STAGE(5, launch_reduce_stats(st, t.n_paths, t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p));
+        STAGE(4, launch_reduce_stats(st, t.n_paths, t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.stat_run.p, t.tiles.p, b->fields.p,
+                                     b->prims.p, &b->cst));
         if (ev) ++b->prof_runs;
         return FCPP_OK;
     }
@@ -911,8 +915,8 @@ int fcpp_batch_set_profiling(fcpp_batch *b, int enable)
         b->ev_set.assign((size_t)kProfRuns * kStages, 0);
         for (hipEvent_t &e : b->events) HIPCHK(hipEventCreate(&e));
     }
-    b->profiling = enable != 0;
-    b->prof_runs = 0;
+    b->profiling = enable > 0 ? enable : 0;
+    b->prof_runs = 0; b->run_counter = 0;
     return FCPP_OK;
 }
 
@@ -944,7 +948,7 @@ int fcpp_batch_stage_points(const fcpp_batch *b, int mode, int stage, int64_t *p
     const DevTiling &t = b->til;
     const int64_t all = b->hp.total_points;
     if (mode == 0) { *points = all; return FCPP_OK; }         // every staged kernel sees every point
-    const int64_t per_stage[6] = { t.quiet_points, t.span_points, t.chunk_points, t.wave_points, all - t.quiet_points - t.wave_points, all };
+    const int64_t per_stage[5] = { t.span_points, t.chunk_points, t.wave_points, all - t.quiet_points - t.wave_points, all };
     *points = per_stage[stage];
     return FCPP_OK;
 }

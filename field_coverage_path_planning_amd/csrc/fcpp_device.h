@@ -57,8 +57,11 @@ int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
 int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
                     const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
-int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
-                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr);
+// ids / run_count: see k_reduce_stats; tiles, fields, prims, cst are only needed with run_count
+int launch_reduce_stats(hipStream_t st, int64_t n_paths, TilePartial *partial, const int64_t *tile_first,
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr,
+                        const int64_t *run_count = nullptr, const DevTile *tiles = nullptr, const DevField *fields = nullptr,
+                        const DevPrim *prims = nullptr, const DevConst *cst = nullptr);
 int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc);
 // ids: tile indices the launch covers (NULL = all tiles in order)
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,
@@ -76,8 +79,6 @@ int launch_field_junctions(hipStream_t st, int64_t n_fields, const DevField *fie
 int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, int kinds, const DevField *fields, const DevPrim *prims,
                       const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
                       TilePartial *partial);
-int launch_quiet_run_stats(hipStream_t st, int64_t n_runs, const DevRun *runs, const DevTile *tiles, const DevField *fields,
-                           const DevPrim *prims, const DevConst &cst, TilePartial *partial);
 int launch_straight(hipStream_t st, int64_t n_seg, const double *seg, int n_pts, const int32_t *mask, double *out);
 int launch_corner_turns(hipStream_t st, int64_t n, const double *corners, const int32_t *ci, const int32_t *rev, double R, double L,
                         double H, int stride, double *out, int32_t *counts);

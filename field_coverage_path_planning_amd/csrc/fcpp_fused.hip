@@ -214,18 +214,6 @@ __global__ void k_field_junctions(int64_t n_fields, const DevField *__restrict__
     junc[i] = o;
 }
 
-// length / time statistics of the quiet runs, one thread per run, credited to the run's first tile; the flag counts of the run's
-// points are added to the same slot by k_plan_quiet, which runs after this kernel
-__global__ __launch_bounds__(256) void k_quiet_run_stats(int64_t n_runs, const DevRun *__restrict__ runs, const DevTile *__restrict__ tiles,
-                                                           const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
-                                                           DevConst cst, TilePartial *__restrict__ partial)
-{
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_runs) return;
-    const DevRun run = runs[r];
-    partial[run.tile] = quiet_run_partial(run, tiles[run.tile], fields, prims, cst);
-}
-
 // the quiet path: one tile per wavefront, four per workgroup; pure HBM streaming at full occupancy
 template <int KINDS, bool SCALAR_DESC>
 __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
@@ -855,16 +843,6 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
     if (kinds == 16) FCPP_QUIET(16, true);
     else FCPP_QUIET(14, false);
 #undef FCPP_QUIET
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
-}
-
-int launch_quiet_run_stats(hipStream_t st, int64_t n_runs, const DevRun *runs, const DevTile *tiles, const DevField *fields,
-                           const DevPrim *prims, const DevConst &cst, TilePartial *partial)
-{
-    if (n_runs <= 0) return 0;
-    FCPP_LAUNCH(k_quiet_run_stats, dim3((unsigned)((n_runs + 255) / 256)), dim3(256), 0, st, n_runs, runs, tiles, fields, prims, cst,
-                       partial);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -21,7 +21,9 @@
 #include <math.h>
 #include <stdint.h>
 
-#include "fcpp_devfn.h"
+#include <string.h>
+
+#include "fcpp_quiet_fn.h"
 
 namespace fcpp {
 
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_apply(const DevTile *__restrict_
 // --------------------------------------------------------------------------------------------
 struct RedShared { double d[NWAVE][9]; long long i[NWAVE][3]; };
 
-static constexpr int OBS_LDS_VERTS = 1024;
+static constexpr int VAL_LDS_VERTS = 1024;   // (staged validator: one polygon staged per workgroup)
 
 __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ tiles,
                                                     const DevPath *__restrict__ paths,
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ 
                                                     TilePartial *__restrict__ partial)
 {
     __shared__ RedShared R;
-    __shared__ double ox[OBS_LDS_VERTS], oy[OBS_LDS_VERTS];
+    __shared__ double ox[VAL_LDS_VERTS], oy[VAL_LDS_VERTS];
     const DevTile t = tiles[blockIdx.x];
     const DevPath p = paths[t.field];
     const int64_t n_main = fields ? fields[t.field].n_main : p.n;
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ 
     if (fields && fields[t.field].obs_count > 0) {
         ob0 = fields[t.field].obs_first; ob1 = ob0 + fields[t.field].obs_count;
         ov0 = obs.offsets[ob0]; ov1 = obs.offsets[ob1];
-        obs_lds = (ov1 - ov0) <= OBS_LDS_VERTS;
+        obs_lds = (ov1 - ov0) <= VAL_LDS_VERTS;
         if (obs_lds)
             for (int k = threadIdx.x; k < (int)(ov1 - ov0); k += BLOCK) { ox[k] = obs.x[ov0 + k]; oy[k] = obs.y[ov0 + k]; }
         __syncthreads();
@@ -295,11 +297,16 @@ __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ 
 
 // one wave per path: lanes stride over the path's tiles in a fixed assignment, then a fixed butterfly
 // ids (optional): the reduction runs over partial[ids[k]], k in [tile_first[p], tile_first[p+1]) -- the fused pipeline lists only the
-// tiles that can hold statistics (general tiles and the first tile of every quiet run; the others stay zero)
+// tiles that can hold statistics (general tiles, wave tiles and the first tile of every quiet run; the others stay zero).
+// run_count (with ids): > 0 for the first tile of a quiet run of that many points: its length / time / curvature statistics are the
+// run's closed form (fcpp_quiet_fn.h), evaluated here; its partial slot only collects the flag counts k_plan_quiet adds while it
+// stores the run, and is cleared again for the next step.
 __global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_paths, const int64_t *__restrict__ tile_first,
-                                                     const TilePartial *__restrict__ partial,
+                                                     TilePartial *__restrict__ partial,
                                                      const unsigned long long *__restrict__ n_adjusted,
-                                                     fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids)
+                                                     fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids,
+                                                     const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
+                                                     const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst)
 {
     const int64_t pth = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wavefront per path, four per workgroup
     if (pth >= n_paths) return;
@@ -307,7 +314,17 @@ __global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_paths, const int
     double a[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long b[4] = { 0, 0, 0, 0 };
     for (int64_t t = tile_first[pth] + lane; t < tile_first[pth + 1]; t += 64) {
-        const TilePartial tp = partial[ids ? (int64_t)ids[t] : t];
+        const int64_t slot = ids ? (int64_t)ids[t] : t;
+        TilePartial tp = partial[slot];
+        const int64_t rc = run_count ? run_count[t] : 0;
+        if (rc > 0) {
+            const DevRun run = { (int32_t)slot, 0, rc };
+            const TilePartial rp = quiet_run_partial(run, tiles[slot], fields, prims, cst);
+            tp.main_len = rp.main_len; tp.main_time_pre = rp.main_time_pre; tp.main_time = rp.main_time;
+            tp.head_len = rp.head_len; tp.head_time_pre = rp.head_time_pre; tp.head_time = rp.head_time;
+            tp.max_kappa = rp.max_kappa; tp.max_alat = rp.max_alat; tp.max_jump = rp.max_jump;
+            if (tp.n_outside | tp.n_in_obstacle) { partial[slot].n_outside = 0; partial[slot].n_in_obstacle = 0; }
+        }
         a[0] += tp.main_len; a[1] += tp.main_time_pre; a[2] += tp.main_time;
         a[3] += tp.head_len; a[4] += tp.head_time_pre; a[5] += tp.head_time;
         a[6] = fmax(a[6], tp.max_kappa); a[7] = fmax(a[7], tp.max_alat); a[8] = fmax(a[8], tp.max_jump);
@@ -546,12 +563,15 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
     return 0;
 }
 
-int launch_reduce_stats(hipStream_t st, int64_t n_paths, const TilePartial *partial, const int64_t *tile_first,
-                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids)
+int launch_reduce_stats(hipStream_t st, int64_t n_paths, TilePartial *partial, const int64_t *tile_first,
+                        const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids, const int64_t *run_count,
+                        const DevTile *tiles, const DevField *fields, const DevPrim *prims, const DevConst *cst)
 {
     if (n_paths <= 0) return 0;
+    DevConst c0;
+    memset(&c0, 0, sizeof c0);
     FCPP_LAUNCH(k_reduce_stats, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, n_paths, tile_first, partial,
-                       n_adjusted, stats, ids);
+                       n_adjusted, stats, ids, run_count, tiles, fields, prims, cst ? *cst : c0);
     FCPP_LAUNCH_CHECK();
     return 0;
 }

@@ -288,8 +288,9 @@ class Batch:
         L.check(self.lib.fcpp_batch_connectors(self.handle, _ptr(ap), _ptr(dp)))
         return ap, dp
 
-    def set_profiling(self, on=True):
-        L.check(self.lib.fcpp_batch_set_profiling(self.handle, int(bool(on))))
+    def set_profiling(self, on=True, every=1):
+        """Per-kernel HIP-event timing of every `every`-th run() from now on (on=False: off)."""
+        L.check(self.lib.fcpp_batch_set_profiling(self.handle, int(every) if on else 0))
 
     def stage_times(self):
         """-> ({kernel name: mean ms per run}, runs) from the HIP events recorded since the last call."""

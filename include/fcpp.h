@@ -164,10 +164,11 @@ int fcpp_batch_run(fcpp_batch *batch, double *x_dev, double *y_dev, double *kapp
  * field at [field*100 .. +100); rows of fields without a kept start/end point are left untouched. */
 int fcpp_batch_connectors(fcpp_batch *batch, double *approach_xy_dev, double *departure_xy_dev);
 int fcpp_batch_destroy(fcpp_batch *batch);
-/* Per-kernel device timing with HIP events on the context's stream (bench.py's roofline leg).  While
- * enabled, each fcpp_batch_run records one event per kernel (up to 64 runs are kept).
- * fcpp_batch_stage_times synchronises, returns the summed milliseconds per stage over the recorded
- * runs and clears the record. */
+/* Per-kernel device timing with HIP events (bench.py's roofline leg).  enable = k > 0: every k-th fcpp_batch_run from now on
+ * dispatches each of its kernels with a start and a stop event of its own (hipExtLaunchKernel: the dispatch's time stamps, no
+ * marker packets between the kernels; up to 256 runs are kept); such a run costs ~15 us more than a plain one, hence the stride.
+ * fcpp_batch_stage_times synchronises, returns the summed milliseconds per stage over the recorded runs, their number, and
+ * clears the record. */
 int fcpp_batch_set_profiling(fcpp_batch *batch, int enable);
 int fcpp_batch_stage_times(fcpp_batch *batch, int max_stages, double *ms_sum_out, int *n_stages_out, int *n_runs_out);
 const char *fcpp_batch_stage_name(int mode, int stage);
