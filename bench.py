@@ -152,10 +152,10 @@ def roofline_of(r, traffic_key=None):
             'step_frac': BYTES_PER_POINT * r['points'] / (r['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
-def config_entry(name, workload, r, cpu=None, extra=None):
+def config_entry(name, workload, r, cpu=None, extra=None, traffic_key=None):
     e = {'name': name, 'workload': workload, 'points': r['points'], 'ms_per_step': r['ms_per_step'],
          'value': r['points'] / (r['ms_per_step'] * 1e-3), 'unit': 'points/s', 'dtype': 'f64',
-         'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'roofline': roofline_of(r), 'cpu_baseline': cpu}
+         'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'roofline': roofline_of(r, traffic_key or name), 'cpu_baseline': cpu}
     if extra:
         e.update(extra)
     return e
@@ -250,7 +250,7 @@ def main():
                 'pipeline': 'staged (7 kernels)' if args.mode == 0 else 'fused: k_plan_quiet (closed-form runs and spans) + k_plan_sparse (wave tiles, one point per lane) + k_plan_fused (all other tiles) + k_reduce_stats',
                 'quiet_points': r['quiet_points'], 'general_points': r['general_points'],
             },
-            'roofline': roofline_of(r),
+            'roofline': roofline_of(r, 'cfg1'),
             'cpu_baseline': None,
         }
     if rank == 0 and cpu_on:
