@@ -37,3 +37,10 @@ def golden_cover():
 def golden_plans():
     import numpy as np
     return np.load(os.path.join(GOLDEN, 'golden_plans.npz'))
+
+
+@pytest.fixture(scope='session')
+def golden_mfp():
+    """MultiFieldPlannerV38 run by the reference itself (tools/gen_golden.py tier_mfp): distance matrix and best connections"""
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, 'golden_mfp.npz'))

@@ -1,6 +1,17 @@
 """GPU parity of the coverage rasteriser (fcpp_cover_grid), through the C ABI: against the reference's
-corner grids (golden_cover.npz), against the CPU oracle on seeded jobs, and through the Python mirror of
-verify_all_corners_coverage / _calculate_coverage_rate.  Flags and counts are integers: everything is compared exactly."""
+corner grids (golden_cover.npz), against the CPU oracle on seeded jobs, through the Python mirror of
+verify_all_corners_coverage / _calculate_coverage_rate, and -- independently of the kernel's own arithmetic -- against exact
+rational point-to-segment distances.  Flags and counts are integers: everything is compared exactly.
+
+What golden_cover.npz pins: the reference's verify_all_corners_coverage was run with tools/_shapely_standin.py answering
+`LineString.buffer(W/2).contains(Point)`, and the stand-in uses the same division-free distance test as the oracle and the kernel.
+The fixture therefore pins the reference's GENERATOR POLYLINES (turn, reverse fill: pure numpy code of the reference), its grid
+layout (origin by corner, 0.1 m cell corners, grid[j, i] order, turn first and reverse fill on the open cells) and its coverage
+percentages' bookkeeping -- not the inside test itself, which real GEOS answers on a 32-gon approximation of the round caps.  The
+inside test is checked by test_cover_flags_vs_exact_rational_distances below."""
+from fractions import Fraction
+
+
 import numpy as np
 import pytest
 
@@ -41,6 +52,47 @@ def test_corner_grids_vs_reference_and_oracle(golden_cover):
         assert np.array_equal(got != 0, wgrid), k
         assert counts[k, 0] == gs * gs and counts[k, 1] == (got == 1).sum() and counts[k, 2] == (got != 0).sum()
         assert counts[k, 1] / (gs * gs) * 100 == cov[0] and counts[k, 2] / (gs * gs) * 100 == cov[1]
+
+
+def test_cover_flags_vs_exact_rational_distances():
+    """An inside test that shares no arithmetic with the kernel: the exact squared distance of every sample to every segment in
+    rational arithmetic (fractions.Fraction of the float64 inputs: no rounding anywhere), compared with radius^2.  The kernel's
+    float64 test may only disagree where the exact distance is within rounding of the radius."""
+    rng = np.random.default_rng(2024)
+    nx, ny, res, radius = 48, 40, 0.37, 1.6
+    ox, oy = -3.0, 2.5
+    a = np.cumsum(rng.normal(0, 2.5, size=(9, 2)), axis=0) + [4.0, 9.0]
+    a[4] = a[3]                                                   # a repeated point (zero-length segment)
+    job = E.make_cover_job(ox, oy, res, nx, ny, radius, len(a), 0, shift=0.5, strict=True)
+    counts, grid = E.cover_grid([job], a[:, 0].copy(), a[:, 1].copy(), want_grid=True)
+    got = _np(grid).reshape(ny, nx) != 0
+    F = Fraction
+    seg = [((F(float(a[k, 0])), F(float(a[k, 1]))), (F(float(a[k + 1, 0])), F(float(a[k + 1, 1])))) for k in range(len(a) - 1)]
+    r2 = F(radius) ** 2
+
+    def d2(px, py, s):
+        (ax, ay), (bx, by) = s
+        ex, ey, wx, wy = bx - ax, by - ay, px - ax, py - ay
+        l2 = ex * ex + ey * ey
+        if l2 == 0:
+            return wx * wx + wy * wy
+        t = max(F(0), min(F(1), (wx * ex + wy * ey) / l2))
+        qx, qy = wx - t * ex, wy - t * ey
+        return qx * qx + qy * qy
+
+    n_in, near = 0, 0
+    for j in range(ny):
+        for i in range(nx):
+            # the sample position exactly as the kernel forms it: ox + (i + shift) * res in float64
+            px, py = F(float(ox + (i + 0.5) * res)), F(float(oy + (j + 0.5) * res))
+            dmin = min(d2(px, py, s) for s in seg)
+            inside = dmin < r2
+            n_in += inside
+            if inside != bool(got[j, i]):
+                assert abs(float(dmin / r2) - 1.0) < 1e-12, (i, j, float(dmin), float(r2))      # only within rounding of the boundary
+                near += 1
+    assert near <= 2 and 200 < n_in < nx * ny - 200           # a real mix of covered and open samples
+    assert int(_np(counts)[0, 1]) == int(got.sum())
 
 
 def test_random_jobs_vs_oracle():

@@ -98,3 +98,20 @@ def test_distance_matrix_and_connections_vs_oracle(golden_ga):
     big_f, big_t = rng.uniform(0, 1, size=(300, 2)), rng.uniform(0, 1, size=(257, 2))      # more products than lanes
     bf, bt, bd = E.best_connections([big_f], [big_t])
     assert (int(bf[0]), int(bt[0]), float(bd[0])) == orc.best_connection(big_f, big_t)
+
+
+def test_scheduler_inputs_vs_the_reference_multi_field_planner(golden_mfp):
+    """fcpp_distance_matrix / fcpp_best_connections against what the reference's own MultiFieldPlannerV38 computed
+    (_calculate_distance_matrix MFP:263-288, _find_best_connection MFP:290-320; golden_mfp.npz), the tie included."""
+    g = golden_mfp
+    nodes = np.vstack([g['depot'][None, :], g['centroids']])
+    D = E.distance_matrix(nodes).cpu().numpy()
+    np.testing.assert_allclose(D, g['D'], rtol=4.5e-16, atol=0)
+    cand = lambda node: g['depot'][None, :] if node == 0 else g['vertices'][node - 1]
+    route = g['route']
+    fl = [cand(route[k]) for k in range(len(route) - 1)]
+    tl = [cand(route[k + 1]) for k in range(len(route) - 1)]
+    bf, bt, bd = E.best_connections(fl, tl)
+    for k in range(len(fl)):
+        assert np.array_equal(fl[k][bf[k]], g['conn_from'][k]) and np.array_equal(tl[k][bt[k]], g['conn_to'][k]), k
+    np.testing.assert_allclose(bd, g['conn_dist'], rtol=4.5e-16, atol=0)

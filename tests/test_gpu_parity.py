@@ -38,7 +38,9 @@ def test_native_library_is_loaded():
 @pytest.mark.parametrize('mode', [1, 0])
 def test_batch_vs_golden_plans(golden_plans, mode):
     """All golden scenarios sharing a vehicle are planned as ONE batch; every array is compared.
-    mode 1 = fused single-pass kernel, mode 0 = staged pipeline."""
+    mode 1 = fused single-pass kernel, mode 0 = staged pipeline.
+    (Tier-B vectors: the reference's own code with the Shapely stand-in; the inset corners' ring order is documented intent, not an
+    observation of GEOS -- tests/test_oracle_vs_golden.py::test_full_plans.)"""
     g = golden_plans
     groups = {}
     for name in g['names']:

@@ -125,6 +125,12 @@ def _field_from_golden(g, name):
 
 
 def test_full_plans(golden_plans):
+    """Tier B: the reference's own plan_complete_coverage(), run with tools/_shapely_standin.py in place of Shapely (not installed
+    here).  What these vectors pin is the reference's numpy code given three facts the stand-in supplies: the inset polygon's corner
+    coordinates, the bounds, and `gap.area > 0.1`.  The ORDER in which `buffer(-d).exterior.coords` lists the inset corners (ring
+    orientation and start vertex, MLP:972) is the stand-in's assumption -- the documented intent LL, LR, UR, UL of MLP:957 and
+    1049-1058, which reproduces every number the reference publishes -- not an observation of GEOS: headland loop direction and
+    corner indices are 'documented intent', everything computed from them is reference-pinned."""
     g = golden_plans
     shapes = {'rectangle': 0, 'parallelogram': 1, 'other': 2}
     for name in g['names']:
@@ -286,3 +292,24 @@ def test_best_connection_picks_the_first_shortest_pair():
     t = [[20, 0], [13, 4], [13, -4], [7, 4]]          # distance 5 from f[1] to t[1], t[2], t[3] and from f[2] as well
     assert orc.best_connection(f, t) == (1, 1, 5.0)
     assert orc.best_connection([], t) == (-1, -1, float('inf'))
+
+
+def _mfp_candidates(g, node):
+    """exit / entry candidates of a route node as the reference builds them (MFP:113-140, 292-300): the depot itself, or the field's vertices"""
+    return g['depot'][None, :] if node == 0 else g['vertices'][node - 1]
+
+
+def test_scheduler_inputs_vs_the_reference_multi_field_planner(golden_mfp):
+    """_calculate_distance_matrix (MFP:263-288) and _find_best_connection (MFP:290-320) as the reference's MultiFieldPlannerV38 computed
+    them for 16 fields (14 parallelograms + two squares with a tie), against the oracle."""
+    g = golden_mfp
+    nodes = np.vstack([g['depot'][None, :], g['centroids']])
+    np.testing.assert_allclose(orc.distance_matrix(nodes), g['D'], rtol=4.5e-16, atol=0)
+    route = g['route']
+    for k in range(len(route) - 1):
+        f, t = _mfp_candidates(g, route[k]), _mfp_candidates(g, route[k + 1])
+        bf, bt, bd = orc.best_connection(f, t)
+        assert np.array_equal(f[bf], g['conn_from'][k]) and np.array_equal(t[bt], g['conn_to'][k]), k
+        np.testing.assert_allclose(bd, g['conn_dist'][k], rtol=4.5e-16, atol=0)
+    k = len(route) - 3                                           # tieA -> tieB: two pairs 300 m apart, the first one wins (MFP:308 `<`)
+    assert g['conn_from'][k].tolist() == [4200.0, 0.0] and g['conn_to'][k].tolist() == [4500.0, 0.0]

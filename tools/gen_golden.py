@@ -435,8 +435,48 @@ def tier_cover():
     return out
 
 
+def tier_mfp():
+    """MultiFieldPlannerV38 (MFP:63-320) run for real: its constructor (_prepare_fields: centroid, entry / exit candidates = the
+    field's vertices), _calculate_distance_matrix (MFP:263-288) and _find_best_connection (MFP:290-320) for every consecutive pair
+    of a route over the fields.  multi_field_planner.py imports a class name the reference never defines (MFP:24,
+    TwoLayerPathPlannerV36): the alias below supplies it, as SURVEY.md 0 prescribes; nothing else is touched."""
+    mlp.TwoLayerPathPlannerV36 = mlp.TwoLayerPathPlannerV37
+    with contextlib.redirect_stdout(io.StringIO()):
+        import multi_field_planner as mfp  # the reference
+    rng = np.random.default_rng(38)
+    defs = []
+    for k in range(14):
+        cx, cy = rng.uniform(-1500, 1500, 2)
+        base, height = rng.uniform(120, 600, 2)
+        v = parallelogram(base, height, rng.uniform(65, 115), rng.uniform(-0.6, 0.6), cx, cy)
+        defs.append({'id': f'f{k}', 'vertices': [tuple(map(float, q)) for q in v]})
+    # two squares whose facing sides give TWO equally short connections: the reference keeps the first one (`<`, MFP:308)
+    defs.append({'id': 'tieA', 'vertices': [(4000.0, 0.0), (4200.0, 0.0), (4200.0, 200.0), (4000.0, 200.0)]})
+    defs.append({'id': 'tieB', 'vertices': [(4500.0, 0.0), (4700.0, 0.0), (4700.0, 200.0), (4500.0, 200.0)]})
+    depot = (25.0, -40.0)
+    pl = quiet(mfp.MultiFieldPlannerV38, defs, depot, mlp.VehicleParams(), 1, '2opt')
+    D, node_ids = quiet(pl._calculate_distance_matrix)
+    out = {'depot': np.array(depot), 'D': D,
+           'centroids': np.array([pl.fields[i].centroid for i in node_ids[1:]], dtype=np.float64),
+           'vertices': np.array([np.asarray(pl.fields[i].vertices, dtype=np.float64) for i in node_ids[1:]])}
+    order = [int(v) for v in rng.permutation(14)] + [14, 15]            # ... tieA -> tieB last
+    route = ['depot'] + [node_ids[1 + k] for k in order] + ['depot']
+    fr, to, dist = [], [], []
+    for a, b in zip(route[:-1], route[1:]):
+        c = quiet(pl._find_best_connection, a, b)
+        fr.append(np.asarray(c.from_point, dtype=np.float64)); to.append(np.asarray(c.to_point, dtype=np.float64)); dist.append(c.distance)
+    out['route'] = np.array([0] + [1 + k for k in order] + [0], dtype=np.int64)        # node indices (0 = depot)
+    out['conn_from'] = np.array(fr); out['conn_to'] = np.array(to); out['conn_dist'] = np.array(dist)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if '--mfp-only' in sys.argv:
+        m = tier_mfp()
+        np.savez_compressed(os.path.join(OUT, 'golden_mfp.npz'), **m)
+        print('golden_mfp.npz:', {k: v.shape for k, v in m.items()})
+        return
     if '--ga-only' in sys.argv:
         g = tier_ga()
         np.savez_compressed(os.path.join(OUT, 'golden_ga.npz'), **g)
@@ -455,6 +495,7 @@ def main():
     b = tier_b()
     np.savez_compressed(os.path.join(OUT, 'golden_plans.npz'), **b)
     np.savez_compressed(os.path.join(OUT, 'golden_cover.npz'), **tier_cover())
+    np.savez_compressed(os.path.join(OUT, 'golden_mfp.npz'), **tier_mfp())
 
     # --- the reference's own published pins (README_en.md:199-215, doc/V3.5.1:109-111)
     assert len(b['cfg1_500x200/main_path']) == 1256, len(b['cfg1_500x200/main_path'])
