@@ -117,10 +117,10 @@ PROTOTYPES = [
     ('fcpp_batch_stage_name', C.c_char_p, [C.c_int, C.c_int]),
     ('fcpp_batch_stage_points', C.c_int, [_VP, C.c_int, C.c_int, c_i64_p]),
     ('fcpp_batch_point_split', C.c_int, [_VP, c_i64_p, c_i64_p]),
-    ('fcpp_curvature', C.c_int, [_VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP]),
+    ('fcpp_curvature', C.c_int, [_VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     ('fcpp_speed_plan', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP,
-                                  _VP, _VP]),
-    ('fcpp_verify', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
+                                  _VP, _VP, _VP]),
+    ('fcpp_verify', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP]),
     ('fcpp_straight_segments', C.c_int, [_VP, C.c_int64, _VP, C.c_int32, _VP]),
     ('fcpp_corner_turns', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, _VP, _VP, C.c_double, C.c_double, C.c_int32, _VP, _VP]),
     ('fcpp_fresnel', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),
@@ -154,7 +154,7 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.fcpp_abi_version() != 1:
+        if lib.fcpp_abi_version() != 2:
             raise ImportError('libfcpp.so ABI version mismatch')
         _lib = lib
     return _lib

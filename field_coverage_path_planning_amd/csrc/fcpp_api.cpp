@@ -352,6 +352,7 @@ struct DevTiling {
     DevBuf<int64_t> tile_first;
     DevBuf<char> agg_f, agg_b;   // Agg = 2 doubles
     DevBuf<double> carry_f, carry_b;
+    DevBuf<char> spine;          // scratch of the three-level spine (large batches)
     DevBuf<TilePartial> partial;
     DevBuf<unsigned long long> n_adj;
     DevBuf<int32_t> general_ids;   // fused pipeline: the tiles of k_plan_fused
@@ -374,6 +375,7 @@ struct DevTiling {
         if ((e = agg_b.alloc((size_t)n_tiles * 16)) != hipSuccess) return e;
         if ((e = carry_f.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = carry_b.alloc((size_t)n_tiles)) != hipSuccess) return e;
+        if ((e = spine.alloc((size_t)spine_scratch_bytes(n_tiles))) != hipSuccess) return e;
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
         std::vector<int32_t> gv, sv;
@@ -460,8 +462,11 @@ struct DevTiling {
 };
 }  // namespace
 
+namespace { struct PathTiling; }
+
 struct fcpp_ctx {
     int device = 0;
+    PathTiling *paths_cache = nullptr;     // tile table of the standalone operators' last path set (make_tiling)
     hipStream_t own = nullptr, stream = nullptr;
     // side stream of the fused pipeline: the ALU-bound kernels (wave tiles, general tiles) run beside the HBM-bound streaming
     // kernels of the same step; ev_fork / ev_join order the two streams inside a step
@@ -556,6 +561,8 @@ static bool closed_form_turns(const fcpp_vehicle &veh, const TurnTemplates &tt, 
     return true;
 }
 
+static void free_paths_cache(fcpp_ctx *c);
+
 extern "C" {
 
 const char *fcpp_last_error(void) { return g_err.c_str(); }
@@ -611,6 +618,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    free_paths_cache(c);
     delete c;
     return FCPP_OK;
 }
@@ -897,7 +905,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     STAGE(0, launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
     STAGE(1, launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
     STAGE(2, launch_scan_tiles(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, x, y, v, t.agg_f.p, t.agg_b.p));
-    STAGE(3, launch_scan_spine(st, t.n_tiles, t.agg_f.p, t.agg_b.p, t.carry_f.p, t.carry_b.p));
+    STAGE(3, launch_scan_spine(st, t.n_tiles, t.agg_f.p, t.agg_b.p, t.carry_f.p, t.carry_b.p, t.spine.p));
     STAGE(4, launch_scan_apply(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 3, x, y, v, v, t.carry_f.p, t.carry_b.p));
     STAGE(5, launch_validate(st, t.n_tiles, t.tiles.p, t.paths.p, b->fields.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
     STAGE(6, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, t.n_adj.p, stats));
@@ -990,20 +998,46 @@ int fcpp_batch_destroy(fcpp_batch *b)
 
 // ---- standalone operators -------------------------------------------------------------------
 namespace {
-// pulls the CSR offsets to the host (they size the launch), builds and uploads the tile table
-int make_tiling(fcpp_ctx *c, int64_t n_paths, const int64_t *offsets_dev, int64_t total, Tiling &til, DevTiling &dt)
+// The tile table of a path set, kept in the context between calls of the standalone operators: a caller that plans and verifies
+// the same paths (the planner mirror does: speed plan, verify, verify again) pays for the host-side tiling and its upload once.
+struct PathTiling {
+    std::vector<int64_t> offs;
+    DevTiling dt;
+};
+
+// offsets on the host: the caller's copy, or read back from the device (one copy + synchronisation); the tile table is rebuilt
+// only when they differ from the cached set's
+int make_tiling(fcpp_ctx *c, int64_t n_paths, const int64_t *offsets_dev, const int64_t *offsets_host, int64_t total, DevTiling **out)
 {
     if (n_paths < 0 || total < 0 || n_paths > INT32_MAX) return fail(FCPP_ESIZE, "bad sizes");
     std::vector<int64_t> offs((size_t)n_paths + 1, 0);
-    HIPCHK(hipMemcpyAsync(offs.data(), offsets_dev, offs.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (offsets_host) memcpy(offs.data(), offsets_host, offs.size() * sizeof(int64_t));
+    else {
+        HIPCHK(hipMemcpyAsync(offs.data(), offsets_dev, offs.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     if (offs[0] != 0 || offs.back() != total) return fail(FCPP_ESIZE, "offsets do not span [0, total_points]");
     for (int64_t p = 0; p < n_paths; ++p)
         if (offs[(size_t)p + 1] < offs[(size_t)p]) return fail(FCPP_ESIZE, "offsets must be non-decreasing");
-    til.build(n_paths, offs.data());
-    HIPCHK(dt.upload(til, c->stream));
+    if (!c->paths_cache || c->paths_cache->offs != offs) {
+        PathTiling *pt = new (std::nothrow) PathTiling();
+        if (!pt) return fail(FCPP_ENOMEM, "out of host memory");
+        Tiling til;
+        til.build(n_paths, offs.data());
+        hipError_t e = pt->dt.upload(til, c->stream);
+        if (e != hipSuccess) { delete pt; return fail(FCPP_EHIP, std::string("tile table upload: ") + hipGetErrorString(e)); }
+        pt->offs.swap(offs);
+        // (work of earlier calls on the old table has completed: every standalone operator synchronises before it returns)
+        delete c->paths_cache;
+        c->paths_cache = pt;
+    }
+    *out = &c->paths_cache->dt;
     return FCPP_OK;
 }
+
+}  // namespace
+static void free_paths_cache(fcpp_ctx *c) { delete c->paths_cache; c->paths_cache = nullptr; }
+namespace {
 
 DevConst const_from_vehicle(const fcpp_vehicle &veh)
 {
@@ -1014,13 +1048,14 @@ DevConst const_from_vehicle(const fcpp_vehicle &veh)
 }  // namespace
 
 int fcpp_curvature(fcpp_ctx *c, int64_t n_paths, const int64_t *offsets, int64_t total, const double *x,
-                   const double *y, double *kappa)
+                   const double *y, double *kappa, const int64_t *offsets_host)
 {
-    if (!c || !offsets || (total > 0 && (!x || !y || !kappa))) return fail(FCPP_EINVAL, "bad arguments");
+    if (!c || (!offsets && !offsets_host) || (total > 0 && (!x || !y || !kappa))) return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
-    Tiling til; DevTiling dt;
-    int rc = make_tiling(c, n_paths, offsets, total, til, dt);
+    DevTiling *dtp = nullptr;
+    int rc = make_tiling(c, n_paths, offsets, offsets_host, total, &dtp);
     if (rc) return rc;
+    DevTiling &dt = *dtp;
     fcpp_vehicle veh;
     fcpp_vehicle_default(&veh);
     DevConst cst = const_from_vehicle(veh);
@@ -1034,20 +1069,21 @@ int fcpp_curvature(fcpp_ctx *c, int64_t n_paths, const int64_t *offsets, int64_t
 
 int fcpp_speed_plan(fcpp_ctx *c, const fcpp_vehicle *veh, int clamp, int64_t n_paths, const int64_t *offsets,
                     int64_t total, const double *x, const double *y, const double *v_in, double *v_out, double *kappa,
-                    int64_t *n_adjusted)
+                    int64_t *n_adjusted, const int64_t *offsets_host)
 {
-    if (!c || !veh || !offsets || (total > 0 && (!x || !y || !v_in || !v_out))) return fail(FCPP_EINVAL, "bad arguments");
+    if (!c || !veh || (!offsets && !offsets_host) || (total > 0 && (!x || !y || !v_in || !v_out))) return fail(FCPP_EINVAL, "bad arguments");
     if (!(veh->max_longitudinal_accel > 0) || !(veh->max_lateral_accel > 0)) return fail(FCPP_EINVAL, "accelerations must be positive");
     HIPCHK(hipSetDevice(c->device));
-    Tiling til; DevTiling dt;
-    int rc = make_tiling(c, n_paths, offsets, total, til, dt);
+    DevTiling *dtp = nullptr;
+    int rc = make_tiling(c, n_paths, offsets, offsets_host, total, &dtp);
     if (rc) return rc;
+    DevTiling &dt = *dtp;
     DevConst cst = const_from_vehicle(*veh);
     hipStream_t st = c->stream;
     if (n_paths) HIPCHK(hipMemsetAsync(dt.n_adj.p, 0, (size_t)n_paths * sizeof(unsigned long long), st));
     LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, clamp ? 1 : 0, x, y, v_in, v_out, kappa, dt.n_adj.p));
     LAUNCHCHK(launch_scan_tiles(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, x, y, v_out, dt.agg_f.p, dt.agg_b.p));
-    LAUNCHCHK(launch_scan_spine(st, dt.n_tiles, dt.agg_f.p, dt.agg_b.p, dt.carry_f.p, dt.carry_b.p));
+    LAUNCHCHK(launch_scan_spine(st, dt.n_tiles, dt.agg_f.p, dt.agg_b.p, dt.carry_f.p, dt.carry_b.p, dt.spine.p));
     LAUNCHCHK(launch_scan_apply(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, clamp ? 3 : 2, x, y, v_out, v_out,
                                 dt.carry_f.p, dt.carry_b.p));
     if (n_adjusted && n_paths)
@@ -1057,13 +1093,14 @@ int fcpp_speed_plan(fcpp_ctx *c, const fcpp_vehicle *veh, int clamp, int64_t n_p
 }
 
 int fcpp_verify(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n_paths, const int64_t *offsets, int64_t total,
-                const double *x, const double *y, const double *v, fcpp_field_stats *stats)
+                const double *x, const double *y, const double *v, fcpp_field_stats *stats, const int64_t *offsets_host)
 {
-    if (!c || !veh || !offsets || !stats || (total > 0 && (!x || !y || !v))) return fail(FCPP_EINVAL, "bad arguments");
+    if (!c || !veh || (!offsets && !offsets_host) || !stats || (total > 0 && (!x || !y || !v))) return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
-    Tiling til; DevTiling dt;
-    int rc = make_tiling(c, n_paths, offsets, total, til, dt);
+    DevTiling *dtp = nullptr;
+    int rc = make_tiling(c, n_paths, offsets, offsets_host, total, &dtp);
     if (rc) return rc;
+    DevTiling &dt = *dtp;
     DevConst cst = const_from_vehicle(*veh);
     hipStream_t st = c->stream;
     DevBuf<double> kap, vtmp;

@@ -49,8 +49,10 @@ int launch_curv_clamp(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
                       double *v_out, double *kappa, unsigned long long *n_adjusted);
 int launch_scan_tiles(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
                       const double *x, const double *y, const double *v_in, void *agg_f, void *agg_b);
+// scratch: spine_scratch_bytes(n_tiles) bytes of device memory (0 / NULL: small batches, one workgroup walks all tiles)
+int64_t spine_scratch_bytes(int64_t n_tiles);
 int launch_scan_spine(hipStream_t st, int64_t n_tiles, const void *agg_f, const void *agg_b, double *carry_f,
-                      double *carry_b);
+                      double *carry_b, void *scratch = nullptr);
 int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const DevConst &cst,
                       int min_n, const double *x, const double *y, const double *v_in, double *v_out,
                       const double *carry_f, const double *carry_b);

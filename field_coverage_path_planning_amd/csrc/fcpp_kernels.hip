@@ -157,6 +157,64 @@ __global__ __launch_bounds__(BLOCK) void k_scan_spine(int64_t n_tiles, const Agg
     }
 }
 
+// The spine of a large batch in three levels (2 M tiles at cfg2 / 0.1 m would keep the single workgroup above busy for milliseconds):
+// every workgroup composes the maps of SPINE_BLOCK consecutive tiles (k_spine_blocks<false>), the single-workgroup spine scans those
+// block aggregates, and the blocks are scanned again with their carries (k_spine_blocks<true>).  The maps compose associatively, so
+// the carries are those of the one-level scan up to the rounding of w's sums.  blockIdx.y = direction; direction 1 walks the
+// tiles from the last to the first, its block aggregates are stored in reverse so that the top-level spine walks them its usual way.
+static constexpr int SPINE_IPT = 8, SPINE_BLOCK = BLOCK * SPINE_IPT;
+
+template <bool APPLY>
+__global__ __launch_bounds__(BLOCK) void k_spine_blocks(int64_t n_tiles, int64_t n_blocks, const Agg *__restrict__ agg_f,
+                                                        const Agg *__restrict__ agg_b, Agg *__restrict__ block_f, Agg *__restrict__ block_b,
+                                                        const double *__restrict__ cin_f, const double *__restrict__ cin_b,
+                                                        double *__restrict__ carry_f, double *__restrict__ carry_b)
+{
+    __shared__ Agg sh[NWAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, dir = blockIdx.y;
+    const Agg *__restrict__ agg = dir ? agg_b : agg_f;
+    const int64_t b = blockIdx.x, bi = dir ? (n_blocks - 1 - b) : b;
+    const int64_t q0 = b * SPINE_BLOCK + (int64_t)tid * SPINE_IPT;             // first scan position of this thread
+    Agg me[SPINE_IPT], ta = { FCPP_INF, 0.0 };
+#pragma unroll
+    for (int k = 0; k < SPINE_IPT; ++k) {
+        const int64_t q = q0 + k;
+        me[k] = { FCPP_INF, 0.0 };
+        if (q < n_tiles) me[k] = agg[dir ? (n_tiles - 1 - q) : q];
+        ta = combine_after(ta, me[k]);
+    }
+    Agg inc = ta;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Agg pv = { __shfl_up(inc.c, o), __shfl_up(inc.w, o) };
+        if (lane >= o) inc = combine_after(pv, inc);
+    }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    if (!APPLY) {
+        if (tid == 0) {
+            Agg tot = { FCPP_INF, 0.0 };
+            for (int k = 0; k < NWAVE; ++k) tot = combine_after(tot, sh[k]);
+            (dir ? block_b : block_f)[bi] = tot;
+        }
+        return;
+    }
+    Agg ex = { __shfl_up(inc.c, 1), __shfl_up(inc.w, 1) };
+    if (lane == 0) ex = { FCPP_INF, 0.0 };
+    Agg pre = { FCPP_INF, 0.0 };
+    for (int k = 0; k < wave; ++k) pre = combine_after(pre, sh[k]);
+    ex = combine_after(pre, ex);
+    const double cin = (dir ? cin_b : cin_f)[bi];
+    double *__restrict__ carry = dir ? carry_b : carry_f;
+    double u = fmin(ex.c, cin + ex.w);                                          // value entering this thread's first tile
+#pragma unroll
+    for (int k = 0; k < SPINE_IPT; ++k) {
+        const int64_t q = q0 + k;
+        if (q < n_tiles) carry[dir ? (n_tiles - 1 - q) : q] = u;
+        u = fmin(me[k].c, u + me[k].w);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_scan_apply(const DevTile *__restrict__ tiles,
                                                       const DevPath *__restrict__ paths, DevConst cst, int min_n,
                                                       const double *__restrict__ x, const double *__restrict__ y,
@@ -531,12 +589,32 @@ int launch_scan_tiles(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
     return 0;
 }
 
+int64_t spine_scratch_bytes(int64_t n_tiles)
+{
+    const int64_t nb = (n_tiles + SPINE_BLOCK - 1) / SPINE_BLOCK;
+    return n_tiles > SPINE_BLOCK ? nb * (int64_t)(2 * sizeof(Agg) + 2 * sizeof(double)) : 0;
+}
+
 int launch_scan_spine(hipStream_t st, int64_t n_tiles, const void *agg_f, const void *agg_b, double *carry_f,
-                      double *carry_b)
+                      double *carry_b, void *scratch)
 {
     if (n_tiles <= 0) return 0;
-    FCPP_LAUNCH(k_scan_spine, dim3(1), dim3(BLOCK), 0, st, n_tiles, (const Agg *)agg_f, (const Agg *)agg_b,
-                       carry_f, carry_b);
+    if (n_tiles <= SPINE_BLOCK || !scratch) {       // one workgroup walks every tile aggregate
+        FCPP_LAUNCH(k_scan_spine, dim3(1), dim3(BLOCK), 0, st, n_tiles, (const Agg *)agg_f, (const Agg *)agg_b, carry_f, carry_b);
+        FCPP_LAUNCH_CHECK();
+        return 0;
+    }
+    const int64_t nb = (n_tiles + SPINE_BLOCK - 1) / SPINE_BLOCK;
+    Agg *block_f = (Agg *)scratch, *block_b = block_f + nb;
+    double *cin_f = (double *)(block_b + nb), *cin_b = cin_f + nb;
+    const dim3 grid((unsigned)nb, 2u);
+    FCPP_LAUNCH(k_spine_blocks<false>, grid, dim3(BLOCK), 0, st, n_tiles, nb, (const Agg *)agg_f, (const Agg *)agg_b, block_f, block_b,
+                (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr);
+    FCPP_LAUNCH_CHECK();
+    FCPP_LAUNCH(k_scan_spine, dim3(1), dim3(BLOCK), 0, st, nb, (const Agg *)block_f, (const Agg *)block_b, cin_f, cin_b);
+    FCPP_LAUNCH_CHECK();
+    FCPP_LAUNCH(k_spine_blocks<true>, grid, dim3(BLOCK), 0, st, n_tiles, nb, (const Agg *)agg_f, (const Agg *)agg_b, block_f, block_b,
+                (const double *)cin_f, (const double *)cin_b, carry_f, carry_b);
     FCPP_LAUNCH_CHECK();
     return 0;
 }

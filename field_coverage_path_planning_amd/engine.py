@@ -341,12 +341,21 @@ def _dev_f64(a, device):
 
 
 def _offsets(offsets, n, device):
+    """-> (device tensor, host numpy copy or None): CSR offsets of the paths.  Host-side offsets (lists, numpy) are handed to the
+    library as they are, so it need not read the device copy back."""
     torch = _torch()
     if offsets is None:
         offsets = [0, n]
     if isinstance(offsets, torch.Tensor):
-        return offsets.to(device=device, dtype=torch.int64).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(offsets, dtype=np.int64), device=device)
+        if offsets.is_cuda:
+            return offsets.to(device=device, dtype=torch.int64).contiguous(), None
+        offsets = offsets.numpy()
+    host = np.ascontiguousarray(offsets, dtype=np.int64)
+    return torch.as_tensor(host, device=device), host
+
+
+def _host_ptr(a):
+    return C.c_void_p(a.ctypes.data if a is not None else 0)
 
 
 def curvature(x, y, offsets=None, device=None):
@@ -354,10 +363,10 @@ def curvature(x, y, offsets=None, device=None):
     torch = _torch()
     dev = torch.device('cuda', ctx.device)
     x, y = _dev_f64(x, dev), _dev_f64(y, dev)
-    off = _offsets(offsets, x.numel(), dev)
+    off, off_h = _offsets(offsets, x.numel(), dev)
     k = torch.empty_like(x)
     ctx.bind_stream()
-    L.check(ctx.lib.fcpp_curvature(ctx.handle, off.numel() - 1, _ptr(off), x.numel(), _ptr(x), _ptr(y), _ptr(k)))
+    L.check(ctx.lib.fcpp_curvature(ctx.handle, off.numel() - 1, _ptr(off), x.numel(), _ptr(x), _ptr(y), _ptr(k), _host_ptr(off_h)))
     return k
 
 
@@ -367,13 +376,13 @@ def speed_plan(x, y, v, vehicle, clamp=True, offsets=None, device=None, want_kap
     torch = _torch()
     dev = torch.device('cuda', ctx.device)
     x, y, v = _dev_f64(x, dev), _dev_f64(y, dev), _dev_f64(v, dev)
-    off = _offsets(offsets, x.numel(), dev)
+    off, off_h = _offsets(offsets, x.numel(), dev)
     out = torch.empty_like(v)
     kap = torch.empty_like(v) if want_kappa else None
     nadj = torch.zeros(off.numel() - 1, dtype=torch.int64, device=dev)
     ctx.bind_stream()
     L.check(ctx.lib.fcpp_speed_plan(ctx.handle, C.byref(vehicle), int(bool(clamp)), off.numel() - 1, _ptr(off),
-                                    x.numel(), _ptr(x), _ptr(y), _ptr(v), _ptr(out), _ptr(kap), _ptr(nadj)))
+                                    x.numel(), _ptr(x), _ptr(y), _ptr(v), _ptr(out), _ptr(kap), _ptr(nadj), _host_ptr(off_h)))
     return (out, nadj, kap) if want_kappa else (out, nadj)
 
 
@@ -383,12 +392,12 @@ def verify(x, y, v, vehicle, offsets=None, device=None):
     torch = _torch()
     dev = torch.device('cuda', ctx.device)
     x, y, v = _dev_f64(x, dev), _dev_f64(y, dev), _dev_f64(v, dev)
-    off = _offsets(offsets, x.numel(), dev)
+    off, off_h = _offsets(offsets, x.numel(), dev)
     n_paths = off.numel() - 1
     stats = torch.zeros((n_paths, L.STATS_WORDS), dtype=torch.int64, device=dev)
     ctx.bind_stream()
     L.check(ctx.lib.fcpp_verify(ctx.handle, C.byref(vehicle), n_paths, _ptr(off), x.numel(), _ptr(x), _ptr(y),
-                                _ptr(v), _ptr(stats)))
+                                _ptr(v), _ptr(stats), _host_ptr(off_h)))
     raw = stats.cpu().numpy()
     out = {}
     for k, (n, _) in enumerate(L.FieldStats._fields_):

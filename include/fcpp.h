@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FCPP_ABI_VERSION 1
+#define FCPP_ABI_VERSION 2
 
 enum {
     FCPP_OK = 0,
@@ -178,22 +178,26 @@ int fcpp_batch_stage_points(const fcpp_batch *batch, int mode, int stage, int64_
 /* how the fused pipeline (mode 1) splits the batch: points in closed-form runs and spans (k_plan_quiet) / all other points */
 int fcpp_batch_point_split(const fcpp_batch *batch, int64_t *quiet_points, int64_t *general_points);
 
-/* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) ------- */
+/* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) -------
+ * The offsets size the launches, so the host needs them: offsets_host (n_paths + 1 values, same content as offsets_dev) spares
+ * the call a device-to-host copy and a stream synchronisation; NULL = the library reads offsets_dev back itself.  The tile table
+ * built from the offsets is kept in the context and reused while consecutive calls bring the same offsets (compared by
+ * content when offsets_host is given). */
 /* _calculate_curvature for every interior point (MLP:513-536); end points get 0 */
 int fcpp_curvature(fcpp_ctx *ctx, int64_t n_paths, const int64_t *offsets_dev, int64_t total_points,
-                   const double *x_dev, const double *y_dev, double *kappa_dev);
+                   const double *x_dev, const double *y_dev, double *kappa_dev, const int64_t *offsets_host);
 /* _apply_curvature_based_speed_limit incl. _smooth_speed_profile (MLP:467-589); paths with fewer
  * than 3 points are returned unchanged (MLP:480-481).  clamp=0 runs _smooth_speed_profile only.
  * v_out_dev may alias v_in_dev; kappa_dev and n_adjusted_dev (int64[n_paths]) may be NULL. */
 int fcpp_speed_plan(fcpp_ctx *ctx, const fcpp_vehicle *veh, int clamp, int64_t n_paths,
                     const int64_t *offsets_dev, int64_t total_points, const double *x_dev,
                     const double *y_dev, const double *v_in_dev, double *v_out_dev, double *kappa_dev,
-                    int64_t *n_adjusted_dev);
+                    int64_t *n_adjusted_dev, const int64_t *offsets_host);
 /* verify_curvature_constraints (MLP:1373-1424) + _calculate_path_length/_calculate_work_time
  * (MLP:1290-1311) per path; stats_dev[n_paths] uses the main_* members for the whole path. */
 int fcpp_verify(fcpp_ctx *ctx, const fcpp_vehicle *veh, int64_t n_paths, const int64_t *offsets_dev,
                 int64_t total_points, const double *x_dev, const double *y_dev, const double *v_dev,
-                fcpp_field_stats *stats_dev);
+                fcpp_field_stats *stats_dev, const int64_t *offsets_host);
 /* numpy.linspace straight segments (MLP:1013-1022, 1313-1355): seg_dev = n_seg x (x0,y0,x1,y1),
  * out_xy_dev = n_seg x n_points x 2 */
 int fcpp_straight_segments(fcpp_ctx *ctx, int64_t n_seg, const double *seg_dev, int32_t n_points,

@@ -275,6 +275,37 @@ def test_long_single_path_sweeps_vs_oracle():
     np.testing.assert_allclose(_np(got), want, rtol=0, atol=1e-9)
 
 
+def test_three_level_spine_and_cached_tilings_vs_oracle():
+    """Standalone speed planner on 1.2 M points in 3 paths (2 346 tiles: the spine takes its three-level form, blocks of 2 048 tile
+    aggregates) with a 0.02 m/s^2 vehicle, so that constraints cross tiles AND spine blocks; then the same operator on other path
+    sets: offsets handed over on the host (tile table cached in the context, rebuilt when the offsets change) and as a device tensor
+    (read back by the library)."""
+    import torch
+    rng = np.random.default_rng(11)
+    n = 1_200_000
+    th = np.cumsum(rng.normal(0, 0.03, n))
+    seg = rng.uniform(0.01, 0.05, n)
+    xy = np.cumsum(np.column_stack([seg * np.cos(th), seg * np.sin(th)]), axis=0)
+    for j in rng.integers(1, n, size=80):
+        xy[j] = xy[j - 1]
+    v = rng.choice([0.5, 2.5, 4.0, 9.0, 15.0, 40.0], size=n, p=[0.002, 0.018, 0.08, 0.45, 0.4, 0.05])
+    offs = np.array([0, 500_123, 500_125, n], dtype=np.int64)            # (the middle path has 2 points: returned unchanged)
+    vp = [3.2, 8.0, 9.0, 15.0, 4.0, 2.0, 0.02, 0.85]
+    veh = orc.Vehicle.make(max_longitudinal_accel=0.02)
+    want = np.concatenate([orc.speed_limit(xy[a:b], v[a:b], veh)[0] if b - a >= 3 else v[a:b] for a, b in zip(offs[:-1], offs[1:])])
+    got, _ = E.speed_plan(xy[:, 0], xy[:, 1], v, _veh(vp), clamp=True, offsets=offs)
+    np.testing.assert_allclose(_np(got), want, rtol=0, atol=1e-9)
+    got2, _ = E.speed_plan(xy[:, 0], xy[:, 1], v, _veh(vp), clamp=True, offsets=offs)          # cached tile table
+    assert np.array_equal(_np(got2), _np(got))
+    offs_b = np.array([0, 300_000, n], dtype=np.int64)                                          # other offsets: rebuilt
+    want_b = np.concatenate([orc.speed_limit(xy[a:b], v[a:b], veh)[0] for a, b in zip(offs_b[:-1], offs_b[1:])])
+    got_b, _ = E.speed_plan(xy[:, 0], xy[:, 1], v, _veh(vp), clamp=True, offsets=torch.as_tensor(offs_b, device='cuda'))
+    np.testing.assert_allclose(_np(got_b), want_b, rtol=0, atol=1e-9)
+    k = E.curvature(xy[:1000, 0], xy[:1000, 1], offsets=[0, 400, 1000])
+    k2 = E.curvature(xy[:1000, 0], xy[:1000, 1], offsets=torch.as_tensor([0, 400, 1000], device='cuda'))
+    assert np.array_equal(_np(k), _np(k2)) and float(_np(k)[399]) == 0.0 and float(_np(k)[400]) == 0.0
+
+
 def test_fresnel_vs_mpmath_table():
     import os
     tab = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'fresnel_table.npz'))
