@@ -11,7 +11,8 @@ LIB_PATH = os.environ.get('FCPP_LIBRARY') or os.path.join(_HERE, 'libfcpp.so')  
 
 OK, EINVAL, EHEADLAND, EUNSUPPORTED, EHIP, ENOMEM, ESIZE = 0, -1, -2, -3, -4, -5, -6
 TURN_ARC, TURN_CLOTHOID = 0, 1
-KIND_SWATH, KIND_UTURN, KIND_HEAD_START, KIND_HEAD_STRAIGHT, KIND_CORNER, KIND_REVERSE = range(6)
+KIND_SWATH, KIND_UTURN, KIND_HEAD_START, KIND_HEAD_STRAIGHT, KIND_CORNER, KIND_REVERSE, KIND_DETOUR = range(7)
+OBSTACLES_FLAG, OBSTACLES_AVOID = 0, 1
 KIND_MASK, FLAG_HEADLAND, FLAG_ALAT, FLAG_OUTSIDE, FLAG_OBSTACLE, INDEX_SHIFT = 7, 8, 16, 32, 64, 8
 
 c_double_p = C.POINTER(C.c_double)
@@ -32,7 +33,7 @@ class Vehicle(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('turn_model', C.c_int32), ('clothoid_fit', C.c_int32), ('sample_spacing', C.c_double),
-                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double)]
+                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double), ('obstacle_mode', C.c_int32), ('_pad', C.c_int32)]
 
 
 class Field(C.Structure):
@@ -104,7 +105,7 @@ PROTOTYPES = [
     ('fcpp_free', C.c_int, [_VP, _VP]),
     ('fcpp_memcpy_h2d', C.c_int, [_VP, _VP, _VP, C.c_int64]),
     ('fcpp_memcpy_d2h', C.c_int, [_VP, _VP, _VP, C.c_int64]),
-    ('fcpp_plan_count', C.c_int, [C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field),
+    ('fcpp_plan_count', C.c_int, [C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field), C.POINTER(Polys),
                                   C.POINTER(FieldInfo)]),
     ('fcpp_batch_create', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field),
                                     C.POINTER(Polys), C.POINTER(_VP)]),

@@ -84,7 +84,7 @@ struct Tiling {
     std::vector<int64_t> pass_len;      // per path: points per pass of layer 1 (swath line + U-turn), 0 without structure
     // structure of a field's path, for the fused pipeline's tiling
     struct QuietInfo {
-        int64_t n_line, n_turn, P, n_main;
+        int64_t n_line, n_turn, P, n_main, gen_main;
         double line_step_len, c_line;          // |numpy step| of the swath lines, their nominal u = (v/3.6)^2
         const DevPrim *prims; int prim_count, prim_index0;  // layer 2: the field's primitives, index of the first one in the batch
         double two_a;
@@ -102,7 +102,7 @@ struct Tiling {
     static void host_point(const QuietInfo &q, int64_t i, double &px, double &py)
     {
         const DevField &f = *q.df;
-        if (i < f.n_main) {
+        if (i < f.gen_main) {
             const int64_t per = (int64_t)f.n_line + f.n_turn;
             const int64_t idx = i / per, off = i - idx * per;
             const int64_t pi = f.reverse_order ? (f.P - 1 - idx) : idx;
@@ -130,6 +130,18 @@ struct Tiling {
         if (p.kind == PRIM_LINSPACE) { px = linspace_at(p.a[0], p.a[2], p.a[4], p.n, r); py = linspace_at(p.a[1], p.a[3], p.a[5], p.n, r); }
         else if (p.kind == PRIM_POINT) { px = p.a[0]; py = p.a[1]; }
         else if (p.kind == PRIM_RAY) { const double t = linspace_at(0.0, p.a[4], p.a[5], p.n, r); px = p.a[0] + t * p.a[2]; py = p.a[1] + t * p.a[3]; }
+        else if (p.kind == PRIM_UTURN) {
+            const double2 t = q.tu[r];
+            const bool turn_right = p.form & 1;
+            if (!(p.form & 4)) px = turn_right ? (p.a[0] - t.x) : (p.a[0] + t.x);
+            else px = turn_right ? (p.a[0] + t.x) : (p.a[0] - t.x);
+            py = p.a[1] + t.y;
+            if (p.form & 2) {
+                const double tx = px - p.a[4], ty = py - p.a[5];
+                px = (tx * p.a[2] - ty * p.a[3]) + p.a[4];
+                py = (tx * p.a[3] + ty * p.a[2]) + p.a[5];
+            }
+        }
         else {
             const double2 t = q.tc[r];
             const int ci = p.kind == PRIM_ARC ? p.form : ((p.form + 3) & 3);
@@ -221,19 +233,20 @@ struct Tiling {
             const int64_t first = s - Hb, last = s + c - 1 + Hf;
             DevTile t;
             t.field = (int32_t)p; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
-            if (first < f.n_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
+            if (first < f.gen_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
             else { t.idx0 = q.prim_index0 + prim_of(q, first); t.off0 = 0; }
             // the self-contained record: layer-1 decode of lane 0, and where the (at most 8) further primitives start among the lanes
             DevWaveTile wt;
             memset(&wt, 0, sizeof wt);
             auto clampi = [](int64_t v) { return (int32_t)std::max<int64_t>(-2, std::min<int64_t>(v, (int64_t)1 << 30)); };
             wt.out_base = f.pt_off + first; wt.field = (int32_t)p; wt.tile = (int32_t)out.size();
-            wt.count = (int32_t)c; wt.hb = Hb; wt.hf = Hf;
-            wt.rel_main = clampi(f.n_main - first); wt.rel_last = clampi(n - 1 - first); wt.first_is_0 = first == 0;
+            wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf;
+            wt.rel_main = clampi(f.gen_main - first); wt.rel_seam = clampi(f.n_main - first); wt.rel_last = clampi(n - 1 - first);
+            wt.rel_zero = clampi(-first);
             wt.idx0 = t.idx0; wt.off0 = t.off0;
             for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
-            if (last >= f.n_main) {
-                const int64_t fl2 = std::max<int64_t>(first, f.n_main);        // first layer-2 point of the tile
+            if (last >= f.gen_main) {
+                const int64_t fl2 = std::max<int64_t>(first, f.gen_main);      // first primitive-generated point of the tile
                 const int pa = prim_of(q, fl2), pb = prim_of(q, last);
                 if (pb - pa > 8) { ++wave_fail[3]; out.resize(mark); wtiles.resize(mark_w); return false; }
                 wt.p0 = q.prim_index0 + pa;
@@ -282,7 +295,7 @@ struct Tiling {
                 const int64_t k = (len + TILE_POINTS - 1) / TILE_POINTS, base = len / k, rem = len % k;
                 for (int64_t i = 0; i < k; ++i) {
                     const int64_t c = base + (i < rem ? 1 : 0);
-                    const bool in1 = per > 0 && a < q->n_main;        // layer-1 decode of the tile start for the general kernel
+                    const bool in1 = per > 0 && a < q->gen_main;      // layer-1 decode of the tile start for the general kernel
                     emit(a, c, 0, in1 ? a / per : 0, in1 ? a % per : 0);
                     a += c;
                 }
@@ -300,7 +313,7 @@ struct Tiling {
             int64_t pos = 0;
             if (q) {
                 const int64_t need1 = need_for(q->c_line, q->line_step_len);
-                if (need1 >= 0 && per > 0) {
+                if (need1 >= 0 && per > 0 && q->gen_main > 0) {
                     // With closed-form U-turns nothing propagates into a swath line from the turns around it (a turn starts on
                     // the line's last point: a skipped step; the jump back from the turn's end is too long to bind): all
                     // complete passes (line + turn) form ONE quiet span, whatever the sampling.  The last line ends at the
@@ -578,7 +591,7 @@ void fcpp_vehicle_default(fcpp_vehicle *v)
 void fcpp_options_default(fcpp_options *o)
 {
     o->turn_model = FCPP_TURN_ARC; o->clothoid_fit = 1; o->sample_spacing = 0.0; o->clothoid_frac = 0.5;
-    o->geofence_tol = 1e-6;
+    o->geofence_tol = 1e-6; o->obstacle_mode = FCPP_OBSTACLES_FLAG; o->_pad = 0;
 }
 
 int fcpp_ctx_create(int device_id, fcpp_ctx **out)
@@ -675,13 +688,13 @@ int fcpp_memcpy_d2h(fcpp_ctx *c, void *dst, const void *src, int64_t bytes)
 }
 
 int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
-                    fcpp_field_info *info_out)
+                    const fcpp_polys *obstacles, fcpp_field_info *info_out)
 {
     if (!veh || !opt || n_fields < 0 || (n_fields > 0 && (!fields || !info_out)))
         return fail(FCPP_EINVAL, "bad arguments");
     HostPlan hp;
     std::string err;
-    int rc = build_host_plan(*veh, *opt, n_fields, fields, false, hp, err);
+    int rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, false, hp, err);
     if (rc != FCPP_OK) return fail(rc, err);
     if (n_fields) memcpy(info_out, hp.info.data(), (size_t)n_fields * sizeof(fcpp_field_info));
     return FCPP_OK;
@@ -700,7 +713,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     b->ctx = c; b->veh = *veh; b->opt = *opt; b->n_fields = n_fields;
     b->two_streams = getenv("FCPP_ONE_STREAM") == nullptr;
     std::string err;
-    int rc = build_host_plan(*veh, *opt, n_fields, fields, true, b->hp, err);
+    int rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, true, b->hp, err);
     if (rc != FCPP_OK) { delete b; return fail(rc, err); }
     // obstacle references must stay inside the polygon table
     const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
@@ -755,7 +768,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     for (int64_t i = 0; i < n_fields; ++i) {
         const DevField &df = b->hp.fields[(size_t)i];
         Tiling::QuietInfo q;
-        q.n_line = df.n_line; q.n_turn = df.n_turn; q.P = df.P; q.n_main = df.n_main;
+        q.n_line = df.n_line; q.n_turn = df.n_turn; q.P = df.P; q.n_main = df.n_main; q.gen_main = df.gen_main;
         q.line_step_len = fabs(df.line_step); q.c_line = b->cst.ms_work * b->cst.ms_work;
         q.prims = b->hp.prims.data() + df.prim_first; q.prim_count = df.prim_count; q.prim_index0 = df.prim_first;
         q.two_a = 2 * b->cst.a_lon;

@@ -32,7 +32,7 @@ static constexpr int NWAVE = BLOCK / 64;
 // --------------------------------------------------------------------------------------------
 struct GenOut { double x, y, v; uint32_t fs; };
 
-__device__ __forceinline__ void gen_headland(const DevPrim *__restrict__ prims, int lo, int cnt, int64_t i,
+__device__ __forceinline__ void gen_headland(const DevField &f, const DevPrim *__restrict__ prims, int lo, int cnt, int64_t i,
                                              const DevConst &cst, GenOut &o)
 {
     // binary search: last primitive with start <= i
@@ -61,6 +61,23 @@ __device__ __forceinline__ void gen_headland(const DevPrim *__restrict__ prims, 
             o.x = p.a[0] + t * p.a[2];
             o.y = p.a[1] + t * p.a[3];
         } break;
+        case PRIM_UTURN: {      // a U-turn of layer 1 as a primitive (obstacle-aware swaths): the formulas of gen_point below
+            const bool turn_right = p.form & 1;
+            const double s = linspace_at(0.0, f.turn_end, f.turn_step, f.n_turn, k);
+            double px, py;
+            if (!(p.form & 4)) {
+                double sn, cs;
+                sincos(s, &sn, &cs);
+                px = turn_right ? (p.a[0] - f.R * cs) : (p.a[0] + f.R * cs);
+                py = p.a[1] + f.R * sn;
+            } else cac_world_point(cst.shapes[0], p.a[0], p.a[1], 1, turn_right ? -1.0 : 1.0, f.turn_Re, s, px, py);
+            if (p.form & 2) {
+                const double tx = px - p.a[4], ty = py - p.a[5];
+                const double xn = tx * p.a[2] - ty * p.a[3], yn = tx * p.a[3] + ty * p.a[2];
+                px = xn + p.a[4]; py = yn + p.a[5];
+            }
+            o.x = px; o.y = py;
+        } break;
         default: {  // PRIM_CAC
             const double s = linspace_at(0.0, p.a[6], p.a[5], p.n, k);
             cac_world_point(cst.shapes[1], p.a[0], p.a[1], p.form, p.a[3] < 0 ? -1.0 : 1.0, p.a[4], s, o.x, o.y);
@@ -71,7 +88,7 @@ __device__ __forceinline__ void gen_headland(const DevPrim *__restrict__ prims, 
 __device__ __forceinline__ void gen_point(const DevField &f, const DevPrim *__restrict__ prims, int64_t i,
                                           const DevConst &cst, GenOut &o)
 {
-    if (i >= f.n_main) { gen_headland(prims, f.prim_first, f.prim_count, i, cst, o); return; }
+    if (i >= f.gen_main) { gen_headland(f, prims, f.prim_first, f.prim_count, i, cst, o); return; }
     // layer 1, MLP:750-780: pass idx = i / (n_line + n_turn)
     const int64_t per = (int64_t)f.n_line + f.n_turn;
     const int64_t idx = i / per;
@@ -220,7 +237,7 @@ __device__ __forceinline__ double nominal_speed(uint32_t fs, const DevConst &c)
 {
     switch (fs & FCPP_KIND_MASK) {
         case FCPP_KIND_SWATH: return c.v_work;
-        case FCPP_KIND_UTURN: case FCPP_KIND_CORNER: return c.v_turn;
+        case FCPP_KIND_UTURN: case FCPP_KIND_CORNER: case FCPP_KIND_DETOUR: return c.v_turn;
         case FCPP_KIND_REVERSE: return 2.5;
         default: return c.v_head;
     }
@@ -234,7 +251,7 @@ __device__ __forceinline__ double nominal_ms(uint32_t fs, const DevConst &c)
 {
     switch (fs & FCPP_KIND_MASK) {
         case FCPP_KIND_SWATH: return c.ms_work;
-        case FCPP_KIND_UTURN: case FCPP_KIND_CORNER: return c.ms_turn;
+        case FCPP_KIND_UTURN: case FCPP_KIND_CORNER: case FCPP_KIND_DETOUR: return c.ms_turn;
         case FCPP_KIND_REVERSE: return c.ms_rev;
         default: return c.ms_head;
     }

@@ -72,7 +72,7 @@ __device__ __noinline__ GenOut gen_point_tmpl(const DevField *f, const PrimTable
 {
     GenOut o;
     o.v = 0;
-    if (i < f->n_main) {
+    if (i < f->gen_main) {
         const int64_t per = (int64_t)f->n_line + f->n_turn;
         const int64_t idx = i / per;
         eval_main(*f, *cst, (int)idx, (int)(i - idx * per), o.x, o.y, o.fs);
@@ -105,8 +105,8 @@ __device__ void halo_wave(const DevField &f, const DevField *fg, const PrimTable
         int pos = -1, np = 0;
         uint32_t fw = 0;
         bool rot = false;
-        if (nb < f.n_main) {
-            if (tl.start < f.n_main) {
+        if (nb < f.gen_main) {
+            if (tl.start < f.gen_main) {
                 const int per = f.n_line + f.n_turn;
                 int off = tl.off0 + (int)(nb - tl.start), idx = tl.idx0;
                 if (off >= 0) {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     // record per generated item): from global memory every one of those is a dependent ~1 us round trip.  The field's few
     // primitives are staged in LDS once, by one coalesced load; `prims` is indexed by the batch-wide primitive index either way.
     PrimTable prims = { prims_g, 0 };
-    if (s + cnt >= f.n_main && f.prim_count <= FPRIM_CAP) {     // (block-uniform)
+    if (s + cnt >= f.gen_main && f.prim_count <= FPRIM_CAP) {     // (block-uniform)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(prims_g + f.prim_first);
         for (int q = tid; q < f.prim_count * (int)(sizeof(DevPrim) / 4); q += FBLOCK) S.prims[q] = src[q];
         __syncthreads();
@@ -317,6 +317,9 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     const int64_t rem_end = (n - 1) - i0, rem_seam = f.n_main - i0;
     const int k_end = (rem_end >= 0 && rem_end < FIPT) ? (int)rem_end : 1000;     // item that is the path's last point
     const int k_seam = rem_seam < 0 ? -1 : (rem_seam >= FIPT ? 1000 : (int)rem_seam);  // item with index n_main (first of layer 2)
+    // the same for the closed-form generator: item with index gen_main (= n_main, or 0 when layer 1 is a list of primitives)
+    const int64_t rem_gen = f.gen_main - i0;
+    const int k_gen = rem_gen < 0 ? -1 : (rem_gen >= FIPT ? 1000 : (int)rem_gen);
     double *buf = S.tr[wave];
     const int64_t g0 = f.pt_off + s + wave * (64 * FIPT);
     const int cw = min(max(cnt - wave * (64 * FIPT), 0), 64 * FIPT);
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     //   C. everything else (the seam, corners, reverse fills, the path's end): a cursor walks the run item by item.
     double X[FIPT + 2], Y[FIPT + 2];
     uint32_t fs[FIPT];
-    const bool in_main0 = k_seam > 0;            // item 0 belongs to layer 1
+    const bool in_main0 = k_gen > 0;             // item 0 is generated from the closed form of layer 1
     const int per = f.n_line + f.n_turn;
     int c_idx = 0, c_off = 0, c_a = f.prim_first, c_r = 0;
     if (in_main0) {
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     bool straight = false, turn_run = false;   // uniform runs: one straight primitive / one U-turn (shortcuts further down)
     bool generated = false;
     uint32_t run_fs = 0;
-    if (k_seam >= FIPT && per >= FIPT) {       // A: items 0..7 all have indices < n_main (padding items beyond the tile's count included)
+    if (k_gen >= FIPT && per >= FIPT) {        // A: items 0..7 all have indices < gen_main (padding items beyond the tile's count included)
         const int idx1 = c_idx + 1;
         const int pi0 = f.reverse_order ? (f.P - 1 - c_idx) : c_idx, pi1 = f.reverse_order ? (f.P - 1 - idx1) : idx1;
         const double y0 = f.min_y + (double)pi0 * f.W, y1 = f.min_y + (double)pi1 * f.W;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
     // (Layer 1 only; what remains for the generic code below are line samples -- axis-aligned: no square root, collinear:
     // no angle -- and the junctions.)
     unsigned tmpl_d = 0, tmpl_k = 0;
-    if (k_seam >= FIPT && per >= FIPT) {
+    if (k_gen >= FIPT && per >= FIPT) {
 #pragma unroll
         for (int k = 0; k <= FIPT; ++k) {
             int off = c_off + k;

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "fcpp_geom.h"
 #include "fcpp_internal.h"
@@ -133,15 +134,17 @@ const int kCornerQuadrant[4] = { 1, 2, 3, 0 };  // start heading of the corner a
 
 }  // namespace
 
-int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields,
+int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
                     bool want_device, HostPlan &out, std::string &err)
 {
     const double W = veh.working_width, R = veh.min_turn_radius, ds = opt.sample_spacing;
     if (!(W > 0) || !(R > 0) || !(ds >= 0) || !(opt.clothoid_frac >= 0 && opt.clothoid_frac <= 1) ||
-        (opt.turn_model != FCPP_TURN_ARC && opt.turn_model != FCPP_TURN_CLOTHOID)) {
+        (opt.turn_model != FCPP_TURN_ARC && opt.turn_model != FCPP_TURN_CLOTHOID) ||
+        (opt.obstacle_mode != FCPP_OBSTACLES_FLAG && opt.obstacle_mode != FCPP_OBSTACLES_AVOID)) {
         err = "invalid vehicle parameters or options";
         return FCPP_EINVAL;
     }
+    const bool clip = opt.obstacle_mode == FCPP_OBSTACLES_AVOID;
     if (!(veh.max_longitudinal_accel > 0) || !(veh.max_lateral_accel > 0)) {
         err = "accelerations must be positive";
         return FCPP_EINVAL;
@@ -259,7 +262,95 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         const int64_t n_turn = ds > 0 ? n_for_length(len_uturn, ds) : 20;
         if (P > INT32_MAX || n_line + n_turn > INT32_MAX - 2 * TILE_POINTS) { fail(FCPP_ESIZE); continue; }
         in.n_swaths = (int32_t)P;
-        const int64_t n_main = P * n_line + (P - 1) * n_turn;
+        int64_t n_main = P * n_line + (P - 1) * n_turn;
+        df.gen_main = n_main;
+        df.prim_first = (int32_t)out.prims.size();
+        if (clip) {
+            // ---- obstacle-aware swaths (include/fcpp.h): layer 1 as a list of primitives -- sub-swaths, detour legs, U-turns
+            struct Box { double x0, y0, x1, y1; };
+            std::vector<Box> boxes;
+            const double ca = cos(-rot), sa = sin(-rot);
+            bool bad_obs = f.n_obstacles < 0 || (f.n_obstacles > 0 && (!polys || f.obstacle_first < 0 || f.obstacle_first + f.n_obstacles > polys->n_polys));
+            for (int k = 0; k < f.n_obstacles && !bad_obs; ++k) {
+                const int64_t a0 = polys->offsets[f.obstacle_first + k], a1 = polys->offsets[f.obstacle_first + k + 1];
+                if (a1 <= a0) continue;
+                Box b = { HUGE_VAL, HUGE_VAL, -HUGE_VAL, -HUGE_VAL };
+                for (int64_t q2 = a0; q2 < a1; ++q2) {
+                    double ox = polys->x[q2], oy = polys->y[q2];
+                    if (!(isfinite(ox) && isfinite(oy))) { bad_obs = true; break; }
+                    if (rotated) rotate_point(ox, oy, ca, sa, ccx, ccy, ox, oy);
+                    b.x0 = std::min(b.x0, ox); b.x1 = std::max(b.x1, ox); b.y0 = std::min(b.y0, oy); b.y1 = std::max(b.y1, oy);
+                }
+                b.x0 -= W / 2; b.y0 -= W / 2; b.x1 += W / 2; b.y1 += W / 2;
+                boxes.push_back(b);
+            }
+            if (bad_obs) { fail(FCPP_ESIZE); continue; }
+            const double rc = cos(rot), rs = sin(rot);
+            const double lo = std::min(lsx, lex), hi = std::max(lsx, lex);
+            int64_t pos1 = 0;
+            bool unsupported = false;
+            auto push1 = [&](DevPrim &pr) { pr.start = pos1; pos1 += pr.n; if (want_device) out.prims.push_back(pr); };
+            auto world = [&](double &x, double &y) { if (rotated) rotate_point(x, y, rc, rs, ccx, ccy, x, y); };
+            auto push_line = [&](double ax, double ay, double bx, double by, uint32_t kind, int64_t pi, double vnom, bool detour) {
+                const double len = sqrt((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
+                int64_t np = detour ? (ds > 0 ? n_for_length(len, ds) : std::max<int64_t>(2, (int64_t)(len / 0.5) + 1))
+                                    : (ds > 0 ? n_for_length(len, ds) : 2);
+                if (np > INT32_MAX) { unsupported = true; return; }
+                world(ax, ay); world(bx, by);
+                DevPrim pr;
+                memset(&pr, 0, sizeof(pr));
+                pr.kind = PRIM_LINSPACE; pr.n = (int32_t)np; pr.v_nom = vnom;
+                pr.fs = kind | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+                pr.a[0] = ax; pr.a[1] = ay; pr.a[2] = bx; pr.a[3] = by;
+                pr.a[4] = lin_step(ax, bx, np); pr.a[5] = lin_step(ay, by, np);
+                push1(pr);
+            };
+            std::vector<int> blk;
+            for (int64_t idx = 0; idx < P && !unsupported; ++idx) {
+                const int64_t pi = reverse_order ? (P - 1 - idx) : idx;
+                const double y = min_y + (double)pi * W;
+                const bool go_left = start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+                const double xs = go_left ? lex : lsx, xe = go_left ? lsx : lex;
+                blk.clear();
+                for (size_t k = 0; k < boxes.size(); ++k)
+                    if (boxes[k].y0 < y && y < boxes[k].y1 && boxes[k].x1 > lo && boxes[k].x0 < hi) blk.push_back((int)k);
+                std::sort(blk.begin(), blk.end(), [&](int a, int b) { return go_left ? boxes[a].x1 > boxes[b].x1 : boxes[a].x0 < boxes[b].x0; });
+                double cur = xs;
+                for (size_t k = 0; k < blk.size() && !unsupported; ++k) {
+                    const Box &b = boxes[blk[k]];
+                    const double nearx = go_left ? b.x1 : b.x0, farx = go_left ? b.x0 : b.x1;
+                    // the box must lie strictly inside the line, beyond the previous box
+                    if (!(b.x0 > lo + 1e-9 && b.x1 < hi - 1e-9) || !(go_left ? nearx < cur - 1e-9 : nearx > cur + 1e-9)) { unsupported = true; break; }
+                    const double ys = (b.y1 - y <= y - b.y0) ? b.y1 : b.y0;
+                    push_line(cur, y, nearx, y, FCPP_KIND_SWATH, pi, veh.max_work_speed_kmh, false);
+                    push_line(nearx, y, nearx, ys, FCPP_KIND_DETOUR, pi, veh.headland_turn_speed_kmh, true);
+                    push_line(nearx, ys, farx, ys, FCPP_KIND_DETOUR, pi, veh.headland_turn_speed_kmh, true);
+                    push_line(farx, ys, farx, y, FCPP_KIND_DETOUR, pi, veh.headland_turn_speed_kmh, true);
+                    cur = farx;
+                }
+                if (unsupported) break;
+                push_line(cur, y, xe, y, FCPP_KIND_SWATH, pi, veh.max_work_speed_kmh, false);
+                if (idx < P - 1) {
+                    const bool turn_right = !go_left;
+                    DevPrim pr;
+                    memset(&pr, 0, sizeof(pr));
+                    pr.kind = PRIM_UTURN; pr.n = (int32_t)n_turn; pr.v_nom = veh.headland_turn_speed_kmh;
+                    pr.fs = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
+                    pr.form = (turn_right ? 1 : 0) | (rotated ? 2 : 0) | (cloth ? 4 : 0);
+                    pr.a[0] = cloth ? (turn_right ? (max_x - R) : (min_x + R)) : (turn_right ? max_x : min_x);
+                    pr.a[1] = y;
+                    pr.a[2] = rc; pr.a[3] = rs; pr.a[4] = ccx; pr.a[5] = ccy;
+                    push1(pr);
+                }
+            }
+            if (unsupported) {
+                if (want_device) out.prims.resize((size_t)df.prim_first);
+                fail(FCPP_EUNSUPPORTED);
+                continue;
+            }
+            n_main = pos1;
+            df.gen_main = 0;
+        }
         in.n_main = n_main;
 
         df.n_main = n_main;
@@ -273,7 +364,6 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         df.P = (int32_t)P; df.n_line = (int32_t)n_line; df.n_turn = (int32_t)n_turn;
         df.reverse_order = reverse_order; df.start_from_right = start_from_right; df.rotated = rotated;
         df.turn_model = opt.turn_model;
-        df.prim_first = (int32_t)out.prims.size();
 
         // ---- layer 2 (MLP:898-1084)
         const int num_loops = (int)ceil(hw / W);

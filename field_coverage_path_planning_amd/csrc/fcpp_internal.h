@@ -15,11 +15,12 @@ namespace fcpp {
 
 constexpr int TILE_POINTS = 512;   // points per tile: one wavefront x 8 points in the fused kernel, 256 threads x 2 in the staged ones
 
-enum PrimKind : int32_t { PRIM_POINT = 0, PRIM_LINSPACE = 1, PRIM_ARC = 2, PRIM_RAY = 3, PRIM_CAC = 4 };
+enum PrimKind : int32_t { PRIM_POINT = 0, PRIM_LINSPACE = 1, PRIM_ARC = 2, PRIM_RAY = 3, PRIM_CAC = 4, PRIM_UTURN = 5 };
 
-// one headland primitive (MLP:943-1084): a run of `n` points starting at path index `start`
+// one primitive: a run of `n` points starting at path index `start` -- the headland layer (MLP:943-1084) and, with obstacle-aware
+// swaths (fcpp_options.obstacle_mode), layer 1 as well (sub-swaths, detour legs, U-turns)
 struct DevPrim {
-    int64_t start;   // index in the field's concatenated path (>= n_main)
+    int64_t start;   // index in the field's concatenated path (>= gen_main)
     int32_t n;
     int32_t kind;    // PrimKind
     int32_t form;    // PRIM_ARC: corner index 0..3 selecting the quadrant formula (MLP:1049-1060)
@@ -30,6 +31,8 @@ struct DevPrim {
     // PRIM_ARC      a0,a1 = corner x,y ; a2 = R ; a3 = theta_end ; a4 = theta step
     // PRIM_RAY      a0,a1 = origin ; a2,a3 = unit direction ; a4 = length ; a5 = t step
     // PRIM_CAC      a0,a1 = start ; a2 = heading ; a3 = signed heading change ; a4 = Re ; a5 = s step ; a6 = total length
+    // PRIM_UTURN    a0 = x anchor, a1 = y of the pass, in the frame of layer 1 ; a2,a3 = rot cos, sin ; a4,a5 = rot centre ;
+    //               form: bit 0 turn right, bit 1 rotate back, bit 2 clothoid model (samples = the batch's U-turn template, MLP:791-830)
     double a[7];
 };
 
@@ -37,6 +40,8 @@ struct DevPrim {
 struct DevField {
     int64_t pt_off;      // first point in the batch arrays
     int64_t n_main;      // points of layer 1
+    int64_t gen_main;    // points of layer 1 that are generated in closed form from the point index (n_main; 0 when layer 1 is a list
+                         // of primitives: obstacle-aware swaths)
     int64_t n_total;     // n_main + n_head
     // layer 1 (MLP:720-789) in the rotated frame
     double lsx, lex;     // line_start_x, line_end_x (MLP:736-737)
@@ -84,11 +89,13 @@ struct DevWaveTile {
     int64_t out_base;        // index of lane 0's point in the batch arrays (pt_off + first)
     int32_t field;
     int32_t tile;            // the tile's index in the tile table = its slot in the partial statistics
-    int32_t count;           // output lanes ...
-    int32_t hb, hf;          // ... after hb halo lanes and before hf halo lanes (hb + count + hf <= 64)
-    int32_t rel_main;        // n_main - first: lanes below it lie in layer 1 (clamped to [-2, 1 << 30])
-    int32_t rel_last;        // (n_total - 1) - first: the lane of the path's last point (clamped likewise)
-    int32_t first_is_0;      // lane 0 is the path's first point
+    uint8_t count;           // output lanes ...
+    uint8_t hb, hf;          // ... after hb halo lanes and before hf halo lanes (hb + count + hf <= 64)
+    uint8_t _pad;
+    int32_t rel_main;        // gen_main - first: lanes below it are generated from layer 1's closed form (clamped to [-2, 1 << 30])
+    int32_t rel_seam;        // n_main - first: the lane of the first point of layer 2 (clamped likewise)
+    int32_t rel_last;        // (n_total - 1) - first: the lane of the path's last point (clamped likewise); first == 0 <=> rel_zero == 0
+    int32_t rel_zero;        // -first clamped: the lane of the path's first point (0) or negative
     int32_t idx0, off0;      // layer 1: (pass position, offset in the pass) of lane 0
     int32_t p0;              // layer 2: primitive (batch-wide index) of the first layer-2 lane ...
     int32_t r0;              // ... and that lane's sample index in it is  lane + r0
@@ -127,7 +134,7 @@ struct HostPlan {
     int64_t total_points = 0;
 };
 // Builds info (+ device descriptors when want_device) for n fields; returns FCPP_OK or FCPP_E*.
-int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields,
+int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
                     bool want_device, HostPlan &out, std::string &err);
 // host+device Fresnel / CAC helpers live in fcpp_geom.h
 }  // namespace fcpp

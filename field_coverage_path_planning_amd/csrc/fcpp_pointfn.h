@@ -110,6 +110,17 @@ __device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst,
         const double t = linspace_at32(0.0, p.a[4], p.a[5], p.n, r);
         px = p.a[0] + t * p.a[2];
         py = p.a[1] + t * p.a[3];
+    } else if (p.kind == PRIM_UTURN) {     // a U-turn of layer 1 as a primitive: template sample + translation (mirror), as in eval_main
+        const double2 t = cst.tmpl_u[r];
+        const bool turn_right = p.form & 1;
+        if (!(p.form & 4)) px = turn_right ? (p.a[0] - t.x) : (p.a[0] + t.x);
+        else px = turn_right ? (p.a[0] + t.x) : (p.a[0] - t.x);
+        py = p.a[1] + t.y;
+        if (p.form & 2) {
+            const double tx = px - p.a[4], ty = py - p.a[5];
+            px = (tx * p.a[2] - ty * p.a[3]) + p.a[4];
+            py = (tx * p.a[3] + ty * p.a[2]) + p.a[5];
+        }
     } else {   // corner turn: quadrant formulas MLP:1049-1060 on the template (t1, t2) = (R(1-cos), R sin) or its clothoid analogue
         const double2 t = cst.tmpl_c[r];
         const int ci = p.kind == PRIM_ARC ? p.form : ((p.form + 3) & 3);

@@ -312,7 +312,7 @@ __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, cons
             const DevPrim &p = prims[tl.idx0];
             const double sx = p.a[4], sy = p.a[5];
             step_len = (sy == 0.0) ? fabs(sx) : ((sx == 0.0) ? fabs(sy) : sqrt(sx * sx + sy * sy));
-            msnom = nominal_ms(p.fs, cst); layer = 1;
+            msnom = nominal_ms(p.fs, cst); layer = tl.start >= fields[tl.field].n_main ? 1 : 0;      // (a straight of layer 1: obstacle-aware swaths)
         }
         // one segment of one step per point: a run's first segment comes from its left neighbour on the same straight -- unless the
         // run starts the line (off0 = 0, swath lines between quiet U-turns): then it is the jump from the previous turn's end, or

@@ -27,11 +27,11 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     const bool act = lane < nl;
     const bool out = lane >= Hb && lane < Hb + wt.count;
     // the lane's position on the path, relative to the tile's first lane (32-bit throughout)
-    const bool in_main = lane < wt.rel_main;                 // layer 1
-    const bool is_first = wt.first_is_0 && lane == 0;        // the path's first point
+    const bool in_main = lane < wt.rel_main;                 // generated from layer 1's closed form
+    const bool is_first = lane == wt.rel_zero;               // the path's first point
     const bool is_last = lane == wt.rel_last;                // the path's last point
-    const bool at_seam = lane == wt.rel_main;                // first point of layer 2
-    const bool is_second = wt.first_is_0 && lane == 1;       // path index 1
+    const bool at_seam = lane == wt.rel_seam;                // first point of layer 2
+    const bool is_second = lane == wt.rel_zero + 1;          // path index 1
 
     // ---- 1. the lane's point --------------------------------------------------------------------------------------------------
     // Everything needed to address the point's data is in the tile record: primitive records, turn template samples and the field's
@@ -121,7 +121,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     // ---- 5. metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) on the output lanes ---------------------------------------
     const double vprev = lane_prev(vfin), kprev = lane_prev(kappa), vnprev = lane_prev(vn);
     if (out && !is_first && !at_seam) {                     // the seam main|headland belongs to neither layer
-        const int layer = in_main ? 0 : 1;
+        const int layer = lane < wt.rel_seam ? 0 : 1;
         const double ms_pre = (vnprev == vn) ? msn : ((vnprev + vn) / 2) / 3.6;
         const double tpre = dprev / fmax(ms_pre, 0.1);
         const double t = (vprev == vnprev && vfin == vn) ? tpre : dprev / fmax(((vprev + vfin) / 2) / 3.6, 0.1);

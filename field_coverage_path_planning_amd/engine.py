@@ -69,8 +69,12 @@ def make_vehicle(vp=None, **kw):
     return v
 
 
-def make_options(turn_model=L.TURN_ARC, sample_spacing=0.0, clothoid_frac=0.5, clothoid_fit=1, geofence_tol=1e-6):
+def make_options(turn_model=L.TURN_ARC, sample_spacing=0.0, clothoid_frac=0.5, clothoid_fit=1, geofence_tol=1e-6,
+                 avoid_obstacles=False):
+    """fcpp_options.  avoid_obstacles: clip the swaths of layer 1 at the obstacles and drive around them (build-defined,
+    include/fcpp.h); False = the reference's behaviour (obstacles only flag the points inside them)."""
     o = L.default_options()
+    o.obstacle_mode = L.OBSTACLES_AVOID if avoid_obstacles else L.OBSTACLES_FLAG
     o.turn_model = int(turn_model)
     o.sample_spacing = float(sample_spacing)
     o.clothoid_frac = float(clothoid_frac)
@@ -132,9 +136,9 @@ def pack_fields(specs):
 def plan_count(specs, vehicle, options):
     """Host-only sizing/decisions (fcpp_plan_count); needs no GPU."""
     lib = L.load()
-    arr, _, _keep = pack_fields(specs)
+    arr, polys, _keep = pack_fields(specs)
     info = (L.FieldInfo * max(len(specs), 1))()
-    L.check(lib.fcpp_plan_count(C.byref(vehicle), C.byref(options), len(specs), arr, info))
+    L.check(lib.fcpp_plan_count(C.byref(vehicle), C.byref(options), len(specs), arr, C.byref(polys), info))
     return [info[i] for i in range(len(specs))]
 
 

@@ -60,7 +60,23 @@ typedef struct fcpp_options {
     double sample_spacing;  /* 0: the reference's fixed counts (2/20/15/20, reverse 0.5 m); >0: uniform arc-length spacing [m] */
     double clothoid_frac;   /* share of a turn's heading change spent in its two clothoids, in [0,1] */
     double geofence_tol;    /* a point further than this outside the field polygon is flagged [m] */
+    int32_t obstacle_mode;  /* FCPP_OBSTACLES_FLAG: obstacles only set the validity flag of the points inside them (the reference: its
+                               swath generator ignores the differenced work area, MLP:731-732); FCPP_OBSTACLES_AVOID: the swaths
+                               of layer 1 are clipped against the obstacles and re-routed around them (below) */
+    int32_t _pad;
 } fcpp_options;
+
+/* Obstacle-aware swaths (what README_en.md:156-178 promises and MLP:601-609 prepares: obstacles expanded by
+ * working_width / 2 and taken out of the work area).  Build-defined -- the reference has no code for it.  In the frame of layer 1
+ * (MLP:686-687) every obstacle is represented by the bounding box of its vertices grown by W/2 on every side.  A swath line whose
+ * y lies strictly inside a box is CLIPPED at the box: the vehicle works up to the box's near side, drives three straight legs
+ * around it -- along the near side to the box's top or bottom (the closer one), along that side, and back along the far side to
+ * the line -- and resumes the swath (segment kind FCPP_KIND_DETOUR, nominal speed headland_turn_speed_kmh; sampled like the
+ * reverse fills at the reference's sampling: 0.5 m, at least 2 points per leg).  Sub-swaths and legs are numpy.linspace runs
+ * between their end points in field coordinates; U-turns are unchanged.  A field where a box reaches a swath line's end zone
+ * (within 1e-9 of line_start_x / line_end_x), or where two boxes overlap along one line, is refused with FCPP_EUNSUPPORTED (its
+ * status; the other fields of the batch are planned).  The headland loops are not re-routed. */
+enum { FCPP_OBSTACLES_FLAG = 0, FCPP_OBSTACLES_AVOID = 1 };
 
 /* ---- one field = one planner instance (ctor arguments, MLP:63-72) ---------------------- */
 typedef struct fcpp_field {
@@ -113,7 +129,7 @@ typedef struct fcpp_field_stats {
 /* ---- flag / segment word -------------------------------------------------------------- */
 enum {
     FCPP_KIND_SWATH = 0, FCPP_KIND_UTURN = 1, FCPP_KIND_HEAD_START = 2, FCPP_KIND_HEAD_STRAIGHT = 3,
-    FCPP_KIND_CORNER = 4, FCPP_KIND_REVERSE = 5
+    FCPP_KIND_CORNER = 4, FCPP_KIND_REVERSE = 5, FCPP_KIND_DETOUR = 6
 };
 #define FCPP_KIND_MASK 7u
 #define FCPP_FLAG_HEADLAND 8u     /* layer 2 */
@@ -145,7 +161,8 @@ int fcpp_memcpy_d2h(fcpp_ctx *ctx, void *dst, const void *src_dev, int64_t bytes
  * _select_best_start_corner (:360-385), _determine_optimal_pass_order (:631-668), num_passes (:739),
  * num_loops (:916), reverse-fill lengths (:1154-1288).  Fields that raise get info[i].status < 0. */
 int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
-                    const fcpp_field *fields, fcpp_field_info *info_out);
+                    const fcpp_field *fields, const fcpp_polys *obstacles /* may be NULL unless obstacle_mode = AVOID */,
+                    fcpp_field_info *info_out);
 /* Same setup, plus upload of the per-field descriptors to the device. */
 int fcpp_batch_create(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
                       const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **batch);

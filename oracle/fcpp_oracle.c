@@ -666,7 +666,107 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
     out->reverse_order = reverse_order; out->start_from_right = start_from_right;
 
     pbuf pb; memset(&pb, 0, sizeof(pb));
-    {   /* MLP:720-789 */
+    if (opt->obstacle_mode == 1) {
+        /* ---- BUILD-DEFINED: obstacle-aware swaths (include/fcpp.h, fcpp_options.obstacle_mode).  Every obstacle = the bounding box
+         * of its vertices in the frame of layer 1, grown by W/2; a swath line strictly inside a box's y-range is clipped at the box and
+         * the box is passed on three straight legs over its nearer side (top or bottom).  Sub-swaths and legs are numpy.linspace runs
+         * between their end points in FIELD coordinates (the end points are rotated back, not the samples); U-turns as in the
+         * reference (rotated back point by point). ---- */
+        double lsx = min_x + R, lex = max_x - R;
+        int64_t P = (int64_t)((max_y - min_y) / W) + 1;
+        out->n_swaths = (int32_t)P;
+        int64_t n_turn = ds > 0 ? n_for_length(turn_length(M_PI, R, opt), ds) : 20;
+        int nb = f->n_obstacles;
+        double *bx0 = (double *)malloc((size_t)(nb + 1) * 4 * sizeof(double)), *by0 = bx0 + nb + 1, *bx1 = by0 + nb + 1, *by1 = bx1 + nb + 1;
+        int *ord = (int *)malloc((size_t)(nb + 1) * sizeof(int));
+        int nbox = 0;
+        for (int k = 0; k < nb; ++k) {
+            int64_t a0 = f->obs_offsets[k], a1 = f->obs_offsets[k + 1];
+            if (a1 <= a0) continue;
+            double x0 = HUGE_VAL, y0 = HUGE_VAL, x1 = -HUGE_VAL, y1 = -HUGE_VAL;
+            for (int64_t q = a0; q < a1; ++q) {
+                double o[2] = { f->obs_xy[2 * q], f->obs_xy[2 * q + 1] };
+                if (rotated) orc_rotate_point(o[0], o[1], -rot, ccx, ccy, o);
+                if (o[0] < x0) x0 = o[0];
+                if (o[0] > x1) x1 = o[0];
+                if (o[1] < y0) y0 = o[1];
+                if (o[1] > y1) y1 = o[1];
+            }
+            bx0[nbox] = x0 - W / 2; by0[nbox] = y0 - W / 2; bx1[nbox] = x1 + W / 2; by1[nbox] = y1 + W / 2;
+            ++nbox;
+        }
+        double lo = lsx < lex ? lsx : lex, hi = lsx < lex ? lex : lsx;
+        int unsupported = 0;
+        double *tb = (double *)malloc((size_t)n_turn * 2 * sizeof(double));
+        for (int64_t idx = 0; idx < P && !unsupported; ++idx) {
+            int64_t i = reverse_order ? (P - 1 - idx) : idx;
+            double y = min_y + (double)i * W;
+            int go_left = start_from_right ? (idx % 2 == 0) : (idx % 2 == 1);
+            double xs = go_left ? lex : lsx, xe = go_left ? lsx : lex;
+            uint32_t swath = ORC_KIND_SWATH | ((uint32_t)i << ORC_INDEX_SHIFT), detour = ORC_KIND_DETOUR | ((uint32_t)i << ORC_INDEX_SHIFT);
+            /* the boxes this line runs into, in travel order */
+            int m = 0;
+            for (int k = 0; k < nbox; ++k)
+                if (by0[k] < y && y < by1[k] && bx1[k] > lo && bx0[k] < hi) ord[m++] = k;
+            for (int a = 1; a < m; ++a) {                       /* insertion sort by the near side */
+                int k = ord[a], b = a - 1;
+                while (b >= 0 && (go_left ? bx1[ord[b]] < bx1[k] : bx0[ord[b]] > bx0[k])) { ord[b + 1] = ord[b]; --b; }
+                ord[b + 1] = k;
+            }
+            /* legs of the pass: (ax, ay) -> (bx, by) in the frame, kind */
+            double cur = xs;
+            for (int a = 0; a <= m && !unsupported; ++a) {
+                double legs[4][4];
+                uint32_t kinds[4];
+                int nleg = 0;
+                if (a < m) {
+                    int k = ord[a];
+                    double nearx = go_left ? bx1[k] : bx0[k], farx = go_left ? bx0[k] : bx1[k];
+                    if (!(bx0[k] > lo + 1e-9 && bx1[k] < hi - 1e-9) || !(go_left ? nearx < cur - 1e-9 : nearx > cur + 1e-9)) { unsupported = 1; break; }
+                    double ys = (by1[k] - y <= y - by0[k]) ? by1[k] : by0[k];
+                    double L4[4][4] = { { cur, y, nearx, y }, { nearx, y, nearx, ys }, { nearx, ys, farx, ys }, { farx, ys, farx, y } };
+                    memcpy(legs, L4, sizeof(L4));
+                    kinds[0] = swath; kinds[1] = kinds[2] = kinds[3] = detour;
+                    nleg = 4;
+                    cur = farx;
+                } else {
+                    legs[0][0] = cur; legs[0][1] = y; legs[0][2] = xe; legs[0][3] = y;
+                    kinds[0] = swath;
+                    nleg = 1;
+                }
+                for (int l = 0; l < nleg; ++l) {
+                    double ax = legs[l][0], ay = legs[l][1], bxx = legs[l][2], byy = legs[l][3];
+                    double len = sqrt((bxx - ax) * (bxx - ax) + (byy - ay) * (byy - ay));
+                    int is_detour = kinds[l] == detour;
+                    int64_t np;
+                    if (ds > 0) np = n_for_length(len, ds);
+                    else if (is_detour) { np = (int64_t)(len / 0.5) + 1; if (np < 2) np = 2; }
+                    else np = 2;
+                    if (rotated) {
+                        double o[2];
+                        orc_rotate_point(ax, ay, rot, ccx, ccy, o); ax = o[0]; ay = o[1];
+                        orc_rotate_point(bxx, byy, rot, ccx, ccy, o); bxx = o[0]; byy = o[1];
+                    }
+                    double *lb = (double *)malloc((size_t)np * 2 * sizeof(double));
+                    orc_straight(ax, ay, bxx, byy, np, lb);
+                    pb_push(&pb, lb, np, is_detour ? veh->headland_turn_speed_kmh : veh->max_work_speed_kmh, kinds[l]);
+                    free(lb);
+                }
+            }
+            if (unsupported) break;
+            if (idx < P - 1) {
+                int turn_right = !go_left;
+                if (opt->turn_model == 0) arc_uturn(y, turn_right, min_x, max_x, R, n_turn, tb);
+                else if (turn_right) cac_sample(max_x - R, y, M_PI / 2, -M_PI, R, opt, n_turn, tb);
+                else cac_sample(min_x + R, y, M_PI / 2, M_PI, R, opt, n_turn, tb);
+                if (rotated)
+                    for (int64_t q = 0; q < n_turn; ++q) orc_rotate_point(tb[2 * q], tb[2 * q + 1], rot, ccx, ccy, tb + 2 * q);
+                pb_push(&pb, tb, n_turn, veh->headland_turn_speed_kmh, ORC_KIND_UTURN | ((uint32_t)i << ORC_INDEX_SHIFT));
+            }
+        }
+        free(tb); free(ord); free(bx0);
+        if (unsupported) { free(pb.xy); free(pb.v); free(pb.fs); return -3; }
+    } else {
         double lsx = min_x + R, lex = max_x - R;
         int64_t P = (int64_t)((max_y - min_y) / W) + 1;
         out->n_swaths = (int32_t)P;
@@ -691,10 +791,10 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             }
         }
         free(lb);
+        if (rotated)                                                             /* MLP:709-714 */
+            for (int64_t i = 0; i < pb.n; ++i)
+                orc_rotate_point(pb.xy[2 * i], pb.xy[2 * i + 1], rot, ccx, ccy, pb.xy + 2 * i);
     }
-    if (rotated)                                                                 /* MLP:709-714 */
-        for (int64_t i = 0; i < pb.n; ++i)
-            orc_rotate_point(pb.xy[2 * i], pb.xy[2 * i + 1], rot, ccx, ccy, pb.xy + 2 * i);
     int64_t n_main = pb.n;
     out->n_main = n_main;
 

@@ -37,6 +37,8 @@ typedef struct {
     double sample_spacing;  /* 0 = reference counts 2/20/15/20 ; >0 = uniform arc-length spacing [m] */
     double clothoid_frac;   /* share of a turn's heading change spent in the two clothoids, [0,1] */
     double geofence_tol;    /* a point is out of field if it is more than this outside [m] */
+    int32_t obstacle_mode;  /* 0 obstacles only flag points (the reference, MLP:731-732) ; 1 swaths clipped and re-routed (include/fcpp.h) */
+    int32_t _pad;
 } orc_options;
 
 typedef struct {
@@ -52,7 +54,7 @@ typedef struct {
 /* flag/segment word, one per path point (same packing as include/fcpp.h) */
 enum {
     ORC_KIND_SWATH = 0, ORC_KIND_UTURN = 1, ORC_KIND_HEAD_START = 2, ORC_KIND_HEAD_STRAIGHT = 3,
-    ORC_KIND_CORNER = 4, ORC_KIND_REVERSE = 5,
+    ORC_KIND_CORNER = 4, ORC_KIND_REVERSE = 5, ORC_KIND_DETOUR = 6,
     ORC_KIND_MASK = 7u, ORC_FLAG_HEADLAND = 8u, ORC_FLAG_ALAT = 16u, ORC_FLAG_OUTSIDE = 32u,
     ORC_FLAG_OBSTACLE = 64u, ORC_INDEX_SHIFT = 8
 };

@@ -13,7 +13,7 @@ c_i64_p = C.POINTER(C.c_int64)
 c_i32_p = C.POINTER(C.c_int32)
 c_u32_p = C.POINTER(C.c_uint32)
 
-KIND_SWATH, KIND_UTURN, KIND_HEAD_START, KIND_HEAD_STRAIGHT, KIND_CORNER, KIND_REVERSE = range(6)
+KIND_SWATH, KIND_UTURN, KIND_HEAD_START, KIND_HEAD_STRAIGHT, KIND_CORNER, KIND_REVERSE, KIND_DETOUR = range(7)
 KIND_MASK, FLAG_HEADLAND, FLAG_ALAT, FLAG_OUTSIDE, FLAG_OBSTACLE, INDEX_SHIFT = 7, 8, 16, 32, 64, 8
 
 
@@ -55,11 +55,11 @@ class GaResult(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('turn_model', C.c_int32), ('clothoid_fit', C.c_int32), ('sample_spacing', C.c_double),
-                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double)]
+                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double), ('obstacle_mode', C.c_int32), ('_pad', C.c_int32)]
 
     @classmethod
-    def make(cls, turn_model=0, clothoid_fit=1, sample_spacing=0.0, clothoid_frac=0.5, geofence_tol=1e-6):
-        return cls(turn_model, clothoid_fit, sample_spacing, clothoid_frac, geofence_tol)
+    def make(cls, turn_model=0, clothoid_fit=1, sample_spacing=0.0, clothoid_frac=0.5, geofence_tol=1e-6, obstacle_mode=0):
+        return cls(turn_model, clothoid_fit, sample_spacing, clothoid_frac, geofence_tol, obstacle_mode, 0)
 
 
 class Field(C.Structure):

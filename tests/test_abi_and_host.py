@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(L.Vehicle) == 64 and C.sizeof(L.Options) == 32
+    assert C.sizeof(L.Vehicle) == 64 and C.sizeof(L.Options) == 40     # 2 ints | 3 doubles | obstacle_mode + pad
     assert C.sizeof(L.Field) == 64 + 12 + 4 + 32 + 8 + 8       # vx,vy | 3 ints + pad | 4 doubles | 2 ints | int64
     assert C.sizeof(L.FieldStats) == 13 * 8
     v = L.default_vehicle()
@@ -103,6 +103,26 @@ def test_plan_count_dense_and_clothoid_vs_oracle():
         assert rc == 0 and info.status == 0
         assert (info.n_main, info.n_head, info.n_swaths) == (p.n_main, p.n_head, p.n_swaths), (trial, ds, tm, frac, fit)
         assert list(info.n_reverse) == p.n_reverse
+
+
+def test_plan_count_with_obstacle_aware_swaths_vs_oracle():
+    """obstacle_mode = AVOID (include/fcpp.h): the host-side sizing -- sub-swaths, detour legs, U-turns as primitives --
+    gives the oracle's point counts, and the same refusals."""
+    rect_obs = [[(150.0, 60.0), (170.0, 60.0), (170.0, 80.0), (150.0, 80.0)], [(240.0, 120.0), (262.0, 124.0), (249.0, 141.0)]]
+    near_end = [[(10.0, 100.0), (30.0, 100.0), (30.0, 120.0), (10.0, 120.0)]]
+    cases = [(dict(field_length=400.0, field_width=220.0, obstacles=rect_obs), dict(L=400.0, H=220.0, obstacles=rect_obs)),
+             (dict(field_length=400.0, field_width=220.0, obstacles=near_end), dict(L=400.0, H=220.0, obstacles=near_end)),
+             (dict(field_length=300.0, field_width=150.0), dict(L=300.0, H=150.0))]
+    for tm, sp in ((0, 0.0), (0, 0.5), (1, 0.25)):
+        infos = E.plan_count([E.FieldSpec(**a) for a, _ in cases], E.make_vehicle(), E.make_options(tm, sp, avoid_obstacles=True))
+        base = E.plan_count([E.FieldSpec(**a) for a, _ in cases], E.make_vehicle(), E.make_options(tm, sp))
+        for k, (_, okw) in enumerate(cases):
+            rc, p = orc.plan_field(orc.make_field(**okw), orc.Vehicle.make(), orc.Options.make(tm, 1, sp, 0.5, 1e-6, 1))
+            assert rc == infos[k].status, (tm, sp, k)
+            if rc == 0:
+                assert (infos[k].n_main, infos[k].n_head) == (p.n_main, p.n_head)
+        assert infos[1].status == L.EUNSUPPORTED and base[1].status == 0
+        assert infos[0].n_main > base[0].n_main and infos[2].n_main == base[2].n_main      # detours add points; no obstacles: none
 
 
 def test_plan_count_errors_and_batches():

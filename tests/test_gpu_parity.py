@@ -95,7 +95,7 @@ def _compare_with_oracle_mode(mode, specs, ofields, veh_arr, opt_kw, xy_tol, k_t
     res = batch.run(mode=mode)
     x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
     st = res.stats()
-    oopt = orc.Options.make(o.turn_model, o.clothoid_fit, o.sample_spacing, o.clothoid_frac, o.geofence_tol)
+    oopt = orc.Options.make(o.turn_model, o.clothoid_fit, o.sample_spacing, o.clothoid_frac, o.geofence_tol, o.obstacle_mode)
     for i, of in enumerate(ofields):
         rc, p = orc.plan_field(of, orc.Vehicle.make(veh_arr), oopt)
         info = batch.info[i]
@@ -171,6 +171,69 @@ def test_obstacles_and_geofence_flags_vs_oracle():
     b = E.Batch(specs[:8], _veh(DEFAULT_VP), E.make_options(sample_spacing=1.0))
     assert b.run().stats()['n_in_obstacle'].sum() > 0
     b.close()
+
+
+def _clip_fields():
+    """fields whose obstacles sit inside the work area, away from the swath lines' end zones: a rectangle with a square, a triangle
+    and a pentagon (the last two side by side on the same swaths), and a tilted parallelogram with two obstacles"""
+    rect_obs = [[(150.0, 60.0), (170.0, 60.0), (170.0, 80.0), (150.0, 80.0)],
+                [(240.0, 120.0), (262.0, 124.0), (249.0, 141.0)],
+                [(300.0, 118.0), (312.0, 114.0), (321.0, 125.0), (314.0, 138.0), (301.0, 134.0)]]
+    specs = [E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=rect_obs, start_point=(390.0, 200.0))]
+    ofs = [orc.make_field(L=400.0, H=220.0, obstacles=rect_obs, start=(390.0, 200.0))]
+    rot = 0.3
+    c, s = np.cos(rot), np.sin(rot)
+    tilt = lambda pts: [(float(x * c - y * s), float(x * s + y * c)) for x, y in pts]
+    verts = tilt([(0.0, 0.0), (500.0, 0.0), (560.0, 260.0), (60.0, 260.0)])
+    para_obs = [tilt([(200.0, 100.0), (230.0, 100.0), (230.0, 125.0), (200.0, 125.0)]), tilt([(340.0, 150.0), (365.0, 160.0), (350.0, 185.0)])]
+    specs.append(E.FieldSpec(field_vertices=verts, obstacles=para_obs))
+    ofs.append(orc.make_field(verts=verts, obstacles=para_obs))
+    return specs, ofs
+
+
+@pytest.mark.parametrize('opt', [dict(), dict(sample_spacing=0.5), dict(turn_model=1, sample_spacing=0.2), dict(turn_model=1)])
+def test_obstacle_aware_swaths_vs_oracle(opt):
+    """SURVEY.md 8f-4 (build-defined, include/fcpp.h): with obstacle_mode = AVOID the swaths are clipped at the obstacles' boxes and
+    re-routed around them.  Every array against the oracle's independent restatement, in both pipelines; no path point of layer 1 is
+    left inside an obstacle, while the reference's behaviour (obstacles only flagged) leaves some."""
+    specs, ofs = _clip_fields()
+    ds = opt.get('sample_spacing', 0.0) or 0.5
+    k_tol = max(K_TOL, 4e-12 / ds ** 2)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(opt, avoid_obstacles=True), xy_tol=1e-9, k_tol=k_tol, v_tol=max(V_TOL, 200 * k_tol))
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(avoid_obstacles=True, **opt))
+    res = b.run()
+    st = res.stats()
+    fs = _np(res.flagseg).view(np.uint32)
+    assert int(st['n_in_obstacle'].sum()) == 0 and int((fs & L.FLAG_OBSTACLE != 0).sum()) == 0
+    assert int(((fs & L.KIND_MASK) == L.KIND_DETOUR).sum()) > 0
+    assert all(i.status == 0 for i in b.info)
+    b.close()
+    if opt.get('sample_spacing', 0.0) > 0:
+        b0 = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**opt))
+        assert int(b0.run().stats()['n_in_obstacle'].sum()) > 0          # the same fields without the option: swaths cross the obstacles
+        b0.close()
+
+
+def test_obstacle_aware_swaths_edge_cases():
+    """An obstacle box that reaches a swath line's end zone, or two boxes that overlap along a line: FCPP_EUNSUPPORTED for that field
+    only (library and oracle agree); a field without obstacles plans exactly as without the option (unrotated: bit for bit)."""
+    near_end = [[(10.0, 100.0), (30.0, 100.0), (30.0, 120.0), (10.0, 120.0)]]
+    overlap = [[(150.0, 60.0), (170.0, 60.0), (170.0, 80.0), (150.0, 80.0)], [(165.0, 65.0), (190.0, 65.0), (190.0, 85.0), (165.0, 85.0)]]
+    specs = [E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=near_end),
+             E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=overlap),
+             E.FieldSpec(field_length=400.0, field_width=220.0)]
+    ofs = [orc.make_field(L=400.0, H=220.0, obstacles=near_end), orc.make_field(L=400.0, H=220.0, obstacles=overlap),
+           orc.make_field(L=400.0, H=220.0)]
+    for kw in (dict(avoid_obstacles=True), dict(avoid_obstacles=True, sample_spacing=0.5)):
+        _compare_with_oracle(specs, ofs, DEFAULT_VP, kw, k_tol=1e-8, v_tol=1e-6)
+        b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**kw))
+        assert [i.status for i in b.info] == [L.EUNSUPPORTED, L.EUNSUPPORTED, 0]
+        r1 = b.run()
+        b0 = E.Batch(specs[2:], _veh(DEFAULT_VP), E.make_options(**{k: v for k, v in kw.items() if k != 'avoid_obstacles'}))
+        r0 = b0.run()
+        for a in ('x', 'y', 'kappa', 'v', 'flagseg'):
+            assert np.array_equal(_np(getattr(r1, a)), _np(getattr(r0, a))), a
+        b.close(); b0.close()
 
 
 def test_error_fields_inside_a_batch():
