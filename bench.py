@@ -178,10 +178,15 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
+    # FCPP_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (ranks share devices, the
+    # collectives carry host tensors); the measured configuration is nccl = RCCL, one rank per GPU
+    backend = os.environ.get('FCPP_BENCH_BACKEND', 'nccl')
+    local = local % torch.cuda.device_count() if backend == 'gloo' else local
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    cdev = dev if backend == 'nccl' else torch.device('cpu')          # where the collectives' tensors live
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     def fence():
         if world > 1:
@@ -189,13 +194,13 @@ def main():
         torch.cuda.synchronize()
 
     def allmax(v):
-        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def allsum(v):
-        t = torch.tensor([float(v)], dtype=torch.float64, device=dev)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
@@ -216,11 +221,11 @@ def main():
             return
         nonlocal gather_bufs
         if gather_bufs is None:
-            gather_bufs = [[torch.empty_like(res.stats_raw) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+            gather_bufs = [[torch.empty_like(res.stats_raw, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(2)]
         slot = len(pending) & 1
         if len(pending) >= 2:
             pending[-2].wait()
-        snap = res.stats_raw.clone()                        # the batch's stats buffer is rewritten by the next step
+        snap = res.stats_raw.clone() if backend == 'nccl' else res.stats_raw.cpu()     # (the stats buffer is rewritten by the next step)
         pending.append(dist.gather(snap, gather_bufs[slot], dst=0, async_op=True))
 
     def fence_headline():
@@ -319,7 +324,7 @@ def main():
         if 'cfg4' in want:
             configs.append(run_cfg4(E, torch, WL, cpu_on))
     if 'cfg5' in want or world > 1:
-        entry = run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, fence, allmax, max(5, args.steps // 5), cpu_on)
+        entry = run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, max(5, args.steps // 5), cpu_on)
         if rank == 0:
             configs.append(entry)
     if world > 1 and 'cfg2_0.1' in want:
@@ -388,7 +393,7 @@ def run_cfg4(E, torch, WL, cpu_on):
             'cpu_baseline': cpu}
 
 
-def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, fence, allmax, steps, cpu_on):
+def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, steps, cpu_on):
     """cfg5: 65 536 parallelograms through sharding.plan_sharded -- one block of fields per rank, cut on the analytic point counts."""
     V = WL.cfg5_parallelograms()
     specs = WL.specs_from_vertices(E, V)
@@ -419,7 +424,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, fence, allmax, steps, 
     dt_local = time.perf_counter() - t0
     fence()
     my_points = batch.total_points
-    per_rank = torch.zeros(world, 2, dtype=torch.float64, device=dev)
+    per_rank = torch.zeros(world, 2, dtype=torch.float64, device=cdev)
     per_rank[rank, 0], per_rank[rank, 1] = float(my_points), dt_local / steps
     if world > 1:
         dist.all_reduce(per_rank)

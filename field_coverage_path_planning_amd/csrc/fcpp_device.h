@@ -59,11 +59,11 @@ int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
 int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
                     const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
-// ids / run_count: see k_reduce_stats; tiles, fields, prims, cst are only needed with run_count
-int launch_reduce_stats(hipStream_t st, int64_t n_paths, TilePartial *partial, const int64_t *tile_first,
+// ids / run_count / path_list / group (lanes per path: 8, 64 or 256): see k_reduce_stats; tiles, fields, prims, cst only with run_count
+int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr,
                         const int64_t *run_count = nullptr, const DevTile *tiles = nullptr, const DevField *fields = nullptr,
-                        const DevPrim *prims = nullptr, const DevConst *cst = nullptr);
+                        const DevPrim *prims = nullptr, const DevConst *cst = nullptr, const int32_t *path_list = nullptr, int group = 64);
 int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc);
 // ids: tile indices the launch covers (NULL = all tiles in order)
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,

@@ -353,58 +353,117 @@ __global__ __launch_bounds__(BLOCK) void k_validate(const DevTile *__restrict__ 
     }
 }
 
-// one wave per path: lanes stride over the path's tiles in a fixed assignment, then a fixed butterfly
+// G lanes per path: the lanes stride over the path's entries in a fixed assignment, then a fixed butterfly over the group.
 // ids (optional): the reduction runs over partial[ids[k]], k in [tile_first[p], tile_first[p+1]) -- the fused pipeline lists only the
 // tiles that can hold statistics (general tiles, wave tiles and the first tile of every quiet run; the others stay zero).
 // run_count (with ids): > 0 for the first tile of a quiet run of that many points: its length / time / curvature statistics are the
 // run's closed form (fcpp_quiet_fn.h), evaluated here; its partial slot only collects the flag counts k_plan_quiet adds while it
 // stores the run, and is cleared again for the next step.
-__global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_paths, const int64_t *__restrict__ tile_first,
-                                                     TilePartial *__restrict__ partial,
-                                                     const unsigned long long *__restrict__ n_adjusted,
+// path_list (optional): the paths this launch reduces.  The fused pipeline sorts its paths into three classes BY THEIR NUMBER OF
+// ENTRIES -- a property of the field alone, so that a field's sums are added in the same order whatever batch it is part of --:
+// up to 64 entries: 8 lanes per path (a plan at the reference's sampling has about ten); up to 8192: a wavefront per path; above
+// (one path of 6e7 points has 1.2e5): a workgroup per path, k_reduce_stats_wg.
+struct StatAcc {
+    double a[9];
+    long long b[4];
+};
+
+__device__ __forceinline__ void stat_entry(StatAcc &s, int64_t t, TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
+                                           const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
+                                           const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, const DevConst &cst)
+{
+    const int64_t slot = ids ? (int64_t)ids[t] : t;
+    TilePartial tp = partial[slot];
+    const int64_t rc = run_count ? run_count[t] : 0;
+    if (rc > 0) {
+        const DevRun run = { (int32_t)slot, 0, rc };
+        const TilePartial rp = quiet_run_partial(run, tiles[slot], fields, prims, cst);
+        tp.main_len = rp.main_len; tp.main_time_pre = rp.main_time_pre; tp.main_time = rp.main_time;
+        tp.head_len = rp.head_len; tp.head_time_pre = rp.head_time_pre; tp.head_time = rp.head_time;
+        tp.max_kappa = rp.max_kappa; tp.max_alat = rp.max_alat; tp.max_jump = rp.max_jump;
+        if (tp.n_outside | tp.n_in_obstacle) { partial[slot].n_outside = 0; partial[slot].n_in_obstacle = 0; }
+    }
+    s.a[0] += tp.main_len; s.a[1] += tp.main_time_pre; s.a[2] += tp.main_time;
+    s.a[3] += tp.head_len; s.a[4] += tp.head_time_pre; s.a[5] += tp.head_time;
+    s.a[6] = fmax(s.a[6], tp.max_kappa); s.a[7] = fmax(s.a[7], tp.max_alat); s.a[8] = fmax(s.a[8], tp.max_jump);
+    s.b[0] += tp.n_viol; s.b[1] += tp.n_outside; s.b[2] += tp.n_in_obstacle; s.b[3] += tp.n_adjusted;
+}
+
+__device__ __forceinline__ void stat_store(const StatAcc &s, int64_t pth, const unsigned long long *__restrict__ n_adjusted,
+                                           fcpp_field_stats *__restrict__ stats)
+{
+    fcpp_field_stats o;
+    o.main_len_m = s.a[0]; o.main_time_pre_s = s.a[1]; o.main_time_s = s.a[2];
+    o.head_len_m = s.a[3]; o.head_time_pre_s = s.a[4]; o.head_time_s = s.a[5];
+    o.max_kappa = s.a[6]; o.max_alat = s.a[7]; o.max_jump = s.a[8];
+    o.n_viol = s.b[0]; o.n_outside = s.b[1]; o.n_in_obstacle = s.b[2];
+    o.n_adjusted = s.b[3] + (n_adjusted ? (int64_t)n_adjusted[pth] : 0);
+    stats[pth] = o;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_list, const int32_t *__restrict__ path_list, const int64_t *__restrict__ tile_first,
+                                                     TilePartial *__restrict__ partial, const unsigned long long *__restrict__ n_adjusted,
                                                      fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids,
                                                      const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
                                                      const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst)
 {
-    const int64_t pth = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // one wavefront per path, four per workgroup
-    if (pth >= n_paths) return;
-    const int lane = threadIdx.x & 63;
-    double a[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    long long b[4] = { 0, 0, 0, 0 };
-    for (int64_t t = tile_first[pth] + lane; t < tile_first[pth + 1]; t += 64) {
-        const int64_t slot = ids ? (int64_t)ids[t] : t;
-        TilePartial tp = partial[slot];
-        const int64_t rc = run_count ? run_count[t] : 0;
-        if (rc > 0) {
-            const DevRun run = { (int32_t)slot, 0, rc };
-            const TilePartial rp = quiet_run_partial(run, tiles[slot], fields, prims, cst);
-            tp.main_len = rp.main_len; tp.main_time_pre = rp.main_time_pre; tp.main_time = rp.main_time;
-            tp.head_len = rp.head_len; tp.head_time_pre = rp.head_time_pre; tp.head_time = rp.head_time;
-            tp.max_kappa = rp.max_kappa; tp.max_alat = rp.max_alat; tp.max_jump = rp.max_jump;
-            if (tp.n_outside | tp.n_in_obstacle) { partial[slot].n_outside = 0; partial[slot].n_in_obstacle = 0; }
-        }
-        a[0] += tp.main_len; a[1] += tp.main_time_pre; a[2] += tp.main_time;
-        a[3] += tp.head_len; a[4] += tp.head_time_pre; a[5] += tp.head_time;
-        a[6] = fmax(a[6], tp.max_kappa); a[7] = fmax(a[7], tp.max_alat); a[8] = fmax(a[8], tp.max_jump);
-        b[0] += tp.n_viol; b[1] += tp.n_outside; b[2] += tp.n_in_obstacle; b[3] += tp.n_adjusted;
+    const int64_t slot = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    const int sub = threadIdx.x % G;
+    StatAcc s;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s.a[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.b[k] = 0;
+    const int64_t pth = slot < n_list ? (path_list ? (int64_t)path_list[slot] : slot) : -1;
+    if (pth >= 0)
+        for (int64_t t = tile_first[pth] + sub; t < tile_first[pth + 1]; t += G) stat_entry(s, t, partial, ids, run_count, tiles, fields, prims, cst);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s.a[k] += __shfl_xor(s.a[k], o);
+#pragma unroll
+        for (int k = 6; k < 9; ++k) s.a[k] = fmax(s.a[k], __shfl_xor(s.a[k], o));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s.b[k] += __shfl_xor(s.b[k], o);
     }
+    if (pth >= 0 && sub == 0) stat_store(s, pth, n_adjusted, stats);
+}
+
+// a workgroup per path: every thread strides over the entries, the wavefronts' butterflies meet in LDS in wave order
+__global__ __launch_bounds__(256) void k_reduce_stats_wg(int64_t n_list, const int32_t *__restrict__ path_list, const int64_t *__restrict__ tile_first,
+                                                        TilePartial *__restrict__ partial, const unsigned long long *__restrict__ n_adjusted,
+                                                        fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids,
+                                                        const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
+                                                        const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst)
+{
+    __shared__ StatAcc sh[4];
+    const int64_t pth = path_list ? (int64_t)path_list[blockIdx.x] : (int64_t)blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    StatAcc s;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s.a[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.b[k] = 0;
+    for (int64_t t = tile_first[pth] + threadIdx.x; t < tile_first[pth + 1]; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fields, prims, cst);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] += __shfl_xor(a[k], o);
+        for (int k = 0; k < 6; ++k) s.a[k] += __shfl_xor(s.a[k], o);
 #pragma unroll
-        for (int k = 6; k < 9; ++k) a[k] = fmax(a[k], __shfl_xor(a[k], o));
+        for (int k = 6; k < 9; ++k) s.a[k] = fmax(s.a[k], __shfl_xor(s.a[k], o));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) b[k] += __shfl_xor(b[k], o);
+        for (int k = 0; k < 4; ++k) s.b[k] += __shfl_xor(s.b[k], o);
     }
-    if (lane == 0) {
-        fcpp_field_stats s;
-        s.main_len_m = a[0]; s.main_time_pre_s = a[1]; s.main_time_s = a[2];
-        s.head_len_m = a[3]; s.head_time_pre_s = a[4]; s.head_time_s = a[5];
-        s.max_kappa = a[6]; s.max_alat = a[7]; s.max_jump = a[8];
-        s.n_viol = b[0]; s.n_outside = b[1]; s.n_in_obstacle = b[2];
-        s.n_adjusted = b[3] + (n_adjusted ? (int64_t)n_adjusted[pth] : 0);
-        stats[pth] = s;
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w2 = 1; w2 < 4; ++w2) {
+            for (int k = 0; k < 6; ++k) s.a[k] += sh[w2].a[k];
+            for (int k = 6; k < 9; ++k) s.a[k] = fmax(s.a[k], sh[w2].a[k]);
+            for (int k = 0; k < 4; ++k) s.b[k] += sh[w2].b[k];
+        }
+        stat_store(s, pth, n_adjusted, stats);
     }
 }
 
@@ -641,15 +700,25 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
     return 0;
 }
 
-int launch_reduce_stats(hipStream_t st, int64_t n_paths, TilePartial *partial, const int64_t *tile_first,
+// group = lanes per path: 8, 64, or 256 (a workgroup per path)
+int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids, const int64_t *run_count,
-                        const DevTile *tiles, const DevField *fields, const DevPrim *prims, const DevConst *cst)
+                        const DevTile *tiles, const DevField *fields, const DevPrim *prims, const DevConst *cst, const int32_t *path_list,
+                        int group)
 {
-    if (n_paths <= 0) return 0;
+    if (n_list <= 0) return 0;
     DevConst c0;
     memset(&c0, 0, sizeof c0);
-    FCPP_LAUNCH(k_reduce_stats, dim3((unsigned)((n_paths + 3) / 4)), dim3(256), 0, st, n_paths, tile_first, partial,
-                       n_adjusted, stats, ids, run_count, tiles, fields, prims, cst ? *cst : c0);
+    const DevConst &c = cst ? *cst : c0;
+    if (group == 8)
+        FCPP_LAUNCH(k_reduce_stats<8>, dim3((unsigned)((n_list + 31) / 32)), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted,
+                    stats, ids, run_count, tiles, fields, prims, c);
+    else if (group == 256)
+        FCPP_LAUNCH(k_reduce_stats_wg, dim3((unsigned)n_list), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted, stats, ids,
+                    run_count, tiles, fields, prims, c);
+    else
+        FCPP_LAUNCH(k_reduce_stats<64>, dim3((unsigned)((n_list + 3) / 4)), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted,
+                    stats, ids, run_count, tiles, fields, prims, c);
     FCPP_LAUNCH_CHECK();
     return 0;
 }
