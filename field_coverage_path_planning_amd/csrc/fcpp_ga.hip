@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
 }
 
 static constexpr int GA_LDS_POP = 6144;      // 48 KiB of fitness values cached in LDS
-static constexpr int SB = 1024, SW = SB / 64; // the bookkeeping kernel: one workgroup, a chain of ~20 dependent reductions
+static constexpr int SB = 1024, SW = SB / 64; // the bookkeeping kernel: one workgroup
 
 // block-wide reduction of (value, index) pairs with a caller-supplied "a is better than b": shuffles inside the waves, one
 // LDS exchange across them.  Every thread returns the winner.
@@ -233,7 +233,74 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
         for (int k = tid; k < n; k += SB) best_route[k] = cur[(int64_t)s_copy * n + k];
     if (s_stop || gen + 1 >= cfg.max_generations) return;
     // elites of this population for the next generation (GA:254-268): the t-th best in the order (fitness, index) goes to row
-    // pop - 1 - t; each is the maximum among the entries below the previous pick
+    // pop - 1 - t.
+    auto better = [](double af, int ai, double cf, int ci) { return ai >= 0 && (ci < 0 || af > cf || (af == cf && ai > ci)); };
+    if (cached && cfg.elite_size <= 64) {
+        // Up to 64 elites, the population in LDS: every wavefront picks the elite_size best of ITS 1/16 of the population -- elite_size
+        // rounds of a wave-wide arg-max, shuffles only, all wavefronts at once -- and one wavefront picks the elite_size best of those
+        // candidates the same way.  The global top elite_size are among the per-wave ones, and the order (fitness, then the larger
+        // index) is total, so the picks are those of the sequential definition; two dependent phases instead of elite_size.
+        __shared__ double c_f[SW * 64];
+        __shared__ int c_i[SW * 64];
+        constexpr int KPT = GA_LDS_POP / SB;
+        const int lane = tid & 63, wave = tid >> 6, E = cfg.elite_size;
+        double ef[KPT];
+        unsigned taken = 0;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) { const int i = tid + k * SB; ef[k] = i < pop ? s_fit[i] : -1.0; }
+        for (int t = 0; t < E; ++t) {
+            double f = -1.0;
+            int idx = -1, kk = 0;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                const int i = tid + k * SB;
+                if (i < pop && !((taken >> k) & 1u) && better(ef[k], i, f, idx)) { f = ef[k]; idx = i; kk = k; }
+            }
+            double wf = f;
+            int wi = idx;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double of = __shfl_xor(wf, o);
+                const int oi = __shfl_xor(wi, o);
+                if (better(of, oi, wf, wi)) { wf = of; wi = oi; }
+            }
+            if (idx >= 0 && wi == idx) taken |= 1u << kk;         // its owner retires the pick
+            if (lane == 0) { c_f[wave * 64 + t] = wf; c_i[wave * 64 + t] = wi; }
+        }
+        __syncthreads();
+        if (wave == 0) {            // lane t holds the t-th candidate of every wavefront
+            double cf[SW];
+            int ci[SW];
+            unsigned tk = 0;
+#pragma unroll
+            for (int w = 0; w < SW; ++w) { cf[w] = lane < E ? c_f[w * 64 + lane] : -1.0; ci[w] = lane < E ? c_i[w * 64 + lane] : -1; }
+            for (int t = 0; t < E; ++t) {
+                double f = -1.0;
+                int idx = -1, kk = 0;
+#pragma unroll
+                for (int w = 0; w < SW; ++w)
+                    if (!((tk >> w) & 1u) && better(cf[w], ci[w], f, idx)) { f = cf[w]; idx = ci[w]; kk = w; }
+                double wf = f;
+                int wi = idx;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double of = __shfl_xor(wf, o);
+                    const int oi = __shfl_xor(wi, o);
+                    if (better(of, oi, wf, wi)) { wf = of; wi = oi; }
+                }
+                if (idx >= 0 && wi == idx) tk |= 1u << kk;
+                if (lane == 0) s_pick[t] = wi;
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < E * n; q += SB) {
+            const int t = q / n, k = q - t * n;
+            nxt[(int64_t)(pop - 1 - t) * n + k] = cur[(int64_t)s_pick[t] * n + k];
+        }
+        if (tid < E) { const int src = s_pick[tid], row = pop - 1 - tid; nxt_fit[row] = fitv[src]; nxt_dist[row] = cur_dist[src]; }
+        return;
+    }
+    // general case: each pick is the maximum among the entries below the previous pick (elite_size dependent block reductions)
     double pf = 0.0;
     int pi = 0;
     for (int t0 = 0; t0 < cfg.elite_size; t0 += 64) {          // picks in batches of 64, their rows copied together
@@ -246,7 +313,7 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
                 if (t > 0 && !(v < pf || (v == pf && i < pi))) continue;
                 if (idx < 0 || v > f || (v == f && i > idx)) { f = v; idx = i; }
             }
-            block_best(f, idx, s_f, s_i, [](double af, int ai, double cf, int ci) { return ai >= 0 && (ci < 0 || af > cf || (af == cf && ai > ci)); });
+            block_best(f, idx, s_f, s_i, better);
             pf = f; pi = idx;
             if (tid == 0) s_pick[t - t0] = idx;
         }
