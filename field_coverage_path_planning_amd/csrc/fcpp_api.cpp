@@ -903,12 +903,13 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
             HIPCHK(hipMemsetAsync(t.partial.p, 0, (size_t)t.n_tiles * sizeof(TilePartial), st));
             b->partial_dirty = false;
         }
-        // Two streams inside the step where the general tiles are few and long-lived (dense sampling: a handful of tiles that walk
-        // long halos, e.g. cfg3's 5873 points in 0.37 ms): beside the HBM-bound streaming kernel they cost nothing (cfg3 0.87 -> 0.51
-        // ms).  Not at sparse sampling: k_plan_sparse and the span kernel both live on vector-instruction issue (profiles/: SQ
-        // counters) and only slow each other down side by side (measured: cfg5 2.66 vs 2.64 ms, cfg1 x 4096 0.134 vs 0.126 ms).
+        // Two streams inside the step where the general tiles are FEW and long-lived (dense sampling of a single large field: a dozen
+        // tiles that walk long halos, cfg3: 5873 points in 0.37 ms): beside the HBM-bound streaming kernel they cost nothing (cfg3
+        // 0.87 -> 0.51 ms).  Not when the general kernel can fill the chip itself -- side by side it takes compute units from the
+        // streaming kernel (cfg2 at 0.1 m, 5950 general tiles: 6.5 vs 5.6 ms) -- and not at sparse sampling: k_plan_sparse and the
+        // span kernel both live on vector-instruction issue (profiles/: SQ counters; cfg5 2.66 vs 2.64 ms, cfg1 x 4096 0.134 vs 0.126).
         hipStream_t sd = st;
-        const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_wave == 0;
+        const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_general <= 512 && t.n_wave == 0;
         if (two) {
             sd = b->ctx->side;
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));
