@@ -71,6 +71,7 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     c.inv_sf36 = 1.0 / (c.sf * 3.6);
     c.ms_work = c.v_work / 3.6; c.ms_turn = c.v_turn / 3.6; c.ms_head = c.v_head / 3.6; c.ms_rev = 2.5 / 3.6;
     c.shapes = nullptr; c.tmpl_u = nullptr; c.tmpl_c = nullptr; c.tmpl_u_dk = nullptr; c.field_junc = nullptr;
+    c.tmpl_n = 0; c._pad_tmpl = 0;
     c.turn_kappa_last[0] = c.turn_kappa_last[1] = c.turn_len = c.turn_time = 0.0;
     c.turn_max_kappa[0] = c.turn_max_kappa[1] = c.turn_max_jump[0] = c.turn_max_jump[1] = 0.0;
     return c;
@@ -762,6 +763,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
             if (le != 0) e = (hipError_t)le;
         }
         b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p; b->cst.tmpl_u_dk = b->tmpl_u_dk.p;
+        b->cst.tmpl_n = (int)nu;
         if (e == hipSuccess) {
             const int nc = b->hp.tt.nc;
             std::vector<double2> dk((size_t)nu);
@@ -907,7 +909,8 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // tiles that walk long halos, cfg3: 5873 points in 0.37 ms): beside the HBM-bound streaming kernel they cost nothing (cfg3
         // 0.87 -> 0.51 ms).  Not when the general kernel can fill the chip itself -- side by side it takes compute units from the
         // streaming kernel (cfg2 at 0.1 m, 5950 general tiles: 6.5 vs 5.6 ms) -- and not at sparse sampling: k_plan_sparse and the
-        // span kernel both live on vector-instruction issue (profiles/: SQ counters; cfg5 2.66 vs 2.64 ms, cfg1 x 4096 0.134 vs 0.126).
+        // span kernel get in each other's way (cfg5 2.41 vs 2.29 ms, cfg1 x 4096 0.114 vs 0.098 ms, also with the span kernel held to five
+        // waves per SIMD).
         hipStream_t sd = st;
         const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_general <= 512 && t.n_wave == 0;
         if (two) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fcpp_device.h"
 #include "fcpp_geom.h"
@@ -21,6 +22,14 @@
     } while (0)
 
 namespace fcpp {
+
+// launch-time tuning knobs (extra LDS per workgroup = fewer resident waves): an environment variable read at every launch, so that
+// tools/ab_knob.py can flip it between runs of one process on identical memory
+inline int tune_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 
 static constexpr int BLOCK = 256;
 static constexpr int IPT = TILE_POINTS / BLOCK;  // 8

@@ -215,7 +215,7 @@ __global__ void k_field_junctions(int64_t n_fields, const DevField *__restrict__
 }
 
 // the quiet path: one tile per wavefront, four per workgroup; pure HBM streaming at full occupancy
-template <int KINDS, bool SCALAR_DESC>
+template <int KINDS, bool SCALAR_DESC, bool STAGED>
 __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
                                                       const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                       double *__restrict__ xo,
@@ -224,13 +224,15 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
                                                       TilePartial *__restrict__ partial, int64_t n_chunks)
 {
     __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
+    __shared__ double tmpl_lds[4][STAGED ? 3 * TMPL_LDS : 1];
     // the wave index as a scalar: the chunk and field descriptors are then fetched by scalar loads and live in scalar registers
     // (as per-lane copies of the same values they cost ~40 vector registers, i.e. one wave per SIMD of occupancy)
     const int wave = SCALAR_DESC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
     const int64_t slot = (int64_t)blockIdx.x * 4 + wave;   // one chunk per wavefront
     if (slot >= n_chunks) return;
+    if (STAGED) stage_turn_template(cst, tmpl_lds[wave]);  // (its loads are in flight while the descriptors arrive)
     const DevTile tl = chunks[slot];
-    quiet_tile<KINDS>(tl, &fields[tl.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso,
+    quiet_tile<KINDS, STAGED>(tl, &fields[tl.field], prims, cst, obs, obs_lds[wave], tmpl_lds[wave], xo, yo, ko, vo, fso,
                       reinterpret_cast<unsigned long long *>(&partial[tl.stat_tile].n_outside),
                       reinterpret_cast<unsigned long long *>(&partial[tl.stat_tile].n_in_obstacle));
 }
@@ -839,12 +841,15 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
 {
     if (n_chunks <= 0) return 0;
     const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
-#define FCPP_QUIET(K, SD) FCPP_LAUNCH((k_plan_quiet<K, SD>), grid, block, 0, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
+    const int pad = kinds == 16 ? tune_int("FCPP_SPAN_PAD", 6144) : tune_int("FCPP_QUIET_PAD", 0);
+#define FCPP_QUIET(K, SD, TL) FCPP_LAUNCH((k_plan_quiet<K, SD, TL>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
     // Descriptors by scalar loads: 55 instead of 116 vector registers, 7 instead of 4 waves per SIMD.  That nearly halves the time of
     // the spans (latency-bound: pass decode, short runs) but costs the dense kernel 2-4 % on identical memory (tools/ab_quiet.py:
     // 5.61 vs 5.49 ms; capping the occupancy below 4 waves costs more: 5.90 ms at 3, 6.70 ms at 2).
-    if (kinds == 16) FCPP_QUIET(16, true);
-    else FCPP_QUIET(14, false);
+    // Spans of a batch whose U-turn template is short (the reference's 20 samples) read it from LDS (fcpp_quiet_fn.h).
+    if (kinds == 16 && cst.tmpl_n > 0 && cst.tmpl_n <= TMPL_LDS) FCPP_QUIET(16, true, true);
+    else if (kinds == 16) FCPP_QUIET(16, true, false);
+    else FCPP_QUIET(14, false, false);
 #undef FCPP_QUIET
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -8,6 +8,15 @@ namespace fcpp {
 
 // nominal speeds by primitive kind (fs & FCPP_KIND_MASK): a per-lane LDS lookup instead of a divergent switch over scalars
 struct NomTable { double v[8], ms[8]; };
+// a wave-uniform value as an opaque scalar register: the compiler keeps (or spills to a vector-register lane) what it cannot re-derive
+// (values that went through the vector unit -- f64 arithmetic -- come back through readfirstlane)
+__device__ __forceinline__ double uniform_value(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int uniform_value(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#define FCPP_PIN(x) do { x = uniform_value(x); asm volatile("" : "+s"(x)); } while (0)
+static constexpr int TMPL_LDS = 64;        // turn-template samples a wavefront stages in LDS (k_plan_quiet; the reference's turn has 20)
 __device__ __forceinline__ double nom_v(const NomTable &t, uint32_t fs) { return t.v[fs & FCPP_KIND_MASK]; }
 __device__ __forceinline__ double nom_ms(const NomTable &t, uint32_t fs) { return t.ms[fs & FCPP_KIND_MASK]; }
 
@@ -150,43 +159,55 @@ __device__ __forceinline__ int find_prim(const DevField &f, const PrimTable prim
 
 // ---- data-parallel-primitive moves: a lane reads a neighbour's register without a trip through the LDS crossbar (ds_bpermute).
 // ctrl: 0x138 wave_shr:1 (lane i <- i-1), 0x130 wave_shl:1 (lane i <- i+1), quad_perm 0xB1 = [1,0,3,2], 0x4E = [2,3,0,1],
-// 0x141 row_half_mirror, 0x140 row_mirror, 0x142 row_bcast:15, 0x143 row_bcast:31.  Lanes without a source (or outside row_mask)
-// receive `old`.
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ double dpp_mov(double old, double v)
+// 0x141 row_half_mirror, 0x140 row_mirror, 0x142 row_bcast:15, 0x143 row_bcast:31.  bound_ctrl is set: a lane without a source
+// receives 0 and no `old` operand has to be materialised (without it every move costs a second v_mov for the destination's
+// previous contents: the moves were 35 % of k_plan_sparse's vector instructions).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double lane_prev(double v) { return dpp_mov<0x138>(v, v); }   // lane 0 keeps its own value
-__device__ __forceinline__ double lane_next(double v) { return dpp_mov<0x130>(v, v); }   // lane 63 keeps its own value
-__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ double lane_prev(double v) { return dpp_mov<0x138>(v); }   // lane 0 receives 0
+__device__ __forceinline__ double lane_next(double v) { return dpp_mov<0x130>(v); }   // lane 63 receives 0
 
-// wave totals by DPP butterflies (quad, half row, row) and two row broadcasts; the result is valid in LANE 63 only.  Fixed order
-// of the additions => run-to-run identical sums.  Values of the max variant must be >= 0.
+// wave totals by DPP butterflies (quad, half row, row) and two row broadcasts; the result is valid in LANE 63 only (the
+// broadcasts go to every row, rows 0-2 end up with sums nobody reads; lane 63 adds ((r3 + r2) + (r1 + r0))).  Fixed order of
+// the additions => run-to-run identical sums.  Values of the max variant must be >= 0.
 __device__ __forceinline__ double wave_sum_to63(double v)
 {
     if (__ballot(v != 0.0) == 0ull) return 0.0;
-    v += dpp_mov<0xB1>(0.0, v);
-    v += dpp_mov<0x4E>(0.0, v);
-    v += dpp_mov<0x141>(0.0, v);
-    v += dpp_mov<0x140>(0.0, v);
-    v += dpp_mov<0x142, 0xa>(0.0, v);
-    v += dpp_mov<0x143, 0xc>(0.0, v);
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    v += dpp_mov<0x142>(v);
+    v += dpp_mov<0x143>(v);
     return v;
 }
 __device__ __forceinline__ double wave_max0_to63(double v)
 {
     if (__ballot(v != 0.0) == 0ull) return 0.0;
-    v = fmax(v, dpp_mov<0xB1>(0.0, v));
-    v = fmax(v, dpp_mov<0x4E>(0.0, v));
-    v = fmax(v, dpp_mov<0x141>(0.0, v));
-    v = fmax(v, dpp_mov<0x140>(0.0, v));
-    v = fmax(v, dpp_mov<0x142, 0xa>(0.0, v));
-    v = fmax(v, dpp_mov<0x143, 0xc>(0.0, v));
+    v = fmax(v, dpp_mov<0xB1>(v));
+    v = fmax(v, dpp_mov<0x4E>(v));
+    v = fmax(v, dpp_mov<0x141>(v));
+    v = fmax(v, dpp_mov<0x140>(v));
+    v = fmax(v, dpp_mov<0x142>(v));
+    v = fmax(v, dpp_mov<0x143>(v));
     return v;
 }
+
+// a / b for a divisor whose correctly rounded reciprocal rb = RN(1 / b) is at hand (constants, per-batch speeds): q = RN(a rb) is
+// within an ulp, the residual a - b q is exact in one fma, and RN(q + r rb) is the correctly rounded quotient (Markstein 1990;
+// the exception, a significand of b that is all ones, does not occur among the divisors used).  3 instructions instead of the
+// 12-15 of the IEEE division sequence, bit-identical results (tests/test_gpu_parity.py::test_reciprocal_division_is_exact).
+__device__ __forceinline__ double div_by(double a, double b, double rb)
+{
+    const double q = a * rb;
+    return fma(fma(-q, b, a), rb, q);
+}
+__device__ __forceinline__ double div36(double a) { return div_by(a, 3.6, 1.0 / 3.6); }   // km/h -> m/s
 
 // ... and with the fallback in line (one point per lane: fcpp_sparse_fn.h)
 __device__ __forceinline__ double curv_chords_inline(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)

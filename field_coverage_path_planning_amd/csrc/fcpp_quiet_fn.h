@@ -46,11 +46,23 @@ __device__ __forceinline__ double line_start_curvature(const DevField &q, const 
     return curv_chords(dx1, dy1, jump_len, dx2, dy2, seg_len(dx2, dy2));
 }
 
+// the batch's U-turn template into the wavefront's LDS copy: x[TMPL_LDS] | y[TMPL_LDS] | kappa[TMPL_LDS]
+__device__ __forceinline__ void stage_turn_template(const DevConst &cst, double *__restrict__ tmpl_lds)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < cst.tmpl_n) {
+        const double2 t = cst.tmpl_u[lane];
+        tmpl_lds[lane] = t.x; tmpl_lds[TMPL_LDS + lane] = t.y; tmpl_lds[2 * TMPL_LDS + lane] = cst.tmpl_u_dk[lane].y;
+    }
+    wave_sync();
+}
+
 // KINDS: bit k set = chunks of kind k may occur in this instance (1 swath line, 2 headland straight, 3 U-turn, 4 layer-1 span).
 // The kinds are compiled into separate kernels where that saves registers (occupancy of a pure streaming kernel).
-template <int KINDS>
-__device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg, const DevPrim *__restrict__ prims,
+template <int KINDS, bool STAGED>
+__device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__restrict__ fg, const DevPrim *__restrict__ prims,
                                            const DevConst &cst, const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
+                                           double *__restrict__ tmpl_lds /* STAGED: 3*TMPL_LDS doubles of this wave */,
                                            double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
                                            double *__restrict__ vo, uint32_t *__restrict__ fso,
                                            unsigned long long *sink_outside, unsigned long long *sink_obstacle)
@@ -75,50 +87,89 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *fg
         // ---- a span of layer 1 whose passes (swath line + U-turn) are all closed form.  Point i of the span is (pass i / per,
         // offset i % per): a line sample k * step + start (kappa 0; the first point of a line after a turn has the curvature of
         // the jump stencil), or a turn sample = template + translation (mirror), curvature = the shape's own, nominal speeds.
-        const int per = q.n_line + q.n_turn, nl = q.n_line, last = q.n_turn - 1;
+        // The field's constants are fetched ONCE, into scalar registers the compiler must treat as opaque (FCPP_PIN): it would
+        // otherwise re-load them from the descriptor after every group of stores (it cannot hold ~40 scalar values and prefers
+        // re-loading to spilling), and every such re-load is a scalar-cache round trip the wave waits out -- eight samples times
+        // four or five waits a wave.  Pinned values that do not fit are spilled to lanes of a vector register, which costs an
+        // instruction, not a memory access.
+        int per = q.n_line + q.n_turn, nl = q.n_line, last = q.n_turn - 1, n_pass = q.P, idx_base = tl.idx0;
+        int rev = q.reverse_order, sfr = q.start_from_right, rotated = q.rotated;
         const bool arc = q.turn_model == FCPP_TURN_ARC;
-        const double xr = arc ? q.max_x : (q.max_x - q.R), xl = arc ? q.min_x : (q.min_x + q.R);
-        const double k_last = cst.turn_kappa_last[q.reverse_order ? 1 : 0];
-        const double k_start = cst.field_junc[tl.field].x;     // the same for every line of the field (mirror images)
-        auto sample = [&](int j, double &px, double &py, double &kp, double &v, uint32_t &fw) {
-            const unsigned a = (unsigned)(tl.off0 + max(j, 0));
-            const unsigned dq = a / (unsigned)per;
-            const int off = (int)(a - dq * (unsigned)per), idx = tl.idx0 + (int)dq;
-            const int pi = q.reverse_order ? (q.P - 1 - idx) : idx;
-            const double y = q.min_y + (double)pi * q.W;
-            const bool go_left = q.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
+        double xr = arc ? q.max_x : (q.max_x - q.R), xl = arc ? q.min_x : (q.min_x + q.R);
+        double k_last = cst.turn_kappa_last[q.reverse_order ? 1 : 0];
+        double k_start = cst.field_junc[tl.field].x;     // the same for every line of the field (mirror images)
+        double min_y = q.min_y, Wd = q.W, lstep = q.line_step, lex = q.lex, lsx = q.lsx;
+        double rc = q.rot_cos, rs = q.rot_sin, rcx = q.rot_cx, rcy = q.rot_cy;
+        double v_work = cst.v_work, v_turn = cst.v_turn;
+        double e0x = q.ex[0], e0y = q.ey[0], e0o = q.eo[0], e1x = q.ex[1], e1y = q.ey[1], e1o = q.eo[1];
+        double e2x = q.ex[2], e2y = q.ey[2], e2o = q.eo[2], e3x = q.ex[3], e3y = q.ey[3], e3o = q.eo[3];
+        double ntl = ntol;
+        int n_obs = q.obs_count;
+        FCPP_PIN(per); FCPP_PIN(nl); FCPP_PIN(last); FCPP_PIN(n_pass); FCPP_PIN(idx_base); FCPP_PIN(rev); FCPP_PIN(sfr); FCPP_PIN(rotated);
+        FCPP_PIN(xr); FCPP_PIN(xl); FCPP_PIN(k_last); FCPP_PIN(k_start); FCPP_PIN(min_y); FCPP_PIN(Wd); FCPP_PIN(lstep); FCPP_PIN(lex); FCPP_PIN(lsx);
+        FCPP_PIN(rc); FCPP_PIN(rs); FCPP_PIN(rcx); FCPP_PIN(rcy); FCPP_PIN(v_work); FCPP_PIN(v_turn);
+        FCPP_PIN(e0x); FCPP_PIN(e0y); FCPP_PIN(e0o); FCPP_PIN(e1x); FCPP_PIN(e1y); FCPP_PIN(e1o);
+        FCPP_PIN(e2x); FCPP_PIN(e2y); FCPP_PIN(e2o); FCPP_PIN(e3x); FCPP_PIN(e3y); FCPP_PIN(e3o); FCPP_PIN(ntl); FCPP_PIN(n_obs);
+        auto outside_s = [&](double px, double py) -> bool {
+            return (e0x * px + e0y * py + e0o < ntl) | (e1x * px + e1y * py + e1o < ntl) | (e2x * px + e2y * py + e2o < ntl) |
+                   (e3x * px + e3y * py + e3o < ntl);
+        };
+        // The turn template goes through LDS (x, y, kappa of its <= TMPL_LDS samples, one copy per wavefront): vector loads inside
+        // the store loop would share the wave's memory counter with its stores -- waiting for a template sample then means waiting
+        // for every store issued before it to be acknowledged by the memory system -- while LDS reads have a counter of their own.
+        // STAGED is chosen per launch: the template is the batch's (cst.tmpl_n samples), spans exist only for fields that use it.
+        // (staged by the kernel before it fetches its chunk descriptor: stage_turn_template)
+        auto sample = [&](int dq, int off, double &px, double &py, double &kp, double &v, uint32_t &fw) {
+            const int idx = idx_base + dq;
+            const int pi = rev ? (n_pass - 1 - idx) : idx;
+            const double y = min_y + (double)pi * Wd;
+            const bool go_left = sfr ? ((idx & 1) == 0) : ((idx & 1) == 1);
             if (off < nl) {
-                px = go_left ? ((double)off * -q.line_step + q.lex) : ((double)off * q.line_step + q.lsx);
-                if (off == nl - 1) px = go_left ? q.lsx : q.lex;
+                px = go_left ? ((double)off * -lstep + lex) : ((double)off * lstep + lsx);
+                if (off == nl - 1) px = go_left ? lsx : lex;
                 py = y;
                 kp = (off == 0 && idx > 0) ? k_start : 0.0;
-                v = cst.v_work;
+                v = v_work;
                 fw = FCPP_KIND_SWATH | ((uint32_t)pi << FCPP_INDEX_SHIFT);
             } else {
                 const int c = off - nl;
-                const double2 t = cst.tmpl_u[c];
+                double tx, ty, tk;
+                if (STAGED) { tx = tmpl_lds[c]; ty = tmpl_lds[TMPL_LDS + c]; tk = tmpl_lds[2 * TMPL_LDS + c]; }
+                else { const double2 t = cst.tmpl_u[c]; tx = t.x; ty = t.y; tk = cst.tmpl_u_dk[c].y; }
                 const bool turn_right = !go_left;
-                px = arc ? (turn_right ? (xr - t.x) : (xl + t.x)) : (turn_right ? (xr + t.x) : (xl - t.x));
-                py = y + t.y;
-                kp = c == last ? k_last : cst.tmpl_u_dk[c].y;
-                v = cst.v_turn;
+                px = arc ? (turn_right ? (xr - tx) : (xl + tx)) : (turn_right ? (xr + tx) : (xl - tx));
+                py = y + ty;
+                kp = c == last ? k_last : tk;
+                v = v_turn;
                 fw = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
             }
-            if (q.rotated) rotate_back(q, px, py);
+            if (rotated) {                                     // rotate_back (fcpp_pointfn.h) on the pinned copies
+                const double tx = px - rcx, ty = py - rcy;
+                px = (tx * rc - ty * rs) + rcx;
+                py = (tx * rs + ty * rc) + rcy;
+            }
         };
+        // (pass, offset) of the pair's second point by one division; its first point is the point before it, and the pairs of the
+        // following rounds lie 128 points further on: both by carry, not by division
+        const unsigned uper = (unsigned)per, step_q = 128u / uper, step_r = 128u - step_q * uper;      // wave-uniform
+        const unsigned a1 = (unsigned)(tl.off0 + 2 * lane - odd + 1);
+        int dq1 = (int)(a1 / uper), off1 = (int)(a1 - (unsigned)dq1 * uper);
 #pragma unroll
         for (int k = 0; k < TILE_POINTS / 128; ++k) {
             const int j = 2 * (lane + 64 * k) - odd;
             const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;
             double px0, py0, k0, v0, px1, py1, k1, v1;
             uint32_t f0, f1;
-            sample(j, px0, py0, k0, v0, f0);
-            sample(min(j + 1, cnt - 1), px1, py1, k1, v1, f1);
-            const bool o0 = has0 && outside(px0, py0), o1 = has1 && outside(px1, py1);      // turns may leave the field: every point is tested
+            const int dq0 = off1 == 0 ? dq1 - 1 : dq1, off0 = off1 == 0 ? per - 1 : off1 - 1;
+            sample(dq0, off0, px0, py0, k0, v0, f0);     // (lanes beyond the chunk decode points beyond it: arithmetic only, never stored)
+            sample(dq1, off1, px1, py1, k1, v1, f1);
+            off1 += (int)step_r; dq1 += (int)step_q;
+            if (off1 >= per) { off1 -= per; ++dq1; }
+            const bool o0 = has0 && outside_s(px0, py0), o1 = has1 && outside_s(px1, py1);      // turns may leave the field: every point is tested
             nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
             f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
             f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
-            if (q.obs_count > 0) {
+            if (n_obs > 0) {
                 // bounding box of the wave's points of this pass, then the culled polygon tests
                 double mnx = has0 ? px0 : (has1 ? px1 : FCPP_INF), mxx = has0 ? px0 : (has1 ? px1 : -FCPP_INF);
                 double mny = has0 ? py0 : (has1 ? py1 : FCPP_INF), mxy = has0 ? py0 : (has1 ? py1 : -FCPP_INF);

@@ -70,29 +70,44 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     bool cl = false;
     double v0 = vn;
     if (kappa > 1e-6) v0 = clamped_speed(vn, kappa, cst, cl);
-    const double ms0 = cl ? v0 / 3.6 : msn;
+    const double ms0 = cl ? div36(v0) : msn;
     const double u0 = act ? ms0 * ms0 : FCPP_INF;
 
-    // ---- 3. sweeps (MLP:538-589) as min-plus scans over the lanes; skipped when no single step binds ----------------------------
-    // w = coupling of segment (i-1, i); +inf: nothing propagates (skipped step, the wave's first lane, the path's first point)
+    // ---- 3. sweeps (MLP:538-589); skipped when no single step binds ----------------------------------------------------------------
+    // w = coupling of segment (i-1, i); +inf: nothing propagates (skipped step, the wave's first lane, the path's first point).
+    // At this sampling a constraint reaches one to three points, so the sweeps run as a relaxation u_i = min(u_i, u_(i-1) + w_i,
+    // u_(i+1) + w_(i+1)) until a ballot reports no change: every round moves all constraints one point on, in both directions,
+    // ~10 instructions a round, and the sums accumulate point by point as in the reference's loops.  A tile that has not settled after
+    // SWEEP_ROUNDS rounds (dense stretches) finishes with the two min-plus scans, started from where the relaxation got to (same
+    // fixed point).
+    constexpr int SWEEP_ROUNDS = 5;
     const double two_a = 2 * cst.a_lon;
-    const double w = !act ? 0.0 : ((!has_prev || dprev < 1e-6) ? FCPP_INF : two_a * dprev);
+    const double w = (!has_prev || dprev < 1e-6) ? FCPP_INF : two_a * dprev;      // (has_prev is false on the lanes beyond the tile)
     const double u0m = lane_prev(u0);
     const bool binds = has_prev && w < FCPP_INF && (u0m + w < u0 || u0 + w < u0m);
     double u = u0;
     if (__ballot(binds) != 0ull) {
-        Agg fi = { u0, w };
         double wn = lane_next(w);                      // coupling to the next lane
-        if (lane >= nl - 1) wn = act ? FCPP_INF : 0.0;
-        Agg bi = { u0, wn };
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            Agg pf = { __shfl_up(fi.c, o), __shfl_up(fi.w, o) };
-            Agg pb = { __shfl_down(bi.c, o), __shfl_down(bi.w, o) };
-            if (lane >= o) fi = combine_after(pf, fi);
-            if (lane + o < 64) bi = combine_after(pb, bi);
+        if (lane >= nl - 1) wn = FCPP_INF;
+        bool settled = false;
+#pragma unroll 1
+        for (int round = 0; round < SWEEP_ROUNDS; ++round) {
+            const double m = fmin(u, fmin(lane_prev(u) + w, lane_next(u) + wn));    // (lane 0: 0 + inf; the last lane: 0 + inf)
+            const bool moved = m < u;
+            u = m;
+            if (__ballot(moved) == 0ull) { settled = true; break; }
         }
-        u = fmin(fi.c, bi.c);
+        if (!settled) {
+            Agg fi = { u, w }, bi = { u, wn };
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                Agg pf = { __shfl_up(fi.c, o), __shfl_up(fi.w, o) };
+                Agg pb = { __shfl_down(bi.c, o), __shfl_down(bi.w, o) };
+                if (lane >= o) fi = combine_after(pf, fi);
+                if (lane + o < 64) bi = combine_after(pb, bi);
+            }
+            u = fmin(fi.c, bi.c);
+        }
     }
     // untouched points keep exactly their clamped / nominal value
     const double vfin = (u < u0) ? sqrt(u) * 3.6 : (cl ? v0 : vn);
@@ -122,15 +137,15 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     const double vprev = lane_prev(vfin), kprev = lane_prev(kappa), vnprev = lane_prev(vn);
     if (out && !is_first && !at_seam) {                     // the seam main|headland belongs to neither layer
         const int layer = lane < wt.rel_seam ? 0 : 1;
-        const double ms_pre = (vnprev == vn) ? msn : ((vnprev + vn) / 2) / 3.6;
+        const double ms_pre = (vnprev == vn) ? msn : div36((vnprev + vn) / 2);
         const double tpre = dprev / fmax(ms_pre, 0.1);
-        const double t = (vprev == vnprev && vfin == vn) ? tpre : dprev / fmax(((vprev + vfin) / 2) / 3.6, 0.1);
+        const double t = (vprev == vnprev && vfin == vn) ? tpre : dprev / fmax(div36((vprev + vfin) / 2), 0.1);
         acc.s_len[layer] += dprev; acc.s_tpre[layer] += tpre; acc.s_t[layer] += t;
     }
     if (out && !is_first && !is_last) {                     // interior points of the path
         if (kappa > 0.0) {
             // (v / 3.6)^2 kappa with the final speed: an untouched point's v / 3.6 is ms0 (the clamped value / 3.6, or the tabulated nominal one)
-            const double ms = (u < u0) ? vfin / 3.6 : ms0, alat = ms * ms * kappa;
+            const double ms = (u < u0) ? div36(vfin) : ms0, alat = ms * ms * kappa;
             acc.mk = fmax(acc.mk, kappa); acc.ma = fmax(acc.ma, alat);
             if (alat > cst.a_lat) { o_viol = true; fw |= FCPP_FLAG_ALAT; }
         }

@@ -185,10 +185,19 @@ class Batch:
         self.info = [info[i] for i in range(self.n_fields)]
         self.total_points = tot.value
 
-    def alloc(self, best_of=1):
+    def alloc(self, best_of=1, probe='step', include=()):
         """Output buffers (x, y, kappa, v, flagseg, stats) for run().
 
-        best_of > 1: placement calibration.  Where the allocator puts an array in device memory changes the rate at which it
+        best_of > 1, probe='step' (default): placement calibration with the batch's own step.  `best_of` complete sets of output
+        arrays are allocated side by side, one warm-up and three timed run()s go into each, the fastest set is kept and the others
+        are released (`self.placement` = {'step_ms': per candidate, 'chosen': index}).  Measured on MI355X: the same kernels on the
+        same batch write one set of arrays 30-45 % faster than another of the same process (cfg5: 1.31 vs 1.90 ms in the span
+        kernel, cfg2 at 0.1 m: 4.45 vs 5.75 ms), the difference follows the allocation, not the relative offsets of the arrays
+        inside it, and a single-stream fill of each array does not predict it.  Setup work for a long-lived caller that plans into
+        the same arena again and again; never inside a timed region.  `include`: sets the caller already holds, timed as further
+        candidates (index 0.. in `step_ms`).
+
+        best_of > 1, probe='fill' (round 1): where the allocator puts an array in device memory changes the rate at which it
         can be written (a single-stream fill of the same 8 GB differs by ~5 % between buffers; five such streams written
         together, as k_plan_quiet does, by up to 30 %: 5.2 vs 6.8 ms on the bench workload), and it is a
         property of the buffer, not of the kernel.  `best_of` candidate buffers per output array are allocated side by side, each
@@ -199,6 +208,28 @@ class Batch:
         torch = _torch()
         dev = torch.device('cuda', self.ctx.device)
         n = self.total_points
+        if probe == 'step':
+            import time
+            sets, ms = list(include), []
+            for _ in range(int(best_of)):
+                try:
+                    sets.append(self._alloc_once())
+                except RuntimeError:          # out of device memory: choose among what we have
+                    break
+            for s in sets:
+                self.run(s)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    self.run(s)
+                torch.cuda.synchronize(dev)
+                ms.append((time.perf_counter() - t0) / 3 * 1e3)
+            k = min(range(len(sets)), key=lambda i: ms[i])
+            self.placement = {'probe': 'step', 'step_ms': [round(v, 4) for v in ms], 'chosen': k}
+            keep = sets[k]
+            del sets
+            torch.cuda.empty_cache()
+            return keep
 
         def fill_ms(t):
             t.fill_(0)

@@ -553,15 +553,22 @@ def test_standalone_operators_on_ragged_paths():
 
 
 def test_placement_calibrated_buffers_give_the_same_plan():
-    """Batch.alloc(best_of=K) only chooses WHICH buffers receive the output (fill probe)."""
+    """Batch.alloc(best_of=K) only chooses WHICH buffers receive the output (step probe and fill probe)."""
     specs, _ = _random_fields(5, 6)
     b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(1, 0.2))
     r0 = b.run()
     keep = [t.clone() for t in (r0.x, r0.y, r0.kappa, r0.v, r0.flagseg, r0.stats_raw)]
-    bufs = b.alloc(best_of=3)
+    mine = b.alloc()
+    bufs = b.alloc(best_of=3, include=[mine])
     p = b.placement
-    assert len(p['fill_ms_f64']) == 12 and len(p['chosen_f64']) == 4 and len(p['fill_ms_i32']) == 3
+    assert p['probe'] == 'step' and len(p['step_ms']) == 4 and 0 <= p['chosen'] < 4
     r1 = b.run(bufs)
     for a, c in zip(keep, (r1.x, r1.y, r1.kappa, r1.v, r1.flagseg, r1.stats_raw)):
+        assert bool((a == c).all())
+    bufs = b.alloc(best_of=3, probe='fill')
+    p = b.placement
+    assert len(p['fill_ms_f64']) == 12 and len(p['chosen_f64']) == 4 and len(p['fill_ms_i32']) == 3
+    r2 = b.run(bufs)
+    for a, c in zip(keep, (r2.x, r2.y, r2.kappa, r2.v, r2.flagseg, r2.stats_raw)):
         assert bool((a == c).all())
     b.close()
