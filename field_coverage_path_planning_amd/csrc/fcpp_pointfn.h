@@ -172,6 +172,21 @@ __device__ __forceinline__ double dpp_mov(double v)
 __device__ __forceinline__ double lane_prev(double v) { return dpp_mov<0x138>(v); }   // lane 0 receives 0
 __device__ __forceinline__ double lane_next(double v) { return dpp_mov<0x130>(v); }   // lane 63 receives 0
 
+// fmin / fmax on values known not to be signalling NaNs: the library calls put a canonicalising v_max_f64 x, x, x in front of every
+// operand that did not come straight out of an arithmetic instruction (lane moves, selects), doubling the cost of a butterfly
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double min_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // wave totals by DPP butterflies (quad, half row, row) and two row broadcasts; the result is valid in LANE 63 only (the
 // broadcasts go to every row, rows 0-2 end up with sums nobody reads; lane 63 adds ((r3 + r2) + (r1 + r0))).  Fixed order of
 // the additions => run-to-run identical sums.  Values of the max variant must be >= 0.
@@ -189,19 +204,44 @@ __device__ __forceinline__ double wave_sum_to63(double v)
 __device__ __forceinline__ double wave_max0_to63(double v)
 {
     if (__ballot(v != 0.0) == 0ull) return 0.0;
-    v = fmax(v, dpp_mov<0xB1>(v));
-    v = fmax(v, dpp_mov<0x4E>(v));
-    v = fmax(v, dpp_mov<0x141>(v));
-    v = fmax(v, dpp_mov<0x140>(v));
-    v = fmax(v, dpp_mov<0x142>(v));
-    v = fmax(v, dpp_mov<0x143>(v));
+    v = max_raw(v, dpp_mov<0xB1>(v));
+    v = max_raw(v, dpp_mov<0x4E>(v));
+    v = max_raw(v, dpp_mov<0x141>(v));
+    v = max_raw(v, dpp_mov<0x140>(v));
+    v = max_raw(v, dpp_mov<0x142>(v));
+    v = max_raw(v, dpp_mov<0x143>(v));
+    return v;
+}
+
+// Three (four) per-lane values reduced over the wave together: after the exchange with lane ^ 1 every lane carries two of the four
+// slots (for its pair of lanes), after lane ^ 2 one slot (for its quad) -- the first two butterfly stages cost 7 + 7 additions and
+// moves for all four values instead of 4 x 6 -- then the quads are added down the row (row_shr:4, row_shr:8) and the rows down the
+// wave (two LDS-crossbar moves, which keep the lane's position in its row).  Lane 60 + j ends up with the total of slot
+// WAVE4_SLOT(j) = 0, 2, 1, 3 for j = 0..3; the other lanes hold partial results nobody reads.  Fixed order => identical sums run
+// to run.  OP: 0 add, 1 max of non-negative values.
+#define WAVE4_SLOT(lane) ((((lane) & 1) << 1) | (((lane) >> 1) & 1))
+template <int OP>
+__device__ __forceinline__ double wave4_to_hi(double s0, double s1, double s2, double s3)
+{
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    auto op = [](double a, double b) { return OP == 0 ? a + b : max_raw(a, b); };
+    const double a = op(b0 ? s2 : s0, dpp_mov<0xB1>(b0 ? s0 : s2));      // slot 0 (even lanes) / slot 2 (odd lanes) of the lane pair
+    const double c = op(b0 ? s3 : s1, dpp_mov<0xB1>(b0 ? s1 : s3));      // slot 1 / slot 3
+    double v = op(b1 ? c : a, dpp_mov<0x4E>(b1 ? a : c));                  // one slot per lane, for its quad
+    v = op(v, dpp_mov<0x114>(v));                                          // row_shr:4
+    v = op(v, dpp_mov<0x118>(v));                                          // row_shr:8: lanes 12-15 of a row hold the row's four totals
+    const double u16 = __shfl_up(v, 16);
+    if (lane >= 16) v = op(v, u16);
+    const double u32 = __shfl_up(v, 32);
+    if (lane >= 32) v = op(v, u32);
     return v;
 }
 
 // a / b for a divisor whose correctly rounded reciprocal rb = RN(1 / b) is at hand (constants, per-batch speeds): q = RN(a rb) is
 // within an ulp, the residual a - b q is exact in one fma, and RN(q + r rb) is the correctly rounded quotient (Markstein 1990;
 // the exception, a significand of b that is all ones, does not occur among the divisors used).  3 instructions instead of the
-// 12-15 of the IEEE division sequence, bit-identical results (tests/test_gpu_parity.py::test_reciprocal_division_is_exact).
+// 12-15 of the IEEE division sequence, bit-identical results (tests/test_recip_div.py).
 __device__ __forceinline__ double div_by(double a, double b, double rb)
 {
     const double q = a * rb;

@@ -37,19 +37,22 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
     acc.clear();
     sparse_tile(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
 
-    // the tile's partial statistics (fixed butterfly => run-to-run identical sums)
-    double dv[9] = { acc.s_len[0], acc.s_tpre[0], acc.s_t[0], acc.s_len[1], acc.s_tpre[1], acc.s_t[1], acc.mk, acc.ma, acc.mj };
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dv[k] = wave_sum_to63(dv[k]);
-#pragma unroll
-    for (int k = 6; k < 9; ++k) dv[k] = wave_max0_to63(dv[k]);
+    // the tile's partial statistics: the three sums of a layer (and the three maxima) go through the wave together (wave4_to_hi),
+    // groups in which every lane holds zero (the other layer, tiles without curvature) are skipped by a ballot
+    double g[3] = { 0.0, 0.0, 0.0 };
+    // (which layers the output lanes lie in is in the tile record: scalar compares)
+    const int out0 = wt.hb, out1 = wt.hb + wt.count;
+    if (out0 < wt.rel_seam) g[0] = wave4_to_hi<0>(acc.s_len[0], acc.s_tpre[0], acc.s_t[0], 0.0);
+    if (out1 > wt.rel_seam + 1) g[1] = wave4_to_hi<0>(acc.s_len[1], acc.s_tpre[1], acc.s_t[1], 0.0);     // (the seam point itself belongs to neither)
+    if (__ballot(acc.mk != 0.0 || acc.mj != 0.0) != 0ull) g[2] = wave4_to_hi<1>(acc.mk, acc.ma, acc.mj, 0.0);  // (a_lat > 0 needs kappa > 0)
+    const int vs = WAVE4_SLOT(lane);
+    if (lane >= 60 && vs < 3) {          // TilePartial: 9 doubles (len, time_pre, time per layer; max kappa, a_lat, jump), 4 counters
+        double *tp = reinterpret_cast<double *>(&partial[wt.tile]);
+        tp[vs] = g[0]; tp[3 + vs] = g[1]; tp[6 + vs] = g[2];
+    }
     if (lane == 63) {
-        TilePartial tp;
-        tp.main_len = dv[0]; tp.main_time_pre = dv[1]; tp.main_time = dv[2];
-        tp.head_len = dv[3]; tp.head_time_pre = dv[4]; tp.head_time = dv[5];
-        tp.max_kappa = dv[6]; tp.max_alat = dv[7]; tp.max_jump = dv[8];
+        TilePartial &tp = partial[wt.tile];
         tp.n_viol = acc.c_viol; tp.n_outside = acc.c_out; tp.n_in_obstacle = acc.c_obs; tp.n_adjusted = acc.c_adj;
-        partial[wt.tile] = tp;
     }
 }
 

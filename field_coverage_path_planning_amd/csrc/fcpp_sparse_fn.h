@@ -92,7 +92,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
         bool settled = false;
 #pragma unroll 1
         for (int round = 0; round < SWEEP_ROUNDS; ++round) {
-            const double m = fmin(u, fmin(lane_prev(u) + w, lane_next(u) + wn));    // (lane 0: 0 + inf; the last lane: 0 + inf)
+            const double m = min_raw(u, min_raw(lane_prev(u) + w, lane_next(u) + wn));    // (lane 0: 0 + inf; the last lane: 0 + inf)
             const bool moved = m < u;
             u = m;
             if (__ballot(moved) == 0ull) { settled = true; break; }
@@ -146,10 +146,10 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
         if (kappa > 0.0) {
             // (v / 3.6)^2 kappa with the final speed: an untouched point's v / 3.6 is ms0 (the clamped value / 3.6, or the tabulated nominal one)
             const double ms = (u < u0) ? div36(vfin) : ms0, alat = ms * ms * kappa;
-            acc.mk = fmax(acc.mk, kappa); acc.ma = fmax(acc.ma, alat);
+            acc.mk = max_raw(acc.mk, kappa); acc.ma = max_raw(acc.ma, alat);
             if (alat > cst.a_lat) { o_viol = true; fw |= FCPP_FLAG_ALAT; }
         }
-        if (kappa != kprev && !is_second) acc.mj = fmax(acc.mj, fabs(kappa - kprev));          // |kappa_i - kappa_(i-1)| for i >= 2 (MLP:1404-1406)
+        if (kappa != kprev && !is_second) acc.mj = max_raw(acc.mj, fabs(kappa - kprev));          // |kappa_i - kappa_(i-1)| for i >= 2 (MLP:1404-1406)
     }
 
     // ---- 6. stores: consecutive lanes, consecutive addresses ------------------------------------------------------------------------
