@@ -21,6 +21,7 @@
 // primitive the carried value is its nominal u0 (closed form); otherwise wave 0 (wave 3) re-generates 64-point
 // chunks before (after) the tile until the accumulated 2a*distance exceeds u_cap or the path ends.  The
 // recomputation uses the same arithmetic as the owning tile, so results do not depend on the tiling.
+#include <algorithm>
 #include "fcpp_quiet_fn.h"
 
 namespace fcpp {
@@ -215,7 +216,7 @@ __global__ void k_field_junctions(int64_t n_fields, const DevField *__restrict__
 }
 
 // the quiet path: one tile per wavefront, four per workgroup; pure HBM streaming at full occupancy
-template <int KINDS, bool SCALAR_DESC, bool STAGED>
+template <int KINDS, bool SCALAR_DESC, bool STAGED, bool OBS>
 __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
                                                       const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                       double *__restrict__ xo,
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
                                                       double *__restrict__ vo, uint32_t *__restrict__ fso,
                                                       TilePartial *__restrict__ partial, int64_t n_chunks)
 {
-    __shared__ double obs_lds[4][2 * OBS_LDS_VERTS];
+    __shared__ double obs_lds[4][OBS ? 2 * OBS_LDS_VERTS : 1];
     __shared__ double tmpl_lds[4][STAGED ? 3 * TMPL_LDS : 1];
     // the wave index as a scalar: the chunk and field descriptors are then fetched by scalar loads and live in scalar registers
     // (as per-lane copies of the same values they cost ~40 vector registers, i.e. one wave per SIMD of occupancy)
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ 
     if (slot >= n_chunks) return;
     if (STAGED) stage_turn_template(cst, tmpl_lds[wave]);  // (its loads are in flight while the descriptors arrive)
     const DevTile tl = chunks[slot];
-    quiet_tile<KINDS, STAGED>(tl, &fields[tl.field], prims, cst, obs, obs_lds[wave], tmpl_lds[wave], xo, yo, ko, vo, fso,
+    quiet_tile<KINDS, STAGED, OBS>(tl, &fields[tl.field], prims, cst, obs, obs_lds[wave], tmpl_lds[wave], xo, yo, ko, vo, fso,
                       reinterpret_cast<unsigned long long *>(&partial[tl.stat_tile].n_outside),
                       reinterpret_cast<unsigned long long *>(&partial[tl.stat_tile].n_in_obstacle));
 }
@@ -841,15 +842,23 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
 {
     if (n_chunks <= 0) return 0;
     const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
-    const int pad = kinds == 16 ? tune_int("FCPP_SPAN_PAD", 6144) : tune_int("FCPP_QUIET_PAD", 0);
-#define FCPP_QUIET(K, SD, TL) FCPP_LAUNCH((k_plan_quiet<K, SD, TL>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
-    // Descriptors by scalar loads: 55 instead of 116 vector registers, 7 instead of 4 waves per SIMD.  That nearly halves the time of
-    // the spans (latency-bound: pass decode, short runs) but costs the dense kernel 2-4 % on identical memory (tools/ab_quiet.py:
-    // 5.61 vs 5.49 ms; capping the occupancy below 4 waves costs more: 5.90 ms at 3, 6.70 ms at 2).
-    // Spans of a batch whose U-turn template is short (the reference's 20 samples) read it from LDS (fcpp_quiet_fn.h).
-    if (kinds == 16 && cst.tmpl_n > 0 && cst.tmpl_n <= TMPL_LDS) FCPP_QUIET(16, true, true);
-    else if (kinds == 16) FCPP_QUIET(16, true, false);
-    else FCPP_QUIET(14, false, false);
+    const bool staged = cst.tmpl_n > 0 && cst.tmpl_n <= TMPL_LDS, has_obs = obs.offsets != nullptr;
+    // Resident waves of the span kernel are held to FOUR per SIMD by its LDS footprint (34 KiB per four-wave workgroup of 160 KiB per
+    // CU): measured on identical memory (tools/ab_knob.py) cfg5 1.33 vs 1.44 ms at 5-7 waves and 1.59 ms at 3; the other
+    // configurations do not care (+-1 %).  FCPP_SPAN_LDS / FCPP_QUIET_PAD: bytes, for that tool.
+    const int static_lds = (has_obs ? 4 * 2 * OBS_LDS_VERTS * 8 : 32) + (kinds == 16 && staged ? 4 * 3 * TMPL_LDS * 8 : 32);
+    const int pad = kinds == 16 ? std::max(0, tune_int("FCPP_SPAN_LDS", 34 * 1024) - static_lds) : tune_int("FCPP_QUIET_PAD", 0);
+#define FCPP_QUIET(K, SD, TL, OB) FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
+    // Instances: spans fetch their descriptors by scalar loads (SCALAR_DESC: that nearly halved their time in round 1), stage the
+    // turn template in LDS when it is the reference's short one (STAGED), and every instance exists with and without the polygon
+    // tests (OBS; without: 68 instead of 93 vector registers and no scalar spills in the span kernel, 80 instead of 116 in the dense
+    // one -- cfg2 at 0.5 m 1.63 -> 1.39 ms).
+    if (kinds == 16 && staged && !has_obs) FCPP_QUIET(16, true, true, false);
+    else if (kinds == 16 && staged) FCPP_QUIET(16, true, true, true);
+    else if (kinds == 16 && !has_obs) FCPP_QUIET(16, true, false, false);
+    else if (kinds == 16) FCPP_QUIET(16, true, false, true);
+    else if (!has_obs) FCPP_QUIET(14, false, false, false);
+    else FCPP_QUIET(14, false, false, true);
 #undef FCPP_QUIET
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

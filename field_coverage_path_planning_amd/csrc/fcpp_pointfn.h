@@ -16,6 +16,7 @@ __device__ __forceinline__ double uniform_value(double v)
 }
 __device__ __forceinline__ int uniform_value(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #define FCPP_PIN(x) do { x = uniform_value(x); asm volatile("" : "+s"(x)); } while (0)
+#define FCPP_PIN_V(x) asm volatile("" : "+v"(x))       // the same, kept in a vector register
 static constexpr int TMPL_LDS = 64;        // turn-template samples a wavefront stages in LDS (k_plan_quiet; the reference's turn has 20)
 __device__ __forceinline__ double nom_v(const NomTable &t, uint32_t fs) { return t.v[fs & FCPP_KIND_MASK]; }
 __device__ __forceinline__ double nom_ms(const NomTable &t, uint32_t fs) { return t.ms[fs & FCPP_KIND_MASK]; }

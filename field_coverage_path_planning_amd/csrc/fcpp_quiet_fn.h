@@ -57,9 +57,10 @@ __device__ __forceinline__ void stage_turn_template(const DevConst &cst, double 
     wave_sync();
 }
 
+// OBS: the batch has obstacle polygons (without them the polygon tests are compiled out: registers and code of a streaming kernel).
 // KINDS: bit k set = chunks of kind k may occur in this instance (1 swath line, 2 headland straight, 3 U-turn, 4 layer-1 span).
 // The kinds are compiled into separate kernels where that saves registers (occupancy of a pure streaming kernel).
-template <int KINDS, bool STAGED>
+template <int KINDS, bool STAGED, bool OBS>
 __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__restrict__ fg, const DevPrim *__restrict__ prims,
                                            const DevConst &cst, const DevObstacles &obs, double *my_lds /* 2*OBS_LDS_VERTS doubles of this wave */,
                                            double *__restrict__ tmpl_lds /* STAGED: 3*TMPL_LDS doubles of this wave */,
@@ -107,9 +108,12 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
         int n_obs = q.obs_count;
         FCPP_PIN(per); FCPP_PIN(nl); FCPP_PIN(last); FCPP_PIN(n_pass); FCPP_PIN(idx_base); FCPP_PIN(rev); FCPP_PIN(sfr); FCPP_PIN(rotated);
         FCPP_PIN(xr); FCPP_PIN(xl); FCPP_PIN(k_last); FCPP_PIN(k_start); FCPP_PIN(min_y); FCPP_PIN(Wd); FCPP_PIN(lstep); FCPP_PIN(lex); FCPP_PIN(lsx);
-        FCPP_PIN(rc); FCPP_PIN(rs); FCPP_PIN(rcx); FCPP_PIN(rcy); FCPP_PIN(v_work); FCPP_PIN(v_turn);
-        FCPP_PIN(e0x); FCPP_PIN(e0y); FCPP_PIN(e0o); FCPP_PIN(e1x); FCPP_PIN(e1y); FCPP_PIN(e1o);
-        FCPP_PIN(e2x); FCPP_PIN(e2y); FCPP_PIN(e2o); FCPP_PIN(e3x); FCPP_PIN(e3y); FCPP_PIN(e3o); FCPP_PIN(ntl); FCPP_PIN(n_obs);
+        FCPP_PIN(v_work); FCPP_PIN(v_turn); FCPP_PIN(n_obs);
+        // ... and the rotation and the geofence edges (17 values that only ever meet vector operands) in VECTOR registers: the kernel
+        // runs five waves per SIMD (launch_plan_quiet), which leaves each wave 100 of them
+        FCPP_PIN_V(rc); FCPP_PIN_V(rs); FCPP_PIN_V(rcx); FCPP_PIN_V(rcy);
+        FCPP_PIN_V(e0x); FCPP_PIN_V(e0y); FCPP_PIN_V(e0o); FCPP_PIN_V(e1x); FCPP_PIN_V(e1y); FCPP_PIN_V(e1o);
+        FCPP_PIN_V(e2x); FCPP_PIN_V(e2y); FCPP_PIN_V(e2o); FCPP_PIN_V(e3x); FCPP_PIN_V(e3y); FCPP_PIN_V(e3o); FCPP_PIN_V(ntl);
         auto outside_s = [&](double px, double py) -> bool {
             return (e0x * px + e0y * py + e0o < ntl) | (e1x * px + e1y * py + e1o < ntl) | (e2x * px + e2y * py + e2o < ntl) |
                    (e3x * px + e3y * py + e3o < ntl);
@@ -169,7 +173,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
             nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
             f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
             f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
-            if (n_obs > 0) {
+            if (OBS && n_obs > 0) {
                 // bounding box of the wave's points of this pass, then the culled polygon tests
                 double mnx = has0 ? px0 : (has1 ? px1 : FCPP_INF), mxx = has0 ? px0 : (has1 ? px1 : -FCPP_INF);
                 double mny = has0 ? py0 : (has1 ? py1 : FCPP_INF), mxy = has0 ? py0 : (has1 ? py1 : -FCPP_INF);
@@ -232,7 +236,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
             nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
             f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
             f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
-            if (q.obs_count > 0) {
+            if (OBS && q.obs_count > 0) {
                 // bounding box of the wave's points of this pass, then the culled polygon tests
                 double mnx = has0 ? px0 : (has1 ? px1 : FCPP_INF), mxx = has0 ? px0 : (has1 ? px1 : -FCPP_INF);
                 double mny = has0 ? py0 : (has1 ? py1 : FCPP_INF), mxy = has0 ? py0 : (has1 ? py1 : -FCPP_INF);
@@ -303,7 +307,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
                 f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
                 f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
             }
-            if (q.obs_count > 0) {
+            if (OBS && q.obs_count > 0) {
                 // lanes without a valid first point test only their second one (or nothing)
                 const double ox[2] = { has0 ? px0 : px1, px1 }, oy[2] = { has0 ? py0 : py1, py1 };
                 const unsigned m = obstacle_mask<2>(obs, q.obs_first, q.obs_first + q.obs_count, my_lds, bminx, bminy, bmaxx, bmaxy,

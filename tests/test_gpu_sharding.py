@@ -36,3 +36,39 @@ def test_real_batch_sharded_equals_single_process(tmp_path, world):
     loads = [sum(i.n_main + i.n_head for i in batch.info[lo:hi]) for lo, hi in blocks]
     assert max(loads) <= batch.total_points / world + max(i.n_main + i.n_head for i in batch.info)
     batch.close()
+
+
+def test_stats_and_points_identical_for_1_2_4_8_shards():
+    """The cut of sharding.partition_by_points for 1, 2, 4 and 8 ranks, every block planned as a batch of its own (what each rank of
+    an N-GPU job does), blocks concatenated in rank order: statistics and point arrays byte-identical to the single batch.  Mixed
+    workload: parallelograms at the reference sampling and dense clothoid rectangles, so that every kernel of the fused pipeline
+    takes part."""
+    import torch
+    from field_coverage_path_planning_amd import engine as E, sharding as S, workloads as WL
+    veh = E.make_vehicle()
+    for specs, opt in ((WL.specs_from_vertices(E, WL.cfg5_parallelograms(160, seed=7)), E.make_options()),
+                       (WL.specs_from_lh(E, WL.cfg2_rectangles(40, seed=9)), E.make_options(1, 0.5))):
+        infos = E.plan_count(specs, veh, opt)
+        counts = [i.n_main + i.n_head for i in infos]
+        whole = E.Batch(specs, veh, opt)
+        ref = whole.run()
+        ref_stats = ref.stats_raw.cpu().numpy()
+        ref_arrays = [a.cpu().numpy() for a in (ref.x, ref.y, ref.kappa, ref.v, ref.flagseg)]
+        for world in (1, 2, 4, 8):
+            blocks = S.partition_by_points(counts, world)
+            assert len(blocks) == world and blocks[0][0] == 0 and blocks[-1][1] == len(specs)
+            stats, arrays = [], [[] for _ in range(5)]
+            for lo, hi in blocks:
+                if hi == lo:
+                    continue
+                b = E.Batch(specs[lo:hi], veh, opt)
+                r = b.run()
+                stats.append(r.stats_raw.cpu().numpy())
+                for k, a in enumerate((r.x, r.y, r.kappa, r.v, r.flagseg)):
+                    arrays[k].append(a.cpu().numpy())
+                b.close()
+            assert np.array_equal(np.concatenate(stats), ref_stats), world
+            for k in range(5):
+                assert np.array_equal(np.concatenate(arrays[k]), ref_arrays[k]), (world, k)
+        whole.close()
+        torch.cuda.empty_cache()
