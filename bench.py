@@ -459,6 +459,8 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
         stage_points = batch.stage_points()
         dom_points = stage_points[dom]
         achieved = BYTES_PER_POINT * dom_points / (kernels[dom] * 1e-3) / 1e9
+        tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+        traffic5 = json.load(open(tpath)).get(f'{dom}|cfg5') if os.path.exists(tpath) else None      # (counters of the whole job on one GPU)
         pr = per_rank.cpu().numpy()
         entry = {'name': 'cfg5', 'workload': 'cfg5: 65 536 parallelograms (base / height U[100,1000) m, angle U[60,120) deg, rotation U[-pi/4,pi/4), seed 65536), '
                                              'arc turns at the reference sampling, sharded over the ranks by sharding.plan_sharded '
@@ -478,7 +480,8 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
                                                 'the root\'s arrays (dist.batch_isend_irecv)'},
                  'quiet_points': q_pts, 'general_points': g_pts,
                  'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                              'traffic': None, 'kernel_ms': kernels[dom], 'kernel_points_per_launch': dom_points, 'all_kernels_ms': kernels, 'all_kernels_points': stage_points,
+                              'traffic': traffic5 if world == 1 else None, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
+                              'kernel_ms': kernels[dom], 'kernel_points_per_launch': dom_points, 'all_kernels_ms': kernels, 'all_kernels_points': stage_points,
                               'rank': 0, 'step_frac': BYTES_PER_POINT * total / (dt_dev / steps) / 1e9 / HBM_PEAK_GBS / world},
                  'cpu_baseline': None}
         if cpu_on:

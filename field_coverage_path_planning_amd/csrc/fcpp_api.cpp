@@ -376,8 +376,9 @@ struct DevTiling {
     DevBuf<int32_t> stat_ids;      // ... the tiles that can hold statistics (general tiles, first tile of every run), path by path
     DevBuf<int64_t> stat_first;    //     CSR offsets into stat_ids per path
     DevBuf<int64_t> stat_run;      //     per entry of stat_ids: points of the quiet run that starts there (0: not a run)
-    DevBuf<int32_t> red_paths;     //     the paths by their number of entries: [<= 64 | <= 8192 | more] (k_reduce_stats)
-    int64_t n_red[3] = { 0, 0, 0 };
+    DevBuf<int32_t> red_paths;     //     the paths by their number of entries: [<= 64 | <= 256 | <= 4096 | more] (k_reduce_stats)
+    DevBuf<char> red_scratch;      //     slice results of the paths of the last class (64 x 104 bytes each)
+    int64_t n_red[4] = { 0, 0, 0, 0 };
     int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_general = 0, n_wave = 0, quiet_points = 0;
     int64_t span_points = 0, chunk_points = 0, wave_points = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
@@ -473,14 +474,16 @@ struct DevTiling {
         if ((e = stat_first.upload(sf, st)) != hipSuccess) return e;
         if ((e = stat_run.upload(srun, st)) != hipSuccess) return e;
         {   // classes of the reduction: by the number of entries of each path (a property of the field alone)
-            std::vector<int32_t> cls[3];
+            // (8 lanes, a wavefront, a workgroup, 64 workgroups per path: at most 8 / 4 / 16 entries per lane in the first three)
+            std::vector<int32_t> cls[4];
             for (int64_t p = 0; p < n_paths; ++p) {
                 const int64_t ne = sf[(size_t)p + 1] - sf[(size_t)p];
-                cls[ne <= 64 ? 0 : (ne <= 8192 ? 1 : 2)].push_back((int32_t)p);
+                cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= 4096 ? 2 : 3))].push_back((int32_t)p);
             }
             std::vector<int32_t> all;
-            for (int c = 0; c < 3; ++c) { n_red[c] = (int64_t)cls[c].size(); all.insert(all.end(), cls[c].begin(), cls[c].end()); }
+            for (int c = 0; c < 4; ++c) { n_red[c] = (int64_t)cls[c].size(); all.insert(all.end(), cls[c].begin(), cls[c].end()); }
             if ((e = red_paths.upload(all, st)) != hipSuccess) return e;
+            if ((e = red_scratch.alloc((size_t)n_red[3] * 64 * 104)) != hipSuccess) return e;
         }
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the staging vectors die here
         return hipSuccess;
@@ -926,20 +929,20 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
         STAGE(1, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
-        // (three classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
+        // (four classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
         // time the first launch)
         {
-            const int groups[3] = { 8, 64, 256 };
+            const int groups[4] = { 8, 64, 256, 256 };
             const int32_t *pl = t.red_paths.p;
             bool first = true;
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < 4; ++c) {
                 if (t.n_red[c] == 0) continue;
                 if (first)
                     STAGE(4, launch_reduce_stats(st, t.n_red[c], t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.stat_run.p, t.tiles.p,
-                                                 b->fields.p, b->prims.p, &b->cst, pl, groups[c]));
+                                                 b->fields.p, b->prims.p, &b->cst, pl, groups[c], c == 3 ? t.red_scratch.p : nullptr));
                 else
                     LAUNCHCHK(launch_reduce_stats(st, t.n_red[c], t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.stat_run.p, t.tiles.p,
-                                                  b->fields.p, b->prims.p, &b->cst, pl, groups[c]));
+                                                  b->fields.p, b->prims.p, &b->cst, pl, groups[c], c == 3 ? t.red_scratch.p : nullptr));
                 first = false;
                 pl += t.n_red[c];
             }

@@ -367,6 +367,7 @@ struct StatAcc {
     double a[9];
     long long b[4];
 };
+static_assert(sizeof(StatAcc) == 104, "red_scratch in fcpp_api.cpp is sized for 104-byte slice results");
 
 __device__ __forceinline__ void stat_entry(StatAcc &s, int64_t t, TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
                                            const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
@@ -428,6 +429,68 @@ __global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_list, const int3
         for (int k = 0; k < 4; ++k) s.b[k] += __shfl_xor(s.b[k], o);
     }
     if (pth >= 0 && sub == 0) stat_store(s, pth, n_adjusted, stats);
+}
+
+// ... and for paths with very many entries (one field of 10^5 chunk runs: cfg3) REDUCE_SPLIT workgroups per path, each over a contiguous
+// slice of the entries, whose results a second launch adds up in slice order (k_reduce_stats_join)
+static constexpr int REDUCE_SPLIT = 64;
+static_assert(REDUCE_SPLIT == 64, "k_reduce_stats_join: one slice per lane");
+__global__ __launch_bounds__(256) void k_reduce_stats_slice(const int32_t *__restrict__ path_list, const int64_t *__restrict__ tile_first,
+                                                           TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
+                                                           const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
+                                                           const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst,
+                                                           StatAcc *__restrict__ scratch)
+{
+    __shared__ StatAcc sh[4];
+    const int64_t li = blockIdx.x / REDUCE_SPLIT;
+    const int slice = blockIdx.x % REDUCE_SPLIT;
+    const int64_t pth = path_list ? (int64_t)path_list[li] : li;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t t0 = tile_first[pth], ne = tile_first[pth + 1] - t0, per = (ne + REDUCE_SPLIT - 1) / REDUCE_SPLIT;
+    const int64_t a = t0 + slice * per, b = min(t0 + ne, a + per);
+    StatAcc s;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s.a[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.b[k] = 0;
+    for (int64_t t = a + threadIdx.x; t < b; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fields, prims, cst);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s.a[k] += __shfl_xor(s.a[k], o);
+#pragma unroll
+        for (int k = 6; k < 9; ++k) s.a[k] = fmax(s.a[k], __shfl_xor(s.a[k], o));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s.b[k] += __shfl_xor(s.b[k], o);
+    }
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w2 = 1; w2 < 4; ++w2) {
+            for (int k = 0; k < 6; ++k) s.a[k] += sh[w2].a[k];
+            for (int k = 6; k < 9; ++k) s.a[k] = fmax(s.a[k], sh[w2].a[k]);
+            for (int k = 0; k < 4; ++k) s.b[k] += sh[w2].b[k];
+        }
+        scratch[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_reduce_stats_join(const int32_t *__restrict__ path_list, const StatAcc *__restrict__ scratch,
+                                                         const unsigned long long *__restrict__ n_adjusted, fcpp_field_stats *__restrict__ stats)
+{
+    const int64_t li = blockIdx.x;
+    const int64_t pth = path_list ? (int64_t)path_list[li] : li;
+    StatAcc s = scratch[li * REDUCE_SPLIT + threadIdx.x];        // REDUCE_SPLIT == the wavefront: lane = slice, fixed butterfly
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s.a[k] += __shfl_xor(s.a[k], o);
+#pragma unroll
+        for (int k = 6; k < 9; ++k) s.a[k] = fmax(s.a[k], __shfl_xor(s.a[k], o));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s.b[k] += __shfl_xor(s.b[k], o);
+    }
+    if (threadIdx.x == 0) stat_store(s, pth, n_adjusted, stats);
 }
 
 // a workgroup per path: every thread strides over the entries, the wavefronts' butterflies meet in LDS in wave order
@@ -704,7 +767,7 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
 int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids, const int64_t *run_count,
                         const DevTile *tiles, const DevField *fields, const DevPrim *prims, const DevConst *cst, const int32_t *path_list,
-                        int group)
+                        int group, void *scratch)
 {
     if (n_list <= 0) return 0;
     DevConst c0;
@@ -713,7 +776,11 @@ int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, co
     if (group == 8)
         FCPP_LAUNCH(k_reduce_stats<8>, dim3((unsigned)((n_list + 31) / 32)), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted,
                     stats, ids, run_count, tiles, fields, prims, c);
-    else if (group == 256)
+    else if (group == 256 && scratch) {
+        FCPP_LAUNCH(k_reduce_stats_slice, dim3((unsigned)(n_list * REDUCE_SPLIT)), dim3(256), 0, st, path_list, tile_first, partial, ids, run_count,
+                    tiles, fields, prims, c, (StatAcc *)scratch);
+        hipLaunchKernelGGL(k_reduce_stats_join, dim3((unsigned)n_list), dim3(64), 0, st, path_list, (const StatAcc *)scratch, n_adjusted, stats);
+    } else if (group == 256)
         FCPP_LAUNCH(k_reduce_stats_wg, dim3((unsigned)n_list), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted, stats, ids,
                     run_count, tiles, fields, prims, c);
     else

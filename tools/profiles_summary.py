@@ -14,8 +14,15 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, 'gpurun_out', 'prof_r02')
 DST = os.path.join(REPO, 'profiles')
-STAGE = {'k_plan_quiet<16, true>': 'k_plan_quiet_spans', 'k_plan_quiet<14, false>': 'k_plan_quiet', 'k_plan_sparse': 'k_plan_sparse',
-         'k_plan_fused<3>': 'k_plan_fused', 'k_reduce_stats': 'k_reduce_stats'}
+STAGE_PREFIX = (('k_plan_quiet<16', 'k_plan_quiet_spans'), ('k_plan_quiet<14', 'k_plan_quiet'), ('k_plan_sparse', 'k_plan_sparse'),
+                ('k_plan_fused<', 'k_plan_fused'), ('k_reduce_stats', 'k_reduce_stats'))
+
+
+def stage_of(kernel):
+    for prefix, stage in STAGE_PREFIX:
+        if kernel.startswith(prefix):
+            return stage
+    return None
 
 
 def short(name):
@@ -26,14 +33,29 @@ traffic = {}
 notes = {}
 for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
     cfg = os.path.basename(cdir)
-    stats = glob.glob(os.path.join(cdir, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+    # kernel statistics over the LAST `timed_steps` dispatches of every kernel of the trace (tools/prof_cfg.py prints the count): the
+    # warm-up step and the placement calibration of cfg2_0.1 / cfg5 come before them.  Same columns as rocprofv3's own *_kernel_stats.csv.
+    stats = glob.glob(os.path.join(cdir, 'stats', '**', '*kernel_trace.csv'), recursive=True)
     if stats:
-        rows = [r for r in csv.DictReader(open(stats[0])) if 'fcpp' in r['Name']]
+        steps = 10
+        log = os.path.join(cdir, 'stats.log')
+        if os.path.exists(log):
+            for line in open(log, errors='replace'):
+                if 'timed_steps' in line:
+                    steps = int(line.split('timed_steps')[1].split()[0])
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(stats[0])):
+            if 'fcpp' in r['Kernel_Name']:
+                per[short(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        sel = {k: (v[-steps:] if len(v) > steps else v) for k, v in per.items()}
+        grand = sum(sum(v) for v in sel.values()) or 1
         with open(os.path.join(DST, f'r02_{cfg}_kernel_stats.csv'), 'w', newline='') as fh:
             w = csv.writer(fh)
             w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
-            for r in rows:
-                w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs'], r['StdDev']])
+            for k, v in sorted(sel.items(), key=lambda kv: -sum(kv[1])):
+                mean = sum(v) / len(v)
+                sd = (sum((x - mean) ** 2 for x in v) / len(v)) ** 0.5
+                w.writerow([k, len(v), sum(v), f'{mean:.1f}', f'{100 * sum(v) / grand:.2f}', min(v), max(v), f'{sd:.1f}'])
     acc = collections.defaultdict(lambda: [0, 0.0])
     for path in glob.glob(os.path.join(cdir, 'pmc_*', '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(path)):
@@ -48,11 +70,14 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
             for (k, c), (n, s) in sorted(acc.items()):
                 w.writerow([k, c, n, f'{s / n:.1f}'])
         for k in sorted({k for k, _ in acc}):
-            if k in STAGE and (k, 'WRITE_SIZE') in acc and (k, 'FETCH_SIZE') in acc:
+            if stage_of(k) and (k, 'WRITE_SIZE') in acc and (k, 'FETCH_SIZE') in acc:
                 wkb = acc[(k, 'WRITE_SIZE')][1] / acc[(k, 'WRITE_SIZE')][0]
                 fkb = acc[(k, 'FETCH_SIZE')][1] / acc[(k, 'FETCH_SIZE')][0]
-                traffic[f'{STAGE[k]}|{cfg}'] = wkb * 1024 + 2 * fkb * 1024
-                notes[f'{STAGE[k]}|{cfg}'] = {'WRITE_SIZE_KB_per_launch': wkb, 'FETCH_SIZE_KB_per_launch': fkb}
+                key = f'{stage_of(k)}|{cfg}'
+                if key in traffic:            # (a stage launched in several classes, e.g. k_reduce_stats<8> and <64>: the first one is what bench.py times)
+                    continue
+                traffic[key] = wkb * 1024 + 2 * fkb * 1024
+                notes[key] = {'kernel': k, 'WRITE_SIZE_KB_per_launch': wkb, 'FETCH_SIZE_KB_per_launch': fkb}
     print(cfg, 'stats' if stats else 'NO stats', len(acc), 'counter rows')
 traffic['_notes'] = {
     'source': 'rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, separate passes, program directly after `--` (tools/collect_profiles.sh), round 2',
