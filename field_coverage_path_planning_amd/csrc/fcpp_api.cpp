@@ -444,6 +444,8 @@ struct DevTiling {
             int64_t rc_begin = 0;                // its first point, relative to the group
             for (int64_t done = 0; done < total;) {
                 const int64_t g = g_grp + done;
+                // (also for the short spans of sparse sampling, where one chunk in eight is partial: near-equal chunks from the span's
+                // start, i.e. 12 % fewer waves with unaligned stores, took 1.81 instead of 1.50 ms on cfg5)
                 const int64_t c = std::min<int64_t>(total - done, TILE_POINTS - (g % TILE_POINTS));
                 while (done >= rc_begin + rv[rc].count) { rc_begin += rv[rc].count; ++rc; }
                 const DevTile &tr = t.tiles[(size_t)rv[rc].tile];

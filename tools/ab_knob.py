@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of launch-time tuning knobs on IDENTICAL memory: one process, one batch, one set of output arrays; the knob (an environment
 variable the launchers read at every launch, csrc/fcpp_devfn.h tune_int) is flipped between interleaved groups of runs.
-    ab_knob.py <workload> <stage> VAR=V1,V2,...        workload: cfg1 | cfg2_ref | cfg2_0.5 | cfg2_0.1 | cfg5
+    ab_knob.py <workload> <stage> [create:]VAR=V1,V2,...        workload: cfg1 | cfg2_ref | cfg2_0.5 | cfg2_0.1 | cfg5
+(create:VAR = a knob the tiler reads when the batch is created: one batch per value, same arrays)
 Prints min / median of the stage's per-launch time (HIP events of the dispatch) and of the whole step per value."""
 import os
 import sys
@@ -27,13 +28,26 @@ elif wl.startswith('cfg2'):
     specs, opt = WL.specs_from_lh(E, WL.cfg2_rectangles()), (E.make_options() if sp is None else E.make_options(1, sp))
 else:
     raise SystemExit(__doc__)
-b = E.Batch(specs, veh, opt)
+create = var.startswith('create:')          # a knob read when the batch is created (the tiler's): one batch per value
+if create:
+    var = var[7:]
+    batches = {}
+    for v in vals:
+        os.environ[var] = v
+        batches[v] = E.Batch(specs, veh, opt)
+    del os.environ[var]
+    b = batches[vals[0]]
+else:
+    b = E.Batch(specs, veh, opt)
 bufs = b.alloc()
 res = {v: [] for v in vals}
 step = {v: [] for v in vals}
 for rnd in range(8):
     for v in vals:
-        os.environ[var] = v
+        if create:
+            b = batches[v]
+        else:
+            os.environ[var] = v
         b.run(bufs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
