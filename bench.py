@@ -156,6 +156,8 @@ def config_entry(name, workload, r, cpu=None, extra=None, traffic_key=None):
     e = {'name': name, 'workload': workload, 'points': r['points'], 'ms_per_step': r['ms_per_step'],
          'value': r['points'] / (r['ms_per_step'] * 1e-3), 'unit': 'points/s', 'dtype': 'f64',
          'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'roofline': roofline_of(r, traffic_key or name), 'cpu_baseline': cpu}
+    if r.get('placement'):
+        e['placement'] = r['placement']
     if extra:
         e.update(extra)
     return e
