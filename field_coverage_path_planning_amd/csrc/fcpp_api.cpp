@@ -799,7 +799,10 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         // own sampling and coarse uniform spacings; dense sampling keeps the eight-points-per-lane kernel
         q.df = &df; q.tu = h_tu.data(); q.tc = h_tc.data(); q.u_cap = b->cst.u_cap;
         q.wave_ok = e == hipSuccess && df.n_turn == b->hp.tt.nu && (int)h_tc.size() == b->hp.tt.nc &&
-                    8.0 * q.two_a * q.line_step_len >= b->cst.u_cap;
+                    (double)tune_int("FCPP_WAVE_FACTOR", 24) * q.two_a * q.line_step_len >= b->cst.u_cap;
+        // (a sweep reaches at most u_cap / (2 a step) points: up to 24 halo lanes either side still leave 14 of a wave's 64 lanes for
+        // output, which beats the eight-points-per-lane kernel -- cfg2 at 0.5 m: 0.18 ms of k_plan_fused -> 0.04 ms of k_plan_sparse,
+        // step 1.41 -> 1.28 ms; at 0.25 m 2.77 -> 2.68 ms; finer sampling stays with k_plan_fused)
         qi[(size_t)i] = q;
     }
     til.build(n_fields, offs.data(), qi.data());
@@ -917,7 +920,8 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // span kernel get in each other's way (cfg5 2.41 vs 2.29 ms, cfg1 x 4096 0.114 vs 0.098 ms, also with the span kernel held to five
         // waves per SIMD).
         hipStream_t sd = st;
-        const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_general <= 512 && t.n_wave == 0;
+        const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_general <= tune_int("FCPP_TWO_STREAM_MAX", 512) &&
+                         t.n_wave == 0;
         if (two) {
             sd = b->ctx->side;
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));

@@ -23,14 +23,6 @@
 
 namespace fcpp {
 
-// launch-time tuning knobs (extra LDS per workgroup = fewer resident waves): an environment variable read at every launch, so that
-// tools/ab_knob.py can flip it between runs of one process on identical memory
-inline int tune_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 static constexpr int BLOCK = 256;
 static constexpr int IPT = TILE_POINTS / BLOCK;  // 8
 static constexpr int NWAVE = BLOCK / 64;

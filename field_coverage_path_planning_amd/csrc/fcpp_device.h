@@ -1,5 +1,6 @@
 // fcpp_device.h -- interface between the C-ABI glue (fcpp_api.cpp) and the kernels (fcpp_kernels.hip)
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_vector_types.h>
 #include <stdint.h>
@@ -35,6 +36,14 @@ struct DevConst {
     const double2 *field_junc;        // per field: (curvature of the first point of a line that follows a U-turn, length of the jump from the turn's end)
     const double2 *tmpl_u_dk;         // per U-turn sample k: (|t_k - t_(k-1)|, curvature at t_k), the shape's own segment lengths / curvatures
 };
+
+// launch-time tuning knobs (extra LDS per workgroup = fewer resident waves, ...): an environment variable read at every launch, so that
+// tools/ab_knob.py can flip it between runs of one process on identical memory
+inline int tune_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 
 // Per-kernel device timing (fcpp_batch_set_profiling): when the caller has armed g_launch_prof, the next launcher call dispatches
 // its kernel with hipExtLaunchKernelGGL(start, stop): the two events take the dispatch's own begin / end time stamps -- no marker

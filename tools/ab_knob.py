@@ -21,10 +21,12 @@ vals = vals.split(',')
 veh = E.make_vehicle()
 if wl == 'cfg1':
     specs, opt = WL.specs_from_lh(E, WL.cfg1_batch(4096)), E.make_options()
+elif wl == 'cfg1_dense':
+    specs, opt = WL.specs_from_lh(E, WL.cfg1_batch(4096)), E.make_options(1, 0.1)
 elif wl == 'cfg5':
     specs, opt = WL.specs_from_vertices(E, WL.cfg5_parallelograms()), E.make_options()
 elif wl.startswith('cfg2'):
-    sp = {'cfg2_ref': None, 'cfg2_0.5': 0.5, 'cfg2_0.1': 0.1}[wl]
+    sp = {'cfg2_ref': None, 'cfg2_0.5': 0.5, 'cfg2_0.1': 0.1, 'cfg2_0.25': 0.25, 'cfg2_1.0': 1.0}[wl]
     specs, opt = WL.specs_from_lh(E, WL.cfg2_rectangles()), (E.make_options() if sp is None else E.make_options(1, sp))
 else:
     raise SystemExit(__doc__)
