@@ -1246,18 +1246,58 @@ int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const doub
     int32_t *buf[2] = { routes, scratch.p };
     double *fit[2] = { fd.p, fd.p + 2 * (size_t)pop }, *dist[2] = { fd.p + pop, fd.p + 3 * (size_t)pop };
     LAUNCHCHK(launch_ga_fitness(st, n, pop, D, routes, dist[0], fit[0], 0));                       // GA:64
-    LAUNCHCHK(launch_ga_stats_elite(st, n, pop, buf[0], fit[0], dist[0], buf[1], fit[1], dist[1], *cfg, -1, state.p, best_route, hist));
     GaState h = {};
+    if (ga_generation_fits(n, pop)) {
+        // One launch per generation (k_ga_generation): the population in buffer a -> its statistics and elites (the bookkeeping of
+        // generation g - 1) and its children (generation g) at once; the launch after the last generation only evaluates the final
+        // population.  cfg4: 77 -> 61 us per generation.
+        for (int g = 0; g <= cfg->max_generations; ++g) {
+            const int a = g & 1, b = a ^ 1;
+            LAUNCHCHK(launch_ga_generation(st, n, pop, D, buf[a], fit[a], dist[a], buf[b], fit[b], dist[b], *cfg, g, state.p, best_route, hist));
+            if ((g & 31) == 31) {                      // the kernel is a no-op once converged; stop launching it
+                HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (h.converged) break;
+            }
+        }
+    } else {
+    LAUNCHCHK(launch_ga_stats_elite(st, n, pop, buf[0], fit[0], dist[0], buf[1], fit[1], dist[1], *cfg, -1, state.p, best_route, hist));
+    // Larger tours: two launches per generation on two streams.  Population g + 1 (buffer b) = the children k_ga_pairs(g) makes of population g (buffer a) + the elites of population
+    // g, which k_ga_stats_elite(g - 1) copied into b's last rows while it evaluated population g.  So k_ga_stats_elite(g) -- statistics
+    // of population g + 1, its elites into a's last rows -- and k_ga_pairs(g + 1) -- children of population g + 1 into a's other rows --
+    // need the same two predecessors (k_ga_pairs(g), k_ga_stats_elite(g - 1)) and write disjoint rows: they run side by side, the pairs on the context's stream, the
+    // single-workgroup bookkeeping (the longer of the two) on its side stream, a generation costs the longer kernel instead of the sum
+    // (measured on cfg4, which normally takes the one-launch path: 77 -> 72 us, the cross-stream waits cost ~13 us a generation).  The pairs of the generation that follows convergence may still run (they read the flag at their start):
+    // they write the buffer that is NOT the final population.
+    struct Events {
+        hipEvent_t p[2] = { nullptr, nullptr }, s[2] = { nullptr, nullptr };
+        ~Events() { for (int k = 0; k < 2; ++k) { if (p[k]) (void)hipEventDestroy(p[k]); if (s[k]) (void)hipEventDestroy(s[k]); } }
+    } ev;
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipEventCreateWithFlags(&ev.p[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev.s[k], hipEventDisableTiming));
+    }
+    hipStream_t sd = c->side;
+    HIPCHK(hipEventRecord(ev.s[1], st));              // k_ga_stats_elite(-1) ran on the main stream
+    HIPCHK(hipStreamWaitEvent(sd, ev.s[1], 0));
+    HIPCHK(hipEventRecord(ev.s[0], st));              // (so that every event a stream waits on has been recorded)
     for (int g = 0; g < cfg->max_generations; ++g) {
         const int a = g & 1, b = a ^ 1;               // generation g: buffer a -> buffer b
+        HIPCHK(hipStreamWaitEvent(st, ev.s[g & 1], 0));                // the elites of population g are in a: k_ga_stats_elite(g - 2)
         LAUNCHCHK(launch_ga_pairs(st, n, pop, D, buf[a], fit[a], buf[b], fit[b], dist[b], *cfg, g, state.p));
-        LAUNCHCHK(launch_ga_stats_elite(st, n, pop, buf[b], fit[b], dist[b], buf[a], fit[a], dist[a], *cfg, g, state.p, best_route, hist));
+        HIPCHK(hipEventRecord(ev.p[g & 1], st));
+        HIPCHK(hipStreamWaitEvent(sd, ev.p[g & 1], 0));                 // the children of population g are in b
+        LAUNCHCHK(launch_ga_stats_elite(sd, n, pop, buf[b], fit[b], dist[b], buf[a], fit[a], dist[a], *cfg, g, state.p, best_route, hist));
+        HIPCHK(hipEventRecord(ev.s[g & 1], sd));
         if ((g & 31) == 31) {                          // the kernels are no-ops once converged; stop launching them
-            HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, sd));
+            HIPCHK(hipStreamSynchronize(sd));
             if (h.converged) break;
         }
     }
+    HIPCHK(hipStreamSynchronize(sd));
+    }
+    HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (h.generations & 1)                             // the last completed generation wrote the scratch buffer

@@ -24,5 +24,11 @@ int launch_ga_pairs(hipStream_t st, int n, int pop, const double *D, const int32
 int launch_ga_stats_elite(hipStream_t st, int n, int pop, const int32_t *cur, const double *cur_fit, const double *cur_dist, int32_t *nxt,
                           double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, GaState *state, int32_t *best_route,
                           double *hist);
+// one generation in one launch: statistics / elites of `cur` (generation index gen - 1) beside its children (generation index gen);
+// for tours and populations whose LDS needs fit (ga_generation_fits)
+bool ga_generation_fits(int n, int pop);
+int launch_ga_generation(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, const double *cur_dist,
+                         int32_t *nxt, double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, GaState *state,
+                         int32_t *best_route, double *hist);
 
 }  // namespace fcpp

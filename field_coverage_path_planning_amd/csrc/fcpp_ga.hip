@@ -1,6 +1,7 @@
 // fcpp_ga.hip -- the GA's evolution loop on the device (include/fcpp.h: fcpp_ga_evolve; GA:64-115, 183-268).
 //
-// Two launches per generation, no host round trip:
+// One launch per generation (k_ga_generation: both roles below side by side; tours too long for that: two launches on two streams),
+// no host round trip:
 //   k_ga_pairs        one wavefront per pair of offspring: two tournaments (GA:183-196), order crossover of the winners
 //                     (GA:212-242: the kept segment is marked in LDS, the donor's genes are ranked with ballots and
 //                     scattered to (b + rank) mod n), swap mutation (GA:244-252), and the children's tour length in the
@@ -11,6 +12,8 @@
 // Every random decision is a pure function of (seed, generation, pair): Philox4x32-10, see include/fcpp.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "fcpp_ga.h"
 
@@ -80,17 +83,13 @@ __device__ __forceinline__ void ox_child(const int32_t *keep, const int32_t *don
     wsync();
 }
 
-__global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
-                                                 const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
-                                                 double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
-                                                 int gen, const GaState *__restrict__ state)
+// one wavefront, one pair of offspring.  lds: 4 n genes + n presence bytes of this wavefront, s_w: two ints of it
+__device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s_w, int n, int pop, const double *__restrict__ D,
+                                        const int32_t *__restrict__ cur, const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
+                                        double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg, int gen)
 {
-    extern __shared__ int32_t lds[];                    // 4 n genes + n presence bytes (sized by the launcher: small tours -> many waves per CU)
     int32_t *const P[2] = { lds, lds + n }, *const Cc[2] = { lds + 2 * n, lds + 3 * n };
     unsigned char *const present = reinterpret_cast<unsigned char *>(lds + 4 * n);
-    __shared__ int s_w[2];
-    if (state->converged) return;
-    const int lane = threadIdx.x, pair = blockIdx.x;
     const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
     if (lane < 2) {      // the two tournaments (GA:189-194): k distinct candidates, the FIRST maximum wins (np.argmax)
         int cand[64];
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
         }
         s_w[lane] = w;
     }
-    __syncthreads();
+    wsync();
     const int32_t *p1g = cur + (int64_t)s_w[0] * n, *p2g = cur + (int64_t)s_w[1] * n;
     for (int i = lane; i < n; i += 64) { P[0][i] = p1g[i]; P[1][i] = p2g[i]; }
     wsync();
@@ -153,6 +152,17 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
     }
 }
 
+__global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
+                                                 const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
+                                                 double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
+                                                 int gen, const GaState *__restrict__ state)
+{
+    extern __shared__ int32_t lds[];                    // 4 n genes + n presence bytes (sized by the launcher: small tours -> many waves per CU)
+    __shared__ int s_w[2];
+    if (state->converged) return;
+    ga_pair(threadIdx.x, blockIdx.x, lds, s_w, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen);
+}
+
 static constexpr int GA_LDS_POP = 6144;      // 48 KiB of fitness values cached in LDS
 static constexpr int SB = 1024, SW = SB / 64; // the bookkeeping kernel: one workgroup
 
@@ -176,17 +186,16 @@ __device__ __forceinline__ void block_best(double &f, int &i, double *s_f, int *
     for (int w = 1; w < SW; ++w) if (better(s_f[w], s_i[w], f, i)) { f = s_f[w]; i = s_i[w]; }
 }
 
-__global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int32_t *__restrict__ cur, const double *__restrict__ cur_fit,
-                                                       const double *__restrict__ cur_dist, int32_t *__restrict__ nxt,
-                                                       double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
-                                                       int gen, GaState *__restrict__ state, int32_t *__restrict__ best_route,
-                                                       double *__restrict__ hist)
+// one workgroup of SB threads.  s_fit: pop doubles of LDS when pop <= GA_LDS_POP
+__device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, const int32_t *__restrict__ cur, const double *__restrict__ cur_fit,
+                                               const double *__restrict__ cur_dist, int32_t *__restrict__ nxt,
+                                               double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg,
+                                               int gen, GaState *__restrict__ state, int32_t *__restrict__ best_route,
+                                               double *__restrict__ hist)
 {
-    extern __shared__ double s_fit[];      // the population's fitness, read once (pop <= GA_LDS_POP; otherwise re-read from global)
     __shared__ double s_f[SW], s_sum[SB];
     __shared__ int s_i[SW], s_pick[64];
     __shared__ int s_copy, s_stop;
-    if (state->converged) return;
     const int tid = threadIdx.x;
     const bool cached = pop <= GA_LDS_POP;
     const double *__restrict__ fitv = cached ? s_fit : cur_fit;
@@ -327,6 +336,43 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
     }
 }
 
+__global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int32_t *__restrict__ cur, const double *__restrict__ cur_fit,
+                                                       const double *__restrict__ cur_dist, int32_t *__restrict__ nxt,
+                                                       double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
+                                                       int gen, GaState *__restrict__ state, int32_t *__restrict__ best_route,
+                                                       double *__restrict__ hist)
+{
+    extern __shared__ double s_fit_dyn[];  // the population's fitness, read once (pop <= GA_LDS_POP; otherwise re-read from global)
+    if (state->converged) return;
+    ga_stats_elite(s_fit_dyn, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen, state, best_route, hist);
+}
+
+// One generation in ONE launch (small tours): population `cur` -> its statistics and best-so-far bookkeeping (generation index
+// gen - 1, the last workgroup), its elites into the last rows of `nxt` (the same workgroup), and its children into the other rows
+// (generation index gen; GA_PAIRS_PER_WG wavefronts = pairs per workgroup).  The two roles read the same population and write
+// disjoint rows, so they need no order between them; a generation then costs the longer role, not the sum of two launches.
+// stats_gen == -2: no bookkeeping role (never used); pairs_gen < 0: no children (the final population's statistics).
+static constexpr int GA_PAIRS_PER_WG = SB / 64;
+__global__ __launch_bounds__(SB) void k_ga_generation(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
+                                                      const double *__restrict__ cur_fit, const double *__restrict__ cur_dist,
+                                                      int32_t *__restrict__ nxt, double *__restrict__ nxt_fit, double *__restrict__ nxt_dist,
+                                                      fcpp_ga_config cfg, int gen, int pair_lds_ints, GaState *__restrict__ state,
+                                                      int32_t *__restrict__ best_route, double *__restrict__ hist)
+{
+    extern __shared__ double dyn_lds[];
+    __shared__ int s_w[GA_PAIRS_PER_WG][2];
+    if (state->converged) return;           // (the children of the generation in which convergence is found go to the buffer that is not the result)
+    if (blockIdx.x == gridDim.x - 1) {
+        ga_stats_elite(dyn_lds, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen - 1, state, best_route, hist);
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * GA_PAIRS_PER_WG + wave;
+    if (pair >= pop / 2 || gen >= cfg.max_generations) return;
+    ga_pair(lane, pair, reinterpret_cast<int32_t *>(dyn_lds) + (size_t)wave * pair_lds_ints, s_w[wave], n, pop, D, cur, cur_fit, nxt, nxt_fit,
+            nxt_dist, cfg, gen);
+}
+
 // precondition of fcpp_ga_evolve: every row of `routes` is a permutation of 0 .. n-1.  One wavefront per chromosome marks its genes
 // in LDS; a gene out of range or seen twice raises the flag.
 __global__ __launch_bounds__(64) void k_ga_check_perm(int n, int pop, const int32_t *__restrict__ routes, int32_t *__restrict__ bad)
@@ -377,6 +423,27 @@ int launch_ga_stats_elite(hipStream_t st, int n, int pop, const int32_t *cur, co
     const size_t lds = pop <= GA_LDS_POP ? (size_t)pop * sizeof(double) : 0;
     hipLaunchKernelGGL(k_ga_stats_elite, dim3(1), dim3(SB), lds, st, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen, state,
                        best_route, hist);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// lds ints of one pair: 4 n genes + n presence bytes, rounded to 16 bytes
+static inline size_t ga_pair_lds_ints(int n) { return ((size_t)n * 4 * sizeof(int32_t) + (size_t)((n + 3) & ~3) + 15) / 16 * 4; }
+
+bool ga_generation_fits(int n, int pop)
+{
+    return pop <= GA_LDS_POP && ga_pair_lds_ints(n) * sizeof(int32_t) * GA_PAIRS_PER_WG <= 60 * 1024;
+}
+
+int launch_ga_generation(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, const double *cur_dist,
+                         int32_t *nxt, double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, GaState *state,
+                         int32_t *best_route, double *hist)
+{
+    const size_t pl = ga_pair_lds_ints(n);
+    const size_t lds = std::max(pl * sizeof(int32_t) * GA_PAIRS_PER_WG, (size_t)pop * sizeof(double));
+    const unsigned blocks = (unsigned)((pop / 2 + GA_PAIRS_PER_WG - 1) / GA_PAIRS_PER_WG) + 1u;
+    hipLaunchKernelGGL(k_ga_generation, dim3(blocks), dim3(SB), lds, st, n, pop, D, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen,
+                       (int)pl, state, best_route, hist);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

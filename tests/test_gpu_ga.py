@@ -27,6 +27,11 @@ def _problem(seed, n, pop, asym=False):
     (64, 200, dict(max_generations=120, elite_size=20, tournament_size=5, convergence_threshold=15, mutation_rate=0.3), 3),   # converges early
     (200, 128, dict(max_generations=33, elite_size=0, tournament_size=64, convergence_threshold=50, crossover_rate=0.5), 4),
     (2, 4, dict(max_generations=5, elite_size=1, tournament_size=1, convergence_threshold=50), 5),
+    # tours too long for the one-launch-per-generation kernel's LDS: the two-stream path (pairs beside the bookkeeping)
+    (700, 96, dict(max_generations=9, elite_size=10, tournament_size=5, convergence_threshold=50), 6),
+    (520, 64, dict(max_generations=40, elite_size=4, tournament_size=3, convergence_threshold=6, mutation_rate=0.0, crossover_rate=0.0), 7),   # converges
+    # a population beyond the LDS cache of the bookkeeping workgroup, with more than 64 elites (its general path)
+    (40, 6400, dict(max_generations=4, elite_size=70, tournament_size=4, convergence_threshold=50), 8),
 ])
 def test_evolution_equals_oracle(n, pop, cfg, seed):
     D, routes = _problem(seed % 1000, n, pop, asym=(n == 64))
