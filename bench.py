@@ -389,10 +389,11 @@ def run_cfg4(E, torch, WL, cpu_on):
             'value': evals / dt, 'unit': 'chromosome evaluations/s', 'dtype': 'f64', 'gathers_per_s': evals * 128 / dt,
             'best_distance_m': float(res.best_distance),
             'fitness_only': {'ms_501_launches': dtf * 1e3, 'chromosomes_per_s': evals / dtf, 'gathers_per_s': evals * 128 / dtf},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_ga_pairs + k_ga_stats_elite', 'achieved': evals * bytes_per_chrom / dt / 1e9, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': 'k_ga_generation', 'achieved': evals * bytes_per_chrom / dt / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': evals * bytes_per_chrom / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                         'note': 'algorithmic HBM bytes per chromosome = 4 n + 8 = 520 B (SURVEY.md 8d): the loop is bound by the latency of its 1000 '
-                                 'dependent launches (D and the population live in L2 / LDS), not by HBM; the fraction is tiny by construction'},
+                         'note': 'algorithmic HBM bytes per chromosome = 4 n + 8 = 520 B (SURVEY.md 8d): the loop is bound by the latency of its 501 '
+                                 'dependent launches, each as long as one workgroup\'s bookkeeping chain (D and the population live in L2 / LDS), not by HBM; '
+                                 'the fraction is tiny by construction'},
             'cpu_baseline': cpu}
 
 
