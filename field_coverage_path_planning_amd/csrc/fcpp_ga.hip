@@ -163,6 +163,42 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
     ga_pair(threadIdx.x, blockIdx.x, lds, s_w, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen);
 }
 
+// wave-wide arg-max of (fitness, index) pairs in the order of the elitism: larger fitness first, among equals the larger index;
+// lanes without a candidate pass idx < 0 (their fitness is ignored).  The maximum fitness goes through DPP moves (no index is
+// carried along), one ballot finds who holds it -- normally one lane, whose index is read directly; several lanes with exactly the
+// same fitness settle the index by a butterfly.  Returns the winning index (-1: no candidate) in every lane, its fitness in `wf`.
+template <int CTRL>
+__device__ __forceinline__ double ga_dpp(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ga_max(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int wave_argmax(double f, int idx, double &wf)
+{
+    double v = idx >= 0 ? f : 0.0;                       // fitness values are positive: 0 is "nothing"
+    v = ga_max(v, ga_dpp<0xB1>(v));                      // quad_perm [1,0,3,2]
+    v = ga_max(v, ga_dpp<0x4E>(v));                      // quad_perm [2,3,0,1]
+    v = ga_max(v, ga_dpp<0x141>(v));                     // row_half_mirror
+    v = ga_max(v, ga_dpp<0x140>(v));                     // row_mirror
+    v = ga_max(v, ga_dpp<0x142>(v));                     // row_bcast:15
+    v = ga_max(v, ga_dpp<0x143>(v));                     // row_bcast:31: lane 63 holds the maximum
+    wf = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+    const unsigned long long m = __ballot(idx >= 0 && f == wf);
+    if (m == 0ull) return -1;
+    if ((m & (m - 1ull)) == 0ull) return __shfl(idx, (int)__ffsll((long long)m) - 1);
+    int wi = (idx >= 0 && f == wf) ? idx : -1;           // ties: the larger index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wi = max(wi, __shfl_xor(wi, o));
+    return wi;
+}
+
 static constexpr int GA_LDS_POP = 6144;      // 48 KiB of fitness values cached in LDS
 static constexpr int SB = 1024, SW = SB / 64; // the bookkeeping kernel: one workgroup
 
@@ -265,16 +301,10 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
                 const int i = tid + k * SB;
                 if (i < pop && !((taken >> k) & 1u) && better(ef[k], i, f, idx)) { f = ef[k]; idx = i; kk = k; }
             }
-            double wf = f;
-            int wi = idx;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double of = __shfl_xor(wf, o);
-                const int oi = __shfl_xor(wi, o);
-                if (better(of, oi, wf, wi)) { wf = of; wi = oi; }
-            }
+            double wf;
+            const int wi = wave_argmax(f, idx, wf);
             if (idx >= 0 && wi == idx) taken |= 1u << kk;         // its owner retires the pick
-            if (lane == 0) { c_f[wave * 64 + t] = wf; c_i[wave * 64 + t] = wi; }
+            if (lane == 0) { c_f[wave * 64 + t] = wi >= 0 ? wf : -1.0; c_i[wave * 64 + t] = wi; }
         }
         __syncthreads();
         if (wave == 0) {            // lane t holds the t-th candidate of every wavefront
@@ -289,14 +319,8 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
 #pragma unroll
                 for (int w = 0; w < SW; ++w)
                     if (!((tk >> w) & 1u) && better(cf[w], ci[w], f, idx)) { f = cf[w]; idx = ci[w]; kk = w; }
-                double wf = f;
-                int wi = idx;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double of = __shfl_xor(wf, o);
-                    const int oi = __shfl_xor(wi, o);
-                    if (better(of, oi, wf, wi)) { wf = of; wi = oi; }
-                }
+                double wf;
+                const int wi = wave_argmax(f, idx, wf);
                 if (idx >= 0 && wi == idx) tk |= 1u << kk;
                 if (lane == 0) s_pick[t] = wi;
             }
