@@ -103,26 +103,32 @@ def cpu_baseline_fields(make_ofield, n_fields, oopt, budget_s, what):
 
 
 # ---- one planner configuration on this rank --------------------------------------------------------------------------------------
-def run_planner(E, torch, specs, opt, steps, warmup, mode=1, placement=1, fence=None, after_step=None):
+def run_planner(E, torch, specs, opt, steps, warmup, mode=1, placement=1, fence=None, after_step=None, stats_of=None):
     """-> dict(points, ms_per_step, kernels {name: ms}, dominant kernel + its points, batch, bufs, res): K timed steps bracketed by
-    fence() (barrier + synchronize), per-kernel HIP events recorded inside the timed region."""
+    fence() (barrier + synchronize), per-kernel HIP events recorded inside the timed region.  stats_of(i, batch): the stats tensor step i
+    writes (default: the one of alloc()); after_step(i, res): called after step i has been enqueued."""
     fence = fence or torch.cuda.synchronize
     batch = E.Batch(specs, E.make_vehicle(), opt)
     bufs = batch.alloc(best_of=placement)
     res = None
-    for _ in range(warmup):
-        res = batch.run(bufs, mode=mode)
+    k = 0
+
+    def step():
+        nonlocal res, k
+        res = batch.run(bufs[:5] + (stats_of(k, batch),) if stats_of else bufs, mode=mode)
         if after_step:
-            after_step(res)
+            after_step(k, res)
+        k += 1
+
+    for _ in range(warmup):
+        step()
     fence()
     # per-kernel HIP events inside the timed region, on a sample of its steps (a profiled step dispatches every kernel with its own
     # start / stop events and costs ~15 us more than a plain one: on every step that would be 14 % of the headline's 110 us)
     batch.set_profiling(True, every=max(1, steps // 8))
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = batch.run(bufs, mode=mode)
-        if after_step:
-            after_step(res)
+        step()
     fence()
     dt = time.perf_counter() - t0
     kernels, prof_runs = batch.stage_times()
@@ -212,31 +218,49 @@ def main():
     cpu_on = world == 1 and not args.no_cpu_baseline
 
     # ---- headline: 4096 x (500 x 200 m) per GPU, arcs at the reference's sampling (the pinned mode) ------------------------------
-    # the only collective of the path: the final gather of the per-field stats.  It runs asynchronously on RCCL's own stream,
-    # double-buffered, and overlaps the next step's kernels.
+    # the only collective of the path: the gather of every step's per-field stats on rank 0.  Every step writes its stats into the next
+    # slot of a ring on the device; after GATHER_EVERY steps their slots go to the root in ONE asynchronous gather on RCCL's own
+    # stream (a collective per 0.1 ms step would cost more host time than the step's kernels take), double-buffered: while one half of
+    # the ring travels, the steps fill the other.
     LH1 = WL.cfg1_batch(args.fields)
+    GATHER_EVERY = 8
     pending = []
-    gather_bufs = None
+    ring = gather_bufs = None
+    steps_done = [0]
 
-    def gather_stats(res):
-        if world == 1:
-            return
+    def stats_slot(i, batch):
+        nonlocal ring
+        if ring is None:
+            ring = torch.zeros((2 * GATHER_EVERY, batch.n_fields, E.L.STATS_WORDS), dtype=torch.int64, device=dev)
+        return ring[i % (2 * GATHER_EVERY)]
+
+    def send_group(g):
+        """gather the ring half that holds the stats of steps [8 g, 8 g + 8)"""
         nonlocal gather_bufs
         if gather_bufs is None:
-            gather_bufs = [[torch.empty_like(res.stats_raw, device=cdev) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-        slot = len(pending) & 1
-        if len(pending) >= 2:
-            pending[-2].wait()
-        snap = res.stats_raw.clone() if backend == 'nccl' else res.stats_raw.cpu()     # (the stats buffer is rewritten by the next step)
-        pending.append(dist.gather(snap, gather_bufs[slot], dst=0, async_op=True))
+            gather_bufs = [[torch.empty((GATHER_EVERY,) + tuple(ring.shape[1:]), dtype=ring.dtype, device=cdev) for _ in range(world)]
+                           if rank == 0 else None for _ in range(2)]
+        if pending:
+            pending[-1].wait()          # the other half has left before the coming steps refill it (for RCCL: a stream-side wait)
+        half = g & 1
+        part = ring[half * GATHER_EVERY:(half + 1) * GATHER_EVERY]
+        pending.append(dist.gather(part if backend == 'nccl' else part.cpu(), gather_bufs[half], dst=0, async_op=True))
+
+    def count_and_gather(i, res):
+        steps_done[0] = i + 1
+        if world > 1 and (i + 1) % GATHER_EVERY == 0:
+            send_group(i // GATHER_EVERY)
 
     def fence_headline():
-        for h in pending[-2:]:
-            h.wait()
+        if world > 1:
+            if steps_done[0] % GATHER_EVERY:          # an unfinished group at a fence travels as it is (and again when it is complete)
+                send_group(steps_done[0] // GATHER_EVERY)
+            if pending:
+                pending[-1].wait()
         fence()
 
     r = run_planner(E, torch, WL.specs_from_lh(E, LH1), E.make_options(), args.steps, args.warmup, mode=args.mode, fence=fence_headline,
-                    after_step=gather_stats)
+                    after_step=count_and_gather, stats_of=stats_slot if world > 1 else None)
     dt = allmax(r['dt'])
     total_points = allsum(r['points'])
     out = None
