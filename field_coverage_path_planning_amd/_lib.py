@@ -118,6 +118,7 @@ PROTOTYPES = [
     ('fcpp_batch_stage_name', C.c_char_p, [C.c_int, C.c_int]),
     ('fcpp_batch_stage_points', C.c_int, [_VP, C.c_int, C.c_int, c_i64_p]),
     ('fcpp_batch_point_split', C.c_int, [_VP, c_i64_p, c_i64_p]),
+    ('fcpp_batch_reduce_classes', C.c_int, [_VP, c_i64_p]),
     ('fcpp_curvature', C.c_int, [_VP, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP]),
     ('fcpp_speed_plan', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP,
                                   _VP, _VP, _VP]),

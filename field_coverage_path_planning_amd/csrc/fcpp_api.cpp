@@ -1024,6 +1024,13 @@ int fcpp_batch_point_split(const fcpp_batch *b, int64_t *quiet_points, int64_t *
     return FCPP_OK;
 }
 
+int fcpp_batch_reduce_classes(const fcpp_batch *b, int64_t *classes_out)
+{
+    if (!b || !classes_out) return fail(FCPP_EINVAL, "bad arguments");
+    for (int c = 0; c < 4; ++c) classes_out[c] = b->til.n_red[c];
+    return FCPP_OK;
+}
+
 const char *fcpp_batch_stage_name(int mode, int stage)
 {
     return (mode >= 0 && mode < 2 && stage >= 0 && stage < kStages) ? kStageNames[mode][stage] : "";

@@ -349,6 +349,12 @@ class Batch:
             k += 1
         return out
 
+    def reduce_classes(self):
+        """-> [paths whose statistics 8 lanes / a wavefront / a workgroup / 64 workgroups reduce] (fused pipeline)"""
+        out = (C.c_int64 * 4)()
+        L.check(self.lib.fcpp_batch_reduce_classes(self.handle, out))
+        return list(out)
+
     def point_split(self):
         """-> (points handled by k_plan_quiet, points handled by k_plan_fused) in the fused pipeline."""
         q, g = C.c_int64(), C.c_int64()

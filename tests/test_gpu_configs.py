@@ -166,3 +166,39 @@ def test_cfg4_ga_population_4096_vs_oracle():
     dd, _ = E.ga_fitness(bad, D)
     dd = dd.cpu().numpy()
     assert np.isnan(dd[7]) and np.isfinite(np.delete(dd, 7)).all()
+
+
+def test_one_path_with_more_than_4096_statistic_entries():
+    """A single field of 2900 passes: its path holds ~5800 closed-form runs plus the general tiles, more than a workgroup takes in
+    k_reduce_stats -- the sliced reduction (64 workgroups + join).  Whole path against the oracle, statistics included; mixed with
+    small fields so that every class of the reduction runs in one batch."""
+    big = dict(L=120.0, H=9300.0)
+    small = [dict(L=500.0, H=200.0), dict(L=260.0, H=140.0), dict(L=900.0, H=700.0)]
+    for tm, sp in ((0, 0.1), (1, 0.2)):
+        fields = [big] + small
+        batch = E.Batch([E.FieldSpec(field_length=f['L'], field_width=f['H']) for f in fields], E.make_vehicle(), E.make_options(tm, sp))
+        assert batch.info[0].n_swaths > 2800
+        res = batch.run(mode=1)
+        st = res.stats()
+        x, y, kap, v = (getattr(res, k).cpu().numpy() for k in ('x', 'y', 'kappa', 'v'))
+        fs = res.flagseg.cpu().numpy().view(np.uint32)
+        off = 0
+        for k, f in enumerate(fields):
+            rc, p = orc.plan_field(orc.make_field(**f), orc.Vehicle.make(), orc.Options.make(tm, 1, sp, 0.5))
+            assert rc == 0 and p.n == batch.info[k].n_main + batch.info[k].n_head
+            sl = slice(off, off + p.n)
+            assert float(np.abs(x[sl] - p.xy[:, 0]).max()) <= 1e-9 and float(np.abs(y[sl] - p.xy[:, 1]).max()) <= 1e-9
+            k_tol = 4e-12 / sp ** 2 * 4          # the 3-point stencil amplifies coordinate rounding by 4 / ds^2
+            assert float(np.abs(kap[sl] - p.kappa).max()) <= k_tol and float(np.abs(v[sl] - p.v).max()) <= 200 * k_tol
+            assert np.array_equal(fs[sl], p.flagseg)
+            assert (int(st['n_viol'][k]), int(st['n_outside'][k]), int(st['n_adjusted'][k])) == (p.n_viol, p.n_outside, p.n_adjusted)
+            np.testing.assert_allclose([st['main_len_m'][k], st['head_len_m'][k]], [p.main_len_m, p.head_len_m], rtol=1e-11)
+            np.testing.assert_allclose([st['main_time_s'][k], st['head_time_s'][k]], [p.main_time_s, p.head_time_s], rtol=1e-10)
+            np.testing.assert_allclose([st['max_kappa'][k], st['max_alat'][k], st['max_jump'][k]], [p.max_kappa, p.max_alat, p.max_jump], rtol=1e-9)
+            off += p.n
+        res0 = batch.run(mode=0)
+        st0 = res0.stats()
+        np.testing.assert_allclose(st0['main_len_m'], st['main_len_m'], rtol=1e-12)
+        np.testing.assert_allclose(st0['head_time_s'], st['head_time_s'], rtol=1e-10)
+        assert batch.reduce_classes()[3] == 1            # the long path went through the sliced reduction
+        batch.close()
