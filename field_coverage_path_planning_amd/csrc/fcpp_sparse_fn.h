@@ -109,8 +109,10 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
             u = fmin(fi.c, bi.c);
         }
     }
-    // untouched points keep exactly their clamped / nominal value
-    const double vfin = (u < u0) ? sqrt(u) * 3.6 : (cl ? v0 : vn);
+    // untouched points keep exactly their clamped / nominal value; the square root only in waves where a sweep lowered somebody
+    double vfin = cl ? v0 : vn;
+    const bool lowered = u < u0;
+    if (__ballot(lowered) != 0ull) vfin = lowered ? sqrt(u) * 3.6 : vfin;
 
     // ---- 4. validation flags ------------------------------------------------------------------------------------------------------
     bool o_out = false, o_obs = false, o_viol = false;
@@ -135,17 +137,28 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
 
     // ---- 5. metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) on the output lanes ---------------------------------------
     const double vprev = lane_prev(vfin), kprev = lane_prev(kappa), vnprev = lane_prev(vn);
-    if (out && !is_first && !at_seam) {                     // the seam main|headland belongs to neither layer
-        const int layer = lane < wt.rel_seam ? 0 : 1;
-        const double ms_pre = (vnprev == vn) ? msn : div36((vnprev + vn) / 2);
-        const double tpre = dprev / fmax(ms_pre, 0.1);
-        const double t = (vprev == vnprev && vfin == vn) ? tpre : dprev / fmax(div36((vprev + vfin) / 2), 0.1);
-        acc.s_len[layer] += dprev; acc.s_tpre[layer] += tpre; acc.s_t[layer] += t;
+    {
+        const bool seg = out && !is_first && !at_seam;        // the seam main|headland belongs to neither layer
+        const bool l0 = lane < wt.rel_seam;                   // layer 1 (statistics index 0)
+        double tpre = 0.0, t = 0.0;
+        if (seg) {
+            const double ms_pre = (vnprev == vn) ? msn : div36((vnprev + vn) / 2);
+            tpre = dprev / fmax(ms_pre, 0.1);
+        }
+        // the time at the planned speeds differs from the one at nominal speeds only where a speed was changed: the second division
+        // only in waves that hold such a segment
+        const bool changed = seg && !(vprev == vnprev && vfin == vn);
+        t = tpre;
+        if (__ballot(changed) != 0ull) t = changed ? dprev / fmax(div36((vprev + vfin) / 2), 0.1) : tpre;
+        const double len = seg ? dprev : 0.0;
+        // (static indices: a per-lane index into the accumulator arrays would put them in scratch memory)
+        acc.s_len[0] += l0 ? len : 0.0; acc.s_tpre[0] += l0 ? tpre : 0.0; acc.s_t[0] += l0 ? t : 0.0;
+        acc.s_len[1] += l0 ? 0.0 : len; acc.s_tpre[1] += l0 ? 0.0 : tpre; acc.s_t[1] += l0 ? 0.0 : t;
     }
     if (out && !is_first && !is_last) {                     // interior points of the path
         if (kappa > 0.0) {
             // (v / 3.6)^2 kappa with the final speed: an untouched point's v / 3.6 is ms0 (the clamped value / 3.6, or the tabulated nominal one)
-            const double ms = (u < u0) ? div36(vfin) : ms0, alat = ms * ms * kappa;
+            const double ms = lowered ? div36(vfin) : ms0, alat = ms * ms * kappa;
             acc.mk = max_raw(acc.mk, kappa); acc.ma = max_raw(acc.ma, alat);
             if (alat > cst.a_lat) { o_viol = true; fw |= FCPP_FLAG_ALAT; }
         }
