@@ -1,5 +1,5 @@
 // fcpp_quiet_fn.h -- closed-form ("quiet") runs as device functions: the chunk writer of k_plan_quiet and the run statistics, shared
-// by the streaming kernel (fcpp_fused.hip) and the one-workgroup-per-field kernel of sparse sampling (fcpp_field.hip).
+// by the streaming kernel k_plan_quiet (fcpp_fused.hip) and the statistics reduction (fcpp_kernels.hip).
 #pragma once
 #include "fcpp_pointfn.h"
 
@@ -330,7 +330,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
 }
 
 // length / time statistics of one quiet run in closed form (count x step; a span: per pass the line's steps and the turn shape's own
-// totals).  The flag counts of the run's points are not part of it (k_plan_quiet / k_plan_field count them while storing).
+// totals).  The flag counts of the run's points are not part of it (k_plan_quiet counts them while storing).
 __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, const DevTile &tl, const DevField *__restrict__ fields,
                                                          const DevPrim *__restrict__ prims, const DevConst &cst)
 {

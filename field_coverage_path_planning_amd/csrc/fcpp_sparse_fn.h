@@ -1,6 +1,5 @@
-// fcpp_sparse_fn.h -- one wave tile of the sparse-sampling path as a device function (see fcpp_sparse.hip for the method): used by
-// k_plan_sparse (one wave tile per wavefront, statistics per tile) and by k_plan_field (fcpp_field.hip: all the tiles of a field in
-// one workgroup, statistics per field).
+// fcpp_sparse_fn.h -- one wave tile of the sparse-sampling path as a device function (see fcpp_sparse.hip for the method), used by
+// k_plan_sparse: one wave tile per wavefront, statistics per tile.
 #pragma once
 #include "fcpp_pointfn.h"
 
