@@ -308,6 +308,16 @@ __device__ __forceinline__ unsigned obstacle_mask(const DevObstacles &obs, int o
         while (cand) {
             const int k = __ffsll((long long)cand) - 1;
             cand &= cand - 1;
+            // which of this wave's points lie in the polygon's own box (with a margin far above any rounding of the crossing test): a
+            // tile's box can be huge -- the tile that holds the jump from the last swath to the headland spans the field, every one of
+            // cfg3's 32 polygons passed the cull above and its 163 points cost 340 us of crossing tests -- the points' boxes are not
+            const double *pb = obs.bbox + 4 * (int64_t)(base + k);
+            const double qx0 = pb[0] - 1e-6, qy0 = pb[1] - 1e-6, qx1 = pb[2] + 1e-6, qy1 = pb[3] + 1e-6;
+            unsigned near = 0;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                if (p < nvalid && px[p] >= qx0 && px[p] <= qx1 && py[p] >= qy0 && py[p] <= qy1) near |= 1u << p;
+            if (__ballot(near != 0u) == 0ull) continue;
             const int64_t a0 = obs.offsets[base + k], a1 = obs.offsets[base + k + 1];
             const int nv = (int)(a1 - a0);
             const bool staged = nv <= OBS_LDS_VERTS;
@@ -318,7 +328,9 @@ __device__ __forceinline__ unsigned obstacle_mask(const DevObstacles &obs, int o
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                if (p < nvalid && !((inside >> p) & 1u)) {
+                const bool test = ((near >> p) & 1u) && !((inside >> p) & 1u);
+                if (__ballot(test) == 0ull) continue;
+                if (test) {
                     bool in = false;
                     for (int q = 0, r = nv - 1; q < nv; r = q++) {
                         const double xi = staged ? lds[2 * q] : obs.x[a0 + q], yi = staged ? lds[2 * q + 1] : obs.y[a0 + q];
