@@ -109,7 +109,23 @@ def run_planner(E, torch, specs, opt, steps, warmup, mode=1, placement=1, fence=
     writes (default: the one of alloc()); after_step(i, res): called after step i has been enqueued."""
     fence = fence or torch.cuda.synchronize
     batch = E.Batch(specs, E.make_vehicle(), opt)
-    bufs = batch.alloc(best_of=placement)
+    plain_ms = None
+    if placement > 1:
+        # the plain allocation first (its figure is reported beside the calibrated one), then the fastest of it and `placement` more
+        # candidate sets under the batch's own step (Batch.alloc(best_of): setup only, engine.py)
+        bufs0 = batch.alloc()
+        for _ in range(2):
+            batch.run(bufs0, mode=mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            batch.run(bufs0, mode=mode)
+        torch.cuda.synchronize()
+        plain_ms = (time.perf_counter() - t0) / steps * 1e3
+        bufs = batch.alloc(best_of=placement, include=[bufs0])
+        del bufs0
+    else:
+        bufs = batch.alloc()
     res = None
     k = 0
 
@@ -139,7 +155,8 @@ def run_planner(E, torch, specs, opt, steps, warmup, mode=1, placement=1, fence=
     stage_points = batch.stage_points()
     dom_points = stage_points[dom]
     return {'stage_points': stage_points, 'prof_runs': prof_runs,'points': n_points, 'dt': dt, 'ms_per_step': dt / steps * 1e3, 'kernels': kernels, 'dominant': dom, 'dominant_points': dom_points,
-            'quiet_points': q_pts, 'general_points': g_pts, 'batch': batch, 'bufs': bufs, 'res': res, 'placement': getattr(batch, 'placement', None)}
+            'quiet_points': q_pts, 'general_points': g_pts, 'batch': batch, 'bufs': bufs, 'res': res, 'placement': getattr(batch, 'placement', None),
+            'plain_ms': plain_ms}
 
 
 def roofline_of(r, traffic_key=None):
@@ -164,6 +181,10 @@ def config_entry(name, workload, r, cpu=None, extra=None, traffic_key=None):
          'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'roofline': roofline_of(r, traffic_key or name), 'cpu_baseline': cpu}
     if r.get('placement'):
         e['placement'] = r['placement']
+    if r.get('plain_ms'):
+        e['placement1'] = {'ms_per_step': r['plain_ms'], 'value': r['points'] / (r['plain_ms'] * 1e-3),
+                           'step_frac': BYTES_PER_POINT * r['points'] / (r['plain_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           'note': 'output arrays as the allocator returns them (device time of the same steps, no per-kernel events)'}
     if extra:
         e.update(extra)
     return e
@@ -315,9 +336,10 @@ def main():
                            WL.specs_from_lh(E, LH1), E.make_options(1, 0.0), args.steps, args.warmup,
                            lambda k: orc.make_field(L=500.0, H=200.0), len(LH1), orc.Options.make(1, 1, 0.0, 0.5), what='500 x 200 m fields, clothoid, reference sampling')
         if 'cfg1_clothoid_dense' in want:
-            planner_config('cfg1_clothoid_dense', f'cfg1 x {args.fields}, clothoid turns, uniform 0.1 m sample spacing',
+            planner_config('cfg1_clothoid_dense', f'cfg1 x {args.fields}, clothoid turns, uniform 0.1 m sample spacing; output arrays calibrated (placement1: the plain allocation)',
                            WL.specs_from_lh(E, LH1), E.make_options(1, 0.1), max(3, args.steps // 10), 2,
-                           lambda k: orc.make_field(L=500.0, H=200.0), len(LH1), orc.Options.make(1, 1, 0.1, 0.5), what='500 x 200 m fields, clothoid, 0.1 m')
+                           lambda k: orc.make_field(L=500.0, H=200.0), len(LH1), orc.Options.make(1, 1, 0.1, 0.5), what='500 x 200 m fields, clothoid, 0.1 m',
+                           placement=2)
         LH2 = WL.cfg2_rectangles()
         for key, tm, sp, st_, wu in (('cfg2_ref', 0, 0.0, args.steps, args.warmup), ('cfg2_0.5', 1, 0.5, max(5, args.steps // 5), 2),
                                       ('cfg2_0.1', 1, 0.1, max(3, args.steps // 10), 2)):
@@ -330,24 +352,25 @@ def main():
                 # sets, the batch's own step timed on each, the fastest kept (setup only)
                 planner_config('cfg2_0.1_placement1', wl + ', output arrays as the allocator returns them', WL.specs_from_lh(E, LH2),
                                E.make_options(tm, sp), st_, wu)
-                planner_config('cfg2_0.1', wl + ', output arrays = the fastest of 3 candidate sets under the batch\'s own step (setup only)', WL.specs_from_lh(E, LH2),
+                planner_config('cfg2_0.1', wl + ', output arrays = the fastest of 4 candidate sets (the plain allocation and 3 more) under the batch\'s own step (setup only)', WL.specs_from_lh(E, LH2),
                                E.make_options(tm, sp), st_, wu, lambda k: orc.make_field(L=float(LH2[k, 0]), H=float(LH2[k, 1])), len(LH2),
                                orc.Options.make(tm, 1, sp, 0.5), placement=3, what=f'cfg2 fields, clothoid, {sp} m')
             else:
-                planner_config(key, wl, WL.specs_from_lh(E, LH2), E.make_options(tm, sp), st_, wu,
+                planner_config(key, wl + (', output arrays calibrated (placement1: the plain allocation)' if sp > 0 else ''), WL.specs_from_lh(E, LH2),
+                               E.make_options(tm, sp), st_, wu,
                                lambda k: orc.make_field(L=float(LH2[k, 0]), H=float(LH2[k, 1])), len(LH2), orc.Options.make(tm, 1, sp, 0.5),
-                               what=f'cfg2 fields, {"arcs, reference sampling" if sp == 0 else f"clothoid, {sp} m"}')
+                               what=f'cfg2 fields, {"arcs, reference sampling" if sp == 0 else f"clothoid, {sp} m"}', placement=3 if sp > 0 else 1)
         if 'cfg3' in want:
             (L3, H3), obst = WL.cfg3_field()
 
             def cfg3_extra(rr):
                 st3 = rr['res'].stats()
                 return {'n_in_obstacle': int(st3['n_in_obstacle'][0]), 'n_outside': int(st3['n_outside'][0])}
-            planner_config('cfg3', 'cfg3: one 5000 x 2000 m field, 32 convex eight-gon obstacles, clothoid turns, 0.05 m sample spacing',
+            planner_config('cfg3', 'cfg3: one 5000 x 2000 m field, 32 convex eight-gon obstacles, clothoid turns, 0.05 m sample spacing; output arrays calibrated (placement1: the plain allocation)',
                            [E.FieldSpec(field_length=L3, field_width=H3, obstacles=obst)], E.make_options(1, 0.05), max(5, args.steps // 5), 2,
                            lambda k: orc.make_field(L=1000.0, H=400.0, obstacles=[[(x / 5, y / 5) for x, y in o] for o in obst]), 1,
                            orc.Options.make(1, 1, 0.05, 0.5), what='a 1000 x 400 m field with the 32 obstacles scaled by 1/5, clothoid, 0.05 m (1/25 of cfg3)',
-                           extra_fn=cfg3_extra, budget=6.0)
+                           extra_fn=cfg3_extra, budget=6.0, placement=3)
         if 'cfg4' in want:
             configs.append(run_cfg4(E, torch, WL, cpu_on))
     if 'cfg5' in want or world > 1:
