@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('config')
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--mode', type=int, default=1)
-ap.add_argument('--placement', type=int, default=-1, help='candidate sets of output arrays (Batch.alloc best_of); default: as bench.py, 3 for cfg2_0.1 and 3 + the plain one for cfg5, else 1')
+ap.add_argument('--placement', type=int, default=-1, help='candidate sets of output arrays (Batch.alloc best_of); default: as bench.py -- the plain allocation + 2-3 more for the dense configurations and cfg5, else 1')
 a = ap.parse_args()
 c = a.config
 if c.startswith('cfg1'):
@@ -34,9 +34,9 @@ else:
 b = E.Batch(specs, E.make_vehicle(), opt)
 # the same output placement as bench.py gives the configuration (setup; its launches precede the `steps` timed ones in the trace --
 # tools/profiles_summary.py takes the kernel statistics from the LAST `steps` dispatches of every kernel)
-placement = a.placement if a.placement >= 0 else {'cfg2_0.1': 3, 'cfg5': 3}.get(c, 1)
+placement = a.placement if a.placement >= 0 else {'cfg1_clothoid_dense': 2, 'cfg2_0.5': 3, 'cfg2_0.1': 3, 'cfg3': 3, 'cfg5': 3}.get(c, 1)
 if placement > 1 and a.mode == 1:
-    bufs = b.alloc(best_of=placement, include=[b.alloc()] if c == 'cfg5' else ())
+    bufs = b.alloc(best_of=placement, include=[b.alloc()])
 else:
     bufs = b.alloc()
 b.run(bufs, mode=a.mode)
