@@ -141,7 +141,7 @@ def run_planner(E, torch, specs, opt, steps, warmup, mode=1, placement=1, fence=
     fence()
     # per-kernel HIP events inside the timed region, on a sample of its steps (a profiled step dispatches every kernel with its own
     # start / stop events and costs ~15 us more than a plain one: on every step that would be 14 % of the headline's 110 us)
-    batch.set_profiling(True, every=max(1, steps // 8))
+    batch.set_profiling(True, every=max(8, steps // 8))
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -469,7 +469,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
         res = S.plan_sharded(specs, veh, opt, device=dev.index, batch=batch, buffers=bufs, infos=infos)
     fence()
     # timed: the device work of every rank + the stats gather (sizing and batch setup were done once, above: setup_s)
-    batch.set_profiling(True, every=max(1, steps // 4))
+    batch.set_profiling(True, every=max(4, steps // 4))
     t0 = time.perf_counter()
     for _ in range(steps):
         res = S.plan_sharded(specs, veh, opt, device=dev.index, batch=batch, buffers=bufs, infos=infos)
