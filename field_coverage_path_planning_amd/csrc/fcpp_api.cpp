@@ -71,7 +71,7 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     c.inv_sf36 = 1.0 / (c.sf * 3.6);
     c.ms_work = c.v_work / 3.6; c.ms_turn = c.v_turn / 3.6; c.ms_head = c.v_head / 3.6; c.ms_rev = 2.5 / 3.6;
     c.shapes = nullptr; c.tmpl_u = nullptr; c.tmpl_c = nullptr; c.tmpl_u_dk = nullptr; c.field_junc = nullptr;
-    c.tmpl_n = 0; c._pad_tmpl = 0;
+    c.tmpl_n = 0; c.tmpl_nc = 1;
     c.turn_kappa_last[0] = c.turn_kappa_last[1] = c.turn_len = c.turn_time = 0.0;
     c.turn_max_kappa[0] = c.turn_max_kappa[1] = c.turn_max_jump[0] = c.turn_max_jump[1] = 0.0;
     return c;
@@ -768,7 +768,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
             if (le != 0) e = (hipError_t)le;
         }
         b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p; b->cst.tmpl_u_dk = b->tmpl_u_dk.p;
-        b->cst.tmpl_n = (int)nu;
+        b->cst.tmpl_n = (int)nu; b->cst.tmpl_nc = std::max(1, (int)b->hp.tt.nc);
         if (e == hipSuccess) {
             const int nc = b->hp.tt.nc;
             std::vector<double2> dk((size_t)nu);

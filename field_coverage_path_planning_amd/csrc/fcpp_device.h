@@ -28,7 +28,7 @@ struct DevConst {
     double inv_sf36;           // 1 / (safety_factor * 3.6), for the clamp pre-test
     const CacShape *shapes;
     const double2 *tmpl_u, *tmpl_c;   // turn templates of the batch (fused kernel), see TurnTemplates
-    int tmpl_n, _pad_tmpl;            // samples of the U-turn template
+    int tmpl_n, tmpl_nc;              // samples of the U-turn template / of the corner template
     // quiet U-turns (k_plan_quiet kind 3): per-batch constants of the turn shape; index 0 / 1 = passes ascending / descending in y
     double turn_kappa_last[2];        // curvature at the turn's last sample (its stencil spans the jump to the next swath line)
     double turn_len, turn_time;       // sum of the turn's segment lengths, and that over the nominal turn speed

@@ -109,8 +109,9 @@ __device__ __forceinline__ void eval_main(const DevField &f, const DevConst &cst
     if (f.rotated) rotate_back(f, px, py);
 }
 
-// layer 2 (MLP:943-1084): sample r of primitive p
-__device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst, int r, double &px, double &py)
+// layer 2 (MLP:943-1084): sample r of primitive p.  tc: the corner template's sample r if the caller has fetched it already
+// (k_plan_sparse asks for it together with the primitive record instead of after it), else NULL
+__device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst, int r, double &px, double &py, const double2 *tc = nullptr)
 {
     if (p.kind == PRIM_LINSPACE) {
         px = linspace_at32(p.a[0], p.a[2], p.a[4], p.n, r);
@@ -132,7 +133,7 @@ __device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst,
             py = (tx * p.a[3] + ty * p.a[2]) + p.a[5];
         }
     } else {   // corner turn: quadrant formulas MLP:1049-1060 on the template (t1, t2) = (R(1-cos), R sin) or its clothoid analogue
-        const double2 t = cst.tmpl_c[r];
+        const double2 t = tc ? *tc : cst.tmpl_c[r];
         const int ci = p.kind == PRIM_ARC ? p.form : ((p.form + 3) & 3);
         if (ci == 0)      { px = p.a[0] + t.x; py = p.a[1] + t.y; }
         else if (ci == 1) { px = p.a[0] - t.y; py = p.a[1] + t.x; }

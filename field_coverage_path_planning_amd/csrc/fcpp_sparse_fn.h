@@ -51,8 +51,14 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
             const int th = wt.thr[k];
             if (lane >= th) { ++pi; r = lane - th; }
         }
-        const DevPrim &p = prims[pi];
-        eval_prim(p, cst, r, px, py);
+        // The corner template's sample is asked for BESIDE the primitive record, not after it (inside the corner branch its latency
+        // would be paid in full, one dependent round trip more: phase stamps showed 36 % of a wave's life in eval_prim).  The empty
+        // asm needs both values, so both loads are in flight before either is waited for.
+        double2 tc = cst.tmpl_c[min(max(r, 0), cst.tmpl_nc - 1)];
+        const DevPrim p = prims[pi];                    // the whole record at once: read field by field inside the branches of
+        int kind = p.kind;                              // eval_prim, every primitive kind present in the wave paid a round trip of its own
+        asm volatile("" : "+v"(tc.x), "+v"(tc.y), "+v"(kind));
+        eval_prim(p, cst, r, px, py, &tc);
         fw = p.fs;
     }
     const double vn = nominal_speed(fw, cst), msn = nominal_ms(fw, cst);
