@@ -83,89 +83,6 @@ __device__ __forceinline__ void ox_child(const int32_t *keep, const int32_t *don
     wsync();
 }
 
-// one wavefront, one pair of offspring.  lds: 4 n genes + n presence bytes of this wavefront, s_w: two ints of it
-__device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s_w, int n, int pop, const double *__restrict__ D,
-                                        const int32_t *__restrict__ cur, const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
-                                        double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg, int gen)
-{
-    int32_t *const P[2] = { lds, lds + n }, *const Cc[2] = { lds + 2 * n, lds + 3 * n };
-    unsigned char *const present = reinterpret_cast<unsigned char *>(lds + 4 * n);
-    const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
-    if (lane < 2) {      // the two tournaments (GA:189-194): k distinct candidates, the FIRST maximum wins (np.argmax)
-        int cand[64];
-        int nc = 0, w = 0;
-        double wf = 0.0;
-        U4 blk = { { 0, 0, 0, 0 } };
-        for (uint32_t j = 0; nc < cfg.tournament_size; ++j) {
-            if ((j & 3u) == 0u) blk = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(1 + lane), j >> 2, k0, k1);
-            const uint32_t word = (j & 3u) == 0u ? blk.w[0] : ((j & 3u) == 1u ? blk.w[1] : ((j & 3u) == 2u ? blk.w[2] : blk.w[3]));
-            const int c = (int)(word % (uint32_t)pop);
-            bool dup = false;
-            for (int q = 0; q < nc; ++q) dup |= cand[q] == c;
-            if (!dup) {
-                cand[nc] = c;
-                const double f = cur_fit[c];
-                if (nc == 0 || f > wf) { w = c; wf = f; }
-                ++nc;
-            }
-        }
-        s_w[lane] = w;
-    }
-    wsync();
-    const int32_t *p1g = cur + (int64_t)s_w[0] * n, *p2g = cur + (int64_t)s_w[1] * n;
-    for (int i = lane; i < n; i += 64) { P[0][i] = p1g[i]; P[1][i] = p2g[i]; }
-    wsync();
-    const U4 X = philox((uint32_t)gen, (uint32_t)pair, 3u, 0u, k0, k1);
-    if (unit(X.w[0], X.w[1]) < cfg.crossover_rate) {      // GA:207
-        int i, j;
-        two_positions(X.w[2], X.w[3], n, i, j);
-        const int a = min(i, j), b = max(i, j);
-        ox_child(P[0], P[1], n, a, b, Cc[0], present, lane);
-        ox_child(P[1], P[0], n, a, b, Cc[1], present, lane);
-    } else {
-        for (int i = lane; i < n; i += 64) { Cc[0][i] = P[0][i]; Cc[1][i] = P[1][i]; }
-        wsync();
-    }
-    if (lane < 2) {      // GA:246-250
-        const U4 M = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(4 + lane), 0u, k0, k1);
-        if (unit(M.w[0], M.w[1]) < cfg.mutation_rate) {
-            int i, j;
-            two_positions(M.w[2], M.w[3], n, i, j);
-            const int32_t t = Cc[lane][i]; Cc[lane][i] = Cc[lane][j]; Cc[lane][j] = t;
-        }
-    }
-    wsync();
-    for (int c = 0; c < 2; ++c) {
-        const int row = 2 * pair + c;
-        if (row >= pop - cfg.elite_size) continue;     // an elite takes this row (GA:266)
-        const int32_t *ch = Cc[c];
-        for (int i = lane; i < n; i += 64) nxt[(int64_t)row * n + i] = ch[i];
-        double total = 0.0;                             // GA:174-181, left to right
-        for (int base = 0; base < n; base += 64) {
-            const int k = base + lane;
-            double d = 0.0;
-            if (k < n) d = D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]];
-            const int m = min(64, n - base);
-            // left to right, as the reference's loop adds: lane l's term through v_readlane (a scalar lane index: no trip through the
-            // LDS crossbar, whose latency 128 dependent additions would pay one after the other)
-            for (int l = 0; l < m; ++l)
-                total += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), l), __builtin_amdgcn_readlane(__double2loint(d), l));
-        }
-        if (lane == 0) { nxt_dist[row] = total; nxt_fit[row] = 1.0 / (total + 1e-6); }
-    }
-}
-
-__global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
-                                                 const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
-                                                 double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
-                                                 int gen, const GaState *__restrict__ state)
-{
-    extern __shared__ int32_t lds[];                    // 4 n genes + n presence bytes (sized by the launcher: small tours -> many waves per CU)
-    __shared__ int s_w[2];
-    if (state->converged) return;
-    ga_pair(threadIdx.x, blockIdx.x, lds, s_w, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen);
-}
-
 // wave-wide arg-max of (fitness, index) pairs in the order of the elitism: larger fitness first, among equals the larger index;
 // lanes without a candidate pass idx < 0 (their fitness is ignored).  The maximum fitness goes through DPP moves (no index is
 // carried along), one ballot finds who holds it -- normally one lane, whose index is read directly; several lanes with exactly the
@@ -200,6 +117,131 @@ __device__ __forceinline__ int wave_argmax(double f, int idx, double &wf)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wi = max(wi, __shfl_xor(wi, o));
     return wi;
+}
+
+// int32 words of a wavefront's LDS slice before its 2 x 64 tournament candidates: 4 n genes + n presence bytes, rounded to 16 bytes
+#define GA_PAIR_LDS_HEAD(n) ((((size_t)(n) * 4 * sizeof(int32_t) + (size_t)(((n) + 3) & ~3) + 15) / 16) * 4)
+// one wavefront, one pair of offspring.  lds: 4 n genes + n presence bytes + 128 candidate indices of this wavefront, s_w: two ints of it
+__device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s_w, int n, int pop, const double *__restrict__ D,
+                                        const int32_t *__restrict__ cur, const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
+                                        double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg, int gen)
+{
+    int32_t *const P[2] = { lds, lds + n }, *const Cc[2] = { lds + 2 * n, lds + 3 * n };
+    unsigned char *const present = reinterpret_cast<unsigned char *>(lds + 4 * n);
+    const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
+    // The two tournaments (GA:189-194): k distinct candidates each, the FIRST maximum wins (np.argmax).  Lanes 0 and 1 draw the
+    // candidates (the stream of draws and the rejection of repeats are sequential) into LDS -- a per-lane array indexed at run time
+    // would live in scratch memory, a memory round trip per look-up -- then ALL lanes fetch the candidates' fitness at once and
+    // the winner is the first lane that holds the maximum.
+    int32_t *const s_cand = lds + GA_PAIR_LDS_HEAD(n);          // 2 x 64 candidate indices of this wavefront
+    if (lane < 2) {
+        int nc = 0;
+        U4 blk = { { 0, 0, 0, 0 } };
+        for (uint32_t j = 0; nc < cfg.tournament_size; ++j) {
+            if ((j & 3u) == 0u) blk = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(1 + lane), j >> 2, k0, k1);
+            const uint32_t word = (j & 3u) == 0u ? blk.w[0] : ((j & 3u) == 1u ? blk.w[1] : ((j & 3u) == 2u ? blk.w[2] : blk.w[3]));
+            const int c = (int)(word % (uint32_t)pop);
+            bool dup = false;
+            for (int q = 0; q < nc; ++q) dup |= s_cand[64 * lane + q] == c;
+            if (!dup) { s_cand[64 * lane + nc] = c; ++nc; }
+        }
+    }
+    wsync();
+    {
+        const int k = cfg.tournament_size;
+        const int c0 = lane < k ? s_cand[lane] : -1, c1 = lane < k ? s_cand[64 + lane] : -1;
+        const double f0 = c0 >= 0 ? cur_fit[c0] : 0.0, f1 = c1 >= 0 ? cur_fit[c1] : 0.0;      // (both tournaments' loads in flight together)
+        double m0, m1;
+        (void)wave_argmax(f0, c0 >= 0 ? lane : -1, m0);          // (only the maximum is used: the FIRST lane holding it wins)
+        (void)wave_argmax(f1, c1 >= 0 ? lane : -1, m1);
+        const unsigned long long b0 = __ballot(c0 >= 0 && f0 == m0), b1 = __ballot(c1 >= 0 && f1 == m1);
+        if (lane == 0) { s_w[0] = s_cand[__ffsll((long long)b0) - 1]; s_w[1] = s_cand[64 + __ffsll((long long)b1) - 1]; }
+    }
+    wsync();
+    const int32_t *p1g = cur + (int64_t)s_w[0] * n, *p2g = cur + (int64_t)s_w[1] * n;
+    for (int i = lane; i < n; i += 64) { P[0][i] = p1g[i]; P[1][i] = p2g[i]; }
+    wsync();
+    const U4 X = philox((uint32_t)gen, (uint32_t)pair, 3u, 0u, k0, k1);
+    if (unit(X.w[0], X.w[1]) < cfg.crossover_rate) {      // GA:207
+        int i, j;
+        two_positions(X.w[2], X.w[3], n, i, j);
+        const int a = min(i, j), b = max(i, j);
+        ox_child(P[0], P[1], n, a, b, Cc[0], present, lane);
+        ox_child(P[1], P[0], n, a, b, Cc[1], present, lane);
+    } else {
+        for (int i = lane; i < n; i += 64) { Cc[0][i] = P[0][i]; Cc[1][i] = P[1][i]; }
+        wsync();
+    }
+    if (lane < 2) {      // GA:246-250
+        const U4 M = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(4 + lane), 0u, k0, k1);
+        if (unit(M.w[0], M.w[1]) < cfg.mutation_rate) {
+            int i, j;
+            two_positions(M.w[2], M.w[3], n, i, j);
+            const int32_t t = Cc[lane][i]; Cc[lane][i] = Cc[lane][j]; Cc[lane][j] = t;
+        }
+    }
+    wsync();
+    // the children's rows and tour lengths (GA:174-181).  The matrix entries of BOTH children are asked for first (tours of up to
+    // 256 nodes: four loads in flight instead of four round trips one after the other), then each child's terms are added left to
+    // right, as the reference's loop adds them: lane l's term through v_readlane (a scalar lane index: no trip through the LDS
+    // crossbar, whose latency the dependent additions would pay one after the other).
+    const int nchunk = (n + 63) >> 6;
+    const bool rowok[2] = { 2 * pair < pop - cfg.elite_size, 2 * pair + 1 < pop - cfg.elite_size };     // an elite takes the other rows (GA:266)
+    if (nchunk <= 4) {
+        double dd[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int32_t *ch = Cc[c];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int k = 64 * b + lane;
+                dd[c][b] = (rowok[c] && k < n) ? D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (!rowok[c]) continue;
+            const int row = 2 * pair + c;
+            const int32_t *ch = Cc[c];
+            for (int i = lane; i < n; i += 64) nxt[(int64_t)row * n + i] = ch[i];
+            double total = 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int m = min(64, n - 64 * b);
+                for (int l = 0; l < m; ++l)
+                    total += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd[c][b]), l), __builtin_amdgcn_readlane(__double2loint(dd[c][b]), l));
+            }
+            if (lane == 0) { nxt_dist[row] = total; nxt_fit[row] = 1.0 / (total + 1e-6); }
+        }
+        return;
+    }
+    for (int c = 0; c < 2; ++c) {
+        const int row = 2 * pair + c;
+        if (!rowok[c]) continue;
+        const int32_t *ch = Cc[c];
+        for (int i = lane; i < n; i += 64) nxt[(int64_t)row * n + i] = ch[i];
+        double total = 0.0;
+        for (int base = 0; base < n; base += 64) {
+            const int k = base + lane;
+            double d = 0.0;
+            if (k < n) d = D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]];
+            const int m = min(64, n - base);
+            for (int l = 0; l < m; ++l)
+                total += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), l), __builtin_amdgcn_readlane(__double2loint(d), l));
+        }
+        if (lane == 0) { nxt_dist[row] = total; nxt_fit[row] = 1.0 / (total + 1e-6); }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
+                                                 const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
+                                                 double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, fcpp_ga_config cfg,
+                                                 int gen, const GaState *__restrict__ state)
+{
+    extern __shared__ int32_t lds[];                    // 4 n genes + n presence bytes (sized by the launcher: small tours -> many waves per CU)
+    __shared__ int s_w[2];
+    if (state->converged) return;
+    ga_pair(threadIdx.x, blockIdx.x, lds, s_w, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen);
 }
 
 static constexpr int GA_LDS_POP = 6144;      // 48 KiB of fitness values cached in LDS
@@ -439,7 +481,7 @@ int launch_ga_check_perm(hipStream_t st, int n, int pop, const int32_t *routes, 
 int launch_ga_pairs(hipStream_t st, int n, int pop, const double *D, const int32_t *cur, const double *cur_fit, int32_t *nxt,
                     double *nxt_fit, double *nxt_dist, const fcpp_ga_config &cfg, int gen, const GaState *state)
 {
-    const size_t lds = (size_t)n * 4 * sizeof(int32_t) + (size_t)((n + 3) & ~3);
+    const size_t lds = (GA_PAIR_LDS_HEAD(n) + 128) * sizeof(int32_t);
     hipLaunchKernelGGL(k_ga_pairs, dim3((unsigned)(pop / 2)), dim3(64), lds, st, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen,
                        state);
     hipError_t e = hipGetLastError();
@@ -458,7 +500,7 @@ int launch_ga_stats_elite(hipStream_t st, int n, int pop, const int32_t *cur, co
 }
 
 // lds ints of one pair: 4 n genes + n presence bytes, rounded to 16 bytes
-static inline size_t ga_pair_lds_ints(int n) { return ((size_t)n * 4 * sizeof(int32_t) + (size_t)((n + 3) & ~3) + 15) / 16 * 4; }
+static inline size_t ga_pair_lds_ints(int n) { return GA_PAIR_LDS_HEAD(n) + 128; }
 
 bool ga_generation_fits(int n, int pop)
 {
