@@ -112,7 +112,7 @@ __device__ __forceinline__ int wave_argmax(double f, int idx, double &wf)
     wf = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
     const unsigned long long m = __ballot(idx >= 0 && f == wf);
     if (m == 0ull) return -1;
-    if ((m & (m - 1ull)) == 0ull) return __shfl(idx, (int)__ffsll((long long)m) - 1);
+    if ((m & (m - 1ull)) == 0ull) return __builtin_amdgcn_readlane(idx, (int)__ffsll((long long)m) - 1);      // (a scalar lane index)
     int wi = (idx >= 0 && f == wf) ? idx : -1;           // ties: the larger index
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wi = max(wi, __shfl_xor(wi, o));
