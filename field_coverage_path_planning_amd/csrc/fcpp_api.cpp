@@ -917,7 +917,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // tiles that walk long halos, cfg3: 5873 points in 0.37 ms): beside the HBM-bound streaming kernel they cost nothing (cfg3
         // 0.87 -> 0.51 ms).  Not when the general kernel can fill the chip itself -- side by side it takes compute units from the
         // streaming kernel (cfg2 at 0.1 m, 5950 general tiles: 6.5 vs 5.6 ms) -- and not at sparse sampling: k_plan_sparse and the
-        // span kernel get in each other's way (cfg5 2.41 vs 2.29 ms, cfg1 x 4096 0.114 vs 0.098 ms, also with the span kernel held to five
+        // span kernel get in each other's way (cfg5 2.41 vs 2.29 ms, cfg1 x 4096 0.114 vs 0.098 ms, also with the span kernel held to four or five
         // waves per SIMD).
         hipStream_t sd = st;
         const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_general <= tune_int("FCPP_TWO_STREAM_MAX", 512) &&

@@ -110,7 +110,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
         FCPP_PIN(xr); FCPP_PIN(xl); FCPP_PIN(k_last); FCPP_PIN(k_start); FCPP_PIN(min_y); FCPP_PIN(Wd); FCPP_PIN(lstep); FCPP_PIN(lex); FCPP_PIN(lsx);
         FCPP_PIN(v_work); FCPP_PIN(v_turn); FCPP_PIN(n_obs);
         // ... and the rotation and the geofence edges (17 values that only ever meet vector operands) in VECTOR registers: the kernel
-        // runs five waves per SIMD (launch_plan_quiet), which leaves each wave 100 of them
+        // runs four waves per SIMD (launch_plan_quiet), which leaves each wave more than 100 of them
         FCPP_PIN_V(rc); FCPP_PIN_V(rs); FCPP_PIN_V(rcx); FCPP_PIN_V(rcy);
         FCPP_PIN_V(e0x); FCPP_PIN_V(e0y); FCPP_PIN_V(e0o); FCPP_PIN_V(e1x); FCPP_PIN_V(e1y); FCPP_PIN_V(e1o);
         FCPP_PIN_V(e2x); FCPP_PIN_V(e2y); FCPP_PIN_V(e2o); FCPP_PIN_V(e3x); FCPP_PIN_V(e3y); FCPP_PIN_V(e3o); FCPP_PIN_V(ntl);
