@@ -326,9 +326,8 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
     // pop - 1 - t.
     auto better = [](double af, int ai, double cf, int ci) { return ai >= 0 && (ci < 0 || af > cf || (af == cf && ai > ci)); };
     if (cached && cfg.elite_size <= 64) {
-        // Up to 64 elites, the population in LDS: every wavefront picks the elite_size best of ITS 1/16 of the population -- elite_size
-        // rounds of a wave-wide arg-max, shuffles only, all wavefronts at once -- and one wavefront picks the elite_size best of those
-        // candidates the same way.  The global top elite_size are among the per-wave ones, and the order (fitness, then the larger
+        // Up to 64 elites, the population in LDS: every wavefront lists the best of ITS 1/16 of the population -- rounds of a wave-wide
+        // arg-max, all wavefronts at once -- and the lists are merged by rank.  The global top elite_size are among the per-wave ones, and the order (fitness, then the larger
         // index) is total, so the picks are those of the sequential definition; two dependent phases instead of elite_size.
         __shared__ double c_f[SW * 64];
         __shared__ int c_i[SW * 64];
@@ -336,34 +335,44 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
         const int lane = tid & 63, wave = tid >> 6, E = cfg.elite_size;
         double ef[KPT];
         unsigned taken = 0;
+        // (key i belongs to wavefront i % 16: the previous generation's elites, which sit in consecutive rows and are likely to be picked
+        // again, spread over all wavefronts instead of filling one wavefront's list)
+        static_assert(SW == 16, "key ownership below");
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) { const int i = tid + k * SB; ef[k] = i < pop ? s_fit[i] : -1.0; }
-        for (int t = 0; t < E; ++t) {
-            double f = -1.0;
-            int idx = -1, kk = 0;
+        for (int k = 0; k < KPT; ++k) { const int i = ((k * 64 + lane) << 4) | wave; ef[k] = i < pop ? s_fit[i] : -1.0; }
+        // The wavefronts' lists are first built ELITE_FIRST deep only: the global top E lie in the union of the per-wave top R as long as
+        // no wavefront holds R of them, which the merge itself shows -- a wavefront whose R-th candidate is picked may hold more, and
+        // only then are the lists continued to E and merged again (a wavefront holds E / 16 of the elites on average).
+        constexpr int ELITE_FIRST = 6;
+        int done = 0;
+        for (int depth = min(E, ELITE_FIRST);; depth = E) {
+            for (int t = done; t < depth; ++t) {
+                double f = -1.0;
+                int idx = -1, kk = 0;
 #pragma unroll
-            for (int k = 0; k < KPT; ++k) {
-                const int i = tid + k * SB;
-                if (i < pop && !((taken >> k) & 1u) && better(ef[k], i, f, idx)) { f = ef[k]; idx = i; kk = k; }
+                for (int k = 0; k < KPT; ++k) {
+                    const int i = ((k * 64 + lane) << 4) | wave;
+                    if (i < pop && !((taken >> k) & 1u) && better(ef[k], i, f, idx)) { f = ef[k]; idx = i; kk = k; }
+                }
+                double wf;
+                const int wi = wave_argmax(f, idx, wf);
+                if (idx >= 0 && wi == idx) taken |= 1u << kk;         // its owner retires the pick
+                if (lane == 0) { c_f[wave * 64 + t] = wi >= 0 ? wf : -1.0; c_i[wave * 64 + t] = wi; }
             }
-            double wf;
-            const int wi = wave_argmax(f, idx, wf);
-            if (idx >= 0 && wi == idx) taken |= 1u << kk;         // its owner retires the pick
-            if (lane == 0) { c_f[wave * 64 + t] = wi >= 0 ? wf : -1.0; c_i[wave * 64 + t] = wi; }
-        }
-        __syncthreads();
-        {
+            done = depth;
+            __syncthreads();
             // Merge by rank: every wavefront's candidates are in the elitism's order (best first, exhausted slots last), which is a
             // strict total order; thread (w, t) owns candidate t of wavefront w, and its global rank is t plus, for every other
-            // wavefront, the number of that list's candidates that beat it -- a binary search per list, all 16 x E candidates at
+            // wavefront, the number of that list's candidates that beat it -- a binary search per list, all 16 x depth candidates at
             // once (the 16 lists used to be merged by one wavefront in E dependent rounds: 22 of the kernel's 40 us).
-            const int myi = lane < E ? c_i[wave * 64 + lane] : -1;
-            const double myf = lane < E ? c_f[wave * 64 + lane] : -1.0;
+            const int myi = lane < depth ? c_i[wave * 64 + lane] : -1;
+            const double myf = lane < depth ? c_f[wave * 64 + lane] : -1.0;
+            int deeper = 0;
             if (myi >= 0) {
                 int rank = lane;
                 for (int w2 = 0; w2 < SW; ++w2) {
                     if (w2 == wave) continue;
-                    int lo = 0, hi = E;
+                    int lo = 0, hi = depth;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
                         if (better(c_f[w2 * 64 + mid], c_i[w2 * 64 + mid], myf, myi)) lo = mid + 1; else hi = mid;
@@ -371,9 +380,10 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
                     rank += lo;
                 }
                 if (rank < E) s_pick[rank] = myi;
+                deeper = depth < E && lane == depth - 1 && rank < E;
             }
+            if (!__syncthreads_or(deeper)) break;
         }
-        __syncthreads();
         for (int q = tid; q < E * n; q += SB) {
             const int t = q / n, k = q - t * n;
             nxt[(int64_t)(pop - 1 - t) * n + k] = cur[(int64_t)s_pick[t] * n + k];
