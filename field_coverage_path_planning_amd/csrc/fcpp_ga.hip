@@ -208,8 +208,13 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int m = min(64, n - 64 * b);
-                for (int l = 0; l < m; ++l)
-                    total += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dd[c][b]), l), __builtin_amdgcn_readlane(__double2loint(dd[c][b]), l));
+                const int dh = __double2hiint(dd[c][b]), dl = __double2loint(dd[c][b]);
+                if (m == 64) {              // a full chunk: 64 constant lane indices, no loop bookkeeping between the dependent additions
+#pragma unroll
+                    for (int l = 0; l < 64; ++l) total += __hiloint2double(__builtin_amdgcn_readlane(dh, l), __builtin_amdgcn_readlane(dl, l));
+                } else {
+                    for (int l = 0; l < m; ++l) total += __hiloint2double(__builtin_amdgcn_readlane(dh, l), __builtin_amdgcn_readlane(dl, l));
+                }
             }
             if (lane == 0) { nxt_dist[row] = total; nxt_fit[row] = 1.0 / (total + 1e-6); }
         }

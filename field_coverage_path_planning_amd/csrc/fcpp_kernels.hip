@@ -619,8 +619,13 @@ __global__ __launch_bounds__(BLOCK) void k_ga_fitness(int n, int64_t pop, const 
                 d = ((unsigned)a < (unsigned)n && (unsigned)b < (unsigned)n) ? D[(int64_t)a * n + b] : __builtin_nan("");   // precondition, include/fcpp.h
             }
             const int m = min(64, n - base);
-            for (int l = 0; l < m; ++l)      // (left to right; a scalar lane index: v_readlane, not the LDS crossbar)
-                total += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), l), __builtin_amdgcn_readlane(__double2loint(d), l));
+            const int dh = __double2hiint(d), dl = __double2loint(d);      // (left to right; a scalar lane index: v_readlane, not the LDS crossbar)
+            if (m == 64) {
+#pragma unroll
+                for (int l = 0; l < 64; ++l) total += __hiloint2double(__builtin_amdgcn_readlane(dh, l), __builtin_amdgcn_readlane(dl, l));
+            } else {
+                for (int l = 0; l < m; ++l) total += __hiloint2double(__builtin_amdgcn_readlane(dh, l), __builtin_amdgcn_readlane(dl, l));
+            }
         }
     } else {
         for (int k = lane; k < n; k += 64) {
