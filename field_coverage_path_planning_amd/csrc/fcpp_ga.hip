@@ -335,7 +335,7 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
         // arg-max, all wavefronts at once -- and the lists are merged by rank.  The global top elite_size are among the per-wave ones, and the order (fitness, then the larger
         // index) is total, so the picks are those of the sequential definition; two dependent phases instead of elite_size.
         __shared__ double c_f[SW * 64];
-        __shared__ int c_i[SW * 64];
+        __shared__ int c_i[SW * 64], s_rank[SW * 64];
         constexpr int KPT = GA_LDS_POP / SB;
         const int lane = tid & 63, wave = tid >> 6, E = cfg.elite_size;
         double ef[KPT];
@@ -370,20 +370,26 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
             // strict total order; thread (w, t) owns candidate t of wavefront w, and its global rank is t plus, for every other
             // wavefront, the number of that list's candidates that beat it -- a binary search per list, all 16 x depth candidates at
             // once (the 16 lists used to be merged by one wavefront in E dependent rounds: 22 of the kernel's 40 us).
+            // (one task per candidate and OTHER list, spread over all threads; the partial ranks meet in LDS)
+            if (lane < depth) s_rank[wave * 64 + lane] = lane;
+            __syncthreads();
+            for (int q = tid; q < SW * depth * SW; q += SB) {
+                const int c = q / SW, w2 = q - c * SW, cw = c / depth, ct = c - cw * depth;
+                const int ci0 = c_i[cw * 64 + ct];
+                if (w2 == cw || ci0 < 0) continue;
+                const double cf0 = c_f[cw * 64 + ct];
+                int lo = 0, hi = depth;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (better(c_f[w2 * 64 + mid], c_i[w2 * 64 + mid], cf0, ci0)) lo = mid + 1; else hi = mid;
+                }
+                if (lo) atomicAdd(&s_rank[cw * 64 + ct], lo);
+            }
+            __syncthreads();
             const int myi = lane < depth ? c_i[wave * 64 + lane] : -1;
-            const double myf = lane < depth ? c_f[wave * 64 + lane] : -1.0;
             int deeper = 0;
             if (myi >= 0) {
-                int rank = lane;
-                for (int w2 = 0; w2 < SW; ++w2) {
-                    if (w2 == wave) continue;
-                    int lo = 0, hi = depth;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (better(c_f[w2 * 64 + mid], c_i[w2 * 64 + mid], myf, myi)) lo = mid + 1; else hi = mid;
-                    }
-                    rank += lo;
-                }
+                const int rank = s_rank[wave * 64 + lane];
                 if (rank < E) s_pick[rank] = myi;
                 deeper = depth < E && lane == depth - 1 && rank < E;
             }
