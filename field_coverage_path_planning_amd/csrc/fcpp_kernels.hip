@@ -371,14 +371,14 @@ static_assert(sizeof(StatAcc) == 104, "red_scratch in fcpp_api.cpp is sized for 
 
 __device__ __forceinline__ void stat_entry(StatAcc &s, int64_t t, TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
                                            const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
-                                           const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, const DevConst &cst)
+                                           const FieldStatView &fv, const DevPrim *__restrict__ prims, const DevConst &cst)
 {
     const int64_t slot = ids ? (int64_t)ids[t] : t;
     TilePartial tp = partial[slot];
     const int64_t rc = run_count ? run_count[t] : 0;
     if (rc > 0) {
         const DevRun run = { (int32_t)slot, 0, rc };
-        const TilePartial rp = quiet_run_partial(run, tiles[slot], fields, prims, cst);
+        const TilePartial rp = quiet_run_partial(run, tiles[slot], fv, prims, cst);
         tp.main_len = rp.main_len; tp.main_time_pre = rp.main_time_pre; tp.main_time = rp.main_time;
         tp.head_len = rp.head_len; tp.head_time_pre = rp.head_time_pre; tp.head_time = rp.head_time;
         tp.max_kappa = rp.max_kappa; tp.max_alat = rp.max_alat; tp.max_jump = rp.max_jump;
@@ -417,8 +417,11 @@ __global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_list, const int3
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.b[k] = 0;
     const int64_t pth = slot < n_list ? (path_list ? (int64_t)path_list[slot] : slot) : -1;
-    if (pth >= 0)
-        for (int64_t t = tile_first[pth] + sub; t < tile_first[pth + 1]; t += G) stat_entry(s, t, partial, ids, run_count, tiles, fields, prims, cst);
+    if (pth >= 0) {
+        FieldStatView fv = {};
+        if (fields) fv.load(fields, cst, pth);          // (the path's field: asked for beside the entry list, not through the tile records)
+        for (int64_t t = tile_first[pth] + sub; t < tile_first[pth + 1]; t += G) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst);
+    }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) {
 #pragma unroll
@@ -453,7 +456,9 @@ __global__ __launch_bounds__(256) void k_reduce_stats_slice(const int32_t *__res
     for (int k = 0; k < 9; ++k) s.a[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.b[k] = 0;
-    for (int64_t t = a + threadIdx.x; t < b; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fields, prims, cst);
+    FieldStatView fv = {};
+    if (fields) fv.load(fields, cst, pth);
+    for (int64_t t = a + threadIdx.x; t < b; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -508,7 +513,9 @@ __global__ __launch_bounds__(256) void k_reduce_stats_wg(int64_t n_list, const i
     for (int k = 0; k < 9; ++k) s.a[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.b[k] = 0;
-    for (int64_t t = tile_first[pth] + threadIdx.x; t < tile_first[pth + 1]; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fields, prims, cst);
+    FieldStatView fv = {};
+    if (fields) fv.load(fields, cst, pth);
+    for (int64_t t = tile_first[pth] + threadIdx.x; t < tile_first[pth + 1]; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll

@@ -331,7 +331,22 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
 
 // length / time statistics of one quiet run in closed form (count x step; a span: per pass the line's steps and the turn shape's own
 // totals).  The flag counts of the run's points are not part of it (k_plan_quiet counts them while storing).
-__device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, const DevTile &tl, const DevField *__restrict__ fields,
+// what the closed-form run statistics need of a field: fetched by the reduction as soon as it knows its path (the field IS the path),
+// beside the entry lists -- through the tile record it would be one more dependent round trip per entry
+struct FieldStatView {
+    int n_line, n_turn, reverse_order;
+    double line_step;
+    int64_t n_main;
+    double2 junc;
+    __device__ __forceinline__ void load(const DevField *__restrict__ fields, const DevConst &cst, int64_t field)
+    {
+        const DevField &q = fields[field];
+        n_line = q.n_line; n_turn = q.n_turn; reverse_order = q.reverse_order; line_step = q.line_step; n_main = q.n_main;
+        junc = cst.field_junc ? cst.field_junc[field] : make_double2(0.0, 0.0);
+    }
+};
+
+__device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, const DevTile &tl, const FieldStatView &q,
                                                          const DevPrim *__restrict__ prims, const DevConst &cst)
 {
     TilePartial tp;
@@ -341,12 +356,11 @@ __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, cons
     if (tl.quiet == 4) {
         // a span of whole passes: per pass the line's n_line - 1 steps and the turn shape's own totals (the turn's first segment has
         // length 0: it starts on the line's end); every pass but the path's first starts with the jump from the previous turn
-        const DevField &q = fields[tl.field];
         const int v = q.reverse_order ? 1 : 0;
         const int per = q.n_line + q.n_turn;
         const double n_pass = (double)(run.count / per), n_jump = n_pass - (tl.idx0 == 0 ? 1.0 : 0.0);
         const double line_len = (double)(q.n_line - 1) * fabs(q.line_step);
-        const double2 junc = cst.field_junc[tl.field];
+        const double2 junc = q.junc;
         const double jl = n_jump > 0.0 ? junc.y : 0.0, k0 = n_jump > 0.0 ? junc.x : 0.0;
         tp.main_len = n_pass * (line_len + cst.turn_len) + n_jump * jl;
         tp.main_time_pre = tp.main_time = n_pass * (line_len / fmax(cst.ms_work, 0.1) + cst.turn_time) +
@@ -355,19 +369,19 @@ __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, cons
         tp.max_alat = fmax(cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v], cst.ms_work * cst.ms_work * k0);
         tp.max_jump = fmax(cst.turn_max_jump[v], n_jump > 0.0 ? fmax(fabs(k0 - cst.turn_kappa_last[v]), k0) : 0.0);
     } else     if (tl.quiet == 3) {            // a whole U-turn: the shape's own totals (its first segment has length 0: the turn starts on the line's end)
-        const int v = fields[tl.field].reverse_order ? 1 : 0;
+        const int v = q.reverse_order ? 1 : 0;
         tp.main_len = cst.turn_len; tp.main_time_pre = tp.main_time = cst.turn_time;
         tp.max_kappa = cst.turn_max_kappa[v]; tp.max_alat = cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v];
         tp.max_jump = cst.turn_max_jump[v];
     } else {
         double step_len, msnom;
         int layer;
-        if (tl.quiet == 1) { step_len = fabs(fields[tl.field].line_step); msnom = cst.ms_work; layer = 0; }
+        if (tl.quiet == 1) { step_len = fabs(q.line_step); msnom = cst.ms_work; layer = 0; }
         else {
             const DevPrim &p = prims[tl.idx0];
             const double sx = p.a[4], sy = p.a[5];
             step_len = (sy == 0.0) ? fabs(sx) : ((sx == 0.0) ? fabs(sy) : sqrt(sx * sx + sy * sy));
-            msnom = nominal_ms(p.fs, cst); layer = tl.start >= fields[tl.field].n_main ? 1 : 0;      // (a straight of layer 1: obstacle-aware swaths)
+            msnom = nominal_ms(p.fs, cst); layer = tl.start >= q.n_main ? 1 : 0;      // (a straight of layer 1: obstacle-aware swaths)
         }
         // one segment of one step per point: a run's first segment comes from its left neighbour on the same straight -- unless the
         // run starts the line (off0 = 0, swath lines between quiet U-turns): then it is the jump from the previous turn's end, or
@@ -375,8 +389,7 @@ __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, cons
         const bool at_line_start = tl.quiet == 1 && tl.off0 == 0;
         double len = (double)(at_line_start ? run.count - 1 : run.count) * step_len, t = len / fmax(msnom, 0.1);
         if (at_line_start && tl.idx0 > 0) {
-            const DevField &q = fields[tl.field];
-            const double k0 = cst.field_junc[tl.field].x, jl = cst.field_junc[tl.field].y;
+            const double k0 = q.junc.x, jl = q.junc.y;
             len += jl;
             t += jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1);        // MLP:1305-1309: mean of the two end speeds
             tp.max_kappa = k0; tp.max_alat = cst.ms_work * cst.ms_work * k0;
