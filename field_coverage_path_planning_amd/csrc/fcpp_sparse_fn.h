@@ -37,6 +37,25 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     // geofence are fetched side by side, not one after the other.
     double px = 0.0, py = 0.0;
     uint32_t fw = 0;
+    // layer 2: primitive and sample index from the record's lane thresholds.  The primitive record is read WHOLE (read field by field
+    // inside the branches of eval_prim every primitive kind present in the wave paid a round trip of its own: phase stamps showed 36 %
+    // of a wave's life there) and the corner template's sample is asked for beside it; both are requested BEFORE the layer-1 lanes of
+    // a seam tile are evaluated, whose own chain of loads (field constants, turn template) then runs beside them.
+    const bool in_l2 = act && !in_main;
+    int r = 0;
+    DevPrim p;
+    double2 tc = make_double2(0.0, 0.0);
+    if (in_l2) {
+        int pi = wt.p0;
+        r = lane + wt.r0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int th = wt.thr[k];
+            if (lane >= th) { ++pi; r = lane - th; }
+        }
+        tc = cst.tmpl_c[min(max(r, 0), cst.tmpl_nc - 1)];
+        p = prims[pi];
+    }
     if (__ballot(act && in_main) != 0ull) {                  // (wave-uniform) layer 1: (pass, offset) from the host's decode of lane 0
         if (act && in_main) {
             const unsigned per = (unsigned)(f.n_line + f.n_turn);
@@ -44,20 +63,9 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
             eval_main(f, cst, wt.idx0 + (int)q, (int)(off - q * per), px, py, fw);
         }
     }
-    if (act && !in_main) {                                   // layer 2: primitive and sample index from the record's lane thresholds
-        int pi = wt.p0, r = lane + wt.r0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int th = wt.thr[k];
-            if (lane >= th) { ++pi; r = lane - th; }
-        }
-        // The corner template's sample is asked for BESIDE the primitive record, not after it (inside the corner branch its latency
-        // would be paid in full, one dependent round trip more: phase stamps showed 36 % of a wave's life in eval_prim).  The empty
-        // asm needs both values, so both loads are in flight before either is waited for.
-        double2 tc = cst.tmpl_c[min(max(r, 0), cst.tmpl_nc - 1)];
-        const DevPrim p = prims[pi];                    // the whole record at once: read field by field inside the branches of
-        int kind = p.kind;                              // eval_prim, every primitive kind present in the wave paid a round trip of its own
-        asm volatile("" : "+v"(tc.x), "+v"(tc.y), "+v"(kind));
+    if (in_l2) {
+        int kind = p.kind;
+        asm volatile("" : "+v"(tc.x), "+v"(tc.y), "+v"(kind));     // (needs both values: neither load may be sunk behind the other's wait)
         eval_prim(p, cst, r, px, py, &tc);
         fw = p.fs;
     }
