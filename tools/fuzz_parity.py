@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--seconds', type=float, default=180.0)
 ap.add_argument('--seed', type=int, default=1)
 ap.add_argument('--mode', type=int, default=1, help='1 = fused pipeline, 0 = staged pipeline')
+ap.add_argument('--avoid', action='store_true', help='obstacle-aware swaths (every batch has obstacles; layouts the mode refuses must be refused by both)')
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 t0, rounds, fields, fails = time.time(), 0, 0, 0
@@ -25,11 +26,13 @@ VEHS = [T.DEFAULT_VP, [4.0, 5.0, 9.0, 20.0, 3.0, 2.5, 3.0, 0.8], [2.4, 6.0, 12.0
 while time.time() - t0 < a.seconds:
     seed = int(rng.integers(1, 1 << 30))
     n = int(rng.integers(3, 24))
-    para, obst = bool(rng.integers(0, 2)), bool(rng.integers(0, 3) == 0)
+    para, obst = bool(rng.integers(0, 2)), a.avoid or bool(rng.integers(0, 3) == 0)
     specs, ofs = T._random_fields(seed, n, para=para, with_obstacles=obst)
     tm = int(rng.integers(0, 2))
     sp = float(rng.choice([0.0, 0.0, 2.0, 1.0, 0.7, 0.5, 0.4, 0.33, 0.27, 0.25, 0.22, 0.2, 0.15, 0.1]))
     opt = dict(turn_model=tm, sample_spacing=sp)
+    if a.avoid:
+        opt['avoid_obstacles'] = True
     if tm:
         opt['clothoid_frac'] = float(rng.choice([0.0, 0.3, 0.5, 1.0]))
     veh = VEHS[int(rng.integers(0, len(VEHS)))]
