@@ -69,7 +69,10 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
         eval_prim(p, cst, r, px, py, &tc);
         fw = p.fs;
     }
-    const double vn = nominal_speed(fw, cst), msn = nominal_ms(fw, cst);
+    // nominal speed: layer 1 by kind (swath / U-turn), layer 2 from the primitive record (the host sets it by the same table as
+    // nominal_speed()); in m/s by the exact reciprocal division, i.e. the tabulated v / 3.6 bit for bit
+    const double vn = in_l2 ? p.v_nom : (((fw & FCPP_KIND_MASK) == FCPP_KIND_SWATH) ? cst.v_work : cst.v_turn);
+    const double msn = div36(vn);
 
     // ---- 2. chords, curvature (MLP:513-536), clamp (MLP:490-504) ----------------------------------------------------------------
     const double xm = lane_prev(px), ym = lane_prev(py), xp = lane_next(px), yp = lane_next(py);
