@@ -917,7 +917,8 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // tiles that walk long halos, cfg3: 5873 points in 0.37 ms): beside the HBM-bound streaming kernel they cost nothing (cfg3
         // 0.87 -> 0.51 ms).  Not when the general kernel can fill the chip itself -- side by side it takes compute units from the
         // streaming kernel (cfg2 at 0.1 m, 5950 general tiles: 6.5 vs 5.6 ms) -- and not at sparse sampling: k_plan_sparse and the
-        // span kernel get in each other's way (cfg5 2.41 vs 2.29 ms, cfg1 x 4096 0.114 vs 0.098 ms, also with the span kernel held to four or five
+        // span kernel get in each other's way (cfg5 2.41 vs 2.29 ms, cfg1 x 4096 0.114 vs 0.098 ms; measured again with the final kernels: 2.46 vs 2.40
+        // and 0.091 vs 0.085 ms, k_plan_sparse 1.07 instead of 0.69 ms; also with the span kernel held to four or five
         // waves per SIMD).
         hipStream_t sd = st;
         const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_general <= tune_int("FCPP_TWO_STREAM_MAX", 512) &&
@@ -938,7 +939,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // (four classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
         // time the first launch)
         {
-            const int groups[4] = { 8, 64, 256, 256 };
+            const int groups[4] = { 8, 64, 256, 256 };     // (16 or 32 lanes for the first class: 49 -> 53 / 79 us on cfg5)
             const int32_t *pl = t.red_paths.p;
             bool first = true;
             for (int c = 0; c < 4; ++c) {

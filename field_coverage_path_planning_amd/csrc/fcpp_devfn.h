@@ -236,12 +236,11 @@ __device__ __forceinline__ void tile_scan(TileScanShared &S, int count, double c
 
 __device__ __forceinline__ double nominal_speed(uint32_t fs, const DevConst &c)
 {
-    switch (fs & FCPP_KIND_MASK) {
-        case FCPP_KIND_SWATH: return c.v_work;
-        case FCPP_KIND_UTURN: case FCPP_KIND_CORNER: case FCPP_KIND_DETOUR: return c.v_turn;
-        case FCPP_KIND_REVERSE: return 2.5;
-        default: return c.v_head;
-    }
+    const uint32_t k = fs & FCPP_KIND_MASK;         // (selects: see nominal_ms)
+    double r = c.v_head;
+    r = (k == FCPP_KIND_REVERSE) ? 2.5 : r;
+    r = (k == FCPP_KIND_UTURN || k == FCPP_KIND_CORNER || k == FCPP_KIND_DETOUR) ? c.v_turn : r;
+    return (k == FCPP_KIND_SWATH) ? c.v_work : r;
 }
 
 // out-of-line copy of atan2_fd (fcpp_geom.h) for the eight-points-per-lane kernel's halo code: only turn points reach it, and keeping
@@ -250,12 +249,12 @@ __device__ __noinline__ double atan2_slow(double y, double x) { return atan2_fd(
 
 __device__ __forceinline__ double nominal_ms(uint32_t fs, const DevConst &c)
 {
-    switch (fs & FCPP_KIND_MASK) {
-        case FCPP_KIND_SWATH: return c.ms_work;
-        case FCPP_KIND_UTURN: case FCPP_KIND_CORNER: case FCPP_KIND_DETOUR: return c.ms_turn;
-        case FCPP_KIND_REVERSE: return c.ms_rev;
-        default: return c.ms_head;
-    }
+    // (selects, not a switch: the compiler turns a switch over run-time values into a five-entry table in scratch memory)
+    const uint32_t k = fs & FCPP_KIND_MASK;
+    double r = c.ms_head;
+    r = (k == FCPP_KIND_REVERSE) ? c.ms_rev : r;
+    r = (k == FCPP_KIND_UTURN || k == FCPP_KIND_CORNER || k == FCPP_KIND_DETOUR) ? c.ms_turn : r;
+    return (k == FCPP_KIND_SWATH) ? c.ms_work : r;
 }
 
 }  // namespace fcpp

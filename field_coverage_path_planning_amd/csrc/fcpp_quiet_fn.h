@@ -356,7 +356,10 @@ __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, cons
     if (tl.quiet == 4) {
         // a span of whole passes: per pass the line's n_line - 1 steps and the turn shape's own totals (the turn's first segment has
         // length 0: it starts on the line's end); every pass but the path's first starts with the jump from the previous turn
-        const int v = q.reverse_order ? 1 : 0;
+        // (per-lane selects: a per-lane index into the kernel-argument arrays would copy them to scratch memory)
+        const bool rv = q.reverse_order != 0;
+        const double tmk = rv ? cst.turn_max_kappa[1] : cst.turn_max_kappa[0], tmj = rv ? cst.turn_max_jump[1] : cst.turn_max_jump[0];
+        const double tkl = rv ? cst.turn_kappa_last[1] : cst.turn_kappa_last[0];
         const int per = q.n_line + q.n_turn;
         const double n_pass = (double)(run.count / per), n_jump = n_pass - (tl.idx0 == 0 ? 1.0 : 0.0);
         const double line_len = (double)(q.n_line - 1) * fabs(q.line_step);
@@ -365,14 +368,15 @@ __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, cons
         tp.main_len = n_pass * (line_len + cst.turn_len) + n_jump * jl;
         tp.main_time_pre = tp.main_time = n_pass * (line_len / fmax(cst.ms_work, 0.1) + cst.turn_time) +
                                           n_jump * (jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1));     // MLP:1305-1309
-        tp.max_kappa = fmax(cst.turn_max_kappa[v], k0);
-        tp.max_alat = fmax(cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v], cst.ms_work * cst.ms_work * k0);
-        tp.max_jump = fmax(cst.turn_max_jump[v], n_jump > 0.0 ? fmax(fabs(k0 - cst.turn_kappa_last[v]), k0) : 0.0);
+        tp.max_kappa = fmax(tmk, k0);
+        tp.max_alat = fmax(cst.ms_turn * cst.ms_turn * tmk, cst.ms_work * cst.ms_work * k0);
+        tp.max_jump = fmax(tmj, n_jump > 0.0 ? fmax(fabs(k0 - tkl), k0) : 0.0);
     } else     if (tl.quiet == 3) {            // a whole U-turn: the shape's own totals (its first segment has length 0: the turn starts on the line's end)
-        const int v = q.reverse_order ? 1 : 0;
+        const bool rv = q.reverse_order != 0;
+        const double tmk = rv ? cst.turn_max_kappa[1] : cst.turn_max_kappa[0];
         tp.main_len = cst.turn_len; tp.main_time_pre = tp.main_time = cst.turn_time;
-        tp.max_kappa = cst.turn_max_kappa[v]; tp.max_alat = cst.ms_turn * cst.ms_turn * cst.turn_max_kappa[v];
-        tp.max_jump = cst.turn_max_jump[v];
+        tp.max_kappa = tmk; tp.max_alat = cst.ms_turn * cst.ms_turn * tmk;
+        tp.max_jump = rv ? cst.turn_max_jump[1] : cst.turn_max_jump[0];
     } else {
         double step_len, msnom;
         int layer;
@@ -393,7 +397,7 @@ __device__ __forceinline__ TilePartial quiet_run_partial(const DevRun &run, cons
             len += jl;
             t += jl / fmax(((cst.v_turn + cst.v_work) / 2) / 3.6, 0.1);        // MLP:1305-1309: mean of the two end speeds
             tp.max_kappa = k0; tp.max_alat = cst.ms_work * cst.ms_work * k0;
-            tp.max_jump = fmax(fabs(k0 - cst.turn_kappa_last[q.reverse_order ? 1 : 0]), k0);
+            tp.max_jump = fmax(fabs(k0 - (q.reverse_order ? cst.turn_kappa_last[1] : cst.turn_kappa_last[0])), k0);
         }
         tp.main_len = layer ? 0.0 : len; tp.main_time_pre = layer ? 0.0 : t; tp.main_time = layer ? 0.0 : t;
         tp.head_len = layer ? len : 0.0; tp.head_time_pre = layer ? t : 0.0; tp.head_time = layer ? t : 0.0;
