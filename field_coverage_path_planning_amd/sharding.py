@@ -171,3 +171,58 @@ def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1
         per_rank = [int(sum(counts[a:b])) for a, b in blocks]
         points_all = gather_arrays([_comm_tensor(a) for a in arrays], per_rank, dst=0)
     return ShardedResult((lo, hi), local, stats_all, infos, blocks, points_all, batch)
+
+
+def partition_even(n_items, world_size):
+    """Contiguous blocks [lo, hi) of n_items equal-cost items (GA chromosomes), one per rank, in rank order; the first
+    n_items % world_size ranks get one item more."""
+    if world_size <= 0:
+        raise ValueError('world_size must be positive')
+    q, r = divmod(int(n_items), world_size)
+    cuts = [0]
+    for k in range(world_size):
+        cuts.append(cuts[-1] + q + (1 if k < r else 0))
+    return [(cuts[k], cuts[k + 1]) for k in range(world_size)]
+
+
+def ga_fitness_sharded(routes, D, order_mode=0, device=None, compute=None, with_distance=False):
+    """Evaluate a GA population across the ranks ("shard population across GPUs, all-gather 8 B fitness per
+    chromosome"; GA:168-181).  Every rank holds the same `routes` (pop, n) and D (n, n) -- the population of a generation is
+    produced from the same counter-based draws on every rank --, evaluates its contiguous block of chromosomes with
+    fcpp_ga_fitness, and the blocks are all-gathered, so every rank returns the fitness of the WHOLE population (what selection
+    needs next), identical to one process evaluating it: a chromosome's tour is summed by one wavefront in a fixed order wherever
+    it is evaluated.  with_distance: also all-gather the tour lengths (another 8 B per chromosome).
+    -> fitness (pop,) float64 tensor [, distance (pop,) float64 tensor]
+
+    compute(routes_block, D, order_mode) -> (distance, fitness) 1-D float64 tensors replaces the GPU call in the CPU (gloo) tests."""
+    import torch
+    dist = _dist()
+    rank, ws = world()
+    r = routes if isinstance(routes, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(routes, dtype=np.int32))
+    n = int(D.shape[0])
+    r = r.reshape(-1, n)
+    pop = int(r.shape[0])
+    blocks = partition_even(pop, ws)
+    lo, hi = blocks[rank]
+    if compute is not None:
+        d_loc, f_loc = compute(r[lo:hi], D, order_mode)
+    elif hi > lo:
+        d_loc, f_loc = E.ga_fitness(r[lo:hi], D, order_mode, device=device)
+    else:
+        dev = torch.device('cuda', device if device is not None else torch.cuda.current_device())
+        d_loc = f_loc = torch.empty(0, dtype=torch.float64, device=dev)
+    if ws == 1:
+        return (f_loc, d_loc) if with_distance else f_loc
+    # one all-gather of equal-sized blocks (the last ranks' blocks padded by at most one element): a single collective whatever the
+    # population size, [fitness | distance] side by side when both are asked for
+    width = blocks[0][1] - blocks[0][0]
+    cols = 2 if with_distance else 1
+    send = torch.zeros((cols, width), dtype=torch.float64, device=f_loc.device)
+    send[0, :hi - lo] = f_loc
+    if with_distance:
+        send[1, :hi - lo] = d_loc
+    send = _comm_tensor(send)
+    recv = [torch.empty_like(send) for _ in range(ws)]
+    dist.all_gather(recv, send)
+    out = [torch.cat([recv[k][c, :blocks[k][1] - blocks[k][0]] for k in range(ws)]).to(f_loc.device) for c in range(cols)]
+    return (out[0], out[1]) if with_distance else out[0]

@@ -72,3 +72,27 @@ def test_stats_and_points_identical_for_1_2_4_8_shards():
                 assert np.array_equal(np.concatenate(arrays[k]), ref_arrays[k]), (world, k)
         whole.close()
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('world,pop,n', [(2, 4096, 128), (3, 1001, 129)])
+def test_ga_population_sharded_on_the_gpu(tmp_path, world, pop, n):
+    """SURVEY.md 8e, GA: the population cut into contiguous blocks over the ranks, fcpp_ga_fitness per block, one all-gather of the
+    fitness (and tour lengths): every rank ends with the whole population's values, byte-identical to one process and to the oracle
+    (cfg4's size; and blocks of unequal length with tours longer than two wavefront passes)."""
+    out = str(tmp_path / 'ga')
+    port = 35500 + (os.getpid() % 2000) + world
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', '_shard_ga_gpu_worker.py'), str(r), str(world), str(port),
+                               str(pop), str(n), out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode(errors='replace') for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(logs)
+
+    import oracle as orc
+    from field_coverage_path_planning_amd import engine as E, workloads as WL
+    D, routes = WL.cfg4_ga(n, pop)
+    dist1, fit1 = E.ga_fitness(routes, D)
+    f_orc, d_orc = orc.ga_fitness(routes, D), orc.ga_distance(routes, D)
+    assert np.array_equal(fit1.cpu().numpy(), f_orc) and np.array_equal(dist1.cpu().numpy(), d_orc)
+    for r in range(world):
+        got = np.load(f'{out}.{r}.npz')
+        assert np.array_equal(got['fit'], f_orc) and np.array_equal(got['dist'], d_orc), r

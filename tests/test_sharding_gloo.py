@@ -148,3 +148,60 @@ def test_plan_count_feeds_the_partition():
     blocks = partition_by_points(counts, 8)
     loads = [sum(counts[lo:hi]) for lo, hi in blocks]
     assert max(loads) / (sum(counts) / 8) < 1.25
+
+
+def _oracle_ga_compute(routes_block, D, order_mode):
+    import oracle as orc
+    r = routes_block.numpy().astype(np.int32)
+    Dn = D.numpy() if isinstance(D, torch.Tensor) else np.asarray(D)
+    if len(r) == 0:
+        z = torch.zeros(0, dtype=torch.float64)
+        return z, z
+    return torch.from_numpy(orc.ga_distance(r, Dn)), torch.from_numpy(orc.ga_fitness(r, Dn))
+
+
+def _ga_case(pop, n=17, seed=4096):
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(0, 1000, size=(n, 2))
+    D = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    routes = np.stack([rng.permutation(n) for _ in range(pop)]).astype(np.int32)
+    return torch.from_numpy(D), torch.from_numpy(routes)
+
+
+def _worker_ga(rank, world_size, port, pop, out_path):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    from field_coverage_path_planning_amd import sharding as S
+    D, routes = _ga_case(pop)
+    fit, dst = S.ga_fitness_sharded(routes, D, compute=_oracle_ga_compute, with_distance=True)
+    only = S.ga_fitness_sharded(routes, D, compute=_oracle_ga_compute)
+    assert fit.shape == (pop,) and torch.equal(only, fit)           # every rank holds the whole population's fitness
+    np.savez(out_path + f'.{rank}.npz', fit=fit.numpy(), dist=dst.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world_size,pop', [(2, 37), (3, 64), (4, 3)])
+def test_ga_population_sharded_equals_single_process(tmp_path, world_size, pop):
+    """SURVEY.md 8e, GA: the population is cut into contiguous blocks, each rank evaluates its own, one all-gather of 8 B per
+    chromosome (16 with the tour lengths) leaves the whole population's fitness on EVERY rank, byte-identical to one process; block
+    sizes that differ by one (37 over 2, 64 over 3) and empty blocks (3 over 4)."""
+    out = str(tmp_path / 'ga')
+    port = 27500 + (os.getpid() % 2000) + world_size
+    mp.spawn(_worker_ga, args=(world_size, port, pop, out), nprocs=world_size, join=True)
+    D, routes = _ga_case(pop)
+    d_ref, f_ref = _oracle_ga_compute(routes, D, 0)
+    for rank in range(world_size):
+        got = np.load(out + f'.{rank}.npz')
+        assert np.array_equal(got['fit'], f_ref.numpy()) and np.array_equal(got['dist'], d_ref.numpy()), rank
+
+
+def test_partition_even_properties():
+    from field_coverage_path_planning_amd.sharding import partition_even
+    for n in (0, 1, 3, 37, 4096):
+        for ws in (1, 2, 3, 4, 8):
+            b = partition_even(n, ws)
+            assert len(b) == ws and b[0][0] == 0 and b[-1][1] == n and all(b[k][1] == b[k + 1][0] for k in range(ws - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
