@@ -111,9 +111,13 @@ void rotate_point(double x, double y, double ca, double sa, double cx, double cy
     ox = xn + cx; oy = yn + cy;
 }
 
+// (saturates at 2^40 points -- far beyond any size check of the callers -- instead of converting an out-of-range double)
+constexpr int64_t kCountCap = (int64_t)1 << 40;
 int64_t n_for_length(double len, double ds)
 {
-    int64_t n = (int64_t)ceil(len / ds) + 1;
+    const double c = ceil(len / ds);
+    if (!(c < (double)kCountCap)) return kCountCap;
+    int64_t n = (int64_t)c + 1;
     return n < 2 ? 2 : n;
 }
 
@@ -148,6 +152,14 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
     if (!(veh.max_longitudinal_accel > 0) || !(veh.max_lateral_accel > 0)) {
         err = "accelerations must be positive";
         return FCPP_EINVAL;
+    }
+    {   // every parameter a finite number (a NaN passes none of the comparisons above, an infinity or a denormal width all of them)
+        const double vals[] = { veh.working_width, veh.min_turn_radius, veh.max_work_speed_kmh, veh.max_headland_speed_kmh,
+                                veh.headland_turn_speed_kmh, veh.max_lateral_accel, veh.max_longitudinal_accel, veh.safety_factor,
+                                opt.sample_spacing, opt.clothoid_frac, opt.geofence_tol };
+        for (double v : vals)
+            if (!isfinite(v)) { err = "vehicle parameters and options must be finite"; return FCPP_EINVAL; }
+        if (W < 1e-6 || R < 1e-6 || (ds > 0 && ds < 1e-9)) { err = "working width, turn radius or sample spacing too small"; return FCPP_EINVAL; }
     }
     const bool cloth = opt.turn_model == FCPP_TURN_CLOTHOID;
     CacShape sh_pi = make_cac_shape(kPi, opt.clothoid_frac), sh_half = make_cac_shape(kHalfPi, opt.clothoid_frac);
@@ -257,10 +269,12 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
 
         // ---- layer 1 sizes (MLP:736-739)
         const double lsx = min_x + R, lex = max_x - R;
-        const int64_t P = (int64_t)((max_y - min_y) / W) + 1;
+        const double Pd = (max_y - min_y) / W;          // int(height / W) + 1 (MLP:739); refused below when beyond 32 bits
+        const int64_t P = Pd < (double)INT32_MAX ? (int64_t)Pd + 1 : (int64_t)INT32_MAX + 1;
         const int64_t n_line = ds > 0 ? n_for_length(fabs(lex - lsx), ds) : 2;
         const int64_t n_turn = ds > 0 ? n_for_length(len_uturn, ds) : 20;
-        if (P > INT32_MAX || n_line + n_turn > INT32_MAX - 2 * TILE_POINTS) { fail(FCPP_ESIZE); continue; }
+        // (the swath index lives in bits 8..31 of the flag / segment word)
+        if (P >= ((int64_t)1 << (32 - FCPP_INDEX_SHIFT)) || n_line + n_turn > INT32_MAX - 2 * TILE_POINTS) { fail(FCPP_ESIZE); continue; }
         in.n_swaths = (int32_t)P;
         int64_t n_main = P * n_line + (P - 1) * n_turn;
         df.gen_main = n_main;
@@ -474,6 +488,14 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
                 df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
             }
             out.fields.push_back(df);
+        }
+        if (pos > kCountCap || pt_off > kCountCap) {          // (2^40 points = 40 TB of output: no batch gets there)
+            err = "batch too large";
+            return FCPP_ESIZE;
+        }
+        if (out.prims.size() > ((size_t)1 << 26)) {           // (primitive indices are 32-bit; 2^26 records are 7 GB of host memory)
+            err = "too many path primitives in one batch (obstacle-aware swaths of very large fields): split the batch";
+            return FCPP_ESIZE;
         }
         pt_off += pos;
     }

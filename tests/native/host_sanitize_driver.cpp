@@ -1,0 +1,110 @@
+// Host-side planner under AddressSanitizer + UndefinedBehaviorSanitizer (tests/test_host_sanitizers.py builds and runs this on the
+// CPU; the GPU pool has no sanitizer runs).  fcpp_host.cpp -- everything fcpp_plan_count and fcpp_batch_create decide on the host:
+// shapes, corners, pass order, swath counts, headland primitives, reverse fills, obstacle-aware sub-swaths and detours -- is driven
+// with random and hostile inputs: degenerate and concave quadrilaterals, tiny and huge fields, NaN / infinite coordinates, start and end
+// points anywhere, obstacle tables with empty, tiny and overlapping polygons, every option combination.  Any status is fine; a
+// sanitizer report (or a crash) fails the test.  Prints one line: fields planned, fields refused, a checksum of the decisions.
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <chrono>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../field_coverage_path_planning_amd/csrc/fcpp_internal.h"
+
+int main(int argc, char **argv)
+{
+    const uint64_t seed = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 300;
+    std::mt19937_64 rng(seed);
+    auto U = [&](double a, double b) { return a + (b - a) * (double)(rng() >> 11) * (1.0 / 9007199254740992.0); };
+    auto pick = [&](int n) { return (int)(rng() % (uint64_t)n); };
+    const double weird[] = { 0.0, -0.0, 1e-300, 1e-9, 1e9, 1e300, NAN, INFINITY, -INFINITY };
+    int64_t planned = 0, refused = 0, failed_calls = 0;
+    uint64_t sum = 0;
+    for (int round = 0; round < rounds; ++round) {
+        fcpp_vehicle veh = { 3.2, 8.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85 };
+        if (pick(3) == 0) { veh.working_width = U(0.5, 12.0); veh.min_turn_radius = U(1.0, 20.0); veh.max_longitudinal_accel = U(0.05, 3.0); }
+        if (pick(25) == 0) veh.working_width = weird[pick(9)];
+        if (pick(25) == 0) veh.min_turn_radius = weird[pick(9)];
+        fcpp_options opt = { pick(2), pick(2), 0.0, U(0.0, 1.0), 1e-6, pick(2), 0 };
+        const int sp = pick(4);
+        opt.sample_spacing = sp == 0 ? 0.0 : (sp == 1 ? U(0.2, 3.0) : (sp == 2 ? 0.5 : U(0.05, 0.2)));
+        if (pick(30) == 0) opt.sample_spacing = weird[pick(9)];
+        if (pick(30) == 0) opt.clothoid_frac = weird[pick(9)];
+        const int n = pick(7);
+        std::vector<fcpp_field> fields((size_t)n);
+        std::vector<int64_t> offsets(1, 0);
+        std::vector<double> px, py;
+        for (int i = 0; i < n; ++i) {
+            fcpp_field f = {};
+            const double L = pick(20) == 0 ? U(1.0, 40.0) : U(60.0, 900.0), H = pick(20) == 0 ? U(1.0, 40.0) : U(60.0, 600.0);
+            const int kind = pick(10);
+            if (kind < 4) {                      // field_length / field_width
+                f.vx[1] = L; f.vx[2] = L; f.vy[2] = H; f.vy[3] = H;
+            } else if (kind < 8) {               // rotated parallelogram
+                const double ang = U(1.0, 2.1), rot = U(-0.8, 0.8), sx = H / tan(ang);
+                const double qx[4] = { 0, L, L + sx, sx }, qy[4] = { 0, 0, H, H };
+                for (int k = 0; k < 4; ++k) { f.vx[k] = qx[k] * cos(rot) - qy[k] * sin(rot); f.vy[k] = qx[k] * sin(rot) + qy[k] * cos(rot); }
+                f.from_vertices = 1;
+            } else {                             // anything: concave, self-crossing, collapsed, non-finite
+                for (int k = 0; k < 4; ++k) { f.vx[k] = U(-300, 300); f.vy[k] = U(-300, 300); }
+                if (pick(3) == 0) { const int w = pick(9); f.vx[pick(4)] = w == 4 ? 3e4 : weird[w]; }     // (1e9 m of field is hours of planning)
+                if (pick(4) == 0) { f.vx[1] = f.vx[0]; f.vy[1] = f.vy[0]; }
+                f.from_vertices = 1;
+            }
+            f.has_start = pick(2); f.has_end = pick(2);
+            f.start_x = U(-50, L + 50); f.start_y = U(-50, H + 50); f.end_x = U(-50, L + 50); f.end_y = U(-50, H + 50);
+            if (pick(20) == 0) f.start_x = weird[pick(9)];
+            if (pick(20) == 0) f.end_y = weird[pick(9)];
+            f.obstacle_first = (int64_t)offsets.size() - 1;
+            f.n_obstacles = pick(3) == 0 ? pick(5) : 0;
+            for (int o = 0; o < f.n_obstacles; ++o) {
+                const int nv = pick(12) == 0 ? pick(3) : 3 + pick(6);       // sometimes fewer than three vertices
+                const double cx = U(0, L), cy = U(0, H), r = pick(8) == 0 ? U(1e-9, 0.5) : U(2.0, 40.0);
+                for (int k = 0; k < nv; ++k) {
+                    const double a = 6.283185307179586 * k / (nv > 0 ? nv : 1);
+                    px.push_back(cx + r * cos(a)); py.push_back(cy + r * sin(a));
+                }
+                if (nv > 0 && pick(40) == 0) px.back() = weird[pick(9)];
+                offsets.push_back((int64_t)px.size());
+            }
+            fields[(size_t)i] = f;
+        }
+        fcpp_polys polys = { (int64_t)offsets.size() - 1, offsets.data(), px.data(), py.data() };
+        for (int want_device = 0; want_device < 2; ++want_device) {
+            fcpp::HostPlan hp;
+            std::string err;
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = fcpp::build_host_plan(veh, opt, n, fields.data(), (polys.n_polys > 0 || pick(2)) ? &polys : nullptr, want_device != 0,
+                                                 hp, err);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (sec > 2.0)
+                fprintf(stderr, "slow call: %.1f s, round %d, n %d, W %g R %g ds %g mode %d/%d, rc %d, points %lld, prims %zu\n", sec, round, n,
+                        veh.working_width, veh.min_turn_radius, opt.sample_spacing, opt.turn_model, opt.obstacle_mode, rc,
+                        (long long)hp.total_points, hp.prims.size());
+            if (rc != FCPP_OK) { ++failed_calls; continue; }
+            int64_t expect = 0;
+            for (int i = 0; i < n; ++i) {
+                const fcpp_field_info &q = hp.info[(size_t)i];
+                if (q.point_offset != expect || q.n_main < 0 || q.n_head < 0) { fprintf(stderr, "bad offsets at round %d field %d\n", round, i); return 2; }
+                if (q.status != FCPP_OK && (q.n_main | q.n_head) != 0) { fprintf(stderr, "refused field with points, round %d field %d\n", round, i); return 2; }
+                expect += q.n_main + q.n_head;
+                (q.status == FCPP_OK ? planned : refused) += 1;
+                sum = sum * 1099511628211ull + (uint64_t)(q.n_main * 31 + q.n_head * 7 + q.n_swaths + q.status);
+            }
+            if (hp.total_points != expect) { fprintf(stderr, "total_points mismatch at round %d\n", round); return 2; }
+            if (want_device) {               // the descriptors the tiler and the kernels index with: touch every one
+                for (const auto &f : hp.fields) sum += (uint64_t)f.n_total + (uint64_t)f.prim_count;
+                for (const auto &p : hp.prims) sum += (uint64_t)p.kind + (uint64_t)p.n;
+            }
+        }
+    }
+    printf("planned %lld refused %lld failed_calls %lld checksum %llu\n", (long long)planned, (long long)refused, (long long)failed_calls,
+           (unsigned long long)sum);
+    return 0;
+}
