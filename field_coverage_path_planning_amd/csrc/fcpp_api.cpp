@@ -944,12 +944,14 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
             bool first = true;
             for (int c = 0; c < 4; ++c) {
                 if (t.n_red[c] == 0) continue;
+                // (a class that holds every path lists them in order: no list, one dependent load less in a latency-bound kernel)
+                const int32_t *list = t.n_red[c] == t.n_paths ? nullptr : pl;
                 if (first)
                     STAGE(4, launch_reduce_stats(st, t.n_red[c], t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.stat_run.p, t.tiles.p,
-                                                 b->fields.p, b->prims.p, &b->cst, pl, groups[c], c == 3 ? t.red_scratch.p : nullptr));
+                                                 b->fields.p, b->prims.p, &b->cst, list, groups[c], c == 3 ? t.red_scratch.p : nullptr));
                 else
                     LAUNCHCHK(launch_reduce_stats(st, t.n_red[c], t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.stat_run.p, t.tiles.p,
-                                                  b->fields.p, b->prims.p, &b->cst, pl, groups[c], c == 3 ? t.red_scratch.p : nullptr));
+                                                  b->fields.p, b->prims.p, &b->cst, list, groups[c], c == 3 ? t.red_scratch.p : nullptr));
                 first = false;
                 pl += t.n_red[c];
             }
