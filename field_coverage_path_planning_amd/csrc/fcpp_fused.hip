@@ -845,9 +845,12 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
     const bool staged = cst.tmpl_n > 0 && cst.tmpl_n <= TMPL_LDS, has_obs = obs.offsets != nullptr;
     // Resident waves of the span kernel are held to FOUR per SIMD by its LDS footprint (34 KiB per four-wave workgroup of 160 KiB per
     // CU): measured on identical memory (tools/ab_knob.py) cfg5 1.33 vs 1.44 ms at 5-7 waves and 1.59 ms at 3; the other
-    // configurations do not care (+-1 %).  FCPP_SPAN_LDS / FCPP_QUIET_PAD: bytes, for that tool.
+    // configurations do not care (+-1 %) -- except launches of a few rounds of workgroups, where FIVE per SIMD (27 KiB) end a round
+    // earlier: the headline's 3530 workgroups 31.9 vs 33.2 us, step 0.0819 vs 0.0837 ms; cfg2 at the reference's sampling, 2064
+    // workgroups, the same either way.  FCPP_SPAN_LDS / FCPP_QUIET_PAD: bytes, for that tool.
     const int static_lds = (has_obs ? 4 * 2 * OBS_LDS_VERTS * 8 : 32) + (kinds == 16 && staged ? 4 * 3 * TMPL_LDS * 8 : 32);
-    const int pad = kinds == 16 ? std::max(0, tune_int("FCPP_SPAN_LDS", 34 * 1024) - static_lds) : tune_int("FCPP_QUIET_PAD", 0);
+    const int span_lds = grid.x < 16384u ? 27 * 1024 : 34 * 1024;
+    const int pad = kinds == 16 ? std::max(0, tune_int("FCPP_SPAN_LDS", span_lds) - static_lds) : tune_int("FCPP_QUIET_PAD", 0);
 #define FCPP_QUIET(K, SD, TL, OB) FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
     // Instances: spans fetch their descriptors by scalar loads (SCALAR_DESC: that nearly halved their time in round 1), stage the
     // turn template in LDS when it is the reference's short one (STAGED), and every instance exists with and without the polygon
