@@ -386,6 +386,10 @@ def main():
                            extra_fn=cfg3_extra, budget=6.0, placement=3)
         if 'cfg4' in want:
             configs.append(run_cfg4(E, torch, WL, cpu_on))
+    if world > 1 and 'cfg4' in want:
+        entry = run_cfg4_sharded(E, S, WL, torch, dev, world, fence, allmax)
+        if rank == 0:
+            configs.append(entry)
     if 'cfg5' in want or world > 1:
         entry = run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, max(5, args.steps // 10), cpu_on)
         if rank == 0:
@@ -405,6 +409,30 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_cfg4_sharded(E, S, WL, torch, dev, world, fence, allmax):
+    """cfg4 over the ranks: the population cut into contiguous blocks, fcpp_ga_fitness per block, one all-gather of the
+    fitness (8 B per chromosome) to every rank -- sharding.ga_fitness_sharded; 501 evaluations of the resident population, as
+    fitness_only of the one-GPU entry."""
+    D, routes = WL.cfg4_ga()
+    Dd, rd = torch.as_tensor(D, device=dev), torch.as_tensor(routes, device=dev)
+    fit = None
+    for _ in range(5):
+        fit = S.ga_fitness_sharded(rd, Dd, device=dev.index)
+    same = bool(torch.equal(fit.to(dev), E.ga_fitness(rd, Dd, device=dev.index)[1]))     # every rank holds the whole population's fitness
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(501):
+        S.ga_fitness_sharded(rd, Dd, device=dev.index)
+    fence()
+    dt = allmax(time.perf_counter() - t0)
+    evals = 501 * routes.shape[0]
+    return {'name': 'cfg4_fitness_sharded', 'workload': f'cfg4 population (4096 tours of 128 nodes) evaluated in {world} contiguous blocks, one per rank, '
+            'fitness all-gathered to every rank after each of 501 evaluations (sharding.ga_fitness_sharded)', 'n_gpus': world, 'scaling': 'strong',
+            'ms_501_evaluations': dt * 1e3, 'value': evals / dt, 'unit': 'chromosome evaluations/s', 'dtype': 'f64',
+            'identical_to_one_process': same,
+            'note': 'a collective per 11 us kernel: the figure is the all-gather latency, reported so that the sharded GA path has a measured line'}
 
 
 def run_cfg4(E, torch, WL, cpu_on):
