@@ -376,7 +376,7 @@ struct DevTiling {
     DevBuf<int32_t> stat_ids;      // ... the tiles that can hold statistics (general tiles, first tile of every run), path by path
     DevBuf<int64_t> stat_first;    //     CSR offsets into stat_ids per path
     DevBuf<int64_t> stat_run;      //     per entry of stat_ids: points of the quiet run that starts there (0: not a run)
-    DevBuf<int32_t> red_paths;     //     the paths by their number of entries: [<= 64 | <= 256 | <= 4096 | more] (k_reduce_stats)
+    DevBuf<int32_t> red_paths;     //     the paths by their number of entries: [<= 64 | <= 256 | <= 1024 | more] (k_reduce_stats)
     DevBuf<char> red_scratch;      //     slice results of the paths of the last class (64 x 104 bytes each)
     int64_t n_red[4] = { 0, 0, 0, 0 };
     int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_general = 0, n_wave = 0, quiet_points = 0;
@@ -476,11 +476,13 @@ struct DevTiling {
         if ((e = stat_first.upload(sf, st)) != hipSuccess) return e;
         if ((e = stat_run.upload(srun, st)) != hipSuccess) return e;
         {   // classes of the reduction: by the number of entries of each path (a property of the field alone)
-            // (8 lanes, a wavefront, a workgroup, 64 workgroups per path: at most 8 / 4 / 16 entries per lane in the first three)
+            // (8 lanes, a wavefront, a workgroup, 64 workgroups per path: at most 8 / 4 / 4 entries per lane in the first three)
             std::vector<int32_t> cls[4];
+            // (one workgroup walks up to 1024 entries; beyond that 64 workgroups + a join launch are faster: cfg3, 3900 entries, 21.8 -> 8 us)
+            const int64_t wg_max = tune_int("FCPP_REDUCE_WG_MAX", 1024);
             for (int64_t p = 0; p < n_paths; ++p) {
                 const int64_t ne = sf[(size_t)p + 1] - sf[(size_t)p];
-                cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= 4096 ? 2 : 3))].push_back((int32_t)p);
+                cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= wg_max ? 2 : 3))].push_back((int32_t)p);
             }
             std::vector<int32_t> all;
             for (int c = 0; c < 4; ++c) { n_red[c] = (int64_t)cls[c].size(); all.insert(all.end(), cls[c].begin(), cls[c].end()); }

@@ -195,7 +195,7 @@ int fcpp_batch_stage_points(const fcpp_batch *batch, int mode, int stage, int64_
 /* how the fused pipeline (mode 1) splits the batch: points in closed-form runs and spans (k_plan_quiet) / all other points */
 int fcpp_batch_point_split(const fcpp_batch *batch, int64_t *quiet_points, int64_t *general_points);
 /* how the per-field statistics of the fused pipeline are reduced: paths per class of k_reduce_stats, by statistic entries of a path
- * (<= 64: 8 lanes, <= 256: a wavefront, <= 4096: a workgroup, more: 64 workgroups + join); classes_out[4] */
+ * (<= 64: 8 lanes, <= 256: a wavefront, <= 1024: a workgroup, more: 64 workgroups + join); classes_out[4] */
 int fcpp_batch_reduce_classes(const fcpp_batch *batch, int64_t *classes_out);
 
 /* ---- standalone operators on caller-supplied paths (CSR offsets, n_paths+1, device) -------

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of launch-time tuning knobs on IDENTICAL memory: one process, one batch, one set of output arrays; the knob (an environment
 variable the launchers read at every launch, csrc/fcpp_devfn.h tune_int) is flipped between interleaved groups of runs.
-    ab_knob.py <workload> <stage> [create:]VAR=V1,V2,...        workload: cfg1 | cfg2_ref | cfg2_0.5 | cfg2_0.1 | cfg5
+    ab_knob.py <workload> <stage> [create:]VAR=V1,V2,...        workload: cfg1 | cfg1_dense | cfg2_ref | cfg2_0.5 | cfg2_0.1 | cfg3 | cfg5
 (create:VAR = a knob the tiler reads when the batch is created: one batch per value, same arrays)
 Prints min / median of the stage's per-launch time (HIP events of the dispatch) and of the whole step per value."""
 import os
@@ -25,6 +25,9 @@ elif wl == 'cfg1_dense':
     specs, opt = WL.specs_from_lh(E, WL.cfg1_batch(4096)), E.make_options(1, 0.1)
 elif wl == 'cfg5':
     specs, opt = WL.specs_from_vertices(E, WL.cfg5_parallelograms()), E.make_options()
+elif wl == 'cfg3':
+    (L3, H3), obst = WL.cfg3_field()
+    specs, opt = [E.FieldSpec(field_length=L3, field_width=H3, obstacles=obst)], E.make_options(1, 0.05)
 elif wl.startswith('cfg2'):
     sp = {'cfg2_ref': None, 'cfg2_0.5': 0.5, 'cfg2_0.1': 0.1, 'cfg2_0.25': 0.25, 'cfg2_1.0': 1.0}[wl]
     specs, opt = WL.specs_from_lh(E, WL.cfg2_rectangles()), (E.make_options() if sp is None else E.make_options(1, sp))
