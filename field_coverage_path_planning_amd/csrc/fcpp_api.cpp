@@ -95,6 +95,7 @@ struct Tiling {
         const DevField *df = nullptr;
         const double2 *tu = nullptr, *tc = nullptr;
         double u_cap = 0.0;
+        double fence_margin = 1e-3;   // a point this far inside every edge of the field polygon cannot be flagged by the device's test
         bool wave_ok = false;  // sampling sparse enough for halos of a few lanes
     };
 
@@ -168,6 +169,7 @@ struct Tiling {
     static constexpr int WAVE_LANES = 64;                // fcpp_sparse.hip: one wavefront per wave tile
     mutable int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };   // diagnostics (FCPP_DEBUG_TILING): stretches that did not fit, by reason
     mutable std::vector<double> wave_d;                  // scratch: step lengths of the stretch and its surroundings
+    mutable std::vector<double> wave_x, wave_y;          // scratch: the points themselves (index i - (lo - 1))
     mutable std::vector<DevWaveTile> wtiles;             // the wave tiles' records, in the order of their DevTile entries
     bool wave_tiles(int64_t p, const QuietInfo &q, int64_t a, int64_t b, std::vector<DevTile> &out) const
     {
@@ -179,16 +181,30 @@ struct Tiling {
         if (hi - lo > (int64_t)1 << 22) { ++wave_fail[4]; return false; }
         std::vector<double> &d = wave_d;
         d.resize((size_t)std::max<int64_t>(hi - lo, 0));
+        std::vector<double> &hx = wave_x, &hy = wave_y;
+        hx.resize(d.size() + 1); hy.resize(d.size() + 1);
         {
             double x0, y0, x1, y1;
-            if (hi > lo) host_point(q, lo - 1, x0, y0);
+            if (hi > lo) { host_point(q, lo - 1, x0, y0); hx[0] = x0; hy[0] = y0; }
             for (int64_t i = lo; i < hi; ++i) {
                 host_point(q, i, x1, y1);
                 const double dx = x1 - x0, dy = y1 - y0;
                 d[(size_t)(i - lo)] = sqrt(dx * dx + dy * dy);
+                hx[(size_t)(i - lo + 1)] = x1; hy[(size_t)(i - lo + 1)] = y1;
                 x0 = x1; y0 = y1;
             }
         }
+        // every output point of [s, s + c) well inside the field polygon?  (host and device evaluate a point with the same formulas;
+        // their roundings differ by ~1e-12 m, the margin is a millimetre: the device's test of such a point cannot fire)
+        auto all_inside = [&](int64_t s, int64_t c) -> bool {
+            for (int64_t i = s; i < s + c; ++i) {
+                if (i < lo - 1 || i >= hi) return false;
+                const double px = hx[(size_t)(i - lo + 1)], py = hy[(size_t)(i - lo + 1)];
+                for (int e = 0; e < 4; ++e)
+                    if (!(f.ex[e] * px + f.ey[e] * py + f.eo[e] >= q.fence_margin)) return false;
+            }
+            return true;
+        };
         auto dist = [&](int64_t i) { return d[(size_t)(i - lo)]; };     // lo <= i < hi by the halo bound below
         // (a step within 0.1 % of the 1e-6 threshold counts neither as skipped nor as a coupling)
         auto back_halo = [&](int64_t s) -> int {
@@ -241,7 +257,7 @@ struct Tiling {
             memset(&wt, 0, sizeof wt);
             auto clampi = [](int64_t v) { return (int32_t)std::max<int64_t>(-2, std::min<int64_t>(v, (int64_t)1 << 30)); };
             wt.out_base = f.pt_off + first; wt.field = (int32_t)p; wt.tile = (int32_t)out.size();
-            wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf;
+            wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = all_inside(s, c) ? 1 : 0;
             wt.rel_main = clampi(f.gen_main - first); wt.rel_seam = clampi(f.n_main - first); wt.rel_last = clampi(n - 1 - first);
             wt.rel_zero = clampi(-first);
             wt.idx0 = t.idx0; wt.off0 = t.off0;
@@ -800,6 +816,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         // wave tiles (fcpp_sparse.hip) where eight steps of a swath line already exceed the reach of the sweeps: the reference's
         // own sampling and coarse uniform spacings; dense sampling keeps the eight-points-per-lane kernel
         q.df = &df; q.tu = h_tu.data(); q.tc = h_tc.data(); q.u_cap = b->cst.u_cap;
+        q.fence_margin = 1e-3 + std::max(0.0, -opt->geofence_tol);
         q.wave_ok = e == hipSuccess && df.n_turn == b->hp.tt.nu && (int)h_tc.size() == b->hp.tt.nc &&
                     (double)tune_int("FCPP_WAVE_FACTOR", 24) * q.two_a * q.line_step_len >= b->cst.u_cap;
         // (a sweep reaches at most u_cap / (2 a step) points: up to 24 halo lanes either side still leave 14 of a wave's 64 lanes for
@@ -808,10 +825,14 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         qi[(size_t)i] = q;
     }
     til.build(n_fields, offs.data(), qi.data());
-    if (getenv("FCPP_DEBUG_TILING"))
+    if (getenv("FCPP_DEBUG_TILING")) {
+        size_t n_inside = 0;
+        for (const DevWaveTile &w : til.wtiles) n_inside += w.inside;
         fprintf(stderr, "[fcpp] tiling: %zu tiles; wave-tile stretches refused: back halo %lld, forward halo %lld, too few outputs %lld, "
-                "primitive span %lld\n", til.tiles.size(), (long long)til.wave_fail[0], (long long)til.wave_fail[1],
-                (long long)til.wave_fail[2], (long long)til.wave_fail[3]);
+                "primitive span %lld; %zu wave tiles, %zu of them inside the geofence by the host's test\n", til.tiles.size(),
+                (long long)til.wave_fail[0], (long long)til.wave_fail[1], (long long)til.wave_fail[2], (long long)til.wave_fail[3],
+                til.wtiles.size(), n_inside);
+    }
     ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) &&
         ok(b->til.upload(til, st)) &&
         ok(b->field_junc.alloc((size_t)n_fields));

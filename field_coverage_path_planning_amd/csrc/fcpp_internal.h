@@ -91,7 +91,7 @@ struct DevWaveTile {
     int32_t tile;            // the tile's index in the tile table = its slot in the partial statistics
     uint8_t count;           // output lanes ...
     uint8_t hb, hf;          // ... after hb halo lanes and before hf halo lanes (hb + count + hf <= 64)
-    uint8_t _pad;
+    uint8_t inside;          // 1: the host found every output point at least a millimetre inside the field polygon (no geofence test needed)
     int32_t rel_main;        // gen_main - first: lanes below it are generated from layer 1's closed form (clamped to [-2, 1 << 30])
     int32_t rel_seam;        // n_main - first: the lane of the first point of layer 2 (clamped likewise)
     int32_t rel_last;        // (n_total - 1) - first: the lane of the path's last point (clamped likewise); first == 0 <=> rel_zero == 0

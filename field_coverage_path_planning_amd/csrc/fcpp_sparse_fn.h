@@ -132,7 +132,8 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
 
     // ---- 4. validation flags ------------------------------------------------------------------------------------------------------
     bool o_out = false, o_obs = false, o_viol = false;
-    if (out) {
+    // (wave-uniform: tiles whose output points the host found a millimetre inside the polygon skip the test -- most headland tiles)
+    if (!wt.inside && out) {
         const double ntol = -cst.geofence_tol;
         bool o = false;
 #pragma unroll

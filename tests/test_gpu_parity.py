@@ -173,6 +173,24 @@ def test_obstacles_and_geofence_flags_vs_oracle():
     b.close()
 
 
+def test_geofence_tolerances_vs_oracle():
+    """A negative tolerance flags points that lie INSIDE the polygon, closer to an edge than |tol| (the outer headland loop runs W/2 =
+    1.6 m inside, reverse fills end on the edge; the U-turns of a skewed field leave it): the wave tiles the host marks as "inside by a
+    margin" (DevWaveTile.inside: no test on the device) must take the tolerance into account.  Flags and n_outside exact against the
+    oracle, rectangles and parallelograms; the count falls as the tolerance grows."""
+    counts = []
+    for tol in (-2.0, -0.4, 0.0, 0.3):
+        n_out = 0
+        for para in (False, True):
+            specs, ofs = _random_fields(77 + int(para), 12, para=para)
+            _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(geofence_tol=tol))
+            b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(geofence_tol=tol))
+            n_out += int(b.run().stats()['n_outside'].sum())
+            b.close()
+        counts.append(n_out)
+    assert counts[0] > counts[1] > counts[2] >= counts[3] and counts[0] > 0, counts
+
+
 def _clip_fields():
     """fields whose obstacles sit inside the work area, away from the swath lines' end zones: a rectangle with a square, a triangle
     and a pentagon (the last two side by side on the same swaths), and a tilted parallelogram with two obstacles"""
