@@ -20,8 +20,10 @@
 
 namespace fcpp {
 
-static constexpr int SP_WAVES = 4;     // wave tiles per workgroup (independent of each other: no barrier)
-
+// SP_WAVES wave tiles per workgroup (independent of each other: no barrier).  Four for launches of a few rounds of workgroups (the
+// headline's 32 768 tiles: 41 us, 43 with two, 45-48 with one), two for long launches (cfg5's 622 016 tiles: 661-682 us, 674-688 with four,
+// 737-752 with eight); measured on the same box, tools/ab_knob.py per build.
+template <int SP_WAVES>
 __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile *__restrict__ wtiles, int64_t n_wtiles,
                                                                const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
                                                                DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
@@ -61,8 +63,12 @@ int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtil
                        TilePartial *partial)
 {
     if (n_wtiles <= 0) return 0;
-    FCPP_LAUNCH(k_plan_sparse, dim3((unsigned)((n_wtiles + SP_WAVES - 1) / SP_WAVES)), dim3(64 * SP_WAVES), 0, st, wtiles, n_wtiles, fields,
-                prims, cst, obs, x, y, kappa, v, fs, partial);
+    if (n_wtiles >= 131072)
+        FCPP_LAUNCH(k_plan_sparse<2>, dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v,
+                    fs, partial);
+    else
+        FCPP_LAUNCH(k_plan_sparse<4>, dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v,
+                    fs, partial);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
