@@ -216,20 +216,20 @@ __global__ void k_field_junctions(int64_t n_fields, const DevField *__restrict__
 }
 
 // the quiet path: one tile per wavefront, four per workgroup; pure HBM streaming at full occupancy
-template <int KINDS, bool SCALAR_DESC, bool STAGED, bool OBS>
-__global__ __launch_bounds__(256) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
+template <int KINDS, bool SCALAR_DESC, bool STAGED, bool OBS, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_plan_quiet(const DevTile *__restrict__ chunks, const DevField *__restrict__ fields,
                                                       const DevPrim *__restrict__ prims, DevConst cst, DevObstacles obs,
                                                       double *__restrict__ xo,
                                                       double *__restrict__ yo, double *__restrict__ ko,
                                                       double *__restrict__ vo, uint32_t *__restrict__ fso,
                                                       TilePartial *__restrict__ partial, int64_t n_chunks)
 {
-    __shared__ double obs_lds[4][OBS ? 2 * OBS_LDS_VERTS : 1];
-    __shared__ double tmpl_lds[4][STAGED ? 3 * TMPL_LDS : 1];
+    __shared__ double obs_lds[WPB][OBS ? 2 * OBS_LDS_VERTS : 1];
+    __shared__ double tmpl_lds[WPB][STAGED ? 3 * TMPL_LDS : 1];
     // the wave index as a scalar: the chunk and field descriptors are then fetched by scalar loads and live in scalar registers
     // (as per-lane copies of the same values they cost ~40 vector registers, i.e. one wave per SIMD of occupancy)
     const int wave = SCALAR_DESC ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
-    const int64_t slot = (int64_t)blockIdx.x * 4 + wave;   // one chunk per wavefront
+    const int64_t slot = (int64_t)blockIdx.x * WPB + wave;   // one chunk per wavefront
     if (slot >= n_chunks) return;
     if (STAGED) stage_turn_template(cst, tmpl_lds[wave]);  // (its loads are in flight while the descriptors arrive)
     const DevTile tl = chunks[slot];
@@ -841,17 +841,26 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
                       TilePartial *partial)
 {
     if (n_chunks <= 0) return 0;
-    const dim3 grid((unsigned)((n_chunks + 3) / 4)), block(256);
     const bool staged = cst.tmpl_n > 0 && cst.tmpl_n <= TMPL_LDS, has_obs = obs.offsets != nullptr;
+    // Chunks (= wavefronts) per workgroup: eight for long launches of the dense instances -- on ten sets of output arrays each
+    // (tools/ab_knob.py FCPP_QUIET_WPB=4,8 and a sweep over allocations) cfg2 at 0.5 m 1.202 -> 1.190 ms on its fastest set and ~1 % on all
+    // others, the dense kernel of cfg2 at 0.1 m 4772 -> 4705 us, cfg3 394 -> 387 us -- four for launches of a few rounds (the headline's
+    // 14 120 chunks: 31.9 us, 34.3 with eight) and for the spans at the reference's sampling (STAGED): cfg5 gains 2-5 % with eight on the
+    // slow allocations (2.40 -> 2.33, 2.61 -> 2.55 ms) and loses 1 % on the fast ones (2.045 -> 2.07 ms), which calibration finds; two per
+    // workgroup: +11 % on cfg5.
+    const int wpb_k = tune_int("FCPP_QUIET_WPB", 0);
+    const int wpb = wpb_k == 8 || wpb_k == 4 ? wpb_k : (n_chunks >= 65536 && !(kinds == 16 && staged) ? 8 : 4);
+    const dim3 grid((unsigned)((n_chunks + wpb - 1) / wpb)), block(64 * wpb);
     // Resident waves of the span kernel are held to FOUR per SIMD by its LDS footprint (34 KiB per four-wave workgroup of 160 KiB per
     // CU): measured on identical memory (tools/ab_knob.py) cfg5 1.33 vs 1.44 ms at 5-7 waves and 1.59 ms at 3; the other
     // configurations do not care (+-1 %) -- except launches of a few rounds of workgroups, where FIVE per SIMD (27 KiB) end a round
     // earlier: the headline's 3530 workgroups 31.9 vs 33.2 us, step 0.0819 vs 0.0837 ms; cfg2 at the reference's sampling, 2064
     // workgroups, the same either way.  FCPP_SPAN_LDS / FCPP_QUIET_PAD: bytes, for that tool.
-    const int static_lds = (has_obs ? 4 * 2 * OBS_LDS_VERTS * 8 : 32) + (kinds == 16 && staged ? 4 * 3 * TMPL_LDS * 8 : 32);
-    const int span_lds = grid.x < 16384u ? 27 * 1024 : 34 * 1024;
+    const int static_lds = (has_obs ? wpb * 2 * OBS_LDS_VERTS * 8 : 32) + (kinds == 16 && staged ? wpb * 3 * TMPL_LDS * 8 : 32);
+    const int span_lds = (n_chunks < 65536 ? 27 * 1024 : 34 * 1024) * wpb / 4;
     const int pad = kinds == 16 ? std::max(0, tune_int("FCPP_SPAN_LDS", span_lds) - static_lds) : tune_int("FCPP_QUIET_PAD", 0);
-#define FCPP_QUIET(K, SD, TL, OB) FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks)
+#define FCPP_QUIET(K, SD, TL, OB) do { if (wpb == 8) FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB, 8>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks); \
+                                       else FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB, 4>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks); } while (0)
     // Instances: spans fetch their descriptors by scalar loads (SCALAR_DESC: that nearly halved their time in round 1), stage the
     // turn template in LDS when it is the reference's short one (STAGED), and every instance exists with and without the polygon
     // tests (OBS; without: 68 instead of 93 vector registers and no scalar spills in the span kernel, 80 instead of 116 in the dense
