@@ -157,6 +157,20 @@ def test_cfg4_ga_population_4096_vs_oracle():
     assert (res.generations, res.convergence_gen, res.best_distance, res.best_fitness) == \
         (wres.generations, wres.convergence_gen, wres.best_distance, wres.best_fitness)
     assert all(sorted(r.tolist()) == list(range(128)) for r in pop.cpu().numpy()[::257])
+
+    # the whole configuration: 500 generations (501 population evaluations), never converging early -- and with the reference's default
+    # threshold, where the loop stops on its own -- replayed by the oracle bit for bit: final population, best route, both histories
+    for threshold in (10 ** 9, 50):
+        class Full:
+            population_size, max_generations, crossover_rate, mutation_rate = 4096, 500, 0.85, 0.02
+            elite_size, tournament_size, convergence_threshold = 20, 5, threshold
+        pop, best, hb, ha, res = E.ga_evolve(D, routes, Full, seed=4096)
+        wpop, wbest, whb, wha, wres = orc.ga_evolve(D, routes, max_generations=500, convergence_threshold=threshold, seed=4096)
+        assert res.generations == wres.generations and (threshold < 10 ** 9 or res.generations == 500)
+        assert np.array_equal(pop.cpu().numpy(), wpop) and np.array_equal(best.cpu().numpy(), wbest), threshold
+        assert np.array_equal(hb, whb) and np.array_equal(ha, wha), threshold
+        assert (res.convergence_gen, res.best_distance, res.best_fitness) == (wres.convergence_gen, wres.best_distance, wres.best_fitness)
+        assert res.best_distance < 0.5 * float(orc.ga_distance(routes, D).min())          # it did optimise
     # precondition checks of the entry points
     bad = routes.copy()
     bad[7, 3] = bad[7, 4]
