@@ -67,6 +67,12 @@ class FieldStats(C.Structure):
                 ('n_adjusted', C.c_int64)]
 
 
+class SetupTimes(C.Structure):
+    """fcpp_setup_times: where the time of fcpp_batch_create went"""
+    _fields_ = [('host_plan_ms', C.c_double), ('templates_ms', C.c_double), ('tiler_ms', C.c_double), ('image_ms', C.c_double),
+                ('h2d_ms', C.c_double), ('total_ms', C.c_double), ('image_bytes', C.c_int64), ('threads', C.c_int32), ('_pad', C.c_int32)]
+
+
 class GaConfig(C.Structure):
     """fcpp_ga_config = GAConfig (GA:20-29) + seed"""
     _fields_ = [('population_size', C.c_int32), ('max_generations', C.c_int32), ('crossover_rate', C.c_double),
@@ -110,6 +116,7 @@ PROTOTYPES = [
     ('fcpp_batch_create', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field),
                                     C.POINTER(Polys), C.POINTER(_VP)]),
     ('fcpp_batch_info', C.c_int, [_VP, C.POINTER(FieldInfo), c_i64_p]),
+    ('fcpp_batch_setup_times', C.c_int, [_VP, C.POINTER(SetupTimes)]),
     ('fcpp_batch_run', C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int]),
     ('fcpp_batch_connectors', C.c_int, [_VP, _VP, _VP]),
     ('fcpp_batch_destroy', C.c_int, [_VP]),
@@ -156,7 +163,7 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.fcpp_abi_version() != 2:
+        if lib.fcpp_abi_version() != 3:
             raise ImportError('libfcpp.so ABI version mismatch')
         _lib = lib
     return _lib

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -15,6 +17,8 @@
 #include "fcpp_ga.h"
 #include "fcpp_device.h"
 #include "fcpp_internal.h"
+#include "fcpp_parallel.h"
+#include "fcpp_tiler.h"
 
 using namespace fcpp;
 
@@ -77,300 +81,31 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     return c;
 }
 
-// tile table of a set of paths
+// plain tile table of a set of paths (the staged pipeline and the standalone operators): tiles never straddle paths, hold at most
+// TILE_POINTS points, a path is cut into near-equal tiles.  (The fused pipeline's tiler lives in fcpp_tiler.cpp.)
 struct Tiling {
     std::vector<DevPath> paths;
     std::vector<DevTile> tiles;
     std::vector<int64_t> tile_first;
-    std::vector<int64_t> pass_len;      // per path: points per pass of layer 1 (swath line + U-turn), 0 without structure
-    // structure of a field's path, for the fused pipeline's tiling
-    struct QuietInfo {
-        int64_t n_line, n_turn, P, n_main, gen_main;
-        double line_step_len, c_line;          // |numpy step| of the swath lines, their nominal u = (v/3.6)^2
-        const DevPrim *prims; int prim_count, prim_index0;  // layer 2: the field's primitives, index of the first one in the batch
-        double two_a;
-        bool enable;
-        bool turn_quiet;       // U-turns are closed form and swath lines are isolated by them (see fcpp_batch_create)
-        // geometry for the wave tiles of the sparse kernel (fcpp_sparse.hip): the field, host copies of the batch's turn templates
-        const DevField *df = nullptr;
-        const double2 *tu = nullptr, *tc = nullptr;
-        double u_cap = 0.0;
-        double fence_margin = 1e-3;   // a point this far inside every edge of the field polygon cannot be flagged by the device's test
-        bool wave_ok = false;  // sampling sparse enough for halos of a few lanes
-    };
-
-    // Host evaluation of path point i of a field (same formulas as eval_main / eval_prim in fcpp_pointfn.h, from the host copies of
-    // the templates).  Only distances between consecutive points are taken from it, to size the halos of the wave tiles.
-    static void host_point(const QuietInfo &q, int64_t i, double &px, double &py)
-    {
-        const DevField &f = *q.df;
-        if (i < f.gen_main) {
-            const int64_t per = (int64_t)f.n_line + f.n_turn;
-            const int64_t idx = i / per, off = i - idx * per;
-            const int64_t pi = f.reverse_order ? (f.P - 1 - idx) : idx;
-            const double y = f.min_y + (double)pi * f.W;
-            const bool go_left = f.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
-            if (off < f.n_line) {
-                px = go_left ? linspace_at(f.lex, f.lsx, -f.line_step, f.n_line, off) : linspace_at(f.lsx, f.lex, f.line_step, f.n_line, off);
-                py = y;
-            } else {
-                const double2 t = q.tu[off - f.n_line];
-                const bool turn_right = !go_left;
-                if (f.turn_model == FCPP_TURN_ARC) px = turn_right ? (f.max_x - t.x) : (f.min_x + t.x);
-                else px = turn_right ? ((f.max_x - f.R) + t.x) : ((f.min_x + f.R) - t.x);
-                py = y + t.y;
-            }
-            if (f.rotated) {
-                const double tx = px - f.rot_cx, ty = py - f.rot_cy;
-                px = (tx * f.rot_cos - ty * f.rot_sin) + f.rot_cx;
-                py = (tx * f.rot_sin + ty * f.rot_cos) + f.rot_cy;
-            }
-            return;
-        }
-        const DevPrim &p = q.prims[prim_of(q, i)];
-        const int64_t r = i - p.start;
-        if (p.kind == PRIM_LINSPACE) { px = linspace_at(p.a[0], p.a[2], p.a[4], p.n, r); py = linspace_at(p.a[1], p.a[3], p.a[5], p.n, r); }
-        else if (p.kind == PRIM_POINT) { px = p.a[0]; py = p.a[1]; }
-        else if (p.kind == PRIM_RAY) { const double t = linspace_at(0.0, p.a[4], p.a[5], p.n, r); px = p.a[0] + t * p.a[2]; py = p.a[1] + t * p.a[3]; }
-        else if (p.kind == PRIM_UTURN) {
-            const double2 t = q.tu[r];
-            const bool turn_right = p.form & 1;
-            if (!(p.form & 4)) px = turn_right ? (p.a[0] - t.x) : (p.a[0] + t.x);
-            else px = turn_right ? (p.a[0] + t.x) : (p.a[0] - t.x);
-            py = p.a[1] + t.y;
-            if (p.form & 2) {
-                const double tx = px - p.a[4], ty = py - p.a[5];
-                px = (tx * p.a[2] - ty * p.a[3]) + p.a[4];
-                py = (tx * p.a[3] + ty * p.a[2]) + p.a[5];
-            }
-        }
-        else {
-            const double2 t = q.tc[r];
-            const int ci = p.kind == PRIM_ARC ? p.form : ((p.form + 3) & 3);
-            if (ci == 0)      { px = p.a[0] + t.x; py = p.a[1] + t.y; }
-            else if (ci == 1) { px = p.a[0] - t.y; py = p.a[1] + t.x; }
-            else if (ci == 2) { px = p.a[0] - t.x; py = p.a[1] - t.y; }
-            else              { px = p.a[0] + t.y; py = p.a[1] - t.x; }
-        }
-    }
-    static int prim_of(const QuietInfo &q, int64_t i)      // index (within the field) of the headland primitive that holds point i
-    {
-        int a = 0, b = q.prim_count - 1;
-        while (a < b) { const int m = (a + b + 1) >> 1; if (q.prims[m].start <= i) a = m; else b = m - 1; }
-        return a;
-    }
-
-    // Wave tiles of the sparse kernel for the general stretch [a, b) of path p: [ Hb halo | count outputs | Hf halo ] <= WAVE_LANES lanes.
-    // The halos are sized from the path's own step lengths (see fcpp_sparse.hip): backwards from the point before the first output
-    // (whose final speed the segment metrics need) until the couplings 2a|dp| add up to u_cap, a skipped step or the path's start,
-    // plus one lane for the stencil of the outermost point; forwards likewise from the last output.  Every tile takes as many
-    // outputs as fit.  false = some tile would hold fewer than 8 outputs (dense sampling): the stretch stays with k_plan_fused.
-    static constexpr int WAVE_HALO_MAX = 40;
-    static constexpr int WAVE_LANES = 64;                // fcpp_sparse.hip: one wavefront per wave tile
-    mutable int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };   // diagnostics (FCPP_DEBUG_TILING): stretches that did not fit, by reason
-    mutable std::vector<double> wave_d;                  // scratch: step lengths of the stretch and its surroundings
-    mutable std::vector<double> wave_x, wave_y;          // scratch: the points themselves (index i - (lo - 1))
-    mutable std::vector<DevWaveTile> wtiles;             // the wave tiles' records, in the order of their DevTile entries
-    bool wave_tiles(int64_t p, const QuietInfo &q, int64_t a, int64_t b, std::vector<DevTile> &out) const
-    {
-        const DevField &f = *q.df;
-        const int64_t n = f.n_total, per = (int64_t)f.n_line + f.n_turn;
-        const double cap = q.u_cap * (1.0 + 1e-9) + 1e-12;
-        // d[i - lo] = |p_i - p_(i-1)| for the stretch and WAVE_HALO_MAX + 2 points either side
-        const int64_t lo = std::max<int64_t>(a - WAVE_HALO_MAX - 2, 1), hi = std::min<int64_t>(b + WAVE_HALO_MAX + 2, n);   // i in [lo, hi)
-        if (hi - lo > (int64_t)1 << 22) { ++wave_fail[4]; return false; }
-        std::vector<double> &d = wave_d;
-        d.resize((size_t)std::max<int64_t>(hi - lo, 0));
-        std::vector<double> &hx = wave_x, &hy = wave_y;
-        hx.resize(d.size() + 1); hy.resize(d.size() + 1);
-        {
-            double x0, y0, x1, y1;
-            if (hi > lo) { host_point(q, lo - 1, x0, y0); hx[0] = x0; hy[0] = y0; }
-            for (int64_t i = lo; i < hi; ++i) {
-                host_point(q, i, x1, y1);
-                const double dx = x1 - x0, dy = y1 - y0;
-                d[(size_t)(i - lo)] = sqrt(dx * dx + dy * dy);
-                hx[(size_t)(i - lo + 1)] = x1; hy[(size_t)(i - lo + 1)] = y1;
-                x0 = x1; y0 = y1;
-            }
-        }
-        // every output point of [s, s + c) well inside the field polygon?  (host and device evaluate a point with the same formulas;
-        // their roundings differ by ~1e-12 m, the margin is a millimetre: the device's test of such a point cannot fire)
-        auto all_inside = [&](int64_t s, int64_t c) -> bool {
-            for (int64_t i = s; i < s + c; ++i) {
-                if (i < lo - 1 || i >= hi) return false;
-                const double px = hx[(size_t)(i - lo + 1)], py = hy[(size_t)(i - lo + 1)];
-                for (int e = 0; e < 4; ++e)
-                    if (!(f.ex[e] * px + f.ey[e] * py + f.eo[e] >= q.fence_margin)) return false;
-            }
-            return true;
-        };
-        auto dist = [&](int64_t i) { return d[(size_t)(i - lo)]; };     // lo <= i < hi by the halo bound below
-        // (a step within 0.1 % of the 1e-6 threshold counts neither as skipped nor as a coupling)
-        auto back_halo = [&](int64_t s) -> int {
-            if (s == 0) return 0;
-            const int64_t j = s - 1;
-            int64_t m = j;
-            double acc = 0.0;
-            for (;;) {
-                if (m == 0) return (int)(j + 1);
-                const double dm = dist(m);
-                if (dm < 0.999e-6) return (int)(j - (m - 1) + 1);
-                if (dm > 1.001e-6) acc += q.two_a * dm;
-                --m;
-                if (acc >= cap) return (int)(j - m + 1);
-                if (j - m + 1 > WAVE_HALO_MAX) return -1;
-            }
-        };
-        auto fwd_halo = [&](int64_t e) -> int {
-            if (e == n - 1) return 0;
-            int64_t m = e;
-            double acc = 0.0;
-            for (;;) {
-                const double dm = dist(m + 1);
-                if (dm < 0.999e-6) return (int)(m + 1 - e);
-                if (dm > 1.001e-6) acc += q.two_a * dm;
-                ++m;
-                if (m == n - 1 || acc >= cap) return (int)(m - e);
-                if (m - e > WAVE_HALO_MAX) return -1;
-            }
-        };
-        const size_t mark = out.size(), mark_w = wtiles.size();
-        for (int64_t s = a; s < b;) {
-            const int Hb = back_halo(s);
-            if (Hb < 0) { ++wave_fail[0]; out.resize(mark); wtiles.resize(mark_w); return false; }
-            // the largest count whose forward halo still fits
-            int64_t c = std::min<int64_t>(b - s, WAVE_LANES - Hb);
-            int Hf = -1;
-            for (; c >= 1; --c) {
-                Hf = fwd_halo(s + c - 1);
-                if (Hf >= 0 && Hb + c + Hf <= WAVE_LANES) break;
-            }
-            if (c < std::min<int64_t>(8, b - s)) { ++wave_fail[Hf < 0 ? 1 : 2]; out.resize(mark); wtiles.resize(mark_w); return false; }
-            const int64_t first = s - Hb, last = s + c - 1 + Hf;
-            DevTile t;
-            t.field = (int32_t)p; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
-            if (first < f.gen_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
-            else { t.idx0 = q.prim_index0 + prim_of(q, first); t.off0 = 0; }
-            // the self-contained record: layer-1 decode of lane 0, and where the (at most 8) further primitives start among the lanes
-            DevWaveTile wt;
-            memset(&wt, 0, sizeof wt);
-            auto clampi = [](int64_t v) { return (int32_t)std::max<int64_t>(-2, std::min<int64_t>(v, (int64_t)1 << 30)); };
-            wt.out_base = f.pt_off + first; wt.field = (int32_t)p; wt.tile = (int32_t)out.size();
-            wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = all_inside(s, c) ? 1 : 0;
-            wt.rel_main = clampi(f.gen_main - first); wt.rel_seam = clampi(f.n_main - first); wt.rel_last = clampi(n - 1 - first);
-            wt.rel_zero = clampi(-first);
-            wt.idx0 = t.idx0; wt.off0 = t.off0;
-            for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
-            if (last >= f.gen_main) {
-                const int64_t fl2 = std::max<int64_t>(first, f.gen_main);      // first primitive-generated point of the tile
-                const int pa = prim_of(q, fl2), pb = prim_of(q, last);
-                if (pb - pa > 8) { ++wave_fail[3]; out.resize(mark); wtiles.resize(mark_w); return false; }
-                wt.p0 = q.prim_index0 + pa;
-                wt.r0 = (int32_t)(first - q.prims[pa].start);
-                for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(q.prims[k].start - first);
-            }
-            wtiles.push_back(wt);
-            out.push_back(t);
-            s += c;
-        }
-        return true;
-    }
-
-    // Tiles never straddle paths and hold at most TILE_POINTS points.  Without structure information (standalone operators)
-    // a path is cut into near-equal tiles.  With it (planner batches) every straight primitive -- swath lines of layer 1,
-    // headland straights of layer 2 -- is cut as
-    //     [ need | quiet zone ............................. | need ]
-    // quiet zone = samples whose sweep neighbourhood stays on the straight: `need` samples span u_nominal / (2a) metres, the
-    // farthest a slower point can lower speeds that are nominal for this straight.  Quiet zones become "quiet" tiles
-    // (closed-form kernel); everything else -- turns, corner arcs, reverse fills and the margins around them -- becomes
-    // general tiles.  The cut depends only on the field itself, never on its position in the batch.
-    void build(int64_t n_paths, const int64_t *offsets, const QuietInfo *quiet = nullptr)
+    void build(int64_t n_paths, const int64_t *offsets)
     {
         paths.resize((size_t)n_paths);
         tile_first.assign((size_t)n_paths + 1, 0);
-        pass_len.assign((size_t)n_paths, 0);
         tiles.clear();
-        wtiles.clear();
         for (int64_t p = 0; p < n_paths; ++p) {
             const int64_t n = offsets[p + 1] - offsets[p];
             paths[(size_t)p] = { offsets[p], n };
             tile_first[(size_t)p] = (int64_t)tiles.size();
-            const QuietInfo *q = (quiet && quiet[p].enable) ? &quiet[p] : nullptr;
-            const int64_t per = q ? q->n_line + q->n_turn : 0;
-            pass_len[(size_t)p] = per;
-            auto emit = [&](int64_t s, int64_t cnt, int kind, int64_t i0, int64_t o0) {
+            if (n <= 0) continue;
+            const int64_t k = (n + TILE_POINTS - 1) / TILE_POINTS, base = n / k, rem = n % k;
+            int64_t a = 0;
+            for (int64_t i = 0; i < k; ++i) {
+                const int64_t c = base + (i < rem ? 1 : 0);
                 DevTile t;
-                t.field = (int32_t)p; t.start = s; t.count = (int32_t)cnt; t.quiet = kind; t.stat_tile = 0;
-                t.idx0 = (int32_t)i0; t.off0 = (int32_t)o0;
+                t.field = (int32_t)p; t.start = a; t.count = (int32_t)c; t.quiet = 0; t.stat_tile = 0; t.idx0 = 0; t.off0 = 0;
                 tiles.push_back(t);
-            };
-            auto emit_general = [&](int64_t a, int64_t b) {
-                const int64_t len = b - a;
-                if (len <= 0) return;
-                if (q && q->wave_ok && wave_tiles(p, *q, a, b, tiles)) return;
-                const int64_t k = (len + TILE_POINTS - 1) / TILE_POINTS, base = len / k, rem = len % k;
-                for (int64_t i = 0; i < k; ++i) {
-                    const int64_t c = base + (i < rem ? 1 : 0);
-                    const bool in1 = per > 0 && a < q->gen_main;      // layer-1 decode of the tile start for the general kernel
-                    emit(a, c, 0, in1 ? a / per : 0, in1 ? a % per : 0);
-                    a += c;
-                }
-            };
-            // near-equal quiet tiles of at most TILE_POINTS - 2 points (the kernel stores aligned PAIRS; a tile that starts on an
-            // odd global index needs one pair more than half its points)
-            auto emit_quiet = [&](int64_t zs, int64_t Z, int kind, int64_t i0, int64_t o0) {
-                const int64_t cap = TILE_POINTS - 2, k = (Z + cap - 1) / cap, base = Z / k, rem = Z % k;
-                for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(zs, c, kind, i0, o0); zs += c; o0 += c; }
-            };
-            auto need_for = [&](double c_nom, double step_len) -> int64_t {
-                if (!(step_len >= 1e-6)) return -1;
-                return (int64_t)(c_nom / (q->two_a * step_len)) + 3;
-            };
-            int64_t pos = 0;
-            if (q) {
-                const int64_t need1 = need_for(q->c_line, q->line_step_len);
-                if (need1 >= 0 && per > 0 && q->gen_main > 0) {
-                    // With closed-form U-turns nothing propagates into a swath line from the turns around it (a turn starts on
-                    // the line's last point: a skipped step; the jump back from the turn's end is too long to bind): all
-                    // complete passes (line + turn) form ONE quiet span, whatever the sampling.  The last line ends at the
-                    // seam to the headland layer: it is cut like any other straight, without a margin at its start.
-                    // Dense sampling keeps lines and turns as runs of their own (cheaper per point: no pass decode); the span is for
-                    // short lines -- the reference's own sampling has 2 points per line and 20 per turn.
-                    int64_t first_idx = 0;
-                    const bool span = q->turn_quiet && q->P >= 2 && q->n_line - need1 < 64 && (q->P - 1) * per < (int64_t)0x7fffffff;
-                    if (span) {
-                        const int64_t S = (q->P - 1) * per, cap = TILE_POINTS - 2, k = (S + cap - 1) / cap, base = S / k, rem = S % k;
-                        int64_t a = 0;
-                        for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(a, c, 4, a / per, a % per); a += c; }
-                        pos = S; first_idx = q->P - 1;
-                    }
-                    for (int64_t idx = first_idx; idx < q->P; ++idx) {
-                        // closed-form turns, dense sampling: the whole line is a quiet run, and so is the turn after it
-                        const bool full = q->turn_quiet && !span;
-                        const int64_t need_s = (full || (span && idx > 0)) ? 0 : need1, need_e = (full && idx < q->P - 1) ? 0 : need1;
-                        const int64_t L0 = idx * per, zs = L0 + need_s, Z = q->n_line - need_s - need_e;
-                        if (Z < 64) break;
-                        emit_general(pos, zs);
-                        emit_quiet(zs, Z, 1, idx, need_s);
-                        pos = zs + Z;
-                        if (full && idx < q->P - 1) { emit_quiet(L0 + q->n_line, q->n_turn, 3, idx, 0); pos = L0 + per; }
-                    }
-                }
-                for (int k = 0; k < q->prim_count; ++k) {
-                    const DevPrim &pr = q->prims[k];
-                    if (pr.kind != PRIM_LINSPACE) continue;
-                    const double ms = pr.v_nom / 3.6;
-                    const int64_t need2 = need_for(ms * ms, sqrt(pr.a[4] * pr.a[4] + pr.a[5] * pr.a[5]));
-                    if (need2 < 0) continue;
-                    const int64_t zs = pr.start + need2, Z = (int64_t)pr.n - 2 * need2;
-                    if (Z < 64 || zs < pos) continue;
-                    emit_general(pos, zs);
-                    emit_quiet(zs, Z, 2, q->prim_index0 + k, need2);
-                    pos = zs + Z;
-                }
+                a += c;
             }
-            emit_general(pos, n);
         }
         tile_first[(size_t)n_paths] = (int64_t)tiles.size();
     }
@@ -385,18 +120,7 @@ struct DevTiling {
     DevBuf<char> spine;          // scratch of the three-level spine (large batches)
     DevBuf<TilePartial> partial;
     DevBuf<unsigned long long> n_adj;
-    DevBuf<int32_t> general_ids;   // fused pipeline: the tiles of k_plan_fused
-    DevBuf<DevWaveTile> wave_tiles; // ... the wave tiles of k_plan_sparse (self-contained records)
-    DevBuf<DevTile> chunks;        // ... the quiet runs cut on 512-point boundaries of the batch arrays (k_plan_quiet)
-    DevBuf<DevTile> span_chunks;   // ... the same for the layer-1 spans (their own kernel instance)
-    DevBuf<int32_t> stat_ids;      // ... the tiles that can hold statistics (general tiles, first tile of every run), path by path
-    DevBuf<int64_t> stat_first;    //     CSR offsets into stat_ids per path
-    DevBuf<int64_t> stat_run;      //     per entry of stat_ids: points of the quiet run that starts there (0: not a run)
-    DevBuf<int32_t> red_paths;     //     the paths by their number of entries: [<= 64 | <= 256 | <= 1024 | more] (k_reduce_stats)
-    DevBuf<char> red_scratch;      //     slice results of the paths of the last class (64 x 104 bytes each)
-    int64_t n_red[4] = { 0, 0, 0, 0 };
-    int64_t n_tiles = 0, n_paths = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_general = 0, n_wave = 0, quiet_points = 0;
-    int64_t span_points = 0, chunk_points = 0, wave_points = 0;
+    int64_t n_tiles = 0, n_paths = 0;
     hipError_t upload(const Tiling &t, hipStream_t st)
     {
         n_tiles = (int64_t)t.tiles.size(); n_paths = (int64_t)t.paths.size();
@@ -411,103 +135,22 @@ struct DevTiling {
         if ((e = spine.alloc((size_t)spine_scratch_bytes(n_tiles))) != hipSuccess) return e;
         if ((e = partial.alloc((size_t)n_tiles)) != hipSuccess) return e;
         if ((e = n_adj.alloc((size_t)n_paths)) != hipSuccess) return e;
-        std::vector<int32_t> gv, sv;
-        std::vector<int64_t> srun;
-        std::vector<int64_t> sf((size_t)n_paths + 1, 0);
-        wave_points = 0;
-        std::vector<DevTile> cv, cs;
-        std::vector<DevRun> rv;
-        quiet_points = 0;
-        for (size_t i = 0; i < t.tiles.size();) {
-            const DevTile &t0 = t.tiles[i];
-            sv.push_back((int32_t)i);                 // a general tile, a wave tile, or the first tile of a run
-            srun.push_back(0);
-            sf[(size_t)t0.field + 1] = (int64_t)sv.size();
-            if (!t0.quiet) { gv.push_back((int32_t)i); ++i; continue; }
-            if (t0.quiet == 5) { wave_points += t0.count; ++i; continue; }       // (its record: t.wtiles)
-            // the run: quiet tiles that continue each other on the same straight
-            int64_t cnt = t0.count;
-            size_t j = i + 1;
-            for (; j < t.tiles.size(); ++j) {
-                const DevTile &tj = t.tiles[j];
-                const bool cont = tj.quiet == t0.quiet && tj.field == t0.field && tj.start == t0.start + cnt &&
-                                  (t0.quiet == 4 || (tj.idx0 == t0.idx0 && (int64_t)tj.off0 == (int64_t)t0.off0 + cnt));
-                if (!cont) break;
-                cnt += tj.count;
-            }
-            rv.push_back({ (int32_t)i, 0, cnt });
-            srun.back() = cnt;
-            quiet_points += cnt;
-            i = j;
-        }
-        // Chunks: every run is cut on 512-point boundaries of the batch arrays.  Consecutive layer-1 runs (swath line, U-turn, swath
-        // line, ...) are cut TOGETHER: a chunk that holds the end of one run and the start of the next is written by one wave through
-        // the span decode (kind 4) instead of two partial chunks (measured 4-5 % on the streaming kernel on identical memory; the mixed
-        // chunks in the same launch as the others or in the span instance's launch: no difference).
-        const bool merge_runs = true;
-        for (size_t r = 0; r < rv.size();) {
-            const DevTile &t0 = t.tiles[(size_t)rv[r].tile];
-            size_t r1 = r + 1;
-            int64_t total = rv[r].count;
-            if (merge_runs && (t0.quiet == 1 || t0.quiet == 3))
-                for (; r1 < rv.size(); ++r1) {
-                    const DevTile &tn = t.tiles[(size_t)rv[r1].tile];
-                    if (!((tn.quiet == 1 || tn.quiet == 3) && tn.field == t0.field && tn.start == t0.start + total)) break;
-                    total += rv[r1].count;
-                }
-            const int64_t g_grp = t.paths[(size_t)t0.field].off + t0.start, per = t.pass_len[(size_t)t0.field];
-            size_t rc = r;                       // run that holds the current position
-            int64_t rc_begin = 0;                // its first point, relative to the group
-            for (int64_t done = 0; done < total;) {
-                const int64_t g = g_grp + done;
-                // (also for the short spans of sparse sampling, where one chunk in eight is partial: near-equal chunks from the span's
-                // start, i.e. 12 % fewer waves with unaligned stores, took 1.81 instead of 1.50 ms on cfg5)
-                const int64_t c = std::min<int64_t>(total - done, TILE_POINTS - (g % TILE_POINTS));
-                while (done >= rc_begin + rv[rc].count) { rc_begin += rv[rc].count; ++rc; }
-                const DevTile &tr = t.tiles[(size_t)rv[rc].tile];
-                DevTile ch = tr;
-                ch.start = t0.start + done; ch.count = (int32_t)c; ch.stat_tile = rv[rc].tile;
-                const bool one_run = done + c <= rc_begin + rv[rc].count;
-                if (one_run && tr.quiet != 4) ch.off0 = (int32_t)(tr.off0 + (done - rc_begin));
-                else {      // a span of layer 1 (or a chunk across runs): (pass, offset in the pass) of the chunk's first point
-                    ch.quiet = 4;
-                    ch.idx0 = (int32_t)(ch.start / per); ch.off0 = (int32_t)(ch.start % per);
-                }
-                (ch.quiet == 4 ? cs : cv).push_back(ch);
-                done += c;
-            }
-            r = r1;
-        }
-        n_chunks = (int64_t)cv.size(); n_span_chunks = (int64_t)cs.size(); n_runs = (int64_t)rv.size(); n_general = (int64_t)gv.size();
-        n_wave = (int64_t)t.wtiles.size();
-        span_points = chunk_points = 0;
-        for (const DevTile &c : cs) span_points += c.count;
-        for (const DevTile &c : cv) chunk_points += c.count;
-        if ((e = wave_tiles.upload(t.wtiles, st)) != hipSuccess) return e;
-        if ((e = chunks.upload(cv, st)) != hipSuccess) return e;
-        if ((e = span_chunks.upload(cs, st)) != hipSuccess) return e;
-        if ((e = general_ids.upload(gv, st)) != hipSuccess) return e;
-        for (size_t p = 1; p < sf.size(); ++p) sf[p] = std::max(sf[p], sf[p - 1]);      // paths without tiles
-        if ((e = stat_ids.upload(sv, st)) != hipSuccess) return e;
-        if ((e = stat_first.upload(sf, st)) != hipSuccess) return e;
-        if ((e = stat_run.upload(srun, st)) != hipSuccess) return e;
-        {   // classes of the reduction: by the number of entries of each path (a property of the field alone)
-            // (8 lanes, a wavefront, a workgroup, 64 workgroups per path: at most 8 / 4 / 4 entries per lane in the first three)
-            std::vector<int32_t> cls[4];
-            // (one workgroup walks up to 1024 entries; beyond that 64 workgroups + a join launch are faster: cfg3, 3900 entries, 21.8 -> 8 us)
-            const int64_t wg_max = tune_int("FCPP_REDUCE_WG_MAX", 1024);
-            for (int64_t p = 0; p < n_paths; ++p) {
-                const int64_t ne = sf[(size_t)p + 1] - sf[(size_t)p];
-                cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= wg_max ? 2 : 3))].push_back((int32_t)p);
-            }
-            std::vector<int32_t> all;
-            for (int c = 0; c < 4; ++c) { n_red[c] = (int64_t)cls[c].size(); all.insert(all.end(), cls[c].begin(), cls[c].end()); }
-            if ((e = red_paths.upload(all, st)) != hipSuccess) return e;
-            if ((e = red_scratch.alloc((size_t)n_red[3] * 64 * 104)) != hipSuccess) return e;
-        }
         if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // the staging vectors die here
         return hipSuccess;
     }
+};
+
+// The turn templates of a batch (every field shares the vehicle and the sampling options, hence the shape and the sample count of
+// its U-turns and corner turns): sampled once on the device (k_build_templates), copied back for the tiler's halo sizing and the
+// closed-form test.  A context keeps the last set: a caller that creates batch after batch with one vehicle (the planner mirror does,
+// one per plan_complete_coverage) pays for the two launches and the copy once.
+struct TemplateSet {
+    TurnTemplates tt;
+    double clothoid_frac = 0.0;
+    DevBuf<CacShape> shapes;                       // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
+    DevBuf<double2> tmpl_u, tmpl_c, tmpl_u_dk;     // sampled turn templates (fcpp_fused.hip), (segment length, curvature) per U-turn sample
+    std::vector<double2> h_tu, h_tc, h_dk;         // host copies
+    bool same(const TurnTemplates &o, double frac) const { return memcmp(&tt, &o, sizeof tt) == 0 && clothoid_frac == frac; }
 };
 }  // namespace
 
@@ -521,6 +164,23 @@ struct fcpp_ctx {
     // kernels of the same step; ev_fork / ev_join order the two streams inside a step
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // batch setup (fcpp_batch_create): the image of a batch's tables is built in pinned host memory that the context keeps (grow-only,
+    // up to kStageMax; larger images go through a pageable buffer), and the last destroyed batch's device allocation is kept for the
+    // next one (up to kSpareMax): a caller that plans batch after batch allocates nothing after the first
+    void *stage = nullptr; size_t stage_cap = 0;
+    void *spare = nullptr; size_t spare_cap = 0;
+    std::shared_ptr<TemplateSet> templates;         // the last batch's turn templates
+    fcpp_setup_times last_setup = {};
+};
+
+// device pointers of a batch's tables: all inside ONE allocation laid out by the tiler (fcpp_tiler.h: ImageLayout)
+struct FusedTables {
+    DevField *fields = nullptr; DevPrim *prims = nullptr; DevTile *tiles = nullptr; DevWaveTile *wave_tiles = nullptr;
+    int32_t *general_ids = nullptr; DevTile *chunks = nullptr, *span_chunks = nullptr;
+    int32_t *stat_ids = nullptr; int64_t *stat_first = nullptr, *stat_run = nullptr; int32_t *red_paths = nullptr;
+    int64_t *obs_off = nullptr; double *obs_x = nullptr, *obs_y = nullptr, *obs_bbox = nullptr;
+    double *seg = nullptr; int32_t *seg_mask = nullptr;
+    TilePartial *partial = nullptr; char *red_scratch = nullptr; double2 *field_junc = nullptr;
 };
 
 struct fcpp_batch {
@@ -528,20 +188,14 @@ struct fcpp_batch {
     fcpp_vehicle veh;
     fcpp_options opt;
     int64_t n_fields = 0;
-    HostPlan hp;
+    HostPlan hp;               // info + field descriptors (the blocks' primitive lists are dropped once the image is built)
     DevConst cst;
-    DevBuf<DevField> fields;
-    DevBuf<DevPrim> prims;
-    DevTiling til;             // fused pipeline (mode 1): quiet runs, wave tiles, general tiles
+    void *slab = nullptr; size_t slab_bytes = 0;
+    ImageLayout lay;           // counts and offsets of the tables in the slab
+    FusedTables t;             // fused pipeline (mode 1): quiet runs, wave tiles, general tiles, reduction lists
     DevTiling til0;            // staged pipeline (mode 0): plain near-equal tiles, built on its first run
     bool til0_built = false;
-    DevBuf<int64_t> obs_off;
-    DevBuf<double> obs_x, obs_y, obs_bbox;
-    DevBuf<CacShape> shapes;   // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
-    DevBuf<double2> tmpl_u, tmpl_c, tmpl_u_dk;   // sampled turn templates (fcpp_fused.hip)
-    DevBuf<double2> field_junc;                  // per field: line-start curvature and jump length after a U-turn
-    DevBuf<double> seg;        // connector segments
-    DevBuf<int32_t> seg_mask;
+    std::shared_ptr<TemplateSet> templates;
     // optional per-stage HIP-event timing (fcpp_batch_set_profiling)
     int profiling = 0;           // 0: off; k > 0: every k-th run carries the per-kernel events
     int64_t run_counter = 0;
@@ -551,6 +205,8 @@ struct fcpp_batch {
     int last_mode = 0;
     bool partial_dirty = true;   // the fused pipeline's tile partials have not been zeroed yet
     bool two_streams = true;     // ALU-bound kernels of a step on the context's side stream (FCPP_ONE_STREAM=1 in the environment: off)
+    int two_stream_max = 512;    // ... when there are at most this many general tiles (FCPP_TWO_STREAM_MAX, read at batch creation)
+    fcpp_setup_times setup = {};
     ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 
@@ -668,6 +324,9 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     free_paths_cache(c);
+    if (c->stage) (void)hipHostFree(c->stage);
+    if (c->spare) (void)hipFree(c->spare);
+    c->templates.reset();
     delete c;
     return FCPP_OK;
 }
@@ -736,6 +395,44 @@ int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_
     return FCPP_OK;
 }
 
+// the context's turn templates for (tt, clothoid_frac): the kept set, or a new one sampled on the device (asynchronous: the caller
+// synchronises the stream before it reads the host copies; `fresh` tells it to)
+static int get_templates(fcpp_ctx *c, const TurnTemplates &tt, const fcpp_options &opt, hipStream_t st, std::shared_ptr<TemplateSet> &out, bool &fresh)
+{
+    fresh = false;
+    if (c->templates && c->templates->same(tt, opt.clothoid_frac)) { out = c->templates; return FCPP_OK; }
+    std::shared_ptr<TemplateSet> ts(new (std::nothrow) TemplateSet());
+    if (!ts) return fail(FCPP_ENOMEM, "out of host memory");
+    ts->tt = tt; ts->clothoid_frac = opt.clothoid_frac;
+    const int nu = tt.nu, nc = tt.nc;
+    std::vector<CacShape> shp = { make_cac_shape(kPi, opt.clothoid_frac), make_cac_shape(kHalfPi, opt.clothoid_frac) };
+    HIPCHK(ts->shapes.upload(shp, st));
+    HIPCHK(hipStreamSynchronize(st));             // (shp dies with this scope)
+    HIPCHK(ts->tmpl_u.alloc((size_t)nu));
+    HIPCHK(ts->tmpl_c.alloc((size_t)nc));
+    HIPCHK(ts->tmpl_u_dk.alloc((size_t)nu));
+    LAUNCHCHK(launch_build_templates(st, tt, ts->shapes.p, ts->tmpl_u.p, ts->tmpl_c.p));
+    LAUNCHCHK(launch_build_template_metrics(st, nu, ts->tmpl_u.p, ts->tmpl_u_dk.p));
+    ts->h_tu.resize((size_t)nu); ts->h_tc.resize((size_t)nc); ts->h_dk.resize((size_t)nu);
+    if (nu > 0) {
+        HIPCHK(hipMemcpyAsync(ts->h_tu.data(), ts->tmpl_u.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(ts->h_dk.data(), ts->tmpl_u_dk.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st));
+    }
+    if (nc > 0) HIPCHK(hipMemcpyAsync(ts->h_tc.data(), ts->tmpl_c.p, (size_t)nc * sizeof(double2), hipMemcpyDeviceToHost, st));
+    out = ts;
+    fresh = true;
+    return FCPP_OK;
+}
+
+namespace {
+constexpr size_t kStageMax = (size_t)2 << 30;      // pinned setup memory a context keeps at most
+constexpr size_t kSpareMax = (size_t)1 << 30;      // device allocation of a destroyed batch kept for the next one at most
+double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+}
+
 int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
                       const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **out)
 {
@@ -743,141 +440,142 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         return fail(FCPP_EINVAL, "bad arguments");
     if (n_fields > INT32_MAX) return fail(FCPP_ESIZE, "too many fields");
     *out = nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(c->device));
-    fcpp_batch *b = new (std::nothrow) fcpp_batch();
+    std::unique_ptr<fcpp_batch> b(new (std::nothrow) fcpp_batch());
     if (!b) return fail(FCPP_ENOMEM, "out of host memory");
     b->ctx = c; b->veh = *veh; b->opt = *opt; b->n_fields = n_fields;
     b->two_streams = getenv("FCPP_ONE_STREAM") == nullptr;
+    b->two_stream_max = std::max(0, std::min(tune_int("FCPP_TWO_STREAM_MAX", 512), 1 << 20));
+    fcpp_setup_times &tm = b->setup;
+    tm.threads = WorkerPool::width();
     std::string err;
-    int rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, true, b->hp, err);
-    if (rc != FCPP_OK) { delete b; return fail(rc, err); }
-    // obstacle references must stay inside the polygon table
-    const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
-    if (n_polys < 0 || n_polys > INT32_MAX) { delete b; return fail(FCPP_ESIZE, "bad polygon count"); }
-    if (n_polys > 0) {      // CSR table: offsets[0] = 0, non-decreasing, coordinates present
-        if (!obstacles->offsets || obstacles->offsets[0] != 0) { delete b; return fail(FCPP_ESIZE, "polygon offsets must start at 0"); }
-        for (int64_t k = 0; k < n_polys; ++k)
-            if (obstacles->offsets[k + 1] < obstacles->offsets[k]) { delete b; return fail(FCPP_ESIZE, "polygon offsets must be non-decreasing"); }
-        if (obstacles->offsets[n_polys] > 0 && (!obstacles->x || !obstacles->y)) { delete b; return fail(FCPP_EINVAL, "polygon coordinates are NULL"); }
-    }
-    for (int64_t i = 0; i < n_fields; ++i) {
-        if (fields[i].n_obstacles < 0 || fields[i].obstacle_first < 0 ||
-            (fields[i].n_obstacles > 0 && fields[i].obstacle_first + fields[i].n_obstacles > n_polys)) {
-            delete b;
-            return fail(FCPP_ESIZE, "field obstacle range outside the polygon table");
-        }
-    }
-    b->cst = make_const(*veh, *opt);
     hipStream_t st = c->stream;
-    std::vector<CacShape> shp = { make_cac_shape(kPi, opt->clothoid_frac), make_cac_shape(kHalfPi, opt->clothoid_frac) };
-    // turn templates first: the tiler needs to know whether the U-turns of this batch are closed form
-    hipError_t e = hipSuccess;
-    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
-    ok(b->shapes.upload(shp, st));
-    b->cst.shapes = b->shapes.p;
-    bool turn_quiet = false;
-    std::vector<double2> h_tu, h_tc;      // host copies of the turn templates (closed-form test, halos of the wave tiles)
-    if (e == hipSuccess) {
-        const int nu = b->hp.tt.nu;
-        ok(b->tmpl_u.alloc((size_t)nu)) && ok(b->tmpl_c.alloc((size_t)b->hp.tt.nc)) && ok(b->tmpl_u_dk.alloc((size_t)nu));
-        if (e == hipSuccess) {
-            int le = launch_build_templates(st, b->hp.tt, b->shapes.p, b->tmpl_u.p, b->tmpl_c.p);
-            if (le == 0) le = launch_build_template_metrics(st, nu, b->tmpl_u.p, b->tmpl_u_dk.p);
-            if (le != 0) e = (hipError_t)le;
+
+    // ---- 1. the turn templates go first: their two launches and the copy back run on the device while the host plans the fields
+    auto t0 = std::chrono::steady_clock::now();
+    bool fresh = false;
+    {
+        TurnTemplates tt;
+        int rc = plan_templates(*veh, *opt, tt, err);
+        if (rc != FCPP_OK) return fail(rc, err);
+        rc = get_templates(c, tt, *opt, st, b->templates, fresh);
+        if (rc != FCPP_OK) return rc;
+    }
+    tm.templates_ms = ms_since(t0);
+
+    // ---- 2. host plan: __init__ + the O(1) decisions of every field, blocks of fields side by side (fcpp_host.cpp)
+    t0 = std::chrono::steady_clock::now();
+    int rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, true, b->hp, err);
+    if (rc != FCPP_OK) { if (fresh) (void)hipStreamSynchronize(st); return fail(rc, err); }
+    tm.host_plan_ms = ms_since(t0);
+
+    // ---- 3. templates on the host; are the U-turns of this batch closed form?
+    t0 = std::chrono::steady_clock::now();
+    if (fresh) HIPCHK(hipStreamSynchronize(st));
+    c->templates = b->templates;
+    const TemplateSet &ts = *b->templates;
+    b->cst = make_const(*veh, *opt);
+    b->cst.shapes = ts.shapes.p;
+    b->cst.tmpl_u = ts.tmpl_u.p; b->cst.tmpl_c = ts.tmpl_c.p; b->cst.tmpl_u_dk = ts.tmpl_u_dk.p;
+    b->cst.tmpl_n = (int)ts.tt.nu; b->cst.tmpl_nc = std::max(1, (int)ts.tt.nc);
+    const bool turn_quiet = ts.tt.nu >= 3 && closed_form_turns(*veh, ts.tt, ts.h_tu, ts.h_dk, b->cst);
+    tm.templates_ms += ms_since(t0);
+
+    // ---- 4. tiler: every field's path cut into work for the four kernels, blocks side by side (fcpp_tiler.cpp)
+    t0 = std::chrono::steady_clock::now();
+    TileConsts tc;
+    tc.tu = reinterpret_cast<const Pt2 *>(ts.h_tu.data()); tc.tc = reinterpret_cast<const Pt2 *>(ts.h_tc.data());
+    tc.nu = ts.tt.nu; tc.nc = ts.tt.nc; tc.templates_ok = true;
+    tc.turn_quiet = turn_quiet;
+    tc.two_a = 2 * b->cst.a_lon; tc.u_cap = b->cst.u_cap; tc.c_line = b->cst.ms_work * b->cst.ms_work;
+    tc.fence_margin = 1e-3 + std::max(0.0, -opt->geofence_tol);
+    // (tuning knobs, read once per batch and clamped; both change which kernel plans a stretch or which reduction class a path falls
+    // into, i.e. the order of its sums at the last bit: diagnostic builds only)
+    tc.wave_factor = std::max(0, std::min(tune_int("FCPP_WAVE_FACTOR", 24), 64));
+    tc.reduce_wg_max = std::max(256, std::min(tune_int("FCPP_REDUCE_WG_MAX", 1024), 1 << 20));
+    BatchTiler tiler;
+    ImageLayout &lay = b->lay;
+    rc = tiler.plan(b->hp, tc, obstacles, lay, err);
+    if (rc != FCPP_OK) return fail(rc, err);
+    tm.tiler_ms = ms_since(t0);
+    if (getenv("FCPP_DEBUG_TILING"))
+        fprintf(stderr, "[fcpp] tiling: %lld tiles; wave-tile stretches refused: back halo %lld, forward halo %lld, too few outputs %lld, "
+                "primitive span %lld; %lld wave tiles, %lld of them inside the geofence by the host's test\n", (long long)lay.n_tiles,
+                (long long)lay.wave_fail[0], (long long)lay.wave_fail[1], (long long)lay.wave_fail[2], (long long)lay.wave_fail[3],
+                (long long)lay.n_wave, (long long)lay.wave_inside);
+
+    // ---- 5. the image: one device allocation (the context's spare if it is large enough), the tables written into pinned memory
+    t0 = std::chrono::steady_clock::now();
+    if (c->spare && c->spare_cap >= lay.total_bytes) { b->slab = c->spare; b->slab_bytes = c->spare_cap; c->spare = nullptr; c->spare_cap = 0; }
+    else {
+        hipError_t e = hipMalloc(&b->slab, std::max<size_t>(lay.total_bytes, 256));
+        if (e != hipSuccess) { b->slab = nullptr; return fail(FCPP_ENOMEM, std::string("batch tables: ") + hipGetErrorString(e)); }
+        b->slab_bytes = std::max<size_t>(lay.total_bytes, 256);
+    }
+    struct SlabGuard {       // (an error below must not leak the allocation)
+        fcpp_batch *b; bool armed = true;
+        ~SlabGuard() { if (armed && b->slab) { (void)hipFree(b->slab); b->slab = nullptr; } }
+    } guard{ b.get() };
+    unsigned char *img = nullptr;
+    std::vector<unsigned char> pageable;
+    if (lay.upload_bytes <= kStageMax) {
+        if (c->stage_cap < lay.upload_bytes) {
+            if (c->stage) { (void)hipHostFree(c->stage); c->stage = nullptr; c->stage_cap = 0; }
+            const size_t want = std::min(kStageMax, std::max<size_t>(lay.upload_bytes + lay.upload_bytes / 4, (size_t)1 << 20));
+            if (hipHostMalloc(&c->stage, want, hipHostMallocDefault) == hipSuccess) c->stage_cap = want;
+            else { c->stage = nullptr; (void)hipGetLastError(); }
         }
-        b->cst.tmpl_u = b->tmpl_u.p; b->cst.tmpl_c = b->tmpl_c.p; b->cst.tmpl_u_dk = b->tmpl_u_dk.p;
-        b->cst.tmpl_n = (int)nu; b->cst.tmpl_nc = std::max(1, (int)b->hp.tt.nc);
-        if (e == hipSuccess) {
-            const int nc = b->hp.tt.nc;
-            std::vector<double2> dk((size_t)nu);
-            h_tu.resize((size_t)nu); h_tc.resize((size_t)nc);
-            if (nu > 0) ok(hipMemcpyAsync(h_tu.data(), b->tmpl_u.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st)) &&
-                ok(hipMemcpyAsync(dk.data(), b->tmpl_u_dk.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st));
-            if (nc > 0) ok(hipMemcpyAsync(h_tc.data(), b->tmpl_c.p, (size_t)nc * sizeof(double2), hipMemcpyDeviceToHost, st));
-            ok(hipStreamSynchronize(st));
-            if (e == hipSuccess && nu >= 3) turn_quiet = closed_form_turns(*veh, b->hp.tt, h_tu, dk, b->cst);
+        if (c->stage_cap >= lay.upload_bytes) img = static_cast<unsigned char *>(c->stage);
+    }
+    if (!img) {
+        try { pageable.resize(lay.upload_bytes); } catch (const std::bad_alloc &) { return fail(FCPP_ENOMEM, "out of host memory"); }
+        img = pageable.data();
+    }
+    tiler.fill(b->hp, obstacles, lay, img);
+    {
+        unsigned char *d = static_cast<unsigned char *>(b->slab);
+        FusedTables &t = b->t;
+        t.fields = reinterpret_cast<DevField *>(d + lay.fields); t.prims = reinterpret_cast<DevPrim *>(d + lay.prims);
+        t.tiles = reinterpret_cast<DevTile *>(d + lay.tiles); t.wave_tiles = reinterpret_cast<DevWaveTile *>(d + lay.wtiles);
+        t.general_ids = reinterpret_cast<int32_t *>(d + lay.general_ids);
+        t.chunks = reinterpret_cast<DevTile *>(d + lay.chunks); t.span_chunks = reinterpret_cast<DevTile *>(d + lay.span_chunks);
+        t.stat_ids = reinterpret_cast<int32_t *>(d + lay.stat_ids); t.stat_first = reinterpret_cast<int64_t *>(d + lay.stat_first);
+        t.stat_run = reinterpret_cast<int64_t *>(d + lay.stat_run); t.red_paths = reinterpret_cast<int32_t *>(d + lay.red_paths);
+        if (lay.n_polys > 0) {
+            t.obs_off = reinterpret_cast<int64_t *>(d + lay.obs_off); t.obs_x = reinterpret_cast<double *>(d + lay.obs_x);
+            t.obs_y = reinterpret_cast<double *>(d + lay.obs_y); t.obs_bbox = reinterpret_cast<double *>(d + lay.obs_bbox);
         }
+        t.seg = reinterpret_cast<double *>(d + lay.seg); t.seg_mask = reinterpret_cast<int32_t *>(d + lay.seg_mask);
+        t.partial = reinterpret_cast<TilePartial *>(d + lay.partial); t.red_scratch = d ? reinterpret_cast<char *>(d + lay.red_scratch) : nullptr;
+        t.field_junc = reinterpret_cast<double2 *>(d + lay.field_junc);
     }
-    Tiling til;
-    std::vector<int64_t> offs((size_t)n_fields + 1, 0);
-    for (int64_t i = 0; i < n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
-    std::vector<Tiling::QuietInfo> qi((size_t)n_fields);
-    for (int64_t i = 0; i < n_fields; ++i) {
-        const DevField &df = b->hp.fields[(size_t)i];
-        Tiling::QuietInfo q;
-        q.n_line = df.n_line; q.n_turn = df.n_turn; q.P = df.P; q.n_main = df.n_main; q.gen_main = df.gen_main;
-        q.line_step_len = fabs(df.line_step); q.c_line = b->cst.ms_work * b->cst.ms_work;
-        q.prims = b->hp.prims.data() + df.prim_first; q.prim_count = df.prim_count; q.prim_index0 = df.prim_first;
-        q.two_a = 2 * b->cst.a_lon;
-        q.enable = df.n_total > 0;
-        // (fields narrower than 4R have line_end_x < line_start_x: their lines run against the jump from the previous turn, the
-        // first point of every line is clamped -- general kernel)
-        q.turn_quiet = turn_quiet && df.n_turn == b->hp.tt.nu && df.line_step > 0.0;
-        // wave tiles (fcpp_sparse.hip) where eight steps of a swath line already exceed the reach of the sweeps: the reference's
-        // own sampling and coarse uniform spacings; dense sampling keeps the eight-points-per-lane kernel
-        q.df = &df; q.tu = h_tu.data(); q.tc = h_tc.data(); q.u_cap = b->cst.u_cap;
-        q.fence_margin = 1e-3 + std::max(0.0, -opt->geofence_tol);
-        q.wave_ok = e == hipSuccess && df.n_turn == b->hp.tt.nu && (int)h_tc.size() == b->hp.tt.nc &&
-                    (double)tune_int("FCPP_WAVE_FACTOR", 24) * q.two_a * q.line_step_len >= b->cst.u_cap;
-        // (a sweep reaches at most u_cap / (2 a step) points: up to 24 halo lanes either side still leave 14 of a wave's 64 lanes for
-        // output, which beats the eight-points-per-lane kernel -- cfg2 at 0.5 m: 0.18 ms of k_plan_fused -> 0.04 ms of k_plan_sparse,
-        // step 1.41 -> 1.28 ms; at 0.25 m 2.77 -> 2.68 ms; finer sampling stays with k_plan_fused)
-        qi[(size_t)i] = q;
+    // (the primitives live in the image now; the host keeps the per-field records for fcpp_batch_info and the staged pipeline's tiling)
+    for (PlanBlock &blk : b->hp.blocks) std::vector<DevPrim>().swap(blk.prims);
+    std::vector<int32_t>().swap(b->hp.same_as);
+    tm.image_ms = ms_since(t0);
+    tm.image_bytes = (int64_t)lay.upload_bytes;
+
+    // ---- 6. one copy, the per-field junction constants, and the stream drained (the staging memory is the context's)
+    t0 = std::chrono::steady_clock::now();
+    if (lay.upload_bytes > 0) HIPCHK(hipMemcpyAsync(b->slab, img, lay.upload_bytes, hipMemcpyHostToDevice, st));
+    if (n_fields > 0) {
+        b->cst.field_junc = b->t.field_junc;
+        LAUNCHCHK(launch_field_junctions(st, n_fields, b->t.fields, b->cst, b->t.field_junc));
     }
-    til.build(n_fields, offs.data(), qi.data());
-    if (getenv("FCPP_DEBUG_TILING")) {
-        size_t n_inside = 0;
-        for (const DevWaveTile &w : til.wtiles) n_inside += w.inside;
-        fprintf(stderr, "[fcpp] tiling: %zu tiles; wave-tile stretches refused: back halo %lld, forward halo %lld, too few outputs %lld, "
-                "primitive span %lld; %zu wave tiles, %zu of them inside the geofence by the host's test\n", til.tiles.size(),
-                (long long)til.wave_fail[0], (long long)til.wave_fail[1], (long long)til.wave_fail[2], (long long)til.wave_fail[3],
-                til.wtiles.size(), n_inside);
-    }
-    ok(b->fields.upload(b->hp.fields, st)) && ok(b->prims.upload(b->hp.prims, st)) &&
-        ok(b->til.upload(til, st)) &&
-        ok(b->field_junc.alloc((size_t)n_fields));
-    if (e == hipSuccess && n_fields > 0) {
-        b->cst.field_junc = b->field_junc.p;
-        const int le = launch_field_junctions(st, n_fields, b->fields.p, b->cst, b->field_junc.p);
-        if (le != 0) e = (hipError_t)le;
-    }
-    if (e == hipSuccess && n_polys > 0) {
-        std::vector<int64_t> po(obstacles->offsets, obstacles->offsets + n_polys + 1);
-        const int64_t nv = po.back();
-        std::vector<double> px(obstacles->x, obstacles->x + nv), py(obstacles->y, obstacles->y + nv);
-        std::vector<double> bb((size_t)n_polys * 4);
-        for (int64_t k = 0; k < n_polys; ++k) {
-            double mnx = HUGE_VAL, mny = HUGE_VAL, mxx = -HUGE_VAL, mxy = -HUGE_VAL;
-            for (int64_t q = po[(size_t)k]; q < po[(size_t)k + 1]; ++q) {
-                mnx = std::min(mnx, px[(size_t)q]); mxx = std::max(mxx, px[(size_t)q]);
-                mny = std::min(mny, py[(size_t)q]); mxy = std::max(mxy, py[(size_t)q]);
-            }
-            bb[(size_t)k * 4] = mnx; bb[(size_t)k * 4 + 1] = mny; bb[(size_t)k * 4 + 2] = mxx; bb[(size_t)k * 4 + 3] = mxy;
-        }
-        ok(b->obs_off.upload(po, st)) && ok(b->obs_x.upload(px, st)) && ok(b->obs_y.upload(py, st)) && ok(b->obs_bbox.upload(bb, st)) &&
-            ok(hipStreamSynchronize(st));      // the staging vectors die with this block
-    }
-    if (e == hipSuccess) {
-        std::vector<double> seg((size_t)n_fields * 8, 0.0);
-        std::vector<int32_t> mask((size_t)n_fields * 2, 0);
-        for (int64_t i = 0; i < n_fields; ++i) {
-            const fcpp_field_info &in = b->hp.info[(size_t)i];
-            const bool okf = in.status == FCPP_OK;
-            double *s = &seg[(size_t)i * 4];
-            s[0] = in.approach_from[0]; s[1] = in.approach_from[1]; s[2] = in.approach_to[0]; s[3] = in.approach_to[1];
-            mask[(size_t)i] = okf && in.start_kept;
-            double *d = &seg[(size_t)(n_fields + i) * 4];
-            d[0] = in.departure_from[0]; d[1] = in.departure_from[1]; d[2] = in.departure_to[0]; d[3] = in.departure_to[1];
-            mask[(size_t)(n_fields + i)] = okf && in.end_kept;
-        }
-        ok(b->seg.upload(seg, st)) && ok(b->seg_mask.upload(mask, st)) && ok(hipStreamSynchronize(st));
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);   // host vectors above die at scope exit
-    if (e != hipSuccess) {
-        delete b;
-        return fail(FCPP_EHIP, std::string("batch upload: ") + hipGetErrorString(e));
-    }
-    *out = b;
+    HIPCHK(hipStreamSynchronize(st));
+    tm.h2d_ms = ms_since(t0);
+    tm.total_ms = ms_since(t_begin);
+    c->last_setup = tm;
+    guard.armed = false;
+    *out = b.release();
+    return FCPP_OK;
+}
+
+int fcpp_batch_setup_times(const fcpp_batch *b, fcpp_setup_times *out)
+{
+    if (!b || !out) return fail(FCPP_EINVAL, "bad arguments");
+    *out = b->setup;
     return FCPP_OK;
 }
 
@@ -914,9 +612,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         HIPCHK(b->til0.upload(t0, st));
         b->til0_built = true;
     }
-    DevTiling &t = mode == 0 ? b->til0 : b->til;
-    DevObstacles obs = { b->obs_off.p, b->obs_x.p, b->obs_y.p, b->obs_bbox.p };
-    if (mode == 0) HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
+    DevObstacles obs = { b->t.obs_off, b->t.obs_x, b->t.obs_y, b->t.obs_bbox };
     hipEvent_t *ev = nullptr;
     unsigned char *evs = nullptr;
     if (b->profiling > 0 && b->prof_runs < kProfRuns && (b->run_counter++ % b->profiling) == 0) {
@@ -932,8 +628,10 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         if (e_ != 0) return fail(FCPP_EHIP, std::string(#call) + ": " + hipGetErrorString((hipError_t)e_)); \
     } while (0)
     if (mode == 1) {
+        const FusedTables &t = b->t;
+        const ImageLayout &lay = b->lay;
         if (b->partial_dirty) {   // slots of quiet tiles that are not the first of their run stay zero from here on
-            HIPCHK(hipMemsetAsync(t.partial.p, 0, (size_t)t.n_tiles * sizeof(TilePartial), st));
+            if (lay.n_tiles > 0) HIPCHK(hipMemsetAsync(t.partial, 0, (size_t)lay.n_tiles * sizeof(TilePartial), st));
             b->partial_dirty = false;
         }
         // Two streams inside the step where the general tiles are FEW and long-lived (dense sampling of a single large field: a dozen
@@ -944,50 +642,52 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // and 0.091 vs 0.085 ms, k_plan_sparse 1.07 instead of 0.69 ms; also with the span kernel held to four or five
         // waves per SIMD).
         hipStream_t sd = st;
-        const bool two = b->two_streams && t.span_points + t.chunk_points > 0 && t.n_general > 0 && t.n_general <= tune_int("FCPP_TWO_STREAM_MAX", 512) &&
-                         t.n_wave == 0;
+        const bool two = b->two_streams && lay.span_points + lay.chunk_points > 0 && lay.n_general > 0 && lay.n_general <= b->two_stream_max &&
+                         lay.n_wave == 0;
         if (two) {
             sd = b->ctx->side;
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(sd, b->ctx->ev_fork, 0));
         }
-        STAGE(2, launch_plan_sparse(sd, t.n_wave, t.wave_tiles.p, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
-        STAGE(3, launch_plan_fused(sd, variant, t.n_general, t.general_ids.p, t.tiles.p, b->fields.p, b->prims.p, b->cst, obs, x,
-                                   y, kappa, v, fs, t.partial.p));
+        STAGE(2, launch_plan_sparse(sd, lay.n_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
+        STAGE(3, launch_plan_fused(sd, variant, lay.n_general, t.general_ids, t.tiles, t.fields, t.prims, b->cst, obs, x,
+                                   y, kappa, v, fs, t.partial));
         if (two) HIPCHK(hipEventRecord(b->ctx->ev_join, sd));
-        STAGE(0, launch_plan_quiet(st, t.n_span_chunks, t.span_chunks.p, 16, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(0, launch_plan_quiet(st, lay.n_span_chunks, t.span_chunks, 16, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
-        STAGE(1, launch_plan_quiet(st, t.n_chunks, t.chunks.p, 14, b->fields.p, b->prims.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+        STAGE(1, launch_plan_quiet(st, lay.n_chunks, t.chunks, 14, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
         // (four classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
         // time the first launch)
         {
             const int groups[4] = { 8, 64, 256, 256 };     // (16 or 32 lanes for the first class: 49 -> 53 / 79 us on cfg5)
-            const int32_t *pl = t.red_paths.p;
+            const int32_t *pl = t.red_paths;
             bool first = true;
             for (int c = 0; c < 4; ++c) {
-                if (t.n_red[c] == 0) continue;
+                if (lay.n_red[c] == 0) continue;
                 // (a class that holds every path lists them in order: no list, one dependent load less in a latency-bound kernel)
-                const int32_t *list = t.n_red[c] == t.n_paths ? nullptr : pl;
+                const int32_t *list = lay.n_red[c] == lay.n_fields ? nullptr : pl;
                 if (first)
-                    STAGE(4, launch_reduce_stats(st, t.n_red[c], t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.stat_run.p, t.tiles.p,
-                                                 b->fields.p, b->prims.p, &b->cst, list, groups[c], c == 3 ? t.red_scratch.p : nullptr));
+                    STAGE(4, launch_reduce_stats(st, lay.n_red[c], t.partial, t.stat_first, nullptr, stats, t.stat_ids, t.stat_run, t.tiles,
+                                                 t.fields, t.prims, &b->cst, list, groups[c], c == 3 ? t.red_scratch : nullptr));
                 else
-                    LAUNCHCHK(launch_reduce_stats(st, t.n_red[c], t.partial.p, t.stat_first.p, nullptr, stats, t.stat_ids.p, t.stat_run.p, t.tiles.p,
-                                                  b->fields.p, b->prims.p, &b->cst, list, groups[c], c == 3 ? t.red_scratch.p : nullptr));
+                    LAUNCHCHK(launch_reduce_stats(st, lay.n_red[c], t.partial, t.stat_first, nullptr, stats, t.stat_ids, t.stat_run, t.tiles,
+                                                  t.fields, t.prims, &b->cst, list, groups[c], c == 3 ? t.red_scratch : nullptr));
                 first = false;
-                pl += t.n_red[c];
+                pl += lay.n_red[c];
             }
         }
         if (ev) ++b->prof_runs;
         return FCPP_OK;
     }
-    STAGE(0, launch_generate(st, t.n_tiles, t.tiles.p, b->fields.p, b->prims.p, b->cst, x, y, v, fs));
+    DevTiling &t = b->til0;
+    HIPCHK(hipMemsetAsync(t.n_adj.p, 0, (size_t)t.n_paths * sizeof(unsigned long long), st));
+    STAGE(0, launch_generate(st, t.n_tiles, t.tiles.p, b->t.fields, b->t.prims, b->cst, x, y, v, fs));
     STAGE(1, launch_curv_clamp(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 1, x, y, v, v, kappa, t.n_adj.p));
     STAGE(2, launch_scan_tiles(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, x, y, v, t.agg_f.p, t.agg_b.p));
     STAGE(3, launch_scan_spine(st, t.n_tiles, t.agg_f.p, t.agg_b.p, t.carry_f.p, t.carry_b.p, t.spine.p));
     STAGE(4, launch_scan_apply(st, t.n_tiles, t.tiles.p, t.paths.p, b->cst, 3, x, y, v, v, t.carry_f.p, t.carry_b.p));
-    STAGE(5, launch_validate(st, t.n_tiles, t.tiles.p, t.paths.p, b->fields.p, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
+    STAGE(5, launch_validate(st, t.n_tiles, t.tiles.p, t.paths.p, b->t.fields, b->cst, obs, x, y, kappa, v, fs, t.partial.p));
     STAGE(6, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, t.n_adj.p, stats));
 #undef STAGE
     if (ev) ++b->prof_runs;
@@ -1033,7 +733,7 @@ int fcpp_batch_stage_times(fcpp_batch *b, int max_stages, double *ms_sum, int *n
 int fcpp_batch_stage_points(const fcpp_batch *b, int mode, int stage, int64_t *points)
 {
     if (!b || !points || mode < 0 || mode > 1 || stage < 0 || stage >= kStageCount[mode]) return fail(FCPP_EINVAL, "bad arguments");
-    const DevTiling &t = b->til;
+    const ImageLayout &t = b->lay;
     const int64_t all = b->hp.total_points;
     if (mode == 0) { *points = all; return FCPP_OK; }         // every staged kernel sees every point
     const int64_t per_stage[5] = { t.span_points, t.chunk_points, t.wave_points, all - t.quiet_points - t.wave_points, all };
@@ -1044,7 +744,7 @@ int fcpp_batch_stage_points(const fcpp_batch *b, int mode, int stage, int64_t *p
 int fcpp_batch_point_split(const fcpp_batch *b, int64_t *quiet_points, int64_t *general_points)
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
-    const int64_t q = b->til.quiet_points;
+    const int64_t q = b->lay.quiet_points;
     if (quiet_points) *quiet_points = q;
     if (general_points) *general_points = b->hp.total_points - q;
     return FCPP_OK;
@@ -1053,7 +753,7 @@ int fcpp_batch_point_split(const fcpp_batch *b, int64_t *quiet_points, int64_t *
 int fcpp_batch_reduce_classes(const fcpp_batch *b, int64_t *classes_out)
 {
     if (!b || !classes_out) return fail(FCPP_EINVAL, "bad arguments");
-    for (int c = 0; c < 4; ++c) classes_out[c] = b->til.n_red[c];
+    for (int c = 0; c < 4; ++c) classes_out[c] = b->lay.n_red[c];
     return FCPP_OK;
 }
 
@@ -1068,17 +768,26 @@ int fcpp_batch_connectors(fcpp_batch *b, double *approach_xy, double *departure_
     if (b->n_fields == 0) return FCPP_OK;
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
-    if (approach_xy) LAUNCHCHK(launch_straight(st, b->n_fields, b->seg.p, 50, b->seg_mask.p, approach_xy));
+    if (approach_xy) LAUNCHCHK(launch_straight(st, b->n_fields, b->t.seg, 50, b->t.seg_mask, approach_xy));
     if (departure_xy)
-        LAUNCHCHK(launch_straight(st, b->n_fields, b->seg.p + 4 * b->n_fields, 50, b->seg_mask.p + b->n_fields, departure_xy));
+        LAUNCHCHK(launch_straight(st, b->n_fields, b->t.seg + 4 * b->n_fields, 50, b->t.seg_mask + b->n_fields, departure_xy));
     return FCPP_OK;
 }
 
 int fcpp_batch_destroy(fcpp_batch *b)
 {
     if (!b) return FCPP_OK;
-    (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    fcpp_ctx *c = b->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (b->slab) {      // the larger of this allocation and the context's spare stays for the next batch
+        if (b->slab_bytes <= kSpareMax && b->slab_bytes > c->spare_cap) {
+            if (c->spare) (void)hipFree(c->spare);
+            c->spare = b->slab; c->spare_cap = b->slab_bytes;
+        } else (void)hipFree(b->slab);
+        b->slab = nullptr;
+    }
     delete b;
     return FCPP_OK;
 }

@@ -10,6 +10,7 @@
 // generator handles meaningfully): mitre inset, area centroid, bounds.  GEOS-specific values are
 // not reproducible here (DESIGN.md "parity unpinned").
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -17,6 +18,7 @@
 
 #include "fcpp_geom.h"
 #include "fcpp_internal.h"
+#include "fcpp_parallel.h"
 
 namespace fcpp {
 namespace {
@@ -39,8 +41,10 @@ double area_centroid(const Quad &q, double &cx, double &cy)
     return a;
 }
 
-// Polygon.buffer(-d) for a convex quadrilateral: mitre inset, vertex order kept.  false = empty.
-bool inset(const Quad &q, double d, Quad &o)
+// Polygon.buffer(-d) for a convex quadrilateral: mitre inset, vertex order kept.  The directions along which the vertices move do
+// not depend on d: a field computes them once (four insets per field: the work area and the headland loops).
+struct Mitre { double sx[4], sy[4], den[4]; };
+void mitre_of(const Quad &q, Mitre &m)
 {
     double cx, cy;
     const double sgn = area_centroid(q, cx, cy) > 0 ? 1.0 : -1.0;
@@ -53,9 +57,16 @@ bool inset(const Quad &q, double d, Quad &o)
     }
     for (int i = 0; i < 4; ++i) {
         int p = (i + 3) & 3;
-        double den = 1.0 + (nx[p] * nx[i] + ny[p] * ny[i]);
-        o.x[i] = q.x[i] + d * (nx[p] + nx[i]) / den;
-        o.y[i] = q.y[i] + d * (ny[p] + ny[i]) / den;
+        m.den[i] = 1.0 + (nx[p] * nx[i] + ny[p] * ny[i]);
+        m.sx[i] = nx[p] + nx[i]; m.sy[i] = ny[p] + ny[i];
+    }
+}
+// false = empty
+bool inset(const Quad &q, const Mitre &m, double d, Quad &o)
+{
+    for (int i = 0; i < 4; ++i) {
+        o.x[i] = q.x[i] + d * m.sx[i] / m.den[i];
+        o.y[i] = q.y[i] + d * m.sy[i] / m.den[i];
     }
     for (int i = 0; i < 4; ++i) {
         int j = (i + 1) & 3;
@@ -136,10 +147,19 @@ double distance_to_boundary(double x, double y, double dx, double dy, double L, 
 
 const int kCornerQuadrant[4] = { 1, 2, 3, 0 };  // start heading of the corner arcs = q * pi/2 (MLP:1049-1060)
 
-}  // namespace
+// everything about a batch that does not depend on the field: validated parameters, turn shapes, sample counts
+struct PlanConsts {
+    const fcpp_vehicle *veh; const fcpp_options *opt;
+    double W, R, ds;
+    bool clip, cloth;
+    CacShape sh_pi, sh_half;
+    double Re_pi, Re_half, len_uturn, len_corner, gap_lb;
+    // the last two samples of a corner turn (the reverse fill leaves along their chord): angle / arc length and, for arcs, cos and sin
+    int64_t nt_corner;
+    double arc_step, arc_c1, arc_s1, arc_c2, arc_s2;
+};
 
-int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
-                    bool want_device, HostPlan &out, std::string &err)
+int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c, TurnTemplates &tt, std::string &err)
 {
     const double W = veh.working_width, R = veh.min_turn_radius, ds = opt.sample_spacing;
     if (!(W > 0) || !(R > 0) || !(ds >= 0) || !(opt.clothoid_frac >= 0 && opt.clothoid_frac <= 1) ||
@@ -148,7 +168,6 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         err = "invalid vehicle parameters or options";
         return FCPP_EINVAL;
     }
-    const bool clip = opt.obstacle_mode == FCPP_OBSTACLES_AVOID;
     if (!(veh.max_longitudinal_accel > 0) || !(veh.max_lateral_accel > 0)) {
         err = "accelerations must be positive";
         return FCPP_EINVAL;
@@ -161,49 +180,64 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
             if (!isfinite(v)) { err = "vehicle parameters and options must be finite"; return FCPP_EINVAL; }
         if (W < 1e-6 || R < 1e-6 || (ds > 0 && ds < 1e-9)) { err = "working width, turn radius or sample spacing too small"; return FCPP_EINVAL; }
     }
-    const bool cloth = opt.turn_model == FCPP_TURN_CLOTHOID;
-    CacShape sh_pi = make_cac_shape(kPi, opt.clothoid_frac), sh_half = make_cac_shape(kHalfPi, opt.clothoid_frac);
+    c.veh = &veh; c.opt = &opt; c.W = W; c.R = R; c.ds = ds;
+    c.clip = opt.obstacle_mode == FCPP_OBSTACLES_AVOID;
+    c.cloth = opt.turn_model == FCPP_TURN_CLOTHOID;
+    c.sh_pi = make_cac_shape(kPi, opt.clothoid_frac); c.sh_half = make_cac_shape(kHalfPi, opt.clothoid_frac);
     auto fit_radius = [&](const CacShape &sh) {
         if (!opt.clothoid_fit) return R;
         return R * (2 * sin(sh.D / 2)) / sqrt(sh.ex * sh.ex + sh.ey * sh.ey);
     };
-    const double Re_pi = cloth ? fit_radius(sh_pi) : R, Re_half = cloth ? fit_radius(sh_half) : R;
-    const double len_uturn = cloth ? sh_pi.T * Re_pi : kPi * R;
-    const double len_corner = cloth ? sh_half.T * Re_half : kHalfPi * R;
+    c.Re_pi = c.cloth ? fit_radius(c.sh_pi) : R; c.Re_half = c.cloth ? fit_radius(c.sh_half) : R;
+    c.len_uturn = c.cloth ? c.sh_pi.T * c.Re_pi : kPi * R;
+    c.len_corner = c.cloth ? c.sh_half.T * c.Re_half : kHalfPi * R;
     // gap.area > 0.1 (MLP:1070): 2R x 2R square minus the arc buffered by W/2.  The buffer's area is at
     // most (pi R/2) W + pi W^2/4, so the decision is certain when this lower bound exceeds 0.1.
-    const double gap_lb = 4 * R * R - (kPi * R / 2 * W + kPi * W * W / 4);
-
-    {   // turn templates (same sample counts as every field computes below)
-        TurnTemplates &tt = out.tt;
-        memset(&tt, 0, sizeof(tt));
-        tt.turn_model = opt.turn_model; tt.R = R;
-        tt.nu = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(len_uturn, ds) : 20, INT32_MAX);
-        tt.nc = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(len_corner, ds) : 15, INT32_MAX);
-        tt.u_end = cloth ? sh_pi.T * Re_pi : kPi; tt.u_step = lin_step(0.0, tt.u_end, tt.nu); tt.u_Re = Re_pi;
-        tt.c_end = cloth ? sh_half.T * Re_half : kHalfPi; tt.c_step = lin_step(0.0, tt.c_end, tt.nc); tt.c_Re = Re_half;
+    c.gap_lb = 4 * R * R - (kPi * R / 2 * W + kPi * W * W / 4);
+    c.nt_corner = ds > 0 ? n_for_length(c.len_corner, ds) : 15;
+    c.arc_step = lin_step(0.0, kHalfPi, c.nt_corner);
+    {
+        const double th1 = linspace_at(0.0, kHalfPi, c.arc_step, c.nt_corner, c.nt_corner - 1);
+        const double th2 = linspace_at(0.0, kHalfPi, c.arc_step, c.nt_corner, c.nt_corner - 2);
+        c.arc_c1 = cos(th1); c.arc_s1 = sin(th1); c.arc_c2 = cos(th2); c.arc_s2 = sin(th2);
     }
-    out.info.assign((size_t)n, fcpp_field_info());
-    out.fields.clear(); out.prims.clear();
-    if (want_device) out.fields.reserve((size_t)n);
-    int64_t pt_off = 0;
+    // turn templates (same sample counts as every field computes)
+    memset(&tt, 0, sizeof(tt));
+    tt.turn_model = opt.turn_model; tt.R = R;
+    tt.nu = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(c.len_uturn, ds) : 20, INT32_MAX);
+    tt.nc = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(c.len_corner, ds) : 15, INT32_MAX);
+    tt.u_end = c.cloth ? c.sh_pi.T * c.Re_pi : kPi; tt.u_step = lin_step(0.0, tt.u_end, tt.nu); tt.u_Re = c.Re_pi;
+    tt.c_end = c.cloth ? c.sh_half.T * c.Re_half : kHalfPi; tt.c_step = lin_step(0.0, tt.c_end, tt.nc); tt.c_Re = c.Re_half;
+    return FCPP_OK;
+}
 
-    for (int64_t fi = 0; fi < n; ++fi) {
-        const fcpp_field &f = fields[fi];
-        fcpp_field_info &in = out.info[(size_t)fi];
-        memset(&in, 0, sizeof(in));
-        in.point_offset = pt_off;
-        DevField df;
-        memset(&df, 0, sizeof(df));
-        df.pt_off = pt_off;
-        auto fail = [&](int code) {
-            in.status = code; in.n_main = in.n_head = 0;
-            if (want_device) { df.n_main = df.n_total = 0; out.fields.push_back(df); }
-        };
+// One field: __init__ + the O(1) decisions of plan_complete_coverage.  Fills `in` (point_offset stays 0) and, with want_device, `df`
+// (pt_off 0, prim_first = index into `prims`, to which the field's primitives are appended).  A field that raises gets in.status < 0
+// and no points.  -> points of the field.
+int64_t plan_field(const PlanConsts &pc, const fcpp_field &f, const fcpp_polys *polys, bool want_device, fcpp_field_info &in, DevField &df,
+                   std::vector<DevPrim> &prims)
+{
+    const fcpp_vehicle &veh = *pc.veh;
+    const fcpp_options &opt = *pc.opt;
+    const double W = pc.W, R = pc.R, ds = pc.ds;
+    const bool clip = pc.clip, cloth = pc.cloth;
+    const CacShape &sh_pi = pc.sh_pi, &sh_half = pc.sh_half;
+    const double Re_pi = pc.Re_pi, Re_half = pc.Re_half, len_uturn = pc.len_uturn, gap_lb = pc.gap_lb;
+    memset(&in, 0, sizeof(in));
+    memset(&df, 0, sizeof(df));
+    const size_t prim_mark = prims.size();
+    auto fail = [&](int code) -> int64_t {
+        in.status = code; in.n_main = in.n_head = 0;
+        memset(in.n_reverse, 0, sizeof(in.n_reverse));
+        df.n_main = df.n_total = 0; df.gen_main = 0; df.prim_first = (int32_t)prim_mark; df.prim_count = 0;
+        prims.resize(prim_mark);
+        return 0;
+    };
+    {
         Quad q;
         bool finite = true;
         for (int i = 0; i < 4; ++i) { q.x[i] = f.vx[i]; q.y[i] = f.vy[i]; finite = finite && isfinite(q.x[i]) && isfinite(q.y[i]); }
-        if (!finite || !is_convex(q)) { fail(FCPP_EUNSUPPORTED); continue; }
+        if (!finite || !is_convex(q)) { return fail(FCPP_EUNSUPPORTED); }
 
         // ---- __init__ (MLP:109-135, 137-163, 310, 322-343)
         double bminx = q.x[0], bmaxx = q.x[0], bminy = q.y[0], bmaxy = q.y[0];
@@ -242,7 +276,9 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
 
         // ---- layer 1 frame (MLP:591-611, 670-718)
         Quad mq;
-        if (!inset(q, hw, mq) || abs_area(mq) < 1.0) { fail(FCPP_EINVAL); continue; }
+        Mitre mit;
+        mitre_of(q, mit);
+        if (!inset(q, mit, hw, mq) || abs_area(mq) < 1.0) { return fail(FCPP_EINVAL); }
         const double rot = atan2(q.y[1] - q.y[0], q.x[1] - q.x[0]);
         in.rotation_angle = rot;
         const bool rotated = fabs(rot) > 0.01;
@@ -274,11 +310,11 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         const int64_t n_line = ds > 0 ? n_for_length(fabs(lex - lsx), ds) : 2;
         const int64_t n_turn = ds > 0 ? n_for_length(len_uturn, ds) : 20;
         // (the swath index lives in bits 8..31 of the flag / segment word)
-        if (P >= ((int64_t)1 << (32 - FCPP_INDEX_SHIFT)) || n_line + n_turn > INT32_MAX - 2 * TILE_POINTS) { fail(FCPP_ESIZE); continue; }
+        if (P >= ((int64_t)1 << (32 - FCPP_INDEX_SHIFT)) || n_line + n_turn > INT32_MAX - 2 * TILE_POINTS) { return fail(FCPP_ESIZE); }
         in.n_swaths = (int32_t)P;
         int64_t n_main = P * n_line + (P - 1) * n_turn;
         df.gen_main = n_main;
-        df.prim_first = (int32_t)out.prims.size();
+        df.prim_first = (int32_t)prims.size();
         if (clip) {
             // ---- obstacle-aware swaths (include/fcpp.h): layer 1 as a list of primitives -- sub-swaths, detour legs, U-turns
             struct Box { double x0, y0, x1, y1; };
@@ -298,12 +334,12 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
                 b.x0 -= W / 2; b.y0 -= W / 2; b.x1 += W / 2; b.y1 += W / 2;
                 boxes.push_back(b);
             }
-            if (bad_obs) { fail(FCPP_ESIZE); continue; }
+            if (bad_obs) { return fail(FCPP_ESIZE); }
             const double rc = cos(rot), rs = sin(rot);
             const double lo = std::min(lsx, lex), hi = std::max(lsx, lex);
             int64_t pos1 = 0;
             bool unsupported = false;
-            auto push1 = [&](DevPrim &pr) { pr.start = pos1; pos1 += pr.n; if (want_device) out.prims.push_back(pr); };
+            auto push1 = [&](DevPrim &pr) { pr.start = pos1; pos1 += pr.n; if (want_device) prims.push_back(pr); };
             auto world = [&](double &x, double &y) { if (rotated) rotate_point(x, y, rc, rs, ccx, ccy, x, y); };
             auto push_line = [&](double ax, double ay, double bx, double by, uint32_t kind, int64_t pi, double vnom, bool detour) {
                 const double len = sqrt((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
@@ -358,9 +394,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
                 }
             }
             if (unsupported) {
-                if (want_device) out.prims.resize((size_t)df.prim_first);
-                fail(FCPP_EUNSUPPORTED);
-                continue;
+                return fail(FCPP_EUNSUPPORTED);
             }
             n_main = pos1;
             df.gen_main = 0;
@@ -385,11 +419,11 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         int64_t pos = n_main;
         bool bad = false;
         double first_head[2] = { 0, 0 }, last_head[2] = { 0, 0 };
-        auto push = [&](DevPrim &p) { p.start = pos; pos += p.n; if (want_device) out.prims.push_back(p); };
+        auto push = [&](DevPrim &p) { p.start = pos; pos += p.n; if (want_device) prims.push_back(p); };
         for (int loop = 0; loop < num_loops && !bad; ++loop) {
             const double offset = W / 2 + loop * W;
             Quad c;
-            if (!inset(q, offset, c) || abs_area(c) < 1.0) { bad = true; break; }
+            if (!inset(q, mit, offset, c) || abs_area(c) < 1.0) { bad = true; break; }
             const uint32_t lp = FCPP_FLAG_HEADLAND | ((uint32_t)(loop * 8) << FCPP_INDEX_SHIFT);
             DevPrim p;
             memset(&p, 0, sizeof(p));
@@ -402,7 +436,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
                 const int cur = (sci + i) & 3, nxt = (sci + i + 1) & 3;
                 const double seg_len = hypot(c.x[nxt] - c.x[cur], c.y[nxt] - c.y[cur]);
                 const int64_t ns = ds > 0 ? n_for_length(seg_len, ds) : 20;
-                const int64_t nt = ds > 0 ? n_for_length(len_corner, ds) : 15;
+                const int64_t nt = pc.nt_corner;
                 if (ns > INT32_MAX || nt > INT32_MAX) { bad = true; break; }
                 memset(&p, 0, sizeof(p));
                 p.kind = PRIM_LINSPACE; p.n = (int32_t)ns; p.v_nom = veh.max_headland_speed_kmh;
@@ -420,11 +454,9 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
                 if (!cloth) {
                     p.kind = PRIM_ARC; p.form = nxt;
                     p.a[0] = c.x[nxt]; p.a[1] = c.y[nxt]; p.a[2] = R; p.a[3] = kHalfPi;
-                    p.a[4] = lin_step(0.0, kHalfPi, nt);
-                    const double th1 = linspace_at(0.0, kHalfPi, p.a[4], nt, nt - 1);
-                    const double th2 = linspace_at(0.0, kHalfPi, p.a[4], nt, nt - 2);
-                    corner_arc_point(nxt, c.x[nxt], c.y[nxt], R, cos(th1), sin(th1), e1[0], e1[1]);
-                    corner_arc_point(nxt, c.x[nxt], c.y[nxt], R, cos(th2), sin(th2), e2[0], e2[1]);
+                    p.a[4] = pc.arc_step;
+                    corner_arc_point(nxt, c.x[nxt], c.y[nxt], R, pc.arc_c1, pc.arc_s1, e1[0], e1[1]);
+                    corner_arc_point(nxt, c.x[nxt], c.y[nxt], R, pc.arc_c2, pc.arc_s2, e2[0], e2[1]);
                 } else {
                     p.kind = PRIM_CAC; p.form = kCornerQuadrant[nxt];
                     const double T = sh_half.T * Re_half;
@@ -458,11 +490,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
             }
         }
         if (bad) {
-            if (want_device) out.prims.resize((size_t)df.prim_first);
-            int code = in.status ? in.status : FCPP_EHEADLAND;
-            memset(in.n_reverse, 0, sizeof(in.n_reverse));
-            fail(code);
-            continue;
+            return fail(in.status ? in.status : FCPP_EHEADLAND);
         }
         in.n_head = pos - n_main;
         if (has_start) {   // MLP:437-441
@@ -475,7 +503,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         }
         if (want_device) {
             df.n_total = pos;
-            df.prim_count = (int32_t)out.prims.size() - df.prim_first;
+            df.prim_count = (int32_t)prims.size() - df.prim_first;
             df.obs_first = (int32_t)f.obstacle_first; df.obs_count = f.n_obstacles;
             // geofence half-planes: inside <=> ex*px + ey*py + eo >= -tol
             double cx, cy;
@@ -487,19 +515,148 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
                 df.ex[i] = -ey / ln * sgn; df.ey[i] = ex / ln * sgn;
                 df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
             }
-            out.fields.push_back(df);
         }
-        if (pos > kCountCap || pt_off > kCountCap) {          // (2^40 points = 40 TB of output: no batch gets there)
-            err = "batch too large";
-            return FCPP_ESIZE;
+        return pos;
+    }
+}
+
+// what decides a field's plan besides the vehicle and the options: its constructor arguments (the obstacle list only matters for
+// obstacle-aware swaths; such fields are never shared)
+struct FieldKey {
+    double v[12];
+    int32_t from_vertices, has_start, has_end;
+    bool operator==(const FieldKey &o) const { return memcmp(this, &o, sizeof(FieldKey)) == 0; }
+};
+FieldKey key_of(const fcpp_field &f)
+{
+    FieldKey k;
+    memset(&k, 0, sizeof(k));
+    for (int i = 0; i < 4; ++i) { k.v[i] = f.vx[i]; k.v[4 + i] = f.vy[i]; }
+    k.has_start = f.has_start != 0; k.has_end = f.has_end != 0;
+    if (k.has_start) { k.v[8] = f.start_x; k.v[9] = f.start_y; }
+    if (k.has_end) { k.v[10] = f.end_x; k.v[11] = f.end_y; }
+    k.from_vertices = f.from_vertices != 0;
+    return k;
+}
+uint64_t hash_of(const FieldKey &k)
+{
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&k);
+    uint64_t w;
+    for (size_t i = 0; i + 8 <= sizeof(FieldKey); i += 8) { memcpy(&w, p + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 29; }
+    return h;
+}
+
+}  // namespace
+
+int plan_templates(const fcpp_vehicle &veh, const fcpp_options &opt, TurnTemplates &tt, std::string &err)
+{
+    PlanConsts pc;
+    return plan_prepare(veh, opt, pc, tt, err);
+}
+
+int validate_polys(const fcpp_polys *polys, std::string &err)
+{
+    if (!polys) return FCPP_OK;
+    const int64_t n = polys->n_polys;
+    if (n < 0 || n > INT32_MAX) { err = "bad polygon count"; return FCPP_ESIZE; }
+    if (n == 0) return FCPP_OK;
+    if (!polys->offsets || polys->offsets[0] != 0) { err = "polygon offsets must start at 0"; return FCPP_ESIZE; }
+    for (int64_t k = 0; k < n; ++k)
+        if (polys->offsets[k + 1] < polys->offsets[k]) { err = "polygon offsets must be non-decreasing"; return FCPP_ESIZE; }
+    if (polys->offsets[n] > 0 && (!polys->x || !polys->y)) { err = "polygon coordinates are NULL"; return FCPP_EINVAL; }
+    return FCPP_OK;
+}
+
+int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
+                    bool want_device, HostPlan &out, std::string &err)
+{
+    PlanConsts pc;
+    int rc = plan_prepare(veh, opt, pc, out.tt, err);
+    if (rc != FCPP_OK) return rc;
+    // the polygon table is checked before any field dereferences it (obstacle-aware swaths read it on the host)
+    if ((rc = validate_polys(polys, err)) != FCPP_OK) return rc;
+    const int64_t n_polys = polys ? polys->n_polys : 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (fields[i].n_obstacles < 0 || fields[i].obstacle_first < 0 ||
+            (fields[i].n_obstacles > 0 && fields[i].obstacle_first + fields[i].n_obstacles > n_polys)) {
+            // (without a table -- fcpp_plan_count(..., NULL, ...) in the reference's mode -- the ranges are not used by anything)
+            if (polys || pc.clip) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
         }
-        if (out.prims.size() > ((size_t)1 << 26)) {           // (primitive indices are 32-bit; 2^26 records are 7 GB of host memory)
+    out.info.assign((size_t)n, fcpp_field_info());
+    out.fields.clear(); out.blocks.clear();
+    if (want_device) out.fields.resize((size_t)n);
+    out.same_as.clear();
+    if (want_device) out.same_as.assign((size_t)n, -1);
+    const int64_t nb = (n + PLAN_BLOCK_FIELDS - 1) / PLAN_BLOCK_FIELDS;
+    out.blocks.resize((size_t)nb);
+    std::vector<int64_t> block_points((size_t)nb, 0);
+    const bool share = getenv("FCPP_NO_SHARE") == nullptr;      // (diagnostic: plan every field on its own; tests/native/tiler_check_driver.cpp)
+
+    // ---- the blocks, side by side: every block plans its fields into its own primitive list; point offsets and primitive indices are
+    // relative to the block until the bases are known
+    WorkerPool::parallel_for(nb, [&](int64_t b) {
+        PlanBlock &blk = out.blocks[(size_t)b];
+        blk.f0 = b * PLAN_BLOCK_FIELDS; blk.f1 = std::min(n, blk.f0 + PLAN_BLOCK_FIELDS);
+        // fields with the same constructor arguments (a batch of equal fields is the headline workload) are planned once per block:
+        // the later ones copy the first one's decisions and share its primitives
+        FieldKey keys[PLAN_BLOCK_FIELDS];
+        uint64_t hashes[PLAN_BLOCK_FIELDS];
+        int n_proto = 0, proto_field[PLAN_BLOCK_FIELDS];
+        int64_t pt = 0;
+        DevField scratch_df;
+        for (int64_t fi = blk.f0; fi < blk.f1; ++fi) {
+            const fcpp_field &f = fields[fi];
+            fcpp_field_info &in = out.info[(size_t)fi];
+            DevField &df = want_device ? out.fields[(size_t)fi] : scratch_df;
+            const bool shareable = share && !(pc.clip && f.n_obstacles > 0);
+            int64_t npts = -1;
+            if (shareable) {
+                const FieldKey k = key_of(f);
+                const uint64_t h = hash_of(k);
+                int hit = -1;
+                for (int j = 0; j < n_proto; ++j)
+                    if (hashes[j] == h && keys[j] == k) { hit = j; break; }
+                if (hit >= 0) {
+                    const int64_t pf = proto_field[hit];
+                    in = out.info[(size_t)pf];
+                    if (want_device) { df = out.fields[(size_t)pf]; out.same_as[(size_t)fi] = (int32_t)pf; }
+                    npts = in.n_main + in.n_head;
+                } else { keys[n_proto] = k; hashes[n_proto] = h; proto_field[n_proto] = (int)fi; ++n_proto; }
+            }
+            if (npts < 0) npts = plan_field(pc, f, polys, want_device, in, df, blk.prims);
+            in.point_offset = pt;
+            if (want_device) {
+                df.pt_off = pt;
+                df.obs_first = (int32_t)f.obstacle_first; df.obs_count = f.n_obstacles;
+            }
+            pt += npts;
+        }
+        blk.points = pt;
+        block_points[(size_t)b] = pt;
+    });
+
+    // ---- bases: a serial prefix over the blocks, then the fields' offsets made batch-wide (side by side again)
+    int64_t pt_off = 0, prim_off = 0;
+    for (int64_t b = 0; b < nb; ++b) {
+        PlanBlock &blk = out.blocks[(size_t)b];
+        blk.point_base = pt_off; blk.prim_base = prim_off;
+        pt_off += blk.points; prim_off += (int64_t)blk.prims.size();
+        if (pt_off > kCountCap) { err = "batch too large"; return FCPP_ESIZE; }          // (2^40 points = 40 TB of output: no batch gets there)
+        if (prim_off > ((int64_t)1 << 26)) {     // (primitive indices are 32-bit; 2^26 records are 7 GB of host memory)
             err = "too many path primitives in one batch (obstacle-aware swaths of very large fields): split the batch";
             return FCPP_ESIZE;
         }
-        pt_off += pos;
     }
-    out.total_points = pt_off;
+    out.total_points = pt_off; out.total_prims = prim_off;
+    WorkerPool::parallel_for(nb, [&](int64_t b) {
+        const PlanBlock &blk = out.blocks[(size_t)b];
+        for (int64_t fi = blk.f0; fi < blk.f1; ++fi) {
+            out.info[(size_t)fi].point_offset += blk.point_base;
+            if (want_device) { out.fields[(size_t)fi].pt_off += blk.point_base; out.fields[(size_t)fi].prim_first += (int32_t)blk.prim_base; }
+        }
+    });
+    if (!want_device) out.blocks.clear();
     return FCPP_OK;
 }
 

@@ -126,16 +126,37 @@ struct TilePartial {
 #include <string>
 #include <vector>
 namespace fcpp {
+// The setup of a batch is cut into blocks of PLAN_BLOCK_FIELDS consecutive fields, planned (and tiled, fcpp_tiler.h) side by side on the
+// host's cores; a block owns the primitives of its fields.  The cut is fixed, so what is built does not depend on the thread count.
+constexpr int64_t PLAN_BLOCK_FIELDS = 64;
+struct PlanBlock {
+    int64_t f0 = 0, f1 = 0;          // fields [f0, f1)
+    std::vector<DevPrim> prims;      // the block's primitives: fields with identical constructor arguments share one list
+    int64_t prim_base = 0;           // index of prims[0] in the batch-wide primitive table
+    int64_t point_base = 0;          // first point of field f0 in the batch arrays
+    int64_t points = 0;
+};
 struct HostPlan {
     std::vector<fcpp_field_info> info;
-    std::vector<DevField> fields;
-    std::vector<DevPrim> prims;
+    std::vector<DevField> fields;    // pt_off and prim_first are batch-wide
+    std::vector<PlanBlock> blocks;   // (empty without want_device)
+    std::vector<int32_t> same_as;    // per field: an earlier field of the same block with equal constructor arguments (its plan was copied,
+                                     // its primitives are shared), or -1; with want_device only
     TurnTemplates tt;
-    int64_t total_points = 0;
+    int64_t total_points = 0, total_prims = 0;
+    const DevPrim *prims_of(int64_t field) const      // the primitives of a field: [0, fields[field].prim_count)
+    {
+        const PlanBlock &b = blocks[(size_t)(field / PLAN_BLOCK_FIELDS)];
+        return b.prims.data() + (fields[(size_t)field].prim_first - b.prim_base);
+    }
 };
-// Builds info (+ device descriptors when want_device) for n fields; returns FCPP_OK or FCPP_E*.
+// Builds info (+ device descriptors when want_device) for n fields; returns FCPP_OK or FCPP_E*.  Threaded over blocks of fields.
 int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
                     bool want_device, HostPlan &out, std::string &err);
+// the batch-wide turn templates' description (sample counts, shape parameters) for a vehicle and options; validates both
+int plan_templates(const fcpp_vehicle &veh, const fcpp_options &opt, TurnTemplates &tt, std::string &err);
+// the polygon table of a batch: counts, offsets (start at 0, non-decreasing) and coordinate pointers; FCPP_OK or FCPP_ESIZE / FCPP_EINVAL
+int validate_polys(const fcpp_polys *polys, std::string &err);
 // host+device Fresnel / CAC helpers live in fcpp_geom.h
 }  // namespace fcpp
 #endif

@@ -1,0 +1,63 @@
+// fcpp_tiler.h -- the host-side tiler of the fused pipeline: cuts every field's path into work for the four single-pass kernels
+// (spans and closed-form runs for k_plan_quiet, wave tiles for k_plan_sparse, general tiles for k_plan_fused) plus the lists
+// k_reduce_stats walks, and lays all of it out as ONE image that goes to the device in one copy.
+//
+// Pure C++ (no HIP): fields are tiled block by block on the host's cores (fcpp_parallel.h), the blocks' records are merged in block
+// order, so the image does not depend on the thread count.  A field's cut depends on the field alone, never on its position in the
+// batch; only indices (field, tile slot, primitive, output offset) differ between two equal fields.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "fcpp_internal.h"
+
+namespace fcpp {
+
+struct Pt2 { double x, y; };      // layout of HIP's double2: the turn templates as the device built them
+
+// what the tiler needs to know about the batch besides the host plan
+struct TileConsts {
+    const Pt2 *tu = nullptr, *tc = nullptr;   // host copies of the U-turn / corner templates (nu / nc samples)
+    int nu = 0, nc = 0;
+    bool templates_ok = false;                // the copies are there (wave tiles need them to size their halos)
+    bool turn_quiet = false;                  // U-turns of this batch are closed form (closed_form_turns, fcpp_api.cpp)
+    double two_a = 0.0, u_cap = 0.0, c_line = 0.0;     // 2 a_lon, (v_max / 3.6)^2, (v_work / 3.6)^2
+    double fence_margin = 1e-3;               // a point this far inside every edge cannot be flagged by the device's geofence test
+    int wave_factor = 24;                     // wave tiles where wave_factor * 2a * line step >= u_cap
+    int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
+};
+
+// the tables of the fused pipeline inside one allocation; all offsets in bytes from the image's start, 256-byte aligned
+struct ImageLayout {
+    size_t fields = 0, prims = 0, tiles = 0, wtiles = 0, general_ids = 0, chunks = 0, span_chunks = 0, stat_ids = 0, stat_first = 0,
+           stat_run = 0, red_paths = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
+    size_t upload_bytes = 0;                  // [0, upload_bytes) is built on the host and copied
+    size_t partial = 0, red_scratch = 0, field_junc = 0;      // device-only scratch behind it
+    size_t total_bytes = 0;
+    int64_t n_fields = 0, n_prims = 0, n_tiles = 0, n_wave = 0, n_general = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_stat = 0;
+    int64_t n_red[4] = { 0, 0, 0, 0 };
+    int64_t n_polys = 0, n_poly_verts = 0;
+    int64_t quiet_points = 0, span_points = 0, chunk_points = 0, wave_points = 0;
+    int64_t wave_fail[5] = { 0, 0, 0, 0, 0 }; // diagnostics: stretches refused for wave tiles, by reason
+    int64_t wave_inside = 0;                  // wave tiles whose outputs the host found inside the geofence
+};
+
+struct BlockTiles;      // a block's records before the merge (fcpp_tiler.cpp)
+
+class BatchTiler {
+public:
+    BatchTiler();
+    ~BatchTiler();
+    // phase 1: tile every block of `hp` (side by side), size the image.  `polys` (may be NULL): the batch's obstacle table, copied into
+    // the image with one bounding box per polygon.
+    int plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys *polys, ImageLayout &lay, std::string &err);
+    // phase 2: write the image into `dst` (lay.upload_bytes bytes; pinned host memory in fcpp_batch_create), side by side
+    void fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst) const;
+private:
+    std::vector<BlockTiles> *blocks_;
+};
+
+}  // namespace fcpp

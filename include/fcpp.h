@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FCPP_ABI_VERSION 2
+#define FCPP_ABI_VERSION 3
 
 enum {
     FCPP_OK = 0,
@@ -168,6 +168,21 @@ int fcpp_batch_create(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options
                       const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **batch);
 int fcpp_batch_info(const fcpp_batch *batch, fcpp_field_info *info_out /* n_fields, may be NULL */,
                     int64_t *total_points);
+/* Where the time of fcpp_batch_create went (wall-clock milliseconds on the host): the plan call of the reference,
+ * plan_complete_coverage (MLP:387-465), times its field setup together with the generation -- fcpp_batch_create + one fcpp_batch_run is
+ * that call for a whole batch, and bench.py reports it as such (end to end) beside the time of the step alone. */
+typedef struct fcpp_setup_times {
+    double host_plan_ms;    /* __init__ + the O(1) decisions of every field (MLP:63-107, 591-668, 898-1084), blocks of fields on the host's cores */
+    double templates_ms;    /* turn templates sampled on the device and copied back (close to 0 when the context already had them) */
+    double tiler_ms;        /* the paths cut into kernel work (quiet runs, spans, wave tiles with their halos, general tiles) */
+    double image_ms;        /* device allocation + the tables written into the context's pinned staging memory */
+    double h2d_ms;          /* the one host-to-device copy, the per-field junction kernel, and the stream drained */
+    double total_ms;        /* the whole call */
+    int64_t image_bytes;    /* bytes copied to the device */
+    int32_t threads;        /* host threads that took part (FCPP_THREADS; default: the machine's, at most 16) */
+    int32_t _pad;
+} fcpp_setup_times;
+int fcpp_batch_setup_times(const fcpp_batch *batch, fcpp_setup_times *out);
 /* The hot path: sample every path point (MLP:720-830, 898-1084, 1154-1218, 1580-1608), curvature
  * (MLP:513-536), curvature clamp (MLP:467-511), forward/backward sweeps (MLP:538-589), validator
  * (MLP:1373-1424 + geofence / obstacle flags) and metrics (MLP:1290-1311).  Outputs are device

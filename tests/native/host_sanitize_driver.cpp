@@ -86,7 +86,7 @@ int main(int argc, char **argv)
             if (sec > 2.0)
                 fprintf(stderr, "slow call: %.1f s, round %d, n %d, W %g R %g ds %g mode %d/%d, rc %d, points %lld, prims %zu\n", sec, round, n,
                         veh.working_width, veh.min_turn_radius, opt.sample_spacing, opt.turn_model, opt.obstacle_mode, rc,
-                        (long long)hp.total_points, hp.prims.size());
+                        (long long)hp.total_points, (size_t)hp.total_prims);
             if (rc != FCPP_OK) { ++failed_calls; continue; }
             int64_t expect = 0;
             for (int i = 0; i < n; ++i) {
@@ -100,7 +100,23 @@ int main(int argc, char **argv)
             if (hp.total_points != expect) { fprintf(stderr, "total_points mismatch at round %d\n", round); return 2; }
             if (want_device) {               // the descriptors the tiler and the kernels index with: touch every one
                 for (const auto &f : hp.fields) sum += (uint64_t)f.n_total + (uint64_t)f.prim_count;
-                for (const auto &p : hp.prims) sum += (uint64_t)p.kind + (uint64_t)p.n;
+                int64_t n_prims = 0;
+                for (const auto &blk : hp.blocks) {
+                    if (blk.prim_base != n_prims) { fprintf(stderr, "primitive bases out of step at round %d\n", round); return 2; }
+                    n_prims += (int64_t)blk.prims.size();
+                    for (const auto &p : blk.prims) sum += (uint64_t)p.kind + (uint64_t)p.n;
+                }
+                for (int i = 0; i < n; ++i) {          // every field's primitives lie inside its block's list and tile its layer-2 points
+                    const auto &f = hp.fields[(size_t)i];
+                    const auto &blk = hp.blocks[(size_t)(i / fcpp::PLAN_BLOCK_FIELDS)];
+                    if (f.prim_count < 0 || f.prim_first < blk.prim_base || f.prim_first + f.prim_count > blk.prim_base + (int64_t)blk.prims.size()) {
+                        fprintf(stderr, "primitive range outside the block at round %d field %d\n", round, i); return 2;
+                    }
+                    const fcpp::DevPrim *pp = hp.prims_of(i);
+                    int64_t at = f.gen_main;
+                    for (int k = 0; k < f.prim_count; ++k) { if (pp[k].start != at) { fprintf(stderr, "primitives do not tile the path, round %d field %d\n", round, i); return 2; } at += pp[k].n; }
+                    if (f.n_total > 0 && at != f.n_total) { fprintf(stderr, "primitives end before the path, round %d field %d\n", round, i); return 2; }
+                }
             }
         }
     }
