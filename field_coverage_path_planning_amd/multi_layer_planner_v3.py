@@ -125,6 +125,7 @@ class TwoLayerPathPlannerV37:
         self._device = device
         self.coverage_resolution = float(coverage_resolution)   # sample spacing of coverage_rate [m] (build-defined)
         self._spec = E.FieldSpec(field_length, field_width, field_vertices, self.obstacles, start_point, end_point)
+        self._batch = self._bufs = None
         self._veh = E.make_vehicle(self.vehicle)
         self._opt = E.make_options(L.TURN_CLOTHOID if str(turn_model).lower().startswith('cloth') else L.TURN_ARC,
                                    sample_spacing, clothoid_frac, clothoid_fit, geofence_tol, avoid_obstacles)
@@ -136,7 +137,8 @@ class TwoLayerPathPlannerV37:
         else:
             raise ValueError("必须提供 field_vertices 或 (field_length, field_width)")
         self.field_polygon = QuadPolygon(self.field_vertices)
-        info = E.plan_count([self._spec], self._veh, self._opt)[0]      # host-side setup in libfcpp
+        self._table = E.FieldTable.from_specs([self._spec])
+        info = E.plan_count(self._table, self._veh, self._opt)[0]       # host-side setup in libfcpp
         self._info = info
         self.field_length = info.field_length if field_vertices is not None else field_length
         self.field_width = info.field_width if field_vertices is not None else field_width
@@ -163,19 +165,21 @@ class TwoLayerPathPlannerV37:
                              "exactly (headland loop inset is empty, MLP:967-969 -> :939)")
         if info.status != L.OK:
             raise ValueError(f"unsupported field (libfcpp status {info.status})")
-        batch = E.Batch([self._spec], self._veh, self._opt, device=self._device)
-        try:
-            res = batch.run()
-            ap, dp = batch.connectors()
-            n_main, n_head = info.n_main, info.n_head
-            # coverage of the headland ring by the headland path, straight from the device arrays (MLP:884, 1357-1371)
-            coverage_rate = self._coverage_rate_dev(res.x[n_main:], res.y[n_main:], self._headland_area())
-            x, y = res.x.cpu().numpy(), res.y.cpu().numpy()
-            v, kappa, fs = res.v.cpu().numpy(), res.kappa.cpu().numpy(), res.flagseg.cpu().numpy().view(np.uint32)
-            st = {k: a[0] for k, a in res.stats().items()}
-            ap, dp = ap.cpu().numpy()[0], dp.cpu().numpy()[0]
-        finally:
-            batch.close()
+        # the planner keeps its batch (descriptors on the device, tiling, output arrays): a second plan_complete_coverage() of the same
+        # planner only runs the kernels again.  Results are copied out, so the caller owns fresh arrays every time (as in the reference).
+        if self._batch is None:
+            self._batch = E.Batch(self._table, self._veh, self._opt, device=self._device)
+            self._bufs = self._batch.alloc()
+        batch = self._batch
+        res = batch.run(self._bufs)
+        ap, dp = batch.connectors()
+        n_main, n_head = info.n_main, info.n_head
+        # coverage of the headland ring by the headland path, straight from the device arrays (MLP:884, 1357-1371)
+        coverage_rate = self._coverage_rate_dev(res.x[n_main:], res.y[n_main:], self._headland_area())
+        x, y = res.x.cpu().numpy(), res.y.cpu().numpy()
+        v, kappa, fs = res.v.cpu().numpy(), res.kappa.cpu().numpy(), res.flagseg.cpu().numpy().view(np.uint32)
+        st = {k: a[0] for k, a in res.stats().items()}
+        ap, dp = ap.cpu().numpy()[0], dp.cpu().numpy()[0]
         path = np.column_stack([x, y])
         main_len, head_len = st['main_len_m'], st['head_len_m']
         main_pre, head_pre = st['main_time_pre_s'], st['head_time_pre_s']
@@ -219,6 +223,18 @@ class TwoLayerPathPlannerV37:
         return result
 
     plan = plan_complete_coverage   # README_en.md:274-302
+
+    def close(self):
+        """release the planner's device batch (also done when the planner is collected)"""
+        if getattr(self, '_batch', None) is not None:
+            self._batch.close()
+            self._batch = self._bufs = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------------------
     def verify_curvature_constraints(self, path: np.ndarray, speeds: np.ndarray) -> Dict:

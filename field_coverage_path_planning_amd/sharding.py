@@ -34,9 +34,33 @@ def partition_by_points(point_counts, world_size):
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
+# Exercising the collectives where only ONE GPU exists (tests/test_gpu_rccl.py, bench.py under FCPP_BENCH_FORCE_DIST=1): with this
+# set, a world of one rank does not take the "nothing to exchange" shortcuts -- the stats rows, the point arrays and the GA fitness
+# really travel through the process group (ncclSend / ncclRecv addressed to the rank itself, ncclAllGather over one rank), on device
+# tensors with the nccl backend, so the RCCL code path a multi-GPU job takes has run on the hardware at hand.
+FORCE_COLLECTIVES = False
+
+
 def _dist():
     import torch.distributed as dist
     return dist
+
+
+def _send_to_self(tensors):
+    """every tensor through one batch of isend / irecv addressed to this rank -> the received copies"""
+    import torch
+    dist = _dist()
+    rank, _ = world()
+    out = [torch.empty_like(t) for t in tensors]
+    ops = []
+    for t, o in zip(tensors, out):
+        if t.numel() > 0:
+            ops.append(dist.P2POp(dist.isend, t.contiguous(), rank))
+            ops.append(dist.P2POp(dist.irecv, o, rank))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    return out
 
 
 def world():
@@ -56,6 +80,8 @@ def gather_rows(local_rows, rows_per_rank, dst=0):
     dist = _dist()
     rank, ws = world()
     if ws == 1:
+        if FORCE_COLLECTIVES and dist.is_initialized():
+            return _send_to_self([local_rows])[0]
         return local_rows
     if rank == dst:
         parts, reqs = [], []
@@ -86,6 +112,8 @@ def gather_arrays(local_arrays, counts_per_rank, dst=0):
     dist = _dist()
     rank, ws = world()
     if ws == 1:
+        if FORCE_COLLECTIVES and dist.is_initialized():
+            return _send_to_self([a[:int(counts_per_rank[0])] for a in local_arrays])
         return list(local_arrays)
     starts = np.concatenate([[0], np.cumsum(np.asarray(counts_per_rank, dtype=np.int64))])
     ops, out = [], None
@@ -213,7 +241,7 @@ def ga_fitness_sharded(routes, D, order_mode=0, device=None, compute=None, with_
     else:
         dev = torch.device('cuda', device if device is not None else torch.cuda.current_device())
         d_loc = f_loc = torch.empty(0, dtype=torch.float64, device=dev)
-    if ws == 1:
+    if ws == 1 and not (FORCE_COLLECTIVES and dist.is_initialized()):
         return (f_loc, d_loc) if with_distance else f_loc
     # one all-gather of equal-sized blocks (the last ranks' blocks padded by at most one element): a single collective whatever the
     # population size, [fitness | distance] side by side when both are asked for
