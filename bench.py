@@ -124,7 +124,8 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
        drained; the batch of the last repetition is kept for
     2. the timed region: `reps` x K steps bracketed by fence() (barrier + synchronize), median reported, per-kernel HIP events recorded
        inside it on a sample of the steps.
-    The output arrays are the ones the allocator returns.  calibrate > 1 (opt-in, reported beside the primary figure, never as it):
+    The output arrays come from Batch.alloc() with its default layout rule ('auto': large batches get the five arrays >= 24 GiB apart
+    inside one allocation; reported per entry as output_arrays).  calibrate > 1 (opt-in, reported beside the primary figure, never as it):
     Batch.alloc(best_of=calibrate) picks the fastest of `calibrate` further candidate sets under the batch's own step.
     stats_of(i, batch): the stats tensor step i writes (default: the one of alloc()); after_step(i, res): called after step i has
     been enqueued."""
@@ -201,7 +202,7 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     dom_points = stage_points[dom]
     return {'stage_points': stage_points, 'prof_runs': prof_runs, 'points': n_points, 'dt': dt, 'dts': dts, 'ms_per_step': dt / steps * 1e3, 'kernels': kernels,
             'dominant': dom, 'dominant_points': dom_points, 'quiet_points': q_pts, 'general_points': g_pts, 'batch': batch, 'bufs': bufs, 'res': res,
-            'calibrated': calibrated, 'end_to_end': end_to_end, 'steps': steps}
+            'calibrated': calibrated, 'end_to_end': end_to_end, 'steps': steps, 'layout': getattr(batch, 'layout', None)}
 
 
 def roofline_of(r, traffic_key=None):
@@ -234,7 +235,7 @@ def config_entry(name, workload, r, cpu=None, extra=None, traffic_key=None):
     e = {'name': name, 'workload': workload, 'points': r['points'], 'ms_per_step': r['ms_per_step'],
          'value': r['points'] / (r['ms_per_step'] * 1e-3), 'unit': 'points/s', 'dtype': 'f64', 'timed_region': timed_region_of(r),
          'value_end_to_end': r['end_to_end']['points_per_s'], 'end_to_end': r['end_to_end'], 'setup_ms': r['end_to_end']['setup_ms'],
-         'output_arrays': 'as the allocator returns them',
+         'output_arrays': r['layout'],
          'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'roofline': roofline_of(r, traffic_key or name), 'cpu_baseline': cpu}
     if r.get('calibrated'):
         e['calibrated'] = r['calibrated']
@@ -392,7 +393,7 @@ def main():
                             f'the reference\'s outputs; the clothoid variants of the same batch are configs[cfg1_clothoid*] below and value_clothoid',
                 'turn_model': 'arc (reference, pinned)', 'points_per_gpu_step': r['points'], 'fields_per_gpu': args.fields,
                 'pipeline': 'staged (7 kernels)' if args.mode == 0 else 'fused: k_plan_quiet (closed-form runs and spans) + k_plan_sparse (wave tiles, one point per lane) + k_plan_fused (all other tiles) + k_reduce_stats',
-                'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'output_arrays': 'as the allocator returns them',
+                'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'output_arrays': r['layout'],
             },
             'roofline': roofline_of(r, 'cfg1'),
             'cpu_baseline': None,
@@ -701,7 +702,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
         entry = {'name': 'cfg5', 'workload': 'cfg5: 65 536 parallelograms (base / height U[100,1000) m, angle U[60,120) deg, rotation U[-pi/4,pi/4), seed 65536), '
                                              'arc turns at the reference sampling, sharded over the ranks by sharding.plan_sharded '
                                              '(contiguous blocks cut on the analytic point counts; the only collective is the stats gather)',
-                 'n_gpus': world, 'scaling': 'strong', 'points': total, 'output_arrays': 'as the allocator returns them',
+                 'n_gpus': world, 'scaling': 'strong', 'points': total, 'output_arrays': getattr(batch, 'layout', None),
                  'ms_per_step': dt_dev / steps * 1e3, 'value': total * steps / dt_dev, 'unit': 'points/s', 'dtype': 'f64',
                  'timed_region': {'reps': len(dts), 'steps_per_rep': steps, 'ms_per_step_each_rep': [round(d / steps * 1e3, 5) for d in dts], 'reported': 'median (rank 0 shown)'},
                  'value_end_to_end': total / (mid['ms'] * 1e-3),

@@ -14,6 +14,7 @@ TURN_ARC, TURN_CLOTHOID = 0, 1
 KIND_SWATH, KIND_UTURN, KIND_HEAD_START, KIND_HEAD_STRAIGHT, KIND_CORNER, KIND_REVERSE, KIND_DETOUR = range(7)
 OBSTACLES_FLAG, OBSTACLES_AVOID = 0, 1
 KIND_MASK, FLAG_HEADLAND, FLAG_ALAT, FLAG_OUTSIDE, FLAG_OBSTACLE, INDEX_SHIFT = 7, 8, 16, 32, 64, 8
+OUTPUT_PITCH = 24 << 30          # FCPP_OUTPUT_PITCH (include/fcpp.h)
 
 c_double_p = C.POINTER(C.c_double)
 c_i64_p = C.POINTER(C.c_int64)
@@ -109,6 +110,8 @@ PROTOTYPES = [
     ('fcpp_ctx_synchronize', C.c_int, [_VP]),
     ('fcpp_malloc', C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
     ('fcpp_free', C.c_int, [_VP, _VP]),
+    ('fcpp_outputs_alloc', C.c_int, [_VP, C.c_int64, C.c_int64] + [C.POINTER(_VP)] * 5),
+    ('fcpp_outputs_free', C.c_int, [_VP, _VP]),
     ('fcpp_memcpy_h2d', C.c_int, [_VP, _VP, _VP, C.c_int64]),
     ('fcpp_memcpy_d2h', C.c_int, [_VP, _VP, _VP, C.c_int64]),
     ('fcpp_plan_count', C.c_int, [C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field), C.POINTER(Polys),

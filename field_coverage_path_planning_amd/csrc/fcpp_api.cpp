@@ -364,6 +364,42 @@ int fcpp_free(fcpp_ctx *c, void *p)
     return FCPP_OK;
 }
 
+// ---- output arrays with the placement rule of DESIGN.md section 4 ("where the five arrays lie"): ONE device allocation, the five arrays
+// FCPP_OUTPUT_PITCH apart.  Measured on MI355X: the streaming kernels write x, y, kappa, v and flagseg side by side, and five write
+// streams that lie within a few GiB of each other in device memory run at 4.6 TB/s, the same streams >= 12-24 GiB apart at 6.3-6.6 TB/s
+// (tools/placement_pitch.py: the class follows the pitch and nothing else).
+int fcpp_outputs_alloc(fcpp_ctx *c, int64_t n_points, int64_t pitch_bytes, double **x, double **y, double **kappa, double **v, uint32_t **flagseg)
+{
+    if (!c || n_points < 0 || !x || !y || !kappa || !v || !flagseg) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t S = (((size_t)n_points * 8 + 4095) / 4096) * 4096;
+    size_t P = pitch_bytes > 0 ? (size_t)pitch_bytes : (size_t)FCPP_OUTPUT_PITCH;
+    if (pitch_bytes == 0) {      // default: the full pitch if the device has room for it, else as wide as fits, else back to back
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        const size_t reserve = (size_t)8 << 30;
+        if (P < S + ((size_t)1 << 30)) P = S + ((size_t)1 << 30);
+        if (free_b < 4 * P + S + reserve) P = free_b > 5 * S + reserve ? (free_b - reserve - S) / 4 : S;
+    }
+    if (P < S) P = S;
+    P = (P / 4096) * 4096;
+    void *slab = nullptr;
+    hipError_t e = hipMalloc(&slab, std::max<size_t>(4 * P + S, 4096));
+    if (e != hipSuccess) return fail(FCPP_ENOMEM, std::string("output arrays: ") + hipGetErrorString(e));
+    char *b = static_cast<char *>(slab);
+    *x = reinterpret_cast<double *>(b); *y = reinterpret_cast<double *>(b + P); *kappa = reinterpret_cast<double *>(b + 2 * P);
+    *v = reinterpret_cast<double *>(b + 3 * P); *flagseg = reinterpret_cast<uint32_t *>(b + 4 * P);
+    return FCPP_OK;
+}
+
+int fcpp_outputs_free(fcpp_ctx *c, double *x)
+{
+    if (!c) return fail(FCPP_EINVAL, "ctx is NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (x) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(x)); }
+    return FCPP_OK;
+}
+
 int fcpp_memcpy_h2d(fcpp_ctx *c, void *dst, const void *src, int64_t bytes)
 {
     if (!c || bytes < 0) return fail(FCPP_EINVAL, "bad arguments");

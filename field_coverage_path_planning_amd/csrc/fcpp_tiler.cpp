@@ -3,6 +3,7 @@
 #include "fcpp_tiler.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -557,6 +558,21 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         }
     });
     if (n == 0) *at<int64_t>(dst, lay.stat_first) = 0;
+    // diagnostic (FCPP_CHUNK_SPREAD=S): the ORDER of the chunk lists permuted so that consecutive workgroups write chunks N/S apart
+    // instead of neighbours -- which memory the waves in flight cover at any moment (tools/placement_probe.py)
+    if (const char *e = getenv("FCPP_CHUNK_SPREAD")) {
+        const int64_t S = atoll(e);
+        for (int pass = 0; pass < 2 && S > 1; ++pass) {
+            DevTile *L = at<DevTile>(dst, pass ? lay.span_chunks : lay.chunks);
+            const int64_t N = pass ? lay.n_span_chunks : lay.n_chunks;
+            if (N < 2 * S) continue;
+            int64_t P = N / S;
+            auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+            while (gcd(P, N) != 1) ++P;
+            std::vector<DevTile> tmp(L, L + N);
+            for (int64_t i = 0; i < N; ++i) L[i] = tmp[(size_t)((__int128)i * P % N)];
+        }
+    }
     if (lay.n_polys > 0) {
         const int64_t np = lay.n_polys, nv = lay.n_poly_verts;
         memcpy(at<int64_t>(dst, lay.obs_off), polys->offsets, (size_t)(np + 1) * sizeof(int64_t));

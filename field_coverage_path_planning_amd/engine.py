@@ -301,6 +301,7 @@ class Batch:
         tot = C.c_int64()
         L.check(self.lib.fcpp_batch_info(self.handle, self.info._c, C.byref(tot)))
         self.total_points = tot.value
+        self._last_mode = 1
 
     def setup_times(self):
         """Where the time of this batch's creation went, in ms: {'pack', 'host_plan', 'templates', 'tiler', 'image', 'h2d', 'create'
@@ -311,37 +312,35 @@ class Batch:
         return {'pack': self.pack_ms, 'host_plan': t.host_plan_ms, 'templates': t.templates_ms, 'tiler': t.tiler_ms, 'image': t.image_ms,
                 'h2d': t.h2d_ms, 'create': t.total_ms, 'threads': int(t.threads), 'image_bytes': int(t.image_bytes)}
 
-    def alloc(self, best_of=1, probe='step', include=()):
+    SPREAD_MIN_BYTES = 512 << 20        # batches with less output than this live in the caches: placement does not matter
+
+    def alloc(self, layout='auto', best_of=1, include=()):
         """Output buffers (x, y, kappa, v, flagseg, stats) for run().
 
-        best_of > 1, probe='step' (default): placement calibration with the batch's own step.  `best_of` complete sets of output
-        arrays are allocated side by side, one warm-up and three timed run()s go into each, the fastest set is kept and the others
-        are released (`self.placement` = {'step_ms': per candidate, 'chosen': index}).  Measured on MI355X: the same kernels on the
-        same batch write one set of arrays 30-45 % faster than another of the same process (cfg5: 1.31 vs 1.90 ms in the span
-        kernel, cfg2 at 0.1 m: 4.45 vs 5.75 ms), the difference follows the allocation, not the relative offsets of the arrays
-        inside it, and a single-stream fill of each array does not predict it.  Setup work for a long-lived caller that plans into
-        the same arena again and again; never inside a timed region.  `include`: sets the caller already holds, timed as further
-        candidates (index 0.. in `step_ms`).
+        layout: where the five arrays lie in device memory.  The hot kernels write them side by side, and on MI355X five write streams
+        that lie within a few GiB of each other reach 4.6 TB/s where the same streams 12-24 GiB or more apart reach 6.3-6.6 TB/s
+        (tools/placement_pitch.py: the speed class follows the pitch between the arrays, nothing else).
+          'spread': ONE allocation, the arrays L.OUTPUT_PITCH (24 GiB) + their own size apart (less if the device has less room); the gaps
+                    belong to the allocation -- a caller that needs them sub-allocates its own slab with the same rule.
+          'plain' : five separate tensors, wherever the allocator puts them (usually back to back: the slow class).
+          'auto'  : 'spread' when the arrays are large enough to matter (>= 512 MiB of output) and the device has the room, else 'plain'.
+        self.layout tells which one was used and the pitch.
 
-        best_of > 1, probe='fill' (round 1): where the allocator puts an array in device memory changes the rate at which it
-        can be written (a single-stream fill of the same 8 GB differs by ~5 % between buffers; five such streams written
-        together, as k_plan_quiet does, by up to 30 %: 5.2 vs 6.8 ms on the bench workload), and it is a
-        property of the buffer, not of the kernel.  `best_of` candidate buffers per output array are allocated side by side, each
-        is timed with a plain device fill, the fastest ones are kept and the others released.  The timings are left in
-        `self.placement` ({'fill_ms': per candidate, 'chosen': indices})."""
-        if best_of <= 1 or self.total_points == 0:
-            return self._alloc_once()
-        torch = _torch()
-        dev = torch.device('cuda', self.ctx.device)
-        n = self.total_points
-        if probe == 'step':
+        best_of > 1 (opt-in, round 2's remedy): `best_of` further candidate sets are allocated ('plain'), the batch's own step is timed on
+        each (and on the sets in `include`), the fastest is kept (`self.placement`).  Setup work; never inside a timed region; not what
+        bench.py reports as its primary figures."""
+        if best_of > 1 and self.total_points > 0:
+            torch = _torch()
             import time
+            dev = torch.device('cuda', self.ctx.device)
             sets, ms = list(include), []
             for _ in range(int(best_of)):
                 try:
                     sets.append(self._alloc_once())
                 except RuntimeError:          # out of device memory: choose among what we have
                     break
+            if not sets:
+                raise RuntimeError(f'out of device memory: no candidate set of output arrays ({36 * self.total_points / 2**30:.1f} GiB each) could be allocated')
             for s in sets:
                 self.run(s)
                 torch.cuda.synchronize(dev)
@@ -356,43 +355,41 @@ class Batch:
             del sets
             torch.cuda.empty_cache()
             return keep
-
-        def fill_ms(t):
-            t.fill_(0)
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                t.fill_(0)
-            e1.record()
-            torch.cuda.synchronize(dev)
-            return e0.elapsed_time(e1) / 3
-
-        def candidates(count, dtype):
-            out = []
-            for _ in range(count):
-                try:
-                    out.append(torch.empty(n, dtype=dtype, device=dev))
-                except RuntimeError:          # out of device memory: choose among what we have
-                    break
-            return out
-
-        f64 = candidates(4 * int(best_of), torch.float64)
-        i32 = candidates(int(best_of), torch.int32)
-        if len(f64) < 4 or not i32:
-            del f64, i32
-            torch.cuda.empty_cache()
+        if layout not in ('auto', 'plain', 'spread'):
+            raise ValueError("layout: 'auto', 'plain' or 'spread'")
+        n = self.total_points
+        if layout == 'plain' or (layout == 'auto' and 36 * n < self.SPREAD_MIN_BYTES):
+            self.layout = {'layout': 'plain'}
             return self._alloc_once()
-        t64, t32 = [fill_ms(t) for t in f64], [fill_ms(t) for t in i32]
-        pick = sorted(sorted(range(len(f64)), key=lambda k: t64[k])[:4])
-        pick_fs = min(range(len(i32)), key=lambda k: t32[k])
-        self.placement = {'fill_ms_f64': [round(v, 3) for v in t64], 'chosen_f64': pick,
-                          'fill_ms_i32': [round(v, 3) for v in t32], 'chosen_i32': pick_fs}
-        x, y, kappa, v = (f64[k] for k in pick)
-        fs = i32[pick_fs]
-        del f64, i32
-        torch.cuda.empty_cache()
+        return self._alloc_spread(strict=layout == 'spread')
+
+    def _alloc_spread(self, strict=False):
+        torch = _torch()
+        dev = torch.device('cuda', self.ctx.device)
+        n = self.total_points
+        S = (8 * n + 4095) // 4096 * 4096
+        free, _total = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)       # (what the caching allocator could hand back)
+        reserve = 8 << 30
+        P = max(L.OUTPUT_PITCH, S + (1 << 30))
+        if free < 4 * P + S + reserve:
+            P = (free - reserve - S) // 4 if free > 5 * S + reserve else 0
+        P = P // 4096 * 4096
+        if P < S + (1 << 30) and not strict:       # no room to spread: the plain layout
+            self.layout = {'layout': 'plain', 'note': 'no room for the spread layout'}
+            return self._alloc_once()
+        P = max(P, S)
+        try:
+            slab = torch.empty(4 * P + S, dtype=torch.uint8, device=dev)
+        except RuntimeError:
+            if strict:
+                raise
+            self.layout = {'layout': 'plain', 'note': 'the spread allocation failed'}
+            return self._alloc_once()
+        x, y, kappa, v = (slab[k * P: k * P + 8 * n].view(torch.float64) for k in range(4))
+        fs = slab[4 * P: 4 * P + 4 * n].view(torch.int32)
         stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
+        self.layout = {'layout': 'spread', 'pitch_GiB': round(P / 2**30, 3), 'allocation_GiB': round((4 * P + S) / 2**30, 3)}
         return x, y, kappa, v, fs, stats
 
     def _alloc_once(self):

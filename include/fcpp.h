@@ -153,6 +153,15 @@ int fcpp_ctx_synchronize(fcpp_ctx *ctx);
 /* device memory for hosts without their own allocator (torch users pass tensor pointers instead) */
 int fcpp_malloc(fcpp_ctx *ctx, int64_t bytes, void **dev_ptr);
 int fcpp_free(fcpp_ctx *ctx, void *dev_ptr);
+/* Output arrays for fcpp_batch_run with the placement rule measured on MI355X: the hot kernels write x, y, kappa,
+ * v and flagseg side by side, and five write streams within a few GiB of each other in device memory reach 4.6 TB/s where the same
+ * streams >= 12-24 GiB apart reach 6.3-6.6 TB/s.  One device allocation, the five arrays pitch_bytes apart (0: FCPP_OUTPUT_PITCH, or
+ * as wide as the free device memory allows; small batches -- a few hundred MB of output -- live in the caches and do not care).
+ * Free all five with fcpp_outputs_free(ctx, x). */
+#define FCPP_OUTPUT_PITCH ((int64_t)24 << 30)
+int fcpp_outputs_alloc(fcpp_ctx *ctx, int64_t n_points, int64_t pitch_bytes, double **x_dev, double **y_dev, double **kappa_dev,
+                       double **v_dev, uint32_t **flagseg_dev);
+int fcpp_outputs_free(fcpp_ctx *ctx, double *x_dev);
 int fcpp_memcpy_h2d(fcpp_ctx *ctx, void *dst_dev, const void *src, int64_t bytes);
 int fcpp_memcpy_d2h(fcpp_ctx *ctx, void *dst, const void *src_dev, int64_t bytes);
 

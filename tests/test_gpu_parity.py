@@ -570,23 +570,49 @@ def test_standalone_operators_on_ragged_paths():
     assert _np(d).tolist() == [0.0, 0.0, 0.0] and np.allclose(_np(f), 1e6)
 
 
-def test_placement_calibrated_buffers_give_the_same_plan():
-    """Batch.alloc(best_of=K) only chooses WHICH buffers receive the output (step probe and fill probe)."""
+def test_output_layouts_give_the_same_plan():
+    """Batch.alloc(layout=...) and alloc(best_of=K) only choose WHERE the output arrays lie (five write streams
+    far apart in device memory run a class faster than the same streams back to back); the plan is the same bit for bit.  Also the C
+    ABI's fcpp_outputs_alloc: one allocation, the arrays a pitch apart."""
+    import ctypes as C
+    import torch
     specs, _ = _random_fields(5, 6)
     b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(1, 0.2))
-    r0 = b.run()
+    r0 = b.run(b.alloc(layout='plain'))
+    assert b.layout['layout'] == 'plain'
     keep = [t.clone() for t in (r0.x, r0.y, r0.kappa, r0.v, r0.flagseg, r0.stats_raw)]
-    mine = b.alloc()
-    bufs = b.alloc(best_of=3, include=[mine])
-    p = b.placement
-    assert p['probe'] == 'step' and len(p['step_ms']) == 4 and 0 <= p['chosen'] < 4
-    r1 = b.run(bufs)
+    small = b.alloc()                                   # a small batch: 'auto' stays plain
+    assert b.layout['layout'] == 'plain' and 36 * b.total_points < b.SPREAD_MIN_BYTES
+    spread = b.alloc(layout='spread')
+    assert b.layout['layout'] == 'spread' and b.layout['pitch_GiB'] >= 1.0
+    assert spread[1].data_ptr() - spread[0].data_ptr() == int(b.layout['pitch_GiB'] * 2**30) == spread[4].data_ptr() - spread[3].data_ptr()
+    r1 = b.run(spread)
     for a, c in zip(keep, (r1.x, r1.y, r1.kappa, r1.v, r1.flagseg, r1.stats_raw)):
         assert bool((a == c).all())
-    bufs = b.alloc(best_of=3, probe='fill')
+    del spread, r1
+    torch.cuda.empty_cache()
+    mine = b.alloc(layout='plain')
+    bufs = b.alloc(best_of=3, include=[mine, small])
     p = b.placement
-    assert len(p['fill_ms_f64']) == 12 and len(p['chosen_f64']) == 4 and len(p['fill_ms_i32']) == 3
+    assert p['probe'] == 'step' and len(p['step_ms']) == 5 and 0 <= p['chosen'] < 5
     r2 = b.run(bufs)
     for a, c in zip(keep, (r2.x, r2.y, r2.kappa, r2.v, r2.flagseg, r2.stats_raw)):
         assert bool((a == c).all())
+    # the C ABI's allocator: five pointers one pitch apart inside one allocation
+    ptrs = [C.c_void_p() for _ in range(5)]
+    pitch = 3 << 30
+    L.check(b.lib.fcpp_outputs_alloc(b.ctx.handle, b.total_points, pitch, *[C.byref(q) for q in ptrs]))
+    assert all(ptrs[k + 1].value - ptrs[k].value == pitch for k in range(4))
+    stats = torch.zeros((b.n_fields, L.STATS_WORDS), dtype=torch.int64, device='cuda')
+    b.ctx.bind_stream()
+    L.check(b.lib.fcpp_batch_run(b.handle, *ptrs, C.c_void_p(stats.data_ptr()), 1))
+    torch.cuda.synchronize()
+    assert bool((stats == keep[5]).all())
+    got = torch.empty_like(keep[0])
+    L.check(b.lib.fcpp_memcpy_d2h(b.ctx.handle, C.c_void_p(0), C.c_void_p(0), 0))
+    host = np.empty(b.total_points, dtype=np.float64)
+    L.check(b.lib.fcpp_memcpy_d2h(b.ctx.handle, C.c_void_p(host.ctypes.data), ptrs[3], 8 * b.total_points))
+    assert np.array_equal(host, keep[3].cpu().numpy())
+    del got
+    L.check(b.lib.fcpp_outputs_free(b.ctx.handle, ptrs[0]))
     b.close()

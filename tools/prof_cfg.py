@@ -16,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('config')
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--mode', type=int, default=1)
-ap.add_argument('--placement', type=int, default=-1, help='candidate sets of output arrays (Batch.alloc best_of); default: as bench.py -- the plain allocation + 2-3 more for the dense configurations and cfg5, else 1')
+ap.add_argument('--placement', type=int, default=1, help='> 1: candidate sets of output arrays (Batch.alloc best_of, opt-in); default 1: Batch.alloc() with its layout rule, as bench.py')
 a = ap.parse_args()
 c = a.config
 if c.startswith('cfg1'):
@@ -34,7 +34,7 @@ else:
 b = E.Batch(specs, E.make_vehicle(), opt)
 # the same output placement as bench.py gives the configuration (setup; its launches precede the `steps` timed ones in the trace --
 # tools/profiles_summary.py takes the kernel statistics from the LAST `steps` dispatches of every kernel)
-placement = a.placement if a.placement >= 0 else {'cfg1_clothoid_dense': 2, 'cfg2_0.5': 3, 'cfg2_0.1': 3, 'cfg3': 3, 'cfg5': 3}.get(c, 1)
+placement = a.placement
 if placement > 1 and a.mode == 1:
     bufs = b.alloc(best_of=placement, include=[b.alloc()])
 else:
@@ -44,4 +44,4 @@ torch.cuda.synchronize()
 for _ in range(a.steps):
     b.run(bufs, mode=a.mode)
 torch.cuda.synchronize()
-print(c, 'points', b.total_points, 'stage points', b.stage_points(), 'timed_steps', a.steps, 'placement', getattr(b, 'placement', None))
+print(c, 'points', b.total_points, 'stage points', b.stage_points(), 'timed_steps', a.steps, 'layout', getattr(b, 'layout', None), 'placement', getattr(b, 'placement', None))
