@@ -145,6 +145,14 @@ double distance_to_boundary(double x, double y, double dx, double dy, double L, 
     return std::min(best, 3.0 * R);
 }
 
+// a straight primitive whose numpy.linspace step underflowed to 0 although its ends differ (no real field has one): form bit 3 sends the
+// one-point-per-lane kernel through the general evaluation (fcpp_pointfn.h: eval_prim_lanes)
+void flag_degenerate(DevPrim &p)
+{
+    if (p.kind == PRIM_LINSPACE && ((p.a[4] == 0.0 && p.a[2] != p.a[0]) || (p.a[5] == 0.0 && p.a[3] != p.a[1]))) p.form |= 8;
+    if (p.kind == PRIM_RAY && p.a[5] == 0.0 && p.a[4] != 0.0) p.form |= 8;
+}
+
 const int kCornerQuadrant[4] = { 1, 2, 3, 0 };  // start heading of the corner arcs = q * pi/2 (MLP:1049-1060)
 
 // everything about a batch that does not depend on the field: validated parameters, turn shapes, sample counts
@@ -339,7 +347,7 @@ int64_t plan_field(const PlanConsts &pc, const fcpp_field &f, const fcpp_polys *
             const double lo = std::min(lsx, lex), hi = std::max(lsx, lex);
             int64_t pos1 = 0;
             bool unsupported = false;
-            auto push1 = [&](DevPrim &pr) { pr.start = pos1; pos1 += pr.n; if (want_device) prims.push_back(pr); };
+            auto push1 = [&](DevPrim &pr) { pr.start = pos1; pos1 += pr.n; flag_degenerate(pr); if (want_device) prims.push_back(pr); };
             auto world = [&](double &x, double &y) { if (rotated) rotate_point(x, y, rc, rs, ccx, ccy, x, y); };
             auto push_line = [&](double ax, double ay, double bx, double by, uint32_t kind, int64_t pi, double vnom, bool detour) {
                 const double len = sqrt((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
@@ -419,7 +427,7 @@ int64_t plan_field(const PlanConsts &pc, const fcpp_field &f, const fcpp_polys *
         int64_t pos = n_main;
         bool bad = false;
         double first_head[2] = { 0, 0 }, last_head[2] = { 0, 0 };
-        auto push = [&](DevPrim &p) { p.start = pos; pos += p.n; if (want_device) prims.push_back(p); };
+        auto push = [&](DevPrim &p) { p.start = pos; pos += p.n; flag_degenerate(p); if (want_device) prims.push_back(p); };
         for (int loop = 0; loop < num_loops && !bad; ++loop) {
             const double offset = W / 2 + loop * W;
             Quad c;

@@ -142,6 +142,27 @@ __device__ __forceinline__ void eval_prim(const DevPrim &p, const DevConst &cst,
     }
 }
 
+// The same for the one-point-per-lane kernel (fcpp_sparse_fn.h), whose wavefronts hold several primitive kinds side by side and pay for
+// every branch that any lane takes: the three straight kinds -- point, numpy.linspace segment, reverse ray -- go through ONE form
+//     t = r * ts ;  p = a0 + t * d        (linspace: ts = 1, d = step;  ray: ts = t-step, d = unit direction;  point: r = 0)
+// with the last sample of a segment set to its end point (numpy.linspace stores `stop` itself) and the last ray parameter to the ray's
+// length: the same roundings as linspace_at32 / eval_prim, sample for sample.  A segment whose step underflowed to zero although its
+// ends differ (form bit 3, set by the host; no real field has one) takes eval_prim.
+__device__ __forceinline__ void eval_prim_lanes(const DevPrim &p, const DevConst &cst, int r, double &px, double &py, const double2 &tc)
+{
+    const int kind = p.kind;
+    if (kind == PRIM_POINT || kind == PRIM_LINSPACE || kind == PRIM_RAY) {
+        if (__builtin_expect(p.form & 8, 0)) { eval_prim(p, cst, r, px, py, &tc); return; }
+        const bool ray = kind == PRIM_RAY;
+        const bool last = p.n > 1 && r == p.n - 1;
+        const double ts = ray ? p.a[5] : 1.0, dx = ray ? p.a[2] : p.a[4], dy = ray ? p.a[3] : p.a[5];
+        const double t = (ray && last) ? p.a[4] : (double)r * ts;
+        px = p.a[0] + t * dx;
+        py = p.a[1] + t * dy;
+        if (last && !ray) { px = p.a[2]; py = p.a[3]; }
+    } else eval_prim(p, cst, r, px, py, &tc);
+}
+
 // the batch's primitive table, or a field's primitives staged in LDS: indexed by the batch-wide primitive index either way
 struct PrimTable {
     const DevPrim *p;
@@ -258,6 +279,18 @@ __device__ __forceinline__ double curv_chords_inline(double dx1, double dy1, dou
     const double k = curv_chords_fast(dx1, dy1, ds1, dx2, dy2, ds2, slow);
     if (!slow) return k;
     return fabs(2 * atan2_fd(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / (ds1 + ds2));
+}
+
+// ... and through atan2_fd alone (one point per lane: fcpp_sparse_fn.h).  At the reference's sampling every wavefront of that kernel
+// holds junctions between primitives, whose turning angles are far beyond the short series of curv_chords_fast, so it paid for the
+// series AND for the atan2 fallback; atan2_fd's first interval (|cross| < 7/16 dot) is a series of the same length anyway.  Exactly
+// collinear chords still give exactly 0 (atan2_fd(0, dot > 0) = 0).
+__device__ __forceinline__ double curv_chords_atan(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)
+{
+    if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
+    const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
+    if (cr == 0.0 && dt > 0.0) return 0.0;
+    return fabs(2 * atan2_fd(cr, dt) / (ds1 + ds2));
 }
 
 // wave-wide reductions; a ballot skips the butterfly when every lane holds the neutral element (most tiles have

@@ -66,7 +66,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     if (in_l2) {
         int kind = p.kind;
         asm volatile("" : "+v"(tc.x), "+v"(tc.y), "+v"(kind));     // (needs both values: neither load may be sunk behind the other's wait)
-        eval_prim(p, cst, r, px, py, &tc);
+        eval_prim_lanes(p, cst, r, px, py, tc);
         fw = p.fs;
     }
     // nominal speed: layer 1 by kind (swath / U-turn), layer 2 from the primitive record (the host sets it by the same table as
@@ -82,7 +82,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     const double dnext = lane_next(dprev);
     const bool interior = has_prev && lane < nl - 1 && !is_last;             // both neighbours are lanes of this wave
     double kappa = 0.0;
-    if (interior) kappa = curv_chords_inline(dx1, dy1, dprev, xp - px, yp - py, dnext);
+    if (interior) kappa = curv_chords_atan(dx1, dy1, dprev, xp - px, yp - py, dnext);
     bool cl = false;
     double v0 = vn;
     if (kappa > 1e-6) v0 = clamped_speed(vn, kappa, cst, cl);
