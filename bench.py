@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument('--fields', type=int, default=4096, help='fields of 500 x 200 m per GPU in the headline batch')
     ap.add_argument('--mode', type=int, default=1, help='1 = fused pipeline (default), 0 = staged pipeline')
     ap.add_argument('--configs', default='all',
-                    help="'all', 'none' or a comma list of: cfg1_clothoid,cfg1_clothoid_dense,cfg2_ref,cfg2_0.5,cfg2_0.1,cfg3,cfg4,cfg5,single_field")
+                    help="'all', 'none' or a comma list of: cfg1_clothoid,cfg1_clothoid_dense,cfg2_ref,cfg2_0.5,cfg2_0.1,cfg3,cfg3_avoid,cfg4,cfg5,single_field")
     ap.add_argument('--calibrate', type=int, default=0, help='opt-in: also report the dense configs and cfg5 with Batch.alloc(best_of=N) output arrays (never the primary figure)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=8.0, help='seconds of CPU baseline for the headline (the other configs get 3 s each)')
@@ -324,7 +324,7 @@ def main():
         return float(t.item())
 
     want = args.configs.split(',') if args.configs not in ('all', 'none') else (
-        ['cfg1_clothoid', 'cfg1_clothoid_dense', 'cfg2_ref', 'cfg2_0.5', 'cfg2_0.1', 'cfg3', 'cfg4', 'cfg5', 'single_field'] if args.configs == 'all' else [])
+        ['cfg1_clothoid', 'cfg1_clothoid_dense', 'cfg2_ref', 'cfg2_0.5', 'cfg2_0.1', 'cfg3', 'cfg3_avoid', 'cfg4', 'cfg5', 'single_field'] if args.configs == 'all' else [])
     cpu_on = world == 1 and not args.no_cpu_baseline
 
     # ---- headline: 4096 x (500 x 200 m) per GPU, arcs at the reference's sampling (the pinned mode) ------------------------------
@@ -472,6 +472,17 @@ def main():
             planner_config('cfg3', 'cfg3: one 5000 x 2000 m field, 32 convex eight-gon obstacles, clothoid turns, 0.05 m sample spacing',
                            E.FieldTable.from_specs([E.FieldSpec(field_length=L3, field_width=H3, obstacles=obst)]), E.make_options(1, 0.05), max(5, args.steps // 10), 2,
                            extra_fn=cfg3_extra, calibrate=args.calibrate, e2e_reps=3, cpu_fn=cfg3_cpu)
+        if 'cfg3_avoid' in want:
+            (L3, H3), obst = WL.cfg3_field()
+
+            def cfg3a_extra(rr):
+                st3 = rr['res'].stats()
+                fs = rr['res'].flagseg
+                return {'n_in_obstacle': int(st3['n_in_obstacle'][0]), 'detour_points': int(((fs & E.L.KIND_MASK) == E.L.KIND_DETOUR).sum())}
+            planner_config('cfg3_avoid', 'cfg3 with obstacle-aware swaths (fcpp_options.obstacle_mode = AVOID, SURVEY.md 8f-4): every swath that meets one of '
+                           'the 32 obstacles is clipped and driven around it; clothoid turns, 0.05 m',
+                           E.FieldTable.from_specs([E.FieldSpec(field_length=L3, field_width=H3, obstacles=obst)]), E.make_options(1, 0.05, avoid_obstacles=True),
+                           max(5, args.steps // 10), 2, extra_fn=cfg3a_extra, e2e_reps=3)
         if 'cfg4' in want:
             configs.append(run_cfg4(E, torch, WL, cpu_on))
         if 'single_field' in want:

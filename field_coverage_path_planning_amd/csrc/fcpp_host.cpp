@@ -343,6 +343,21 @@ int64_t plan_field(const PlanConsts &pc, const fcpp_field &f, const fcpp_polys *
                 boxes.push_back(b);
             }
             if (bad_obs) { return fail(FCPP_ESIZE); }
+            // grown boxes that overlap or touch become ONE box (their bounding box), until no two do: the boxes are then disjoint,
+            // so a detour leg -- which runs on the boundary of its own box -- cannot enter another one
+            for (bool merged = true; merged;) {
+                merged = false;
+                for (size_t i = 0; i < boxes.size(); ++i)
+                    for (size_t j = i + 1; j < boxes.size();) {
+                        Box &a = boxes[i];
+                        const Box &b = boxes[j];
+                        if (a.x0 <= b.x1 + 1e-9 && b.x0 <= a.x1 + 1e-9 && a.y0 <= b.y1 + 1e-9 && b.y0 <= a.y1 + 1e-9) {
+                            a.x0 = std::min(a.x0, b.x0); a.y0 = std::min(a.y0, b.y0); a.x1 = std::max(a.x1, b.x1); a.y1 = std::max(a.y1, b.y1);
+                            boxes.erase(boxes.begin() + (long)j);
+                            merged = true;
+                        } else ++j;
+                    }
+            }
             const double rc = cos(rot), rs = sin(rot);
             const double lo = std::min(lsx, lex), hi = std::max(lsx, lex);
             int64_t pos1 = 0;
@@ -379,7 +394,12 @@ int64_t plan_field(const PlanConsts &pc, const fcpp_field &f, const fcpp_polys *
                     const double nearx = go_left ? b.x1 : b.x0, farx = go_left ? b.x0 : b.x1;
                     // the box must lie strictly inside the line, beyond the previous box
                     if (!(b.x0 > lo + 1e-9 && b.x1 < hi - 1e-9) || !(go_left ? nearx < cur - 1e-9 : nearx > cur + 1e-9)) { unsupported = true; break; }
-                    const double ys = (b.y1 - y <= y - b.y0) ? b.y1 : b.y0;
+                    // over the nearer side (top or bottom) if that keeps the detour inside the work area's y-range, else over the
+                    // other one; a box that leaves room on neither side cannot be driven around
+                    const bool top_ok = b.y1 <= max_y + 1e-9, bot_ok = b.y0 >= min_y - 1e-9;
+                    const bool want_top = b.y1 - y <= y - b.y0;
+                    if (!top_ok && !bot_ok) { unsupported = true; break; }
+                    const double ys = (want_top ? top_ok : !bot_ok) ? b.y1 : b.y0;
                     push_line(cur, y, nearx, y, FCPP_KIND_SWATH, pi, veh.max_work_speed_kmh, false);
                     push_line(nearx, y, nearx, ys, FCPP_KIND_DETOUR, pi, veh.headland_turn_speed_kmh, true);
                     push_line(nearx, ys, farx, ys, FCPP_KIND_DETOUR, pi, veh.headland_turn_speed_kmh, true);

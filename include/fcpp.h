@@ -68,14 +68,17 @@ typedef struct fcpp_options {
 
 /* Obstacle-aware swaths (what README_en.md:156-178 promises and MLP:601-609 prepares: obstacles expanded by
  * working_width / 2 and taken out of the work area).  Build-defined -- the reference has no code for it.  In the frame of layer 1
- * (MLP:686-687) every obstacle is represented by the bounding box of its vertices grown by W/2 on every side.  A swath line whose
- * y lies strictly inside a box is CLIPPED at the box: the vehicle works up to the box's near side, drives three straight legs
- * around it -- along the near side to the box's top or bottom (the closer one), along that side, and back along the far side to
- * the line -- and resumes the swath (segment kind FCPP_KIND_DETOUR, nominal speed headland_turn_speed_kmh; sampled like the
- * reverse fills at the reference's sampling: 0.5 m, at least 2 points per leg).  Sub-swaths and legs are numpy.linspace runs
- * between their end points in field coordinates; U-turns are unchanged.  A field where a box reaches a swath line's end zone
- * (within 1e-9 of line_start_x / line_end_x), or where two boxes overlap along one line, is refused with FCPP_EUNSUPPORTED (its
- * status; the other fields of the batch are planned).  The headland loops are not re-routed. */
+ * (MLP:686-687) every obstacle is represented by the bounding box of its vertices grown by W/2 on every side; grown boxes that overlap
+ * or touch are merged into their common bounding box until no two do, so the boxes are disjoint.  A swath line whose y lies strictly
+ * inside a box is CLIPPED at the box: the vehicle works up to the box's near side, drives three straight legs around it -- along
+ * the near side to the box's top or bottom, along that side, and back along the far side to the line -- and resumes the swath
+ * (segment kind FCPP_KIND_DETOUR, nominal speed headland_turn_speed_kmh; sampled like the reverse fills at the reference's sampling:
+ * 0.5 m, at least 2 points per leg).  The legs run on the boundary of their own box and the boxes are disjoint: no leg enters another
+ * obstacle.  The side is the closer one (top or bottom) unless it lies outside the y-range of the main work area (the detour would
+ * enter the headland), then the other; a box with room on neither side is refused.  Sub-swaths and legs are numpy.linspace runs
+ * between their end points in field coordinates; U-turns are unchanged.  A field where a box reaches a swath line's end zone (within
+ * 1e-9 of line_start_x / line_end_x) or leaves no side to pass is refused with FCPP_EUNSUPPORTED (its status; the other fields of the
+ * batch are planned).  The headland loops are not re-routed. */
 enum { FCPP_OBSTACLES_FLAG = 0, FCPP_OBSTACLES_AVOID = 1 };
 
 /* ---- one field = one planner instance (ctor arguments, MLP:63-72) ---------------------- */

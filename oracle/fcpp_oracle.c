@@ -695,6 +695,22 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             bx0[nbox] = x0 - W / 2; by0[nbox] = y0 - W / 2; bx1[nbox] = x1 + W / 2; by1[nbox] = y1 + W / 2;
             ++nbox;
         }
+        /* grown boxes that overlap or touch become one box (their bounding box), until no two do (include/fcpp.h) */
+        for (int merged = 1; merged;) {
+            merged = 0;
+            for (int i = 0; i < nbox; ++i)
+                for (int j = i + 1; j < nbox;) {
+                    if (bx0[i] <= bx1[j] + 1e-9 && bx0[j] <= bx1[i] + 1e-9 && by0[i] <= by1[j] + 1e-9 && by0[j] <= by1[i] + 1e-9) {
+                        if (bx0[j] < bx0[i]) bx0[i] = bx0[j];
+                        if (by0[j] < by0[i]) by0[i] = by0[j];
+                        if (bx1[j] > bx1[i]) bx1[i] = bx1[j];
+                        if (by1[j] > by1[i]) by1[i] = by1[j];
+                        for (int q = j; q + 1 < nbox; ++q) { bx0[q] = bx0[q + 1]; by0[q] = by0[q + 1]; bx1[q] = bx1[q + 1]; by1[q] = by1[q + 1]; }
+                        --nbox;
+                        merged = 1;
+                    } else ++j;
+                }
+        }
         double lo = lsx < lex ? lsx : lex, hi = lsx < lex ? lex : lsx;
         int unsupported = 0;
         double *tb = (double *)malloc((size_t)n_turn * 2 * sizeof(double));
@@ -723,7 +739,10 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
                     int k = ord[a];
                     double nearx = go_left ? bx1[k] : bx0[k], farx = go_left ? bx0[k] : bx1[k];
                     if (!(bx0[k] > lo + 1e-9 && bx1[k] < hi - 1e-9) || !(go_left ? nearx < cur - 1e-9 : nearx > cur + 1e-9)) { unsupported = 1; break; }
-                    double ys = (by1[k] - y <= y - by0[k]) ? by1[k] : by0[k];
+                    /* the nearer side if it keeps the detour inside the work area's y-range, else the other; neither: refused */
+                    int top_ok = by1[k] <= max_y + 1e-9, bot_ok = by0[k] >= min_y - 1e-9, want_top = by1[k] - y <= y - by0[k];
+                    if (!top_ok && !bot_ok) { unsupported = 1; break; }
+                    double ys = (want_top ? top_ok : !bot_ok) ? by1[k] : by0[k];
                     double L4[4][4] = { { cur, y, nearx, y }, { nearx, y, nearx, ys }, { nearx, ys, farx, ys }, { farx, ys, farx, y } };
                     memcpy(legs, L4, sizeof(L4));
                     kinds[0] = swath; kinds[1] = kinds[2] = kinds[3] = detour;

@@ -107,6 +107,31 @@ def test_cfg3_full_size(turn_model):
     batch.close()
 
 
+def test_cfg3_with_obstacle_aware_swaths():
+    """cfg3 in AVOID mode: the 5000 x 2000 m field, 32 obstacles, 0.05 m -- every swath that meets an obstacle is clipped
+    and driven around it; the whole path against the oracle, no point of it inside an obstacle, detours present."""
+    (Lf, Hf), obstacles = WL.cfg3_field()
+    opt = E.make_options(1, 0.05, avoid_obstacles=True)
+    batch = E.Batch([E.FieldSpec(field_length=Lf, field_width=Hf, obstacles=obstacles)], E.make_vehicle(), opt)
+    assert batch.info[0].status == 0
+    res = batch.run()
+    st = res.stats()
+    fs = res.flagseg
+    assert int(st['n_in_obstacle'][0]) == 0 and int(((fs & L.FLAG_OBSTACLE) != 0).sum()) == 0
+    n_detour = int(((fs & L.KIND_MASK) == L.KIND_DETOUR).sum())
+    assert n_detour > 10000
+    rc, p = orc.plan_field(orc.make_field(L=Lf, H=Hf, obstacles=obstacles), orc.Vehicle.make(), orc.Options.make(1, 1, 0.05, 0.5, 1e-6, 1))
+    assert rc == 0 and p.n == batch.total_points and (p.n_main, p.n_head) == (batch.info[0].n_main, batch.info[0].n_head)
+    assert float(np.abs(res.x.cpu().numpy() - p.xy[:, 0]).max()) <= 1e-9 and float(np.abs(res.y.cpu().numpy() - p.xy[:, 1]).max()) <= 1e-9
+    k_tol = 4e-12 / 0.05 ** 2 * 4
+    assert float(np.abs(res.kappa.cpu().numpy() - p.kappa).max()) <= k_tol
+    assert float(np.abs(res.v.cpu().numpy() - p.v).max()) <= 200 * k_tol
+    assert np.array_equal(fs.cpu().numpy().view(np.uint32), p.flagseg)
+    assert (int(st['n_outside'][0]), int(st['n_viol'][0]), int(st['n_adjusted'][0])) == (p.n_outside, p.n_viol, p.n_adjusted)
+    np.testing.assert_allclose([st['main_len_m'][0], st['head_len_m'][0]], [p.main_len_m, p.head_len_m], rtol=1e-10)
+    batch.close()
+
+
 def test_cfg1_batch_4096_equals_golden_and_single_field(golden_plans):
     """The metric's own workload: 4096 x (500 x 200 m) in the reference's model.  Every field of the batch equals the reference's
     plan (golden cfg1_500x200) -- position in the batch, tile alignment and chunking must not matter."""

@@ -233,28 +233,61 @@ def test_obstacle_aware_swaths_vs_oracle(opt):
 
 
 def test_obstacle_aware_swaths_edge_cases():
-    """An obstacle box that reaches a swath line's end zone, or two boxes that overlap along a line: FCPP_EUNSUPPORTED for that field
-    only (library and oracle agree); a field without obstacles plans as without the option (unrotated: coordinates and segment words
-    bit for bit)."""
+    """An obstacle box that reaches a swath line's end zone, or one that leaves no side to pass (it spans the work area's whole
+    y-range): FCPP_EUNSUPPORTED for that field only (library and oracle agree).  Two boxes that overlap are merged into one and driven
+    around together.  A field without obstacles plans as without the option (unrotated: coordinates and segment words bit for bit)."""
     near_end = [[(10.0, 100.0), (30.0, 100.0), (30.0, 120.0), (10.0, 120.0)]]
     overlap = [[(150.0, 60.0), (170.0, 60.0), (170.0, 80.0), (150.0, 80.0)], [(165.0, 65.0), (190.0, 65.0), (190.0, 85.0), (165.0, 85.0)]]
+    wall = [[(200.0, 5.0), (210.0, 5.0), (210.0, 215.0), (200.0, 215.0)]]
     specs = [E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=near_end),
              E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=overlap),
-             E.FieldSpec(field_length=400.0, field_width=220.0)]
+             E.FieldSpec(field_length=400.0, field_width=220.0),
+             E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=wall)]
     ofs = [orc.make_field(L=400.0, H=220.0, obstacles=near_end), orc.make_field(L=400.0, H=220.0, obstacles=overlap),
-           orc.make_field(L=400.0, H=220.0)]
+           orc.make_field(L=400.0, H=220.0), orc.make_field(L=400.0, H=220.0, obstacles=wall)]
     for kw in (dict(avoid_obstacles=True), dict(avoid_obstacles=True, sample_spacing=0.5)):
         _compare_with_oracle(specs, ofs, DEFAULT_VP, kw, k_tol=1e-8, v_tol=1e-6)
         b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**kw))
-        assert [i.status for i in b.info] == [L.EUNSUPPORTED, L.EUNSUPPORTED, 0]
+        assert [i.status for i in b.info] == [L.EUNSUPPORTED, 0, 0, L.EUNSUPPORTED]
         r1 = b.run()
-        b0 = E.Batch(specs[2:], _veh(DEFAULT_VP), E.make_options(**{k: v for k, v in kw.items() if k != 'avoid_obstacles'}))
+        st = r1.stats()
+        assert int(st['n_in_obstacle'][1]) == 0           # the merged box is passed as one
+        b0 = E.Batch(specs[2:3], _veh(DEFAULT_VP), E.make_options(**{k: v for k, v in kw.items() if k != 'avoid_obstacles'}))
         r0 = b0.run()
+        sl = r1.field_slice(2)
         for a in ('x', 'y', 'flagseg'):
-            assert np.array_equal(_np(getattr(r1, a)), _np(getattr(r0, a))), a
+            assert np.array_equal(_np(getattr(r1, a))[sl], _np(getattr(r0, a))), a
         for a in ('kappa', 'v'):      # (the closed-form U-turns of the plain mode take curvature from the turn shape itself)
-            np.testing.assert_allclose(_np(getattr(r1, a)), _np(getattr(r0, a)), rtol=0, atol=1e-9, err_msg=a)
+            np.testing.assert_allclose(_np(getattr(r1, a))[sl], _np(getattr(r0, a)), rtol=0, atol=1e-9, err_msg=a)
         b.close(); b0.close()
+
+
+def test_detours_never_cross_another_obstacle():
+    """Found by review in round 2: an obstacle just above another one -- the detour around the first ran through the second and the
+    field still came back OK.  Grown boxes that overlap are now merged, a leg runs on the boundary of its own (merged) box, and a side
+    that would leave the work area is not taken: either the field is refused or no path point lies inside an obstacle.  The reviewer's
+    layout, variations of it, and a few hundred random pairs of nearby obstacles, library against oracle."""
+    A = [(240.0, 23.5), (260.0, 23.5), (260.0, 24.4), (240.0, 24.4)]
+    Bq = [(245.0, 25.9), (255.0, 25.9), (255.0, 26.4), (245.0, 26.4)]
+    rng = np.random.default_rng(11)
+    layouts = [[A, Bq], [Bq, A], [A, [(x + 30.0, y) for x, y in Bq]], [A, [(x, y + 1.0) for x, y in Bq]], [A, [(x, y - 4.0) for x, y in Bq]]]
+    for _ in range(40):
+        cx, cy = rng.uniform(80, 420), rng.uniform(30, 170)
+        obs = []
+        for _k in range(int(rng.integers(2, 5))):
+            ox, oy, w, h = cx + rng.uniform(-25, 25), cy + rng.uniform(-12, 12), rng.uniform(2, 20), rng.uniform(0.5, 8)
+            obs.append([(ox, oy), (ox + w, oy), (ox + w, oy + h), (ox, oy + h)])
+        layouts.append(obs)
+    specs = [E.FieldSpec(field_length=500.0, field_width=200.0, obstacles=o) for o in layouts]
+    ofs = [orc.make_field(L=500.0, H=200.0, obstacles=o) for o in layouts]
+    for kw in (dict(avoid_obstacles=True), dict(avoid_obstacles=True, sample_spacing=0.4)):
+        _compare_with_oracle(specs, ofs, DEFAULT_VP, kw, k_tol=1e-8, v_tol=1e-6)
+        b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**kw))
+        st = b.run().stats()
+        ok = np.array([i.status for i in b.info]) == 0
+        assert ok[:5].all() and ok.sum() >= len(layouts) // 2
+        assert int(st['n_in_obstacle'][ok].sum()) == 0
+        b.close()
 
 
 def test_error_fields_inside_a_batch():
