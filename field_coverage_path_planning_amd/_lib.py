@@ -13,6 +13,7 @@ OK, EINVAL, EHEADLAND, EUNSUPPORTED, EHIP, ENOMEM, ESIZE = 0, -1, -2, -3, -4, -5
 TURN_ARC, TURN_CLOTHOID = 0, 1
 KIND_SWATH, KIND_UTURN, KIND_HEAD_START, KIND_HEAD_STRAIGHT, KIND_CORNER, KIND_REVERSE, KIND_DETOUR = range(7)
 OBSTACLES_FLAG, OBSTACLES_AVOID = 0, 1
+RING_AS_VERTICES, RING_REVERSED = 0, 1
 KIND_MASK, FLAG_HEADLAND, FLAG_ALAT, FLAG_OUTSIDE, FLAG_OBSTACLE, INDEX_SHIFT = 7, 8, 16, 32, 64, 8
 OUTPUT_PITCH = 24 << 30          # FCPP_OUTPUT_PITCH (include/fcpp.h)
 
@@ -34,7 +35,7 @@ class Vehicle(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('turn_model', C.c_int32), ('clothoid_fit', C.c_int32), ('sample_spacing', C.c_double),
-                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double), ('obstacle_mode', C.c_int32), ('_pad', C.c_int32)]
+                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double), ('obstacle_mode', C.c_int32), ('ring_order', C.c_int32)]
 
 
 class Field(C.Structure):

@@ -283,7 +283,7 @@ void fcpp_vehicle_default(fcpp_vehicle *v)
 void fcpp_options_default(fcpp_options *o)
 {
     o->turn_model = FCPP_TURN_ARC; o->clothoid_fit = 1; o->sample_spacing = 0.0; o->clothoid_frac = 0.5;
-    o->geofence_tol = 1e-6; o->obstacle_mode = FCPP_OBSTACLES_FLAG; o->_pad = 0;
+    o->geofence_tol = 1e-6; o->obstacle_mode = FCPP_OBSTACLES_FLAG; o->ring_order = FCPP_RING_AS_VERTICES;
 }
 
 int fcpp_ctx_create(int device_id, fcpp_ctx **out)

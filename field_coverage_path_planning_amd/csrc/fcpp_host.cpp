@@ -172,7 +172,8 @@ int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c
     const double W = veh.working_width, R = veh.min_turn_radius, ds = opt.sample_spacing;
     if (!(W > 0) || !(R > 0) || !(ds >= 0) || !(opt.clothoid_frac >= 0 && opt.clothoid_frac <= 1) ||
         (opt.turn_model != FCPP_TURN_ARC && opt.turn_model != FCPP_TURN_CLOTHOID) ||
-        (opt.obstacle_mode != FCPP_OBSTACLES_FLAG && opt.obstacle_mode != FCPP_OBSTACLES_AVOID)) {
+        (opt.obstacle_mode != FCPP_OBSTACLES_FLAG && opt.obstacle_mode != FCPP_OBSTACLES_AVOID) ||
+        (opt.ring_order != FCPP_RING_AS_VERTICES && opt.ring_order != FCPP_RING_REVERSED)) {
         err = "invalid vehicle parameters or options";
         return FCPP_EINVAL;
     }
@@ -452,6 +453,7 @@ int64_t plan_field(const PlanConsts &pc, const fcpp_field &f, const fcpp_polys *
             const double offset = W / 2 + loop * W;
             Quad c;
             if (!inset(q, mit, offset, c) || abs_area(c) < 1.0) { bad = true; break; }
+            if (opt.ring_order == FCPP_RING_REVERSED) { std::swap(c.x[1], c.x[3]); std::swap(c.y[1], c.y[3]); }      // ring lists 0, 3, 2, 1
             const uint32_t lp = FCPP_FLAG_HEADLAND | ((uint32_t)(loop * 8) << FCPP_INDEX_SHIFT);
             DevPrim p;
             memset(&p, 0, sizeof(p));

@@ -70,7 +70,7 @@ def make_vehicle(vp=None, **kw):
 
 
 def make_options(turn_model=L.TURN_ARC, sample_spacing=0.0, clothoid_frac=0.5, clothoid_fit=1, geofence_tol=1e-6,
-                 avoid_obstacles=False):
+                 avoid_obstacles=False, ring_order=L.RING_AS_VERTICES):
     """fcpp_options.  avoid_obstacles: clip the swaths of layer 1 at the obstacles and drive around them (build-defined,
     include/fcpp.h); False = the reference's behaviour (obstacles only flag the points inside them)."""
     o = L.default_options()
@@ -80,6 +80,7 @@ def make_options(turn_model=L.TURN_ARC, sample_spacing=0.0, clothoid_frac=0.5, c
     o.clothoid_frac = float(clothoid_frac)
     o.clothoid_fit = int(clothoid_fit)
     o.geofence_tol = float(geofence_tol)
+    o.ring_order = int(ring_order)      # order of the inset corners in Shapely's buffer(-d).exterior.coords (include/fcpp.h)
     return o
 
 

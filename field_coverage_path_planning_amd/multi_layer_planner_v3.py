@@ -116,7 +116,7 @@ class TwoLayerPathPlannerV37:
                  end_point: Tuple[float, float] = None, *, vehicle: VehicleParams = None, verbose: bool = False,
                  turn_model: str = 'arc', sample_spacing: float = 0.0, clothoid_frac: float = 0.5,
                  clothoid_fit: int = 1, geofence_tol: float = 1e-6, coverage_resolution: float = 0.1, device: int = None,
-                 avoid_obstacles: bool = False):
+                 avoid_obstacles: bool = False, ring_order: int = 0):
         if vehicle_params is None:
             vehicle_params = vehicle if vehicle is not None else VehicleParams()   # README_en.md:274-302 uses vehicle=
         self.vehicle = vehicle_params
@@ -128,7 +128,7 @@ class TwoLayerPathPlannerV37:
         self._batch = self._bufs = None
         self._veh = E.make_vehicle(self.vehicle)
         self._opt = E.make_options(L.TURN_CLOTHOID if str(turn_model).lower().startswith('cloth') else L.TURN_ARC,
-                                   sample_spacing, clothoid_frac, clothoid_fit, geofence_tol, avoid_obstacles)
+                                   sample_spacing, clothoid_frac, clothoid_fit, geofence_tol, avoid_obstacles, ring_order)
         # _process_field_input (MLP:109-135): ValueError when no field is given
         if field_vertices is not None:
             self.field_vertices = field_vertices

@@ -63,8 +63,15 @@ typedef struct fcpp_options {
     int32_t obstacle_mode;  /* FCPP_OBSTACLES_FLAG: obstacles only set the validity flag of the points inside them (the reference: its
                                swath generator ignores the differenced work area, MLP:731-732); FCPP_OBSTACLES_AVOID: the swaths
                                of layer 1 are clipped against the obstacles and re-routed around them (below) */
-    int32_t _pad;
+    int32_t ring_order;     /* the order in which Shapely's `buffer(-offset).exterior.coords[:-1]` lists the four inset corners of a headland
+                               loop (MLP:964-972) -- a GEOS fact the reference neither documents nor tests, and its corner formulas index
+                               the list (MLP:1049-1060): FCPP_RING_AS_VERTICES = in the order of the field vertices (the documented
+                               intent 0=LL, 1=LR, 2=UR, 3=UL of MLP:957; reproduces every number the reference publishes);
+                               FCPP_RING_REVERSED = the other way round from the same first vertex (0, 3, 2, 1: LL, UL, UR, LR -- what a
+                               clockwise shell starting at the first vertex lists).  INTEGRATION.md shows how a user with Shapely
+                               checks which one their GEOS produces.  Host-side permutation only. */
 } fcpp_options;
+enum { FCPP_RING_AS_VERTICES = 0, FCPP_RING_REVERSED = 1 };
 
 /* Obstacle-aware swaths (what README_en.md:156-178 promises and MLP:601-609 prepares: obstacles expanded by
  * working_width / 2 and taken out of the work area).  Build-defined -- the reference has no code for it.  In the frame of layer 1

@@ -827,6 +827,10 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             free(pb.xy); free(pb.v); free(pb.fs);
             return -2;                                                           /* MLP:967-969 then :939 */
         }
+        if (opt->ring_order == 1) {       /* the ring lists the corners the other way round from the same first vertex: 0, 3, 2, 1 */
+            double t = cx4[1]; cx4[1] = cx4[3]; cx4[3] = t;
+            t = cy4[1]; cy4[1] = cy4[3]; cy4[3] = t;
+        }
         uint32_t lp = ORC_FLAG_HEADLAND | ((uint32_t)(loop * 8) << ORC_INDEX_SHIFT);
         double p0[2] = { cx4[sci], cy4[sci] };
         pb_push(&pb, p0, 1, veh->max_headland_speed_kmh, ORC_KIND_HEAD_START | lp | ((uint32_t)sci << ORC_INDEX_SHIFT));

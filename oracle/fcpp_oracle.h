@@ -38,7 +38,9 @@ typedef struct {
     double clothoid_frac;   /* share of a turn's heading change spent in the two clothoids, [0,1] */
     double geofence_tol;    /* a point is out of field if it is more than this outside [m] */
     int32_t obstacle_mode;  /* 0 obstacles only flag points (the reference, MLP:731-732) ; 1 swaths clipped and re-routed (include/fcpp.h) */
-    int32_t _pad;
+    int32_t ring_order;     /* order in which `buffer(-d).exterior.coords[:-1]` lists the inset corners (MLP:964-972), a GEOS fact the reference
+                               never pins: 0 = as the field vertices (the documented intent LL, LR, UR, UL of MLP:957, 1049-1058);
+                               1 = the opposite direction from the same first vertex (LL, UL, UR, LR: a clockwise shell) */
 } orc_options;
 
 typedef struct {

@@ -55,11 +55,11 @@ class GaResult(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('turn_model', C.c_int32), ('clothoid_fit', C.c_int32), ('sample_spacing', C.c_double),
-                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double), ('obstacle_mode', C.c_int32), ('_pad', C.c_int32)]
+                ('clothoid_frac', C.c_double), ('geofence_tol', C.c_double), ('obstacle_mode', C.c_int32), ('ring_order', C.c_int32)]
 
     @classmethod
-    def make(cls, turn_model=0, clothoid_fit=1, sample_spacing=0.0, clothoid_frac=0.5, geofence_tol=1e-6, obstacle_mode=0):
-        return cls(turn_model, clothoid_fit, sample_spacing, clothoid_frac, geofence_tol, obstacle_mode, 0)
+    def make(cls, turn_model=0, clothoid_fit=1, sample_spacing=0.0, clothoid_frac=0.5, geofence_tol=1e-6, obstacle_mode=0, ring_order=0):
+        return cls(turn_model, clothoid_fit, sample_spacing, clothoid_frac, geofence_tol, obstacle_mode, ring_order)
 
 
 class Field(C.Structure):

@@ -65,7 +65,8 @@ def test_plan_count_vs_golden_and_oracle(golden_plans):
     for name in g['names']:
         spec = _specs_from_golden(g, name)
         veh = E.make_vehicle(**dict(zip([n for n, _ in L.Vehicle._fields_], g[f'{name}/vp'])))
-        info = E.plan_count([spec], veh, E.make_options())[0]
+        ring = int(g[f'{name}/ring_order'])
+        info = E.plan_count([spec], veh, E.make_options(ring_order=ring))[0]
         assert info.status == 0, name
         assert info.n_main == len(g[f'{name}/main_path']) and info.n_head == len(g[f'{name}/head_path']), name
         assert info.shape == shapes[str(g[f'{name}/shape'])]
@@ -74,7 +75,7 @@ def test_plan_count_vs_golden_and_oracle(golden_plans):
             np.allclose(list(info.corner_angles), g[f'{name}/corner_angles'], rtol=1e-14)
         # oracle: every integer decision identical
         from tests.test_oracle_vs_golden import _field_from_golden
-        rc, p = orc.plan_field(_field_from_golden(g, name), orc.Vehicle.make(g[f'{name}/vp']))
+        rc, p = orc.plan_field(_field_from_golden(g, name), orc.Vehicle.make(g[f'{name}/vp']), orc.Options.make(ring_order=ring))
         assert rc == 0
         for k in ('n_main', 'n_head', 'n_swaths', 'n_loops', 'start_corner', 'reverse_order', 'start_from_right',
                   'rotated', 'start_kept', 'end_kept', 'shape'):

@@ -44,10 +44,11 @@ def test_batch_vs_golden_plans(golden_plans, mode):
     g = golden_plans
     groups = {}
     for name in g['names']:
-        groups.setdefault(tuple(g[f'{name}/vp']), []).append(str(name))
-    for vp, names in groups.items():
+        groups.setdefault((tuple(g[f'{name}/vp']), int(g[f'{name}/ring_order'])), []).append(str(name))
+    assert any(ring == 1 for _, ring in groups)           # the reversed inset ring (cw_* scenarios): fcpp_options.ring_order = 1
+    for (vp, ring), names in groups.items():
         specs = [_specs_from_golden(g, n) for n in names]
-        batch = E.Batch(specs, _veh(vp))
+        batch = E.Batch(specs, _veh(vp), E.make_options(ring_order=ring))
         res = batch.run(mode=mode)
         ap, dp = batch.connectors()
         x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
@@ -95,7 +96,7 @@ def _compare_with_oracle_mode(mode, specs, ofields, veh_arr, opt_kw, xy_tol, k_t
     res = batch.run(mode=mode)
     x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
     st = res.stats()
-    oopt = orc.Options.make(o.turn_model, o.clothoid_fit, o.sample_spacing, o.clothoid_frac, o.geofence_tol, o.obstacle_mode)
+    oopt = orc.Options.make(o.turn_model, o.clothoid_fit, o.sample_spacing, o.clothoid_frac, o.geofence_tol, o.obstacle_mode, o.ring_order)
     for i, of in enumerate(ofields):
         rc, p = orc.plan_field(of, orc.Vehicle.make(veh_arr), oopt)
         info = batch.info[i]
@@ -139,7 +140,14 @@ def _random_fields(seed, n, para=False, with_obstacles=False, with_points=True):
         if para:
             ang, rot = np.radians(rng.uniform(60, 120)), rng.uniform(-np.pi / 4, np.pi / 4)
             sx = Hy / np.tan(ang)
-            vv = np.array([[0, 0], [Lx, 0], [Lx + sx, Hy], [sx, Hy]]) @ np.array([[np.cos(rot), np.sin(rot)], [-np.sin(rot), np.cos(rot)]])
+            q = np.array([[0, 0], [Lx, 0], [Lx + sx, Hy], [sx, Hy]], dtype=np.float64)
+            if para == 'quad':      # a convex quadrilateral that is no parallelogram (`_detect_field_shape` -> 'other', MLP:137-163)
+                q[2] += rng.uniform(-0.12, 0.12, 2) * (Lx, Hy)
+                q[3] += rng.uniform(-0.12, 0.12, 2) * (Lx, Hy)
+                e = np.roll(q, -1, 0) - q
+                cr = e[:, 0] * np.roll(e, -1, 0)[:, 1] - e[:, 1] * np.roll(e, -1, 0)[:, 0]
+                assert (cr > 0).all()
+            vv = q @ np.array([[np.cos(rot), np.sin(rot)], [-np.sin(rot), np.cos(rot)]])
             verts = [(float(a), float(b)) for a, b in vv]
             specs.append(E.FieldSpec(field_vertices=verts, obstacles=obstacles, start_point=start, end_point=end))
             ofs.append(orc.make_field(verts=verts, start=start, end=end, obstacles=obstacles))
@@ -161,6 +169,24 @@ def test_reference_sampling_random_rectangles_vs_oracle():
 def test_reference_sampling_parallelograms_vs_oracle():
     specs, ofs = _random_fields(65536, 48, para=True)
     _compare_with_oracle(specs, ofs, DEFAULT_VP, {})
+
+
+@pytest.mark.parametrize('ring', [0, 1])
+def test_convex_quadrilaterals_and_both_ring_orders_vs_oracle(ring):
+    """Fields of shape 'other' (convex, neither rectangle nor parallelogram; the reference plans them, MLP:137-163), and
+    fcpp_options.ring_order -- the order in which the inset corners of a headland loop are listed (a GEOS fact the reference leaves
+    open; both orders are pinned to the reference's code by the cw_* fixtures): reference sampling, dense arcs and clothoids."""
+    specs, ofs = _random_fields(4242 + ring, 24, para='quad')
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(ring_order=ring))
+    assert all(i.status == 0 and i.shape == 2 for i in b.info)
+    b.close()
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(ring_order=ring))
+    _compare_with_oracle(specs[:8], ofs[:8], DEFAULT_VP, dict(ring_order=ring, sample_spacing=0.5), k_tol=1e-8, v_tol=1e-6)
+    _compare_with_oracle(specs[:8], ofs[:8], DEFAULT_VP, dict(ring_order=ring, turn_model=1, sample_spacing=0.25), k_tol=1e-8, v_tol=1e-6)
+    specs, ofs = _random_fields(99 + ring, 12, para=True)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(ring_order=ring))
+    specs, ofs = _random_fields(98 + ring, 12)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(ring_order=ring))
 
 
 def test_obstacles_and_geofence_flags_vs_oracle():

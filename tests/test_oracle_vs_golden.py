@@ -130,13 +130,20 @@ def test_full_plans(golden_plans):
     coordinates, the bounds, and `gap.area > 0.1`.  The ORDER in which `buffer(-d).exterior.coords` lists the inset corners (ring
     orientation and start vertex, MLP:972) is the stand-in's assumption -- the documented intent LL, LR, UR, UL of MLP:957 and
     1049-1058, which reproduces every number the reference publishes -- not an observation of GEOS: headland loop direction and
-    corner indices are 'documented intent', everything computed from them is reference-pinned."""
+    corner indices are 'documented intent', everything computed from them is reference-pinned.
+    The `cw_*` scenarios are the same plans with the stand-in listing the inset corners the OTHER way round from the same first vertex
+    (what a clockwise GEOS shell would list): options.ring_order = 1 in the oracle and in the library -- so both candidate orders are
+    pinned to the reference's code, and a user with Shapely selects the one their GEOS produces.
+    The `other_*` scenarios are convex quadrilaterals that are neither rectangles nor parallelograms (MLP:137-163 -> 'other')."""
     g = golden_plans
     shapes = {'rectangle': 0, 'parallelogram': 1, 'other': 2}
+    assert sum(str(n).startswith('cw_') for n in g['names']) >= 8 and sum(str(n).startswith('other_') for n in g['names']) >= 3
     for name in g['names']:
         f = _field_from_golden(g, name)
         veh = orc.Vehicle.make(g[f'{name}/vp'])
-        rc, p = orc.plan_field(f, veh)
+        ring = int(g[f'{name}/ring_order'])
+        assert ring == int(str(name).startswith('cw_'))
+        rc, p = orc.plan_field(f, veh, orc.Options.make(ring_order=ring))
         assert rc == 0, name
         mp, hp = g[f'{name}/main_path'], g[f'{name}/head_path']
         assert p.n_main == len(mp) and p.n_head == len(hp), name             # counts: exact

@@ -121,6 +121,13 @@ class Polygon:
         return False
 
 
+# Order in which buffer(-d).exterior.coords lists the inset corners (MLP:964-972): the one fact about GEOS's output ring the
+# reference's headland generator depends on and never states.  0: the order of the input ring (the documented intent of MLP:957);
+# 1: the opposite direction from the same first vertex (0, 3, 2, 1) -- what a clockwise shell starting there lists.
+# tools/gen_golden.py generates fixtures for both; fcpp_options.ring_order selects it in the library.
+RING_ORDER = 0
+
+
 def _inset_convex(vs, d):
     """Sharp inset of a convex polygon by distance d (same vertex order).
 
@@ -152,6 +159,8 @@ def _inset_convex(vs, d):
         ex, ey = vs[(i + 1) % n][0] - vs[i][0], vs[(i + 1) % n][1] - vs[i][1]
         if (x1 - x0) * ex + (y1 - y0) * ey <= 0:
             return Polygon(None, _empty=True)
+    if RING_ORDER == 1 and n == 4:
+        out = [out[0], out[3], out[2], out[1]]
     return Polygon(out)
 
 

@@ -26,11 +26,11 @@ VEHS = [T.DEFAULT_VP, [4.0, 5.0, 9.0, 20.0, 3.0, 2.5, 3.0, 0.8], [2.4, 6.0, 12.0
 while time.time() - t0 < a.seconds:
     seed = int(rng.integers(1, 1 << 30))
     n = int(rng.integers(3, 24))
-    para, obst = bool(rng.integers(0, 2)), a.avoid or bool(rng.integers(0, 3) == 0)
+    para, obst = [False, True, 'quad'][int(rng.integers(0, 3))], a.avoid or bool(rng.integers(0, 3) == 0)
     specs, ofs = T._random_fields(seed, n, para=para, with_obstacles=obst)
     tm = int(rng.integers(0, 2))
     sp = float(rng.choice([0.0, 0.0, 2.0, 1.0, 0.7, 0.5, 0.4, 0.33, 0.27, 0.25, 0.22, 0.2, 0.15, 0.1]))
-    opt = dict(turn_model=tm, sample_spacing=sp)
+    opt = dict(turn_model=tm, sample_spacing=sp, ring_order=int(rng.integers(0, 2)))
     if a.avoid:
         opt['avoid_obstacles'] = True
     if tm:

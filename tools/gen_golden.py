@@ -340,7 +340,22 @@ def scenarios():
         ang = rng.uniform(60, 120)
         rot = rng.uniform(-np.pi / 4, np.pi / 4)
         sc.append(d(name=f'rand_para_{i}', verts=parallelogram(float(b), float(h), float(ang), float(rot))))
+    # convex quadrilaterals that are neither rectangles nor parallelograms (`_detect_field_shape` -> 'other', MLP:137-163): the
+    # reference plans them like any other field
+    sc.append(d(name='other_trapezoid', verts=[(0.0, 0.0), (400.0, 0.0), (350.0, 150.0), (30.0, 150.0)]))
+    sc.append(d(name='other_trapezoid_rot', verts=rotate([(0.0, 0.0), (520.0, 0.0), (440.0, 210.0), (90.0, 190.0)], 0.4), start=(150.0, 60.0)))
+    sc.append(d(name='other_kite', verts=rotate([(0.0, 0.0), (300.0, -20.0), (360.0, 170.0), (-10.0, 140.0)], -0.25)))
+    # the same plans with the inset corners listed the other way round (the stand-in's RING_ORDER = 1, fcpp_options.ring_order = 1)
+    for base in ('cfg1_500x200', 'v351_start_end', 'v37_small', 'veh_w4_r5', 'verts_para_75', 'verts_para_110_rot', 'other_trapezoid',
+                 'other_trapezoid_rot'):
+        src = next(x for x in sc if x['name'] == base)
+        sc.append(dict(src, name='cw_' + base, ring_order=1))
     return sc
+
+
+def rotate(vs, ang):
+    c, s_ = np.cos(ang), np.sin(ang)
+    return [(float(x * c - y * s_), float(x * s_ + y * c)) for x, y in vs]
 
 
 def run_scenario(s):
@@ -355,14 +370,19 @@ def run_scenario(s):
         kw['field_vertices'] = s['verts']
     else:
         kw['field_length'], kw['field_width'] = s['L'], s['H']
-    pl = quiet(mlp.TwoLayerPathPlannerV37, **kw)
-    res = quiet(pl.plan_complete_coverage)
+    _shapely_standin.RING_ORDER = int(s.get('ring_order', 0))
+    try:
+        pl = quiet(mlp.TwoLayerPathPlannerV37, **kw)
+        res = quiet(pl.plan_complete_coverage)
+    finally:
+        _shapely_standin.RING_ORDER = 0
     mp, hp = res['main_work']['path'], res['headland']['path']
     ms, hs = res['main_work']['speeds'], res['headland']['speeds']
     allp, alls = np.vstack([mp, hp]), np.concatenate([ms, hs])
     ver = quiet(pl.verify_curvature_constraints, allp, alls)
     o = {}
     o['vp'] = vp_array(vp)
+    o['ring_order'] = np.array(int(s.get('ring_order', 0)))
     o['verts'] = np.array(pl.field_vertices, dtype=np.float64)
     o['is_verts_input'] = np.array(int('verts' in s))
     o['start'] = np.array(s.get('start', (np.nan, np.nan)), dtype=np.float64)
