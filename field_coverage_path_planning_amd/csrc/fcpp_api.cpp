@@ -203,7 +203,6 @@ struct fcpp_batch {
     std::vector<unsigned char> ev_set; // kProfRuns x kStages: the stage launched a kernel in that run
     int prof_runs = 0;
     int last_mode = 0;
-    bool partial_dirty = true;   // the fused pipeline's tile partials have not been zeroed yet
     bool two_streams = true;     // ALU-bound kernels of a step on the context's side stream (FCPP_ONE_STREAM=1 in the environment: off)
     int two_stream_max = 512;    // ... when there are at most this many general tiles (FCPP_TWO_STREAM_MAX, read at batch creation)
     fcpp_setup_times setup = {};
@@ -598,6 +597,8 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     if (n_fields > 0) {
         b->cst.field_junc = b->t.field_junc;
         LAUNCHCHK(launch_field_junctions(st, n_fields, b->t.fields, b->cst, b->t.field_junc));
+        // the statistics slots: closed-form statistics of the quiet runs (the same at every step), zeros elsewhere
+        LAUNCHCHK(launch_run_consts(st, lay.n_stat, b->t.stat_ids, b->t.stat_run, b->t.tiles, b->t.fields, b->t.prims, b->cst, b->t.partial));
     }
     HIPCHK(hipStreamSynchronize(st));
     tm.h2d_ms = ms_since(t0);
@@ -666,10 +667,6 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     if (mode == 1) {
         const FusedTables &t = b->t;
         const ImageLayout &lay = b->lay;
-        if (b->partial_dirty) {   // slots of quiet tiles that are not the first of their run stay zero from here on
-            if (lay.n_tiles > 0) HIPCHK(hipMemsetAsync(t.partial, 0, (size_t)lay.n_tiles * sizeof(TilePartial), st));
-            b->partial_dirty = false;
-        }
         // Two streams inside the step where the general tiles are FEW and long-lived (dense sampling of a single large field: a dozen
         // tiles that walk long halos, cfg3: 5873 points in 0.37 ms): beside the HBM-bound streaming kernel they cost nothing (cfg3
         // 0.87 -> 0.51 ms).  Not when the general kernel can fill the chip itself -- side by side it takes compute units from the
@@ -704,11 +701,11 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
                 // (a class that holds every path lists them in order: no list, one dependent load less in a latency-bound kernel)
                 const int32_t *list = lay.n_red[c] == lay.n_fields ? nullptr : pl;
                 if (first)
-                    STAGE(4, launch_reduce_stats(st, lay.n_red[c], t.partial, t.stat_first, nullptr, stats, t.stat_ids, t.stat_run, t.tiles,
-                                                 t.fields, t.prims, &b->cst, list, groups[c], c == 3 ? t.red_scratch : nullptr));
+                    STAGE(4, launch_reduce_stats(st, lay.n_red[c], t.partial, t.stat_first, nullptr, stats, nullptr, nullptr, nullptr,
+                                                 nullptr, nullptr, &b->cst, list, groups[c], c == 3 ? t.red_scratch : nullptr, 1));
                 else
-                    LAUNCHCHK(launch_reduce_stats(st, lay.n_red[c], t.partial, t.stat_first, nullptr, stats, t.stat_ids, t.stat_run, t.tiles,
-                                                  t.fields, t.prims, &b->cst, list, groups[c], c == 3 ? t.red_scratch : nullptr));
+                    LAUNCHCHK(launch_reduce_stats(st, lay.n_red[c], t.partial, t.stat_first, nullptr, stats, nullptr, nullptr, nullptr,
+                                                  nullptr, nullptr, &b->cst, list, groups[c], c == 3 ? t.red_scratch : nullptr, 1));
                 first = false;
                 pl += lay.n_red[c];
             }

@@ -74,7 +74,11 @@ int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, co
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr,
                         const int64_t *run_count = nullptr, const DevTile *tiles = nullptr, const DevField *fields = nullptr,
                         const DevPrim *prims = nullptr, const DevConst *cst = nullptr, const int32_t *path_list = nullptr, int group = 64,
-                        void *scratch = nullptr);      // scratch: 64 x 104 bytes per path of the list (group 256 only: sliced reduction)
+                        void *scratch = nullptr,       // scratch: 64 x 104 bytes per path of the list (group 256 only: sliced reduction)
+                        int clear_counts = 0);         // fused pipeline: entries lie side by side (no ids), flag counts of run slots are cleared
+// batch creation: closed-form statistics of the quiet runs into their slots, zeros into the others (see k_run_consts)
+int launch_run_consts(hipStream_t st, int64_t n_entries, const int32_t *ids, const int64_t *run_count, const DevTile *tiles, const DevField *fields,
+                      const DevPrim *prims, const DevConst &cst, TilePartial *partial);
 int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc);
 // ids: tile indices the launch covers (NULL = all tiles in order)
 int launch_plan_fused(hipStream_t st, int variant, int64_t n_tiles, const int32_t *ids, const DevTile *tiles,

@@ -734,7 +734,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         tp.max_kappa = a[6]; tp.max_alat = a[7]; tp.max_jump = a[8];
         tp.n_viol = b[0]; tp.n_outside = b[1]; tp.n_in_obstacle = b[2]; tp.n_adjusted = b[3];
 #ifndef FCPP_DIAG_STAMPS
-        partial[tile_id] = tp;
+        partial[tl.stat_tile] = tp;      // (the tile's statistics entry: the entries of a path lie side by side)
 #endif
     }
 #ifdef FCPP_DIAG_STAMPS
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(FBLOCK, MINW) void k_plan_fused(const DevTile *__re
         tp.max_kappa = (double)(stamp[10] - stamp[0]); tp.max_alat = (double)(stamp[11] - stamp[10]); tp.max_jump = (double)(stamp[1] - stamp[11]);
         tp.n_viol = (long long)(stamp[7] - stamp[6]); tp.n_outside = (long long)(stamp[8] - stamp[7]);
         tp.n_in_obstacle = (long long)(stamp[9] - stamp[8]); tp.n_adjusted = (long long)(stamp[9] - stamp[0]);
-        partial[tile_id] = tp;
+        partial[tl.stat_tile] = tp;
     }
 #endif
 }

@@ -70,7 +70,7 @@ struct DevTile {
     int64_t start;       // first point of the tile inside the field's path
     int32_t idx0, off0;  // layer 1 only: pass position idx and offset inside the pass of `start` (start = idx0*per + off0)
     int32_t quiet;       // 1: the tile and its sweep neighbourhood lie on ONE swath line (closed-form results, see fcpp_fused.hip)
-    int32_t stat_tile;   // quiet chunks only: the tile whose partial statistics collect this chunk's flag counts
+    int32_t stat_tile;   // general tiles and quiet chunks: the statistics entry (slot of `partial`) that collects this tile's / chunk's results
 };
 
 // A quiet run = one quiet zone of a straight primitive (consecutive quiet tiles).  Its points are STORED by chunks cut on
@@ -88,7 +88,7 @@ struct DevRun {
 struct DevWaveTile {
     int64_t out_base;        // index of lane 0's point in the batch arrays (pt_off + first)
     int32_t field;
-    int32_t tile;            // the tile's index in the tile table = its slot in the partial statistics
+    int32_t tile;            // the tile's statistics entry = its slot in the partial statistics (the entries of a field lie side by side)
     uint8_t count;           // output lanes ...
     uint8_t hb, hf;          // ... after hb halo lanes and before hf halo lanes (hb + count + hf <= 64)
     uint8_t inside;          // 1: the host found every output point at least a millimetre inside the field polygon (no geofence test needed)

@@ -371,10 +371,14 @@ static_assert(sizeof(StatAcc) == 104, "red_scratch in fcpp_api.cpp is sized for 
 
 __device__ __forceinline__ void stat_entry(StatAcc &s, int64_t t, TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
                                            const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
-                                           const FieldStatView &fv, const DevPrim *__restrict__ prims, const DevConst &cst)
+                                           const FieldStatView &fv, const DevPrim *__restrict__ prims, const DevConst &cst, int clear_counts = 0)
 {
     const int64_t slot = ids ? (int64_t)ids[t] : t;
     TilePartial tp = partial[slot];
+    // the fused pipeline (clear_counts): the entries of a path lie side by side in `partial`; the slot of a quiet run holds the run's
+    // closed-form statistics (written once, at batch creation: k_run_consts) and collects the flag counts k_plan_quiet adds while it
+    // stores the run -- cleared here for the next step
+    if (clear_counts && (tp.n_outside | tp.n_in_obstacle)) { partial[slot].n_outside = 0; partial[slot].n_in_obstacle = 0; }
     const int64_t rc = run_count ? run_count[t] : 0;
     if (rc > 0) {
         const DevRun run = { (int32_t)slot, 0, rc };
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_list, const int3
                                                      TilePartial *__restrict__ partial, const unsigned long long *__restrict__ n_adjusted,
                                                      fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids,
                                                      const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
-                                                     const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst)
+                                                     const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst, int clear_counts)
 {
     const int64_t slot = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     const int sub = threadIdx.x % G;
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats(int64_t n_list, const int3
     if (pth >= 0) {
         FieldStatView fv = {};
         if (fields) fv.load(fields, cst, pth);          // (the path's field: asked for beside the entry list, not through the tile records)
-        for (int64_t t = tile_first[pth] + sub; t < tile_first[pth + 1]; t += G) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst);
+        for (int64_t t = tile_first[pth] + sub; t < tile_first[pth + 1]; t += G) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst, clear_counts);
     }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) {
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats_slice(const int32_t *__res
                                                            TilePartial *__restrict__ partial, const int32_t *__restrict__ ids,
                                                            const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
                                                            const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst,
-                                                           StatAcc *__restrict__ scratch)
+                                                           StatAcc *__restrict__ scratch, int clear_counts)
 {
     __shared__ StatAcc sh[4];
     const int64_t li = blockIdx.x / REDUCE_SPLIT;
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats_slice(const int32_t *__res
     for (int k = 0; k < 4; ++k) s.b[k] = 0;
     FieldStatView fv = {};
     if (fields) fv.load(fields, cst, pth);
-    for (int64_t t = a + threadIdx.x; t < b; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst);
+    for (int64_t t = a + threadIdx.x; t < b; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst, clear_counts);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats_wg(int64_t n_list, const i
                                                         TilePartial *__restrict__ partial, const unsigned long long *__restrict__ n_adjusted,
                                                         fcpp_field_stats *__restrict__ stats, const int32_t *__restrict__ ids,
                                                         const int64_t *__restrict__ run_count, const DevTile *__restrict__ tiles,
-                                                        const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst)
+                                                        const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst, int clear_counts)
 {
     __shared__ StatAcc sh[4];
     const int64_t pth = path_list ? (int64_t)path_list[blockIdx.x] : (int64_t)blockIdx.x;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats_wg(int64_t n_list, const i
     for (int k = 0; k < 4; ++k) s.b[k] = 0;
     FieldStatView fv = {};
     if (fields) fv.load(fields, cst, pth);
-    for (int64_t t = tile_first[pth] + threadIdx.x; t < tile_first[pth + 1]; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst);
+    for (int64_t t = tile_first[pth] + threadIdx.x; t < tile_first[pth + 1]; t += 256) stat_entry(s, t, partial, ids, run_count, tiles, fv, prims, cst, clear_counts);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -776,11 +780,43 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
     return 0;
 }
 
+// Batch creation (fused pipeline): the statistics slots of a batch, one per entry.  The slot of a quiet run gets the run's closed-form
+// length / time / curvature statistics -- geometry and nominal speeds only, the same at every step --, every other slot zeros (wave
+// tiles and general tiles overwrite theirs at every step).
+__global__ void k_run_consts(int64_t n_entries, const int32_t *__restrict__ ids, const int64_t *__restrict__ run_count,
+                             const DevTile *__restrict__ tiles, const DevField *__restrict__ fields, const DevPrim *__restrict__ prims, DevConst cst,
+                             TilePartial *__restrict__ partial)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
+    TilePartial tp;
+    memset(&tp, 0, sizeof tp);
+    const int64_t rc = run_count[e];
+    if (rc > 0) {
+        const DevTile tl = tiles[ids[e]];
+        FieldStatView fv = {};
+        fv.load(fields, cst, tl.field);
+        const DevRun run = { ids[e], 0, rc };
+        tp = quiet_run_partial(run, tl, fv, prims, cst);
+        tp.n_viol = tp.n_outside = tp.n_in_obstacle = tp.n_adjusted = 0;
+    }
+    partial[e] = tp;
+}
+
+int launch_run_consts(hipStream_t st, int64_t n_entries, const int32_t *ids, const int64_t *run_count, const DevTile *tiles, const DevField *fields,
+                      const DevPrim *prims, const DevConst &cst, TilePartial *partial)
+{
+    if (n_entries <= 0) return 0;
+    hipLaunchKernelGGL(k_run_consts, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, st, n_entries, ids, run_count, tiles, fields, prims, cst, partial);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // group = lanes per path: 8, 64, or 256 (a workgroup per path)
 int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids, const int64_t *run_count,
                         const DevTile *tiles, const DevField *fields, const DevPrim *prims, const DevConst *cst, const int32_t *path_list,
-                        int group, void *scratch)
+                        int group, void *scratch, int clear_counts)
 {
     if (n_list <= 0) return 0;
     DevConst c0;
@@ -788,17 +824,17 @@ int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, co
     const DevConst &c = cst ? *cst : c0;
     if (group == 8)
         FCPP_LAUNCH(k_reduce_stats<8>, dim3((unsigned)((n_list + 31) / 32)), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted,
-                    stats, ids, run_count, tiles, fields, prims, c);
+                    stats, ids, run_count, tiles, fields, prims, c, clear_counts);
     else if (group == 256 && scratch) {
         FCPP_LAUNCH(k_reduce_stats_slice, dim3((unsigned)(n_list * REDUCE_SPLIT)), dim3(256), 0, st, path_list, tile_first, partial, ids, run_count,
-                    tiles, fields, prims, c, (StatAcc *)scratch);
+                    tiles, fields, prims, c, (StatAcc *)scratch, clear_counts);
         hipLaunchKernelGGL(k_reduce_stats_join, dim3((unsigned)n_list), dim3(64), 0, st, path_list, (const StatAcc *)scratch, n_adjusted, stats);
     } else if (group == 256)
         FCPP_LAUNCH(k_reduce_stats_wg, dim3((unsigned)n_list), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted, stats, ids,
-                    run_count, tiles, fields, prims, c);
+                    run_count, tiles, fields, prims, c, clear_counts);
     else
         FCPP_LAUNCH(k_reduce_stats<64>, dim3((unsigned)((n_list + 3) / 4)), dim3(256), 0, st, n_list, path_list, tile_first, partial, n_adjusted,
-                    stats, ids, run_count, tiles, fields, prims, c);
+                    stats, ids, run_count, tiles, fields, prims, c, clear_counts);
     FCPP_LAUNCH_CHECK();
     return 0;
 }

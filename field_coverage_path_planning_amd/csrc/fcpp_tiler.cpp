@@ -351,11 +351,11 @@ struct FieldTiler {
         const int kp = (int)(proto - b0);
         const DevField &F = hp.fields[(size_t)field], &G = hp.fields[(size_t)proto];
         const int64_t t0 = out.tile0[kp], t1 = out.tile0[kp + 1], w0 = out.w0[kp], w1 = out.w0[kp + 1];
-        const int64_t dt = (int64_t)out.tiles.size() - t0, dp = F.pt_off - G.pt_off;
+        const int64_t dp = F.pt_off - G.pt_off;
         for (int64_t i = t0; i < t1; ++i) { DevTile t = out.tiles[(size_t)i]; t.field = (int32_t)field; out.tiles.push_back(t); }
         for (int64_t i = w0; i < w1; ++i) {
             DevWaveTile w = out.wtiles[(size_t)i];
-            w.field = (int32_t)field; w.tile += (int32_t)dt; w.out_base += dp;
+            w.field = (int32_t)field; w.out_base += dp;       // (w.tile, the statistics entry, is set by derive_field)
             out.wave_inside += w.inside;
             out.wtiles.push_back(w);
         }
@@ -364,20 +364,22 @@ struct FieldTiler {
     // What the kernels' work lists need beyond the tile table, from the field's tiles [t0, t1) (block-relative slots): the tiles of
     // k_plan_fused, the entries k_reduce_stats walks (general tiles, wave tiles, the first tile of every quiet run + the run's length),
     // and the quiet runs cut into chunks on 512-point boundaries of the batch arrays.
-    struct Run { int64_t tile, count; };
+    struct Run { int64_t tile, count; int32_t entry; };
     std::vector<Run> rv;
     void derive_field(int64_t field, int k_local, int64_t t0, int64_t t1)
     {
         const DevField &F = hp.fields[(size_t)field];
-        const std::vector<DevTile> &T = out.tiles;
+        std::vector<DevTile> &T = out.tiles;
         const size_t stat_mark = out.stat_ids.size();
+        int64_t w_next = out.w0[k_local];        // the field's wave-tile records, in the order of their tiles
         rv.clear();
         for (int64_t i = t0; i < t1;) {
-            const DevTile &a = T[(size_t)i];
+            DevTile &a = T[(size_t)i];
+            const int32_t entry = (int32_t)out.stat_ids.size();     // the statistics entry (block-relative): the entries of a field lie side by side
             out.stat_ids.push_back((int32_t)i);                 // a general tile, a wave tile, or the first tile of a run
             out.stat_run.push_back(0);
-            if (!a.quiet) { out.general_ids.push_back((int32_t)i); ++i; continue; }
-            if (a.quiet == 5) { out.wave_points += a.count; ++i; continue; }
+            if (!a.quiet) { a.stat_tile = entry; out.general_ids.push_back((int32_t)i); ++i; continue; }
+            if (a.quiet == 5) { out.wtiles[(size_t)w_next++].tile = entry; out.wave_points += a.count; ++i; continue; }
             // the run: quiet tiles that continue each other on the same straight
             int64_t cnt = a.count, j = i + 1;
             for (; j < t1; ++j) {
@@ -387,7 +389,7 @@ struct FieldTiler {
                 if (!cont) break;
                 cnt += tj.count;
             }
-            rv.push_back({ i, cnt });
+            rv.push_back({ i, cnt, entry });
             out.stat_run.back() = cnt;
             out.quiet_points += cnt;
             i = j;
@@ -423,7 +425,7 @@ struct FieldTiler {
                 while (done >= rc_begin + rv[rc].count) { rc_begin += rv[rc].count; ++rc; }
                 const DevTile &tr = T[(size_t)rv[rc].tile];
                 DevTile ch = tr;
-                ch.start = a.start + done; ch.count = (int32_t)c; ch.stat_tile = (int32_t)rv[rc].tile;
+                ch.start = a.start + done; ch.count = (int32_t)c; ch.stat_tile = rv[rc].entry;
                 const bool one_run = done + c <= rc_begin + rv[rc].count;
                 if (one_run && tr.quiet != 4) ch.off0 = (int32_t)(tr.off0 + (done - rc_begin));
                 else {      // a span of layer 1 (or a chunk across runs): (pass, offset in the pass) of the chunk's first point
@@ -503,7 +505,7 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
     take(lay.seg, (size_t)n * 8 * sizeof(double));
     take(lay.seg_mask, (size_t)n * 2 * sizeof(int32_t));
     lay.upload_bytes = o;
-    take(lay.partial, (size_t)lay.n_tiles * sizeof(TilePartial));
+    take(lay.partial, (size_t)lay.n_stat * sizeof(TilePartial));      // one slot per statistics entry
     take(lay.red_scratch, (size_t)lay.n_red[3] * 64 * 104);
     take(lay.field_junc, (size_t)n * 2 * sizeof(double));
     lay.total_bytes = o;
@@ -522,19 +524,20 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         const int64_t nf = pb.f1 - pb.f0;
         memcpy(at<DevField>(dst, lay.fields) + pb.f0, hp.fields.data() + pb.f0, (size_t)nf * sizeof(DevField));
         if (!pb.prims.empty()) memcpy(at<DevPrim>(dst, lay.prims) + pb.prim_base, pb.prims.data(), pb.prims.size() * sizeof(DevPrim));
-        if (!bt.tiles.empty()) memcpy(at<DevTile>(dst, lay.tiles) + bt.tile_base, bt.tiles.data(), bt.tiles.size() * sizeof(DevTile));
-        const int32_t tb = (int32_t)bt.tile_base;
+        const int32_t tb = (int32_t)bt.tile_base, sb = (int32_t)bt.stat_base;
+        DevTile *td = at<DevTile>(dst, lay.tiles) + bt.tile_base;
+        for (size_t k = 0; k < bt.tiles.size(); ++k) { td[k] = bt.tiles[k]; if (td[k].quiet == 0) td[k].stat_tile += sb; }      // general tiles: their statistics entry
         DevWaveTile *w = at<DevWaveTile>(dst, lay.wtiles) + bt.wave_base;
-        for (size_t k = 0; k < bt.wtiles.size(); ++k) { w[k] = bt.wtiles[k]; w[k].tile += tb; }
+        for (size_t k = 0; k < bt.wtiles.size(); ++k) { w[k] = bt.wtiles[k]; w[k].tile += sb; }
         int32_t *g = at<int32_t>(dst, lay.general_ids) + bt.general_base;
         for (size_t k = 0; k < bt.general_ids.size(); ++k) g[k] = bt.general_ids[k] + tb;
         int32_t *si = at<int32_t>(dst, lay.stat_ids) + bt.stat_base;
         for (size_t k = 0; k < bt.stat_ids.size(); ++k) si[k] = bt.stat_ids[k] + tb;
         if (!bt.stat_run.empty()) memcpy(at<int64_t>(dst, lay.stat_run) + bt.stat_base, bt.stat_run.data(), bt.stat_run.size() * sizeof(int64_t));
         DevTile *c = at<DevTile>(dst, lay.chunks) + bt.chunk_base;
-        for (size_t k = 0; k < bt.chunks.size(); ++k) { c[k] = bt.chunks[k]; c[k].stat_tile += tb; }
+        for (size_t k = 0; k < bt.chunks.size(); ++k) { c[k] = bt.chunks[k]; c[k].stat_tile += sb; }
         DevTile *cs = at<DevTile>(dst, lay.span_chunks) + bt.span_base;
-        for (size_t k = 0; k < bt.span_chunks.size(); ++k) { cs[k] = bt.span_chunks[k]; cs[k].stat_tile += tb; }
+        for (size_t k = 0; k < bt.span_chunks.size(); ++k) { cs[k] = bt.span_chunks[k]; cs[k].stat_tile += sb; }
         int64_t *sf = at<int64_t>(dst, lay.stat_first);
         int64_t run = bt.stat_base;
         for (int64_t k = 0; k < nf; ++k) { sf[pb.f0 + k] = run; run += bt.stat_cnt[k]; }

@@ -145,13 +145,16 @@ int main(int argc, char **argv)
         for (int64_t k = 0; k < lay.n_general; ++k) {
             if (G[k] < 0 || G[k] >= lay.n_tiles || T[G[k]].quiet != 0) FAIL("general id %lld", (long long)k);
             if (!mark(T[G[k]].field, T[G[k]].start, T[G[k]].count, "general tile") || T[G[k]].count > TILE_POINTS) FAIL("general tile %lld", (long long)k);
+            if (T[G[k]].stat_tile < 0 || T[G[k]].stat_tile >= lay.n_stat || SI[T[G[k]].stat_tile] != G[k]) FAIL("general tile %lld: statistics entry", (long long)k);
         }
         for (int64_t k = 0; k < lay.n_wave; ++k) {
             const DevWaveTile &w = Wt[k];
-            if (w.tile < 0 || w.tile >= lay.n_tiles || T[w.tile].quiet != 5 || T[w.tile].field != w.field || T[w.tile].count != w.count) FAIL("wave tile %lld: slot", (long long)k);
+            if (w.tile < 0 || w.tile >= lay.n_stat || w.field < 0 || w.field >= n || w.tile < SF[w.field] || w.tile >= SF[w.field + 1]) FAIL("wave tile %lld: statistics entry", (long long)k);
+            const int32_t wtile = SI[w.tile];
+            if (wtile < 0 || wtile >= lay.n_tiles || T[wtile].quiet != 5 || T[wtile].field != w.field || T[wtile].count != w.count) FAIL("wave tile %lld: slot", (long long)k);
             if (w.hb + w.count + w.hf > 64 || w.field < 0 || w.field >= n) FAIL("wave tile %lld: lanes", (long long)k);
             const int64_t first = w.out_base - F[w.field].pt_off;
-            if (first < 0 || first + w.hb != T[w.tile].start || first + w.hb + w.count + w.hf > F[w.field].n_total) FAIL("wave tile %lld: range", (long long)k);
+            if (first < 0 || first + w.hb != T[wtile].start || first + w.hb + w.count + w.hf > F[w.field].n_total) FAIL("wave tile %lld: range", (long long)k);
             if (!mark(w.field, first + w.hb, w.count, "wave tile")) FAIL("wave tile %lld", (long long)k);
             const int64_t last = first + w.hb + w.count + w.hf - 1;
             if (last >= F[w.field].gen_main) {
@@ -173,7 +176,9 @@ int main(int argc, char **argv)
                 if (!mark(c.field, c.start, c.count, "chunk")) FAIL("chunk %lld/%d", (long long)k, pass);
                 const int64_t g = F[c.field].pt_off + c.start;
                 if (g / TILE_POINTS != (g + c.count - 1) / TILE_POINTS) FAIL("chunk %lld/%d crosses a 512-point boundary", (long long)k, pass);
-                if (c.stat_tile < 0 || c.stat_tile >= lay.n_tiles || T[c.stat_tile].field != c.field || T[c.stat_tile].quiet == 0 || T[c.stat_tile].quiet == 5) FAIL("chunk %lld/%d: statistics slot", (long long)k, pass);
+                if (c.stat_tile < 0 || c.stat_tile >= lay.n_stat || SR[c.stat_tile] <= 0 || T[SI[c.stat_tile]].field != c.field || T[SI[c.stat_tile]].quiet == 0 ||
+                    T[SI[c.stat_tile]].quiet == 5 || c.start < T[SI[c.stat_tile]].start || c.start >= T[SI[c.stat_tile]].start + SR[c.stat_tile])       // (a chunk may run on into the next run of its group)
+                    FAIL("chunk %lld/%d: statistics entry", (long long)k, pass);
                 if ((pass == 1) != (c.quiet == 4)) FAIL("chunk %lld/%d: kind", (long long)k, pass);
                 if (c.quiet == 2 && (c.idx0 < F[c.field].prim_first || c.idx0 >= F[c.field].prim_first + F[c.field].prim_count)) FAIL("chunk %lld: primitive", (long long)k);
             }
@@ -222,6 +227,7 @@ int main(int argc, char **argv)
                     // (idx0 is a pass index or a batch-wide primitive index, depending on where the tile starts: quiet runs of layer 2 are
                     // covered below through their chunks' primitive check, the wave tiles through their records)
                     sem = fnv(sem, &t.count, sizeof t.count); sem = fnv(sem, &t.start, sizeof t.start); sem = fnv(sem, &t.quiet, sizeof t.quiet);
+                    if (t.quiet == 0) t.stat_tile -= (int32_t)SF[i];
                     sem = fnv(sem, &t.off0, sizeof t.off0); sem = fnv(sem, &t.stat_tile, sizeof t.stat_tile);
                 }
                 for (int64_t e = SF[i]; e < SF[i + 1]; ++e) { const int64_t rel = SI[e] - tf; sem = fnv(sem, &rel, 8); sem = fnv(sem, &SR[e], 8); }
@@ -229,7 +235,7 @@ int main(int argc, char **argv)
             for (int64_t k = 0; k < lay.n_wave; ++k) {
                 DevWaveTile w = Wt[k];
                 const DevField &f = F[w.field];
-                w.out_base -= f.pt_off; w.tile -= (int32_t)tile_first_of[(size_t)w.field];
+                w.out_base -= f.pt_off; w.tile -= (int32_t)SF[w.field];
                 if (w.out_base + w.hb + w.count + w.hf - 1 >= f.gen_main) w.p0 -= f.prim_first; else w.p0 = 0;
                 if (w.out_base >= f.gen_main) w.idx0 -= f.prim_first;
                 w.field = 0;
