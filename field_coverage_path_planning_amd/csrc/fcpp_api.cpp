@@ -480,7 +480,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     std::unique_ptr<fcpp_batch> b(new (std::nothrow) fcpp_batch());
     if (!b) return fail(FCPP_ENOMEM, "out of host memory");
     b->ctx = c; b->veh = *veh; b->opt = *opt; b->n_fields = n_fields;
-    b->two_streams = getenv("FCPP_ONE_STREAM") == nullptr;
+    b->two_streams = !(tune_enabled() && getenv("FCPP_ONE_STREAM") != nullptr);
     b->two_stream_max = std::max(0, std::min(tune_int("FCPP_TWO_STREAM_MAX", 512), 1 << 20));
     fcpp_setup_times &tm = b->setup;
     tm.threads = WorkerPool::width();

@@ -37,10 +37,17 @@ struct DevConst {
     const double2 *tmpl_u_dk;         // per U-turn sample k: (|t_k - t_(k-1)|, curvature at t_k), the shape's own segment lengths / curvatures
 };
 
-// launch-time tuning knobs (extra LDS per workgroup = fewer resident waves, ...): an environment variable read at every launch, so that
-// tools/ab_knob.py can flip it between runs of one process on identical memory
+// Tuning knobs (extra LDS per workgroup = fewer resident waves, wave tiles per workgroup, ...) for tools/ab_knob.py, which flips them
+// between runs of one process on identical memory.  They are LIVE only in a process started with FCPP_TUNE=1 (checked once, when the
+// library is first used); otherwise every knob is its default and no launch path reads the environment.  Callers clamp the values.
+inline bool tune_enabled()
+{
+    static const bool on = [] { const char *v = getenv("FCPP_TUNE"); return v && v[0] == '1'; }();
+    return on;
+}
 inline int tune_int(const char *name, int dflt)
 {
+    if (!tune_enabled()) return dflt;
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }

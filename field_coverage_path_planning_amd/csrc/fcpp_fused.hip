@@ -858,7 +858,7 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
     // workgroups, the same either way.  FCPP_SPAN_LDS / FCPP_QUIET_PAD: bytes, for that tool.
     const int static_lds = (has_obs ? wpb * 2 * OBS_LDS_VERTS * 8 : 32) + (kinds == 16 && staged ? wpb * 3 * TMPL_LDS * 8 : 32);
     const int span_lds = (n_chunks < 65536 ? 27 * 1024 : 34 * 1024) * wpb / 4;
-    const int pad = kinds == 16 ? std::max(0, tune_int("FCPP_SPAN_LDS", span_lds) - static_lds) : tune_int("FCPP_QUIET_PAD", 0);
+    const int pad = std::min(64 * 1024, kinds == 16 ? std::max(0, tune_int("FCPP_SPAN_LDS", span_lds) - static_lds) : std::max(0, tune_int("FCPP_QUIET_PAD", 0)));
 #define FCPP_QUIET(K, SD, TL, OB) do { if (wpb == 8) FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB, 8>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks); \
                                        else FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB, 4>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks); } while (0)
     // Instances: spans fetch their descriptors by scalar loads (SCALAR_DESC: that nearly halved their time in round 1), stage the

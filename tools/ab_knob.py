@@ -5,6 +5,7 @@ variable the launchers read at every launch, csrc/fcpp_devfn.h tune_int) is flip
 (create:VAR = a knob the tiler reads when the batch is created: one batch per value, same arrays)
 Prints min / median of the stage's per-launch time (HIP events of the dispatch) and of the whole step per value."""
 import os
+os.environ.setdefault('FCPP_TUNE', '1')      # the knobs are live only in a process started with FCPP_TUNE=1 (fcpp_device.h)
 import sys
 import time
 
