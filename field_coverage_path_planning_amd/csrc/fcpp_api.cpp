@@ -529,6 +529,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     // into, i.e. the order of its sums at the last bit: diagnostic builds only)
     tc.wave_factor = std::max(0, std::min(tune_int("FCPP_WAVE_FACTOR", 24), 64));
     tc.reduce_wg_max = std::max(256, std::min(tune_int("FCPP_REDUCE_WG_MAX", 1024), 1 << 20));
+    tc.wave_points = tune_int("FCPP_WAVE_POINTS", 128) == 64 ? 64 : 128;
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);
@@ -682,7 +683,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(sd, b->ctx->ev_fork, 0));
         }
-        STAGE(2, launch_plan_sparse(sd, lay.n_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
+        STAGE(2, launch_plan_sparse(sd, lay.n_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial, lay.wave_tile_points / 64));
         STAGE(3, launch_plan_fused(sd, variant, lay.n_general, t.general_ids, t.tiles, t.fields, t.prims, b->cst, obs, x,
                                    y, kappa, v, fs, t.partial));
         if (two) HIPCHK(hipEventRecord(b->ctx->ev_join, sd));

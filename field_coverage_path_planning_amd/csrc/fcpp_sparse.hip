@@ -16,14 +16,15 @@
 // The outermost halo lane only lends its coordinates to its neighbour's stencil; its own (possibly unclamped) speed cannot bind
 // anything by the choice above.  Same arithmetic as fcpp_fused.hip (fcpp_pointfn.h) => results do not depend on which of the two
 // kernels plans a stretch.  Stretches whose halos would not fit (dense sampling) stay with k_plan_fused.
-#include "fcpp_sparse_fn.h"
+#include "fcpp_sparse2_fn.h"
 
 namespace fcpp {
 
 // SP_WAVES wave tiles per workgroup (independent of each other: no barrier).  Four for launches of a few rounds of workgroups (the
 // headline's 32 768 tiles: 41 us, 43 with two, 45-48 with one), two for long launches (cfg5's 622 016 tiles: 661-682 us, 674-688 with four,
 // 737-752 with eight); measured on the same box, tools/ab_knob.py per build.
-template <int SP_WAVES>
+// PTS: points per lane -- 1: wave tiles of up to 64 points (sparse_tile), 2: of up to 128 (sparse_tile2, fcpp_sparse2_fn.h)
+template <int SP_WAVES, int PTS>
 __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile *__restrict__ wtiles, int64_t n_wtiles,
                                                                const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
                                                                DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
@@ -37,12 +38,13 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
     const DevWaveTile wt = wtiles[slot];
     SparseAcc acc;
     acc.clear();
-    sparse_tile(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
+    if (PTS == 2) sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
+    else sparse_tile(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
 
     // the tile's partial statistics: the three sums of a layer (and the three maxima) go through the wave together (wave4_to_hi),
     // groups in which every lane holds zero (the other layer, tiles without curvature) are skipped by a ballot
     double g[3] = { 0.0, 0.0, 0.0 };
-    // (which layers the output lanes lie in is in the tile record: scalar compares)
+    // (which layers the output points lie in is in the tile record: scalar compares)
     const int out0 = wt.hb, out1 = wt.hb + wt.count;
     if (out0 < wt.rel_seam) g[0] = wave4_to_hi<0>(acc.s_len[0], acc.s_tpre[0], acc.s_t[0], 0.0);
     if (out1 > wt.rel_seam + 1) g[1] = wave4_to_hi<0>(acc.s_len[1], acc.s_tpre[1], acc.s_t[1], 0.0);     // (the seam point itself belongs to neither)
@@ -60,15 +62,17 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
 
 int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtiles, const DevField *fields, const DevPrim *prims,
                        const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
-                       TilePartial *partial)
+                       TilePartial *partial, int points_per_lane)
 {
     if (n_wtiles <= 0) return 0;
-    if (n_wtiles >= 131072)
-        FCPP_LAUNCH(k_plan_sparse<2>, dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v,
-                    fs, partial);
-    else
-        FCPP_LAUNCH(k_plan_sparse<4>, dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v,
-                    fs, partial);
+    const bool two = points_per_lane == 2;
+    if (n_wtiles >= (two ? 65536 : 131072)) {
+        if (two) FCPP_LAUNCH((k_plan_sparse<2, 2>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        else FCPP_LAUNCH((k_plan_sparse<2, 1>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+    } else {
+        if (two) FCPP_LAUNCH((k_plan_sparse<4, 2>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        else FCPP_LAUNCH((k_plan_sparse<4, 1>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -1,0 +1,217 @@
+// fcpp_sparse2_fn.h -- the wave tile of fcpp_sparse.hip with TWO consecutive points per lane: a wavefront owns up to 128 consecutive
+// points of one field, lane l the points 2l ("a") and 2l + 1 ("b") of the tile.  Same arithmetic per point as sparse_tile
+// (fcpp_sparse_fn.h), so a point's results do not depend on which of the two plans it; what changes is the cost per point: the halo
+// points (about ten per tile, whatever its size), the lane moves (a's successor and b's predecessor are the lane's own registers) and
+// the wave-wide reductions of the statistics are paid once per 128 points instead of once per 64.
+#pragma once
+#include "fcpp_sparse_fn.h"
+
+namespace fcpp {
+
+// one of the lane's two points
+struct SparsePt {
+    double px, py, vn, msn, d, kappa, v0, ms0, u0, u, w, vfin;
+    uint32_t fw;
+    bool act, out, is_first, is_last, at_seam, is_second, cl, lowered, has_prev, interior;
+};
+
+// the point `rel` (index in the tile) of a lane: coordinates, flag word, nominal speed
+__device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst, int rel,
+                                              int nl, SparsePt &q)
+{
+    q.act = rel < nl;
+    q.out = rel >= wt.hb && rel < wt.hb + wt.count;
+    const bool in_main = rel < wt.rel_main;
+    q.is_first = rel == wt.rel_zero; q.is_last = rel == wt.rel_last; q.at_seam = rel == wt.rel_seam; q.is_second = rel == wt.rel_zero + 1;
+    q.px = q.py = 0.0;
+    q.fw = 0;
+    const bool in_l2 = q.act && !in_main;
+    int r = 0;
+    DevPrim p;
+    double2 tc = make_double2(0.0, 0.0);
+    if (in_l2) {
+        int pi = wt.p0;
+        r = rel + wt.r0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int th = wt.thr[k];
+            if (rel >= th) { ++pi; r = rel - th; }
+        }
+        tc = cst.tmpl_c[min(max(r, 0), cst.tmpl_nc - 1)];
+        p = prims[pi];
+    }
+    if (__ballot(q.act && in_main) != 0ull) {
+        if (q.act && in_main) {
+            const unsigned per = (unsigned)(f.n_line + f.n_turn);
+            const unsigned off = (unsigned)wt.off0 + (unsigned)rel, qq = off / per;
+            eval_main(f, cst, wt.idx0 + (int)qq, (int)(off - qq * per), q.px, q.py, q.fw);
+        }
+    }
+    if (in_l2) {
+        int kind = p.kind;
+        asm volatile("" : "+v"(tc.x), "+v"(tc.y), "+v"(kind));
+        eval_prim_lanes(p, cst, r, q.px, q.py, tc);
+        q.fw = p.fs;
+    }
+    q.vn = in_l2 ? p.v_nom : (((q.fw & FCPP_KIND_MASK) == FCPP_KIND_SWATH) ? cst.v_work : cst.v_turn);
+    q.msn = div36(q.vn);
+}
+
+// obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles)
+__device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
+                                             const DevObstacles &obs, double *obs_lds, double *__restrict__ xo, double *__restrict__ yo,
+                                             double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso, SparseAcc &acc)
+{
+    const int lane = threadIdx.x & 63;
+    const int nl = wt.hb + wt.count + wt.hf;                 // active points
+    const int ra = 2 * lane, rb = 2 * lane + 1;
+    SparsePt A, B;
+    sparse2_point(wt, f, prims, cst, ra, nl, A);
+    sparse2_point(wt, f, prims, cst, rb, nl, B);
+
+    // ---- chords, curvature (MLP:513-536), clamp (MLP:490-504) ----------------------------------------------------------------------
+    // a's predecessor is the previous lane's b, its successor the lane's own b; b's predecessor is a, its successor the next lane's a
+    const double xm = lane_prev(B.px), ym = lane_prev(B.py), xn = lane_next(A.px), yn = lane_next(A.py);
+    A.has_prev = A.act && lane > 0;
+    B.has_prev = B.act;
+    const double dxa = A.px - xm, dya = A.py - ym, dxb = B.px - A.px, dyb = B.py - A.py;
+    A.d = A.has_prev ? seg_len(dxa, dya) : 0.0;
+    B.d = B.has_prev ? seg_len(dxb, dyb) : 0.0;
+    const double dn_b = lane_next(A.d);                      // |next lane's a - b|
+    A.interior = A.has_prev && ra < nl - 1 && !A.is_last;
+    B.interior = B.has_prev && rb < nl - 1 && !B.is_last;
+    A.kappa = B.kappa = 0.0;
+    if (A.interior) A.kappa = curv_chords_atan(dxa, dya, A.d, dxb, dyb, B.d);
+    if (B.interior) B.kappa = curv_chords_atan(dxb, dyb, B.d, xn - B.px, yn - B.py, dn_b);
+    A.cl = B.cl = false;
+    A.v0 = A.vn; B.v0 = B.vn;
+    if (A.kappa > 1e-6) A.v0 = clamped_speed(A.vn, A.kappa, cst, A.cl);
+    if (B.kappa > 1e-6) B.v0 = clamped_speed(B.vn, B.kappa, cst, B.cl);
+    A.ms0 = A.cl ? div36(A.v0) : A.msn;
+    B.ms0 = B.cl ? div36(B.v0) : B.msn;
+    A.u0 = A.act ? A.ms0 * A.ms0 : FCPP_INF;
+    B.u0 = B.act ? B.ms0 * B.ms0 : FCPP_INF;
+
+    // ---- sweeps (MLP:538-589) as a relaxation over the tile's 128 points, two per lane ----------------------------------------------
+    constexpr int SWEEP_ROUNDS = 5;
+    const double two_a = 2 * cst.a_lon;
+    A.w = (!A.has_prev || A.d < 1e-6) ? FCPP_INF : two_a * A.d;        // coupling (previous lane's b, a)
+    B.w = (!B.has_prev || B.d < 1e-6) ? FCPP_INF : two_a * B.d;        // coupling (a, b)
+    const double ubm0 = lane_prev(B.u0);
+    const bool binds = (A.has_prev && A.w < FCPP_INF && (ubm0 + A.w < A.u0 || A.u0 + A.w < ubm0)) ||
+                       (B.has_prev && B.w < FCPP_INF && (A.u0 + B.w < B.u0 || B.u0 + B.w < A.u0));
+    A.u = A.u0; B.u = B.u0;
+    if (__ballot(binds) != 0ull) {
+        double wn = lane_next(A.w);                  // coupling (b, next lane's a)
+        if (rb >= nl - 1) wn = FCPP_INF;
+        bool settled = false;
+#pragma unroll 1
+        for (int round = 0; round < SWEEP_ROUNDS; ++round) {
+            const double ubm = lane_prev(B.u), uan = lane_next(A.u);
+            const double ma = min_raw(A.u, min_raw(ubm + A.w, B.u + B.w));
+            const double mb = min_raw(B.u, min_raw(A.u + B.w, uan + wn));
+            const bool moved = ma < A.u || mb < B.u;
+            A.u = ma; B.u = mb;
+            if (__ballot(moved) == 0ull) { settled = true; break; }
+        }
+        if (!settled) {
+            // the two min-plus scans over the lanes' composite maps (a then b forwards, b then a backwards), from where the relaxation got to
+            const Agg fa = { A.u, A.w }, fb = { B.u, B.w }, ba = { A.u, B.w }, bb = { B.u, wn };
+            Agg fi = combine_after(fa, fb), bi = combine_after(bb, ba);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                Agg pf = { __shfl_up(fi.c, o), __shfl_up(fi.w, o) };
+                Agg pb = { __shfl_down(bi.c, o), __shfl_down(bi.w, o) };
+                if (lane >= o) fi = combine_after(pf, fi);
+                if (lane + o < 64) bi = combine_after(pb, bi);
+            }
+            double fprev = __shfl_up(fi.c, 1), bnext = __shfl_down(bi.c, 1);       // the results at the neighbours' facing points
+            if (lane == 0) fprev = FCPP_INF;
+            if (lane == 63) bnext = FCPP_INF;
+            const double fwd_a = fmin(A.u, fprev + A.w), fwd_b = fi.c;
+            const double bwd_b = fmin(B.u, bnext + wn), bwd_a = bi.c;
+            A.u = fmin(fwd_a, bwd_a); B.u = fmin(fwd_b, bwd_b);
+        }
+    }
+    A.vfin = A.cl ? A.v0 : A.vn;
+    B.vfin = B.cl ? B.v0 : B.vn;
+    A.lowered = A.u < A.u0; B.lowered = B.u < B.u0;
+    if (__ballot(A.lowered || B.lowered) != 0ull) {
+        A.vfin = A.lowered ? sqrt(A.u) * 3.6 : A.vfin;
+        B.vfin = B.lowered ? sqrt(B.u) * 3.6 : B.vfin;
+    }
+
+    // ---- validation flags --------------------------------------------------------------------------------------------------------------
+    bool a_out = false, b_out = false, a_obs = false, b_obs = false, a_viol = false, b_viol = false;
+    if (!wt.inside) {
+        const double ntol = -cst.geofence_tol;
+        if (A.out) {
+            bool o = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o = o | (f.ex[e] * A.px + f.ey[e] * A.py + f.eo[e] < ntol);
+            if (o) { A.fw |= FCPP_FLAG_OUTSIDE; a_out = true; }
+        }
+        if (B.out) {
+            bool o = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o = o | (f.ex[e] * B.px + f.ey[e] * B.py + f.eo[e] < ntol);
+            if (o) { B.fw |= FCPP_FLAG_OUTSIDE; b_out = true; }
+        }
+    }
+    if (f.obs_count > 0) {
+        double mnx = FCPP_INF, mxx = -FCPP_INF, mny = FCPP_INF, mxy = -FCPP_INF;
+        if (A.out) { mnx = A.px; mxx = A.px; mny = A.py; mxy = A.py; }
+        if (B.out) { mnx = fmin(mnx, B.px); mxx = fmax(mxx, B.px); mny = fmin(mny, B.py); mxy = fmax(mxy, B.py); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = fmin(mnx, __shfl_xor(mnx, o)); mny = fmin(mny, __shfl_xor(mny, o));
+            mxx = fmax(mxx, __shfl_xor(mxx, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+        }
+        // (obstacle_mask tests the points [0, nvalid) of a lane: a lane whose a is a halo point and whose b is an output tests both)
+        const double ox[2] = { A.px, B.px }, oy[2] = { A.py, B.py };
+        const unsigned m = obstacle_mask<2>(obs, f.obs_first, f.obs_first + f.obs_count, obs_lds, mnx, mny, mxx, mxy, ox, oy, B.out ? 2 : (A.out ? 1 : 0));
+        if (A.out && (m & 1u)) { A.fw |= FCPP_FLAG_OBSTACLE; a_obs = true; }
+        if (B.out && (m & 2u)) { B.fw |= FCPP_FLAG_OBSTACLE; b_obs = true; }
+    }
+
+    // ---- metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) on the output points ------------------------------------------------
+    const double vprev_a = lane_prev(B.vfin), kprev_a = lane_prev(B.kappa), vnprev_a = lane_prev(B.vn);
+    auto metrics = [&](const SparsePt &q, int rel, double vprev, double vnprev, double kprev, bool &viol, uint32_t &fw) {
+        const bool seg = q.out && !q.is_first && !q.at_seam;
+        const bool l0 = rel < wt.rel_seam;
+        double tpre = 0.0, t = 0.0;
+        if (seg) {
+            const double ms_pre = (vnprev == q.vn) ? q.msn : div36((vnprev + q.vn) / 2);
+            tpre = q.d / fmax(ms_pre, 0.1);
+        }
+        const bool changed = seg && !(vprev == vnprev && q.vfin == q.vn);
+        t = tpre;
+        if (__ballot(changed) != 0ull) t = changed ? q.d / fmax(div36((vprev + q.vfin) / 2), 0.1) : tpre;
+        const double len = seg ? q.d : 0.0;
+        acc.s_len[0] += l0 ? len : 0.0; acc.s_tpre[0] += l0 ? tpre : 0.0; acc.s_t[0] += l0 ? t : 0.0;
+        acc.s_len[1] += l0 ? 0.0 : len; acc.s_tpre[1] += l0 ? 0.0 : tpre; acc.s_t[1] += l0 ? 0.0 : t;
+        if (q.out && !q.is_first && !q.is_last) {
+            if (q.kappa > 0.0) {
+                const double ms = q.lowered ? div36(q.vfin) : q.ms0, alat = ms * ms * q.kappa;
+                acc.mk = max_raw(acc.mk, q.kappa); acc.ma = max_raw(acc.ma, alat);
+                if (alat > cst.a_lat) { viol = true; fw |= FCPP_FLAG_ALAT; }
+            }
+            if (q.kappa != kprev && !q.is_second) acc.mj = max_raw(acc.mj, fabs(q.kappa - kprev));
+        }
+    };
+    // (a first, then b: the per-lane accumulators add a's terms before b's; the order of the additions is fixed by the tile alone)
+    metrics(A, ra, vprev_a, vnprev_a, kprev_a, a_viol, A.fw);
+    metrics(B, rb, A.vfin, A.vn, A.kappa, b_viol, B.fw);
+
+    // ---- stores: the lane's two points are neighbours in memory ----------------------------------------------------------------------------
+    const int64_t g = wt.out_base + ra;
+    if (A.out) { xo[g] = A.px; yo[g] = A.py; ko[g] = A.kappa; vo[g] = A.vfin; fso[g] = A.fw; }
+    if (B.out) { xo[g + 1] = B.px; yo[g + 1] = B.py; ko[g + 1] = B.kappa; vo[g + 1] = B.vfin; fso[g + 1] = B.fw; }
+
+    acc.c_viol += __popcll(__ballot(a_viol)) + __popcll(__ballot(b_viol));
+    acc.c_out += __popcll(__ballot(a_out)) + __popcll(__ballot(b_out));
+    acc.c_obs += __popcll(__ballot(a_obs)) + __popcll(__ballot(b_obs));
+    acc.c_adj += __popcll(__ballot(A.out && A.cl)) + __popcll(__ballot(B.out && B.cl));
+}
+
+}  // namespace fcpp

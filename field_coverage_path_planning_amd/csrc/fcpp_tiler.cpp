@@ -32,7 +32,6 @@ struct BlockTiles {
 namespace {
 
 constexpr int WAVE_HALO_MAX = 40;
-constexpr int WAVE_LANES = 64;                  // fcpp_sparse.hip: one wavefront per wave tile
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -140,6 +139,7 @@ struct FieldTiler {
     bool wave_tiles(int64_t a, int64_t b)
     {
         const DevField &F = *f;
+        const int WAVE_LANES = tc.wave_points;           // points of a wave tile (fcpp_sparse.hip: one wavefront per wave tile)
         const int64_t n = F.n_total;
         const double cap = tc.u_cap * (1.0 + 1e-9) + 1e-12;
         // d[i - lo] = |p_i - p_(i-1)| for the stretch and WAVE_HALO_MAX + 2 points either side
@@ -201,12 +201,18 @@ struct FieldTiler {
         for (int64_t s = a; s < b;) {
             const int Hb = back_halo(s);
             if (Hb < 0) return refuse(0);
-            // the largest count whose forward halo still fits
+            // the largest count whose forward halo still fits -- and whose points (halos included) lie in at most nine primitives: the
+            // tile record names the first one and has eight thresholds for the others
             int64_t c = std::min<int64_t>(b - s, WAVE_LANES - Hb);
             int Hf = -1;
+            const int64_t first0 = s - Hb;
+            const int pa0 = first0 + Hb + c - 1 >= F.gen_main ? prim_of(std::max<int64_t>(first0, F.gen_main)) : 0;
             for (; c >= 1; --c) {
                 Hf = fwd_halo(s + c - 1);
-                if (Hf >= 0 && Hb + c + Hf <= WAVE_LANES) break;
+                if (!(Hf >= 0 && Hb + c + Hf <= WAVE_LANES)) continue;
+                const int64_t last0 = s + c - 1 + Hf;
+                if (last0 >= F.gen_main && prim_of(last0) - pa0 > 8) continue;
+                break;
             }
             if (c < std::min<int64_t>(8, b - s)) return refuse(Hf < 0 ? 1 : 2);
             const int64_t first = s - Hb, last = s + c - 1 + Hf;
@@ -470,7 +476,7 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
         }
     });
     lay = ImageLayout();
-    lay.n_fields = n; lay.n_prims = hp.total_prims;
+    lay.n_fields = n; lay.n_prims = hp.total_prims; lay.wave_tile_points = tc.wave_points;
     for (int64_t b = 0; b < nb; ++b) {
         BlockTiles &bt = B[(size_t)b];
         bt.tile_base = lay.n_tiles; bt.wave_base = lay.n_wave; bt.general_base = lay.n_general; bt.stat_base = lay.n_stat;

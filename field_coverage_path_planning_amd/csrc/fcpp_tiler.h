@@ -27,6 +27,7 @@ struct TileConsts {
     double two_a = 0.0, u_cap = 0.0, c_line = 0.0;     // 2 a_lon, (v_max / 3.6)^2, (v_work / 3.6)^2
     double fence_margin = 1e-3;               // a point this far inside every edge cannot be flagged by the device's geofence test
     int wave_factor = 24;                     // wave tiles where wave_factor * 2a * line step >= u_cap
+    int wave_points = 128;                    // points per wave tile: 64 (one per lane) or 128 (two per lane, fcpp_sparse2_fn.h)
     int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
 };
 
@@ -43,6 +44,7 @@ struct ImageLayout {
     int64_t quiet_points = 0, span_points = 0, chunk_points = 0, wave_points = 0;
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 }; // diagnostics: stretches refused for wave tiles, by reason
     int64_t wave_inside = 0;                  // wave tiles whose outputs the host found inside the geofence
+    int wave_tile_points = 64;                // points per wave tile (TileConsts.wave_points)
 };
 
 struct BlockTiles;      // a block's records before the merge (fcpp_tiler.cpp)

@@ -105,6 +105,7 @@ int main(int argc, char **argv)
         TileConsts tc;
         tc.tu = tu.data(); tc.tc = tcn.data(); tc.nu = tt.nu; tc.nc = tt.nc; tc.templates_ok = true;
         tc.turn_quiet = pick(4) != 0;
+        tc.wave_points = pick(2) ? 128 : 64;
         const double vm = 15.0 / 3.6;
         tc.two_a = 2 * veh.max_longitudinal_accel; tc.u_cap = vm * vm; tc.c_line = (9.0 / 3.6) * (9.0 / 3.6);
         tc.fence_margin = 1e-3 + (opt.geofence_tol < 0 ? -opt.geofence_tol : 0.0);
@@ -152,7 +153,7 @@ int main(int argc, char **argv)
             if (w.tile < 0 || w.tile >= lay.n_stat || w.field < 0 || w.field >= n || w.tile < SF[w.field] || w.tile >= SF[w.field + 1]) FAIL("wave tile %lld: statistics entry", (long long)k);
             const int32_t wtile = SI[w.tile];
             if (wtile < 0 || wtile >= lay.n_tiles || T[wtile].quiet != 5 || T[wtile].field != w.field || T[wtile].count != w.count) FAIL("wave tile %lld: slot", (long long)k);
-            if (w.hb + w.count + w.hf > 64 || w.field < 0 || w.field >= n) FAIL("wave tile %lld: lanes", (long long)k);
+            if (w.hb + w.count + w.hf > tc.wave_points || w.field < 0 || w.field >= n) FAIL("wave tile %lld: lanes", (long long)k);
             const int64_t first = w.out_base - F[w.field].pt_off;
             if (first < 0 || first + w.hb != T[wtile].start || first + w.hb + w.count + w.hf > F[w.field].n_total) FAIL("wave tile %lld: range", (long long)k);
             if (!mark(w.field, first + w.hb, w.count, "wave tile")) FAIL("wave tile %lld", (long long)k);
