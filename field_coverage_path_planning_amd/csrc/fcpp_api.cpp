@@ -205,6 +205,7 @@ struct fcpp_batch {
     int last_mode = 0;
     bool two_streams = true;     // ALU-bound kernels of a step on the context's side stream (FCPP_ONE_STREAM=1 in the environment: off)
     int two_stream_max = 512;    // ... when there are at most this many general tiles (FCPP_TWO_STREAM_MAX, read at batch creation)
+    int sparse_beside_max = 0;   // ... or at most this many wave tiles (FCPP_SPARSE_BESIDE_MAX; 0 = never: measured, see fcpp_batch_run)
     fcpp_setup_times setup = {};
     ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
@@ -482,6 +483,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     b->ctx = c; b->veh = *veh; b->opt = *opt; b->n_fields = n_fields;
     b->two_streams = !(tune_enabled() && getenv("FCPP_ONE_STREAM") != nullptr);
     b->two_stream_max = std::max(0, std::min(tune_int("FCPP_TWO_STREAM_MAX", 512), 1 << 20));
+    b->sparse_beside_max = std::max(0, std::min(tune_int("FCPP_SPARSE_BESIDE_MAX", 0), 1 << 30));
     fcpp_setup_times &tm = b->setup;
     tm.threads = WorkerPool::width();
     std::string err;
@@ -676,8 +678,9 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // and 0.091 vs 0.085 ms, k_plan_sparse 1.07 instead of 0.69 ms; also with the span kernel held to four or five
         // waves per SIMD).
         hipStream_t sd = st;
-        const bool two = b->two_streams && lay.span_points + lay.chunk_points > 0 && lay.n_general > 0 && lay.n_general <= b->two_stream_max &&
-                         lay.n_wave == 0;
+        const bool two = b->two_streams && lay.span_points + lay.chunk_points > 0 &&
+                         ((lay.n_general > 0 && lay.n_general <= b->two_stream_max && lay.n_wave == 0) ||
+                          (b->sparse_beside_max > 0 && lay.n_wave > 0 && lay.n_wave <= b->sparse_beside_max));
         if (two) {
             sd = b->ctx->side;
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));

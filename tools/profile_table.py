@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_<config>_{kernel_stats,counters}.csv -> one row per (configuration, kernel): time, waves, vector / scalar / memory
+"""profiles/r03_<config>_{kernel_stats,counters}.csv -> one row per (configuration, kernel): time, waves, vector / scalar / memory
 instructions per wave, wave life, share of wave-cycles spent waiting, vector-ALU utilisation and resident waves per SIMD.
     VALU busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader-engine instances);  waves per SIMD = SQ_WAVE_CYCLES x 4
     / 1024 / the same busy time (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles, MI355X_MICROARCH.md)."""
@@ -9,7 +9,7 @@ import os
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 print(f"{'config':10s} {'kernel':34s} {'us':>8s} {'waves':>9s} {'VALU/w':>7s} {'SALU/w':>7s} {'SMEM/w':>7s} {'VMEMrd/w':>8s} {'LDS/w':>6s} {'cycles/w':>9s} {'wait%':>6s} {'VALUbusy%':>9s} {'waves/SIMD':>10s}")
-for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r02_*_counters.csv'))):
+for path in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r03_*_counters.csv'))):
     cfg = os.path.basename(path)[4:-13]
     rows = {(r['Kernel'], r['Counter']): float(r['MeanPerDispatch']) for r in csv.DictReader(open(path))}
     st = {r['Name']: float(r['AverageNs']) / 1e3 for r in csv.DictReader(open(path.replace('_counters', '_kernel_stats')))}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_r02/<config>/ (tools/collect_profiles.sh) -> profiles/: per configuration
-    r02_<config>_kernel_stats.csv : the rocprofv3 --kernel-trace --stats summary rows of the fcpp kernels (calls, total / average ns)
-    r02_<config>_counters.csv     : per kernel and counter, the mean value per launch (WRITE_SIZE, FETCH_SIZE, SQ_*)
+"""gpurun_out/prof_r03/<config>/ (tools/collect_profiles.sh) -> profiles/: per configuration
+    r03_<config>_kernel_stats.csv : the rocprofv3 --kernel-trace --stats summary rows of the fcpp kernels (calls, total / average ns)
+    r03_<config>_counters.csv     : per kernel and counter, the mean value per launch (WRITE_SIZE, FETCH_SIZE, SQ_*)
 and profiles/traffic.json: HBM bytes per launch = WRITE_SIZE KiB x 1024 + 2 x FETCH_SIZE KiB x 1024 (the gfx950 FETCH_SIZE correction
 of MI355X_MICROARCH.md, section HBM), keyed '<bench stage name>|<config>' as bench.py looks it up."""
 import collections
@@ -12,7 +12,7 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, 'gpurun_out', 'prof_r02')
+SRC = os.path.join(REPO, 'gpurun_out', 'prof_r03')
 DST = os.path.join(REPO, 'profiles')
 STAGE_PREFIX = (('k_plan_quiet<16', 'k_plan_quiet_spans'), ('k_plan_quiet<14', 'k_plan_quiet'), ('k_plan_sparse', 'k_plan_sparse'),
                 ('k_plan_fused<', 'k_plan_fused'), ('k_reduce_stats', 'k_reduce_stats'))
@@ -49,7 +49,7 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
                 per[short(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         sel = {k: (v[-steps:] if len(v) > steps else v) for k, v in per.items()}
         grand = sum(sum(v) for v in sel.values()) or 1
-        with open(os.path.join(DST, f'r02_{cfg}_kernel_stats.csv'), 'w', newline='') as fh:
+        with open(os.path.join(DST, f'r03_{cfg}_kernel_stats.csv'), 'w', newline='') as fh:
             w = csv.writer(fh)
             w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
             for k, v in sorted(sel.items(), key=lambda kv: -sum(kv[1])):
@@ -64,7 +64,7 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
                 acc[key][0] += 1
                 acc[key][1] += float(r['Counter_Value'])
     if acc:
-        with open(os.path.join(DST, f'r02_{cfg}_counters.csv'), 'w', newline='') as fh:
+        with open(os.path.join(DST, f'r03_{cfg}_counters.csv'), 'w', newline='') as fh:
             w = csv.writer(fh)
             w.writerow(['Kernel', 'Counter', 'Dispatches', 'MeanPerDispatch'])
             for (k, c), (n, s) in sorted(acc.items()):
@@ -80,7 +80,7 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
                 notes[key] = {'kernel': k, 'WRITE_SIZE_KB_per_launch': wkb, 'FETCH_SIZE_KB_per_launch': fkb}
     print(cfg, 'stats' if stats else 'NO stats', len(acc), 'counter rows')
 traffic['_notes'] = {
-    'source': 'rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, separate passes, program directly after `--` (tools/collect_profiles.sh), round 2',
+    'source': 'rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, separate passes, program directly after `--` (tools/collect_profiles.sh), round 3',
     'units': 'bytes per kernel launch = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md section HBM)',
     'detail': notes}
 json.dump(traffic, open(os.path.join(DST, 'traffic.json'), 'w'), indent=1)
