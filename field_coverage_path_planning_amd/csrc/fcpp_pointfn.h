@@ -281,6 +281,53 @@ __device__ __forceinline__ double curv_chords_inline(double dx1, double dy1, dou
     return fabs(2 * atan2_fd(dx1 * dy2 - dy1 * dx2, dx1 * dx2 + dy1 * dy2) / (ds1 + ds2));
 }
 
+// a / b for operands of ordinary magnitude (lengths, speeds, their products: nothing near the ends of the exponent range), without the
+// scaling and fix-up instructions of the IEEE sequence: the hardware reciprocal (< 1 ulp), one Newton step, then Markstein's correction
+// of the quotient by its exact residual -- the result is the correctly rounded quotient except for rare last-bit cases, in 1 + 5
+// instructions instead of 12 (k_plan_sparse executes about ten divisions per wavefront: curvatures, clamps, segment times).
+__device__ __forceinline__ double fdiv(double a, double b)
+{
+    double x = __builtin_amdgcn_rcp(b);
+    x = fma(fma(-b, x, 1.0), x, x);
+    const double q = a * x;
+    return fma(fma(-q, b, a), x, q);
+}
+
+// atan2_fd (fcpp_geom.h) with fdiv for its one quotient: same reduction, same polynomial
+__device__ __forceinline__ double atan2_fd_dev(double y, double x)
+{
+    const double a = fabs(y), b = fabs(x);
+    const bool c0 = a < 0.4375 * b, c1 = a < 0.6875 * b, c2 = a < 1.1875 * b, c3 = a < 2.4375 * b;
+    double num, den, hi, lo;
+    if (c0)      { num = a;            den = b;            hi = 0.0;                          lo = 0.0; }
+    else if (c1) { num = 2.0 * a - b;  den = 2.0 * b + a;  hi = 4.63647609000806093515e-01;   lo = 2.26987774529616870924e-17; }
+    else if (c2) { num = a - b;        den = a + b;        hi = 7.85398163397448278999e-01;   lo = 3.06161699786838301793e-17; }
+    else if (c3) { num = a - 1.5 * b;  den = b + 1.5 * a;  hi = 9.82793723247329054082e-01;   lo = 1.39033110312309984516e-17; }
+    else         { num = -b;           den = a;            hi = 1.57079632679489655800e+00;   lo = 6.12323399573676603587e-17; }
+    const double t = fdiv(num, den), z = t * t, w = z * z;
+    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                                                  9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
+    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                                        -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+    double r = hi - ((t * (s1 + s2) - lo) - t);
+    if (x < 0.0) r = 3.14159265358979311600e+00 - (r - 1.22464679914735317720e-16);
+    return y < 0.0 ? -r : r;
+}
+
+// the curvature clamp of clamped_speed with fdiv (k_plan_sparse)
+__device__ __forceinline__ double clamped_speed_fast(double v_nom, double kappa, const DevConst &cst, bool &clamped)
+{
+    clamped = false;
+    if (kappa > 1e-6) {
+        const double q = v_nom * cst.inv_sf36;
+        if (kappa * q * q < cst.a_lat * (1.0 - 1e-9)) return v_nom;
+        const double vmax_ms = sqrt(fdiv(cst.a_lat, kappa)) * cst.sf;
+        const double vmax_kmh = vmax_ms * 3.6;
+        if (v_nom > vmax_kmh) { clamped = true; return vmax_kmh; }
+    }
+    return v_nom;
+}
+
 // ... and through atan2_fd alone (one point per lane: fcpp_sparse_fn.h).  At the reference's sampling every wavefront of that kernel
 // holds junctions between primitives, whose turning angles are far beyond the short series of curv_chords_fast, so it paid for the
 // series AND for the atan2 fallback; atan2_fd's first interval (|cross| < 7/16 dot) is a series of the same length anyway.  Exactly
@@ -290,7 +337,7 @@ __device__ __forceinline__ double curv_chords_atan(double dx1, double dy1, doubl
     if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
     const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
     if (cr == 0.0 && dt > 0.0) return 0.0;
-    return fabs(2 * atan2_fd(cr, dt) / (ds1 + ds2));
+    return fabs(fdiv(2 * atan2_fd_dev(cr, dt), ds1 + ds2));
 }
 
 // wave-wide reductions; a ballot skips the butterfly when every lane holds the neutral element (most tiles have

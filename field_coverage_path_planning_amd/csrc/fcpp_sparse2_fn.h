@@ -85,8 +85,8 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     if (B.interior) B.kappa = curv_chords_atan(dxb, dyb, B.d, xn - B.px, yn - B.py, dn_b);
     A.cl = B.cl = false;
     A.v0 = A.vn; B.v0 = B.vn;
-    if (A.kappa > 1e-6) A.v0 = clamped_speed(A.vn, A.kappa, cst, A.cl);
-    if (B.kappa > 1e-6) B.v0 = clamped_speed(B.vn, B.kappa, cst, B.cl);
+    if (A.kappa > 1e-6) A.v0 = clamped_speed_fast(A.vn, A.kappa, cst, A.cl);
+    if (B.kappa > 1e-6) B.v0 = clamped_speed_fast(B.vn, B.kappa, cst, B.cl);
     A.ms0 = A.cl ? div36(A.v0) : A.msn;
     B.ms0 = B.cl ? div36(B.v0) : B.msn;
     A.u0 = A.act ? A.ms0 * A.ms0 : FCPP_INF;
@@ -182,11 +182,11 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
         double tpre = 0.0, t = 0.0;
         if (seg) {
             const double ms_pre = (vnprev == q.vn) ? q.msn : div36((vnprev + q.vn) / 2);
-            tpre = q.d / fmax(ms_pre, 0.1);
+            tpre = fdiv(q.d, fmax(ms_pre, 0.1));
         }
         const bool changed = seg && !(vprev == vnprev && q.vfin == q.vn);
         t = tpre;
-        if (__ballot(changed) != 0ull) t = changed ? q.d / fmax(div36((vprev + q.vfin) / 2), 0.1) : tpre;
+        if (__ballot(changed) != 0ull) t = changed ? fdiv(q.d, fmax(div36((vprev + q.vfin) / 2), 0.1)) : tpre;
         const double len = seg ? q.d : 0.0;
         acc.s_len[0] += l0 ? len : 0.0; acc.s_tpre[0] += l0 ? tpre : 0.0; acc.s_t[0] += l0 ? t : 0.0;
         acc.s_len[1] += l0 ? 0.0 : len; acc.s_tpre[1] += l0 ? 0.0 : tpre; acc.s_t[1] += l0 ? 0.0 : t;

@@ -85,7 +85,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     if (interior) kappa = curv_chords_atan(dx1, dy1, dprev, xp - px, yp - py, dnext);
     bool cl = false;
     double v0 = vn;
-    if (kappa > 1e-6) v0 = clamped_speed(vn, kappa, cst, cl);
+    if (kappa > 1e-6) v0 = clamped_speed_fast(vn, kappa, cst, cl);
     const double ms0 = cl ? div36(v0) : msn;
     const double u0 = act ? ms0 * ms0 : FCPP_INF;
 
@@ -160,13 +160,13 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
         double tpre = 0.0, t = 0.0;
         if (seg) {
             const double ms_pre = (vnprev == vn) ? msn : div36((vnprev + vn) / 2);
-            tpre = dprev / fmax(ms_pre, 0.1);
+            tpre = fdiv(dprev, fmax(ms_pre, 0.1));
         }
         // the time at the planned speeds differs from the one at nominal speeds only where a speed was changed: the second division
         // only in waves that hold such a segment
         const bool changed = seg && !(vprev == vnprev && vfin == vn);
         t = tpre;
-        if (__ballot(changed) != 0ull) t = changed ? dprev / fmax(div36((vprev + vfin) / 2), 0.1) : tpre;
+        if (__ballot(changed) != 0ull) t = changed ? fdiv(dprev, fmax(div36((vprev + vfin) / 2), 0.1)) : tpre;
         const double len = seg ? dprev : 0.0;
         // (static indices: a per-lane index into the accumulator arrays would put them in scratch memory)
         acc.s_len[0] += l0 ? len : 0.0; acc.s_tpre[0] += l0 ? tpre : 0.0; acc.s_t[0] += l0 ? t : 0.0;
