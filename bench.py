@@ -260,6 +260,12 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
 
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner and gloo its connection messages to stdout when the process
+    # group comes up -- from here on file descriptor 1 is stderr, and the line is written to the real stdout at the very end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -507,9 +513,11 @@ def main():
 
     if rank == 0:
         out['configs'] = configs
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
 
 
 def single_field_latency(torch):
