@@ -66,7 +66,8 @@ int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtil
 {
     if (n_wtiles <= 0) return 0;
     const bool two = points_per_lane == 2;
-    if (n_wtiles >= (two ? 65536 : 131072)) {
+    const int wpb_k = tune_int("FCPP_SPARSE_WPB", 0);         // (FCPP_TUNE=1 only: 2 or 4 wave tiles per workgroup, tools/ab_knob.py)
+    if (wpb_k == 2 || (wpb_k != 4 && n_wtiles >= (two ? 65536 : 131072))) {
         if (two) FCPP_LAUNCH((k_plan_sparse<2, 2>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
         else FCPP_LAUNCH((k_plan_sparse<2, 1>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
     } else {
