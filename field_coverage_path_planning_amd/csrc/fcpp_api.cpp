@@ -178,6 +178,7 @@ struct FusedTables {
     DevField *fields = nullptr; DevPrim *prims = nullptr; DevTile *tiles = nullptr; DevWaveTile *wave_tiles = nullptr;
     int32_t *general_ids = nullptr; DevTile *chunks = nullptr, *span_chunks = nullptr;
     int32_t *stat_ids = nullptr; int64_t *stat_first = nullptr, *stat_run = nullptr; int32_t *red_paths = nullptr;
+    DevFieldWork *field_work = nullptr; int32_t *open_wave_ids = nullptr;
     int64_t *obs_off = nullptr; double *obs_x = nullptr, *obs_y = nullptr, *obs_bbox = nullptr;
     double *seg = nullptr; int32_t *seg_mask = nullptr;
     TilePartial *partial = nullptr; char *red_scratch = nullptr; double2 *field_junc = nullptr;
@@ -532,6 +533,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tc.wave_factor = std::max(0, std::min(tune_int("FCPP_WAVE_FACTOR", 24), 64));
     tc.reduce_wg_max = std::max(256, std::min(tune_int("FCPP_REDUCE_WG_MAX", 1024), 1 << 20));
     tc.wave_points = tune_int("FCPP_WAVE_POINTS", 128) == 64 ? 64 : 128;
+    tc.field_work = tune_int("FCPP_FIELD_WORK", 1) != 0;
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);
@@ -580,6 +582,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         t.chunks = reinterpret_cast<DevTile *>(d + lay.chunks); t.span_chunks = reinterpret_cast<DevTile *>(d + lay.span_chunks);
         t.stat_ids = reinterpret_cast<int32_t *>(d + lay.stat_ids); t.stat_first = reinterpret_cast<int64_t *>(d + lay.stat_first);
         t.stat_run = reinterpret_cast<int64_t *>(d + lay.stat_run); t.red_paths = reinterpret_cast<int32_t *>(d + lay.red_paths);
+        t.field_work = reinterpret_cast<DevFieldWork *>(d + lay.field_work); t.open_wave_ids = reinterpret_cast<int32_t *>(d + lay.open_wave_ids);
         if (lay.n_polys > 0) {
             t.obs_off = reinterpret_cast<int64_t *>(d + lay.obs_off); t.obs_x = reinterpret_cast<double *>(d + lay.obs_x);
             t.obs_y = reinterpret_cast<double *>(d + lay.obs_y); t.obs_bbox = reinterpret_cast<double *>(d + lay.obs_bbox);
@@ -686,13 +689,20 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
             HIPCHK(hipEventRecord(b->ctx->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(sd, b->ctx->ev_fork, 0));
         }
-        STAGE(2, launch_plan_sparse(sd, lay.n_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial, lay.wave_tile_points / 64));
+        // the wave tiles of fields that k_plan_sparse_fields does not take (all of them when there are none of those)
+        const bool fw = lay.n_field_work > 0;
+        if (!fw) STAGE(2, launch_plan_sparse(sd, lay.n_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial, lay.wave_tile_points / 64));
+        else LAUNCHCHK(launch_plan_sparse(sd, lay.n_open_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial, lay.wave_tile_points / 64,
+                                          t.open_wave_ids));
         STAGE(3, launch_plan_fused(sd, variant, lay.n_general, t.general_ids, t.tiles, t.fields, t.prims, b->cst, obs, x,
                                    y, kappa, v, fs, t.partial));
         if (two) HIPCHK(hipEventRecord(b->ctx->ev_join, sd));
         STAGE(0, launch_plan_quiet(st, lay.n_span_chunks, t.span_chunks, 16, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
         STAGE(1, launch_plan_quiet(st, lay.n_chunks, t.chunks, 14, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
+        // fields planned and reduced by one workgroup each: after the streaming kernels, whose flag counts their reduction reads
+        if (fw) STAGE(2, launch_plan_sparse_fields(st, lay.n_field_work, t.field_work, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
+                                                   t.stat_run, stats));
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
         // (four classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
         // time the first launch)

@@ -103,6 +103,21 @@ struct DevWaveTile {
 };
 static_assert(sizeof(DevWaveTile) == 64, "DevWaveTile is fetched as one 64-byte record");
 
+// A field whose general points are all in wave tiles, FIELD_WORK_TILES of them (or one fewer): ONE workgroup of k_plan_sparse_fields
+// plans its tiles (a wavefront each) and then reduces the field's statistics itself -- its tiles' partial results through LDS, the
+// slots of its quiet runs from memory -- so such fields need no k_reduce_stats launch.  (Measured with eight-wave workgroups for fields
+// of up to eight tiles: the idle wavefronts of a half-empty workgroup hold their slots until its barrier -- headline 60 instead of 35 us.)
+constexpr int FIELD_WORK_TILES = 4, FIELD_WORK_ENTRIES = 16;
+struct DevFieldWork {
+    int32_t field;
+    int32_t n_tiles;         // wave tiles wtiles[w_first .. w_first + n_tiles)
+    int32_t w_first;
+    int32_t e_first;         // statistics entries [e_first, e_first + n_entries): the field's runs and tiles in path order
+    int32_t n_entries;
+    int32_t _pad[3];
+};
+static_assert(sizeof(DevFieldWork) == 32, "DevFieldWork is fetched as one 32-byte record");
+
 // batch-wide turn templates: every field of a batch shares the vehicle and the sampling options, hence the number of
 // samples and the shape of its U-turns (nu) and corner turns (nc)
 struct TurnTemplates {

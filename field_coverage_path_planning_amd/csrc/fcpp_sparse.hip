@@ -25,7 +25,7 @@ namespace fcpp {
 // 737-752 with eight); measured on the same box, tools/ab_knob.py per build.
 // PTS: points per lane -- 1: wave tiles of up to 64 points (sparse_tile), 2: of up to 128 (sparse_tile2, fcpp_sparse2_fn.h)
 template <int SP_WAVES, int PTS>
-__global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile *__restrict__ wtiles, int64_t n_wtiles,
+__global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile *__restrict__ wtiles, const int32_t *__restrict__ ids, int64_t n_wtiles,
                                                                const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
                                                                DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
                                                                double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * SP_WAVES + wave;
     if (slot >= n_wtiles) return;
-    const DevWaveTile wt = wtiles[slot];
+    const DevWaveTile wt = wtiles[ids ? (int64_t)ids[slot] : slot];      // (ids: the wave tiles of the fields k_plan_sparse_fields does not take)
     SparseAcc acc;
     acc.clear();
     if (PTS == 2) sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
@@ -60,19 +60,107 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
     }
 }
 
+// One workgroup per FIELD (DevFieldWork): wavefront w plans the field's w-th wave tile (two points per lane), then wavefront 0 reduces
+// the field's statistics -- the tiles' partial results through LDS, the slots of the field's quiet runs (closed-form constants written at
+// batch creation + the flag counts k_plan_quiet has added in this step: this launch comes after the streaming kernels) from memory -- in
+// the order of the field's statistics entries, a fixed butterfly over 16 lanes.  No k_reduce_stats launch for such fields, no global
+// partial slots for their tiles, no cross-workgroup synchronisation: everything the reduction needs is the workgroup's own or final.
+__global__ __launch_bounds__(64 * FIELD_WORK_TILES) void k_plan_sparse_fields(const DevFieldWork *__restrict__ work, const DevWaveTile *__restrict__ wtiles,
+                                                                             const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
+                                                                             DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
+                                                                             double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                                                             TilePartial *__restrict__ partial, const int64_t *__restrict__ stat_run,
+                                                                             fcpp_field_stats *__restrict__ stats)
+{
+    __shared__ double obs_lds[FIELD_WORK_TILES][2 * OBS_LDS_VERTS];
+    __shared__ TilePartial red[FIELD_WORK_TILES];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const DevFieldWork w = work[blockIdx.x];
+    if (wave < w.n_tiles) {
+        const DevWaveTile wt = wtiles[w.w_first + wave];
+        SparseAcc acc;
+        acc.clear();
+        sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
+        double g[3] = { 0.0, 0.0, 0.0 };
+        const int out0 = wt.hb, out1 = wt.hb + wt.count;
+        if (out0 < wt.rel_seam) g[0] = wave4_to_hi<0>(acc.s_len[0], acc.s_tpre[0], acc.s_t[0], 0.0);
+        if (out1 > wt.rel_seam + 1) g[1] = wave4_to_hi<0>(acc.s_len[1], acc.s_tpre[1], acc.s_t[1], 0.0);
+        if (__ballot(acc.mk != 0.0 || acc.mj != 0.0) != 0ull) g[2] = wave4_to_hi<1>(acc.mk, acc.ma, acc.mj, 0.0);
+        const int vs = WAVE4_SLOT(lane);
+        if (lane >= 60 && vs < 3) {
+            double *tp = reinterpret_cast<double *>(&red[wave]);
+            tp[vs] = g[0]; tp[3 + vs] = g[1]; tp[6 + vs] = g[2];
+        }
+        if (lane == 63) { red[wave].n_viol = acc.c_viol; red[wave].n_outside = acc.c_out; red[wave].n_in_obstacle = acc.c_obs; red[wave].n_adjusted = acc.c_adj; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // entry e of the field = lane e: a quiet run (its slot in memory) or the field's next wave tile (its result in LDS)
+    const bool valid = lane < w.n_entries;
+    const int64_t rc = valid ? stat_run[w.e_first + lane] : 1;
+    const bool is_tile = valid && rc == 0;
+    const unsigned long long tiles_before = __ballot(is_tile) & ((1ull << lane) - 1ull);
+    double a[9];
+    long long b[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = 0;
+    if (valid) {
+        TilePartial tp;
+        if (is_tile) tp = red[__popcll(tiles_before)];
+        else {
+            TilePartial &slot = partial[w.e_first + lane];
+            tp = slot;
+            if (tp.n_outside | tp.n_in_obstacle) { slot.n_outside = 0; slot.n_in_obstacle = 0; }       // (collected anew in the next step)
+        }
+        a[0] = tp.main_len; a[1] = tp.main_time_pre; a[2] = tp.main_time; a[3] = tp.head_len; a[4] = tp.head_time_pre; a[5] = tp.head_time;
+        a[6] = tp.max_kappa; a[7] = tp.max_alat; a[8] = tp.max_jump;
+        b[0] = tp.n_viol; b[1] = tp.n_outside; b[2] = tp.n_in_obstacle; b[3] = tp.n_adjusted;
+    }
+#pragma unroll
+    for (int o = FIELD_WORK_ENTRIES / 2; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a[k] += __shfl_xor(a[k], o);
+#pragma unroll
+        for (int k = 6; k < 9; ++k) a[k] = fmax(a[k], __shfl_xor(a[k], o));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] += __shfl_xor(b[k], o);
+    }
+    if (lane == 0) {
+        fcpp_field_stats o;
+        o.main_len_m = a[0]; o.main_time_pre_s = a[1]; o.main_time_s = a[2];
+        o.head_len_m = a[3]; o.head_time_pre_s = a[4]; o.head_time_s = a[5];
+        o.max_kappa = a[6]; o.max_alat = a[7]; o.max_jump = a[8];
+        o.n_viol = b[0]; o.n_outside = b[1]; o.n_in_obstacle = b[2]; o.n_adjusted = b[3];
+        stats[w.field] = o;
+    }
+}
+
+int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldWork *work, const DevWaveTile *wtiles, const DevField *fields,
+                              const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
+                              uint32_t *fs, TilePartial *partial, const int64_t *stat_run, fcpp_field_stats *stats)
+{
+    if (n_work <= 0) return 0;
+    FCPP_LAUNCH(k_plan_sparse_fields, dim3((unsigned)n_work), dim3(64 * FIELD_WORK_TILES), 0, st, work, wtiles, fields, prims, cst, obs, x, y, kappa, v, fs,
+                partial, stat_run, stats);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtiles, const DevField *fields, const DevPrim *prims,
                        const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v, uint32_t *fs,
-                       TilePartial *partial, int points_per_lane)
+                       TilePartial *partial, int points_per_lane, const int32_t *ids)
 {
     if (n_wtiles <= 0) return 0;
     const bool two = points_per_lane == 2;
     const int wpb_k = tune_int("FCPP_SPARSE_WPB", 0);         // (FCPP_TUNE=1 only: 2 or 4 wave tiles per workgroup, tools/ab_knob.py)
     if (wpb_k == 2 || (wpb_k != 4 && n_wtiles >= (two ? 65536 : 131072))) {
-        if (two) FCPP_LAUNCH((k_plan_sparse<2, 2>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
-        else FCPP_LAUNCH((k_plan_sparse<2, 1>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        if (two) FCPP_LAUNCH((k_plan_sparse<2, 2>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        else FCPP_LAUNCH((k_plan_sparse<2, 1>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
     } else {
-        if (two) FCPP_LAUNCH((k_plan_sparse<4, 2>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
-        else FCPP_LAUNCH((k_plan_sparse<4, 1>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        if (two) FCPP_LAUNCH((k_plan_sparse<4, 2>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        else FCPP_LAUNCH((k_plan_sparse<4, 1>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -21,12 +21,14 @@ struct BlockTiles {
     std::vector<int64_t> stat_run;
     std::vector<DevTile> chunks, span_chunks;
     std::vector<int32_t> cls[4];                 // fields (batch-wide indices) by reduction class
+    std::vector<DevFieldWork> work;              // fields planned and reduced by one workgroup (w_first / e_first block-relative)
+    std::vector<int32_t> open_wave;              // wave tiles (block-relative indices) of all other fields
     int64_t tile0[PLAN_BLOCK_FIELDS + 1], w0[PLAN_BLOCK_FIELDS + 1];      // a field's records: [tile0[k], tile0[k + 1]) ...
     int64_t stat_cnt[PLAN_BLOCK_FIELDS];         // statistic entries per field
     int64_t n_runs = 0, quiet_points = 0, wave_points = 0, span_points = 0, chunk_points = 0, wave_inside = 0;
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };
     // bases in the merged tables
-    int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, chunk_base = 0, span_base = 0, cls_base[4] = { 0, 0, 0, 0 };
+    int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, chunk_base = 0, span_base = 0, cls_base[4] = { 0, 0, 0, 0 }, work_base = 0, open_base = 0;
 };
 
 namespace {
@@ -402,9 +404,23 @@ struct FieldTiler {
         }
         const int64_t ne = (int64_t)(out.stat_ids.size() - stat_mark);
         out.stat_cnt[k_local] = ne;
-        // classes of the reduction: by the number of entries of the path (a property of the field alone)
-        // (8 lanes, a wavefront, a workgroup, 64 workgroups per path: at most 8 / 4 / 4 entries per lane in the first three)
-        out.cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= tc.reduce_wg_max ? 2 : 3))].push_back((int32_t)field);
+        // A field whose general points are all in (two-point) wave tiles that fill one workgroup (three or four tiles: a workgroup's
+        // idle wavefronts wait at its barrier, so fewer would waste the chip; fields of the reference's size have four):
+        // k_plan_sparse_fields plans the tiles and reduces the field (DevFieldWork).  All others: their wave tiles go to k_plan_sparse's list, the field to a class of
+        // k_reduce_stats by the number of entries of its path (a property of the field alone; 8 lanes, a wavefront, a workgroup,
+        // 64 workgroups per path: at most 8 / 4 / 4 entries per lane in the first three)
+        const int64_t nw = out.w0[k_local + 1] - out.w0[k_local];
+        bool general = false;
+        for (int64_t i = t0; i < t1 && !general; ++i) general = T[(size_t)i].quiet == 0;
+        if (tc.field_work && tc.wave_points == 128 && !general && nw >= FIELD_WORK_TILES - 1 && nw <= FIELD_WORK_TILES && ne <= FIELD_WORK_ENTRIES) {
+            DevFieldWork w;
+            memset(&w, 0, sizeof w);
+            w.field = (int32_t)field; w.n_tiles = (int32_t)nw; w.w_first = (int32_t)out.w0[k_local]; w.e_first = (int32_t)stat_mark; w.n_entries = (int32_t)ne;
+            out.work.push_back(w);
+        } else {
+            for (int64_t k = out.w0[k_local]; k < out.w0[k_local + 1]; ++k) out.open_wave.push_back((int32_t)k);
+            out.cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= tc.reduce_wg_max ? 2 : 3))].push_back((int32_t)field);
+        }
         out.n_runs += (int64_t)rv.size();
         // Chunks: every run is cut on 512-point boundaries of the batch arrays.  Consecutive layer-1 runs (swath line, U-turn, swath
         // line, ...) are cut TOGETHER: a chunk that holds the end of one run and the start of the next is written by one wave through
@@ -484,6 +500,8 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
         lay.n_tiles += (int64_t)bt.tiles.size(); lay.n_wave += (int64_t)bt.wtiles.size(); lay.n_general += (int64_t)bt.general_ids.size();
         lay.n_stat += (int64_t)bt.stat_ids.size(); lay.n_chunks += (int64_t)bt.chunks.size(); lay.n_span_chunks += (int64_t)bt.span_chunks.size();
         for (int c = 0; c < 4; ++c) { bt.cls_base[c] = lay.n_red[c]; lay.n_red[c] += (int64_t)bt.cls[c].size(); }
+        bt.work_base = lay.n_field_work; bt.open_base = lay.n_open_wave;
+        lay.n_field_work += (int64_t)bt.work.size(); lay.n_open_wave += (int64_t)bt.open_wave.size();
         lay.n_runs += bt.n_runs; lay.quiet_points += bt.quiet_points; lay.wave_points += bt.wave_points;
         lay.span_points += bt.span_points; lay.chunk_points += bt.chunk_points; lay.wave_inside += bt.wave_inside;
         for (int k = 0; k < 5; ++k) lay.wave_fail[k] += bt.wave_fail[k];
@@ -504,6 +522,8 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
     take(lay.stat_first, (size_t)(n + 1) * sizeof(int64_t));
     take(lay.stat_run, (size_t)lay.n_stat * sizeof(int64_t));
     take(lay.red_paths, (size_t)n * sizeof(int32_t));
+    take(lay.field_work, (size_t)lay.n_field_work * sizeof(DevFieldWork));
+    take(lay.open_wave_ids, (size_t)lay.n_open_wave * sizeof(int32_t));
     take(lay.obs_off, lay.n_polys > 0 ? (size_t)(lay.n_polys + 1) * sizeof(int64_t) : 0);
     take(lay.obs_x, (size_t)lay.n_poly_verts * sizeof(double));
     take(lay.obs_y, (size_t)lay.n_poly_verts * sizeof(double));
@@ -548,6 +568,10 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         int64_t run = bt.stat_base;
         for (int64_t k = 0; k < nf; ++k) { sf[pb.f0 + k] = run; run += bt.stat_cnt[k]; }
         if (pb.f1 == n) sf[n] = run;
+        DevFieldWork *fw = at<DevFieldWork>(dst, lay.field_work) + bt.work_base;
+        for (size_t k = 0; k < bt.work.size(); ++k) { fw[k] = bt.work[k]; fw[k].w_first += (int32_t)bt.wave_base; fw[k].e_first += sb; }
+        int32_t *ow = at<int32_t>(dst, lay.open_wave_ids) + bt.open_base;
+        for (size_t k = 0; k < bt.open_wave.size(); ++k) ow[k] = bt.open_wave[k] + (int32_t)bt.wave_base;
         int32_t *rp = at<int32_t>(dst, lay.red_paths);
         for (int cidx = 0; cidx < 4; ++cidx)
             if (!bt.cls[cidx].empty())

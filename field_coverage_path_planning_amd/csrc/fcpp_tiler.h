@@ -28,18 +28,20 @@ struct TileConsts {
     double fence_margin = 1e-3;               // a point this far inside every edge cannot be flagged by the device's geofence test
     int wave_factor = 24;                     // wave tiles where wave_factor * 2a * line step >= u_cap
     int wave_points = 128;                    // points per wave tile: 64 (one per lane) or 128 (two per lane, fcpp_sparse2_fn.h)
+    bool field_work = true;                   // fields with few wave tiles and nothing else general: planned and reduced by one workgroup (DevFieldWork)
     int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
 };
 
 // the tables of the fused pipeline inside one allocation; all offsets in bytes from the image's start, 256-byte aligned
 struct ImageLayout {
     size_t fields = 0, prims = 0, tiles = 0, wtiles = 0, general_ids = 0, chunks = 0, span_chunks = 0, stat_ids = 0, stat_first = 0,
-           stat_run = 0, red_paths = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
+           stat_run = 0, red_paths = 0, field_work = 0, open_wave_ids = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
     size_t upload_bytes = 0;                  // [0, upload_bytes) is built on the host and copied
     size_t partial = 0, red_scratch = 0, field_junc = 0;      // device-only scratch behind it
     size_t total_bytes = 0;
     int64_t n_fields = 0, n_prims = 0, n_tiles = 0, n_wave = 0, n_general = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_stat = 0;
-    int64_t n_red[4] = { 0, 0, 0, 0 };
+    int64_t n_red[4] = { 0, 0, 0, 0 };       // fields reduced by k_reduce_stats, by class (fields of field_work are in none)
+    int64_t n_field_work = 0, n_open_wave = 0;  // fields planned AND reduced by one workgroup each / wave tiles of the other fields
     int64_t n_polys = 0, n_poly_verts = 0;
     int64_t quiet_points = 0, span_points = 0, chunk_points = 0, wave_points = 0;
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 }; // diagnostics: stretches refused for wave tiles, by reason

@@ -105,7 +105,8 @@ int main(int argc, char **argv)
         TileConsts tc;
         tc.tu = tu.data(); tc.tc = tcn.data(); tc.nu = tt.nu; tc.nc = tt.nc; tc.templates_ok = true;
         tc.turn_quiet = pick(4) != 0;
-        tc.wave_points = pick(2) ? 128 : 64;
+        tc.wave_points = pick(3) ? 128 : 64;
+        tc.field_work = pick(4) != 0;
         const double vm = 15.0 / 3.6;
         tc.two_a = 2 * veh.max_longitudinal_accel; tc.u_cap = vm * vm; tc.c_line = (9.0 / 3.6) * (9.0 / 3.6);
         tc.fence_margin = 1e-3 + (opt.geofence_tol < 0 ? -opt.geofence_tol : 0.0);
@@ -198,8 +199,29 @@ int main(int argc, char **argv)
         if (q_pts != lay.quiet_points || lay.span_points + lay.chunk_points != lay.quiet_points) FAIL("quiet point totals");
         {
             std::vector<unsigned char> seen((size_t)n, 0);
-            const int64_t nr = lay.n_red[0] + lay.n_red[1] + lay.n_red[2] + lay.n_red[3];
-            if (nr != n) FAIL("reduction classes hold %lld of %d fields", (long long)nr, n);
+            // fields planned and reduced by one workgroup (DevFieldWork) are in no class; their wave tiles are not in the open list
+            const DevFieldWork *FW = reinterpret_cast<const DevFieldWork *>(img.data() + lay.field_work);
+            const int32_t *OW = reinterpret_cast<const int32_t *>(img.data() + lay.open_wave_ids);
+            std::vector<unsigned char> wseen((size_t)lay.n_wave, 0);
+            for (int64_t k = 0; k < lay.n_field_work; ++k) {
+                const DevFieldWork &w = FW[k];
+                if (w.field < 0 || w.field >= n || seen[(size_t)w.field]++) FAIL("field work %lld: field", (long long)k);
+                if (w.e_first != SF[w.field] || w.n_entries != SF[w.field + 1] - SF[w.field] || w.n_entries > FIELD_WORK_ENTRIES) FAIL("field work %lld: entries", (long long)k);
+                if (w.n_tiles < FIELD_WORK_TILES - 1 || w.n_tiles > FIELD_WORK_TILES || w.w_first < 0 || w.w_first + w.n_tiles > lay.n_wave) FAIL("field work %lld: tiles", (long long)k);
+                int nt = 0;
+                for (int64_t e = SF[w.field]; e < SF[w.field + 1]; ++e) {
+                    if (SR[e] == 0) { if (T[SI[e]].quiet != 5 || Wt[w.w_first + nt].tile != e) FAIL("field work %lld: entry %lld is not its tile %d", (long long)k, (long long)e, nt); ++nt; }
+                }
+                if (nt != w.n_tiles) FAIL("field work %lld: %d tiles among the entries, %d in the record", (long long)k, nt, w.n_tiles);
+                for (int q = 0; q < w.n_tiles; ++q) { if (Wt[w.w_first + q].field != w.field || wseen[(size_t)(w.w_first + q)]++) FAIL("field work %lld: tile %d", (long long)k, q); }
+            }
+            for (int64_t k = 0; k < lay.n_open_wave; ++k) {
+                if (OW[k] < 0 || OW[k] >= lay.n_wave || wseen[(size_t)OW[k]]++) FAIL("open wave tile %lld", (long long)k);
+                if (k > 0 && OW[k] <= OW[k - 1]) FAIL("open wave list not ascending");
+            }
+            for (int64_t k = 0; k < lay.n_wave; ++k) if (wseen[(size_t)k] != 1) FAIL("wave tile %lld planned %d times", (long long)k, wseen[(size_t)k]);
+            const int64_t nr = lay.n_red[0] + lay.n_red[1] + lay.n_red[2] + lay.n_red[3] + lay.n_field_work;
+            if (nr != n) FAIL("reduction classes and field work hold %lld of %d fields", (long long)nr, n);
             int64_t at = 0;
             for (int c = 0; c < 4; ++c)
                 for (int64_t k = 0; k < lay.n_red[c]; ++k, ++at) {

@@ -131,7 +131,8 @@ def test_cfg5_full_size_properties():
     batch = E.Batch(specs, veh, opt)
     n = batch.total_points
     assert len(batch.info) == 65536 and all(i.status == 0 for i in batch.info) and 2.6e8 < n < 2.9e8
-    assert batch.reduce_classes()[0] == 65536                      # every path in the 8-lane class
+    # every path reduced by the 8-lane class of k_reduce_stats or, fields of three or four wave tiles, by its own workgroup of k_plan_sparse_fields
+    assert sum(batch.reduce_classes()[1:]) == 0 and batch.reduce_classes()[0] > 30000
     res = batch.run(mode=1)
     dev = res.x.device
     st = res.stats()
