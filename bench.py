@@ -214,11 +214,11 @@ def roofline_of(r, traffic_key=None):
     if traffic_key and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(f'{dom}|{traffic_key}')
     note = None
-    if dom == 'k_plan_sparse':
+    if dom in ('k_plan_sparse', 'k_plan_sparse_fields'):
         # (the secondary ceiling.  Counters of the kept profiles, not measured in this run.)
-        note = ('k_plan_sparse is bound by fp64 vector issue, not by HBM: 640-680 vector instructions per 64-lane wavefront of ~52 output points, '
-                'vector ALU busy ~100 % of the kernel (profiles/r02_counter_table.txt); its HBM fraction is low by construction, the '
-                'step-level figure is step_frac')
+        note = ('the wave-tile kernels (k_plan_sparse, and k_plan_sparse_fields: the same tiles planned and reduced field by field) are bound by fp64 '
+                'vector issue and by their dependent loads, not by HBM: ~1000 vector instructions per wavefront of ~110 output points '
+                '(profiles/r03_counter_table.txt); their HBM fraction is low by construction, the step-level figure is step_frac')
     return {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'note': note,
             'traffic': traffic, 'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
             'kernel_points_per_launch': dom_points, 'all_kernels_ms': r['kernels'], 'all_kernels_points': r['stage_points'],
@@ -398,7 +398,7 @@ def main():
                             f'(2 / 20 / 15 / 20 points per line / U-turn / corner / headland side), 1691 points per field -- the mode pinned to '
                             f'the reference\'s outputs; the clothoid variants of the same batch are configs[cfg1_clothoid*] below and value_clothoid',
                 'turn_model': 'arc (reference, pinned)', 'points_per_gpu_step': r['points'], 'fields_per_gpu': args.fields,
-                'pipeline': 'staged (7 kernels)' if args.mode == 0 else 'fused: k_plan_quiet (closed-form runs and spans) + k_plan_sparse (wave tiles, one point per lane) + k_plan_fused (all other tiles) + k_reduce_stats',
+                'pipeline': 'staged (7 kernels)' if args.mode == 0 else 'fused: k_plan_quiet (closed-form runs and spans) + k_plan_sparse / k_plan_sparse_fields (wave tiles, two points per lane; the latter also reduces its fields) + k_plan_fused (all other tiles) + k_reduce_stats',
                 'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'output_arrays': r['layout'],
             },
             'roofline': roofline_of(r, 'cfg1'),

@@ -216,8 +216,8 @@ constexpr int kStages = 7;
 constexpr int kProfRuns = 256;
 const char *const kStageNames[2][kStages] = {
     { "k_generate", "k_curv_clamp", "k_scan_tiles", "k_scan_spine", "k_scan_apply", "k_validate", "k_reduce_stats" },
-    { "k_plan_quiet_spans", "k_plan_quiet", "k_plan_sparse", "k_plan_fused", "k_reduce_stats", "", "" } };
-const int kStageCount[2] = { 7, 5 };
+    { "k_plan_quiet_spans", "k_plan_quiet", "k_plan_sparse", "k_plan_fused", "k_reduce_stats", "k_plan_sparse_fields", "" } };
+const int kStageCount[2] = { 7, 6 };
 }
 
 // Are the U-turns of this batch closed form?  A turn is a translate / mirror of the template t[0..nu); its neighbours are the
@@ -534,6 +534,10 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tc.reduce_wg_max = std::max(256, std::min(tune_int("FCPP_REDUCE_WG_MAX", 1024), 1 << 20));
     tc.wave_points = tune_int("FCPP_WAVE_POINTS", 128) == 64 ? 64 : 128;
     tc.field_work = tune_int("FCPP_FIELD_WORK", 1) != 0;
+    {   // (more than one tile per wavefront only with the loop forms of the kernel: FCPP_FIELD_WORK_WAVES=1 or 2, tuning runs)
+        const int wv = tune_int("FCPP_FIELD_WORK_WAVES", FIELD_WORK_WAVES_MAX);
+        tc.field_work_tiles = std::max(1, std::min(tune_int("FCPP_FIELD_WORK_TILES", FIELD_WORK_WAVES_MAX), (wv == 1 || wv == 2) ? FIELD_WORK_TILES : FIELD_WORK_WAVES_MAX));
+    }
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);
@@ -692,8 +696,8 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // the wave tiles of fields that k_plan_sparse_fields does not take (all of them when there are none of those)
         const bool fw = lay.n_field_work > 0;
         if (!fw) STAGE(2, launch_plan_sparse(sd, lay.n_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial, lay.wave_tile_points / 64));
-        else LAUNCHCHK(launch_plan_sparse(sd, lay.n_open_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial, lay.wave_tile_points / 64,
-                                          t.open_wave_ids));
+        else STAGE(2, launch_plan_sparse(sd, lay.n_open_wave, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial, lay.wave_tile_points / 64,
+                                         t.open_wave_ids));
         STAGE(3, launch_plan_fused(sd, variant, lay.n_general, t.general_ids, t.tiles, t.fields, t.prims, b->cst, obs, x,
                                    y, kappa, v, fs, t.partial));
         if (two) HIPCHK(hipEventRecord(b->ctx->ev_join, sd));
@@ -701,7 +705,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
         STAGE(1, launch_plan_quiet(st, lay.n_chunks, t.chunks, 14, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
         // fields planned and reduced by one workgroup each: after the streaming kernels, whose flag counts their reduction reads
-        if (fw) STAGE(2, launch_plan_sparse_fields(st, lay.n_field_work, t.field_work, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
+        if (fw) STAGE(5, launch_plan_sparse_fields(st, lay.n_field_work, t.field_work, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
                                                    t.stat_run, stats));
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
         // (four classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
@@ -783,7 +787,7 @@ int fcpp_batch_stage_points(const fcpp_batch *b, int mode, int stage, int64_t *p
     const ImageLayout &t = b->lay;
     const int64_t all = b->hp.total_points;
     if (mode == 0) { *points = all; return FCPP_OK; }         // every staged kernel sees every point
-    const int64_t per_stage[5] = { t.span_points, t.chunk_points, t.wave_points, all - t.quiet_points - t.wave_points, all };
+    const int64_t per_stage[6] = { t.span_points, t.chunk_points, t.wave_points - t.work_wave_points, all - t.quiet_points - t.wave_points, all, t.work_wave_points };
     *points = per_stage[stage];
     return FCPP_OK;
 }

@@ -103,11 +103,12 @@ struct DevWaveTile {
 };
 static_assert(sizeof(DevWaveTile) == 64, "DevWaveTile is fetched as one 64-byte record");
 
-// A field whose general points are all in wave tiles, FIELD_WORK_TILES of them (or one fewer): ONE workgroup of k_plan_sparse_fields
-// plans its tiles (a wavefront each) and then reduces the field's statistics itself -- its tiles' partial results through LDS, the
-// slots of its quiet runs from memory -- so such fields need no k_reduce_stats launch.  (Measured with eight-wave workgroups for fields
-// of up to eight tiles: the idle wavefronts of a half-empty workgroup hold their slots until its barrier -- headline 60 instead of 35 us.)
-constexpr int FIELD_WORK_TILES = 4, FIELD_WORK_ENTRIES = 16;
+// A field whose general points are all in wave tiles, at most FIELD_WORK_TILES of them: ONE workgroup of k_plan_sparse_fields plans
+// its tiles -- one, two or four wavefronts walk them, by the number of such fields in the batch -- and then reduces the field's
+// statistics itself: its tiles' partial results through LDS, the slots of its quiet runs from memory, so such fields need no
+// k_reduce_stats launch.  (Measured with eight-wave workgroups, a wavefront per tile: the idle wavefronts of a half-empty workgroup hold
+// their slots until its barrier -- headline 60 instead of 35 us.)
+constexpr int FIELD_WORK_TILES = 8, FIELD_WORK_ENTRIES = 16, FIELD_WORK_WAVES_MAX = 4;
 struct DevFieldWork {
     int32_t field;
     int32_t n_tiles;         // wave tiles wtiles[w_first .. w_first + n_tiles)

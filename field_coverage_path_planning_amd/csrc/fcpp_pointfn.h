@@ -293,51 +293,85 @@ __device__ __forceinline__ double fdiv(double a, double b)
     return fma(fma(-q, b, a), x, q);
 }
 
-// atan2_fd (fcpp_geom.h) with fdiv for its one quotient: same reduction, same polynomial
-__device__ __forceinline__ double atan2_fd_dev(double y, double x)
+// sqrt(x) for a positive x of ordinary magnitude (squared lengths and speeds: nothing below 2^-767, never 0 or infinite): the
+// hardware's reciprocal square root, the two coupled Newton steps and the two residual corrections of the compiler's own IEEE sequence
+// -- the same instructions, so the same correctly rounded result -- without its range scaling and special-value selects (10 instead of
+// 20 instructions; k_plan_sparse takes up to six square roots per lane)
+__device__ __forceinline__ double fsqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    return fma(fma(-g, g, x), h, g);
+}
+__device__ __forceinline__ double seg_len_fast(double dx, double dy)      // seg_len with fsqrt_pos (both steps non-zero where it is taken)
+{
+    return (dy == 0.0) ? fabs(dx) : ((dx == 0.0) ? fabs(dy) : fsqrt_pos(dx * dx + dy * dy));
+}
+
+// atan2_fd's (fcpp_geom.h) five reduction intervals as a table of six doubles each: t = num / den with num = na a + nb b and
+// den = da a + db b, then hi, lo.  The products by 0, 1, 2 are exact and 1.5 x rounds as in atan2_fd, so num and den are the values
+// its expressions give; one lookup by the interval's number replaces four selects each of num, den, hi and lo.
+static constexpr int ATAN_TAB_DOUBLES = 32;
+static __constant__ double k_atan_tab[ATAN_TAB_DOUBLES] = {
+    1.0,  0.0, 0.0, 1.0, 0.0,                          0.0,
+    2.0, -1.0, 1.0, 2.0, 4.63647609000806093515e-01,   2.26987774529616870924e-17,
+    1.0, -1.0, 1.0, 1.0, 7.85398163397448278999e-01,   3.06161699786838301793e-17,
+    1.0, -1.5, 1.5, 1.0, 9.82793723247329054082e-01,   1.39033110312309984516e-17,
+    0.0, -1.0, 1.0, 0.0, 1.57079632679489655800e+00,   6.12323399573676603587e-17,
+    0.0,  0.0 };
+// every wavefront writes the whole table itself (all write the same values): no barrier between the workgroup's wavefronts
+__device__ __forceinline__ void atan_tab_stage(double *tab /* LDS, ATAN_TAB_DOUBLES */)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < ATAN_TAB_DOUBLES) tab[lane] = k_atan_tab[lane];
+}
+
+// |atan2_fd(y, x)| (fcpp_geom.h) with fdiv for its one quotient and the table for its reduction: same intervals, same polynomial
+__device__ __forceinline__ double atan2_abs_dev(double y, double x, const double *tab)
 {
     const double a = fabs(y), b = fabs(x);
-    const bool c0 = a < 0.4375 * b, c1 = a < 0.6875 * b, c2 = a < 1.1875 * b, c3 = a < 2.4375 * b;
-    double num, den, hi, lo;
-    if (c0)      { num = a;            den = b;            hi = 0.0;                          lo = 0.0; }
-    else if (c1) { num = 2.0 * a - b;  den = 2.0 * b + a;  hi = 4.63647609000806093515e-01;   lo = 2.26987774529616870924e-17; }
-    else if (c2) { num = a - b;        den = a + b;        hi = 7.85398163397448278999e-01;   lo = 3.06161699786838301793e-17; }
-    else if (c3) { num = a - 1.5 * b;  den = b + 1.5 * a;  hi = 9.82793723247329054082e-01;   lo = 1.39033110312309984516e-17; }
-    else         { num = -b;           den = a;            hi = 1.57079632679489655800e+00;   lo = 6.12323399573676603587e-17; }
+    const int id = (int)!(a < 0.4375 * b) + (int)!(a < 0.6875 * b) + (int)!(a < 1.1875 * b) + (int)!(a < 2.4375 * b);
+    const double2 n = *reinterpret_cast<const double2 *>(tab + 6 * id), d = *reinterpret_cast<const double2 *>(tab + 6 * id + 2),
+                  hl = *reinterpret_cast<const double2 *>(tab + 6 * id + 4);
+    const double num = n.x * a + n.y * b, den = d.x * a + d.y * b;
     const double t = fdiv(num, den), z = t * t, w = z * z;
     const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
                                                   9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
     const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
                                         -1.11111104054623557880e-01), -1.99999999998764832476e-01);
-    double r = hi - ((t * (s1 + s2) - lo) - t);
+    double r = hl.x - ((t * (s1 + s2) - hl.y) - t);
     if (x < 0.0) r = 3.14159265358979311600e+00 - (r - 1.22464679914735317720e-16);
-    return y < 0.0 ? -r : r;
+    return r;
 }
 
-// the curvature clamp of clamped_speed with fdiv (k_plan_sparse)
+// the curvature clamp of clamped_speed with fdiv and fsqrt_pos (k_plan_sparse)
 __device__ __forceinline__ double clamped_speed_fast(double v_nom, double kappa, const DevConst &cst, bool &clamped)
 {
     clamped = false;
     if (kappa > 1e-6) {
         const double q = v_nom * cst.inv_sf36;
         if (kappa * q * q < cst.a_lat * (1.0 - 1e-9)) return v_nom;
-        const double vmax_ms = sqrt(fdiv(cst.a_lat, kappa)) * cst.sf;
+        const double vmax_ms = fsqrt_pos(fdiv(cst.a_lat, kappa)) * cst.sf;
         const double vmax_kmh = vmax_ms * 3.6;
         if (v_nom > vmax_kmh) { clamped = true; return vmax_kmh; }
     }
     return v_nom;
 }
 
-// ... and through atan2_fd alone (one point per lane: fcpp_sparse_fn.h).  At the reference's sampling every wavefront of that kernel
+// the curvature of curv_chords through atan2_fd alone (k_plan_sparse).  At the reference's sampling every wavefront of that kernel
 // holds junctions between primitives, whose turning angles are far beyond the short series of curv_chords_fast, so it paid for the
 // series AND for the atan2 fallback; atan2_fd's first interval (|cross| < 7/16 dot) is a series of the same length anyway.  Exactly
-// collinear chords still give exactly 0 (atan2_fd(0, dot > 0) = 0).
-__device__ __forceinline__ double curv_chords_atan(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2)
+// collinear chords still give exactly 0 (atan2_fd(0, dot > 0) = 0).  |2 atan2 / s| = 2 |atan2| / s: every step of fdiv is odd in its
+// numerator, so the sign of the angle is never formed.
+__device__ __forceinline__ double curv_chords_atan(double dx1, double dy1, double ds1, double dx2, double dy2, double ds2, const double *atab)
 {
     if (ds1 < 1e-6 || ds2 < 1e-6) return 0.0;
     const double cr = dx1 * dy2 - dy1 * dx2, dt = dx1 * dx2 + dy1 * dy2;
     if (cr == 0.0 && dt > 0.0) return 0.0;
-    return fabs(fdiv(2 * atan2_fd_dev(cr, dt), ds1 + ds2));
+    return fdiv(2 * atan2_abs_dev(cr, dt, atab), ds1 + ds2);
 }
 
 // wave-wide reductions; a ballot skips the butterfly when every lane holds the neutral element (most tiles have

@@ -5,6 +5,28 @@
 
 namespace fcpp {
 
+// Stores of the streaming kernel, 16 bytes per lane.  NT: non-temporal -- measured per kernel (one library per variant, fresh processes
+// in turn on one box): the span instance (KINDS 16) at the reference's sampling loses 15 % with it (headline 31.6 -> 36.4 us), the dense
+// instance (KINDS 14) neither gains nor loses (cfg2 at 0.1 m 5.62 vs 5.59 ms, cfg3 0.355 vs 0.358 ms): plain stores in both.
+#ifndef FCPP_DENSE_NT
+#define FCPP_DENSE_NT 0      // (1: a build for the A/B)
+#endif
+typedef double st_pair_f64 __attribute__((ext_vector_type(2)));
+typedef uint32_t st_pair_u32 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ void st2(double *ptr, double a, double b)
+{
+    st_pair_f64 v = { a, b };
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<st_pair_f64 *>(ptr));
+    else *reinterpret_cast<st_pair_f64 *>(ptr) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void st2(uint32_t *ptr, uint32_t a, uint32_t b)
+{
+    st_pair_u32 v = { a, b };
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<st_pair_u32 *>(ptr));
+    else *reinterpret_cast<st_pair_u32 *>(ptr) = v;
+}
 // ---- quiet runs (found by the host tiler): stretches of a straight primitive whose points, and everything within reach of
 // the sweeps, lie on that primitive.  Then kappa = 0, nobody is clamped and u = u_nominal everywhere: closed-form results, no
 // neighbours, no scan, no LDS.  The kernel is pure HBM streaming, so what matters is the shape of its stores: a run is cut into
@@ -12,17 +34,18 @@ namespace fcpp {
 // one ALIGNED KiB (16 bytes per lane) -- measured 15-25 % faster than the same bytes through tiles that start anywhere in a
 // cache line (tools/micro/stream_probe.hip), and far less sensitive to where the arrays happen to live in device memory.
 // aligned pair store of one lane: points (g, g + 1) of the batch arrays, g even
+template <bool NT>
 __device__ __forceinline__ void store_pair(bool has0, bool has1, int64_t g, double px0, double px1, double py0, double py1, double k0,
                                            double k1, double v, uint32_t f0, uint32_t f1, double *__restrict__ xo,
                                            double *__restrict__ yo, double *__restrict__ ko, double *__restrict__ vo,
                                            uint32_t *__restrict__ fso)
 {
     if (has0 && has1) {
-        *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
-        *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
-        *reinterpret_cast<double2 *>(ko + g) = make_double2(k0, k1);
-        *reinterpret_cast<double2 *>(vo + g) = make_double2(v, v);
-        *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
+        st2<NT>(xo + g, px0, px1);
+        st2<NT>(yo + g, py0, py1);
+        st2<NT>(ko + g, k0, k1);
+        st2<NT>(vo + g, v, v);
+        st2<NT>(fso + g, f0, f1);
     } else if (has0) {
         xo[g] = px0; yo[g] = py0; ko[g] = k0; vo[g] = v; fso[g] = f0;
     } else if (has1) {
@@ -76,6 +99,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
     // Aligned pairs: pair m covers the chunk-local points (2m - odd, 2m - odd + 1), whose global index is even whatever the
     // parity of the chunk's first global index (odd = 1: the chunk's first point is the second half of pair 0).
     const int odd = (int)(g0 & 1);
+    constexpr bool NT = FCPP_DENSE_NT && KINDS != 16;                         // non-temporal stores in the dense instance only (st2)
     const double ntol = -cst.geofence_tol;
     auto outside = [&](double px, double py) -> bool {
         bool out = false;
@@ -194,11 +218,11 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
             // (a pair may straddle a line / turn boundary: each point carries its own speed)
             const int64_t g = g0 + j;
             if (has0 && has1) {
-                *reinterpret_cast<double2 *>(xo + g) = make_double2(px0, px1);
-                *reinterpret_cast<double2 *>(yo + g) = make_double2(py0, py1);
-                *reinterpret_cast<double2 *>(ko + g) = make_double2(k0, k1);
-                *reinterpret_cast<double2 *>(vo + g) = make_double2(v0, v1);
-                *reinterpret_cast<uint2 *>(fso + g) = make_uint2(f0, f1);
+                st2<NT>(xo + g, px0, px1);
+                st2<NT>(yo + g, py0, py1);
+                st2<NT>(ko + g, k0, k1);
+                st2<NT>(vo + g, v0, v1);
+                st2<NT>(fso + g, f0, f1);
             } else if (has0) {
                 xo[g] = px0; yo[g] = py0; ko[g] = k0; vo[g] = v0; fso[g] = f0;
             } else if (has1) {
@@ -254,7 +278,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
                 f0 |= b0 ? FCPP_FLAG_OBSTACLE : 0u;
                 f1 |= b1 ? FCPP_FLAG_OBSTACLE : 0u;
             }
-            store_pair(has0, has1, g0 + j, px0, px1, py0, py1, k0, k1, cst.v_turn, f0, f1, xo, yo, ko, vo, fso);
+            store_pair<NT>(has0, has1, g0 + j, px0, px1, py0, py1, k0, k1, cst.v_turn, f0, f1, xo, yo, ko, vo, fso);
         }
     } else if (KINDS & 6) {
         double ax, ay, sx, sy, bx, by, vnom;      // numpy.linspace(a, b, n): sample k = k * step + a, the last one is b itself
@@ -319,7 +343,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
             }
             // chunk-local point 0 is the line's first point only in the run's first chunk (has_start)
             const double k0 = (has_start && j == 0) ? k_start : 0.0, k1 = (has_start && j + 1 == 0) ? k_start : 0.0;
-            store_pair(has0, has1, g0 + j, px0, px1, py0, py1, k0, k1, vnom, f0, f1, xo, yo, ko, vo, fso);
+            store_pair<NT>(has0, has1, g0 + j, px0, px1, py0, py1, k0, k1, vnom, f0, f1, xo, yo, ko, vo, fso);
         }
     }
     if (__ballot(nout | nobs)) {   // integer counts: the order of the additions does not matter

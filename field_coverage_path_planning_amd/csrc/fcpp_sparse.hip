@@ -32,14 +32,17 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
                                                                TilePartial *__restrict__ partial)
 {
     __shared__ double obs_lds[SP_WAVES][2 * OBS_LDS_VERTS];
+    __shared__ double atab[ATAN_TAB_DOUBLES];
+    __shared__ double plds[SP_WAVES][TILE_PRIMS_LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t slot = (int64_t)blockIdx.x * SP_WAVES + wave;
     if (slot >= n_wtiles) return;
+    atan_tab_stage(atab);
     const DevWaveTile wt = wtiles[ids ? (int64_t)ids[slot] : slot];      // (ids: the wave tiles of the fields k_plan_sparse_fields does not take)
     SparseAcc acc;
     acc.clear();
-    if (PTS == 2) sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
-    else sparse_tile(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
+    if (PTS == 2) sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], atab, plds[wave], xo, yo, ko, vo, fso, acc);
+    else sparse_tile(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], atab, plds[wave], xo, yo, ko, vo, fso, acc);
 
     // the tile's partial statistics: the three sums of a layer (and the three maxima) go through the wave together (wave4_to_hi),
     // groups in which every lane holds zero (the other layer, tiles without curvature) are skipped by a ballot
@@ -60,27 +63,37 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
     }
 }
 
-// One workgroup per FIELD (DevFieldWork): wavefront w plans the field's w-th wave tile (two points per lane), then wavefront 0 reduces
-// the field's statistics -- the tiles' partial results through LDS, the slots of the field's quiet runs (closed-form constants written at
-// batch creation + the flag counts k_plan_quiet has added in this step: this launch comes after the streaming kernels) from memory -- in
-// the order of the field's statistics entries, a fixed butterfly over 16 lanes.  No k_reduce_stats launch for such fields, no global
-// partial slots for their tiles, no cross-workgroup synchronisation: everything the reduction needs is the workgroup's own or final.
-__global__ __launch_bounds__(64 * FIELD_WORK_TILES) void k_plan_sparse_fields(const DevFieldWork *__restrict__ work, const DevWaveTile *__restrict__ wtiles,
-                                                                             const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
-                                                                             DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
-                                                                             double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
-                                                                             TilePartial *__restrict__ partial, const int64_t *__restrict__ stat_run,
-                                                                             fcpp_field_stats *__restrict__ stats)
+// One workgroup per FIELD (DevFieldWork): its W wavefronts walk the field's wave tiles (two points per lane; wavefront w the tiles w, w + W,
+// ...), then wavefront 0 reduces the field's statistics -- the tiles' partial results through LDS, the slots of the field's quiet runs
+// (closed-form constants written at batch creation + the flag counts k_plan_quiet has added in this step: this launch comes after the
+// streaming kernels) from memory -- in the order of the field's statistics entries, a fixed butterfly over 16 lanes.  No k_reduce_stats
+// launch for such fields, no global partial slots for their tiles, no cross-workgroup synchronisation: everything the reduction needs is
+// the workgroup's own or final.  W is chosen by the launcher so that all wavefronts of the launch are resident together where that is
+// possible (one round of the chip: no second round that starts in step and ends in a tail); a tile's result and the order of the
+// reduction do not depend on it.
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWork *__restrict__ work, const DevWaveTile *__restrict__ wtiles,
+                                                              const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
+                                                              DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
+                                                              double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                                              TilePartial *__restrict__ partial, const int64_t *__restrict__ stat_run,
+                                                              fcpp_field_stats *__restrict__ stats)
 {
-    __shared__ double obs_lds[FIELD_WORK_TILES][2 * OBS_LDS_VERTS];
+    __shared__ double obs_lds[W][2 * OBS_LDS_VERTS];
     __shared__ TilePartial red[FIELD_WORK_TILES];
+    __shared__ double atab[ATAN_TAB_DOUBLES];
+    __shared__ double plds[W][TILE_PRIMS_LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    atan_tab_stage(atab);
     const DevFieldWork w = work[blockIdx.x];
-    if (wave < w.n_tiles) {
-        const DevWaveTile wt = wtiles[w.w_first + wave];
+#ifdef FCPP_DIAG_SPARSE
+    if (g_sparse_stop == -2) return;
+#endif
+    auto plan_tile = [&](const int t) {
+        const DevWaveTile wt = wtiles[w.w_first + t];
         SparseAcc acc;
         acc.clear();
-        sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], xo, yo, ko, vo, fso, acc);
+        sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], atab, plds[wave], xo, yo, ko, vo, fso, acc);
         double g[3] = { 0.0, 0.0, 0.0 };
         const int out0 = wt.hb, out1 = wt.hb + wt.count;
         if (out0 < wt.rel_seam) g[0] = wave4_to_hi<0>(acc.s_len[0], acc.s_tpre[0], acc.s_t[0], 0.0);
@@ -88,12 +101,20 @@ __global__ __launch_bounds__(64 * FIELD_WORK_TILES) void k_plan_sparse_fields(co
         if (__ballot(acc.mk != 0.0 || acc.mj != 0.0) != 0ull) g[2] = wave4_to_hi<1>(acc.mk, acc.ma, acc.mj, 0.0);
         const int vs = WAVE4_SLOT(lane);
         if (lane >= 60 && vs < 3) {
-            double *tp = reinterpret_cast<double *>(&red[wave]);
+            double *tp = reinterpret_cast<double *>(&red[t]);
             tp[vs] = g[0]; tp[3 + vs] = g[1]; tp[6 + vs] = g[2];
         }
-        if (lane == 63) { red[wave].n_viol = acc.c_viol; red[wave].n_outside = acc.c_out; red[wave].n_in_obstacle = acc.c_obs; red[wave].n_adjusted = acc.c_adj; }
+        if (lane == 63) { red[t].n_viol = acc.c_viol; red[t].n_outside = acc.c_out; red[t].n_in_obstacle = acc.c_obs; red[t].n_adjusted = acc.c_adj; }
+    };
+    // (as a loop the compiler allots this kernel 104 vector registers instead of 71 -- four resident wavefronts per SIMD instead of
+    // seven -- so the one-tile-per-wavefront form, which needs none, is written without one)
+    if (W == FIELD_WORK_WAVES_MAX) { if (wave < w.n_tiles) plan_tile(wave); }
+    else {
+#pragma unroll 1
+        for (int t = wave; t < w.n_tiles; t += W) plan_tile(t);
     }
-    __syncthreads();
+    if (W > 1) __syncthreads();
+    else wave_sync();
     if (wave != 0) return;
     // entry e of the field = lane e: a quiet run (its slot in memory) or the field's next wave tile (its result in LDS)
     const bool valid = lane < w.n_entries;
@@ -142,8 +163,17 @@ int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldWork
                               uint32_t *fs, TilePartial *partial, const int64_t *stat_run, fcpp_field_stats *stats)
 {
     if (n_work <= 0) return 0;
-    FCPP_LAUNCH(k_plan_sparse_fields, dim3((unsigned)n_work), dim3(64 * FIELD_WORK_TILES), 0, st, work, wtiles, fields, prims, cst, obs, x, y, kappa, v, fs,
-                partial, stat_run, stats);
+    // wavefronts per field: four, one per wave tile (FCPP_FIELD_WORK_WAVES=1 or 2 under FCPP_TUNE=1, tools/ab_knob.py: fewer wavefronts
+    // that walk the field's tiles -- measured slower)
+    int wv = 4;
+    const int wv_k = tune_int("FCPP_FIELD_WORK_WAVES", 0);
+    if (wv_k == 1 || wv_k == 2 || wv_k == 4) wv = wv_k;
+#define FCPP_FW(W) FCPP_LAUNCH((k_plan_sparse_fields<W>), dim3((unsigned)n_work), dim3(64 * W), 0, st, work, wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, \
+                               partial, stat_run, stats)
+    if (wv == 4) FCPP_FW(4);
+    else if (wv == 2) FCPP_FW(2);
+    else FCPP_FW(1);
+#undef FCPP_FW
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -167,3 +197,23 @@ int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtil
 }
 
 }  // namespace fcpp
+
+#ifdef FCPP_DIAG_SPARSE
+// diagnostic build only: rows[0 .. n) x 16 = cycles per section of sparse_tile2 of the wave tiles planned since the last call (at most
+// `cap` rows are copied); returns the number of rows claimed, clears the counter
+extern "C" long long fcpp_diag_sparse(unsigned *rows, long long cap)
+{
+    unsigned n = 0, zero = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(fcpp::g_sparse_diag_next), sizeof n) != hipSuccess) return -1;
+    const long long m = n < (unsigned)fcpp::SP_DIAG_SLOTS ? n : fcpp::SP_DIAG_SLOTS;
+    const long long c = m < cap ? m : cap;
+    if (c > 0 && hipMemcpyFromSymbol(rows, HIP_SYMBOL(fcpp::g_sparse_diag), (size_t)c * 16 * sizeof(unsigned)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fcpp::g_sparse_diag_next), &zero, sizeof zero) != hipSuccess) return -1;
+    return n;
+}
+extern "C" int fcpp_diag_sparse_stop(int section)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(fcpp::g_sparse_stop), &section, sizeof section) == hipSuccess ? 0 : -1;
+}
+#endif

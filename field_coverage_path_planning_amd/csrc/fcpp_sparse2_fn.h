@@ -8,6 +8,36 @@
 
 namespace fcpp {
 
+// Diagnostic build only (-DFCPP_DIAG_SPARSE, never shipped; tools/diag_sparse.py): shader-clock cycles of every section of sparse_tile2,
+// summed over the wave tiles of all launches since the last read (fcpp_diag_sparse, fcpp_sparse.hip).
+#ifdef FCPP_DIAG_SPARSE
+static constexpr int SP_DIAG_SLOTS = 1 << 16;
+__device__ unsigned g_sparse_diag[SP_DIAG_SLOTS * 16];     // one row per wave tile (claimed through g_sparse_diag_next): cycles per section
+__device__ unsigned g_sparse_diag_next;
+__device__ int g_sparse_stop = 99;                         // leave sparse_tile2 after this section (instruction counts per section: rocprofv3 --pmc)
+template <class T> __device__ __forceinline__ void sp_pin(T &v) { asm volatile("" : "+v"(v)); }
+#define SP_STAMP_S(k, sval) do { int s_ = (int)(sval); asm volatile("" : "+s"(s_)); const unsigned long long t_now_ = __builtin_readcyclecounter(); \
+                                t_sec_[k] = (unsigned)(t_now_ - t_prev_) + (unsigned)(s_ & 0); t_prev_ = t_now_; } while (0)
+template <class T, class... R> __device__ __forceinline__ void sp_pin(T &v, R &...r) { sp_pin(v); sp_pin(r...); }
+// (the values a section produces go through an empty volatile asm, so the compiler can move their computation neither behind the
+// stamp nor, for what depends on them, before it)
+#define SP_STAMP(k, ...) do { sp_pin(__VA_ARGS__); const unsigned long long t_now_ = __builtin_readcyclecounter(); \
+                              t_sec_[k] = (unsigned)(t_now_ - t_prev_); t_prev_ = t_now_; \
+                              if (stop_ == k) return; } while (0)
+#define SP_STAMP_BEGIN() unsigned t_sec_[15] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; int stop_ = __builtin_amdgcn_readfirstlane(g_sparse_stop); asm volatile("" : "+s"(stop_)); \
+                         unsigned long long t_prev_ = __builtin_readcyclecounter(); t_sec_[13] = (unsigned)(t_prev_ >> 4)
+#define SP_STAMP_END() do { t_sec_[14] = (unsigned)(t_prev_ >> 4); unsigned row_ = 0; if ((threadIdx.x & 63) == 0) row_ = atomicAdd(&g_sparse_diag_next, 1u); \
+                            row_ = __builtin_amdgcn_readfirstlane(row_); \
+                            if ((threadIdx.x & 63) < 15 && row_ < SP_DIAG_SLOTS) { unsigned v_ = 0; \
+                                for (int k_ = 0; k_ < 15; ++k_) if ((int)(threadIdx.x & 63) == k_) v_ = t_sec_[k_]; \
+                                g_sparse_diag[row_ * 16 + (threadIdx.x & 63)] = v_; } } while (0)
+#else
+#define SP_STAMP(k, ...) do { } while (0)
+#define SP_STAMP_BEGIN() do { } while (0)
+#define SP_STAMP_S(k, sval) do { } while (0)
+#define SP_STAMP_END() do { } while (0)
+#endif
+
 // one of the lane's two points
 struct SparsePt {
     double px, py, vn, msn, d, kappa, v0, ms0, u0, u, w, vfin;
@@ -16,7 +46,7 @@ struct SparsePt {
 };
 
 // the point `rel` (index in the tile) of a lane: coordinates, flag word, nominal speed
-__device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst, int rel,
+__device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevField &f, const double *plds, const DevConst &cst, int rel,
                                               int nl, SparsePt &q)
 {
     q.act = rel < nl;
@@ -30,15 +60,15 @@ __device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevFi
     DevPrim p;
     double2 tc = make_double2(0.0, 0.0);
     if (in_l2) {
-        int pi = wt.p0;
+        int slot = 0;
         r = rel + wt.r0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int th = wt.thr[k];
-            if (rel >= th) { ++pi; r = rel - th; }
+            if (rel >= th) { ++slot; r = rel - th; }
         }
         tc = cst.tmpl_c[min(max(r, 0), cst.tmpl_nc - 1)];
-        p = prims[pi];
+        p = reinterpret_cast<const DevPrim *>(plds)[slot];
     }
     if (__ballot(q.act && in_main) != 0ull) {
         if (q.act && in_main) {
@@ -57,17 +87,30 @@ __device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevFi
     q.msn = div36(q.vn);
 }
 
-// obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles)
+// obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles); atab: the staged
+// table of atan2_abs_dev (atan_tab_stage); plds: TILE_PRIMS_LDS doubles of LDS owned by this wavefront (stage_tile_prims)
 __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
-                                             const DevObstacles &obs, double *obs_lds, double *__restrict__ xo, double *__restrict__ yo,
+                                             const DevObstacles &obs, double *obs_lds, const double *atab, double *plds, double *__restrict__ xo, double *__restrict__ yo,
                                              double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso, SparseAcc &acc)
 {
     const int lane = threadIdx.x & 63;
     const int nl = wt.hb + wt.count + wt.hf;                 // active points
     const int ra = 2 * lane, rb = 2 * lane + 1;
     SparsePt A, B;
-    sparse2_point(wt, f, prims, cst, ra, nl, A);
-    sparse2_point(wt, f, prims, cst, rb, nl, B);
+    SP_STAMP_BEGIN();
+#ifdef FCPP_DIAG_SPARSE
+    if (stop_ == -1) return;
+#endif
+    SP_STAMP_S(9, wt.hb);
+    SP_STAMP_S(10, f.n_line);
+    stage_tile_prims(wt, prims, plds, nl);
+    sparse2_point(wt, f, plds, cst, ra, nl, A);
+#ifdef FCPP_DIAG_SPARSE
+    sp_pin(A.px, A.py, A.vn, A.msn, A.fw);
+    if (stop_ == -3) return;
+#endif
+    sparse2_point(wt, f, plds, cst, rb, nl, B);
+    SP_STAMP(0, A.px, A.py, B.px, B.py, A.vn, B.vn, A.msn, B.msn, A.fw, B.fw);
 
     // ---- chords, curvature (MLP:513-536), clamp (MLP:490-504) ----------------------------------------------------------------------
     // a's predecessor is the previous lane's b, its successor the lane's own b; b's predecessor is a, its successor the next lane's a
@@ -75,14 +118,16 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     A.has_prev = A.act && lane > 0;
     B.has_prev = B.act;
     const double dxa = A.px - xm, dya = A.py - ym, dxb = B.px - A.px, dyb = B.py - A.py;
-    A.d = A.has_prev ? seg_len(dxa, dya) : 0.0;
-    B.d = B.has_prev ? seg_len(dxb, dyb) : 0.0;
+    A.d = A.has_prev ? seg_len_fast(dxa, dya) : 0.0;
+    B.d = B.has_prev ? seg_len_fast(dxb, dyb) : 0.0;
     const double dn_b = lane_next(A.d);                      // |next lane's a - b|
     A.interior = A.has_prev && ra < nl - 1 && !A.is_last;
     B.interior = B.has_prev && rb < nl - 1 && !B.is_last;
     A.kappa = B.kappa = 0.0;
-    if (A.interior) A.kappa = curv_chords_atan(dxa, dya, A.d, dxb, dyb, B.d);
-    if (B.interior) B.kappa = curv_chords_atan(dxb, dyb, B.d, xn - B.px, yn - B.py, dn_b);
+    SP_STAMP(1, A.d, B.d);
+    if (A.interior) A.kappa = curv_chords_atan(dxa, dya, A.d, dxb, dyb, B.d, atab);
+    if (B.interior) B.kappa = curv_chords_atan(dxb, dyb, B.d, xn - B.px, yn - B.py, dn_b, atab);
+    SP_STAMP(2, A.kappa, B.kappa);
     A.cl = B.cl = false;
     A.v0 = A.vn; B.v0 = B.vn;
     if (A.kappa > 1e-6) A.v0 = clamped_speed_fast(A.vn, A.kappa, cst, A.cl);
@@ -93,6 +138,7 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     B.u0 = B.act ? B.ms0 * B.ms0 : FCPP_INF;
 
     // ---- sweeps (MLP:538-589) as a relaxation over the tile's 128 points, two per lane ----------------------------------------------
+    SP_STAMP(3, A.u0, B.u0, A.v0, B.v0);
     constexpr int SWEEP_ROUNDS = 5;
     const double two_a = 2 * cst.a_lon;
     A.w = (!A.has_prev || A.d < 1e-6) ? FCPP_INF : two_a * A.d;        // coupling (previous lane's b, a)
@@ -133,15 +179,17 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
             A.u = fmin(fwd_a, bwd_a); B.u = fmin(fwd_b, bwd_b);
         }
     }
+    SP_STAMP(4, A.u, B.u);
     A.vfin = A.cl ? A.v0 : A.vn;
     B.vfin = B.cl ? B.v0 : B.vn;
     A.lowered = A.u < A.u0; B.lowered = B.u < B.u0;
     if (__ballot(A.lowered || B.lowered) != 0ull) {
-        A.vfin = A.lowered ? sqrt(A.u) * 3.6 : A.vfin;
-        B.vfin = B.lowered ? sqrt(B.u) * 3.6 : B.vfin;
+        A.vfin = A.lowered ? fsqrt_pos(A.u) * 3.6 : A.vfin;
+        B.vfin = B.lowered ? fsqrt_pos(B.u) * 3.6 : B.vfin;
     }
 
     // ---- validation flags --------------------------------------------------------------------------------------------------------------
+    SP_STAMP(5, A.vfin, B.vfin);
     bool a_out = false, b_out = false, a_obs = false, b_obs = false, a_viol = false, b_viol = false;
     if (!wt.inside) {
         const double ntol = -cst.geofence_tol;
@@ -175,6 +223,7 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     }
 
     // ---- metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) on the output points ------------------------------------------------
+    SP_STAMP(6, A.fw, B.fw);
     const double vprev_a = lane_prev(B.vfin), kprev_a = lane_prev(B.kappa), vnprev_a = lane_prev(B.vn);
     auto metrics = [&](const SparsePt &q, int rel, double vprev, double vnprev, double kprev, bool &viol, uint32_t &fw) {
         const bool seg = q.out && !q.is_first && !q.at_seam;
@@ -204,14 +253,43 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     metrics(B, rb, A.vfin, A.vn, A.kappa, b_viol, B.fw);
 
     // ---- stores: the lane's two points are neighbours in memory ----------------------------------------------------------------------------
+    SP_STAMP(7, acc.s_len[0], acc.s_len[1], acc.s_t[0], acc.s_t[1], acc.s_tpre[0], acc.s_tpre[1], acc.mk, acc.ma, acc.mj, A.fw, B.fw);
     const int64_t g = wt.out_base + ra;
-    if (A.out) { xo[g] = A.px; yo[g] = A.py; ko[g] = A.kappa; vo[g] = A.vfin; fso[g] = A.fw; }
-    if (B.out) { xo[g + 1] = B.px; yo[g + 1] = B.py; ko[g + 1] = B.kappa; vo[g + 1] = B.vfin; fso[g + 1] = B.fw; }
+#ifdef FCPP_DIAG_SPARSE
+    { unsigned long long px_ = (unsigned long long)xo, pf_ = (unsigned long long)fso; asm volatile("" : "+s"(px_), "+s"(pf_)); SP_STAMP_S(11, (int)(px_ ^ pf_)); }
+#endif
+    // (a lane whose two points are both outputs -- all but the one or two at the ends of the output range -- writes them as one 16-byte
+    // element per array: a store instruction then covers 1 KiB of consecutive bytes, every 64-byte line of it whole, instead of every
+    // other 8 bytes of it; the element is 8-byte aligned, which global memory instructions accept)
+    typedef double pair_f64 __attribute__((ext_vector_type(2), aligned(8)));
+    typedef uint32_t pair_u32 __attribute__((ext_vector_type(2), aligned(4)));
+    if (A.out && B.out) {
+        pair_f64 vx = { A.px, B.px }, vy = { A.py, B.py }, vk = { A.kappa, B.kappa }, vv = { A.vfin, B.vfin };
+        pair_u32 vf = { A.fw, B.fw };
+#ifndef FCPP_SPARSE_NT
+#define FCPP_SPARSE_NT 1     // (0: a build for the A/B)
+#endif
+        if (FCPP_SPARSE_NT) {
+            __builtin_nontemporal_store(vx, reinterpret_cast<pair_f64 *>(xo + g)); __builtin_nontemporal_store(vy, reinterpret_cast<pair_f64 *>(yo + g));
+            __builtin_nontemporal_store(vk, reinterpret_cast<pair_f64 *>(ko + g)); __builtin_nontemporal_store(vv, reinterpret_cast<pair_f64 *>(vo + g));
+            __builtin_nontemporal_store(vf, reinterpret_cast<pair_u32 *>(fso + g));
+        } else {
+            *reinterpret_cast<pair_f64 *>(xo + g) = vx; *reinterpret_cast<pair_f64 *>(yo + g) = vy;
+            *reinterpret_cast<pair_f64 *>(ko + g) = vk; *reinterpret_cast<pair_f64 *>(vo + g) = vv;
+            *reinterpret_cast<pair_u32 *>(fso + g) = vf;
+        }
+    } else {
+        if (A.out) { xo[g] = A.px; yo[g] = A.py; ko[g] = A.kappa; vo[g] = A.vfin; fso[g] = A.fw; }
+        if (B.out) { xo[g + 1] = B.px; yo[g + 1] = B.py; ko[g + 1] = B.kappa; vo[g + 1] = B.vfin; fso[g + 1] = B.fw; }
+    }
 
+    SP_STAMP_S(12, 0);
     acc.c_viol += __popcll(__ballot(a_viol)) + __popcll(__ballot(b_viol));
     acc.c_out += __popcll(__ballot(a_out)) + __popcll(__ballot(b_out));
     acc.c_obs += __popcll(__ballot(a_obs)) + __popcll(__ballot(b_obs));
     acc.c_adj += __popcll(__ballot(A.out && A.cl)) + __popcll(__ballot(B.out && B.cl));
+    SP_STAMP(8, acc.c_viol, acc.c_out, acc.c_obs, acc.c_adj);
+    SP_STAMP_END();
 }
 
 }  // namespace fcpp

@@ -16,9 +16,29 @@ struct SparseAcc {
     }
 };
 
-// obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles)
+// The (at most nine) primitive records of a wave tile, copied into the wavefront's own LDS by two coalesced loads: every lane then
+// reads its primitive's record from there.  (Read from global memory by every lane -- six 16-byte loads per point, 64 lanes asking
+// for the same few cache lines -- the records were 190 of a wavefront's 350 accesses to the vector cache, which was the busiest unit of
+// the kernel: TCP_TOTAL_CACHE_ACCESSES and TCP_PENDING_STALL_CYCLES, profiles/r03_sparse_mem_counters.txt.)
+static constexpr int TILE_PRIMS_MAX = 9, PRIM_DOUBLES = (int)(sizeof(DevPrim) / sizeof(double)), TILE_PRIMS_LDS = TILE_PRIMS_MAX * PRIM_DOUBLES + 1;
+static_assert(sizeof(DevPrim) % sizeof(double) == 0 && TILE_PRIMS_MAX * PRIM_DOUBLES <= 128, "two loads per lane stage a tile's primitives");
+__device__ __forceinline__ void stage_tile_prims(const DevWaveTile &wt, const DevPrim *__restrict__ prims, double *plds, int nl)
+{
+    if (wt.rel_main >= nl) return;                           // (wave-uniform) no point of layer 2 in this tile
+    int np = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) np += wt.thr[k] != 255 ? 1 : 0;
+    const double *src = reinterpret_cast<const double *>(prims + wt.p0);
+    const int lane = threadIdx.x & 63, nw = np * PRIM_DOUBLES;
+    if (lane < nw) plds[lane] = src[lane];
+    if (lane + 64 < nw) plds[lane + 64] = src[lane + 64];
+    wave_sync();
+}
+
+// obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles); atab: the staged
+// table of atan2_abs_dev (atan_tab_stage); plds: TILE_PRIMS_LDS doubles of LDS owned by this wavefront
 __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
-                                            const DevObstacles &obs, double *obs_lds, double *__restrict__ xo, double *__restrict__ yo,
+                                            const DevObstacles &obs, double *obs_lds, const double *atab, double *plds, double *__restrict__ xo, double *__restrict__ yo,
                                             double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso, SparseAcc &acc)
 {
     const int lane = threadIdx.x & 63;
@@ -45,16 +65,17 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     int r = 0;
     DevPrim p;
     double2 tc = make_double2(0.0, 0.0);
+    stage_tile_prims(wt, prims, plds, nl);
     if (in_l2) {
-        int pi = wt.p0;
+        int slot = 0;
         r = lane + wt.r0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int th = wt.thr[k];
-            if (lane >= th) { ++pi; r = lane - th; }
+            if (lane >= th) { ++slot; r = lane - th; }
         }
         tc = cst.tmpl_c[min(max(r, 0), cst.tmpl_nc - 1)];
-        p = prims[pi];
+        p = reinterpret_cast<const DevPrim *>(plds)[slot];
     }
     if (__ballot(act && in_main) != 0ull) {                  // (wave-uniform) layer 1: (pass, offset) from the host's decode of lane 0
         if (act && in_main) {
@@ -78,11 +99,11 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     const double xm = lane_prev(px), ym = lane_prev(py), xp = lane_next(px), yp = lane_next(py);
     const bool has_prev = act && lane > 0;                                    // (lane > 0 => not the path's first point)
     const double dx1 = px - xm, dy1 = py - ym;
-    const double dprev = has_prev ? seg_len(dx1, dy1) : 0.0;                 // |p_i - p_(i-1)|
+    const double dprev = has_prev ? seg_len_fast(dx1, dy1) : 0.0;                 // |p_i - p_(i-1)|
     const double dnext = lane_next(dprev);
     const bool interior = has_prev && lane < nl - 1 && !is_last;             // both neighbours are lanes of this wave
     double kappa = 0.0;
-    if (interior) kappa = curv_chords_atan(dx1, dy1, dprev, xp - px, yp - py, dnext);
+    if (interior) kappa = curv_chords_atan(dx1, dy1, dprev, xp - px, yp - py, dnext, atab);
     bool cl = false;
     double v0 = vn;
     if (kappa > 1e-6) v0 = clamped_speed_fast(vn, kappa, cst, cl);
@@ -128,7 +149,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     // untouched points keep exactly their clamped / nominal value; the square root only in waves where a sweep lowered somebody
     double vfin = cl ? v0 : vn;
     const bool lowered = u < u0;
-    if (__ballot(lowered) != 0ull) vfin = lowered ? sqrt(u) * 3.6 : vfin;
+    if (__ballot(lowered) != 0ull) vfin = lowered ? fsqrt_pos(u) * 3.6 : vfin;
 
     // ---- 4. validation flags ------------------------------------------------------------------------------------------------------
     bool o_out = false, o_obs = false, o_viol = false;

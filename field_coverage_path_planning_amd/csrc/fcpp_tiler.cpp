@@ -25,7 +25,7 @@ struct BlockTiles {
     std::vector<int32_t> open_wave;              // wave tiles (block-relative indices) of all other fields
     int64_t tile0[PLAN_BLOCK_FIELDS + 1], w0[PLAN_BLOCK_FIELDS + 1];      // a field's records: [tile0[k], tile0[k + 1]) ...
     int64_t stat_cnt[PLAN_BLOCK_FIELDS];         // statistic entries per field
-    int64_t n_runs = 0, quiet_points = 0, wave_points = 0, span_points = 0, chunk_points = 0, wave_inside = 0;
+    int64_t n_runs = 0, quiet_points = 0, wave_points = 0, work_wave_points = 0, span_points = 0, chunk_points = 0, wave_inside = 0;
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };
     // bases in the merged tables
     int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, chunk_base = 0, span_base = 0, cls_base[4] = { 0, 0, 0, 0 }, work_base = 0, open_base = 0;
@@ -404,19 +404,19 @@ struct FieldTiler {
         }
         const int64_t ne = (int64_t)(out.stat_ids.size() - stat_mark);
         out.stat_cnt[k_local] = ne;
-        // A field whose general points are all in (two-point) wave tiles that fill one workgroup (three or four tiles: a workgroup's
-        // idle wavefronts wait at its barrier, so fewer would waste the chip; fields of the reference's size have four):
+        // A field whose general points are all in a few (two-point) wave tiles (fields of the reference's size have four):
         // k_plan_sparse_fields plans the tiles and reduces the field (DevFieldWork).  All others: their wave tiles go to k_plan_sparse's list, the field to a class of
         // k_reduce_stats by the number of entries of its path (a property of the field alone; 8 lanes, a wavefront, a workgroup,
         // 64 workgroups per path: at most 8 / 4 / 4 entries per lane in the first three)
         const int64_t nw = out.w0[k_local + 1] - out.w0[k_local];
         bool general = false;
         for (int64_t i = t0; i < t1 && !general; ++i) general = T[(size_t)i].quiet == 0;
-        if (tc.field_work && tc.wave_points == 128 && !general && nw >= FIELD_WORK_TILES - 1 && nw <= FIELD_WORK_TILES && ne <= FIELD_WORK_ENTRIES) {
+        if (tc.field_work && tc.wave_points == 128 && !general && nw >= 1 && nw <= std::min(tc.field_work_tiles, FIELD_WORK_TILES) && ne <= FIELD_WORK_ENTRIES) {
             DevFieldWork w;
             memset(&w, 0, sizeof w);
             w.field = (int32_t)field; w.n_tiles = (int32_t)nw; w.w_first = (int32_t)out.w0[k_local]; w.e_first = (int32_t)stat_mark; w.n_entries = (int32_t)ne;
             out.work.push_back(w);
+            for (int64_t k = out.w0[k_local]; k < out.w0[k_local + 1]; ++k) out.work_wave_points += out.wtiles[(size_t)k].count;
         } else {
             for (int64_t k = out.w0[k_local]; k < out.w0[k_local + 1]; ++k) out.open_wave.push_back((int32_t)k);
             out.cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= tc.reduce_wg_max ? 2 : 3))].push_back((int32_t)field);
@@ -502,7 +502,7 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
         for (int c = 0; c < 4; ++c) { bt.cls_base[c] = lay.n_red[c]; lay.n_red[c] += (int64_t)bt.cls[c].size(); }
         bt.work_base = lay.n_field_work; bt.open_base = lay.n_open_wave;
         lay.n_field_work += (int64_t)bt.work.size(); lay.n_open_wave += (int64_t)bt.open_wave.size();
-        lay.n_runs += bt.n_runs; lay.quiet_points += bt.quiet_points; lay.wave_points += bt.wave_points;
+        lay.n_runs += bt.n_runs; lay.quiet_points += bt.quiet_points; lay.wave_points += bt.wave_points; lay.work_wave_points += bt.work_wave_points;
         lay.span_points += bt.span_points; lay.chunk_points += bt.chunk_points; lay.wave_inside += bt.wave_inside;
         for (int k = 0; k < 5; ++k) lay.wave_fail[k] += bt.wave_fail[k];
     }

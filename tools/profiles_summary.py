@@ -14,7 +14,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(REPO, 'gpurun_out', 'prof_r03')
 DST = os.path.join(REPO, 'profiles')
-STAGE_PREFIX = (('k_plan_quiet<16', 'k_plan_quiet_spans'), ('k_plan_quiet<14', 'k_plan_quiet'), ('k_plan_sparse', 'k_plan_sparse'),
+STAGE_PREFIX = (('k_plan_quiet<16', 'k_plan_quiet_spans'), ('k_plan_quiet<14', 'k_plan_quiet'), ('k_plan_sparse_fields', 'k_plan_sparse_fields'), ('k_plan_sparse', 'k_plan_sparse'),
                 ('k_plan_fused<', 'k_plan_fused'), ('k_reduce_stats', 'k_reduce_stats'))
 
 
