@@ -182,6 +182,7 @@ struct FusedTables {
     int64_t *obs_off = nullptr; double *obs_x = nullptr, *obs_y = nullptr, *obs_bbox = nullptr;
     double *seg = nullptr; int32_t *seg_mask = nullptr;
     TilePartial *partial = nullptr; char *red_scratch = nullptr; double2 *field_junc = nullptr;
+    TilePartial *work_totals = nullptr;
 };
 
 struct fcpp_batch {
@@ -594,6 +595,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         t.seg = reinterpret_cast<double *>(d + lay.seg); t.seg_mask = reinterpret_cast<int32_t *>(d + lay.seg_mask);
         t.partial = reinterpret_cast<TilePartial *>(d + lay.partial); t.red_scratch = d ? reinterpret_cast<char *>(d + lay.red_scratch) : nullptr;
         t.field_junc = reinterpret_cast<double2 *>(d + lay.field_junc);
+        t.work_totals = reinterpret_cast<TilePartial *>(d + lay.work_totals);
     }
     // (the primitives live in the image now; the host keeps the per-field records for fcpp_batch_info and the staged pipeline's tiling)
     for (PlanBlock &blk : b->hp.blocks) std::vector<DevPrim>().swap(blk.prims);
@@ -609,6 +611,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         LAUNCHCHK(launch_field_junctions(st, n_fields, b->t.fields, b->cst, b->t.field_junc));
         // the statistics slots: closed-form statistics of the quiet runs (the same at every step), zeros elsewhere
         LAUNCHCHK(launch_run_consts(st, lay.n_stat, b->t.stat_ids, b->t.stat_run, b->t.tiles, b->t.fields, b->t.prims, b->cst, b->t.partial));
+        LAUNCHCHK(launch_work_totals(st, lay.n_field_work, b->t.field_work, b->t.stat_run, b->t.partial, b->t.work_totals));
     }
     HIPCHK(hipStreamSynchronize(st));
     tm.h2d_ms = ms_since(t0);
@@ -706,7 +709,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         STAGE(1, launch_plan_quiet(st, lay.n_chunks, t.chunks, 14, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
         // fields planned and reduced by one workgroup each: after the streaming kernels, whose flag counts their reduction reads
         if (fw) STAGE(5, launch_plan_sparse_fields(st, lay.n_field_work, t.field_work, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
-                                                   t.stat_run, stats));
+                                                   t.stat_run, t.work_totals, stats));
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
         // (four classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
         // time the first launch)

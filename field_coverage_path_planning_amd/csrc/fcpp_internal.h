@@ -108,7 +108,7 @@ static_assert(sizeof(DevWaveTile) == 64, "DevWaveTile is fetched as one 64-byte 
 // statistics itself: its tiles' partial results through LDS, the slots of its quiet runs from memory, so such fields need no
 // k_reduce_stats launch.  (Measured with eight-wave workgroups, a wavefront per tile: the idle wavefronts of a half-empty workgroup hold
 // their slots until its barrier -- headline 60 instead of 35 us.)
-constexpr int FIELD_WORK_TILES = 8, FIELD_WORK_ENTRIES = 16, FIELD_WORK_WAVES_MAX = 4;
+constexpr int FIELD_WORK_TILES = 4, FIELD_WORK_ENTRIES = 16, FIELD_WORK_WAVES_MAX = 4;
 struct DevFieldWork {
     int32_t field;
     int32_t n_tiles;         // wave tiles wtiles[w_first .. w_first + n_tiles)

@@ -311,6 +311,14 @@ __device__ __forceinline__ double seg_len_fast(double dx, double dy)      // seg
     return (dy == 0.0) ? fabs(dx) : ((dx == 0.0) ? fabs(dy) : fsqrt_pos(dx * dx + dy * dy));
 }
 
+// a * b + k, k a compile-time constant that the scalar unit puts into a scalar register pair (one scalar operand per vector instruction)
+__device__ __forceinline__ double fma_sk(double a, double b, double k)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+}
+
 // atan2_fd's (fcpp_geom.h) five reduction intervals as a table of six doubles each: t = num / den with num = na a + nb b and
 // den = da a + db b, then hi, lo.  The products by 0, 1, 2 are exact and 1.5 x rounds as in atan2_fd, so num and den are the values
 // its expressions give; one lookup by the interval's number replaces four selects each of num, den, hi and lo.
@@ -338,10 +346,12 @@ __device__ __forceinline__ double atan2_abs_dev(double y, double x, const double
                   hl = *reinterpret_cast<const double2 *>(tab + 6 * id + 4);
     const double num = n.x * a + n.y * b, den = d.x * a + d.y * b;
     const double t = fdiv(num, den), z = t * t, w = z * z;
-    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
-                                                  9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
-    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
-                                        -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+    // (Horner steps with the coefficient as the addend from SCALAR registers: the compiler's v_fmac form wants it in the destination, i.e.
+    // two vector moves per 64-bit literal -- 18 of the 95 instructions of one curvature)
+    const double s1 = z * fma_sk(w, fma_sk(w, fma_sk(w, fma_sk(w, fma_sk(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                                                          9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
+    const double s2 = w * fma_sk(w, fma_sk(w, fma_sk(w, fma_sk(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                                                -1.11111104054623557880e-01), -1.99999999998764832476e-01);
     double r = hl.x - ((t * (s1 + s2) - hl.y) - t);
     if (x < 0.0) r = 3.14159265358979311600e+00 - (r - 1.22464679914735317720e-16);
     return r;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWor
                                                               const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
                                                               DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
                                                               double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
-                                                              TilePartial *__restrict__ partial, const int64_t *__restrict__ stat_run,
+                                                              TilePartial *__restrict__ partial, const TilePartial *__restrict__ totals,
                                                               fcpp_field_stats *__restrict__ stats)
 {
     __shared__ double obs_lds[W][2 * OBS_LDS_VERTS];
@@ -113,63 +113,90 @@ __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWor
 #pragma unroll 1
         for (int t = wave; t < w.n_tiles; t += W) plan_tile(t);
     }
-    if (W > 1) __syncthreads();
+#ifdef FCPP_DIAG_SPARSE
+    if (g_sparse_stop == -4 || g_sparse_stop == -5) return;      // (-5: nothing but the tile's section -1 before it)
+#endif
+    // What the reduction needs from memory is asked for BEFORE the barrier and arrives while the other wavefronts finish their tiles:
+    // lane v < 13 the v-th of the thirteen 8-byte components of the field's run totals (k_work_totals: the closed-form statistics of
+    // its quiet runs, the same at every step), lane e < n_entries the two flag counts k_plan_quiet has added to entry e's slot in this
+    // step (this launch comes after the streaming kernels; the slot of an entry that is a wave tile is never written: zeros).
+    static_assert(sizeof(TilePartial) == 13 * 8 && sizeof(fcpp_field_stats) == 13 * 8, "statistics records are thirteen 8-byte components");
+    unsigned long long run_v = 0, c_out = 0, c_obs = 0;
+    if (wave == 0) {
+        if (lane < 13) run_v = reinterpret_cast<const unsigned long long *>(&totals[blockIdx.x])[lane];
+        if (lane < w.n_entries) { const TilePartial &slot = partial[w.e_first + lane]; c_out = (unsigned long long)slot.n_outside; c_obs = (unsigned long long)slot.n_in_obstacle; }
+    }
+    // (the barrier orders the tiles' results in LDS only: no wait for the loads above or for the tiles' stores)
+    if (W > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else wave_sync();
     if (wave != 0) return;
-    // entry e of the field = lane e: a quiet run (its slot in memory) or the field's next wave tile (its result in LDS)
-    const bool valid = lane < w.n_entries;
-    const int64_t rc = valid ? stat_run[w.e_first + lane] : 1;
-    const bool is_tile = valid && rc == 0;
-    const unsigned long long tiles_before = __ballot(is_tile) & ((1ull << lane) - 1ull);
-    double a[9];
-    long long b[4];
+    if (__ballot((c_out | c_obs) != 0ull) != 0ull) {             // (rare) points of the field's runs were flagged in this step
+        if ((c_out | c_obs) != 0ull) { partial[w.e_first + lane].n_outside = 0; partial[w.e_first + lane].n_in_obstacle = 0; }   // collected anew in the next step
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) b[k] = 0;
-    if (valid) {
-        TilePartial tp;
-        if (is_tile) tp = red[__popcll(tiles_before)];
-        else {
-            TilePartial &slot = partial[w.e_first + lane];
-            tp = slot;
-            if (tp.n_outside | tp.n_in_obstacle) { slot.n_outside = 0; slot.n_in_obstacle = 0; }       // (collected anew in the next step)
+        for (int o = FIELD_WORK_ENTRIES / 2; o > 0; o >>= 1) { c_out += __shfl_xor(c_out, o); c_obs += __shfl_xor(c_obs, o); }
+    }
+    if (lane >= 13) return;
+    // component v = the runs' total, then the tiles' results in tile order: sums (0-5), maxima (6-8), counts (9-12)
+    const unsigned long long *rv = reinterpret_cast<const unsigned long long *>(red) + lane;
+    unsigned long long bits;
+    if (lane < 9) {
+        double a = __longlong_as_double((long long)run_v);
+        for (int t = 0; t < w.n_tiles; ++t) {
+            const double x = __longlong_as_double((long long)rv[13 * t]);
+            a = lane < 6 ? a + x : max_raw(a, x);
         }
-        a[0] = tp.main_len; a[1] = tp.main_time_pre; a[2] = tp.main_time; a[3] = tp.head_len; a[4] = tp.head_time_pre; a[5] = tp.head_time;
-        a[6] = tp.max_kappa; a[7] = tp.max_alat; a[8] = tp.max_jump;
-        b[0] = tp.n_viol; b[1] = tp.n_outside; b[2] = tp.n_in_obstacle; b[3] = tp.n_adjusted;
+        bits = (unsigned long long)__double_as_longlong(a);
+    } else {
+        bits = run_v;
+        for (int t = 0; t < w.n_tiles; ++t) bits += rv[13 * t];
+        if (lane == 10) bits += c_out;
+        if (lane == 11) bits += c_obs;
     }
-#pragma unroll
-    for (int o = FIELD_WORK_ENTRIES / 2; o > 0; o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] += __shfl_xor(a[k], o);
-#pragma unroll
-        for (int k = 6; k < 9; ++k) a[k] = fmax(a[k], __shfl_xor(a[k], o));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) b[k] += __shfl_xor(b[k], o);
+    reinterpret_cast<unsigned long long *>(&stats[w.field])[lane] = bits;
+}
+
+// Batch creation: per field of field_work, the closed-form statistics of its quiet runs (their slots, k_run_consts) summed in the order of
+// the field's entries -- the same at every step, so k_plan_sparse_fields adds its tiles' results to ONE record instead of walking the slots
+__global__ void k_work_totals(int64_t n_work, const DevFieldWork *__restrict__ work, const int64_t *__restrict__ stat_run,
+                              const TilePartial *__restrict__ partial, TilePartial *__restrict__ totals)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_work) return;
+    const DevFieldWork w = work[i];
+    TilePartial t;
+    memset(&t, 0, sizeof t);
+    for (int e = 0; e < w.n_entries; ++e) {
+        if (stat_run[w.e_first + e] == 0) continue;          // a wave tile
+        const TilePartial p = partial[w.e_first + e];
+        t.main_len += p.main_len; t.main_time_pre += p.main_time_pre; t.main_time += p.main_time;
+        t.head_len += p.head_len; t.head_time_pre += p.head_time_pre; t.head_time += p.head_time;
+        t.max_kappa = fmax(t.max_kappa, p.max_kappa); t.max_alat = fmax(t.max_alat, p.max_alat); t.max_jump = fmax(t.max_jump, p.max_jump);
+        t.n_viol += p.n_viol; t.n_adjusted += p.n_adjusted;
     }
-    if (lane == 0) {
-        fcpp_field_stats o;
-        o.main_len_m = a[0]; o.main_time_pre_s = a[1]; o.main_time_s = a[2];
-        o.head_len_m = a[3]; o.head_time_pre_s = a[4]; o.head_time_s = a[5];
-        o.max_kappa = a[6]; o.max_alat = a[7]; o.max_jump = a[8];
-        o.n_viol = b[0]; o.n_outside = b[1]; o.n_in_obstacle = b[2]; o.n_adjusted = b[3];
-        stats[w.field] = o;
-    }
+    totals[i] = t;
+}
+
+int launch_work_totals(hipStream_t st, int64_t n_work, const DevFieldWork *work, const int64_t *stat_run, const TilePartial *partial, TilePartial *totals)
+{
+    if (n_work <= 0) return 0;
+    hipLaunchKernelGGL(k_work_totals, dim3((unsigned)((n_work + 255) / 256)), dim3(256), 0, st, n_work, work, stat_run, partial, totals);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldWork *work, const DevWaveTile *wtiles, const DevField *fields,
                               const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
-                              uint32_t *fs, TilePartial *partial, const int64_t *stat_run, fcpp_field_stats *stats)
+                              uint32_t *fs, TilePartial *partial, const int64_t *stat_run, const TilePartial *totals, fcpp_field_stats *stats)
 {
     if (n_work <= 0) return 0;
+    (void)stat_run;
     // wavefronts per field: four, one per wave tile (FCPP_FIELD_WORK_WAVES=1 or 2 under FCPP_TUNE=1, tools/ab_knob.py: fewer wavefronts
     // that walk the field's tiles -- measured slower)
     int wv = 4;
     const int wv_k = tune_int("FCPP_FIELD_WORK_WAVES", 0);
     if (wv_k == 1 || wv_k == 2 || wv_k == 4) wv = wv_k;
 #define FCPP_FW(W) FCPP_LAUNCH((k_plan_sparse_fields<W>), dim3((unsigned)n_work), dim3(64 * W), 0, st, work, wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, \
-                               partial, stat_run, stats)
+                               partial, totals, stats)
     if (wv == 4) FCPP_FW(4);
     else if (wv == 2) FCPP_FW(2);
     else FCPP_FW(1);

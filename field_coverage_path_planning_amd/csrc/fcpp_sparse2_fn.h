@@ -99,7 +99,7 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     SparsePt A, B;
     SP_STAMP_BEGIN();
 #ifdef FCPP_DIAG_SPARSE
-    if (stop_ == -1) return;
+    if (stop_ == -1 || stop_ == -5) return;
 #endif
     SP_STAMP_S(9, wt.hb);
     SP_STAMP_S(10, f.n_line);
@@ -225,6 +225,9 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     // ---- metrics (MLP:1290-1311) and a_lat validation (MLP:1383-1408) on the output points ------------------------------------------------
     SP_STAMP(6, A.fw, B.fw);
     const double vprev_a = lane_prev(B.vfin), kprev_a = lane_prev(B.kappa), vnprev_a = lane_prev(B.vn);
+    // (all but the one tile of a field that holds the seam between the layers have their output points in ONE layer: three sums per
+    // lane -- slot 0, handed to the tile's layer below -- instead of six with two selects each)
+    const bool mixed = wt.rel_seam > wt.hb && wt.rel_seam < wt.hb + wt.count;
     auto metrics = [&](const SparsePt &q, int rel, double vprev, double vnprev, double kprev, bool &viol, uint32_t &fw) {
         const bool seg = q.out && !q.is_first && !q.at_seam;
         const bool l0 = rel < wt.rel_seam;
@@ -237,8 +240,10 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
         t = tpre;
         if (__ballot(changed) != 0ull) t = changed ? fdiv(q.d, fmax(div36((vprev + q.vfin) / 2), 0.1)) : tpre;
         const double len = seg ? q.d : 0.0;
-        acc.s_len[0] += l0 ? len : 0.0; acc.s_tpre[0] += l0 ? tpre : 0.0; acc.s_t[0] += l0 ? t : 0.0;
-        acc.s_len[1] += l0 ? 0.0 : len; acc.s_tpre[1] += l0 ? 0.0 : tpre; acc.s_t[1] += l0 ? 0.0 : t;
+        if (mixed) {
+            acc.s_len[0] += l0 ? len : 0.0; acc.s_tpre[0] += l0 ? tpre : 0.0; acc.s_t[0] += l0 ? t : 0.0;
+            acc.s_len[1] += l0 ? 0.0 : len; acc.s_tpre[1] += l0 ? 0.0 : tpre; acc.s_t[1] += l0 ? 0.0 : t;
+        } else { acc.s_len[0] += len; acc.s_tpre[0] += tpre; acc.s_t[0] += t; }
         if (q.out && !q.is_first && !q.is_last) {
             if (q.kappa > 0.0) {
                 const double ms = q.lowered ? div36(q.vfin) : q.ms0, alat = ms * ms * q.kappa;
@@ -251,6 +256,10 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     // (a first, then b: the per-lane accumulators add a's terms before b's; the order of the additions is fixed by the tile alone)
     metrics(A, ra, vprev_a, vnprev_a, kprev_a, a_viol, A.fw);
     metrics(B, rb, A.vfin, A.vn, A.kappa, b_viol, B.fw);
+    if (!mixed && wt.rel_seam <= wt.hb) {        // (the tile lies in layer 2: the sums collected in slot 0 are its)
+        acc.s_len[1] = acc.s_len[0]; acc.s_tpre[1] = acc.s_tpre[0]; acc.s_t[1] = acc.s_t[0];
+        acc.s_len[0] = 0.0; acc.s_tpre[0] = 0.0; acc.s_t[0] = 0.0;
+    }
 
     // ---- stores: the lane's two points are neighbours in memory ----------------------------------------------------------------------------
     SP_STAMP(7, acc.s_len[0], acc.s_len[1], acc.s_t[0], acc.s_t[1], acc.s_tpre[0], acc.s_tpre[1], acc.mk, acc.ma, acc.mj, A.fw, B.fw);

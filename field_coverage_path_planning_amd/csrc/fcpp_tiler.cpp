@@ -534,6 +534,7 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
     take(lay.partial, (size_t)lay.n_stat * sizeof(TilePartial));      // one slot per statistics entry
     take(lay.red_scratch, (size_t)lay.n_red[3] * 64 * 104);
     take(lay.field_junc, (size_t)n * 2 * sizeof(double));
+    take(lay.work_totals, (size_t)lay.n_field_work * sizeof(TilePartial));   // per field of field_work: the statistics of its quiet runs, summed once
     lay.total_bytes = o;
     return FCPP_OK;
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic only (-DFCPP_DIAG_SPARSE build): the headline batch with sparse_tile2 cut off at the kernel's start (-2), before the first point (-1), after the lanes' first point (-3), after section 0, 1, ... 8, and complete, three steps
+"""Diagnostic only (-DFCPP_DIAG_SPARSE build): the headline batch with sparse_tile2 cut off at the kernel's start (-2), before the first point (-1; -5: and without the field's reduction; -4: complete tiles without the field's reduction), after the lanes' first point (-3), after section 0, 1, ... 8, and complete, three steps
 each, in this order -- under `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES` the differences between consecutive groups of
 dispatches of k_plan_sparse_fields are the instructions of each section.  Results of the cut-off runs are not valid plans."""
 import ctypes
@@ -19,7 +19,7 @@ lib.fcpp_diag_sparse_stop.restype = ctypes.c_int
 torch.cuda.set_stream(torch.cuda.Stream())
 b = E.Batch(table, E.make_vehicle(), E.make_options())
 bufs = b.alloc()
-for stop in [-2, -1, -3] + list(range(9)) + [99]:
+for stop in [-2, -5, -1, -4, -3] + list(range(9)) + [99]:
     torch.cuda.synchronize()
     assert lib.fcpp_diag_sparse_stop(stop) == 0
     for _ in range(3):
