@@ -855,9 +855,11 @@ int launch_plan_quiet(hipStream_t st, int64_t n_chunks, const DevTile *chunks, i
     // CU): measured on identical memory (tools/ab_knob.py) cfg5 1.33 vs 1.44 ms at 5-7 waves and 1.59 ms at 3; the other
     // configurations do not care (+-1 %) -- except launches of a few rounds of workgroups, where FIVE per SIMD (27 KiB) end a round
     // earlier: the headline's 3530 workgroups 31.9 vs 33.2 us, step 0.0819 vs 0.0837 ms; cfg2 at the reference's sampling, 2064
-    // workgroups, the same either way.  FCPP_SPAN_LDS / FCPP_QUIET_PAD: bytes, for that tool.
+    // workgroups, the same either way -- until round 3 put this kernel first in the step: since then four per SIMD are the faster choice
+    // there too (headline 31.2 vs 31.8 us, step 0.0679 vs 0.0685 ms; cfg2 at the reference's sampling 23.4 vs 23.6 us).
+    // FCPP_SPAN_LDS / FCPP_QUIET_PAD: bytes, for that tool.
     const int static_lds = (has_obs ? wpb * 2 * OBS_LDS_VERTS * 8 : 32) + (kinds == 16 && staged ? wpb * 3 * TMPL_LDS * 8 : 32);
-    const int span_lds = (n_chunks < 65536 ? 27 * 1024 : 34 * 1024) * wpb / 4;
+    const int span_lds = 34 * 1024 * wpb / 4;
     const int pad = std::min(64 * 1024, kinds == 16 ? std::max(0, tune_int("FCPP_SPAN_LDS", span_lds) - static_lds) : std::max(0, tune_int("FCPP_QUIET_PAD", 0)));
 #define FCPP_QUIET(K, SD, TL, OB) do { if (wpb == 8) FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB, 8>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks); \
                                        else FCPP_LAUNCH((k_plan_quiet<K, SD, TL, OB, 4>), grid, block, pad, st, chunks, fields, prims, cst, obs, x, y, kappa, v, fs, partial, n_chunks); } while (0)
