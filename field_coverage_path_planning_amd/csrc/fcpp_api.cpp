@@ -535,10 +535,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tc.reduce_wg_max = std::max(256, std::min(tune_int("FCPP_REDUCE_WG_MAX", 1024), 1 << 20));
     tc.wave_points = tune_int("FCPP_WAVE_POINTS", 128) == 64 ? 64 : 128;
     tc.field_work = tune_int("FCPP_FIELD_WORK", 1) != 0;
-    {   // (more than one tile per wavefront only with the loop forms of the kernel: FCPP_FIELD_WORK_WAVES=1 or 2, tuning runs)
-        const int wv = tune_int("FCPP_FIELD_WORK_WAVES", FIELD_WORK_WAVES_MAX);
-        tc.field_work_tiles = std::max(1, std::min(tune_int("FCPP_FIELD_WORK_TILES", FIELD_WORK_WAVES_MAX), (wv == 1 || wv == 2) ? FIELD_WORK_TILES : FIELD_WORK_WAVES_MAX));
-    }
+    tc.field_work_tiles = std::max(1, std::min(tune_int("FCPP_FIELD_WORK_TILES", FIELD_WORK_TILES), FIELD_WORK_TILES));
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);
@@ -708,8 +705,19 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
         // (straights and U-turns in ONE launch: measured 4 % faster on identical memory than an instance each, tools/ab_quiet.py)
         STAGE(1, launch_plan_quiet(st, lay.n_chunks, t.chunks, 14, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial));
         // fields planned and reduced by one workgroup each: after the streaming kernels, whose flag counts their reduction reads
-        if (fw) STAGE(5, launch_plan_sparse_fields(st, lay.n_field_work, t.field_work, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
-                                                   t.stat_run, t.work_totals, stats));
+        if (fw) {       // (one launch per class of fields; normally one class holds them all: the stage's events time the first launch)
+            int64_t off = 0;
+            bool first = true;
+            for (int c = 0; c < 4; ++c) {
+                if (lay.n_work[c] == 0) continue;
+                if (first) STAGE(5, launch_plan_sparse_fields(st, lay.n_work[c], t.field_work + off, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
+                                                              FIELD_WORK_WAVES[c], t.work_totals + off, stats));
+                else LAUNCHCHK(launch_plan_sparse_fields(st, lay.n_work[c], t.field_work + off, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
+                                                         FIELD_WORK_WAVES[c], t.work_totals + off, stats));
+                first = false;
+                off += lay.n_work[c];
+            }
+        }
         if (two) HIPCHK(hipStreamWaitEvent(st, b->ctx->ev_join, 0));
         // (four classes of paths by their number of entries; normally one of them holds every path of a batch: the stage's events
         // time the first launch)

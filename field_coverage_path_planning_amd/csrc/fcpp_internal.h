@@ -104,11 +104,15 @@ struct DevWaveTile {
 static_assert(sizeof(DevWaveTile) == 64, "DevWaveTile is fetched as one 64-byte record");
 
 // A field whose general points are all in wave tiles, at most FIELD_WORK_TILES of them: ONE workgroup of k_plan_sparse_fields plans
-// its tiles -- one, two or four wavefronts walk them, by the number of such fields in the batch -- and then reduces the field's
-// statistics itself: its tiles' partial results through LDS, the slots of its quiet runs from memory, so such fields need no
-// k_reduce_stats launch.  (Measured with eight-wave workgroups, a wavefront per tile: the idle wavefronts of a half-empty workgroup hold
-// their slots until its barrier -- headline 60 instead of 35 us.)
-constexpr int FIELD_WORK_TILES = 4, FIELD_WORK_ENTRIES = 16, FIELD_WORK_WAVES_MAX = 4;
+// its tiles, a wavefront each, and then reduces the field's statistics itself: its tiles' partial results through LDS, its quiet runs'
+// from one record summed at batch creation, so such fields need no k_reduce_stats launch.  (Workgroups of four wavefronts; a wavefront without a tile leaves at once.  Measured with eight-wave
+// workgroups for four-tile fields whose idle wavefronts waited at the barrier: headline 60 instead of 35 us.)
+constexpr int FIELD_WORK_TILES = 4, FIELD_WORK_ENTRIES = 16;
+// The launches of k_plan_sparse_fields, one per class of fields by their number of wave tiles, workgroups of as many wavefronts.  Only
+// the first class is in use: with fields of five to eight tiles in classes of their own (workgroups of 5, 6, 8 wavefronts) cfg5 -- nine
+// fields in ten have five tiles -- took 2.20 instead of 1.97 ms: such fields stay with k_plan_sparse and k_reduce_stats.
+constexpr int FIELD_WORK_WAVES[4] = { 4, 5, 6, 8 };
+inline int field_work_class(int n_tiles) { return n_tiles <= 4 ? 0 : (n_tiles == 5 ? 1 : (n_tiles == 6 ? 2 : 3)); }
 struct DevFieldWork {
     int32_t field;
     int32_t n_tiles;         // wave tiles wtiles[w_first .. w_first + n_tiles)

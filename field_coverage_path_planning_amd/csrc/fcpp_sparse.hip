@@ -63,14 +63,12 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
     }
 }
 
-// One workgroup per FIELD (DevFieldWork): its W wavefronts walk the field's wave tiles (two points per lane; wavefront w the tiles w, w + W,
-// ...), then wavefront 0 reduces the field's statistics -- the tiles' partial results through LDS, the slots of the field's quiet runs
-// (closed-form constants written at batch creation + the flag counts k_plan_quiet has added in this step: this launch comes after the
-// streaming kernels) from memory -- in the order of the field's statistics entries, a fixed butterfly over 16 lanes.  No k_reduce_stats
-// launch for such fields, no global partial slots for their tiles, no cross-workgroup synchronisation: everything the reduction needs is
-// the workgroup's own or final.  W is chosen by the launcher so that all wavefronts of the launch are resident together where that is
-// possible (one round of the chip: no second round that starts in step and ends in a tail); a tile's result and the order of the
-// reduction do not depend on it.
+// One workgroup per FIELD (DevFieldWork) of W wavefronts, W >= the number of wave tiles of any field of the launch: wavefront w
+// plans the field's w-th wave tile (two points per lane; a wavefront without a tile leaves at once), then wavefront 0 reduces the
+// field's statistics -- the tiles' partial results through LDS, the closed-form statistics of the field's quiet runs from one record
+// summed at batch creation (k_work_totals), the flag counts k_plan_quiet has added to the runs' slots in this step (this launch comes
+// after the streaming kernels) from memory.  No k_reduce_stats launch for such fields, no global partial slots for their tiles, no
+// cross-workgroup synchronisation: everything the reduction needs is the workgroup's own or final.
 template <int W>
 __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWork *__restrict__ work, const DevWaveTile *__restrict__ wtiles,
                                                               const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
@@ -106,13 +104,11 @@ __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWor
         }
         if (lane == 63) { red[t].n_viol = acc.c_viol; red[t].n_outside = acc.c_out; red[t].n_in_obstacle = acc.c_obs; red[t].n_adjusted = acc.c_adj; }
     };
-    // (as a loop the compiler allots this kernel 104 vector registers instead of 71 -- four resident wavefronts per SIMD instead of
-    // seven -- so the one-tile-per-wavefront form, which needs none, is written without one)
-    if (W == FIELD_WORK_WAVES_MAX) { if (wave < w.n_tiles) plan_tile(wave); }
-    else {
-#pragma unroll 1
-        for (int t = wave; t < w.n_tiles; t += W) plan_tile(t);
-    }
+    // (one tile per wavefront, no loop: as a loop over the field's tiles -- fewer wavefronts per field -- the compiler allots this kernel
+    // 93-104 vector registers instead of 71, four or five resident wavefronts per SIMD instead of seven: measured 40-44 us instead of
+    // 36.5 on the headline)
+    if (wave >= w.n_tiles) return;               // (a wavefront that has ended is no longer expected at the workgroup's barrier)
+    plan_tile(wave);
 #ifdef FCPP_DIAG_SPARSE
     if (g_sparse_stop == -4 || g_sparse_stop == -5) return;      // (-5: nothing but the tile's section -1 before it)
 #endif
@@ -127,8 +123,7 @@ __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWor
         if (lane < w.n_entries) { const TilePartial &slot = partial[w.e_first + lane]; c_out = (unsigned long long)slot.n_outside; c_obs = (unsigned long long)slot.n_in_obstacle; }
     }
     // (the barrier orders the tiles' results in LDS only: no wait for the loads above or for the tiles' stores)
-    if (W > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else wave_sync();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (wave != 0) return;
     if (__ballot((c_out | c_obs) != 0ull) != 0ull) {             // (rare) points of the field's runs were flagged in this step
         if ((c_out | c_obs) != 0ull) { partial[w.e_first + lane].n_outside = 0; partial[w.e_first + lane].n_in_obstacle = 0; }   // collected anew in the next step
@@ -186,20 +181,13 @@ int launch_work_totals(hipStream_t st, int64_t n_work, const DevFieldWork *work,
 
 int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldWork *work, const DevWaveTile *wtiles, const DevField *fields,
                               const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
-                              uint32_t *fs, TilePartial *partial, const int64_t *stat_run, const TilePartial *totals, fcpp_field_stats *stats)
+                              uint32_t *fs, TilePartial *partial, int waves, const TilePartial *totals, fcpp_field_stats *stats)
 {
     if (n_work <= 0) return 0;
-    (void)stat_run;
-    // wavefronts per field: four, one per wave tile (FCPP_FIELD_WORK_WAVES=1 or 2 under FCPP_TUNE=1, tools/ab_knob.py: fewer wavefronts
-    // that walk the field's tiles -- measured slower)
-    int wv = 4;
-    const int wv_k = tune_int("FCPP_FIELD_WORK_WAVES", 0);
-    if (wv_k == 1 || wv_k == 2 || wv_k == 4) wv = wv_k;
 #define FCPP_FW(W) FCPP_LAUNCH((k_plan_sparse_fields<W>), dim3((unsigned)n_work), dim3(64 * W), 0, st, work, wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, \
                                partial, totals, stats)
-    if (wv == 4) FCPP_FW(4);
-    else if (wv == 2) FCPP_FW(2);
-    else FCPP_FW(1);
+    if (waves == 4) FCPP_FW(4);
+    else return (int)hipErrorInvalidValue;       // (instances for 5, 6, 8 wavefronts: measured slower than the open list, fcpp_internal.h)
 #undef FCPP_FW
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

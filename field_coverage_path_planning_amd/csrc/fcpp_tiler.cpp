@@ -21,14 +21,14 @@ struct BlockTiles {
     std::vector<int64_t> stat_run;
     std::vector<DevTile> chunks, span_chunks;
     std::vector<int32_t> cls[4];                 // fields (batch-wide indices) by reduction class
-    std::vector<DevFieldWork> work;              // fields planned and reduced by one workgroup (w_first / e_first block-relative)
+    std::vector<DevFieldWork> work[4];           // fields planned and reduced by one workgroup, by the size of that workgroup (w_first / e_first block-relative)
     std::vector<int32_t> open_wave;              // wave tiles (block-relative indices) of all other fields
     int64_t tile0[PLAN_BLOCK_FIELDS + 1], w0[PLAN_BLOCK_FIELDS + 1];      // a field's records: [tile0[k], tile0[k + 1]) ...
     int64_t stat_cnt[PLAN_BLOCK_FIELDS];         // statistic entries per field
     int64_t n_runs = 0, quiet_points = 0, wave_points = 0, work_wave_points = 0, span_points = 0, chunk_points = 0, wave_inside = 0;
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };
     // bases in the merged tables
-    int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, chunk_base = 0, span_base = 0, cls_base[4] = { 0, 0, 0, 0 }, work_base = 0, open_base = 0;
+    int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, chunk_base = 0, span_base = 0, cls_base[4] = { 0, 0, 0, 0 }, work_base[4] = { 0, 0, 0, 0 }, open_base = 0;
 };
 
 namespace {
@@ -415,7 +415,7 @@ struct FieldTiler {
             DevFieldWork w;
             memset(&w, 0, sizeof w);
             w.field = (int32_t)field; w.n_tiles = (int32_t)nw; w.w_first = (int32_t)out.w0[k_local]; w.e_first = (int32_t)stat_mark; w.n_entries = (int32_t)ne;
-            out.work.push_back(w);
+            out.work[field_work_class((int)nw)].push_back(w);
             for (int64_t k = out.w0[k_local]; k < out.w0[k_local + 1]; ++k) out.work_wave_points += out.wtiles[(size_t)k].count;
         } else {
             for (int64_t k = out.w0[k_local]; k < out.w0[k_local + 1]; ++k) out.open_wave.push_back((int32_t)k);
@@ -500,8 +500,8 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
         lay.n_tiles += (int64_t)bt.tiles.size(); lay.n_wave += (int64_t)bt.wtiles.size(); lay.n_general += (int64_t)bt.general_ids.size();
         lay.n_stat += (int64_t)bt.stat_ids.size(); lay.n_chunks += (int64_t)bt.chunks.size(); lay.n_span_chunks += (int64_t)bt.span_chunks.size();
         for (int c = 0; c < 4; ++c) { bt.cls_base[c] = lay.n_red[c]; lay.n_red[c] += (int64_t)bt.cls[c].size(); }
-        bt.work_base = lay.n_field_work; bt.open_base = lay.n_open_wave;
-        lay.n_field_work += (int64_t)bt.work.size(); lay.n_open_wave += (int64_t)bt.open_wave.size();
+        for (int c = 0; c < 4; ++c) { bt.work_base[c] = lay.n_work[c]; lay.n_work[c] += (int64_t)bt.work[c].size(); lay.n_field_work += (int64_t)bt.work[c].size(); }
+        bt.open_base = lay.n_open_wave; lay.n_open_wave += (int64_t)bt.open_wave.size();
         lay.n_runs += bt.n_runs; lay.quiet_points += bt.quiet_points; lay.wave_points += bt.wave_points; lay.work_wave_points += bt.work_wave_points;
         lay.span_points += bt.span_points; lay.chunk_points += bt.chunk_points; lay.wave_inside += bt.wave_inside;
         for (int k = 0; k < 5; ++k) lay.wave_fail[k] += bt.wave_fail[k];
@@ -569,8 +569,12 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         int64_t run = bt.stat_base;
         for (int64_t k = 0; k < nf; ++k) { sf[pb.f0 + k] = run; run += bt.stat_cnt[k]; }
         if (pb.f1 == n) sf[n] = run;
-        DevFieldWork *fw = at<DevFieldWork>(dst, lay.field_work) + bt.work_base;
-        for (size_t k = 0; k < bt.work.size(); ++k) { fw[k] = bt.work[k]; fw[k].w_first += (int32_t)bt.wave_base; fw[k].e_first += sb; }
+        int64_t class_off = 0;                    // the records lie class by class: every class is one launch
+        for (int c = 0; c < 4; ++c) {
+            DevFieldWork *fw = at<DevFieldWork>(dst, lay.field_work) + class_off + bt.work_base[c];
+            for (size_t k = 0; k < bt.work[c].size(); ++k) { fw[k] = bt.work[c][k]; fw[k].w_first += (int32_t)bt.wave_base; fw[k].e_first += sb; }
+            class_off += lay.n_work[c];
+        }
         int32_t *ow = at<int32_t>(dst, lay.open_wave_ids) + bt.open_base;
         for (size_t k = 0; k < bt.open_wave.size(); ++k) ow[k] = bt.open_wave[k] + (int32_t)bt.wave_base;
         int32_t *rp = at<int32_t>(dst, lay.red_paths);

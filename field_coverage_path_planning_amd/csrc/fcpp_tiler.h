@@ -29,7 +29,7 @@ struct TileConsts {
     int wave_factor = 24;                     // wave tiles where wave_factor * 2a * line step >= u_cap
     int wave_points = 128;                    // points per wave tile: 64 (one per lane) or 128 (two per lane, fcpp_sparse2_fn.h)
     bool field_work = true;                   // fields with few wave tiles and nothing else general: planned and reduced by one workgroup (DevFieldWork)
-    int field_work_tiles = 4;                 // ... at most this many (<= FIELD_WORK_TILES)
+    int field_work_tiles = FIELD_WORK_TILES;  // ... at most this many (<= FIELD_WORK_TILES)
     int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
 };
 
@@ -46,6 +46,7 @@ struct ImageLayout {
     int64_t n_polys = 0, n_poly_verts = 0;
     int64_t quiet_points = 0, span_points = 0, chunk_points = 0, wave_points = 0;
     int64_t work_wave_points = 0;             // the part of wave_points in fields of field_work
+    int64_t n_work[4] = { 0, 0, 0, 0 };       // fields of field_work by class (field_work_class: wavefronts of the workgroup); n_field_work = their sum
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 }; // diagnostics: stretches refused for wave tiles, by reason
     int64_t wave_inside = 0;                  // wave tiles whose outputs the host found inside the geofence
     int wave_tile_points = 64;                // points per wave tile (TileConsts.wave_points)

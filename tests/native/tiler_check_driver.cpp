@@ -208,6 +208,11 @@ int main(int argc, char **argv)
                 if (w.field < 0 || w.field >= n || seen[(size_t)w.field]++) FAIL("field work %lld: field", (long long)k);
                 if (w.e_first != SF[w.field] || w.n_entries != SF[w.field + 1] - SF[w.field] || w.n_entries > FIELD_WORK_ENTRIES) FAIL("field work %lld: entries", (long long)k);
                 if (w.n_tiles < 1 || w.n_tiles > FIELD_WORK_TILES || w.w_first < 0 || w.w_first + w.n_tiles > lay.n_wave) FAIL("field work %lld: tiles", (long long)k);
+                {   // the records lie class by class (one launch each), a field in the class of its tile count
+                    int c = 0;
+                    for (int64_t lim = lay.n_work[0]; c < 3 && k >= lim; lim += lay.n_work[++c]) {}
+                    if (field_work_class(w.n_tiles) != c || w.n_tiles > FIELD_WORK_WAVES[c]) FAIL("field work %lld: class", (long long)k);
+                }
                 int nt = 0;
                 for (int64_t e = SF[w.field]; e < SF[w.field + 1]; ++e) {
                     if (SR[e] == 0) { if (T[SI[e]].quiet != 5 || Wt[w.w_first + nt].tile != e) FAIL("field work %lld: entry %lld is not its tile %d", (long long)k, (long long)e, nt); ++nt; }
