@@ -528,7 +528,11 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tc.nu = ts.tt.nu; tc.nc = ts.tt.nc; tc.templates_ok = true;
     tc.turn_quiet = turn_quiet;
     tc.two_a = 2 * b->cst.a_lon; tc.u_cap = b->cst.u_cap; tc.c_line = b->cst.ms_work * b->cst.ms_work;
-    tc.fence_margin = 1e-3 + std::max(0.0, -opt->geofence_tol);
+    // (the device flags a point whose edge function is below -geofence_tol; host and device evaluate a point by the same formulas and
+    // differ by roundings of ~1e-12 m: 1e-7 m of slack is five orders of magnitude of safety -- and lets the points that lie ON the boundary,
+    // the ends of the reverse fills, three per field of the metric's size, pass with the default tolerance of 1e-6 m: with the millimetre
+    // of rounds 2-3a those three points sent half of the headline's wave tiles through the geofence test)
+    tc.fence_margin = 1e-7 - opt->geofence_tol;
     // (tuning knobs, read once per batch and clamped; both change which kernel plans a stretch or which reduction class a path falls
     // into, i.e. the order of its sums at the last bit: diagnostic builds only)
     tc.wave_factor = std::max(0, std::min(tune_int("FCPP_WAVE_FACTOR", 24), 64));

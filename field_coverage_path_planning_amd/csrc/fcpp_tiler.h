@@ -25,7 +25,7 @@ struct TileConsts {
     bool templates_ok = false;                // the copies are there (wave tiles need them to size their halos)
     bool turn_quiet = false;                  // U-turns of this batch are closed form (closed_form_turns, fcpp_api.cpp)
     double two_a = 0.0, u_cap = 0.0, c_line = 0.0;     // 2 a_lon, (v_max / 3.6)^2, (v_work / 3.6)^2
-    double fence_margin = 1e-3;               // a point this far inside every edge cannot be flagged by the device's geofence test
+    double fence_margin = 1e-7;               // a point whose edge functions are all at least this cannot be flagged by the device's geofence test (1e-7 - geofence_tol)
     int wave_factor = 24;                     // wave tiles where wave_factor * 2a * line step >= u_cap
     int wave_points = 128;                    // points per wave tile: 64 (one per lane) or 128 (two per lane, fcpp_sparse2_fn.h)
     bool field_work = true;                   // fields with few wave tiles and nothing else general: planned and reduced by one workgroup (DevFieldWork)

@@ -109,7 +109,7 @@ int main(int argc, char **argv)
         tc.field_work = pick(4) != 0;
         const double vm = 15.0 / 3.6;
         tc.two_a = 2 * veh.max_longitudinal_accel; tc.u_cap = vm * vm; tc.c_line = (9.0 / 3.6) * (9.0 / 3.6);
-        tc.fence_margin = 1e-3 + (opt.geofence_tol < 0 ? -opt.geofence_tol : 0.0);
+        tc.fence_margin = 1e-7 - opt.geofence_tol;
         BatchTiler tiler;
         ImageLayout lay;
         rc = tiler.plan(hp, tc, &polys, lay, err);
