@@ -47,7 +47,7 @@ struct SparsePt {
 
 // the point `rel` (index in the tile) of a lane: coordinates, flag word, nominal speed
 __device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevField &f, const double *plds, const DevConst &cst, int rel,
-                                              int nl, SparsePt &q)
+                                              int slot, int nl, SparsePt &q)
 {
     q.act = rel < nl;
     q.out = rel >= wt.hb && rel < wt.hb + wt.count;
@@ -60,13 +60,7 @@ __device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevFi
     DevPrim p;
     double2 tc = make_double2(0.0, 0.0);
     if (in_l2) {
-        int slot = 0;
-        r = rel + wt.r0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int th = wt.thr[k];
-            if (rel >= th) { ++slot; r = rel - th; }
-        }
+        r = rel - reinterpret_cast<const int *>(plds + TILE_STARTS_AT)[slot];
         tc = cst.tmpl_c[min(max(r, 0), cst.tmpl_nc - 1)];
         p = reinterpret_cast<const DevPrim *>(plds)[slot];
     }
@@ -104,12 +98,14 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     SP_STAMP_S(9, wt.hb);
     SP_STAMP_S(10, f.n_line);
     stage_tile_prims(wt, prims, plds, nl);
-    sparse2_point(wt, f, plds, cst, ra, nl, A);
+    int slot_a, slot_b;
+    tile_slots2(wt, lane, slot_a, slot_b);
+    sparse2_point(wt, f, plds, cst, ra, slot_a, nl, A);
 #ifdef FCPP_DIAG_SPARSE
     sp_pin(A.px, A.py, A.vn, A.msn, A.fw);
     if (stop_ == -3) return;
 #endif
-    sparse2_point(wt, f, plds, cst, rb, nl, B);
+    sparse2_point(wt, f, plds, cst, rb, slot_b, nl, B);
     SP_STAMP(0, A.px, A.py, B.px, B.py, A.vn, B.vn, A.msn, B.msn, A.fw, B.fw);
 
     // ---- chords, curvature (MLP:513-536), clamp (MLP:490-504) ----------------------------------------------------------------------

@@ -20,8 +20,28 @@ struct SparseAcc {
 // reads its primitive's record from there.  (Read from global memory by every lane -- six 16-byte loads per point, 64 lanes asking
 // for the same few cache lines -- the records were 190 of a wavefront's 350 accesses to the vector cache, which was the busiest unit of
 // the kernel: TCP_TOTAL_CACHE_ACCESSES and TCP_PENDING_STALL_CYCLES, profiles/r03_sparse_mem_counters.txt.)
-static constexpr int TILE_PRIMS_MAX = 9, PRIM_DOUBLES = (int)(sizeof(DevPrim) / sizeof(double)), TILE_PRIMS_LDS = TILE_PRIMS_MAX * PRIM_DOUBLES + 1;
+static constexpr int TILE_PRIMS_MAX = 9, PRIM_DOUBLES = (int)(sizeof(DevPrim) / sizeof(double)), TILE_STARTS_AT = TILE_PRIMS_MAX * PRIM_DOUBLES + 1,
+                     TILE_PRIMS_LDS = TILE_STARTS_AT + 5;      // (behind the records: nine 32-bit sample-index bases, tile_starts)
 static_assert(sizeof(DevPrim) % sizeof(double) == 0 && TILE_PRIMS_MAX * PRIM_DOUBLES <= 128, "two loads per lane stage a tile's primitives");
+// The primitive of a tile's point: the number of primitives that start at or before it -- the record's thresholds as bits of a 128-bit mask
+// built by the scalar unit, counted by v_bcnt below the point's own bit -- instead of eight compare / select rounds per point.
+// lane l: points 2l (sa) and 2l + 1 (sb).
+__device__ __forceinline__ void tile_slots2(const DevWaveTile &wt, int lane, int &sa, int &sb)
+{
+    unsigned long long mlo = 0, mhi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned t = wt.thr[k];
+        if (t < 64u) mlo |= 1ull << t;
+        else if (t < 128u) mhi |= 1ull << (t - 64u);
+    }
+    const bool hi = lane >= 32;
+    const unsigned long long m = hi ? mhi : mlo;
+    const int p = (2 * lane) & 63;
+    sa = __popcll(m & ((2ull << p) - 1ull)) + (hi ? __popcll(mlo) : 0);
+    sb = sa + (int)((m >> (p + 1)) & 1ull);
+}
+
 __device__ __forceinline__ void stage_tile_prims(const DevWaveTile &wt, const DevPrim *__restrict__ prims, double *plds, int nl)
 {
     if (wt.rel_main >= nl) return;                           // (wave-uniform) no point of layer 2 in this tile
@@ -32,6 +52,14 @@ __device__ __forceinline__ void stage_tile_prims(const DevWaveTile &wt, const De
     const int lane = threadIdx.x & 63, nw = np * PRIM_DOUBLES;
     if (lane < nw) plds[lane] = src[lane];
     if (lane + 64 < nw) plds[lane + 64] = src[lane + 64];
+    // the sample index of a point in its primitive is its index in the tile minus tile_starts[slot]: -r0 for the tile's first
+    // primitive, the primitive's first point (the record's threshold) for the others
+    if (lane < TILE_PRIMS_MAX) {
+        const unsigned long long th = (unsigned long long)wt.thr[0] | (unsigned long long)wt.thr[1] << 8 | (unsigned long long)wt.thr[2] << 16 |
+                                      (unsigned long long)wt.thr[3] << 24 | (unsigned long long)wt.thr[4] << 32 | (unsigned long long)wt.thr[5] << 40 |
+                                      (unsigned long long)wt.thr[6] << 48 | (unsigned long long)wt.thr[7] << 56;
+        reinterpret_cast<int *>(plds + TILE_STARTS_AT)[lane] = lane == 0 ? -wt.r0 : (int)((th >> (8 * (lane - 1))) & 255ull);
+    }
     wave_sync();
 }
 

@@ -238,7 +238,12 @@ struct FieldTiler {
                 if (pb - pa > 8) return refuse(3);
                 wt.p0 = prim_index0 + pa;
                 wt.r0 = (int32_t)(first - prims[pa].start);
-                for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(prims[k].start - first);
+                for (int k = pa + 1; k <= pb; ++k) {
+                    // (strictly ascending: the kernel counts the primitives that start at or before a point as bits of a mask; an empty
+                    // primitive -- two starts on one point, no plan has one -- would be counted once)
+                    if (prims[k].start <= prims[k - 1].start) return refuse(3);
+                    wt.thr[k - pa - 1] = (uint8_t)(prims[k].start - first);
+                }
             }
             out.wave_inside += wt.inside;
             out.wtiles.push_back(wt);

@@ -166,8 +166,10 @@ int main(int argc, char **argv)
                 // lane l of layer 2 = sample (l + r0) of primitive p0, (l - thr[q]) of primitive p0 + 1 + q
                 const int64_t fl2 = first > F[w.field].gen_main ? first : F[w.field].gen_main;
                 if (P[w.p0].start + (fl2 - first) + w.r0 != fl2) FAIL("wave tile %lld: r0", (long long)k);
-                for (int q = 0; q < 8 && w.thr[q] != 255; ++q)
+                for (int q = 0; q < 8 && w.thr[q] != 255; ++q) {
                     if (P[w.p0 + 1 + q].start != first + w.thr[q]) FAIL("wave tile %lld: threshold %d", (long long)k, q);
+                    if (w.thr[q] < 1 || w.thr[q] >= 128 || (q > 0 && w.thr[q] <= w.thr[q - 1])) FAIL("wave tile %lld: thresholds not strictly ascending in [1, 128)", (long long)k);
+                }
             }
         }
         for (int pass = 0; pass < 2; ++pass) {
