@@ -306,9 +306,12 @@ __device__ __forceinline__ double fsqrt_pos(double x)
     g = fma(fma(-g, g, x), h, g);
     return fma(fma(-g, g, x), h, g);
 }
-__device__ __forceinline__ double seg_len_fast(double dx, double dy)      // seg_len with fsqrt_pos (both steps non-zero where it is taken)
+__device__ __forceinline__ double seg_len_fast(double dx, double dy)      // |(dx, dy)|: seg_len's value without its shortcuts
 {
-    return (dy == 0.0) ? fabs(dx) : ((dx == 0.0) ? fabs(dy) : fsqrt_pos(dx * dx + dy * dy));
+    // (seg_len returns |dx| where dy == 0 and |dy| where dx == 0 to save the square root; as selects in a wavefront that holds both
+    // kinds of steps they only add instructions -- and sqrt(fl(t t)) == |t| exactly for a correctly rounded root, which fsqrt_pos is)
+    const double s = dx * dx + dy * dy;
+    return s == 0.0 ? 0.0 : fsqrt_pos(s);
 }
 
 // a * b + k, k a compile-time constant that the scalar unit puts into a scalar register pair (one scalar operand per vector instruction)

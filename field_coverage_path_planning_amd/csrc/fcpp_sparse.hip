@@ -72,10 +72,10 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
 template <int W>
 __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWork *__restrict__ work, const DevWaveTile *__restrict__ wtiles,
                                                               const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
-                                                              DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
+                                                              DevConst cst, double *__restrict__ xo, double *__restrict__ yo,
                                                               double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
-                                                              TilePartial *__restrict__ partial, const TilePartial *__restrict__ totals,
-                                                              fcpp_field_stats *__restrict__ stats)
+                                                              DevObstacles obs, TilePartial *__restrict__ partial,
+                                                              const TilePartial *__restrict__ totals, fcpp_field_stats *__restrict__ stats)
 {
     __shared__ double obs_lds[W][2 * OBS_LDS_VERTS];
     __shared__ TilePartial red[FIELD_WORK_TILES];
@@ -184,7 +184,7 @@ int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldWork
                               uint32_t *fs, TilePartial *partial, int waves, const TilePartial *totals, fcpp_field_stats *stats)
 {
     if (n_work <= 0) return 0;
-#define FCPP_FW(W) FCPP_LAUNCH((k_plan_sparse_fields<W>), dim3((unsigned)n_work), dim3(64 * W), 0, st, work, wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, \
+#define FCPP_FW(W) FCPP_LAUNCH((k_plan_sparse_fields<W>), dim3((unsigned)n_work), dim3(64 * W), 0, st, work, wtiles, fields, prims, cst, x, y, kappa, v, fs, obs, \
                                partial, totals, stats)
     if (waves == 4) FCPP_FW(4);
     else return (int)hipErrorInvalidValue;       // (instances for 5, 6, 8 wavefronts: measured slower than the open list, fcpp_internal.h)

@@ -42,7 +42,7 @@ template <class T, class... R> __device__ __forceinline__ void sp_pin(T &v, R &.
 struct SparsePt {
     double px, py, vn, msn, d, kappa, v0, ms0, u0, u, w, vfin;
     uint32_t fw;
-    bool act, out, is_first, is_last, at_seam, is_second, cl, lowered, has_prev, interior;
+    bool act, out, cl, lowered, has_prev, interior;    // (where the point lies on the path -- first, second, last, at the seam -- is compared where it is asked: a predicate kept from the start to the metrics holds a scalar register pair all that way, and the kernel spills those)
 };
 
 // the point `rel` (index in the tile) of a lane: coordinates, flag word, nominal speed
@@ -52,7 +52,6 @@ __device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevFi
     q.act = rel < nl;
     q.out = rel >= wt.hb && rel < wt.hb + wt.count;
     const bool in_main = rel < wt.rel_main;
-    q.is_first = rel == wt.rel_zero; q.is_last = rel == wt.rel_last; q.at_seam = rel == wt.rel_seam; q.is_second = rel == wt.rel_zero + 1;
     q.px = q.py = 0.0;
     q.fw = 0;
     const bool in_l2 = q.act && !in_main;
@@ -117,8 +116,8 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     A.d = A.has_prev ? seg_len_fast(dxa, dya) : 0.0;
     B.d = B.has_prev ? seg_len_fast(dxb, dyb) : 0.0;
     const double dn_b = lane_next(A.d);                      // |next lane's a - b|
-    A.interior = A.has_prev && ra < nl - 1 && !A.is_last;
-    B.interior = B.has_prev && rb < nl - 1 && !B.is_last;
+    A.interior = A.has_prev && ra < nl - 1 && ra != wt.rel_last;
+    B.interior = B.has_prev && rb < nl - 1 && rb != wt.rel_last;
     A.kappa = B.kappa = 0.0;
     SP_STAMP(1, A.d, B.d);
     if (A.interior) A.kappa = curv_chords_atan(dxa, dya, A.d, dxb, dyb, B.d, atab);
@@ -225,7 +224,8 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     // lane -- slot 0, handed to the tile's layer below -- instead of six with two selects each)
     const bool mixed = wt.rel_seam > wt.hb && wt.rel_seam < wt.hb + wt.count;
     auto metrics = [&](const SparsePt &q, int rel, double vprev, double vnprev, double kprev, bool &viol, uint32_t &fw) {
-        const bool seg = q.out && !q.is_first && !q.at_seam;
+        const bool is_first = rel == wt.rel_zero;
+        const bool seg = q.out && !is_first && rel != wt.rel_seam;
         const bool l0 = rel < wt.rel_seam;
         double tpre = 0.0, t = 0.0;
         if (seg) {
@@ -240,13 +240,13 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
             acc.s_len[0] += l0 ? len : 0.0; acc.s_tpre[0] += l0 ? tpre : 0.0; acc.s_t[0] += l0 ? t : 0.0;
             acc.s_len[1] += l0 ? 0.0 : len; acc.s_tpre[1] += l0 ? 0.0 : tpre; acc.s_t[1] += l0 ? 0.0 : t;
         } else { acc.s_len[0] += len; acc.s_tpre[0] += tpre; acc.s_t[0] += t; }
-        if (q.out && !q.is_first && !q.is_last) {
+        if (q.out && !is_first && rel != wt.rel_last) {
             if (q.kappa > 0.0) {
                 const double ms = q.lowered ? div36(q.vfin) : q.ms0, alat = ms * ms * q.kappa;
                 acc.mk = max_raw(acc.mk, q.kappa); acc.ma = max_raw(acc.ma, alat);
                 if (alat > cst.a_lat) { viol = true; fw |= FCPP_FLAG_ALAT; }
             }
-            if (q.kappa != kprev && !q.is_second) acc.mj = max_raw(acc.mj, fabs(q.kappa - kprev));
+            if (q.kappa != kprev && rel != wt.rel_zero + 1) acc.mj = max_raw(acc.mj, fabs(q.kappa - kprev));
         }
     };
     // (a first, then b: the per-lane accumulators add a's terms before b's; the order of the additions is fixed by the tile alone)
