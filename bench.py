@@ -607,11 +607,11 @@ def run_cfg4(E, torch, WL, cpu_on):
     if cpu_on:
         import oracle as orc
         t0 = time.perf_counter()
-        gens = 12
+        gens = 500                      # (the whole run: ~2.5 s on one thread)
         orc.ga_evolve(D, routes, max_generations=gens, convergence_threshold=10 ** 9, seed=4096)
         tc = time.perf_counter() - t0
         cpu = {'value': (gens + 1) * 4096 / tc, 'unit': 'chromosome evaluations/s', 'cores': 1, 'kind': 'port',
-               'sample': f'{gens} generations of the same run (pop 4096, n 128) through oracle/fcpp_oracle.c: orc_ga_evolve, {tc:.1f} s on one thread'}
+               'sample': f'{gens} generations of the same run (pop 4096, n 128) through oracle/fcpp_oracle.c: orc_ga_evolve, {tc:.2f} s on one thread'}
     bytes_per_chrom = 4 * 128 + 8
     return {'name': 'cfg4', 'workload': 'cfg4: GA over 128 nodes, population 4096, 500 generations (501 population evaluations), whole loop on the device',
             'generations': int(res.generations), 'ms_total': dt * 1e3, 'us_per_generation': dt / 500 * 1e6,
