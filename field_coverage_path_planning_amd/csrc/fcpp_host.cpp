@@ -624,8 +624,13 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
     const bool share = getenv("FCPP_NO_SHARE") == nullptr;      // (diagnostic: plan every field on its own; tests/native/tiler_check_driver.cpp)
 
     // ---- the blocks, side by side: every block plans its fields into its own primitive list; point offsets and primitive indices are
-    // relative to the block until the bases are known
-    WorkerPool::parallel_for(nb, [&](int64_t b) {
+    // relative to the block until the bases are known.  (Side by side from 16 384 fields on: a field takes 0.1-1 us to plan, waking
+    // the pool's threads twice 0.5 ms -- the headline's 4096 equal fields 0.13 ms in the calling thread, 0.71 ms on sixteen.)
+    const auto for_blocks = [&](const std::function<void(int64_t)> &fn) {
+        if (n >= 16384) WorkerPool::parallel_for(nb, fn);
+        else for (int64_t b = 0; b < nb; ++b) fn(b);
+    };
+    for_blocks([&](int64_t b) {
         PlanBlock &blk = out.blocks[(size_t)b];
         blk.f0 = b * PLAN_BLOCK_FIELDS; blk.f1 = std::min(n, blk.f0 + PLAN_BLOCK_FIELDS);
         // fields with the same constructor arguments (a batch of equal fields is the headline workload) are planned once per block:
@@ -679,7 +684,7 @@ int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n,
         }
     }
     out.total_points = pt_off; out.total_prims = prim_off;
-    WorkerPool::parallel_for(nb, [&](int64_t b) {
+    for_blocks([&](int64_t b) {
         const PlanBlock &blk = out.blocks[(size_t)b];
         for (int64_t fi = blk.f0; fi < blk.f1; ++fi) {
             out.info[(size_t)fi].point_offset += blk.point_base;
