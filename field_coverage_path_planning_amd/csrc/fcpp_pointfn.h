@@ -415,7 +415,7 @@ __device__ __forceinline__ long long wave_sum_i(int v)
 // obstacle polygons.  Culling first: lane b compares polygon b's bounding box with the bounding box of the wave's
 // points, a ballot collects the few candidates, and each candidate's vertices are staged in LDS (coalesced load, then
 // broadcast reads) before every lane tests its own points against all its edges.
-static constexpr int OBS_LDS_VERTS = 256;    // polygons with more vertices are read from global memory
+static constexpr int OBS_LDS_VERTS = 240;    // polygons with more vertices are read from global memory (240: four wavefronts' staging areas and the rest of k_plan_sparse_fields' LDS fit 20 KiB, eight workgroups per CU)
 
 // returns the bit mask of the points (bit p = point p of this lane) that lie inside an obstacle
 template <int NP>

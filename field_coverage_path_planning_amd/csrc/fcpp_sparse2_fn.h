@@ -40,7 +40,7 @@ template <class T, class... R> __device__ __forceinline__ void sp_pin(T &v, R &.
 
 // one of the lane's two points
 struct SparsePt {
-    double px, py, vn, msn, d, kappa, v0, ms0, u0, u, w, vfin;
+    double px, py, vn, d, kappa, v0, ms0, u0, u, w, vfin;
     uint32_t fw;
     bool act, out, cl, lowered, has_prev, interior;    // (where the point lies on the path -- first, second, last, at the seam -- is compared where it is asked: a predicate kept from the start to the metrics holds a scalar register pair all that way, and the kernel spills those)
 };
@@ -77,7 +77,6 @@ __device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevFi
         q.fw = p.fs;
     }
     q.vn = in_l2 ? p.v_nom : (((q.fw & FCPP_KIND_MASK) == FCPP_KIND_SWATH) ? cst.v_work : cst.v_turn);
-    q.msn = div36(q.vn);
 }
 
 // obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles); atab: the staged
@@ -101,11 +100,11 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     tile_slots2(wt, lane, slot_a, slot_b);
     sparse2_point(wt, f, plds, cst, ra, slot_a, nl, A);
 #ifdef FCPP_DIAG_SPARSE
-    sp_pin(A.px, A.py, A.vn, A.msn, A.fw);
+    sp_pin(A.px, A.py, A.vn, A.fw);
     if (stop_ == -3) return;
 #endif
     sparse2_point(wt, f, plds, cst, rb, slot_b, nl, B);
-    SP_STAMP(0, A.px, A.py, B.px, B.py, A.vn, B.vn, A.msn, B.msn, A.fw, B.fw);
+    SP_STAMP(0, A.px, A.py, B.px, B.py, A.vn, B.vn, A.fw, B.fw);
 
     // ---- chords, curvature (MLP:513-536), clamp (MLP:490-504) ----------------------------------------------------------------------
     // a's predecessor is the previous lane's b, its successor the lane's own b; b's predecessor is a, its successor the next lane's a
@@ -127,8 +126,8 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
     A.v0 = A.vn; B.v0 = B.vn;
     if (A.kappa > 1e-6) A.v0 = clamped_speed_fast(A.vn, A.kappa, cst, A.cl);
     if (B.kappa > 1e-6) B.v0 = clamped_speed_fast(B.vn, B.kappa, cst, B.cl);
-    A.ms0 = A.cl ? div36(A.v0) : A.msn;
-    B.ms0 = B.cl ? div36(B.v0) : B.msn;
+    A.ms0 = div36(A.cl ? A.v0 : A.vn);
+    B.ms0 = div36(B.cl ? B.v0 : B.vn);
     A.u0 = A.act ? A.ms0 * A.ms0 : FCPP_INF;
     B.u0 = B.act ? B.ms0 * B.ms0 : FCPP_INF;
 
@@ -229,7 +228,7 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
         const bool l0 = rel < wt.rel_seam;
         double tpre = 0.0, t = 0.0;
         if (seg) {
-            const double ms_pre = (vnprev == q.vn) ? q.msn : div36((vnprev + q.vn) / 2);
+            const double ms_pre = div36((vnprev + q.vn) / 2);       // ((a + a) / 2 == a exactly: no case for equal speeds)
             tpre = fdiv(q.d, fmax(ms_pre, 0.1));
         }
         const bool changed = seg && !(vprev == vnprev && q.vfin == q.vn);
@@ -242,7 +241,7 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
         } else { acc.s_len[0] += len; acc.s_tpre[0] += tpre; acc.s_t[0] += t; }
         if (q.out && !is_first && rel != wt.rel_last) {
             if (q.kappa > 0.0) {
-                const double ms = q.lowered ? div36(q.vfin) : q.ms0, alat = ms * ms * q.kappa;
+                const double ms = div36(q.vfin), alat = ms * ms * q.kappa;       // (not lowered: vfin is the value ms0 was taken from)
                 acc.mk = max_raw(acc.mk, q.kappa); acc.ma = max_raw(acc.ma, alat);
                 if (alat > cst.a_lat) { viol = true; fw |= FCPP_FLAG_ALAT; }
             }
