@@ -217,7 +217,7 @@ def roofline_of(r, traffic_key=None):
     if dom in ('k_plan_sparse', 'k_plan_sparse_fields'):
         # (the secondary ceiling.  Counters of the kept profiles, not measured in this run.)
         note = ('the wave-tile kernels (k_plan_sparse, and k_plan_sparse_fields: the same tiles planned and reduced field by field) are bound by fp64 '
-                'vector issue and by their dependent loads, not by HBM: 830-910 vector instructions per wavefront of ~110 output points '
+                'vector issue and by their dependent loads, not by HBM: 800-870 vector instructions per wavefront of ~110 output points '
                 '(profiles/r03_counter_table.txt); their HBM fraction is low by construction, the step-level figure is step_frac')
     return {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'note': note,
             'traffic': traffic, 'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
