@@ -206,25 +206,36 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
 
 
 def roofline_of(r, traffic_key=None):
+    """The roofline record of one configuration.  `frac` / `kernel` name the kernel with the longest launch (two kernels of the headline are
+    0.2 us apart: which one that is flips with noise); `step_frac` -- 36 B x all points of the step / ms_per_step / 8 TB/s -- is the figure
+    that does not, and what the compact line reports as its `roofline.frac` beside every kernel's own fraction.  `traffic`: HBM bytes per
+    launch from the PMC counters of the committed profiles (profiles/traffic.json: a constant of the builder's profiling run on this
+    workload, NOT measured in this run; `traffic_source` says so)."""
     dom, dom_ms, dom_points = r['dominant'], r['kernels'][r['dominant']], r['dominant_points']
     achieved = BYTES_PER_POINT * dom_points / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     pipe_ms = sum(r['kernels'].values())
-    traffic = None
+    traffic = step_traffic = None
     tpath = os.path.join(REPO, 'profiles', 'traffic.json')
+    point_kernels = [k for k, ms in r['kernels'].items() if ms > 0 and k != 'k_reduce_stats']
     if traffic_key and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(f'{dom}|{traffic_key}')
+        tj = json.load(open(tpath))
+        traffic = tj.get(f'{dom}|{traffic_key}')
+        parts = [tj.get(f'{k}|{traffic_key}') for k in point_kernels]
+        step_traffic = sum(parts) if parts and all(p is not None for p in parts) else None
     note = None
     if dom in ('k_plan_sparse', 'k_plan_sparse_fields'):
         # (SURVEY.md 8d: the secondary ceiling.  Counters of the kept profiles, not measured in this run.)
-        note = ('the wave-tile kernels (k_plan_sparse, and k_plan_sparse_fields: the same tiles planned and reduced field by field) are bound by fp64 '
-                'vector issue and by their dependent loads, not by HBM: 800-870 vector instructions per wavefront of ~110 output points '
-                '(profiles/r03_counter_table.txt); their HBM fraction is low by construction, the step-level figure is step_frac')
+        note = ('the wave-tile kernels are bound by fp64 vector issue and dependent loads, not by HBM (profiles/*_counter_table.txt); '
+                'the step-level figure is step_frac')
+    step_achieved = BYTES_PER_POINT * r['points'] / (r['ms_per_step'] * 1e-3) / 1e9
     return {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'note': note,
-            'traffic': traffic, 'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
+            'traffic': traffic, 'traffic_source': 'profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of the builder\'s profiling run; a constant, not measured in this run)' if traffic is not None or step_traffic is not None else None,
+            'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
             'kernel_points_per_launch': dom_points, 'all_kernels_ms': r['kernels'], 'all_kernels_points': r['stage_points'],
             'profiled_steps': r['prof_runs'], 'pipeline_ms': pipe_ms,
             'pipeline_frac': (BYTES_PER_POINT * r['points'] / (pipe_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pipe_ms > 0 else 0.0,
-            'step_frac': BYTES_PER_POINT * r['points'] / (r['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            'step_kernels': 'step: ' + ' + '.join(point_kernels), 'step_achieved': step_achieved, 'step_traffic': step_traffic,
+            'step_frac': step_achieved / HBM_PEAK_GBS}
 
 
 def timed_region_of(r):
@@ -255,6 +266,63 @@ REFERENCE_MEASURED = {
 }
 
 
+
+# ---- the ONE line the driver parses: compact (< 4 KB); everything else goes to bench_detail.json and stderr ----------------------------
+COMPACT_LIMIT = 4000
+
+
+def _r(v, nd=6):
+    if isinstance(v, float):
+        return float(f'{v:.{nd}g}')
+    return v
+
+
+def compact_line(out):
+    """The last stdout line: BASELINE.json's metric on the headline workload with `roofline` (the step's fraction as `frac`, every kernel of
+    the step as [ms per launch, points per launch, its own fraction]) and `cpu_baseline`, plus one short row per configuration.  The full
+    record (per-configuration entries with their setup splits, timed regions, notes) is bench_detail.json."""
+    rf, cfg = out['roofline'], out['config']
+    kern = {}
+    for name, ms in rf['all_kernels_ms'].items():
+        pts = rf['all_kernels_points'].get(name, 0)
+        if ms > 0 and name != 'k_reduce_stats' or (name == 'k_reduce_stats' and ms > 0):
+            kern[name] = [_r(ms, 5), int(pts), _r(BYTES_PER_POINT * pts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if name != 'k_reduce_stats' else None]
+    c = {
+        'metric': out['metric'], 'value': _r(out['value'], 7), 'unit': out['unit'], 'n_gpus': out['n_gpus'], 'steps': out['steps'], 'warmup': out['warmup'],
+        'ms_per_step': _r(out['ms_per_step'], 6), 'higher_is_better': True, 'scaling': out['scaling'], 'vs_baseline': out.get('vs_baseline'),
+        'vs_baseline_of': out.get('vs_baseline_of'), 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': cfg['workload'][:200], 'turn_model': cfg['turn_model'], 'points_per_gpu_step': cfg['points_per_gpu_step'],
+                   'fields_per_gpu': cfg['fields_per_gpu'], 'setup': cfg.get('setup')},
+        'roofline': {'bound': 'hbm', 'kernel': rf['step_kernels'], 'frac': _r(rf['step_frac'], 4), 'achieved': _r(rf['step_achieved'], 6), 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'kernel_ms': _r(out['ms_per_step'], 6), 'algorithmic_bytes_per_launch': BYTES_PER_POINT * cfg['points_per_gpu_step'],
+                     'traffic': rf.get('step_traffic'), 'traffic_source': rf.get('traffic_source'), 'step_frac': _r(rf['step_frac'], 4),
+                     'dominant_kernel': rf['kernel'], 'dominant_frac': _r(rf['frac'], 4), 'kernels': kern},
+        'cpu_baseline': None, 'value_end_to_end': _r(out.get('value_end_to_end'), 6), 'end_to_end_ms': _r(out['end_to_end']['ms'], 5),
+        'value_clothoid': _r(out.get('value_clothoid'), 6), 'rccl_ranks': out.get('rccl_ranks'), 'per_rank_points_per_s': out.get('per_rank_points_per_s'),
+        'host_threads': out.get('host_threads'), 'detail': 'bench_detail.json',
+    }
+    if out.get('forced_dist'):
+        c['forced_dist'] = True
+    cb = out.get('cpu_baseline')
+    if cb:
+        c['cpu_baseline'] = {'value': _r(cb['value'], 5), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:160],
+                             'single_core_value': _r(cb.get('single_core_value'), 5)}
+    rows = {}
+    for e in out.get('configs', []):
+        rr = e.get('roofline') or {}
+        cpu = e.get('cpu_baseline') or {}
+        rows[e['name']] = [_r(e.get('ms_per_step', e.get('ms_total')), 5), _r(e.get('value'), 5), _r(rr.get('step_frac', rr.get('frac')), 3),
+                           _r((e.get('end_to_end') or {}).get('ms'), 4), _r(cpu.get('value'), 4)]
+    c['configs'] = {'columns': ['ms_per_step', 'value', 'step_frac', 'end_to_end_ms', 'cpu_baseline_value'], **rows}
+    line = json.dumps(c, separators=(',', ':'))
+    for drop in ('per_rank_points_per_s', 'configs'):          # (never needed so far: a guard, not a plan)
+        if len(line) <= COMPACT_LIMIT:
+            break
+        c.pop(drop, None)
+        line = json.dumps(c, separators=(',', ':'))
+    return line
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -278,6 +346,13 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
+    # host threads of the batch setup (fcpp_parallel.h reads FCPP_THREADS when its pool starts): N ranks of one node share its cores
+    try:
+        n_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_cores = os.cpu_count() or 1
+    host_threads = int(os.environ.get('FCPP_THREADS') or max(1, min(16, n_cores // max(world, 1))))
+    os.environ['FCPP_THREADS'] = str(host_threads)
     # FCPP_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path on a box with fewer GPUs than ranks (ranks share devices, the
     # collectives carry host tensors); the measured configuration is nccl = RCCL, one rank per GPU
     backend = os.environ.get('FCPP_BENCH_BACKEND', 'nccl')
@@ -380,6 +455,12 @@ def main():
     dt = allmax(r['dt'])
     total_points = allsum(r['points'])
     e2e_ms = allmax(r['end_to_end']['ms'])
+    # every rank's own rate (its points x K / its own time of the K-step region), so that the scaling run checks itself
+    rates = torch.zeros(world, dtype=torch.float64, device=cdev)
+    rates[rank] = r['points'] * args.steps / r['dt']
+    if use_dist:
+        dist.all_reduce(rates)
+    per_rank_rates = [float(f'{v:.5g}') for v in rates.cpu().tolist()]
     out = None
     if rank == 0:
         st = r['res'].stats()
@@ -404,11 +485,19 @@ def main():
             'roofline': roofline_of(r, 'cfg1'),
             'cpu_baseline': None,
             'reference_measured': REFERENCE_MEASURED,
+            'rccl_ranks': (dist.get_world_size() if use_dist else 1) if backend == 'nccl' else 0,
+            'per_rank_points_per_s': per_rank_rates,
+            'host_threads': host_threads,
         }
+        out['config']['setup'] = r['batch'].setup_path() if hasattr(r['batch'], 'setup_path') else 'host'
     if rank == 0 and cpu_on:
         import oracle as orc
         out['cpu_baseline'] = cpu_baseline_fields(lambda k: orc.make_field(L=float(LH1[k, 0]), H=float(LH1[k, 1])), len(LH1), orc.Options.make(),
                                                   args.cpu_budget, '500 x 200 m fields, arcs, reference sampling')
+        # BASELINE.md publishes no points/s figure for this metric: the ratio is against the CPU baseline of THIS run (the C port of the
+        # reference's loops on the box's own cores), and says so
+        out['vs_baseline'] = out['value'] / out['cpu_baseline']['value']
+        out['vs_baseline_of'] = 'cpu_baseline.value of this run (BASELINE.md has no published points/s)'
     r['batch'].close()
     del r
     torch.cuda.empty_cache()
@@ -485,10 +574,18 @@ def main():
                 st3 = rr['res'].stats()
                 fs = rr['res'].flagseg
                 return {'n_in_obstacle': int(st3['n_in_obstacle'][0]), 'detour_points': int(((fs & E.L.KIND_MASK) == E.L.KIND_DETOUR).sum())}
+
+            def cfg3a_cpu():
+                t0 = time.perf_counter()
+                rc, p = orc.plan_field(orc.make_field(L=L3, H=H3, obstacles=obst), orc.Vehicle.make(), orc.Options.make(1, 1, 0.05, 0.5, obstacle_mode=1))
+                tc = time.perf_counter() - t0
+                assert rc == 0
+                return {'value': p.n / tc, 'unit': 'points/s', 'cores': 1, 'kind': 'port', 'single_core_value': p.n / tc,
+                        'sample': f'the whole cfg3 field with obstacle-aware swaths ({p.n} points) once through oracle/fcpp_oracle.c on one thread, {tc:.1f} s'}
             planner_config('cfg3_avoid', 'cfg3 with obstacle-aware swaths (fcpp_options.obstacle_mode = AVOID, SURVEY.md 8f-4): every swath that meets one of '
                            'the 32 obstacles is clipped and driven around it; clothoid turns, 0.05 m',
                            E.FieldTable.from_specs([E.FieldSpec(field_length=L3, field_width=H3, obstacles=obst)]), E.make_options(1, 0.05, avoid_obstacles=True),
-                           max(5, args.steps // 10), 2, extra_fn=cfg3a_extra, e2e_reps=3)
+                           max(5, args.steps // 10), 2, extra_fn=cfg3a_extra, e2e_reps=3, cpu_fn=cfg3a_cpu)
         if 'cfg4' in want:
             configs.append(run_cfg4(E, torch, WL, cpu_on))
         if 'single_field' in want:
@@ -517,7 +614,17 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + '\n').encode())
+        detail = json.dumps(out)
+        for path in (os.path.join(REPO, 'bench_detail.json'), os.path.join(REPO, 'gpurun_out', 'bench_detail.json')):
+            try:
+                if os.path.isdir(os.path.dirname(path)):
+                    with open(path, 'w') as fh:
+                        fh.write(detail + '\n')
+            except OSError:
+                pass
+        sys.stderr.write(detail + '\n')
+        sys.stderr.flush()
+        os.write(real_stdout, (compact_line(out) + '\n').encode())
 
 
 def single_field_latency(torch):

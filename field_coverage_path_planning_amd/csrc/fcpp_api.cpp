@@ -209,6 +209,10 @@ struct fcpp_batch {
     int two_stream_max = 512;    // ... when there are at most this many general tiles (FCPP_TWO_STREAM_MAX, read at batch creation)
     int sparse_beside_max = 0;   // ... or at most this many wave tiles (FCPP_SPARSE_BESIDE_MAX; 0 = never: measured, see fcpp_batch_run)
     fcpp_setup_times setup = {};
+    // every stream this batch's kernels were enqueued on (callers re-bind the context's stream between calls: engine.py binds torch's
+    // current stream): fcpp_batch_destroy drains them all before the tables go back to the context as the next batch's allocation
+    std::vector<hipStream_t> used_streams;
+    void note_stream(hipStream_t s) { if (std::find(used_streams.begin(), used_streams.end(), s) == used_streams.end()) used_streams.push_back(s); }
     ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
 };
 
@@ -490,6 +494,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tm.threads = WorkerPool::width();
     std::string err;
     hipStream_t st = c->stream;
+    b->note_stream(st);
 
     // ---- 1. the turn templates go first: their two launches and the copy back run on the device while the host plans the fields
     auto t0 = std::chrono::steady_clock::now();
@@ -655,6 +660,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     if (!stats) return fail(FCPP_EINVAL, "stats pointer is NULL");
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
+    b->note_stream(st);
     if (mode == 0 && !b->til0_built) {      // the staged pipeline's own tiling: plain tiles of at most TILE_POINTS points
         Tiling t0;
         std::vector<int64_t> offs((size_t)b->n_fields + 1, 0);
@@ -834,6 +840,7 @@ int fcpp_batch_connectors(fcpp_batch *b, double *approach_xy, double *departure_
     if (b->n_fields == 0) return FCPP_OK;
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
+    b->note_stream(st);
     if (approach_xy) LAUNCHCHK(launch_straight(st, b->n_fields, b->t.seg, 50, b->t.seg_mask, approach_xy));
     if (departure_xy)
         LAUNCHCHK(launch_straight(st, b->n_fields, b->t.seg + 4 * b->n_fields, 50, b->t.seg_mask + b->n_fields, departure_xy));
@@ -845,6 +852,8 @@ int fcpp_batch_destroy(fcpp_batch *b)
     if (!b) return FCPP_OK;
     fcpp_ctx *c = b->ctx;
     (void)hipSetDevice(c->device);
+    // (the tables may become the next batch's: nothing that reads them may still be running -- on whichever streams this batch ran)
+    for (hipStream_t s : b->used_streams) (void)hipStreamSynchronize(s);
     (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (b->slab) {      // the larger of this allocation and the context's spare stays for the next batch
