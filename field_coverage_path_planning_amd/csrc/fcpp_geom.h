@@ -194,6 +194,21 @@ FCPP_HD void cac_world_point(const CacShape &sh, double x0, double y0, int q, do
     y = y0 + Re * ry;
 }
 
+// the same from a unit-shape point (X, Y) = cac_unit_point(sh, s / Re) with Y already multiplied by the turn sign: what the setup of a
+// field needs of a corner turn's last two samples, whose unit points are the same for every field of a batch
+FCPP_HD void cac_world_from_unit(double X, double Y, double x0, double y0, int q, double Re, double &x, double &y)
+{
+    double rx, ry;
+    switch (q & 3) {
+        case 0: rx = X; ry = Y; break;
+        case 1: rx = -Y; ry = X; break;
+        case 2: rx = -X; ry = -Y; break;
+        default: rx = Y; ry = -X; break;
+    }
+    x = x0 + Re * rx;
+    y = y0 + Re * ry;
+}
+
 // 90-degree corner arc, quadrant formulas MLP:1049-1060 / 1592-1603
 FCPP_HD void corner_arc_point(int ci, double cx, double cy, double R, double c, double s, double &x, double &y)
 {

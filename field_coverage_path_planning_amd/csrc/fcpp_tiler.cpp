@@ -33,8 +33,6 @@ struct BlockTiles {
 
 namespace {
 
-constexpr int WAVE_HALO_MAX = 40;
-
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // tiler of one block: scratch that lives across its fields
@@ -73,26 +71,7 @@ struct FieldTiler {
         if (i < F.gen_main) {
             int64_t idx = i / per, off = i - idx * per;
             for (; i < last_excl && i < F.gen_main; ++i, ++o) {
-                const int64_t pi = F.reverse_order ? (F.P - 1 - idx) : idx;
-                const double y = F.min_y + (double)pi * F.W;
-                const bool go_left = F.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
-                double px, py;
-                if (off < F.n_line) {
-                    px = go_left ? linspace_at(F.lex, F.lsx, -F.line_step, F.n_line, off) : linspace_at(F.lsx, F.lex, F.line_step, F.n_line, off);
-                    py = y;
-                } else {
-                    const Pt2 t = tc.tu[off - F.n_line];
-                    const bool turn_right = !go_left;
-                    if (F.turn_model == FCPP_TURN_ARC) px = turn_right ? (F.max_x - t.x) : (F.min_x + t.x);
-                    else px = turn_right ? ((F.max_x - F.R) + t.x) : ((F.min_x + F.R) - t.x);
-                    py = y + t.y;
-                }
-                if (F.rotated) {
-                    const double tx = px - F.rot_cx, ty = py - F.rot_cy;
-                    px = (tx * F.rot_cos - ty * F.rot_sin) + F.rot_cx;
-                    py = (tx * F.rot_sin + ty * F.rot_cos) + F.rot_cy;
-                }
-                hx[o] = px; hy[o] = py;
+                tiler_point_main(F, tc.tu, idx, off, hx[o], hy[o]);
                 if (++off == per) { off = 0; ++idx; }
             }
         }
@@ -102,33 +81,7 @@ struct FieldTiler {
         while (i < last_excl) {
             const DevPrim &q = prims[k];
             const int64_t end = std::min<int64_t>(last_excl, q.start + q.n);
-            for (; i < end; ++i, ++o) {
-                const int64_t r = i - q.start;
-                double px, py;
-                if (q.kind == PRIM_LINSPACE) { px = linspace_at(q.a[0], q.a[2], q.a[4], q.n, r); py = linspace_at(q.a[1], q.a[3], q.a[5], q.n, r); }
-                else if (q.kind == PRIM_POINT) { px = q.a[0]; py = q.a[1]; }
-                else if (q.kind == PRIM_RAY) { const double t = linspace_at(0.0, q.a[4], q.a[5], q.n, r); px = q.a[0] + t * q.a[2]; py = q.a[1] + t * q.a[3]; }
-                else if (q.kind == PRIM_UTURN) {
-                    const Pt2 t = tc.tu[r];
-                    const bool turn_right = q.form & 1;
-                    if (!(q.form & 4)) px = turn_right ? (q.a[0] - t.x) : (q.a[0] + t.x);
-                    else px = turn_right ? (q.a[0] + t.x) : (q.a[0] - t.x);
-                    py = q.a[1] + t.y;
-                    if (q.form & 2) {
-                        const double tx = px - q.a[4], ty = py - q.a[5];
-                        px = (tx * q.a[2] - ty * q.a[3]) + q.a[4];
-                        py = (tx * q.a[3] + ty * q.a[2]) + q.a[5];
-                    }
-                } else {
-                    const Pt2 t = tc.tc[r];
-                    const int ci = q.kind == PRIM_ARC ? q.form : ((q.form + 3) & 3);
-                    if (ci == 0)      { px = q.a[0] + t.x; py = q.a[1] + t.y; }
-                    else if (ci == 1) { px = q.a[0] - t.y; py = q.a[1] + t.x; }
-                    else if (ci == 2) { px = q.a[0] - t.x; py = q.a[1] - t.y; }
-                    else              { px = q.a[0] + t.y; py = q.a[1] - t.x; }
-                }
-                hx[o] = px; hy[o] = py;
-            }
+            for (; i < end; ++i, ++o) tiler_point_prim(q, tc.tu, tc.tc, i - q.start, hx[o], hy[o]);
             ++k;
         }
     }
@@ -143,7 +96,7 @@ struct FieldTiler {
         const DevField &F = *f;
         const int WAVE_LANES = tc.wave_points;           // points of a wave tile (fcpp_sparse.hip: one wavefront per wave tile)
         const int64_t n = F.n_total;
-        const double cap = tc.u_cap * (1.0 + 1e-9) + 1e-12;
+        const double cap = tiler_halo_cap(tc.u_cap);
         // d[i - lo] = |p_i - p_(i-1)| for the stretch and WAVE_HALO_MAX + 2 points either side
         const int64_t lo = std::max<int64_t>(a - WAVE_HALO_MAX - 2, 1), hi = std::min<int64_t>(b + WAVE_HALO_MAX + 2, n);   // i in [lo, hi)
         if (hi - lo > (int64_t)1 << 22) { ++out.wave_fail[4]; return false; }
@@ -161,42 +114,13 @@ struct FieldTiler {
         auto all_inside = [&](int64_t s, int64_t c) -> bool {
             for (int64_t i = s; i < s + c; ++i) {
                 if (i < lo - 1 || i >= hi) return false;
-                const double px = hx[(size_t)(i - lo + 1)], py = hy[(size_t)(i - lo + 1)];
-                for (int e = 0; e < 4; ++e)
-                    if (!(F.ex[e] * px + F.ey[e] * py + F.eo[e] >= tc.fence_margin)) return false;
+                if (!tiler_inside(F, hx[(size_t)(i - lo + 1)], hy[(size_t)(i - lo + 1)], tc.fence_margin)) return false;
             }
             return true;
         };
         auto dist = [&](int64_t i) { return d[(size_t)(i - lo)]; };     // lo <= i < hi by the halo bound below
-        // (a step within 0.1 % of the 1e-6 threshold counts neither as skipped nor as a coupling)
-        auto back_halo = [&](int64_t s) -> int {
-            if (s == 0) return 0;
-            const int64_t j = s - 1;
-            int64_t m = j;
-            double acc = 0.0;
-            for (;;) {
-                if (m == 0) return (int)(j + 1);
-                const double dm = dist(m);
-                if (dm < 0.999e-6) return (int)(j - (m - 1) + 1);
-                if (dm > 1.001e-6) acc += tc.two_a * dm;
-                --m;
-                if (acc >= cap) return (int)(j - m + 1);
-                if (j - m + 1 > WAVE_HALO_MAX) return -1;
-            }
-        };
-        auto fwd_halo = [&](int64_t e) -> int {
-            if (e == n - 1) return 0;
-            int64_t m = e;
-            double acc = 0.0;
-            for (;;) {
-                const double dm = dist(m + 1);
-                if (dm < 0.999e-6) return (int)(m + 1 - e);
-                if (dm > 1.001e-6) acc += tc.two_a * dm;
-                ++m;
-                if (m == n - 1 || acc >= cap) return (int)(m - e);
-                if (m - e > WAVE_HALO_MAX) return -1;
-            }
-        };
+        auto back_halo = [&](int64_t s) -> int { return tiler_back_halo(dist, s, tc.two_a, cap); };
+        auto fwd_halo = [&](int64_t e) -> int { return tiler_fwd_halo(dist, e, n, tc.two_a, cap); };
         const size_t mark = out.tiles.size(), mark_w = out.wtiles.size();
         const int64_t inside_mark = out.wave_inside;
         auto refuse = [&](int why) { ++out.wave_fail[why]; out.tiles.resize(mark); out.wtiles.resize(mark_w); out.wave_inside = inside_mark; return false; };
@@ -280,11 +204,7 @@ struct FieldTiler {
         const int64_t cap = TILE_POINTS - 2, k = (Z + cap - 1) / cap, base = Z / k, rem = Z % k;
         for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(zs, c, kind, i0, o0); zs += c; o0 += c; }
     }
-    int64_t need_for(double c_nom, double step_len) const
-    {
-        if (!(step_len >= 1e-6)) return -1;
-        return (int64_t)(c_nom / (tc.two_a * step_len)) + 3;
-    }
+    int64_t need_for(double c_nom, double step_len) const { return tiler_need_for(c_nom, step_len, tc.two_a); }
 
     // Tiles never straddle fields and hold at most TILE_POINTS points.  Every straight primitive -- swath lines of layer 1, headland
     // straights of layer 2 -- is cut as
@@ -424,7 +344,7 @@ struct FieldTiler {
             for (int64_t k = out.w0[k_local]; k < out.w0[k_local + 1]; ++k) out.work_wave_points += out.wtiles[(size_t)k].count;
         } else {
             for (int64_t k = out.w0[k_local]; k < out.w0[k_local + 1]; ++k) out.open_wave.push_back((int32_t)k);
-            out.cls[ne <= 64 ? 0 : (ne <= 256 ? 1 : (ne <= tc.reduce_wg_max ? 2 : 3))].push_back((int32_t)field);
+            out.cls[tiler_reduce_class(ne, tc.reduce_wg_max)].push_back((int32_t)field);
         }
         out.n_runs += (int64_t)rv.size();
         // Chunks: every run is cut on 512-point boundaries of the batch arrays.  Consecutive layer-1 runs (swath line, U-turn, swath

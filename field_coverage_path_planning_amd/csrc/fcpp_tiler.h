@@ -13,10 +13,9 @@
 #include <vector>
 
 #include "fcpp_internal.h"
+#include "fcpp_tilefn.h"
 
 namespace fcpp {
-
-struct Pt2 { double x, y; };      // layout of HIP's double2: the turn templates as the device built them
 
 // what the tiler needs to know about the batch besides the host plan
 struct TileConsts {

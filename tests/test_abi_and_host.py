@@ -81,11 +81,14 @@ def test_plan_count_vs_golden_and_oracle(golden_plans):
                   'rotated', 'start_kept', 'end_kept', 'shape'):
             assert getattr(info, k) == getattr(p, k), (name, k)
         assert list(info.n_reverse) == p.n_reverse, name
-        assert info.rotation_angle == p.rotation_angle and info.field_length == p.field_length
+        # (the library's setup takes its few transcendentals from csrc/fcpp_math.h -- plain IEEE operations, bit-identical on the host and
+        # on the GPU, where the setup of a batch runs -- the oracle from the platform libm: the last bit may differ, no integer does)
+        assert abs(info.rotation_angle - p.rotation_angle) <= 4e-16 and info.field_length == p.field_length
         if p.approach is not None:
-            assert tuple(info.approach_to) == tuple(p.approach[-1]) and tuple(info.approach_from) == tuple(p.approach[0])
+            np.testing.assert_allclose(tuple(info.approach_to), tuple(p.approach[-1]), rtol=0, atol=1e-11)
+            assert tuple(info.approach_from) == tuple(p.approach[0])
         if p.departure is not None:
-            assert tuple(info.departure_from) == tuple(p.departure[0])
+            np.testing.assert_allclose(tuple(info.departure_from), tuple(p.departure[0]), rtol=0, atol=1e-11)
 
 
 def test_plan_count_dense_and_clothoid_vs_oracle():
