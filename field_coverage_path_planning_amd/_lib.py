@@ -72,7 +72,7 @@ class FieldStats(C.Structure):
 class SetupTimes(C.Structure):
     """fcpp_setup_times: where the time of fcpp_batch_create went"""
     _fields_ = [('host_plan_ms', C.c_double), ('templates_ms', C.c_double), ('tiler_ms', C.c_double), ('image_ms', C.c_double),
-                ('h2d_ms', C.c_double), ('total_ms', C.c_double), ('image_bytes', C.c_int64), ('threads', C.c_int32), ('_pad', C.c_int32)]
+                ('h2d_ms', C.c_double), ('total_ms', C.c_double), ('image_bytes', C.c_int64), ('threads', C.c_int32), ('device_setup', C.c_int32)]
 
 
 class GaConfig(C.Structure):
@@ -95,6 +95,8 @@ class CoverJob(C.Structure):
                 ('outer', C.c_double * 12), ('inner', C.c_double * 12)]
 
 
+SETUP_AUTO, SETUP_HOST, SETUP_DEVICE = 0, 1, 2      # fcpp_ctx_set_setup
+
 STATS_DOUBLES = 9   # leading float64 members of FieldStats
 STATS_WORDS = 13    # 8-byte words per FieldStats
 
@@ -109,6 +111,7 @@ PROTOTYPES = [
     ('fcpp_ctx_destroy', C.c_int, [_VP]),
     ('fcpp_ctx_set_stream', C.c_int, [_VP, _VP]),
     ('fcpp_ctx_synchronize', C.c_int, [_VP]),
+    ('fcpp_ctx_set_setup', C.c_int, [_VP, C.c_int]),
     ('fcpp_malloc', C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
     ('fcpp_free', C.c_int, [_VP, _VP]),
     ('fcpp_outputs_alloc', C.c_int, [_VP, C.c_int64, C.c_int64] + [C.POINTER(_VP)] * 5),
@@ -142,6 +145,9 @@ PROTOTYPES = [
     ('fcpp_best_connections', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ('fcpp_ga_evolve', C.c_int, [_VP, C.c_int32, C.POINTER(GaConfig), _VP, _VP, _VP, _VP, C.POINTER(GaResult)]),
     ('fcpp_cover_grid', C.c_int, [_VP, C.c_int64, C.POINTER(CoverJob), C.c_int64, _VP, _VP, _VP, _VP]),
+    ('fcpp_debug_math', C.c_int, [C.c_int, C.c_int64, _VP, _VP, _VP, _VP]),
+    ('fcpp_debug_math_dev', C.c_int, [_VP, C.c_int, C.c_int64, _VP, _VP, _VP, _VP]),
+    ('fcpp_batch_debug_table', C.c_int, [_VP, C.c_int, _VP, C.c_int64, c_i64_p]),
 ]
 
 _lib = None
@@ -167,7 +173,7 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.fcpp_abi_version() != 3:
+        if lib.fcpp_abi_version() != 4:
             raise ImportError('libfcpp.so ABI version mismatch')
         _lib = lib
     return _lib

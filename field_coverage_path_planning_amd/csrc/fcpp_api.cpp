@@ -16,6 +16,7 @@
 #include "fcpp_cover.h"
 #include "fcpp_ga.h"
 #include "fcpp_device.h"
+#include "fcpp_devplan.h"
 #include "fcpp_internal.h"
 #include "fcpp_parallel.h"
 #include "fcpp_tiler.h"
@@ -171,6 +172,11 @@ struct fcpp_ctx {
     void *spare = nullptr; size_t spare_cap = 0;
     std::shared_ptr<TemplateSet> templates;         // the last batch's turn templates
     fcpp_setup_times last_setup = {};
+    // device-side setup (fcpp_devplan.h): FCPP_SETUP_AUTO / _HOST / _DEVICE; its scratch (grow-only) and a small pinned block for the
+    // totals that come back in the middle of it
+    int setup_mode = FCPP_SETUP_AUTO;
+    void *plan_scratch = nullptr; size_t plan_scratch_cap = 0;
+    int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values
 };
 
 // device pointers of a batch's tables: all inside ONE allocation laid out by the tiler (fcpp_tiler.h: ImageLayout)
@@ -317,7 +323,15 @@ int fcpp_ctx_create(int device_id, fcpp_ctx **out)
         return fail(FCPP_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     c->stream = c->own;
+    if (const char *e = getenv("FCPP_SETUP")) c->setup_mode = !strcmp(e, "host") ? FCPP_SETUP_HOST : (!strcmp(e, "device") ? FCPP_SETUP_DEVICE : FCPP_SETUP_AUTO);
     *out = c;
+    return FCPP_OK;
+}
+
+int fcpp_ctx_set_setup(fcpp_ctx *c, int mode)
+{
+    if (!c || mode < FCPP_SETUP_AUTO || mode > FCPP_SETUP_DEVICE) return fail(FCPP_EINVAL, "bad arguments");
+    c->setup_mode = mode;
     return FCPP_OK;
 }
 
@@ -332,6 +346,8 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     free_paths_cache(c);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->spare) (void)hipFree(c->spare);
+    if (c->plan_scratch) (void)hipFree(c->plan_scratch);
+    if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
     c->templates.reset();
     delete c;
     return FCPP_OK;
@@ -475,6 +491,184 @@ double ms_since(std::chrono::steady_clock::time_point t0)
 }
 }
 
+namespace {
+constexpr int kNotOnDevice = 1;      // try_device_setup: this batch is the host's (reason in err)
+
+// pointers of the fused pipeline's tables inside the slab
+void bind_tables(fcpp_batch *b)
+{
+    unsigned char *d = static_cast<unsigned char *>(b->slab);
+    const ImageLayout &lay = b->lay;
+    FusedTables &t = b->t;
+    t.fields = reinterpret_cast<DevField *>(d + lay.fields); t.prims = reinterpret_cast<DevPrim *>(d + lay.prims);
+    t.tiles = reinterpret_cast<DevTile *>(d + lay.tiles); t.wave_tiles = reinterpret_cast<DevWaveTile *>(d + lay.wtiles);
+    t.general_ids = reinterpret_cast<int32_t *>(d + lay.general_ids);
+    t.chunks = reinterpret_cast<DevTile *>(d + lay.chunks); t.span_chunks = reinterpret_cast<DevTile *>(d + lay.span_chunks);
+    t.stat_ids = reinterpret_cast<int32_t *>(d + lay.stat_ids); t.stat_first = reinterpret_cast<int64_t *>(d + lay.stat_first);
+    t.stat_run = reinterpret_cast<int64_t *>(d + lay.stat_run); t.red_paths = reinterpret_cast<int32_t *>(d + lay.red_paths);
+    t.field_work = reinterpret_cast<DevFieldWork *>(d + lay.field_work); t.open_wave_ids = reinterpret_cast<int32_t *>(d + lay.open_wave_ids);
+    if (lay.n_polys > 0) {
+        t.obs_off = reinterpret_cast<int64_t *>(d + lay.obs_off); t.obs_x = reinterpret_cast<double *>(d + lay.obs_x);
+        t.obs_y = reinterpret_cast<double *>(d + lay.obs_y); t.obs_bbox = reinterpret_cast<double *>(d + lay.obs_bbox);
+    }
+    t.seg = reinterpret_cast<double *>(d + lay.seg); t.seg_mask = reinterpret_cast<int32_t *>(d + lay.seg_mask);
+    t.partial = reinterpret_cast<TilePartial *>(d + lay.partial); t.red_scratch = d ? reinterpret_cast<char *>(d + lay.red_scratch) : nullptr;
+    t.field_junc = reinterpret_cast<double2 *>(d + lay.field_junc);
+    t.work_totals = reinterpret_cast<TilePartial *>(d + lay.work_totals);
+}
+
+// the batch's device allocation: the context's spare if it is large enough
+int take_slab(fcpp_ctx *c, fcpp_batch *b, std::string &err)
+{
+    const ImageLayout &lay = b->lay;
+    if (c->spare && c->spare_cap >= lay.total_bytes) { b->slab = c->spare; b->slab_bytes = c->spare_cap; c->spare = nullptr; c->spare_cap = 0; return FCPP_OK; }
+    hipError_t e = hipMalloc(&b->slab, std::max<size_t>(lay.total_bytes, 256));
+    if (e != hipSuccess) { b->slab = nullptr; err = std::string("batch tables: ") + hipGetErrorString(e); return FCPP_ENOMEM; }
+    b->slab_bytes = std::max<size_t>(lay.total_bytes, 256);
+    return FCPP_OK;
+}
+
+#define DEVCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return FCPP_EHIP; } \
+    } while (0)
+
+// FCPP_OK: the batch is set up (tables on the device, info on the host); kNotOnDevice: not this path's batch; else the error.
+// fresh_templates: the batch's template set is still on its way back from the device (cleared once this path has waited for it)
+int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_field *fields, const fcpp_polys *obstacles, bool &fresh_templates,
+                     std::string &err)
+{
+    const fcpp_options &opt = b->opt;
+    fcpp_setup_times &tm = b->setup;
+    if (c->setup_mode == FCPP_SETUP_HOST) { err = "host setup requested"; return kNotOnDevice; }
+    if (n_fields <= 0) { err = "empty batch"; return kNotOnDevice; }
+    if (opt.sample_spacing != 0.0) { err = "sample_spacing > 0 (the device planner takes the reference's sampling)"; return kNotOnDevice; }
+    if (opt.obstacle_mode != FCPP_OBSTACLES_FLAG) { err = "obstacle-aware swaths are planned on the host"; return kNotOnDevice; }
+    if (tune_enabled()) { err = "FCPP_TUNE: the tuning knobs are the host tiler's"; return kNotOnDevice; }
+    PlanConsts pc;
+    TurnTemplates tt;
+    int rc = plan_prepare(b->veh, opt, pc, tt, err);
+    if (rc != FCPP_OK) return rc;
+    if ((rc = validate_polys(obstacles, err)) != FCPP_OK) return rc;
+    if (pc.max_prims > DEVPLAN_PRIMS_CAP) { err = "too many headland loops for the device planner"; return kNotOnDevice; }
+    hipStream_t st = c->stream;
+    auto t0 = std::chrono::steady_clock::now();
+
+    // templates on the host (closed-form test); a fresh set is on its way back
+    if (fresh_templates) { DEVCHK(hipStreamSynchronize(st)); fresh_templates = false; }
+    c->templates = b->templates;
+    const TemplateSet &ts = *b->templates;
+    b->cst = make_const(b->veh, opt);
+    b->cst.shapes = ts.shapes.p;
+    b->cst.tmpl_u = ts.tmpl_u.p; b->cst.tmpl_c = ts.tmpl_c.p; b->cst.tmpl_u_dk = ts.tmpl_u_dk.p;
+    b->cst.tmpl_n = (int)ts.tt.nu; b->cst.tmpl_nc = std::max(1, (int)ts.tt.nc);
+    const bool turn_quiet = ts.tt.nu >= 3 && closed_form_turns(b->veh, ts.tt, ts.h_tu, ts.h_dk, b->cst);
+    tm.templates_ms += ms_since(t0);
+
+    // scratch + the field records
+    t0 = std::chrono::steady_clock::now();
+    DevPlanScratch off;
+    const size_t need = devplan_scratch_layout(n_fields, pc.max_prims, &off);
+    if (c->plan_scratch_cap < need) {
+        if (c->plan_scratch) { DEVCHK(hipStreamSynchronize(st)); (void)hipFree(c->plan_scratch); c->plan_scratch = nullptr; c->plan_scratch_cap = 0; }
+        const size_t want = need + need / 4;
+        if (hipMalloc(&c->plan_scratch, want) != hipSuccess) { (void)hipGetLastError(); err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
+        c->plan_scratch_cap = want;
+    }
+    if (!c->plan_totals_host) DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipHostMallocDefault));
+    unsigned char *sb = static_cast<unsigned char *>(c->plan_scratch);
+    DevPlanScratch s;
+    s.fields_in = reinterpret_cast<fcpp_field *>(sb + (size_t)off.fields_in); s.info = reinterpret_cast<fcpp_field_info *>(sb + (size_t)off.info);
+    s.fields_tmp = reinterpret_cast<DevField *>(sb + (size_t)off.fields_tmp); s.prims_tmp = reinterpret_cast<DevPrim *>(sb + (size_t)off.prims_tmp);
+    s.counts = reinterpret_cast<int64_t *>(sb + (size_t)off.counts); s.bases = reinterpret_cast<int64_t *>(sb + (size_t)off.bases);
+    s.blk_sums = reinterpret_cast<int64_t *>(sb + (size_t)off.blk_sums); s.totals = reinterpret_cast<int64_t *>(sb + (size_t)off.totals);
+    DEVCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
+
+    DevTileConsts tc;
+    tc.tu = reinterpret_cast<const Pt2 *>(ts.tmpl_u.p); tc.tc = reinterpret_cast<const Pt2 *>(ts.tmpl_c.p);
+    tc.nu = ts.tt.nu; tc.nc = ts.tt.nc;
+    tc.turn_quiet = turn_quiet; tc.wave_factor = 24; tc.field_work_tiles = FIELD_WORK_TILES; tc.max_prims = pc.max_prims;
+    tc.two_a = 2 * b->cst.a_lon; tc.u_cap = b->cst.u_cap; tc.c_line = b->cst.ms_work * b->cst.ms_work;
+    tc.fence_margin = 1e-7 - opt.geofence_tol;
+    tc.reduce_wg_max = 1024;
+    const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
+    int lrc = launch_devplan_count(st, n_fields, pc, tc, s, n_polys, obstacles != nullptr);
+    if (lrc) { err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    int64_t *tot = c->plan_totals_host;
+    DEVCHK(hipMemcpyAsync(tot, s.totals, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    DEVCHK(hipStreamSynchronize(st));
+    tm.host_plan_ms = ms_since(t0);          // (the plan and the counting pass, on the device)
+    if (tot[PC_COLS + PF_BAD_OBSTACLES]) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
+    if (tot[PC_COLS + PF_FALLBACK]) { err = "a field beyond the device planner's limits (general stretch, primitives)"; return kNotOnDevice; }
+    if (tot[PC_POINTS] > kCountCap) { err = "batch too large"; return FCPP_ESIZE; }
+    if (tot[PC_PRIMS] > ((int64_t)1 << 26)) { err = "too many path primitives in one batch: split the batch"; return FCPP_ESIZE; }
+    if (tot[PC_TILES] > INT32_MAX) { err = "too many tiles in one batch: split the batch"; return FCPP_ESIZE; }
+
+    // the image's layout from the totals, the allocation, the obstacle table
+    t0 = std::chrono::steady_clock::now();
+    ImageLayout &lay = b->lay;
+    lay = ImageLayout();
+    lay.n_fields = n_fields; lay.n_prims = tot[PC_PRIMS]; lay.wave_tile_points = 128;
+    lay.n_tiles = tot[PC_TILES]; lay.n_wave = tot[PC_WAVE]; lay.n_general = tot[PC_GENERAL]; lay.n_stat = tot[PC_STAT];
+    lay.n_chunks = 0; lay.n_span_chunks = tot[PC_SPAN]; lay.n_runs = tot[PC_RUNS];
+    for (int k = 0; k < 4; ++k) lay.n_red[k] = tot[PC_CLS0 + k];
+    lay.n_work[0] = tot[PC_WORK]; lay.n_field_work = tot[PC_WORK]; lay.n_open_wave = tot[PC_OPEN];
+    lay.quiet_points = tot[PC_SPAN_PTS]; lay.span_points = tot[PC_SPAN_PTS]; lay.chunk_points = 0; lay.wave_points = tot[PC_WAVE_PTS];
+    lay.work_wave_points = tot[PC_WORK_WAVE_PTS]; lay.wave_inside = tot[PC_WAVE_INSIDE];
+    lay.n_polys = n_polys; lay.n_poly_verts = n_polys > 0 ? obstacles->offsets[n_polys] : 0;
+    layout_image(lay);
+    if ((rc = take_slab(c, b, err)) != FCPP_OK) return rc;
+    bind_tables(b);
+    if (lay.n_polys > 0) {
+        // (the obstacle part of the image through the context's pinned staging memory, pageable when that cannot be had)
+        const size_t o0 = lay.obs_off, o1 = lay.seg;
+        std::vector<unsigned char> tmp;
+        unsigned char *img = nullptr;
+        if (o1 <= kStageMax) {
+            if (c->stage_cap < o1) {
+                if (c->stage) { (void)hipHostFree(c->stage); c->stage = nullptr; c->stage_cap = 0; }
+                if (hipHostMalloc(&c->stage, o1 + o1 / 4, hipHostMallocDefault) == hipSuccess) c->stage_cap = o1 + o1 / 4;
+                else { c->stage = nullptr; (void)hipGetLastError(); }
+            }
+            if (c->stage_cap >= o1) img = static_cast<unsigned char *>(c->stage);
+        }
+        if (!img) { try { tmp.resize(o1); } catch (const std::bad_alloc &) { err = "out of host memory"; return FCPP_ENOMEM; } img = tmp.data(); }
+        fill_obstacles(obstacles, lay, img);
+        DEVCHK(hipMemcpyAsync(static_cast<unsigned char *>(b->slab) + o0, img + o0, o1 - o0, hipMemcpyHostToDevice, st));
+        if (!tmp.empty()) DEVCHK(hipStreamSynchronize(st));
+    }
+    tm.image_ms = ms_since(t0);
+    tm.image_bytes = (int64_t)((size_t)n_fields * sizeof(fcpp_field) + (lay.n_polys > 0 ? lay.seg - lay.obs_off : 0));
+
+    // the tables, then the per-batch constants of the steps as on the host path
+    t0 = std::chrono::steady_clock::now();
+    DevPlanTables T;
+    T.fields = b->t.fields; T.prims = b->t.prims; T.tiles = b->t.tiles; T.wtiles = b->t.wave_tiles; T.general_ids = b->t.general_ids;
+    T.span_chunks = b->t.span_chunks; T.stat_ids = b->t.stat_ids; T.stat_first = b->t.stat_first; T.stat_run = b->t.stat_run;
+    T.red_paths = b->t.red_paths; T.field_work = b->t.field_work; T.open_wave_ids = b->t.open_wave_ids; T.seg = b->t.seg; T.seg_mask = b->t.seg_mask;
+    lrc = launch_devplan_fill(st, n_fields, tc, s, T);
+    if (lrc) { err = std::string("launch_devplan_fill: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    b->cst.field_junc = b->t.field_junc;
+    lrc = launch_field_junctions(st, n_fields, b->t.fields, b->cst, b->t.field_junc);
+    if (!lrc) lrc = launch_run_consts(st, lay.n_stat, b->t.stat_ids, b->t.stat_run, b->t.tiles, b->t.fields, b->t.prims, b->cst, b->t.partial);
+    if (!lrc) lrc = launch_work_totals(st, lay.n_field_work, b->t.field_work, b->t.stat_run, b->t.partial, b->t.work_totals);
+    if (lrc) { err = std::string("setup kernels: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    // what the host keeps: fcpp_field_info of every field
+    b->hp.info.resize((size_t)n_fields);
+    DEVCHK(hipMemcpyAsync(b->hp.info.data(), s.info, (size_t)n_fields * sizeof(fcpp_field_info), hipMemcpyDeviceToHost, st));
+    DEVCHK(hipStreamSynchronize(st));
+    b->hp.tt = tt;
+    b->hp.total_points = tot[PC_POINTS]; b->hp.total_prims = tot[PC_PRIMS];
+    b->hp.fields.clear(); b->hp.blocks.clear(); b->hp.same_as.clear();
+    tm.tiler_ms = ms_since(t0);              // (the fill pass, the setup kernels and the copy back of the field records)
+    tm.h2d_ms = 0.0;
+    tm.device_setup = 1;
+    return FCPP_OK;
+}
+#undef DEVCHK
+}  // namespace
+
 int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
                       const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **out)
 {
@@ -507,6 +701,23 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         if (rc != FCPP_OK) return rc;
     }
     tm.templates_ms = ms_since(t0);
+
+    // ---- 2a. the setup on the DEVICE (fcpp_devplan.h) for batches at the reference's own sampling: the field records go up, the plan
+    // function the host would run (fcpp_planfn.h) runs one thread per field, the tiler's cut one wavefront per field, the totals come
+    // back once (they size the tables and the output arrays), the tables are written in place.  The host plans nothing per field.
+    {
+        int rc = try_device_setup(c, b.get(), n_fields, fields, obstacles, fresh, err);
+        if (rc == FCPP_OK) {
+            tm.total_ms = ms_since(t_begin);
+            c->last_setup = tm;
+            *out = b.release();
+            return FCPP_OK;
+        }
+        if (b->slab) { (void)hipStreamSynchronize(c->stream); (void)hipFree(b->slab); b->slab = nullptr; }
+        if (rc != kNotOnDevice) return fail(rc, err);
+        if (c->setup_mode == FCPP_SETUP_DEVICE) return fail(FCPP_EUNSUPPORTED, "FCPP_SETUP_DEVICE: " + err);
+        err.clear();
+    }
 
     // ---- 2. host plan: __init__ + the O(1) decisions of every field, blocks of fields side by side (fcpp_host.cpp)
     t0 = std::chrono::steady_clock::now();
@@ -558,12 +769,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
 
     // ---- 5. the image: one device allocation (the context's spare if it is large enough), the tables written into pinned memory
     t0 = std::chrono::steady_clock::now();
-    if (c->spare && c->spare_cap >= lay.total_bytes) { b->slab = c->spare; b->slab_bytes = c->spare_cap; c->spare = nullptr; c->spare_cap = 0; }
-    else {
-        hipError_t e = hipMalloc(&b->slab, std::max<size_t>(lay.total_bytes, 256));
-        if (e != hipSuccess) { b->slab = nullptr; return fail(FCPP_ENOMEM, std::string("batch tables: ") + hipGetErrorString(e)); }
-        b->slab_bytes = std::max<size_t>(lay.total_bytes, 256);
-    }
+    if ((rc = take_slab(c, b.get(), err)) != FCPP_OK) return fail(rc, err);
     struct SlabGuard {       // (an error below must not leak the allocation)
         fcpp_batch *b; bool armed = true;
         ~SlabGuard() { if (armed && b->slab) { (void)hipFree(b->slab); b->slab = nullptr; } }
@@ -584,25 +790,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         img = pageable.data();
     }
     tiler.fill(b->hp, obstacles, lay, img);
-    {
-        unsigned char *d = static_cast<unsigned char *>(b->slab);
-        FusedTables &t = b->t;
-        t.fields = reinterpret_cast<DevField *>(d + lay.fields); t.prims = reinterpret_cast<DevPrim *>(d + lay.prims);
-        t.tiles = reinterpret_cast<DevTile *>(d + lay.tiles); t.wave_tiles = reinterpret_cast<DevWaveTile *>(d + lay.wtiles);
-        t.general_ids = reinterpret_cast<int32_t *>(d + lay.general_ids);
-        t.chunks = reinterpret_cast<DevTile *>(d + lay.chunks); t.span_chunks = reinterpret_cast<DevTile *>(d + lay.span_chunks);
-        t.stat_ids = reinterpret_cast<int32_t *>(d + lay.stat_ids); t.stat_first = reinterpret_cast<int64_t *>(d + lay.stat_first);
-        t.stat_run = reinterpret_cast<int64_t *>(d + lay.stat_run); t.red_paths = reinterpret_cast<int32_t *>(d + lay.red_paths);
-        t.field_work = reinterpret_cast<DevFieldWork *>(d + lay.field_work); t.open_wave_ids = reinterpret_cast<int32_t *>(d + lay.open_wave_ids);
-        if (lay.n_polys > 0) {
-            t.obs_off = reinterpret_cast<int64_t *>(d + lay.obs_off); t.obs_x = reinterpret_cast<double *>(d + lay.obs_x);
-            t.obs_y = reinterpret_cast<double *>(d + lay.obs_y); t.obs_bbox = reinterpret_cast<double *>(d + lay.obs_bbox);
-        }
-        t.seg = reinterpret_cast<double *>(d + lay.seg); t.seg_mask = reinterpret_cast<int32_t *>(d + lay.seg_mask);
-        t.partial = reinterpret_cast<TilePartial *>(d + lay.partial); t.red_scratch = d ? reinterpret_cast<char *>(d + lay.red_scratch) : nullptr;
-        t.field_junc = reinterpret_cast<double2 *>(d + lay.field_junc);
-        t.work_totals = reinterpret_cast<TilePartial *>(d + lay.work_totals);
-    }
+    bind_tables(b.get());
     // (the primitives live in the image now; the host keeps the per-field records for fcpp_batch_info and the staged pipeline's tiling)
     for (PlanBlock &blk : b->hp.blocks) std::vector<DevPrim>().swap(blk.prims);
     std::vector<int32_t>().swap(b->hp.same_as);
@@ -664,7 +852,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     if (mode == 0 && !b->til0_built) {      // the staged pipeline's own tiling: plain tiles of at most TILE_POINTS points
         Tiling t0;
         std::vector<int64_t> offs((size_t)b->n_fields + 1, 0);
-        for (int64_t i = 0; i < b->n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.fields[(size_t)i].n_total;
+        for (int64_t i = 0; i < b->n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.info[(size_t)i].n_main + b->hp.info[(size_t)i].n_head;
         t0.build(b->n_fields, offs.data());
         HIPCHK(b->til0.upload(t0, st));
         b->til0_built = true;
@@ -1166,6 +1354,53 @@ int fcpp_ga_fitness(fcpp_ctx *c, int32_t n_nodes, int64_t pop, const double *D, 
         return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     LAUNCHCHK(launch_ga_fitness(c->stream, n_nodes, pop, D, routes, dist, fit, order_mode));
+    return FCPP_OK;
+}
+
+// ---- diagnostics (tests) -------------------------------------------------------------------------------------------------------------
+int fcpp_debug_math(int fn, int64_t n, const double *a, const double *b, double *out0, double *out1)
+{
+    if (fn < 0 || fn > 3 || n < 0 || (n > 0 && (!a || !out0)) || ((fn == 1 || fn == 3) && n > 0 && !b) || (fn == 0 && n > 0 && !out1))
+        return fail(FCPP_EINVAL, "bad arguments");
+    for (int64_t i = 0; i < n; ++i) {
+        if (fn == 0) fc_sincos(a[i], out0[i], out1[i]);
+        else if (fn == 1) out0[i] = atan2_fd(a[i], b[i]);
+        else if (fn == 2) out0[i] = fc_acos(a[i]);
+        else out0[i] = fc_hypot(a[i], b[i]);
+    }
+    return FCPP_OK;
+}
+
+int fcpp_debug_math_dev(fcpp_ctx *c, int fn, int64_t n, const double *a, const double *b, double *out0, double *out1)
+{
+    if (!c || fn < 0 || fn > 3 || n < 0) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    LAUNCHCHK(launch_debug_math(c->stream, fn, n, a, b, out0, out1));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return FCPP_OK;
+}
+
+int fcpp_batch_debug_table(const fcpp_batch *b, int table, void *dst, int64_t cap, int64_t *bytes_out)
+{
+    if (!b || !bytes_out) return fail(FCPP_EINVAL, "bad arguments");
+    const ImageLayout &l = b->lay;
+    const size_t n = (size_t)l.n_fields;
+    const size_t off[] = { l.fields, l.prims, l.tiles, l.wtiles, l.general_ids, l.chunks, l.span_chunks, l.stat_ids, l.stat_first, l.stat_run, l.red_paths,
+                           l.field_work, l.open_wave_ids, l.seg, l.seg_mask, l.partial, l.field_junc, l.work_totals, l.obs_off, l.obs_x, l.obs_y, l.obs_bbox };
+    const size_t len[] = { n * sizeof(DevField), (size_t)l.n_prims * sizeof(DevPrim), (size_t)l.n_tiles * sizeof(DevTile), (size_t)l.n_wave * sizeof(DevWaveTile),
+                           (size_t)l.n_general * 4, (size_t)l.n_chunks * sizeof(DevTile), (size_t)l.n_span_chunks * sizeof(DevTile), (size_t)l.n_stat * 4,
+                           (n + 1) * 8, (size_t)l.n_stat * 8, n * 4, (size_t)l.n_field_work * sizeof(DevFieldWork), (size_t)l.n_open_wave * 4, n * 64, n * 8,
+                           (size_t)l.n_stat * sizeof(TilePartial), n * 16, (size_t)l.n_field_work * sizeof(TilePartial),
+                           l.n_polys > 0 ? (size_t)(l.n_polys + 1) * 8 : 0, (size_t)l.n_poly_verts * 8, (size_t)l.n_poly_verts * 8, (size_t)l.n_polys * 32 };
+    constexpr int kTables = (int)(sizeof(off) / sizeof(off[0]));
+    if (table < 0 || table >= kTables) return fail(FCPP_EINVAL, "no such table");
+    *bytes_out = (int64_t)len[table];
+    if (!dst) return FCPP_OK;
+    if (cap < (int64_t)len[table]) return fail(FCPP_ESIZE, "buffer too small");
+    if (len[table] == 0 || n == 0) return FCPP_OK;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    HIPCHK(hipMemcpy(dst, static_cast<const unsigned char *>(b->slab) + off[table], len[table], hipMemcpyDeviceToHost));
     return FCPP_OK;
 }
 

@@ -1,0 +1,71 @@
+// fcpp_devplan.h -- the setup of a batch ON THE DEVICE (fcpp_devplan.hip): what fcpp_host.cpp (one field's plan) and fcpp_tiler.cpp (its
+// path cut into kernel work) do on the host's cores, done by the GPU for batches at the reference's own sampling -- the plan call of the
+// reference, plan_complete_coverage (MLP:387-465), plans a NEW field every time, so the setup belongs on the clock and off the host.
+//
+//   k_plan_fields      one thread per field: fcpp_planfn.h (the same source the host runs) -> fcpp_field_info, DevField, its primitives
+//   k_scan_*           exclusive scans over the fields of the per-field counts (points, primitives; then tiles, wave tiles, entries, ...)
+//   k_tile_fields<0>   one wavefront per field: the tiler's cut at sparse sampling (span of whole passes + wave tiles with halos sized
+//                      from the path's own step lengths), counting its records
+//   k_tile_fields<1>   the same cut again, records written at their scanned positions: the tables of ImageLayout, equal byte for byte
+//                      to what BatchTiler::fill writes on the host (tests/test_gpu_devplan.py)
+// Only the 128-byte fcpp_field records go to the device and the totals (one small copy) and fcpp_field_info come back.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "fcpp_internal.h"
+#include "fcpp_planfn.h"
+#include "fcpp_tilefn.h"
+
+namespace fcpp {
+
+// columns of the per-field count table (counts[col][field]) and of its exclusive scan (bases[col][field]); totals[col] = sum
+enum PlanCol : int {
+    PC_POINTS = 0, PC_PRIMS, PC_TILES, PC_WAVE, PC_GENERAL, PC_STAT, PC_SPAN, PC_WORK, PC_OPEN, PC_CLS0, PC_CLS1, PC_CLS2, PC_CLS3,
+    PC_RUNS, PC_SPAN_PTS, PC_WAVE_PTS, PC_WORK_WAVE_PTS, PC_WAVE_INSIDE, PC_COLS
+};
+// totals[PC_COLS + k]: flags the kernels raise
+enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_COUNT = 2 };
+
+// what the device tiler needs to know about the batch (TileConsts of fcpp_tiler.h with the templates on the device)
+struct DevTileConsts {
+    const Pt2 *tu, *tc;           // the batch's U-turn / corner templates (device)
+    int32_t nu, nc;
+    int32_t turn_quiet, wave_factor, field_work_tiles, max_prims;
+    double two_a, u_cap, c_line, fence_margin;
+    int64_t reduce_wg_max;
+};
+
+// the device planner's scratch: one allocation the context keeps (grow-only); all pointers device
+struct DevPlanScratch {
+    fcpp_field *fields_in;        // n (copied from the host)
+    fcpp_field_info *info;        // n (copied back)
+    DevField *fields_tmp;         // n: pt_off / prim_first still relative to the field
+    DevPrim *prims_tmp;           // n x max_prims
+    int64_t *counts, *bases;      // PC_COLS x n
+    int64_t *blk_sums;            // PC_COLS x blocks of 1024 fields
+    int64_t *totals;              // PC_COLS + PF_COUNT
+};
+size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *offsets_as_pointers /* offsets from 0, cast to pointers */);
+
+// the tables the fill pass writes (pointers into the batch's slab, laid out by the host from the totals)
+struct DevPlanTables {
+    DevField *fields; DevPrim *prims; DevTile *tiles; DevWaveTile *wtiles; int32_t *general_ids; DevTile *span_chunks;
+    int32_t *stat_ids; int64_t *stat_first, *stat_run; int32_t *red_paths; DevFieldWork *field_work; int32_t *open_wave_ids;
+    double *seg; int32_t *seg_mask;
+};
+
+// the device tiler's LDS window over a field's general stretch (it slides), and the most primitives a field may have (8-bit indices in
+// that window); a batch whose vehicle needs more (31+ headland loops) is set up on the host
+constexpr int DEVPLAN_WINDOW = 1632;
+constexpr int DEVPLAN_PRIMS_CAP = 255;
+
+// phase 1: plan + count.  Enqueues k_plan_fields, the scans and the counting pass; afterwards totals[] holds the sums and the flags.
+int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, int64_t n_polys,
+                         int check_obstacles);
+// phase 2: the tables.  `bases` / `totals` as phase 1 left them.
+int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevPlanScratch &s, const DevPlanTables &t);
+// fcpp_math.h on the device (tests): fn 0 sincos, 1 atan2(a, b), 2 acos(a), 3 hypot(a, b)
+int launch_debug_math(hipStream_t st, int fn, int64_t n, const double *a, const double *b, double *out0, double *out1);
+
+}  // namespace fcpp

@@ -1,0 +1,508 @@
+// fcpp_devplan.hip -- batch setup on the device, see fcpp_devplan.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "fcpp_devplan.h"
+
+namespace fcpp {
+
+size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t r = off; off = (off + bytes + 255) & ~(size_t)255; return r; };
+    const size_t nn = (size_t)(n > 0 ? n : 1), nblk = (nn + 1023) / 1024;
+    o->fields_in = reinterpret_cast<fcpp_field *>(take(nn * sizeof(fcpp_field)));
+    o->info = reinterpret_cast<fcpp_field_info *>(take(nn * sizeof(fcpp_field_info)));
+    o->fields_tmp = reinterpret_cast<DevField *>(take(nn * sizeof(DevField)));
+    o->prims_tmp = reinterpret_cast<DevPrim *>(take(nn * (size_t)max_prims * sizeof(DevPrim)));
+    o->counts = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
+    o->bases = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
+    o->blk_sums = reinterpret_cast<int64_t *>(take(nblk * PC_COLS * sizeof(int64_t)));
+    o->totals = reinterpret_cast<int64_t *>(take((PC_COLS + PF_COUNT) * sizeof(int64_t)));
+    return off;
+}
+
+namespace {
+
+// ---- k_plan_fields: one thread per field, the host's own plan function ----------------------------------------------------------------
+struct DevSink {
+    DevPrim *base;
+    int cap;
+    int64_t n;
+    __device__ int64_t size() const { return n; }
+    __device__ void push(const DevPrim &p) { if (n < cap) base[n] = p; ++n; }
+    __device__ void truncate(int64_t m) { n = m; }
+    __device__ int clipped_layer1(const PlanConsts &, const fcpp_field &, const Layer1Frame &, int64_t &) { return FCPP_EUNSUPPORTED; }
+};
+
+__global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, const fcpp_field *__restrict__ fin, fcpp_field_info *__restrict__ info,
+                                                    DevField *__restrict__ ftmp, DevPrim *__restrict__ ptmp, int64_t *__restrict__ counts,
+                                                    int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const fcpp_field f = fin[i];
+    // the field's obstacle range must lie inside the batch's polygon table: the kernels of a step index it
+    if (check_obstacles && (f.n_obstacles < 0 || f.obstacle_first < 0 || (f.n_obstacles > 0 && f.obstacle_first + f.n_obstacles > n_polys)))
+        atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_BAD_OBSTACLES), 1ull);
+    DevSink sink{ ptmp + i * pc.max_prims, pc.max_prims, 0 };
+    const int64_t npts = plan_field_t(pc, f, info[i], ftmp[i], sink);
+    counts[(int64_t)PC_POINTS * n + i] = npts;
+    counts[(int64_t)PC_PRIMS * n + i] = ftmp[i].prim_count;
+    if (sink.n > pc.max_prims) atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), 1ull);
+}
+
+// ---- exclusive scans of count columns [c0, c1) over the fields -------------------------------------------------------------------------
+// inclusive scan of v over the 256 threads of the workgroup; total = the workgroup's sum
+__device__ __forceinline__ int64_t wg_incl_scan(int64_t v, int64_t *lds /* 4 */, int64_t &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    int64_t pre = 0, tot = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int64_t s = lds[q]; if (q < wave) pre += s; tot += s; }
+    __syncthreads();
+    total = tot;
+    return v + pre;
+}
+
+// phase A: sums of blocks of 1024 fields; grid (blocks, columns)
+__global__ __launch_bounds__(256) void k_scan_block_sums(int64_t n, int c0, const int64_t *__restrict__ counts, int64_t *__restrict__ blk_sums, int64_t nblk)
+{
+    __shared__ int64_t lds[4];
+    const int col = c0 + blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * 1024;
+    int64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int64_t i = base + k * 256 + threadIdx.x; if (i < n) v += counts[(int64_t)col * n + i]; }
+    int64_t tot;
+    wg_incl_scan(v, lds, tot);
+    if (threadIdx.x == 0) blk_sums[(int64_t)col * nblk + blockIdx.x] = tot;
+}
+// phase B: one workgroup per column scans the block sums in place (exclusive) and writes the column's total
+__global__ __launch_bounds__(256) void k_scan_block_bases(int c0, int64_t *__restrict__ blk_sums, int64_t nblk, int64_t *__restrict__ totals)
+{
+    __shared__ int64_t lds[4];
+    const int col = c0 + blockIdx.x;
+    int64_t carry = 0;
+    for (int64_t b0 = 0; b0 < nblk; b0 += 256) {
+        const int64_t i = b0 + threadIdx.x;
+        const int64_t v = i < nblk ? blk_sums[(int64_t)col * nblk + i] : 0;
+        int64_t tot;
+        const int64_t inc = wg_incl_scan(v, lds, tot);
+        if (i < nblk) blk_sums[(int64_t)col * nblk + i] = carry + inc - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[col] = carry;
+}
+// phase C: exclusive scan inside each block of 1024 fields + the block's base; grid (blocks, columns)
+__global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int64_t *__restrict__ counts, const int64_t *__restrict__ blk_sums,
+                                                    int64_t nblk, int64_t *__restrict__ bases)
+{
+    __shared__ int64_t lds[4];
+    const int col = c0 + blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * 1024 + (int64_t)threadIdx.x * 4;      // four consecutive fields per thread
+    int64_t v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? counts[(int64_t)col * n + base + k] : 0; s += v[k]; }
+    int64_t tot;
+    int64_t run = wg_incl_scan(s, lds, tot) - s + blk_sums[(int64_t)col * nblk + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
+}
+
+int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s)
+{
+    const int64_t nblk = (n + 1023) / 1024;
+    const int nc = c1 - c0;
+    hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk);
+    hipLaunchKernelGGL(k_scan_block_bases, dim3((unsigned)nc), dim3(256), 0, st, c0, s.blk_sums, nblk, s.totals);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk, s.bases);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// ---- k_tile_fields: one wavefront per field, the tiler's cut at the reference's sampling -------------------------------------------------
+// What FieldTiler::tile_field + derive_field (fcpp_tiler.cpp) decide for a field whose lines have 2 points, whose turns 20 and whose
+// headland straights 20 (sample_spacing = 0): no straight has a quiet zone, so the field is
+//     [ span: all complete passes, closed form ] [ general stretch: the last line + layer 2 ]
+// (or one general stretch when the turns are not closed form), the general stretch cut into wave tiles with halos sized from the
+// path's own step lengths -- the points evaluated lane-parallel into LDS, the greedy cut walked wave-uniformly -- or, when a wave tile
+// cannot be formed, into general tiles of up to 512 points.
+constexpr int TW_WAVES = 2;                                             // fields per workgroup
+constexpr int TW_NW = DEVPLAN_WINDOW;                                   // points of the LDS window that slides along a general stretch
+struct TileWaveLds {
+    double d[TW_NW];              // d[i - lo] = |p_i - p_(i-1)|
+    int32_t pstart[DEVPLAN_PRIMS_CAP + 1];   // start of primitive k relative to n_main
+    uint8_t pidx[TW_NW];          // primitive (index within the field) of window point w; 0 in layer 1
+    uint8_t ins[TW_NW];           // window point w lies inside the geofence with the host's margin
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int32_t clampi(int64_t v) { return (int32_t)(v < -2 ? -2 : (v > ((int64_t)1 << 30) ? ((int64_t)1 << 30) : v)); }
+
+template <bool FILL>
+__global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTileConsts tc, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
+                                                              const fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
+                                                              const int64_t *__restrict__ bases, int64_t *__restrict__ totals, DevPlanTables T)
+{
+    __shared__ TileWaveLds lds_all[TW_WAVES];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int64_t field = (int64_t)blockIdx.x * TW_WAVES + wave;
+    if (field >= n) return;
+    TileWaveLds &L = lds_all[wave];
+    const DevField &F = ftmp[field];
+    const DevPrim *prims = ptmp + field * tc.max_prims;
+    const int64_t n_total = F.n_total;
+    auto base_of = [&](int col) -> int64_t { return bases[(int64_t)col * n + field]; };
+    const int64_t pt_off = base_of(PC_POINTS);       // (scanned before either pass)
+
+    // the field's counts (count pass) / positions (fill pass)
+    int64_t c_tiles = 0, c_wave = 0, c_general = 0, c_stat = 0, c_span = 0, c_work = 0, c_open = 0, c_runs = 0, c_span_pts = 0, c_wave_pts = 0,
+            c_work_wave_pts = 0, c_wave_inside = 0;
+    int cls = 0;
+    int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, span_base = 0, prim_base = 0;
+    if (FILL) {
+        tile_base = base_of(PC_TILES); wave_base = base_of(PC_WAVE); general_base = base_of(PC_GENERAL); stat_base = base_of(PC_STAT);
+        span_base = base_of(PC_SPAN); prim_base = base_of(PC_PRIMS);
+    }
+    const int prim_count = F.prim_count;
+    const int64_t prim_index0 = prim_base;           // batch-wide index of the field's first primitive (fill pass)
+
+    bool fallback = false;
+    int64_t S = 0, span_k = 0;
+    int64_t n_wave = 0, n_general = 0;
+    if (n_total > 0) {
+        const int64_t per = (int64_t)F.n_line + F.n_turn, P = F.P, gen_main = F.gen_main;
+        const double line_step_len = fabs(F.line_step);
+        const bool turn_quiet = tc.turn_quiet && F.n_turn == tc.nu && F.line_step > 0.0;
+        const bool wave_ok = F.n_turn == tc.nu && (double)tc.wave_factor * tc.two_a * line_step_len >= tc.u_cap;
+        // (sample_spacing = 0: 2 points per line, 20 per headland straight -- no quiet zone anywhere; anything else is not this kernel's)
+        if (F.n_line >= 64 || prim_count > DEVPLAN_PRIMS_CAP) fallback = true;
+        int64_t pos = 0;
+        const int64_t need1 = tiler_need_for(tc.c_line, line_step_len, tc.two_a);
+        if (need1 >= 0 && per > 0 && gen_main > 0) {
+            const bool span = turn_quiet && P >= 2 && (int64_t)F.n_line - need1 < 64 && (P - 1) * per < (int64_t)0x7fffffff;
+            if (span) { S = (P - 1) * per; span_k = (S + (TILE_POINTS - 2) - 1) / (TILE_POINTS - 2); pos = S; }
+        }
+        const int64_t a = pos, b = n_total, G = b - a;
+        bool use_wave = wave_ok && G > 0 && !fallback;
+        bool refused = false;
+        // the count pass has already decided whether the stretch takes wave tiles: the fill pass reads its verdict
+        if (FILL && use_wave && counts[(int64_t)PC_WAVE * n + field] == 0) { use_wave = false; refused = true; }
+        if (use_wave) {
+            const double cap = tiler_halo_cap(tc.u_cap);
+            // the host evaluates the points [lo - 1, hi) of the stretch at once; here a window of TW_NW points slides along with the cut
+            // (a tile starting at s touches the points [s - 43, s + 171) at most), the points are the same function values wherever the
+            // window lies
+            const int64_t lo_all = (a - WAVE_HALO_MAX - 2 > 1) ? a - WAVE_HALO_MAX - 2 : 1;
+            const int64_t hi_all = (b + WAVE_HALO_MAX + 2 < n_total) ? b + WAVE_HALO_MAX + 2 : n_total;
+            const int64_t n_main = F.n_main;
+            for (int k = lane; k < prim_count; k += 64) L.pstart[k] = (int32_t)(prims[k].start - n_main);
+            wave_sync();                                     // the starts are in LDS
+            int64_t win0 = 0, win1 = -1;                     // window = path points [win0, win1)
+            auto dist = [&](int64_t i) -> double { return L.d[i - win0 - 1]; };
+            auto prim_of = [&](int64_t i) -> int { return (int)L.pidx[i - win0]; };
+            const int WAVE_LANES = 128;
+            int64_t s = a;
+            int64_t ordinal = 0, wave_pts = 0, inside_cnt = 0;
+            while (s < b) {
+                const int64_t need_lo = (s - WAVE_HALO_MAX - 3 > lo_all - 1) ? s - WAVE_HALO_MAX - 3 : lo_all - 1;
+                const int64_t need_hi = (s + WAVE_LANES + WAVE_HALO_MAX + 3 < hi_all) ? s + WAVE_LANES + WAVE_HALO_MAX + 3 : hi_all;
+                if (!(win0 <= need_lo && need_hi <= win1)) {
+                    // ---- the window's points, lane-parallel: step lengths, geofence margin, primitive of every point
+                    wave_sync();
+                    win0 = need_lo; win1 = (win0 + TW_NW < hi_all) ? win0 + TW_NW : hi_all;
+                    const int nwin = (int)(win1 - win0);
+                    double cx = 0.0, cy = 0.0;               // the previous round's last point
+                    for (int w_base = 0; w_base < nwin; w_base += 64) {
+                        const int w = w_base + lane;
+                        const bool valid = w < nwin;
+                        const int64_t i = win0 + (valid ? w : nwin - 1);
+                        double px, py;
+                        int pk = 0;
+                        if (i < gen_main) {
+                            const int64_t idx = i / per, off = i - idx * per;
+                            tiler_point_main(F, tc.tu, idx, off, px, py);
+                        } else {
+                            const int32_t rel = (int32_t)(i - n_main);
+                            int lo_k = 0, hi_k = prim_count - 1;
+                            while (lo_k < hi_k) { const int m = (lo_k + hi_k + 1) >> 1; if (L.pstart[m] <= rel) lo_k = m; else hi_k = m - 1; }
+                            pk = lo_k;
+                            const DevPrim q = prims[pk];
+                            tiler_point_prim(q, tc.tu, tc.tc, i - q.start, px, py);
+                        }
+                        double qx = __shfl_up(px, 1), qy = __shfl_up(py, 1);
+                        if (lane == 0) { qx = cx; qy = cy; }
+                        cx = __shfl(px, 63); cy = __shfl(py, 63);
+                        if (valid) {
+                            if (w >= 1) { const double dx = px - qx, dy = py - qy; L.d[w - 1] = sqrt(dx * dx + dy * dy); }
+                            L.pidx[w] = (uint8_t)pk;
+                            L.ins[w] = tiler_inside(F, px, py, tc.fence_margin) ? 1 : 0;
+                        }
+                    }
+                    wave_sync();
+                }
+                // ---- one step of the greedy cut, wave-uniform
+                const int Hb = tiler_back_halo(dist, s, tc.two_a, cap);
+                if (Hb < 0) { refused = true; break; }
+                const int64_t cmax = (b - s < WAVE_LANES - Hb) ? b - s : WAVE_LANES - Hb;
+                const int64_t first0 = s - Hb;
+                const int pa0 = first0 + Hb + cmax - 1 >= gen_main ? prim_of(first0 > gen_main ? first0 : gen_main) : 0;
+                // the largest count whose forward halo still fits and whose points lie in at most nine primitives: candidates lane-parallel
+                int64_t c = 0;
+                int Hf = -1;
+                for (int64_t cb = 0; cb < cmax; cb += 64) {
+                    const int64_t cand = cmax - cb - lane;
+                    bool ok = false;
+                    int hf = -1;
+                    if (cand >= 1) {
+                        hf = tiler_fwd_halo(dist, s + cand - 1, n_total, tc.two_a, cap);
+                        ok = hf >= 0 && Hb + cand + hf <= WAVE_LANES;
+                        if (ok) { const int64_t last0 = s + cand - 1 + hf; if (last0 >= gen_main && prim_of(last0) - pa0 > 8) ok = false; }
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (m) {
+                        const int l0 = __builtin_ctzll(m);
+                        c = cmax - cb - l0;
+                        Hf = __shfl(hf, l0);
+                        break;
+                    }
+                }
+                if (c < (b - s < 8 ? b - s : 8)) { refused = true; break; }
+                const int64_t first = s - Hb, last = s + c - 1 + Hf;
+                // every output point inside the geofence with the margin?
+                bool all_in = true;
+                for (int64_t o0 = 0; o0 < c; o0 += 64) {
+                    const int64_t o = o0 + lane;
+                    const bool bad = o < c && L.ins[s + o - win0] == 0;
+                    if (__ballot(bad)) all_in = false;
+                }
+                int pa = 0, pb = 0;
+                if (last >= gen_main) {
+                    const int64_t fl2 = first > gen_main ? first : gen_main;
+                    pa = prim_of(fl2); pb = prim_of(last);
+                    if (pb - pa > 8) { refused = true; break; }
+                    bool bad = false;
+                    for (int k = pa + 1; k <= pb; ++k) if (L.pstart[k] <= L.pstart[k - 1]) bad = true;
+                    if (bad) { refused = true; break; }
+                }
+                if (FILL && lane == 0) {
+                    DevTile t;
+                    t.field = (int32_t)field; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
+                    if (first < gen_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
+                    else { t.idx0 = (int32_t)(prim_index0 + prim_of(first)); t.off0 = 0; }
+                    DevWaveTile wt;
+                    memset(&wt, 0, sizeof wt);
+                    wt.out_base = pt_off + first; wt.field = (int32_t)field; wt.tile = (int32_t)(stat_base + (span_k > 0 ? 1 : 0) + ordinal);
+                    wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = all_in ? 1 : 0;
+                    wt.rel_main = clampi(gen_main - first); wt.rel_seam = clampi(n_main - first); wt.rel_last = clampi(n_total - 1 - first);
+                    wt.rel_zero = clampi(-first);
+                    wt.idx0 = t.idx0; wt.off0 = t.off0;
+                    for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
+                    if (last >= gen_main) {
+                        wt.p0 = (int32_t)(prim_index0 + pa);
+                        wt.r0 = (int32_t)(first - (n_main + L.pstart[pa]));
+                        for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
+                    }
+                    T.tiles[tile_base + span_k + ordinal] = t;
+                    T.wtiles[wave_base + ordinal] = wt;
+                }
+                inside_cnt += all_in ? 1 : 0;
+                wave_pts += c;
+                ++ordinal;
+                s += c;
+            }
+            if (!refused) { n_wave = ordinal; c_wave_pts = wave_pts; c_wave_inside = inside_cnt; }
+        }
+        if (G > 0 && n_wave == 0 && !fallback) {
+            // general tiles of at most 512 points, near-equal
+            n_general = (G + TILE_POINTS - 1) / TILE_POINTS;
+            if (FILL) {
+                const int64_t bs = G / n_general, rem = G % n_general;
+                const bool in1 = per > 0;
+                for (int64_t j = lane; j < n_general; j += 64) {
+                    const int64_t st = a + j * bs + (j < rem ? j : rem), cnt = bs + (j < rem ? 1 : 0);
+                    const bool l1 = in1 && st < gen_main;
+                    DevTile t;
+                    t.field = (int32_t)field; t.start = st; t.count = (int32_t)cnt; t.quiet = 0;
+                    t.stat_tile = (int32_t)(stat_base + (span_k > 0 ? 1 : 0) + j);
+                    t.idx0 = l1 ? (int32_t)(st / per) : 0; t.off0 = l1 ? (int32_t)(st % per) : 0;
+                    T.tiles[tile_base + span_k + j] = t;
+                    T.general_ids[general_base + j] = (int32_t)(tile_base + span_k + j);
+                }
+            }
+        }
+        // ---- the span's tiles (near-equal, at most 510 points: the closed-form kernel stores aligned pairs) and its chunks on 512-point
+        // boundaries of the batch arrays
+        if (span_k > 0) {
+            c_runs = 1; c_span_pts = S;
+            const int64_t g0 = pt_off;                           // the span starts the path
+            c_span = ((g0 % TILE_POINTS) + S + TILE_POINTS - 1) / TILE_POINTS;
+            if (FILL) {
+                const int64_t bs = S / span_k, rem = S % span_k;
+                for (int64_t j = lane; j < span_k; j += 64) {
+                    const int64_t st = j * bs + (j < rem ? j : rem);
+                    DevTile t;
+                    t.field = (int32_t)field; t.start = st; t.count = (int32_t)(bs + (j < rem ? 1 : 0)); t.quiet = 4; t.stat_tile = 0;
+                    t.idx0 = (int32_t)(st / per); t.off0 = (int32_t)(st % per);
+                    T.tiles[tile_base + j] = t;
+                }
+                const int64_t c_first = (S < TILE_POINTS - (g0 % TILE_POINTS)) ? S : TILE_POINTS - (g0 % TILE_POINTS);
+                for (int64_t j = lane; j < c_span; j += 64) {
+                    const int64_t done = j == 0 ? 0 : c_first + (j - 1) * TILE_POINTS;
+                    const int64_t cnt = j == 0 ? c_first : ((S - done < TILE_POINTS) ? S - done : TILE_POINTS);
+                    DevTile ch;
+                    ch.field = (int32_t)field; ch.start = done; ch.count = (int32_t)cnt; ch.quiet = 4; ch.stat_tile = (int32_t)stat_base;
+                    ch.idx0 = (int32_t)(done / per); ch.off0 = (int32_t)(done % per);
+                    T.span_chunks[span_base + j] = ch;
+                }
+            }
+        }
+        c_tiles = span_k + n_wave + n_general;
+        c_wave = n_wave; c_general = n_general;
+        c_stat = (span_k > 0 ? 1 : 0) + n_wave + n_general;
+    }
+    // ---- which kernel reduces the field: its own workgroup (k_plan_sparse_fields) or a class of k_reduce_stats
+    const int64_t ne = c_stat;
+    const int fw_max = tc.field_work_tiles < FIELD_WORK_TILES ? tc.field_work_tiles : FIELD_WORK_TILES;
+    const bool is_work = n_general == 0 && n_wave >= 1 && n_wave <= fw_max && ne <= FIELD_WORK_ENTRIES;
+    if (is_work) { c_work = 1; c_work_wave_pts = c_wave_pts; }
+    else { c_open = n_wave; cls = tiler_reduce_class(ne, tc.reduce_wg_max); }
+    if (fallback && lane == 0) atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), 1ull);
+
+    if (!FILL) {
+        if (lane == 0) {
+            int64_t *c = counts + field;
+            c[(int64_t)PC_TILES * n] = c_tiles; c[(int64_t)PC_WAVE * n] = c_wave; c[(int64_t)PC_GENERAL * n] = c_general; c[(int64_t)PC_STAT * n] = c_stat;
+            c[(int64_t)PC_SPAN * n] = c_span; c[(int64_t)PC_WORK * n] = c_work; c[(int64_t)PC_OPEN * n] = c_open;
+            c[(int64_t)PC_CLS0 * n] = (!is_work && cls == 0) ? 1 : 0; c[(int64_t)PC_CLS1 * n] = (!is_work && cls == 1) ? 1 : 0;
+            c[(int64_t)PC_CLS2 * n] = (!is_work && cls == 2) ? 1 : 0; c[(int64_t)PC_CLS3 * n] = (!is_work && cls == 3) ? 1 : 0;
+            c[(int64_t)PC_RUNS * n] = c_runs; c[(int64_t)PC_SPAN_PTS * n] = c_span_pts; c[(int64_t)PC_WAVE_PTS * n] = c_wave_pts;
+            c[(int64_t)PC_WORK_WAVE_PTS * n] = c_work_wave_pts; c[(int64_t)PC_WAVE_INSIDE * n] = c_wave_inside;
+        }
+        return;
+    }
+
+    // ---- fill pass: the field's descriptor and primitives at their final places, the statistics entries, the work lists
+    {
+        // (8-byte words: DevField and DevPrim are arrays of them)
+        static_assert(sizeof(DevField) % 8 == 0 && sizeof(DevPrim) % 8 == 0, "copied as 8-byte words");
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&F);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&T.fields[field]);
+        // (pt_off and prim_first become batch-wide: patched by the lane that copies their word)
+        constexpr int W_PT = (int)(offsetof(DevField, pt_off) / 8), W_PF = (int)(offsetof(DevField, prim_first) / 8);
+        constexpr bool PF_HI = (offsetof(DevField, prim_first) % 8) != 0;
+        for (int k = lane; k < (int)(sizeof(DevField) / 8); k += 64) {
+            unsigned long long v = src[k];
+            if (k == W_PT) v = (unsigned long long)pt_off;
+            if (k == W_PF) v = PF_HI ? ((v & 0xffffffffull) | ((unsigned long long)(uint32_t)prim_base << 32)) : ((v & 0xffffffff00000000ull) | (unsigned long long)(uint32_t)prim_base);
+            dst[k] = v;
+        }
+        const unsigned long long *ps = reinterpret_cast<const unsigned long long *>(prims);
+        unsigned long long *pd = reinterpret_cast<unsigned long long *>(T.prims + prim_base);
+        const int nwords = prim_count * (int)(sizeof(DevPrim) / 8);
+        for (int k = lane; k < nwords; k += 64) pd[k] = ps[k];
+    }
+    // entries in path order: the span's run, then the wave tiles / general tiles
+    if (span_k > 0 && lane == 0) { T.stat_ids[stat_base] = (int32_t)tile_base; T.stat_run[stat_base] = S; }
+    {
+        const int64_t e0 = stat_base + (span_k > 0 ? 1 : 0), nt = n_wave + n_general;
+        for (int64_t j = lane; j < nt; j += 64) { T.stat_ids[e0 + j] = (int32_t)(tile_base + span_k + j); T.stat_run[e0 + j] = 0; }
+    }
+    if (lane == 0) {
+        T.stat_first[field] = stat_base;
+        if (field == n - 1) T.stat_first[n] = stat_base + c_stat;
+        if (is_work) {
+            DevFieldWork w;
+            memset(&w, 0, sizeof w);
+            w.field = (int32_t)field; w.n_tiles = (int32_t)n_wave; w.w_first = (int32_t)wave_base; w.e_first = (int32_t)stat_base; w.n_entries = (int32_t)ne;
+            T.field_work[base_of(PC_WORK)] = w;              // (every such field has at most four tiles: class 0 is the only class in use)
+        } else {
+            int64_t cls_first = 0;
+            for (int k = 0; k < cls; ++k) cls_first += totals[PC_CLS0 + k];
+            T.red_paths[cls_first + base_of(PC_CLS0 + cls)] = (int32_t)field;
+        }
+        // connector segments (MLP:1313-1355): approach rows [0, n), departure rows [n, 2n)
+        const fcpp_field_info &in = info[field];
+        const bool okf = in.status == FCPP_OK;
+        double *sg = T.seg + field * 4;
+        sg[0] = in.approach_from[0]; sg[1] = in.approach_from[1]; sg[2] = in.approach_to[0]; sg[3] = in.approach_to[1];
+        T.seg_mask[field] = okf && in.start_kept;
+        double *q = T.seg + (n + field) * 4;
+        q[0] = in.departure_from[0]; q[1] = in.departure_from[1]; q[2] = in.departure_to[0]; q[3] = in.departure_to[1];
+        T.seg_mask[n + field] = okf && in.end_kept;
+    }
+    if (!is_work) {
+        const int64_t ob = base_of(PC_OPEN);
+        for (int64_t j = lane; j < n_wave; j += 64) T.open_wave_ids[ob + j] = (int32_t)(wave_base + j);
+    }
+}
+
+// the field table's point offsets into fcpp_field_info (after the scan)
+__global__ void k_info_offsets(int64_t n, const int64_t *__restrict__ bases, fcpp_field_info *__restrict__ info)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) info[i].point_offset = bases[(int64_t)PC_POINTS * n + i];
+}
+
+__global__ void k_debug_math(int fn, int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o0, double *__restrict__ o1)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (fn == 0) { double s, c; fc_sincos(a[i], s, c); o0[i] = s; o1[i] = c; }
+    else if (fn == 1) o0[i] = atan2_fd(a[i], b[i]);
+    else if (fn == 2) o0[i] = fc_acos(a[i]);
+    else o0[i] = fc_hypot(a[i], b[i]);
+}
+
+}  // namespace
+
+int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, int64_t n_polys, int check_obstacles)
+{
+    if (n <= 0) return 0;
+    hipError_t e = hipMemsetAsync(s.totals, 0, (PC_COLS + PF_COUNT) * sizeof(int64_t), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, s.fields_in, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                       n_polys, check_obstacles);
+    int rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_info_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, s.bases, s.info);
+    hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, s.fields_tmp, s.prims_tmp,
+                       s.info, s.counts, s.bases, s.totals, DevPlanTables());
+    rc = launch_scan(st, n, PC_TILES, PC_COLS, s);
+    if (rc) return rc;
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevPlanScratch &s, const DevPlanTables &t)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((k_tile_fields<true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, s.fields_tmp, s.prims_tmp,
+                       s.info, s.counts, s.bases, s.totals, t);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int launch_debug_math(hipStream_t st, int fn, int64_t n, const double *a, const double *b, double *out0, double *out1)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fn, n, a, b, out0, out1);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace fcpp

@@ -393,6 +393,61 @@ T *at(unsigned char *base, size_t off) { return reinterpret_cast<T *>(base + off
 
 }  // namespace
 
+// the tables' places inside the image from their counts (n_fields, n_prims, n_tiles, ...): the same for an image built on the host and
+// one built on the device (fcpp_devplan.hip)
+void layout_image(ImageLayout &lay)
+{
+    size_t o = 0;
+    auto take = [&](size_t &slot, size_t bytes) { slot = o; o = align256(o + bytes); };
+    take(lay.fields, (size_t)lay.n_fields * sizeof(DevField));
+    take(lay.prims, (size_t)lay.n_prims * sizeof(DevPrim));
+    take(lay.tiles, (size_t)lay.n_tiles * sizeof(DevTile));
+    take(lay.wtiles, (size_t)lay.n_wave * sizeof(DevWaveTile));
+    take(lay.general_ids, (size_t)lay.n_general * sizeof(int32_t));
+    take(lay.chunks, (size_t)lay.n_chunks * sizeof(DevTile));
+    take(lay.span_chunks, (size_t)lay.n_span_chunks * sizeof(DevTile));
+    take(lay.stat_ids, (size_t)lay.n_stat * sizeof(int32_t));
+    take(lay.stat_first, (size_t)(lay.n_fields + 1) * sizeof(int64_t));
+    take(lay.stat_run, (size_t)lay.n_stat * sizeof(int64_t));
+    take(lay.red_paths, (size_t)lay.n_fields * sizeof(int32_t));
+    take(lay.field_work, (size_t)lay.n_field_work * sizeof(DevFieldWork));
+    take(lay.open_wave_ids, (size_t)lay.n_open_wave * sizeof(int32_t));
+    take(lay.obs_off, lay.n_polys > 0 ? (size_t)(lay.n_polys + 1) * sizeof(int64_t) : 0);
+    take(lay.obs_x, (size_t)lay.n_poly_verts * sizeof(double));
+    take(lay.obs_y, (size_t)lay.n_poly_verts * sizeof(double));
+    take(lay.obs_bbox, (size_t)lay.n_polys * 4 * sizeof(double));
+    take(lay.seg, (size_t)lay.n_fields * 8 * sizeof(double));
+    take(lay.seg_mask, (size_t)lay.n_fields * 2 * sizeof(int32_t));
+    lay.upload_bytes = o;
+    take(lay.partial, (size_t)lay.n_stat * sizeof(TilePartial));      // one slot per statistics entry
+    take(lay.red_scratch, (size_t)lay.n_red[3] * 64 * 104);
+    take(lay.field_junc, (size_t)lay.n_fields * 2 * sizeof(double));
+    take(lay.work_totals, (size_t)lay.n_field_work * sizeof(TilePartial));   // per field of field_work: the statistics of its quiet runs, summed once
+    lay.total_bytes = o;
+}
+
+// the batch's obstacle polygons (CSR) and one bounding box per polygon
+void fill_obstacles(const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst)
+{
+    if (lay.n_polys > 0) {
+        const int64_t np = lay.n_polys, nv = lay.n_poly_verts;
+        memcpy(at<int64_t>(dst, lay.obs_off), polys->offsets, (size_t)(np + 1) * sizeof(int64_t));
+        if (nv > 0) {
+            memcpy(at<double>(dst, lay.obs_x), polys->x, (size_t)nv * sizeof(double));
+            memcpy(at<double>(dst, lay.obs_y), polys->y, (size_t)nv * sizeof(double));
+        }
+        double *bb = at<double>(dst, lay.obs_bbox);
+        for (int64_t k = 0; k < np; ++k) {
+            double mnx = HUGE_VAL, mny = HUGE_VAL, mxx = -HUGE_VAL, mxy = -HUGE_VAL;
+            for (int64_t q = polys->offsets[k]; q < polys->offsets[k + 1]; ++q) {
+                mnx = std::min(mnx, polys->x[q]); mxx = std::max(mxx, polys->x[q]);
+                mny = std::min(mny, polys->y[q]); mxy = std::max(mxy, polys->y[q]);
+            }
+            bb[k * 4] = mnx; bb[k * 4 + 1] = mny; bb[k * 4 + 2] = mxx; bb[k * 4 + 3] = mxy;
+        }
+    }
+}
+
 BatchTiler::BatchTiler() : blocks_(new std::vector<BlockTiles>()) {}
 BatchTiler::~BatchTiler() { delete blocks_; }
 
@@ -434,33 +489,7 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
     if (lay.n_tiles > INT32_MAX) { err = "too many tiles in one batch: split the batch"; return FCPP_ESIZE; }
     lay.n_polys = polys ? polys->n_polys : 0;
     lay.n_poly_verts = lay.n_polys > 0 ? polys->offsets[lay.n_polys] : 0;
-    size_t o = 0;
-    auto take = [&](size_t &slot, size_t bytes) { slot = o; o = align256(o + bytes); };
-    take(lay.fields, (size_t)n * sizeof(DevField));
-    take(lay.prims, (size_t)lay.n_prims * sizeof(DevPrim));
-    take(lay.tiles, (size_t)lay.n_tiles * sizeof(DevTile));
-    take(lay.wtiles, (size_t)lay.n_wave * sizeof(DevWaveTile));
-    take(lay.general_ids, (size_t)lay.n_general * sizeof(int32_t));
-    take(lay.chunks, (size_t)lay.n_chunks * sizeof(DevTile));
-    take(lay.span_chunks, (size_t)lay.n_span_chunks * sizeof(DevTile));
-    take(lay.stat_ids, (size_t)lay.n_stat * sizeof(int32_t));
-    take(lay.stat_first, (size_t)(n + 1) * sizeof(int64_t));
-    take(lay.stat_run, (size_t)lay.n_stat * sizeof(int64_t));
-    take(lay.red_paths, (size_t)n * sizeof(int32_t));
-    take(lay.field_work, (size_t)lay.n_field_work * sizeof(DevFieldWork));
-    take(lay.open_wave_ids, (size_t)lay.n_open_wave * sizeof(int32_t));
-    take(lay.obs_off, lay.n_polys > 0 ? (size_t)(lay.n_polys + 1) * sizeof(int64_t) : 0);
-    take(lay.obs_x, (size_t)lay.n_poly_verts * sizeof(double));
-    take(lay.obs_y, (size_t)lay.n_poly_verts * sizeof(double));
-    take(lay.obs_bbox, (size_t)lay.n_polys * 4 * sizeof(double));
-    take(lay.seg, (size_t)n * 8 * sizeof(double));
-    take(lay.seg_mask, (size_t)n * 2 * sizeof(int32_t));
-    lay.upload_bytes = o;
-    take(lay.partial, (size_t)lay.n_stat * sizeof(TilePartial));      // one slot per statistics entry
-    take(lay.red_scratch, (size_t)lay.n_red[3] * 64 * 104);
-    take(lay.field_junc, (size_t)n * 2 * sizeof(double));
-    take(lay.work_totals, (size_t)lay.n_field_work * sizeof(TilePartial));   // per field of field_work: the statistics of its quiet runs, summed once
-    lay.total_bytes = o;
+    layout_image(lay);
     return FCPP_OK;
 }
 
@@ -536,23 +565,7 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
             for (int64_t i = 0; i < N; ++i) L[i] = tmp[(size_t)((__int128)i * P % N)];
         }
     }
-    if (lay.n_polys > 0) {
-        const int64_t np = lay.n_polys, nv = lay.n_poly_verts;
-        memcpy(at<int64_t>(dst, lay.obs_off), polys->offsets, (size_t)(np + 1) * sizeof(int64_t));
-        if (nv > 0) {
-            memcpy(at<double>(dst, lay.obs_x), polys->x, (size_t)nv * sizeof(double));
-            memcpy(at<double>(dst, lay.obs_y), polys->y, (size_t)nv * sizeof(double));
-        }
-        double *bb = at<double>(dst, lay.obs_bbox);
-        for (int64_t k = 0; k < np; ++k) {
-            double mnx = HUGE_VAL, mny = HUGE_VAL, mxx = -HUGE_VAL, mxy = -HUGE_VAL;
-            for (int64_t q = polys->offsets[k]; q < polys->offsets[k + 1]; ++q) {
-                mnx = std::min(mnx, polys->x[q]); mxx = std::max(mxx, polys->x[q]);
-                mny = std::min(mny, polys->y[q]); mxy = std::max(mxy, polys->y[q]);
-            }
-            bb[k * 4] = mnx; bb[k * 4 + 1] = mny; bb[k * 4 + 2] = mxx; bb[k * 4 + 3] = mxy;
-        }
-    }
+    fill_obstacles(polys, lay, dst);
 }
 
 }  // namespace fcpp

@@ -51,6 +51,10 @@ struct ImageLayout {
     int wave_tile_points = 64;                // points per wave tile (TileConsts.wave_points)
 };
 
+// offsets of the tables from their counts; the obstacle part of the image (both also used by the device-side setup, fcpp_api.cpp)
+void layout_image(ImageLayout &lay);
+void fill_obstacles(const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst);
+
 struct BlockTiles;      // a block's records before the merge (fcpp_tiler.cpp)
 
 class BatchTiler {

@@ -35,6 +35,12 @@ class Context:
         s = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fcpp_ctx_set_stream(self.handle, C.c_void_p(s)))
 
+    def set_setup(self, mode):
+        """Where batches are set up from now on: 'auto' (on the device where the device planner takes the batch: the reference's sampling,
+        no obstacle-aware swaths), 'host', 'device' (fcpp_ctx_set_setup)."""
+        m = {'auto': L.SETUP_AUTO, 'host': L.SETUP_HOST, 'device': L.SETUP_DEVICE}[mode] if isinstance(mode, str) else int(mode)
+        L.check(self.lib.fcpp_ctx_set_setup(self.handle, m))
+
     def __del__(self):
         try:
             if getattr(self, 'handle', None):
@@ -311,7 +317,22 @@ class Batch:
         t = L.SetupTimes()
         L.check(self.lib.fcpp_batch_setup_times(self.handle, C.byref(t)))
         return {'pack': self.pack_ms, 'host_plan': t.host_plan_ms, 'templates': t.templates_ms, 'tiler': t.tiler_ms, 'image': t.image_ms,
-                'h2d': t.h2d_ms, 'create': t.total_ms, 'threads': int(t.threads), 'image_bytes': int(t.image_bytes)}
+                'h2d': t.h2d_ms, 'create': t.total_ms, 'threads': int(t.threads), 'image_bytes': int(t.image_bytes),
+                'device_setup': int(t.device_setup)}
+
+    def setup_path(self):
+        """'device' if this batch was set up on the GPU (fcpp_devplan), else 'host'"""
+        t = L.SetupTimes()
+        L.check(self.lib.fcpp_batch_setup_times(self.handle, C.byref(t)))
+        return 'device' if t.device_setup else 'host'
+
+    def debug_table(self, table):
+        """One of the batch's device tables as bytes (fcpp_batch_debug_table; tests)."""
+        nb = C.c_int64()
+        L.check(self.lib.fcpp_batch_debug_table(self.handle, int(table), None, 0, C.byref(nb)))
+        buf = np.zeros(max(nb.value, 1), dtype=np.uint8)
+        L.check(self.lib.fcpp_batch_debug_table(self.handle, int(table), C.c_void_p(buf.ctypes.data), nb.value, C.byref(nb)))
+        return buf[:nb.value]
 
     SPREAD_MIN_BYTES = 512 << 20        # batches with less output than this live in the caches: placement does not matter
 

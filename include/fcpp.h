@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FCPP_ABI_VERSION 3
+#define FCPP_ABI_VERSION 4
 
 enum {
     FCPP_OK = 0,
@@ -160,6 +160,14 @@ int fcpp_ctx_create(int device_id, fcpp_ctx **ctx);
 int fcpp_ctx_destroy(fcpp_ctx *ctx);
 int fcpp_ctx_set_stream(fcpp_ctx *ctx, void *hip_stream); /* a hipStream_t; NULL = HIP's default stream.  A new context starts on a private non-blocking stream */
 int fcpp_ctx_synchronize(fcpp_ctx *ctx);
+/* Where the setup of a batch runs (fcpp_batch_create: every field's __init__ and O(1) decisions, MLP:63-107, 591-668, 898-1084, and the
+ * cut of its path into kernel work).  FCPP_SETUP_AUTO: on the DEVICE for batches at the reference's own sampling (sample_spacing = 0,
+ * obstacle_mode = FLAG) -- only the fcpp_field records go up, fcpp_field_info comes back -- and on the host's cores otherwise (dense
+ * sampling, obstacle-aware swaths, fields beyond the device planner's limits).  _HOST: always on the host (the checker of the device
+ * path: both build the same tables, byte for byte).  _DEVICE: batches the device planner does not take fail with FCPP_EUNSUPPORTED.
+ * The environment variable FCPP_SETUP=host|device sets the initial mode of new contexts. */
+enum { FCPP_SETUP_AUTO = 0, FCPP_SETUP_HOST = 1, FCPP_SETUP_DEVICE = 2 };
+int fcpp_ctx_set_setup(fcpp_ctx *ctx, int mode);
 /* device memory for hosts without their own allocator (torch users pass tensor pointers instead) */
 int fcpp_malloc(fcpp_ctx *ctx, int64_t bytes, void **dev_ptr);
 int fcpp_free(fcpp_ctx *ctx, void *dev_ptr);
@@ -199,7 +207,9 @@ typedef struct fcpp_setup_times {
     double total_ms;        /* the whole call */
     int64_t image_bytes;    /* bytes copied to the device */
     int32_t threads;        /* host threads that took part (FCPP_THREADS; default: the machine's, at most 16) */
-    int32_t _pad;
+    int32_t device_setup;   /* 1: the setup ran on the device (fcpp_ctx_set_setup): host_plan_ms = field records up + plan + counting pass + totals
+                               back, image_ms = layout + allocation + obstacle table, tiler_ms = tables written + per-batch constants +
+                               fcpp_field_info back, h2d_ms = 0, image_bytes = bytes copied to the device */
 } fcpp_setup_times;
 int fcpp_batch_setup_times(const fcpp_batch *batch, fcpp_setup_times *out);
 /* The hot path: sample every path point (MLP:720-830, 898-1084, 1154-1218, 1580-1608), curvature
@@ -356,6 +366,20 @@ typedef struct fcpp_cover_job {
  * asks for it; counts_dev: 3 * n_jobs int64 (zeroed by the call).  Runs on the context's stream and synchronises it. */
 int fcpp_cover_grid(fcpp_ctx *ctx, int64_t n_jobs, const fcpp_cover_job *jobs, int64_t n_pts, const double *px_dev,
                     const double *py_dev, uint8_t *grid_dev, int64_t *counts_dev);
+
+/* ---- diagnostics (tests/) -----------------------------------------------------------------------
+ * The setup's transcendentals (csrc/fcpp_math.h: plain IEEE operations so that host and device agree bit for bit) evaluated on the host /
+ * on the device: fn 0 = sin and cos of a -> out0, out1; 1 = atan2(a, b); 2 = acos(a); 3 = hypot(a, b) -> out0.  The _dev variant takes
+ * device pointers and synchronises. */
+int fcpp_debug_math(int fn, int64_t n, const double *a, const double *b, double *out0, double *out1);
+int fcpp_debug_math_dev(fcpp_ctx *ctx, int fn, int64_t n, const double *a_dev, const double *b_dev, double *out0_dev, double *out1_dev);
+/* One of a batch's device tables copied to the host (dst = NULL: only its size in *bytes_out): 0 field descriptors, 1 primitives, 2 tiles,
+ * 3 wave tiles, 4 general tile ids, 5 chunks, 6 span chunks, 7 statistics entry -> tile, 8 first entry per field, 9 run length per entry,
+ * 10 reduction lists, 11 field work, 12 open wave tile ids, 13 connector segments, 14 connector masks, 15 statistics slots (after batch
+ * creation: the closed-form statistics of the quiet runs), 16 junction constants, 17 run totals per field of field work, 18-21 obstacle
+ * offsets / x / y / bounding boxes.  tests/test_gpu_devplan.py compares the tables of a batch set up on the device with those of the
+ * same batch set up on the host. */
+int fcpp_batch_debug_table(const fcpp_batch *batch, int table, void *dst, int64_t cap_bytes, int64_t *bytes_out);
 
 #ifdef __cplusplus
 }

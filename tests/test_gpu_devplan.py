@@ -1,0 +1,174 @@
+"""The setup of a batch ON THE DEVICE (csrc/fcpp_devplan.hip) against the same setup on the host (csrc/fcpp_host.cpp + fcpp_tiler.cpp): every table of
+the batch image byte for byte, fcpp_field_info byte for byte, and the results of a step bit for bit.  The host path is the checker: it is
+what every oracle / golden parity test of rounds 1-3 ran (and still runs under FCPP_SETUP_HOST)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from field_coverage_path_planning_amd import _lib as L
+from field_coverage_path_planning_amd import engine as E
+from field_coverage_path_planning_amd import workloads as WL
+
+pytestmark = pytest.mark.gpu
+
+TABLES = ['fields', 'prims', 'tiles', 'wave_tiles', 'general_ids', 'chunks', 'span_chunks', 'stat_ids', 'stat_first', 'stat_run', 'red_paths', 'field_work',
+          'open_wave_ids', 'seg', 'seg_mask', 'partial', 'field_junc', 'work_totals', 'obs_off', 'obs_x', 'obs_y', 'obs_bbox']
+
+
+def _both(table, veh, opt):
+    """-> (batch set up on the device, the same batch set up on the host without primitive sharing)"""
+    ctx = E.get_context()
+    ctx.set_setup('device')
+    try:
+        bd = E.Batch(table, veh, opt)
+    finally:
+        ctx.set_setup('host')
+    os.environ['FCPP_NO_SHARE'] = '1'          # the device planner gives every field its own primitives
+    try:
+        bh = E.Batch(table, veh, opt)
+    finally:
+        del os.environ['FCPP_NO_SHARE']
+        ctx.set_setup('auto')
+    assert bd.setup_path() == 'device' and bh.setup_path() == 'host'
+    return bd, bh
+
+
+def _compare(bd, bh, what=''):
+    import torch
+    assert bd.total_points == bh.total_points, what
+    assert bytes(bd.info.array.tobytes()) == bytes(bh.info.array.tobytes()), what
+    for k, name in enumerate(TABLES):
+        a, b = bd.debug_table(k), bh.debug_table(k)
+        assert a.size == b.size, (what, name, a.size, b.size)
+        if not np.array_equal(a, b):
+            bad = np.flatnonzero(a != b)
+            raise AssertionError(f'{what}: table {name} differs at byte {bad[0]} of {a.size} ({bad.size} bytes differ)')
+    assert bd.reduce_classes() == bh.reduce_classes() and bd.point_split() == bh.point_split() and bd.stage_points() == bh.stage_points()
+    rd, rh = bd.run(), bh.run()
+    torch.cuda.synchronize()
+    for name in ('x', 'y', 'kappa', 'v', 'flagseg', 'stats_raw'):
+        assert torch.equal(getattr(rd, name), getattr(rh, name)), (what, name)
+    ad, dd = bd.connectors()
+    ah, dh = bh.connectors()
+    assert torch.equal(torch.nan_to_num(ad), torch.nan_to_num(ah)) and torch.equal(torch.nan_to_num(dd), torch.nan_to_num(dh))
+    bd.close()
+    bh.close()
+
+
+def test_shared_math_device_equals_host_bit_for_bit():
+    import torch
+    lib = L.load()
+    ctx = E.get_context()
+    rng = np.random.default_rng(3)
+    a = np.concatenate([rng.uniform(-np.pi, np.pi, 100000), rng.uniform(-1, 1, 100000), rng.uniform(-1e4, 1e4, 50000), [0.0, 1.0, -1.0]])
+    b = rng.uniform(-1e3, 1e3, a.size)
+    for fn in range(4):
+        arg = np.clip(a, -1, 1) if fn == 2 else a
+        h0, h1 = np.empty_like(arg), np.empty_like(arg)
+        L.check(lib.fcpp_debug_math(fn, arg.size, C.c_void_p(arg.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(h0.ctypes.data), C.c_void_p(h1.ctypes.data)))
+        da, db = torch.as_tensor(arg, device='cuda'), torch.as_tensor(b, device='cuda')
+        d0, d1 = torch.empty_like(da), torch.zeros_like(da)
+        L.check(lib.fcpp_debug_math_dev(ctx.handle, fn, arg.size, C.c_void_p(da.data_ptr()), C.c_void_p(db.data_ptr()), C.c_void_p(d0.data_ptr()),
+                                        C.c_void_p(d1.data_ptr())))
+        assert np.array_equal(d0.cpu().numpy().view(np.uint64), h0.view(np.uint64)), fn
+        if fn == 0:
+            assert np.array_equal(d1.cpu().numpy().view(np.uint64), h1.view(np.uint64))
+
+
+def test_headline_and_cfg2_tables_equal_the_hosts():
+    _compare(*_both(E.FieldTable.from_rectangles(WL.cfg1_batch(256)), E.make_vehicle(), E.make_options()), 'cfg1 x 256')
+    _compare(*_both(E.FieldTable.from_rectangles(WL.cfg2_rectangles()), E.make_vehicle(), E.make_options()), 'cfg2')
+    _compare(*_both(E.FieldTable.from_rectangles(WL.cfg2_rectangles()), E.make_vehicle(), E.make_options(1, 0.0)), 'cfg2 clothoid')
+
+
+def test_parallelograms_tables_equal_the_hosts():
+    V = WL.cfg5_parallelograms(4096)
+    _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(), E.make_options()), 'cfg5 x 4096')
+    _compare(*_both(E.FieldTable.from_vertices(V[:777]), E.make_vehicle(), E.make_options(ring_order=1)), 'cfg5 ring 1')
+
+
+def _random_quads(rng, n):
+    """convex quadrilaterals of every shape class, some too small to plan (they raise: status < 0), some degenerate"""
+    out = np.empty((n, 4, 2))
+    for k in range(n):
+        w, h = rng.uniform(20, 900, 2)
+        q = np.array([[0, 0], [w, 0], [w, h], [0, h]], dtype=np.float64)
+        kind = rng.integers(0, 4)
+        if kind == 1:
+            q[2:, 0] += rng.uniform(-0.4, 0.4) * h
+        elif kind == 2:
+            q += rng.uniform(-0.12, 0.12, (4, 2)) * min(w, h)
+        rot = rng.uniform(-np.pi, np.pi) if kind else 0.0
+        q = q @ np.array([[np.cos(rot), np.sin(rot)], [-np.sin(rot), np.cos(rot)]]) + rng.uniform(-50, 50, 2) * (kind > 0)
+        out[k] = q
+    return out
+
+
+@pytest.mark.parametrize('seed', [11, 12, 13])
+def test_random_fields_vehicles_and_points_tables_equal_the_hosts(seed):
+    rng = np.random.default_rng(seed)
+    n = 1500
+    V = _random_quads(rng, n)
+    V[::97] *= 0.01                                    # fields too small to plan: they raise (status < 0) on both paths alike
+    starts = np.where(rng.random((n, 1)) < 0.5, rng.uniform(0, 600, (n, 2)), np.nan)
+    ends = np.where(rng.random((n, 1)) < 0.5, rng.uniform(0, 600, (n, 2)), np.nan)
+    table = E.FieldTable.from_vertices(V, start_points=starts, end_points=ends)
+    vehicles = [E.make_vehicle(), E.make_vehicle(working_width=2.0, min_turn_radius=5.0), E.make_vehicle(working_width=6.0, min_turn_radius=6.0, max_work_speed_kmh=12.0),
+                E.make_vehicle(max_longitudinal_accel=0.3, headland_turn_speed_kmh=6.0), E.make_vehicle(working_width=1.0, min_turn_radius=4.0)]
+    veh = vehicles[seed % len(vehicles)]
+    for tm, ring, tol in ((0, 0, 1e-6), (1, 1, 0.0), (0, 0, -0.5)):
+        bd, bh = _both(table, veh, E.make_options(tm, 0.0, ring_order=ring, geofence_tol=tol))
+        assert (bd.info.array['status'] != 0).any() and (bd.info.array['status'] == 0).any()
+        _compare(bd, bh, f'seed {seed} turn model {tm} ring {ring} tol {tol}')
+
+
+def test_fields_with_obstacle_polygons_flag_mode():
+    rng = np.random.default_rng(5)
+    specs = []
+    for k in range(300):
+        Lx, Hy = rng.uniform(150, 700, 2)
+        obs = [[(float(cx + r * np.cos(t)), float(cy + r * np.sin(t))) for t in np.arange(6) * np.pi / 3]
+               for cx, cy, r in zip(rng.uniform(30, Lx - 30, 3), rng.uniform(30, Hy - 30, 3), rng.uniform(3, 25, 3))] if k % 3 else None
+        specs.append(E.FieldSpec(field_length=float(Lx), field_width=float(Hy), obstacles=obs))
+    _compare(*_both(E.FieldTable.from_specs(specs), E.make_vehicle(), E.make_options()), 'obstacles, flag mode')
+
+
+def test_what_the_device_planner_does_not_take_goes_to_the_host():
+    ctx = E.get_context()
+    t = E.FieldTable.from_rectangles(WL.cfg2_rectangles(64))
+    for opt in (E.make_options(1, 0.5), E.make_options(avoid_obstacles=True)):
+        b = E.Batch(t, E.make_vehicle(), opt)
+        assert b.setup_path() == 'host'
+        b.close()
+        ctx.set_setup('device')
+        try:
+            with pytest.raises(L.FcppError):
+                E.Batch(t, E.make_vehicle(), opt)
+        finally:
+            ctx.set_setup('auto')
+    b = E.Batch(t, E.make_vehicle(), E.make_options())
+    assert b.setup_path() == 'device'
+    b.close()
+
+
+def test_turns_that_are_not_closed_form_make_the_whole_path_general():
+    """a slow-accelerating vehicle: no span, the device tiler's window slides over thousands of points per field"""
+    LH = np.array([[900.0, 700.0], [300.0, 1500.0], [120.0, 90.0], [2500.0, 2200.0]])
+    bd, bh = _both(E.FieldTable.from_rectangles(LH), E.make_vehicle(max_longitudinal_accel=0.01), E.make_options())
+    assert bd.point_split()[0] == 0 and bd.total_points > 20000
+    _compare(bd, bh, 'no closed-form turns')
+    bd, bh = _both(E.FieldTable.from_rectangles(LH), E.make_vehicle(working_width=6.0, min_turn_radius=6.0, max_work_speed_kmh=12.0), E.make_options())
+    _compare(bd, bh, 'fast work speed')
+
+
+def test_malformed_obstacle_ranges_are_refused_by_the_device_path():
+    t = E.FieldTable.from_specs([E.FieldSpec(field_length=300.0, field_width=200.0, obstacles=[[(50.0, 50.0), (60.0, 50.0), (55.0, 60.0)]])])
+    t.rec['n_obstacles'][0] = 5
+    E.get_context().set_setup('device')
+    try:
+        with pytest.raises(L.FcppError):
+            E.Batch(t, E.make_vehicle(), E.make_options())
+    finally:
+        E.get_context().set_setup('auto')
