@@ -42,6 +42,9 @@ def _compare(bd, bh, what=''):
     for k, name in enumerate(TABLES):
         a, b = bd.debug_table(k), bh.debug_table(k)
         assert a.size == b.size, (what, name, a.size, b.size)
+        if name == 'red_paths':          # (room for every field; only the fields k_reduce_stats reduces are listed)
+            used = 4 * sum(bd.reduce_classes())
+            a, b = a[:used], b[:used]
         if not np.array_equal(a, b):
             bad = np.flatnonzero(a != b)
             raise AssertionError(f'{what}: table {name} differs at byte {bad[0]} of {a.size} ({bad.size} bytes differ)')

@@ -229,7 +229,11 @@ def _clip_fields():
     c, s = np.cos(rot), np.sin(rot)
     tilt = lambda pts: [(float(x * c - y * s), float(x * s + y * c)) for x, y in pts]
     verts = tilt([(0.0, 0.0), (500.0, 0.0), (560.0, 260.0), (60.0, 260.0)])
-    para_obs = [tilt([(200.0, 100.0), (230.0, 100.0), (230.0, 125.0), (200.0, 125.0)]), tilt([(340.0, 150.0), (365.0, 160.0), (350.0, 185.0)])]
+    # (the rectangle's sides lie off the half-metre grid of the detour legs' sample counts, int(len / 0.5) + 1: with sides on multiples of 0.1 m some leg is
+    # a multiple of 0.5 m long up to the rounding of the rotation into the frame of layer 1 and back -- a count that hinges on the last bit of a
+    # sine is as platform-dependent here as the reference's own int((max_y - min_y) / W); the library takes its
+    # setup's sine / cosine from csrc/fcpp_math.h, the oracle from the platform libm)
+    para_obs = [tilt([(200.0, 100.33), (230.0, 100.33), (230.0, 125.27), (200.0, 125.27)]), tilt([(340.0, 150.03), (365.0, 160.0), (350.0, 185.07)])]
     specs.append(E.FieldSpec(field_vertices=verts, obstacles=para_obs))
     ofs.append(orc.make_field(verts=verts, obstacles=para_obs))
     return specs, ofs
