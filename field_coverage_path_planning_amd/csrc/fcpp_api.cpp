@@ -177,6 +177,7 @@ struct fcpp_ctx {
     int setup_mode = FCPP_SETUP_AUTO;
     void *plan_scratch = nullptr; size_t plan_scratch_cap = 0;
     int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values
+    hipEvent_t ev_plan = nullptr; bool ev_plan_set = false;   // the last fill pass (it reads the scratch): the next setup waits for it, on whichever stream
 };
 
 // device pointers of a batch's tables: all inside ONE allocation laid out by the tiler (fcpp_tiler.h: ImageLayout)
@@ -215,6 +216,7 @@ struct fcpp_batch {
     int two_stream_max = 512;    // ... when there are at most this many general tiles (FCPP_TWO_STREAM_MAX, read at batch creation)
     int sparse_beside_max = 0;   // ... or at most this many wave tiles (FCPP_SPARSE_BESIDE_MAX; 0 = never: measured, see fcpp_batch_run)
     fcpp_setup_times setup = {};
+    const fcpp_field_info *info_dev = nullptr;     // device-side setup: the records in the slab; hp.info is filled from them on demand
     // every stream this batch's kernels were enqueued on (callers re-bind the context's stream between calls: engine.py binds torch's
     // current stream): fcpp_batch_destroy drains them all before the tables go back to the context as the next batch's allocation
     std::vector<hipStream_t> used_streams;
@@ -346,7 +348,8 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     free_paths_cache(c);
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->spare) (void)hipFree(c->spare);
-    if (c->plan_scratch) (void)hipFree(c->plan_scratch);
+    if (c->plan_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->plan_scratch); }
+    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
     c->templates.reset();
     delete c;
@@ -568,10 +571,12 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
 
     // scratch + the field records
     t0 = std::chrono::steady_clock::now();
+    if (!c->ev_plan) DEVCHK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+    if (c->ev_plan_set) DEVCHK(hipStreamWaitEvent(st, c->ev_plan, 0));       // (the previous batch's fill pass may still read the scratch)
     DevPlanScratch off;
     const size_t need = devplan_scratch_layout(n_fields, pc.max_prims, &off);
     if (c->plan_scratch_cap < need) {
-        if (c->plan_scratch) { DEVCHK(hipStreamSynchronize(st)); (void)hipFree(c->plan_scratch); c->plan_scratch = nullptr; c->plan_scratch_cap = 0; }
+        if (c->plan_scratch) { DEVCHK(hipDeviceSynchronize()); (void)hipFree(c->plan_scratch); c->plan_scratch = nullptr; c->plan_scratch_cap = 0; }
         const size_t want = need + need / 4;
         if (hipMalloc(&c->plan_scratch, want) != hipSuccess) { (void)hipGetLastError(); err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
         c->plan_scratch_cap = want;
@@ -583,6 +588,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     s.fields_tmp = reinterpret_cast<DevField *>(sb + (size_t)off.fields_tmp); s.prims_tmp = reinterpret_cast<DevPrim *>(sb + (size_t)off.prims_tmp);
     s.counts = reinterpret_cast<int64_t *>(sb + (size_t)off.counts); s.bases = reinterpret_cast<int64_t *>(sb + (size_t)off.bases);
     s.blk_sums = reinterpret_cast<int64_t *>(sb + (size_t)off.blk_sums); s.totals = reinterpret_cast<int64_t *>(sb + (size_t)off.totals);
+    s.keep_tiles = reinterpret_cast<DevTile *>(sb + (size_t)off.keep_tiles); s.keep_wtiles = reinterpret_cast<DevWaveTile *>(sb + (size_t)off.keep_wtiles);
     DEVCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
 
     DevTileConsts tc;
@@ -617,6 +623,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     lay.quiet_points = tot[PC_SPAN_PTS]; lay.span_points = tot[PC_SPAN_PTS]; lay.chunk_points = 0; lay.wave_points = tot[PC_WAVE_PTS];
     lay.work_wave_points = tot[PC_WORK_WAVE_PTS]; lay.wave_inside = tot[PC_WAVE_INSIDE];
     lay.n_polys = n_polys; lay.n_poly_verts = n_polys > 0 ? obstacles->offsets[n_polys] : 0;
+    lay.info_on_device = true;
     layout_image(lay);
     if ((rc = take_slab(c, b, err)) != FCPP_OK) return rc;
     bind_tables(b);
@@ -647,17 +654,18 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     T.fields = b->t.fields; T.prims = b->t.prims; T.tiles = b->t.tiles; T.wtiles = b->t.wave_tiles; T.general_ids = b->t.general_ids;
     T.span_chunks = b->t.span_chunks; T.stat_ids = b->t.stat_ids; T.stat_first = b->t.stat_first; T.stat_run = b->t.stat_run;
     T.red_paths = b->t.red_paths; T.field_work = b->t.field_work; T.open_wave_ids = b->t.open_wave_ids; T.seg = b->t.seg; T.seg_mask = b->t.seg_mask;
-    lrc = launch_devplan_fill(st, n_fields, tc, s, T);
-    if (lrc) { err = std::string("launch_devplan_fill: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    T.partial = b->t.partial; T.field_junc = b->t.field_junc; T.work_totals = b->t.work_totals;
+    T.info = reinterpret_cast<fcpp_field_info *>(static_cast<unsigned char *>(b->slab) + lay.info);
     b->cst.field_junc = b->t.field_junc;
-    lrc = launch_field_junctions(st, n_fields, b->t.fields, b->cst, b->t.field_junc);
-    if (!lrc) lrc = launch_run_consts(st, lay.n_stat, b->t.stat_ids, b->t.stat_run, b->t.tiles, b->t.fields, b->t.prims, b->cst, b->t.partial);
-    if (!lrc) lrc = launch_work_totals(st, lay.n_field_work, b->t.field_work, b->t.stat_run, b->t.partial, b->t.work_totals);
-    if (lrc) { err = std::string("setup kernels: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
-    // what the host keeps: fcpp_field_info of every field
-    b->hp.info.resize((size_t)n_fields);
-    DEVCHK(hipMemcpyAsync(b->hp.info.data(), s.info, (size_t)n_fields * sizeof(fcpp_field_info), hipMemcpyDeviceToHost, st));
-    DEVCHK(hipStreamSynchronize(st));
+    // (the fill pass also computes what the host path launches k_field_junctions, k_run_consts and k_work_totals for, field by field)
+    lrc = launch_devplan_fill(st, n_fields, tc, b->cst, s, T);
+    if (lrc) { err = std::string("launch_devplan_fill: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    DEVCHK(hipEventRecord(c->ev_plan, st));
+    c->ev_plan_set = true;
+    // fcpp_field_info stays on the device until somebody asks (fcpp_batch_info); the stream is NOT drained: a step enqueued next runs
+    // right behind the setup
+    b->info_dev = T.info;
+    b->hp.info.clear();
     b->hp.tt = tt;
     b->hp.total_points = tot[PC_POINTS]; b->hp.total_prims = tot[PC_PRIMS];
     b->hp.fields.clear(); b->hp.blocks.clear(); b->hp.same_as.clear();
@@ -816,6 +824,17 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     return FCPP_OK;
 }
 
+// fcpp_field_info of a batch set up on the device: copied back when first needed
+static int ensure_info(fcpp_batch *b)
+{
+    if (!b->info_dev || !b->hp.info.empty() || b->n_fields == 0) return FCPP_OK;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    try { b->hp.info.resize((size_t)b->n_fields); } catch (const std::bad_alloc &) { return fail(FCPP_ENOMEM, "out of host memory"); }
+    for (hipStream_t s : b->used_streams) HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(b->hp.info.data(), b->info_dev, (size_t)b->n_fields * sizeof(fcpp_field_info), hipMemcpyDeviceToHost));
+    return FCPP_OK;
+}
+
 int fcpp_batch_setup_times(const fcpp_batch *b, fcpp_setup_times *out)
 {
     if (!b || !out) return fail(FCPP_EINVAL, "bad arguments");
@@ -826,6 +845,7 @@ int fcpp_batch_setup_times(const fcpp_batch *b, fcpp_setup_times *out)
 int fcpp_batch_info(const fcpp_batch *b, fcpp_field_info *info_out, int64_t *total_points)
 {
     if (!b) return fail(FCPP_EINVAL, "batch is NULL");
+    if (info_out && b->n_fields) { const int rc = ensure_info(const_cast<fcpp_batch *>(b)); if (rc) return rc; }
     if (info_out && b->n_fields) memcpy(info_out, b->hp.info.data(), (size_t)b->n_fields * sizeof(fcpp_field_info));
     if (total_points) *total_points = b->hp.total_points;
     return FCPP_OK;
@@ -850,6 +870,7 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     hipStream_t st = b->ctx->stream;
     b->note_stream(st);
     if (mode == 0 && !b->til0_built) {      // the staged pipeline's own tiling: plain tiles of at most TILE_POINTS points
+        { const int rc = ensure_info(b); if (rc) return rc; }
         Tiling t0;
         std::vector<int64_t> offs((size_t)b->n_fields + 1, 0);
         for (int64_t i = 0; i < b->n_fields; ++i) offs[(size_t)i + 1] = offs[(size_t)i] + b->hp.info[(size_t)i].n_main + b->hp.info[(size_t)i].n_head;

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include "fcpp_device.h"
 #include "fcpp_internal.h"
 #include "fcpp_planfn.h"
 #include "fcpp_tilefn.h"
@@ -45,6 +46,10 @@ struct DevPlanScratch {
     int64_t *counts, *bases;      // PC_COLS x n
     int64_t *blk_sums;            // PC_COLS x blocks of 1024 fields
     int64_t *totals;              // PC_COLS + PF_COUNT
+    // the counting pass keeps the first DEVPLAN_KEEP_TILES wave tiles of every field (records with field-relative indices): the fill pass
+    // copies and rebases them instead of cutting the field again (fields with more are cut again)
+    DevTile *keep_tiles;          // n x DEVPLAN_KEEP_TILES
+    DevWaveTile *keep_wtiles;     // n x DEVPLAN_KEEP_TILES
 };
 size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *offsets_as_pointers /* offsets from 0, cast to pointers */);
 
@@ -53,18 +58,22 @@ struct DevPlanTables {
     DevField *fields; DevPrim *prims; DevTile *tiles; DevWaveTile *wtiles; int32_t *general_ids; DevTile *span_chunks;
     int32_t *stat_ids; int64_t *stat_first, *stat_run; int32_t *red_paths; DevFieldWork *field_work; int32_t *open_wave_ids;
     double *seg; int32_t *seg_mask;
+    // what batch creation computes once from the tables (k_field_junctions, k_run_consts, k_work_totals on the host path), done by the
+    // field's own wavefront here; and the field's fcpp_field_info, kept with the batch for fcpp_batch_info
+    TilePartial *partial; double2 *field_junc; TilePartial *work_totals; fcpp_field_info *info;
 };
 
 // the device tiler's LDS window over a field's general stretch (it slides), and the most primitives a field may have (8-bit indices in
 // that window); a batch whose vehicle needs more (31+ headland loops) is set up on the host
 constexpr int DEVPLAN_WINDOW = 1632;
 constexpr int DEVPLAN_PRIMS_CAP = 255;
+constexpr int DEVPLAN_KEEP_TILES = 8;
 
 // phase 1: plan + count.  Enqueues k_plan_fields, the scans and the counting pass; afterwards totals[] holds the sums and the flags.
 int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, int64_t n_polys,
                          int check_obstacles);
 // phase 2: the tables.  `bases` / `totals` as phase 1 left them.
-int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevPlanScratch &s, const DevPlanTables &t);
+int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevConst &cst, const DevPlanScratch &s, const DevPlanTables &t);
 // fcpp_math.h on the device (tests): fn 0 sincos, 1 atan2(a, b), 2 acos(a), 3 hypot(a, b)
 int launch_debug_math(hipStream_t st, int fn, int64_t n, const double *a, const double *b, double *out0, double *out1);
 

@@ -3,6 +3,7 @@
 #include <stddef.h>
 
 #include "fcpp_devplan.h"
+#include "fcpp_quiet_fn.h"
 
 namespace fcpp {
 
@@ -19,6 +20,8 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
     o->bases = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
     o->blk_sums = reinterpret_cast<int64_t *>(take(nblk * PC_COLS * sizeof(int64_t)));
     o->totals = reinterpret_cast<int64_t *>(take((PC_COLS + PF_COUNT) * sizeof(int64_t)));
+    o->keep_tiles = reinterpret_cast<DevTile *>(take(nn * DEVPLAN_KEEP_TILES * sizeof(DevTile)));
+    o->keep_wtiles = reinterpret_cast<DevWaveTile *>(take(nn * DEVPLAN_KEEP_TILES * sizeof(DevWaveTile)));
     return off;
 }
 
@@ -117,10 +120,35 @@ __global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int
     for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
 }
 
+// small batches: one workgroup per column walks the fields in chunks of 1024 -- one launch instead of three
+__global__ __launch_bounds__(256) void k_scan_small(int64_t n, int c0, const int64_t *__restrict__ counts, int64_t *__restrict__ bases, int64_t *__restrict__ totals)
+{
+    __shared__ int64_t lds[4];
+    const int col = c0 + blockIdx.x;
+    int64_t carry = 0;
+    for (int64_t b0 = 0; b0 < n; b0 += 1024) {
+        const int64_t base = b0 + (int64_t)threadIdx.x * 4;
+        int64_t v[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? counts[(int64_t)col * n + base + k] : 0; s += v[k]; }
+        int64_t tot;
+        int64_t run = wg_incl_scan(s, lds, tot) - s + carry;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) totals[col] = carry;
+}
+
 int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s)
 {
     const int64_t nblk = (n + 1023) / 1024;
     const int nc = c1 - c0;
+    if (nblk <= 8) {
+        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.bases, s.totals);
+        const hipError_t e0 = hipGetLastError();
+        return e0 == hipSuccess ? 0 : (int)e0;
+    }
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk);
     hipLaunchKernelGGL(k_scan_block_bases, dim3((unsigned)nc), dim3(256), 0, st, c0, s.blk_sums, nblk, s.totals);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk, s.bases);
@@ -144,19 +172,13 @@ struct TileWaveLds {
     uint8_t ins[TW_NW];           // window point w lies inside the geofence with the host's margin
 };
 
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __device__ __forceinline__ int32_t clampi(int64_t v) { return (int32_t)(v < -2 ? -2 : (v > ((int64_t)1 << 30) ? ((int64_t)1 << 30) : v)); }
 
 template <bool FILL>
-__global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTileConsts tc, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
-                                                              const fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
-                                                              const int64_t *__restrict__ bases, int64_t *__restrict__ totals, DevPlanTables T)
+__global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTileConsts tc, DevConst cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
+                                                              fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
+                                                              const int64_t *__restrict__ bases, int64_t *__restrict__ totals,
+                                                              DevTile *__restrict__ keep_tiles, DevWaveTile *__restrict__ keep_wtiles, DevPlanTables T)
 {
     __shared__ TileWaveLds lds_all[TW_WAVES];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -168,6 +190,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     const int64_t n_total = F.n_total;
     auto base_of = [&](int col) -> int64_t { return bases[(int64_t)col * n + field]; };
     const int64_t pt_off = base_of(PC_POINTS);       // (scanned before either pass)
+    if (!FILL && lane == 0) info[field].point_offset = pt_off;
 
     // the field's counts (count pass) / positions (fill pass)
     int64_t c_tiles = 0, c_wave = 0, c_general = 0, c_stat = 0, c_span = 0, c_work = 0, c_open = 0, c_runs = 0, c_span_pts = 0, c_wave_pts = 0,
@@ -201,7 +224,27 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
         bool use_wave = wave_ok && G > 0 && !fallback;
         bool refused = false;
         // the count pass has already decided whether the stretch takes wave tiles: the fill pass reads its verdict
-        if (FILL && use_wave && counts[(int64_t)PC_WAVE * n + field] == 0) { use_wave = false; refused = true; }
+        if (FILL && use_wave) {
+            const int64_t cw = counts[(int64_t)PC_WAVE * n + field];
+            if (cw == 0) { use_wave = false; refused = true; }
+            else if (cw <= DEVPLAN_KEEP_TILES) {
+                // the counting pass kept this field's wave tiles: copy them, indices made batch-wide
+                use_wave = false;
+                n_wave = cw;
+                if (lane < cw) {
+                    DevTile t = keep_tiles[field * DEVPLAN_KEEP_TILES + lane];
+                    DevWaveTile wt = keep_wtiles[field * DEVPLAN_KEEP_TILES + lane];
+                    const int64_t first = wt.out_base;                       // (kept relative to the field)
+                    const int nl = (int)wt.hb + wt.count + wt.hf;
+                    if (first >= gen_main) { t.idx0 += (int32_t)prim_index0; wt.idx0 = t.idx0; }
+                    if (wt.rel_main < nl) wt.p0 += (int32_t)prim_index0;     // the tile holds points of layer 2
+                    wt.out_base = pt_off + first;
+                    wt.tile += (int32_t)stat_base;
+                    T.tiles[tile_base + span_k + lane] = t;
+                    T.wtiles[wave_base + lane] = wt;
+                }
+            }
+        }
         if (use_wave) {
             const double cap = tiler_halo_cap(tc.u_cap);
             // the host evaluates the points [lo - 1, hi) of the stretch at once; here a window of TW_NW points slides along with the cut
@@ -299,26 +342,29 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                     for (int k = pa + 1; k <= pb; ++k) if (L.pstart[k] <= L.pstart[k - 1]) bad = true;
                     if (bad) { refused = true; break; }
                 }
-                if (FILL && lane == 0) {
+                if ((FILL || ordinal < DEVPLAN_KEEP_TILES) && lane == 0) {
+                    // (count pass: indices relative to the field -- primitive 0 = the field's first, entry 0 = its first, out_base = first)
+                    const int64_t p_base = FILL ? prim_index0 : 0;
                     DevTile t;
                     t.field = (int32_t)field; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
                     if (first < gen_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
-                    else { t.idx0 = (int32_t)(prim_index0 + prim_of(first)); t.off0 = 0; }
+                    else { t.idx0 = (int32_t)(p_base + prim_of(first)); t.off0 = 0; }
                     DevWaveTile wt;
                     memset(&wt, 0, sizeof wt);
-                    wt.out_base = pt_off + first; wt.field = (int32_t)field; wt.tile = (int32_t)(stat_base + (span_k > 0 ? 1 : 0) + ordinal);
+                    wt.out_base = (FILL ? pt_off : 0) + first; wt.field = (int32_t)field;
+                    wt.tile = (int32_t)((FILL ? stat_base : 0) + (span_k > 0 ? 1 : 0) + ordinal);
                     wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = all_in ? 1 : 0;
                     wt.rel_main = clampi(gen_main - first); wt.rel_seam = clampi(n_main - first); wt.rel_last = clampi(n_total - 1 - first);
                     wt.rel_zero = clampi(-first);
                     wt.idx0 = t.idx0; wt.off0 = t.off0;
                     for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
                     if (last >= gen_main) {
-                        wt.p0 = (int32_t)(prim_index0 + pa);
+                        wt.p0 = (int32_t)(p_base + pa);
                         wt.r0 = (int32_t)(first - (n_main + L.pstart[pa]));
                         for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
                     }
-                    T.tiles[tile_base + span_k + ordinal] = t;
-                    T.wtiles[wave_base + ordinal] = wt;
+                    if (FILL) { T.tiles[tile_base + span_k + ordinal] = t; T.wtiles[wave_base + ordinal] = wt; }
+                    else { keep_tiles[field * DEVPLAN_KEEP_TILES + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_TILES + ordinal] = wt; }
                 }
                 inside_cnt += all_in ? 1 : 0;
                 wave_pts += c;
@@ -449,13 +495,56 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
         const int64_t ob = base_of(PC_OPEN);
         for (int64_t j = lane; j < n_wave; j += 64) T.open_wave_ids[ob + j] = (int32_t)(wave_base + j);
     }
-}
-
-// the field table's point offsets into fcpp_field_info (after the scan)
-__global__ void k_info_offsets(int64_t n, const int64_t *__restrict__ bases, fcpp_field_info *__restrict__ info)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) info[i].point_offset = bases[(int64_t)PC_POINTS * n + i];
+    // ---- what the host path computes with three more launches after its copy (k_field_junctions, k_run_consts, k_work_totals), per field:
+    // the junction after a U-turn, the closed-form statistics of the field's span in its slot (zeros in the slots of its tiles), and for a
+    // field of field work the sum of its runs' statistics
+    {
+        double2 junc = make_double2(0.0, 0.0);
+        if (n_total > 0 && F.P >= 2 && F.n_line >= 2 && F.n_turn >= 1) junc.x = line_start_curvature(F, cst, 1, junc.y);
+        TilePartial tp;
+        memset(&tp, 0, sizeof tp);
+        if (span_k > 0) {
+            DevTile tl;
+            tl.field = (int32_t)field; tl.start = 0; tl.count = 0; tl.quiet = 4; tl.stat_tile = 0; tl.idx0 = 0; tl.off0 = 0;
+            FieldStatView fv;
+            fv.n_line = F.n_line; fv.n_turn = F.n_turn; fv.reverse_order = F.reverse_order; fv.line_step = F.line_step; fv.n_main = F.n_main; fv.junc = junc;
+            const DevRun run = { (int32_t)tile_base, 0, S };
+            tp = quiet_run_partial(run, tl, fv, T.prims, cst);
+            tp.n_viol = tp.n_outside = tp.n_in_obstacle = tp.n_adjusted = 0;
+        }
+        static_assert(sizeof(TilePartial) == 13 * 8, "thirteen 8-byte components");
+        // slots: entry 0 = the span's (when there is one), the others zero
+        unsigned long long *slots = reinterpret_cast<unsigned long long *>(T.partial + stat_base);
+        const unsigned long long *tpw = reinterpret_cast<const unsigned long long *>(&tp);
+        const int64_t nwords = c_stat * 13;
+        for (int64_t k = lane; k < nwords; k += 64) {
+            unsigned long long v = 0;
+            if (span_k > 0 && k < 13) {
+#pragma unroll
+                for (int q = 0; q < 13; ++q) if (k == q) v = tpw[q];
+            }
+            slots[k] = v;
+        }
+        if (lane == 0) {
+            T.field_junc[field] = junc;
+            if (is_work) {
+                TilePartial t;
+                memset(&t, 0, sizeof t);
+                if (span_k > 0) {
+                    t.main_len += tp.main_len; t.main_time_pre += tp.main_time_pre; t.main_time += tp.main_time;
+                    t.head_len += tp.head_len; t.head_time_pre += tp.head_time_pre; t.head_time += tp.head_time;
+                    t.max_kappa = fmax(t.max_kappa, tp.max_kappa); t.max_alat = fmax(t.max_alat, tp.max_alat); t.max_jump = fmax(t.max_jump, tp.max_jump);
+                    t.n_viol += tp.n_viol; t.n_adjusted += tp.n_adjusted;
+                }
+                T.work_totals[base_of(PC_WORK)] = t;
+            }
+        }
+        // the field's fcpp_field_info stays with the batch (fcpp_batch_info copies it back when asked)
+        static_assert(sizeof(fcpp_field_info) % 8 == 0, "copied as 8-byte words");
+        const unsigned long long *is = reinterpret_cast<const unsigned long long *>(&info[field]);
+        unsigned long long *id = reinterpret_cast<unsigned long long *>(&T.info[field]);
+        for (int k = lane; k < (int)(sizeof(fcpp_field_info) / 8); k += 64) id[k] = is[k];
+    }
 }
 
 __global__ void k_debug_math(int fn, int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o0, double *__restrict__ o1)
@@ -479,20 +568,19 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
                        n_polys, check_obstacles);
     int rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_info_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, s.bases, s.info);
-    hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, s.fields_tmp, s.prims_tmp,
-                       s.info, s.counts, s.bases, s.totals, DevPlanTables());
+    hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, DevConst(), s.fields_tmp, s.prims_tmp,
+                       s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
     rc = launch_scan(st, n, PC_TILES, PC_COLS, s);
     if (rc) return rc;
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevPlanScratch &s, const DevPlanTables &t)
+int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevConst &cst, const DevPlanScratch &s, const DevPlanTables &t)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL((k_tile_fields<true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, s.fields_tmp, s.prims_tmp,
-                       s.info, s.counts, s.bases, s.totals, t);
+    hipLaunchKernelGGL((k_tile_fields<true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, cst, s.fields_tmp, s.prims_tmp,
+                       s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, t);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

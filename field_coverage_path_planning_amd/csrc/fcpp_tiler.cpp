@@ -423,6 +423,7 @@ void layout_image(ImageLayout &lay)
     take(lay.red_scratch, (size_t)lay.n_red[3] * 64 * 104);
     take(lay.field_junc, (size_t)lay.n_fields * 2 * sizeof(double));
     take(lay.work_totals, (size_t)lay.n_field_work * sizeof(TilePartial));   // per field of field_work: the statistics of its quiet runs, summed once
+    take(lay.info, lay.info_on_device ? (size_t)lay.n_fields * sizeof(fcpp_field_info) : 0);   // device-side setup: fcpp_field_info, copied back on demand
     lay.total_bytes = o;
 }
 

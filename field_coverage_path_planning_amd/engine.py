@@ -304,11 +304,21 @@ class Batch:
         L.check(self.lib.fcpp_batch_create(self.ctx.handle, C.byref(self.vehicle), C.byref(self.options),
                                            self.n_fields, arr, C.byref(polys), C.byref(h)))
         self.handle = h
-        self.info = InfoTable(self.n_fields)
+        self._info = None
         tot = C.c_int64()
-        L.check(self.lib.fcpp_batch_info(self.handle, self.info._c, C.byref(tot)))
+        L.check(self.lib.fcpp_batch_info(self.handle, None, C.byref(tot)))
         self.total_points = tot.value
         self._last_mode = 1
+
+    @property
+    def info(self):
+        """fcpp_field_info of every field (InfoTable).  A batch set up on the device keeps the records there until they are asked for:
+        the first access copies them back (and waits for the batch's setup)."""
+        if self._info is None:
+            t = InfoTable(self.n_fields)
+            L.check(self.lib.fcpp_batch_info(self.handle, t._c, None))
+            self._info = t
+        return self._info
 
     def setup_times(self):
         """Where the time of this batch's creation went, in ms: {'pack', 'host_plan', 'templates', 'tiler', 'image', 'h2d', 'create'
