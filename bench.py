@@ -749,9 +749,9 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
             batch = bufs = res = None
         fence()
         t0 = time.perf_counter()
-        infos = E.plan_count(table, veh, opt)
+        counts = E.plan_points(table, veh, opt, device=dev.index)      # sizing of ALL fields, on this rank's GPU (fcpp_plan_points)
         t1 = time.perf_counter()
-        res = S.plan_sharded(table, veh, opt, device=dev.index, infos=infos)          # this rank's batch + buffers + one step + stats gather
+        res = S.plan_sharded(table, veh, opt, device=dev.index, counts=counts)          # this rank's batch + buffers + one step + stats gather
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         batch = res.batch
@@ -777,11 +777,11 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
     fence()
     # ---- the job per step with the stats gather (sizing and batch setup done once, above)
     for _ in range(2):
-        res = S.plan_sharded(table, veh, opt, device=dev.index, batch=batch, buffers=bufs, infos=infos)
+        res = S.plan_sharded(table, veh, opt, device=dev.index, batch=batch, buffers=bufs, counts=counts)
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = S.plan_sharded(table, veh, opt, device=dev.index, batch=batch, buffers=bufs, infos=infos)
+        res = S.plan_sharded(table, veh, opt, device=dev.index, batch=batch, buffers=bufs, counts=counts)
     fence()
     dt_job = allmax(time.perf_counter() - t0)
     my_points = batch.total_points
@@ -807,12 +807,12 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
     # the optional point-array gather, once
     fence()
     t0 = time.perf_counter()
-    resg = S.plan_sharded(table, veh, opt, device=dev.index, batch=batch, buffers=bufs, infos=infos, gather_points=True)
+    resg = S.plan_sharded(table, veh, opt, device=dev.index, batch=batch, buffers=bufs, counts=counts, gather_points=True)
     fence()
     t_with_gather = allmax(time.perf_counter() - t0)
     entry = None
     if rank == 0:
-        total = int(infos.counts().sum())
+        total = int(counts.sum())
         st = res.stats()
         assert res.stats_all.shape[0] == len(table) and int(st['n_viol'].sum()) == 0
         if resg.points_all is not None:
@@ -836,8 +836,8 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
                                 'setup_ms': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mid['setup_ms'].items()},
                                 'first_ms': e2e[0]['ms'], 'all_ms': [round(r['ms'], 3) for r in e2e], 'table_from_vertices_ms': t_table,
                                 'what': 'the sharded job from the field table to the gathered stats, fresh batch in a warm context (max over ranks): '
-                                        'fcpp_plan_count over all fields on every rank (threaded, no collective) + this rank\'s engine.Batch + output arrays + '
-                                        'one step + stats gather; median of the repetitions after the first'},
+                                        'fcpp_plan_points over all fields on every rank\'s own GPU (no collective) + this rank\'s engine.Batch (set up on the device) + '
+                                        'output arrays + one step + stats gather; median of the repetitions after the first'},
                  'setup_ms': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mid['setup_ms'].items()},
                  'ms_per_job_with_stats_gather': dt_job / steps * 1e3,
                  'per_gpu': [{'rank': k, 'points': int(pr[k, 0]), 'ms_per_step': float(pr[k, 1] * 1e3), 'points_per_s': float(pr[k, 0] / pr[k, 1])}

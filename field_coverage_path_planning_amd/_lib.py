@@ -120,6 +120,7 @@ PROTOTYPES = [
     ('fcpp_memcpy_d2h', C.c_int, [_VP, _VP, _VP, C.c_int64]),
     ('fcpp_plan_count', C.c_int, [C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field), C.POINTER(Polys),
                                   C.POINTER(FieldInfo)]),
+    ('fcpp_plan_points', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field), C.POINTER(Polys), c_i64_p]),
     ('fcpp_batch_create', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field),
                                     C.POINTER(Polys), C.POINTER(_VP)]),
     ('fcpp_batch_info', C.c_int, [_VP, C.POINTER(FieldInfo), c_i64_p]),

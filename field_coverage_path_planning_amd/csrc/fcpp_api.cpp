@@ -456,6 +456,40 @@ int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_
     return FCPP_OK;
 }
 
+namespace { int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, DevPlanScratch &s, std::string &err); }
+
+// Sizing for a sharded job: points per field.  On the device for the batches the device planner takes (k_plan_fields without primitives,
+// the counts copied back), else on the host's cores.
+int fcpp_plan_points(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
+                     const fcpp_polys *obstacles, int64_t *points_out)
+{
+    if (!c || !veh || !opt || n_fields < 0 || (n_fields > 0 && (!fields || !points_out))) return fail(FCPP_EINVAL, "bad arguments");
+    if (n_fields == 0) return FCPP_OK;
+    std::string err;
+    PlanConsts pc;
+    TurnTemplates tt;
+    int rc = plan_prepare(*veh, *opt, pc, tt, err);
+    if (rc != FCPP_OK) return fail(rc, err);
+    const bool on_device = c->setup_mode != FCPP_SETUP_HOST && opt->sample_spacing == 0.0 && opt->obstacle_mode == FCPP_OBSTACLES_FLAG &&
+                           pc.max_prims <= DEVPLAN_PRIMS_CAP && !tune_enabled();
+    if (!on_device) {
+        HostPlan hp;
+        rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, false, hp, err);
+        if (rc != FCPP_OK) return fail(rc, err);
+        for (int64_t i = 0; i < n_fields; ++i) points_out[i] = hp.info[(size_t)i].n_main + hp.info[(size_t)i].n_head;
+        return FCPP_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    DevPlanScratch s;
+    if ((rc = plan_scratch(c, n_fields, pc.max_prims, st, s, err)) != FCPP_OK) return fail(rc, err);
+    HIPCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
+    LAUNCHCHK(launch_devplan_points(st, n_fields, pc, s));
+    HIPCHK(hipMemcpyAsync(points_out, s.counts + (int64_t)PC_POINTS * n_fields, (size_t)n_fields * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return FCPP_OK;
+}
+
 // the context's turn templates for (tt, clothoid_frac): the kept set, or a new one sampled on the device (asynchronous: the caller
 // synchronises the stream before it reads the host copies; `fresh` tells it to)
 static int get_templates(fcpp_ctx *c, const TurnTemplates &tt, const fcpp_options &opt, hipStream_t st, std::shared_ptr<TemplateSet> &out, bool &fresh)
@@ -537,6 +571,29 @@ int take_slab(fcpp_ctx *c, fcpp_batch *b, std::string &err)
         if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return FCPP_EHIP; } \
     } while (0)
 
+// the context's planner scratch for n fields (grow-only), ordered behind the last fill pass that read it
+int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, DevPlanScratch &s, std::string &err)
+{
+    if (!c->ev_plan) DEVCHK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+    if (c->ev_plan_set) DEVCHK(hipStreamWaitEvent(st, c->ev_plan, 0));       // (the previous batch's fill pass may still read the scratch)
+    DevPlanScratch off;
+    const size_t need = devplan_scratch_layout(n_fields, max_prims, &off);
+    if (c->plan_scratch_cap < need) {
+        if (c->plan_scratch) { DEVCHK(hipDeviceSynchronize()); (void)hipFree(c->plan_scratch); c->plan_scratch = nullptr; c->plan_scratch_cap = 0; }
+        const size_t want = need + need / 4;
+        if (hipMalloc(&c->plan_scratch, want) != hipSuccess) { (void)hipGetLastError(); err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
+        c->plan_scratch_cap = want;
+    }
+    if (!c->plan_totals_host) DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipHostMallocDefault));
+    unsigned char *sb = static_cast<unsigned char *>(c->plan_scratch);
+    s.fields_in = reinterpret_cast<fcpp_field *>(sb + (size_t)off.fields_in); s.info = reinterpret_cast<fcpp_field_info *>(sb + (size_t)off.info);
+    s.fields_tmp = reinterpret_cast<DevField *>(sb + (size_t)off.fields_tmp); s.prims_tmp = reinterpret_cast<DevPrim *>(sb + (size_t)off.prims_tmp);
+    s.counts = reinterpret_cast<int64_t *>(sb + (size_t)off.counts); s.bases = reinterpret_cast<int64_t *>(sb + (size_t)off.bases);
+    s.blk_sums = reinterpret_cast<int64_t *>(sb + (size_t)off.blk_sums); s.totals = reinterpret_cast<int64_t *>(sb + (size_t)off.totals);
+    s.keep_tiles = reinterpret_cast<DevTile *>(sb + (size_t)off.keep_tiles); s.keep_wtiles = reinterpret_cast<DevWaveTile *>(sb + (size_t)off.keep_wtiles);
+    return FCPP_OK;
+}
+
 // FCPP_OK: the batch is set up (tables on the device, info on the host); kNotOnDevice: not this path's batch; else the error.
 // fresh_templates: the batch's template set is still on its way back from the device (cleared once this path has waited for it)
 int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_field *fields, const fcpp_polys *obstacles, bool &fresh_templates,
@@ -571,24 +628,8 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
 
     // scratch + the field records
     t0 = std::chrono::steady_clock::now();
-    if (!c->ev_plan) DEVCHK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
-    if (c->ev_plan_set) DEVCHK(hipStreamWaitEvent(st, c->ev_plan, 0));       // (the previous batch's fill pass may still read the scratch)
-    DevPlanScratch off;
-    const size_t need = devplan_scratch_layout(n_fields, pc.max_prims, &off);
-    if (c->plan_scratch_cap < need) {
-        if (c->plan_scratch) { DEVCHK(hipDeviceSynchronize()); (void)hipFree(c->plan_scratch); c->plan_scratch = nullptr; c->plan_scratch_cap = 0; }
-        const size_t want = need + need / 4;
-        if (hipMalloc(&c->plan_scratch, want) != hipSuccess) { (void)hipGetLastError(); err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
-        c->plan_scratch_cap = want;
-    }
-    if (!c->plan_totals_host) DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipHostMallocDefault));
-    unsigned char *sb = static_cast<unsigned char *>(c->plan_scratch);
     DevPlanScratch s;
-    s.fields_in = reinterpret_cast<fcpp_field *>(sb + (size_t)off.fields_in); s.info = reinterpret_cast<fcpp_field_info *>(sb + (size_t)off.info);
-    s.fields_tmp = reinterpret_cast<DevField *>(sb + (size_t)off.fields_tmp); s.prims_tmp = reinterpret_cast<DevPrim *>(sb + (size_t)off.prims_tmp);
-    s.counts = reinterpret_cast<int64_t *>(sb + (size_t)off.counts); s.bases = reinterpret_cast<int64_t *>(sb + (size_t)off.bases);
-    s.blk_sums = reinterpret_cast<int64_t *>(sb + (size_t)off.blk_sums); s.totals = reinterpret_cast<int64_t *>(sb + (size_t)off.totals);
-    s.keep_tiles = reinterpret_cast<DevTile *>(sb + (size_t)off.keep_tiles); s.keep_wtiles = reinterpret_cast<DevWaveTile *>(sb + (size_t)off.keep_wtiles);
+    if ((rc = plan_scratch(c, n_fields, pc.max_prims, st, s, err)) != FCPP_OK) return rc;
     DEVCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
 
     DevTileConsts tc;

@@ -72,6 +72,8 @@ constexpr int DEVPLAN_KEEP_TILES = 8;
 // phase 1: plan + count.  Enqueues k_plan_fields, the scans and the counting pass; afterwards totals[] holds the sums and the flags.
 int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, int64_t n_polys,
                          int check_obstacles);
+// sizing only (fcpp_plan_points): k_plan_fields without primitives; counts[PC_POINTS][field] = points of the field
+int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s);
 // phase 2: the tables.  `bases` / `totals` as phase 1 left them.
 int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevConst &cst, const DevPlanScratch &s, const DevPlanTables &t);
 // fcpp_math.h on the device (tests): fn 0 sincos, 1 atan2(a, b), 2 acos(a), 3 hypot(a, b)

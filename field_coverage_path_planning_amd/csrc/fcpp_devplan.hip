@@ -40,7 +40,7 @@ struct DevSink {
 
 __global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, const fcpp_field *__restrict__ fin, fcpp_field_info *__restrict__ info,
                                                     DevField *__restrict__ ftmp, DevPrim *__restrict__ ptmp, int64_t *__restrict__ counts,
-                                                    int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles)
+                                                    int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles, int count_only)
 {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
@@ -48,9 +48,10 @@ __global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, co
     // the field's obstacle range must lie inside the batch's polygon table: the kernels of a step index it
     if (check_obstacles && (f.n_obstacles < 0 || f.obstacle_first < 0 || (f.n_obstacles > 0 && f.obstacle_first + f.n_obstacles > n_polys)))
         atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_BAD_OBSTACLES), 1ull);
-    DevSink sink{ ptmp + i * pc.max_prims, pc.max_prims, 0 };
+    DevSink sink{ count_only ? nullptr : ptmp + i * pc.max_prims, count_only ? 0 : pc.max_prims, 0 };
     const int64_t npts = plan_field_t(pc, f, info[i], ftmp[i], sink);
     counts[(int64_t)PC_POINTS * n + i] = npts;
+    if (count_only) return;
     counts[(int64_t)PC_PRIMS * n + i] = ftmp[i].prim_count;
     if (sink.n > pc.max_prims) atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), 1ull);
 }
@@ -565,7 +566,7 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
     hipError_t e = hipMemsetAsync(s.totals, 0, (PC_COLS + PF_COUNT) * sizeof(int64_t), st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, s.fields_in, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
-                       n_polys, check_obstacles);
+                       n_polys, check_obstacles, 0);
     int rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s);
     if (rc) return rc;
     hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, DevConst(), s.fields_tmp, s.prims_tmp,
@@ -573,6 +574,15 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
     rc = launch_scan(st, n, PC_TILES, PC_COLS, s);
     if (rc) return rc;
     e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, s.fields_in, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                       (int64_t)0, 0, 1);
+    const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 

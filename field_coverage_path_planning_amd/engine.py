@@ -264,6 +264,17 @@ def plan_count(specs, vehicle, options):
     return info
 
 
+def plan_points(specs, vehicle, options, device=None):
+    """Points per field (n_main + n_head; 0 for a field that raises) as a numpy int64 array: the sizing a sharded job cuts its blocks on
+    (fcpp_plan_points).  Computed on the GPU where the device-side setup takes the batch, else on the host."""
+    ctx = get_context(device)
+    arr, polys, _keep = pack_fields(specs)
+    out = np.zeros(len(specs), dtype=np.int64)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_plan_points(ctx.handle, C.byref(vehicle), C.byref(options), len(specs), arr, C.byref(polys), out.ctypes.data_as(L.c_i64_p)))
+    return out
+
+
 class BatchResult:
     """Device-resident result of one batch: SoA tensors + per-field stats."""
 

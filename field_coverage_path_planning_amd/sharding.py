@@ -163,22 +163,30 @@ def _comm_tensor(t):
     return t.cpu() if _dist().is_initialized() and _dist().get_backend() == 'gloo' else t
 
 
-def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1, gather_points=False, batch=None, buffers=None, infos=None):
+def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1, gather_points=False, batch=None, buffers=None, infos=None,
+                 counts=None):
     """Plan `specs` (a list of engine.FieldSpec or an engine.FieldTable) across all ranks of the current process group; per-field stats are gathered to rank 0, and so are the point
     arrays (x, y, kappa, v, flagseg) when gather_points is set.
 
     compute(specs_block, vehicle, options) -> (n_block, 13) int64 tensor [, list of 1-D point arrays] replaces the GPU batch in
     the CPU (gloo) tests.  batch / buffers: reuse this rank's engine.Batch (and output buffers) of an earlier call with the same
     specs -- the setup (fcpp_batch_create) is then skipped, as a caller that plans the same fields repeatedly would; infos: the
-    fcpp_plan_count result of an earlier call (the host-side sizing is then skipped too)."""
+    fcpp_plan_count result of an earlier call, or counts: the points per field (engine.plan_points) -- the sizing is then skipped too.
+
+    The sizing -- what every rank needs of ALL fields to cut the blocks -- is the points per field: on a GPU rank it comes from the
+    device (engine.plan_points: the plan function one thread per field, 8 bytes per field back; identical on every rank, so no collective
+    is needed to agree on the partition), in the CPU tests from fcpp_plan_count on the host."""
     import torch
     options = options or E.make_options()
     rank, ws = world()
-    if infos is None:
-        # host only, identical on every rank, threaded over blocks of fields inside the library (65 536 fields: ~10 ms); no collective
-        # is needed to agree on the partition
-        infos = E.plan_count(specs, vehicle, options)
-    counts = infos.counts() if hasattr(infos, 'counts') else np.asarray([i.n_main + i.n_head for i in infos], dtype=np.int64)
+    if counts is None:
+        if infos is None and compute is None:
+            counts = E.plan_points(specs, vehicle, options, device=device)
+        else:
+            if infos is None:
+                infos = E.plan_count(specs, vehicle, options)
+            counts = infos.counts() if hasattr(infos, 'counts') else np.asarray([i.n_main + i.n_head for i in infos], dtype=np.int64)
+    counts = np.asarray(counts, dtype=np.int64)
     blocks = partition_by_points(counts, ws)
     lo, hi = blocks[rank]
     local, arrays = None, None
@@ -200,7 +208,9 @@ def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1
     if gather_points:
         per_rank = [int(np.sum(counts[a:b])) for a, b in blocks]
         points_all = gather_arrays([_comm_tensor(a) for a in arrays], per_rank, dst=0)
-    return ShardedResult((lo, hi), local, stats_all, infos, blocks, points_all, batch)
+    res = ShardedResult((lo, hi), local, stats_all, infos, blocks, points_all, batch)
+    res.counts = counts           # points per field of the whole batch
+    return res
 
 
 def partition_even(n_items, world_size):

@@ -190,7 +190,12 @@ int fcpp_memcpy_d2h(fcpp_ctx *ctx, void *dst, const void *src_dev, int64_t bytes
 int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
                     const fcpp_field *fields, const fcpp_polys *obstacles /* may be NULL unless obstacle_mode = AVOID */,
                     fcpp_field_info *info_out);
-/* Same setup, plus upload of the per-field descriptors to the device. */
+/* Sizing alone, for a job sharded over several GPUs (contiguous blocks of fields cut on the point counts): points_out[i] =
+ * n_main + n_head of field i, 0 for a field that raises.  Runs on the device where the device-side setup takes the batch (fcpp_ctx_set_setup;
+ * only the field records go up, 8 bytes per field come back), else on the host's cores like fcpp_plan_count.  Synchronises. */
+int fcpp_plan_points(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
+                     const fcpp_polys *obstacles, int64_t *points_out);
+/* Same setup, plus the per-field descriptors and the kernels' work lists on the device. */
 int fcpp_batch_create(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
                       const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **batch);
 int fcpp_batch_info(const fcpp_batch *batch, fcpp_field_info *info_out /* n_fields, may be NULL */,

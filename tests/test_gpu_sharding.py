@@ -50,6 +50,8 @@ def test_stats_and_points_identical_for_1_2_4_8_shards():
                        (WL.specs_from_lh(E, WL.cfg2_rectangles(40, seed=9)), E.make_options(1, 0.5))):
         infos = E.plan_count(specs, veh, opt)
         counts = [i.n_main + i.n_head for i in infos]
+        # the sizing a sharded job uses: on the device for the reference's sampling, on the host for the dense batch -- the same counts
+        assert np.array_equal(E.plan_points(specs, veh, opt), np.asarray(counts, dtype=np.int64))
         whole = E.Batch(specs, veh, opt)
         ref = whole.run()
         ref_stats = ref.stats_raw.cpu().numpy()
