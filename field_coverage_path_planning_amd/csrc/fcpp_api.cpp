@@ -185,7 +185,7 @@ struct FusedTables {
     DevField *fields = nullptr; DevPrim *prims = nullptr; DevTile *tiles = nullptr; DevWaveTile *wave_tiles = nullptr;
     int32_t *general_ids = nullptr; DevTile *chunks = nullptr, *span_chunks = nullptr;
     int32_t *stat_ids = nullptr; int64_t *stat_first = nullptr, *stat_run = nullptr; int32_t *red_paths = nullptr;
-    DevFieldWork *field_work = nullptr; int32_t *open_wave_ids = nullptr;
+    DevFieldWork *field_work = nullptr; DevFieldPack *field_packs = nullptr; int32_t *open_wave_ids = nullptr;
     int64_t *obs_off = nullptr; double *obs_x = nullptr, *obs_y = nullptr, *obs_bbox = nullptr;
     double *seg = nullptr; int32_t *seg_mask = nullptr;
     TilePartial *partial = nullptr; char *red_scratch = nullptr; double2 *field_junc = nullptr;
@@ -543,7 +543,8 @@ void bind_tables(fcpp_batch *b)
     t.chunks = reinterpret_cast<DevTile *>(d + lay.chunks); t.span_chunks = reinterpret_cast<DevTile *>(d + lay.span_chunks);
     t.stat_ids = reinterpret_cast<int32_t *>(d + lay.stat_ids); t.stat_first = reinterpret_cast<int64_t *>(d + lay.stat_first);
     t.stat_run = reinterpret_cast<int64_t *>(d + lay.stat_run); t.red_paths = reinterpret_cast<int32_t *>(d + lay.red_paths);
-    t.field_work = reinterpret_cast<DevFieldWork *>(d + lay.field_work); t.open_wave_ids = reinterpret_cast<int32_t *>(d + lay.open_wave_ids);
+    t.field_work = reinterpret_cast<DevFieldWork *>(d + lay.field_work); t.field_packs = reinterpret_cast<DevFieldPack *>(d + lay.field_packs);
+    t.open_wave_ids = reinterpret_cast<int32_t *>(d + lay.open_wave_ids);
     if (lay.n_polys > 0) {
         t.obs_off = reinterpret_cast<int64_t *>(d + lay.obs_off); t.obs_x = reinterpret_cast<double *>(d + lay.obs_x);
         t.obs_y = reinterpret_cast<double *>(d + lay.obs_y); t.obs_bbox = reinterpret_cast<double *>(d + lay.obs_bbox);
@@ -636,6 +637,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     tc.tu = reinterpret_cast<const Pt2 *>(ts.tmpl_u.p); tc.tc = reinterpret_cast<const Pt2 *>(ts.tmpl_c.p);
     tc.nu = ts.tt.nu; tc.nc = ts.tt.nc;
     tc.turn_quiet = turn_quiet; tc.wave_factor = 24; tc.field_work_tiles = FIELD_WORK_TILES; tc.max_prims = pc.max_prims;
+    tc.fuse_spans = ts.tt.nu <= TMPL_LDS_SAMPLES; tc._pad = 0;
     tc.two_a = 2 * b->cst.a_lon; tc.u_cap = b->cst.u_cap; tc.c_line = b->cst.ms_work * b->cst.ms_work;
     tc.fence_margin = 1e-7 - opt.geofence_tol;
     tc.reduce_wg_max = 1024;
@@ -658,10 +660,15 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     lay = ImageLayout();
     lay.n_fields = n_fields; lay.n_prims = tot[PC_PRIMS]; lay.wave_tile_points = 128;
     lay.n_tiles = tot[PC_TILES]; lay.n_wave = tot[PC_WAVE]; lay.n_general = tot[PC_GENERAL]; lay.n_stat = tot[PC_STAT];
-    lay.n_chunks = 0; lay.n_span_chunks = tot[PC_SPAN]; lay.n_runs = tot[PC_RUNS];
+    // the spans of fields of field work are written by the fields' own workgroups (k_plan_sparse_fields) when ALL of them are short enough for
+    // that -- the span launch of such a batch disappears -- and by k_plan_quiet otherwise (a mix loses: measured on cfg2 at the reference's
+    // sampling, a third of its spans fusable, 0.0435 instead of 0.0392 ms)
+    const bool fuse = tc.fuse_spans && tot[PC_UNFUSABLE] == 0 && tot[PC_WORK_SPAN_PTS] > 0;
+    tc.fuse_spans = fuse;
+    lay.n_chunks = 0; lay.n_span_chunks = fuse ? tot[PC_SPAN_F] : tot[PC_SPAN]; lay.n_runs = tot[PC_RUNS];
     for (int k = 0; k < 4; ++k) lay.n_red[k] = tot[PC_CLS0 + k];
     lay.n_work[0] = tot[PC_WORK]; lay.n_field_work = tot[PC_WORK]; lay.n_open_wave = tot[PC_OPEN];
-    lay.quiet_points = tot[PC_SPAN_PTS]; lay.span_points = tot[PC_SPAN_PTS]; lay.chunk_points = 0; lay.wave_points = tot[PC_WAVE_PTS];
+    lay.quiet_points = tot[PC_SPAN_PTS]; lay.span_points = tot[PC_SPAN_PTS] - (fuse ? tot[PC_WORK_SPAN_PTS] : 0); lay.work_span_points = fuse ? tot[PC_WORK_SPAN_PTS] : 0; lay.chunk_points = 0; lay.wave_points = tot[PC_WAVE_PTS];
     lay.work_wave_points = tot[PC_WORK_WAVE_PTS]; lay.wave_inside = tot[PC_WAVE_INSIDE];
     lay.n_polys = n_polys; lay.n_poly_verts = n_polys > 0 ? obstacles->offsets[n_polys] : 0;
     lay.info_on_device = true;
@@ -694,7 +701,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     DevPlanTables T;
     T.fields = b->t.fields; T.prims = b->t.prims; T.tiles = b->t.tiles; T.wtiles = b->t.wave_tiles; T.general_ids = b->t.general_ids;
     T.span_chunks = b->t.span_chunks; T.stat_ids = b->t.stat_ids; T.stat_first = b->t.stat_first; T.stat_run = b->t.stat_run;
-    T.red_paths = b->t.red_paths; T.field_work = b->t.field_work; T.open_wave_ids = b->t.open_wave_ids; T.seg = b->t.seg; T.seg_mask = b->t.seg_mask;
+    T.red_paths = b->t.red_paths; T.field_work = b->t.field_work; T.field_packs = b->t.field_packs; T.open_wave_ids = b->t.open_wave_ids; T.seg = b->t.seg; T.seg_mask = b->t.seg_mask;
     T.partial = b->t.partial; T.field_junc = b->t.field_junc; T.work_totals = b->t.work_totals;
     T.info = reinterpret_cast<fcpp_field_info *>(static_cast<unsigned char *>(b->slab) + lay.info);
     b->cst.field_junc = b->t.field_junc;
@@ -805,10 +812,16 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tc.wave_points = tune_int("FCPP_WAVE_POINTS", 128) == 64 ? 64 : 128;
     tc.field_work = tune_int("FCPP_FIELD_WORK", 1) != 0;
     tc.field_work_tiles = std::max(1, std::min(tune_int("FCPP_FIELD_WORK_TILES", FIELD_WORK_TILES), FIELD_WORK_TILES));
+    tc.fuse_spans = tc.field_work && ts.tt.nu <= TMPL_LDS_SAMPLES && tune_int("FCPP_FUSE_SPANS", 1) != 0;
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);
     if (rc != FCPP_OK) return fail(rc, err);
+    if (tc.fuse_spans && lay.unfusable_work > 0) {       // all spans of fields of field work are fused, or none (as on the device path)
+        tc.fuse_spans = false;
+        rc = tiler.plan(b->hp, tc, obstacles, lay, err);
+        if (rc != FCPP_OK) return fail(rc, err);
+    }
     tm.tiler_ms = ms_since(t0);
     if (getenv("FCPP_DEBUG_TILING"))
         fprintf(stderr, "[fcpp] tiling: %lld tiles; wave-tile stretches refused: back halo %lld, forward halo %lld, too few outputs %lld, "
@@ -970,10 +983,10 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
             bool first = true;
             for (int c = 0; c < 4; ++c) {
                 if (lay.n_work[c] == 0) continue;
-                if (first) STAGE(5, launch_plan_sparse_fields(st, lay.n_work[c], t.field_work + off, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
-                                                              FIELD_WORK_WAVES[c], t.work_totals + off, stats));
-                else LAUNCHCHK(launch_plan_sparse_fields(st, lay.n_work[c], t.field_work + off, t.wave_tiles, t.fields, t.prims, b->cst, obs, x, y, kappa, v, fs, t.partial,
-                                                         FIELD_WORK_WAVES[c], t.work_totals + off, stats));
+                if (first) STAGE(5, launch_plan_sparse_fields(st, lay.n_work[c], t.field_packs + off, b->cst, obs, x, y, kappa, v, fs, t.partial,
+                                                              FIELD_WORK_WAVES[c], t.work_totals + off, stats, lay.work_span_points > 0));
+                else LAUNCHCHK(launch_plan_sparse_fields(st, lay.n_work[c], t.field_packs + off, b->cst, obs, x, y, kappa, v, fs, t.partial,
+                                                         FIELD_WORK_WAVES[c], t.work_totals + off, stats, lay.work_span_points > 0));
                 first = false;
                 off += lay.n_work[c];
             }
@@ -1058,7 +1071,8 @@ int fcpp_batch_stage_points(const fcpp_batch *b, int mode, int stage, int64_t *p
     const ImageLayout &t = b->lay;
     const int64_t all = b->hp.total_points;
     if (mode == 0) { *points = all; return FCPP_OK; }         // every staged kernel sees every point
-    const int64_t per_stage[6] = { t.span_points, t.chunk_points, t.wave_points - t.work_wave_points, all - t.quiet_points - t.wave_points, all, t.work_wave_points };
+    const int64_t per_stage[6] = { t.span_points, t.chunk_points, t.wave_points - t.work_wave_points, all - t.quiet_points - t.wave_points, all,
+                                   t.work_wave_points + t.work_span_points };
     *points = per_stage[stage];
     return FCPP_OK;
 }
@@ -1448,12 +1462,13 @@ int fcpp_batch_debug_table(const fcpp_batch *b, int table, void *dst, int64_t ca
     const ImageLayout &l = b->lay;
     const size_t n = (size_t)l.n_fields;
     const size_t off[] = { l.fields, l.prims, l.tiles, l.wtiles, l.general_ids, l.chunks, l.span_chunks, l.stat_ids, l.stat_first, l.stat_run, l.red_paths,
-                           l.field_work, l.open_wave_ids, l.seg, l.seg_mask, l.partial, l.field_junc, l.work_totals, l.obs_off, l.obs_x, l.obs_y, l.obs_bbox };
+                           l.field_work, l.open_wave_ids, l.seg, l.seg_mask, l.partial, l.field_junc, l.work_totals, l.obs_off, l.obs_x, l.obs_y, l.obs_bbox, l.field_packs };
     const size_t len[] = { n * sizeof(DevField), (size_t)l.n_prims * sizeof(DevPrim), (size_t)l.n_tiles * sizeof(DevTile), (size_t)l.n_wave * sizeof(DevWaveTile),
                            (size_t)l.n_general * 4, (size_t)l.n_chunks * sizeof(DevTile), (size_t)l.n_span_chunks * sizeof(DevTile), (size_t)l.n_stat * 4,
                            (n + 1) * 8, (size_t)l.n_stat * 8, n * 4, (size_t)l.n_field_work * sizeof(DevFieldWork), (size_t)l.n_open_wave * 4, n * 64, n * 8,
                            (size_t)l.n_stat * sizeof(TilePartial), n * 16, (size_t)l.n_field_work * sizeof(TilePartial),
-                           l.n_polys > 0 ? (size_t)(l.n_polys + 1) * 8 : 0, (size_t)l.n_poly_verts * 8, (size_t)l.n_poly_verts * 8, (size_t)l.n_polys * 32 };
+                           l.n_polys > 0 ? (size_t)(l.n_polys + 1) * 8 : 0, (size_t)l.n_poly_verts * 8, (size_t)l.n_poly_verts * 8, (size_t)l.n_polys * 32,
+                           (size_t)l.n_field_work * sizeof(DevFieldPack) };
     constexpr int kTables = (int)(sizeof(off) / sizeof(off[0]));
     if (table < 0 || table >= kTables) return fail(FCPP_EINVAL, "no such table");
     *bytes_out = (int64_t)len[table];

@@ -97,9 +97,9 @@ int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtil
                        TilePartial *partial, int points_per_lane = 1,        // 1: tiles of <= 64 points, 2: of <= 128 (fcpp_sparse2_fn.h)
                        const int32_t *ids = nullptr);                       // ids: the launch covers wtiles[ids[k]] (NULL: all in order)
 // one workgroup per field of `work`: its wave tiles planned (two points per lane) and its statistics reduced, written to stats[field]
-int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldWork *work, const DevWaveTile *wtiles, const DevField *fields,
-                              const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
-                              uint32_t *fs, TilePartial *partial, int waves, const TilePartial *totals, fcpp_field_stats *stats);   // waves: of FIELD_WORK_WAVES
+int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldPack *packs, const DevConst &cst, const DevObstacles &obs, double *x,
+                              double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial, int waves, const TilePartial *totals,
+                              fcpp_field_stats *stats, bool spans);   // waves: of FIELD_WORK_WAVES; spans: some packs carry a fused span (DevFieldPack.span_points)
 int launch_work_totals(hipStream_t st, int64_t n_work, const DevFieldWork *work, const int64_t *stat_run, const TilePartial *partial, TilePartial *totals);
 int launch_distance_matrix(hipStream_t st, int n, const double *x, const double *y, double *D);
 int launch_best_connections(hipStream_t st, int64_t n_pairs, const int64_t *fo, const int64_t *to, const double *fx, const double *fy,

@@ -23,8 +23,10 @@ namespace fcpp {
 // columns of the per-field count table (counts[col][field]) and of its exclusive scan (bases[col][field]); totals[col] = sum
 enum PlanCol : int {
     PC_POINTS = 0, PC_PRIMS, PC_TILES, PC_WAVE, PC_GENERAL, PC_STAT, PC_SPAN, PC_WORK, PC_OPEN, PC_CLS0, PC_CLS1, PC_CLS2, PC_CLS3,
-    PC_RUNS, PC_SPAN_PTS, PC_WAVE_PTS, PC_WORK_WAVE_PTS, PC_WAVE_INSIDE, PC_COLS
+    PC_RUNS, PC_SPAN_PTS, PC_WAVE_PTS, PC_WORK_WAVE_PTS, PC_WAVE_INSIDE, PC_WORK_SPAN_PTS, PC_SPAN_F, PC_UNFUSABLE, PC_COLS
 };
+// (PC_SPAN: span chunks when no span is fused; PC_SPAN_F: when every fusable span is; PC_UNFUSABLE: fields of field work whose span has too
+// many chunks to be fused -- the host fuses all or none, k_tile_fields<true> is told which: DevTileConsts.fuse_spans)
 // totals[PC_COLS + k]: flags the kernels raise
 enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_COUNT = 2 };
 
@@ -32,7 +34,7 @@ enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_COUNT = 2 };
 struct DevTileConsts {
     const Pt2 *tu, *tc;           // the batch's U-turn / corner templates (device)
     int32_t nu, nc;
-    int32_t turn_quiet, wave_factor, field_work_tiles, max_prims;
+    int32_t turn_quiet, wave_factor, field_work_tiles, max_prims, fuse_spans, _pad;
     double two_a, u_cap, c_line, fence_margin;
     int64_t reduce_wg_max;
 };
@@ -56,7 +58,7 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *offsets_
 // the tables the fill pass writes (pointers into the batch's slab, laid out by the host from the totals)
 struct DevPlanTables {
     DevField *fields; DevPrim *prims; DevTile *tiles; DevWaveTile *wtiles; int32_t *general_ids; DevTile *span_chunks;
-    int32_t *stat_ids; int64_t *stat_first, *stat_run; int32_t *red_paths; DevFieldWork *field_work; int32_t *open_wave_ids;
+    int32_t *stat_ids; int64_t *stat_first, *stat_run; int32_t *red_paths; DevFieldWork *field_work; DevFieldPack *field_packs; int32_t *open_wave_ids;
     double *seg; int32_t *seg_mask;
     // what batch creation computes once from the tables (k_field_junctions, k_run_consts, k_work_totals on the host path), done by the
     // field's own wavefront here; and the field's fcpp_field_info, kept with the batch for fcpp_batch_info

@@ -195,19 +195,24 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
 
     // the field's counts (count pass) / positions (fill pass)
     int64_t c_tiles = 0, c_wave = 0, c_general = 0, c_stat = 0, c_span = 0, c_work = 0, c_open = 0, c_runs = 0, c_span_pts = 0, c_wave_pts = 0,
-            c_work_wave_pts = 0, c_wave_inside = 0;
+            c_work_wave_pts = 0, c_wave_inside = 0, c_work_span_pts = 0, c_span_f = 0, c_unfusable = 0;
     int cls = 0;
     int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, span_base = 0, prim_base = 0;
     if (FILL) {
         tile_base = base_of(PC_TILES); wave_base = base_of(PC_WAVE); general_base = base_of(PC_GENERAL); stat_base = base_of(PC_STAT);
-        span_base = base_of(PC_SPAN); prim_base = base_of(PC_PRIMS);
+        span_base = base_of(tc.fuse_spans ? PC_SPAN_F : PC_SPAN); prim_base = base_of(PC_PRIMS);
     }
     const int prim_count = F.prim_count;
     const int64_t prim_index0 = prim_base;           // batch-wide index of the field's first primitive (fill pass)
 
-    bool fallback = false;
-    int64_t S = 0, span_k = 0;
+    bool fallback = false, is_work = false;
+    int64_t S = 0, span_k = 0, fused_span = 0;
     int64_t n_wave = 0, n_general = 0;
+    // fill pass, lane t: the field's t-th wave tile as written (t < DEVPLAN_KEEP_TILES), its first primitive within the field and the
+    // number of primitives its points lie in (0: none of layer 2) -- what the field's pack takes (DevFieldPack)
+    DevWaveTile my_wt;
+    memset(&my_wt, 0, sizeof my_wt);
+    int my_p0_rel = 0, my_np = 0;
     if (n_total > 0) {
         const int64_t per = (int64_t)F.n_line + F.n_turn, P = F.P, gen_main = F.gen_main;
         const double line_step_len = fabs(F.line_step);
@@ -238,11 +243,17 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                     const int64_t first = wt.out_base;                       // (kept relative to the field)
                     const int nl = (int)wt.hb + wt.count + wt.hf;
                     if (first >= gen_main) { t.idx0 += (int32_t)prim_index0; wt.idx0 = t.idx0; }
-                    if (wt.rel_main < nl) wt.p0 += (int32_t)prim_index0;     // the tile holds points of layer 2
+                    if (wt.rel_main < nl) {                                  // the tile holds points of layer 2
+                        my_p0_rel = wt.p0;
+                        my_np = 1;
+                        for (int k = 0; k < 8; ++k) my_np += wt.thr[k] != 255 ? 1 : 0;
+                        wt.p0 += (int32_t)prim_index0;
+                    }
                     wt.out_base = pt_off + first;
                     wt.tile += (int32_t)stat_base;
                     T.tiles[tile_base + span_k + lane] = t;
                     T.wtiles[wave_base + lane] = wt;
+                    my_wt = wt;
                 }
             }
         }
@@ -392,12 +403,28 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                 }
             }
         }
+        // a field whose general points are all in a few wave tiles is planned AND reduced by one workgroup (k_plan_sparse_fields), which
+        // then writes the field's span too (fuse_spans): its chunks are not in k_plan_quiet's list
+        {
+            const int64_t ne0 = (span_k > 0 ? 1 : 0) + n_wave + n_general;
+            const int fw_max = tc.field_work_tiles < FIELD_WORK_TILES ? tc.field_work_tiles : FIELD_WORK_TILES;
+            is_work = n_general == 0 && n_wave >= 1 && n_wave <= fw_max && ne0 <= FIELD_WORK_ENTRIES;
+        }
         // ---- the span's tiles (near-equal, at most 510 points: the closed-form kernel stores aligned pairs) and its chunks on 512-point
         // boundaries of the batch arrays
         if (span_k > 0) {
             c_runs = 1; c_span_pts = S;
             const int64_t g0 = pt_off;                           // the span starts the path
-            c_span = ((g0 % TILE_POINTS) + S + TILE_POINTS - 1) / TILE_POINTS;
+            const int64_t n_chunks = ((g0 % TILE_POINTS) + S + TILE_POINTS - 1) / TILE_POINTS;
+            // (counting pass: fuse_spans = fusing is possible for this batch, both alternatives are counted; fill pass: the host's
+            // decision -- all fields of field work have fusable spans, or nothing is fused)
+            const bool fusable = is_work && n_chunks <= FUSED_SPAN_CHUNKS;
+            fused_span = (fusable && tc.fuse_spans) ? S : 0;
+            c_span = n_chunks;
+            c_span_f = fused_span > 0 ? 0 : n_chunks;
+            c_work_span_pts = fused_span;
+            c_unfusable = (is_work && !fusable) ? 1 : 0;
+            if (FILL && fused_span > 0) c_span = 0;          // (no chunk records for a fused span)
             if (FILL) {
                 const int64_t bs = S / span_k, rem = S % span_k;
                 for (int64_t j = lane; j < span_k; j += 64) {
@@ -424,8 +451,6 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     }
     // ---- which kernel reduces the field: its own workgroup (k_plan_sparse_fields) or a class of k_reduce_stats
     const int64_t ne = c_stat;
-    const int fw_max = tc.field_work_tiles < FIELD_WORK_TILES ? tc.field_work_tiles : FIELD_WORK_TILES;
-    const bool is_work = n_general == 0 && n_wave >= 1 && n_wave <= fw_max && ne <= FIELD_WORK_ENTRIES;
     if (is_work) { c_work = 1; c_work_wave_pts = c_wave_pts; }
     else { c_open = n_wave; cls = tiler_reduce_class(ne, tc.reduce_wg_max); }
     if (fallback && lane == 0) atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), 1ull);
@@ -439,6 +464,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             c[(int64_t)PC_CLS2 * n] = (!is_work && cls == 2) ? 1 : 0; c[(int64_t)PC_CLS3 * n] = (!is_work && cls == 3) ? 1 : 0;
             c[(int64_t)PC_RUNS * n] = c_runs; c[(int64_t)PC_SPAN_PTS * n] = c_span_pts; c[(int64_t)PC_WAVE_PTS * n] = c_wave_pts;
             c[(int64_t)PC_WORK_WAVE_PTS * n] = c_work_wave_pts; c[(int64_t)PC_WAVE_INSIDE * n] = c_wave_inside;
+            c[(int64_t)PC_WORK_SPAN_PTS * n] = c_work_span_pts; c[(int64_t)PC_SPAN_F * n] = c_span_f; c[(int64_t)PC_UNFUSABLE * n] = c_unfusable;
         }
         return;
     }
@@ -476,7 +502,14 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             DevFieldWork w;
             memset(&w, 0, sizeof w);
             w.field = (int32_t)field; w.n_tiles = (int32_t)n_wave; w.w_first = (int32_t)wave_base; w.e_first = (int32_t)stat_base; w.n_entries = (int32_t)ne;
+            w.fused_span = (int32_t)fused_span;
             T.field_work[base_of(PC_WORK)] = w;              // (every such field has at most four tiles: class 0 is the only class in use)
+            DevFieldPack &P = T.field_packs[base_of(PC_WORK)];
+            P.work = w;
+            P.span_points = fused_span;
+            for (int k = 0; k < 6; ++k) P._pad0[k] = 0;
+            P._pad1 = 0.0;
+            for (int k = 0; k < 4; ++k) P._pad2[k] = 0.0;
         } else {
             int64_t cls_first = 0;
             for (int k = 0; k < cls; ++k) cls_first += totals[PC_CLS0 + k];
@@ -495,6 +528,30 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     if (!is_work) {
         const int64_t ob = base_of(PC_OPEN);
         for (int64_t j = lane; j < n_wave; j += 64) T.open_wave_ids[ob + j] = (int32_t)(wave_base + j);
+    } else {
+        // the field's pack: its tiles (lane t holds tile t: at most four, all kept by the counting pass), its descriptor as written to
+        // the field table, and per tile a copy of its primitives
+        DevFieldPack &P = T.field_packs[base_of(PC_WORK)];
+        if (lane < FIELD_WORK_TILES) P.tile[lane] = my_wt;               // (lanes without a tile hold zeros)
+        {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&F);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&P.field);
+            constexpr int W_PT = (int)(offsetof(DevField, pt_off) / 8), W_PF = (int)(offsetof(DevField, prim_first) / 8);
+            constexpr bool PF_HI = (offsetof(DevField, prim_first) % 8) != 0;
+            for (int k = lane; k < (int)(sizeof(DevField) / 8); k += 64) {
+                unsigned long long v = src[k];
+                if (k == W_PT) v = (unsigned long long)pt_off;
+                if (k == W_PF) v = PF_HI ? ((v & 0xffffffffull) | ((unsigned long long)(uint32_t)prim_base << 32)) : ((v & 0xffffffff00000000ull) | (unsigned long long)(uint32_t)prim_base);
+                dst[k] = v;
+            }
+        }
+        constexpr int PW = (int)(sizeof(DevPrim) / 8), TW = PACK_TILE_PRIMS * PW;     // 8-byte words per primitive / per tile's copy
+        const unsigned long long *psrc = reinterpret_cast<const unsigned long long *>(prims);
+        unsigned long long *pdst = reinterpret_cast<unsigned long long *>(&P.prims[0][0]);
+        for (int t = 0; t < FIELD_WORK_TILES; ++t) {
+            const int p0 = __shfl(my_p0_rel, t), np = __shfl(my_np, t);
+            for (int k = lane; k < TW; k += 64) pdst[t * TW + k] = (k / PW < np) ? psrc[(int64_t)p0 * PW + k] : 0ull;
+        }
     }
     // ---- what the host path computes with three more launches after its copy (k_field_junctions, k_run_consts, k_work_totals), per field:
     // the junction after a U-turn, the closed-form statistics of the field's span in its slot (zeros in the slots of its tiles), and for a

@@ -119,9 +119,32 @@ struct DevFieldWork {
     int32_t w_first;
     int32_t e_first;         // statistics entries [e_first, e_first + n_entries): the field's runs and tiles in path order
     int32_t n_entries;
-    int32_t _pad[3];
+    int32_t fused_span;      // points of the field's layer-1 span when the field's workgroup writes it too (at most FUSED_SPAN_CHUNKS chunks), else 0
+    int32_t _pad[2];
 };
 static_assert(sizeof(DevFieldWork) == 32, "DevFieldWork is fetched as one 32-byte record");
+
+// Everything ONE workgroup of k_plan_sparse_fields needs of its field, side by side: the work record, the field's (at most four) wave tiles,
+// its descriptor, and for every tile a copy of the (at most nine) primitives its points lie in.  Every address follows from the
+// workgroup's index alone, so a wavefront asks for its tile, the field's constants and its primitives AT ONCE -- through the separate
+// tables the chain was work -> wave tile -> field / primitives, each hop a trip to memory that the wavefront's 800 vector instructions
+// waited behind (profiles/r03_sparse_sections.txt: four fifths of a wave tile's cycles passed before its points were there).
+constexpr int PACK_TILE_PRIMS = 9;
+constexpr int FUSED_SPAN_CHUNKS = 4;       // a span of at most this many 512-point chunks is written by its field's own workgroup (k_plan_sparse_fields)
+constexpr int TMPL_LDS_SAMPLES = 64;      // turn-template samples a wavefront stages in LDS (fcpp_pointfn.h: TMPL_LDS)
+struct DevFieldPack {
+    DevFieldWork work;                                  //    0
+    int64_t span_points;                                //   32: points of the field's layer-1 span that this workgroup writes too (0: none, or
+                                                        //       the span's chunks are k_plan_quiet's: TileConsts.fuse_spans off)
+    int32_t _pad0[6];                                   //   40
+    DevWaveTile tile[FIELD_WORK_TILES];                 //   64: unused tiles zero
+    DevField field;                                     //  320
+    double _pad1;                                       //  632
+    DevPrim prims[FIELD_WORK_TILES][PACK_TILE_PRIMS];   //  640: tile t's primitives from wtiles[t].p0 on (slots beyond its last primitive zero)
+    double _pad2[4];                                    // 3808
+};
+static_assert(sizeof(DevField) == 312 && sizeof(DevPrim) == 88 && sizeof(DevFieldPack) == 3840 && sizeof(DevFieldPack) % 128 == 0,
+              "a pack is thirty 128-byte lines");
 
 // batch-wide turn templates: every field of a batch shares the vehicle and the sampling options, hence the number of
 // samples and the shape of its U-turns (nu) and corner turns (nc)

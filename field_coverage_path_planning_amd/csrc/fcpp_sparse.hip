@@ -17,6 +17,7 @@
 // anything by the choice above.  Same arithmetic as fcpp_fused.hip (fcpp_pointfn.h) => results do not depend on which of the two
 // kernels plans a stretch.  Stretches whose halos would not fit (dense sampling) stay with k_plan_fused.
 #include "fcpp_sparse2_fn.h"
+#include "fcpp_quiet_fn.h"
 
 namespace fcpp {
 
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
     const DevWaveTile wt = wtiles[ids ? (int64_t)ids[slot] : slot];      // (ids: the wave tiles of the fields k_plan_sparse_fields does not take)
     SparseAcc acc;
     acc.clear();
-    if (PTS == 2) sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], atab, plds[wave], xo, yo, ko, vo, fso, acc);
+    if (PTS == 2) sparse_tile2<false>(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], atab, plds[wave], xo, yo, ko, vo, fso, acc);
     else sparse_tile(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], atab, plds[wave], xo, yo, ko, vo, fso, acc);
 
     // the tile's partial statistics: the three sums of a layer (and the three maxima) go through the wave together (wave4_to_hi),
@@ -69,29 +70,62 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
 // summed at batch creation (k_work_totals), the flag counts k_plan_quiet has added to the runs' slots in this step (this launch comes
 // after the streaming kernels) from memory.  No k_reduce_stats launch for such fields, no global partial slots for their tiles, no
 // cross-workgroup synchronisation: everything the reduction needs is the workgroup's own or final.
-template <int W>
-__global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWork *__restrict__ work, const DevWaveTile *__restrict__ wtiles,
-                                                              const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
+// The span phase of k_plan_sparse_fields: wavefront v writes chunk v of the field's span -- at most W chunks (the tiler fuses only such
+// spans: FUSED_SPAN_CHUNKS), one per wavefront and no loop: as a loop over a wavefront's chunks the chunk writer's forty pinned field
+// constants stayed live around it, 95 vector registers instead of 73.
+template <int W, bool OBS>
+__device__ __forceinline__ void field_span_chunk(const DevFieldPack &pk, int wave, const DevConst &cst, const DevObstacles &obs, double *obs_lds,
+                                                 double *tlds, double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ ko,
+                                                 double *__restrict__ vo, uint32_t *__restrict__ fso, unsigned long long *cnt)
+{
+    static_assert(W == FUSED_SPAN_CHUNKS, "one chunk per wavefront");
+    const int64_t S = pk.span_points;
+    const DevField &f = pk.field;
+    const unsigned per = (unsigned)(f.n_line + f.n_turn);
+    const int r0 = (int)(f.pt_off & (TILE_POINTS - 1));
+    const int c_first = (int)(S < TILE_POINTS - r0 ? S : TILE_POINTS - r0);
+    const int n_chunks = (int)((r0 + S + TILE_POINTS - 1) / TILE_POINTS);
+    if (wave >= n_chunks) return;
+    wave_sync();
+    stage_turn_template(cst, tlds);
+    DevTile tl;
+    const unsigned start = wave == 0 ? 0u : (unsigned)(c_first + (wave - 1) * TILE_POINTS);
+    tl.field = pk.work.field; tl.start = start; tl.quiet = 4; tl.stat_tile = 0;
+    tl.count = wave == 0 ? c_first : (int)((S - start < TILE_POINTS) ? S - start : TILE_POINTS);
+    // (wave-uniform values the compiler computes on the vector unit -- there is no scalar division -- go back to scalar registers)
+    tl.idx0 = __builtin_amdgcn_readfirstlane((int)(start / per)); tl.off0 = __builtin_amdgcn_readfirstlane((int)(start - (unsigned)tl.idx0 * per));
+    tl.count = __builtin_amdgcn_readfirstlane(tl.count);
+    quiet_tile<16, true, OBS>(tl, &f, nullptr, cst, obs, obs_lds, tlds, xo, yo, ko, vo, fso, cnt, cnt + 1);
+}
+
+template <int W, bool OBS, bool SPANS>
+__device__ __forceinline__ void plan_sparse_fields_body(const DevFieldPack *__restrict__ packs,
                                                               DevConst cst, double *__restrict__ xo, double *__restrict__ yo,
                                                               double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
                                                               DevObstacles obs, TilePartial *__restrict__ partial,
                                                               const TilePartial *__restrict__ totals, fcpp_field_stats *__restrict__ stats)
 {
-    __shared__ double obs_lds[W][2 * OBS_LDS_VERTS];
+    __shared__ double obs_lds[W][OBS ? 2 * OBS_LDS_VERTS : 1];
     __shared__ TilePartial red[FIELD_WORK_TILES];
     __shared__ double atab[ATAN_TAB_DOUBLES];
-    __shared__ double plds[W][TILE_PRIMS_LDS];
+    // a wavefront's own LDS: its tile's primitives (stage_tile_prims) while it plans the tile, the turn template (stage_turn_template) while
+    // it writes chunks of the field's span
+    static_assert(3 * TMPL_LDS >= TILE_PRIMS_LDS, "one area serves both phases");
+    __shared__ double wlds[W][3 * TMPL_LDS];
+    __shared__ unsigned long long span_cnt[W][2];        // flag counts (outside the geofence, inside an obstacle) of the span chunks a wavefront wrote
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     atan_tab_stage(atab);
-    const DevFieldWork w = work[blockIdx.x];
+    // everything of the field at addresses that follow from the workgroup's index (DevFieldPack)
+    const DevFieldPack &pk = packs[blockIdx.x];
+    const DevFieldWork w = pk.work;
 #ifdef FCPP_DIAG_SPARSE
     if (g_sparse_stop == -2) return;
 #endif
     auto plan_tile = [&](const int t) {
-        const DevWaveTile wt = wtiles[w.w_first + t];
+        const DevWaveTile wt = pk.tile[t];
         SparseAcc acc;
         acc.clear();
-        sparse_tile2(wt, fields[wt.field], prims, cst, obs, obs_lds[wave], atab, plds[wave], xo, yo, ko, vo, fso, acc);
+        sparse_tile2<true>(wt, pk.field, pk.prims[t], cst, obs, obs_lds[wave], atab, wlds[wave], xo, yo, ko, vo, fso, acc);
         double g[3] = { 0.0, 0.0, 0.0 };
         const int out0 = wt.hb, out1 = wt.hb + wt.count;
         if (out0 < wt.rel_seam) g[0] = wave4_to_hi<0>(acc.s_len[0], acc.s_tpre[0], acc.s_t[0], 0.0);
@@ -107,26 +141,40 @@ __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWor
     // (one tile per wavefront, no loop: as a loop over the field's tiles -- fewer wavefronts per field -- the compiler allots this kernel
     // 93-104 vector registers instead of 71, four or five resident wavefronts per SIMD instead of seven: measured 40-44 us instead of
     // 36.5 on the headline)
-    if (wave >= w.n_tiles) return;               // (a wavefront that has ended is no longer expected at the workgroup's barrier)
-    plan_tile(wave);
-#ifdef FCPP_DIAG_SPARSE
-    if (g_sparse_stop == -4 || g_sparse_stop == -5) return;      // (-5: nothing but the tile's section -1 before it)
-#endif
-    // What the reduction needs from memory is asked for BEFORE the barrier and arrives while the other wavefronts finish their tiles:
+    // ---- the field's layer-1 span (all complete passes, closed form: fcpp_quiet_fn.h), cut into chunks on 512-point boundaries of the
+    // batch arrays as k_plan_quiet's chunks are, wavefront v the chunk v (the tiler fuses spans of at most W chunks): the vector work of
+    // the wave tiles and the stores of the span share the compute units instead of one launch after the other, and the field's statistics
+    // need nothing from another launch.  (Workgroups taking the two phases in alternating order -- so that the resident ones are
+    // spread over both -- measured no better: 61.9 vs 58.8 us.)  SPANS = false: the instance for batches without fused spans (65 instead of
+    // 73 vector registers: seven resident wavefronts per SIMD instead of six).
+    if (lane < 2) span_cnt[wave][lane] = 0;
+    auto span_phase = [&]() {
+        // (the pack's address goes through an opaque register here: the span phase's loads of the field's constants -- some forty values
+        // it pins in registers -- cannot be hoisted above the tile phase, where they would sit in registers the wave tile needs: 133 vector
+        // registers for the kernel instead of the larger of the two phases' 65 and 73)
+        const DevFieldPack *pk2 = &pk;
+        asm volatile("" : "+s"(pk2) : : "memory");
+        if (pk2->span_points > 0) field_span_chunk<W, OBS>(*pk2, wave, cst, obs, obs_lds[wave], wlds[wave], xo, yo, ko, vo, fso, &span_cnt[wave][0]);
+    };
+    if (wave < w.n_tiles) plan_tile(wave);
+    if (SPANS) span_phase();
+    // What the reduction needs from memory is asked for BEFORE the barrier and arrives while the other wavefronts finish their work:
     // lane v < 13 the v-th of the thirteen 8-byte components of the field's run totals (k_work_totals: the closed-form statistics of
     // its quiet runs, the same at every step), lane e < n_entries the two flag counts k_plan_quiet has added to entry e's slot in this
-    // step (this launch comes after the streaming kernels; the slot of an entry that is a wave tile is never written: zeros).
+    // step (runs other than the span, whose chunks are k_plan_quiet's: this launch comes after the streaming kernels; the slot of an
+    // entry that is a wave tile or the fused span is never written: zeros).
     static_assert(sizeof(TilePartial) == 13 * 8 && sizeof(fcpp_field_stats) == 13 * 8, "statistics records are thirteen 8-byte components");
     unsigned long long run_v = 0, c_out = 0, c_obs = 0;
     if (wave == 0) {
         if (lane < 13) run_v = reinterpret_cast<const unsigned long long *>(&totals[blockIdx.x])[lane];
         if (lane < w.n_entries) { const TilePartial &slot = partial[w.e_first + lane]; c_out = (unsigned long long)slot.n_outside; c_obs = (unsigned long long)slot.n_in_obstacle; }
     }
-    // (the barrier orders the tiles' results in LDS only: no wait for the loads above or for the tiles' stores)
+    // (the barrier orders the tiles' results and the span counts in LDS only: no wait for the loads above or for anybody's stores)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (wave != 0) return;
+    if ((c_out | c_obs) != 0ull) { partial[w.e_first + lane].n_outside = 0; partial[w.e_first + lane].n_in_obstacle = 0; }   // collected anew in the next step
+    if (lane < W) { c_out += span_cnt[lane][0]; c_obs += span_cnt[lane][1]; }
     if (__ballot((c_out | c_obs) != 0ull) != 0ull) {             // (rare) points of the field's runs were flagged in this step
-        if ((c_out | c_obs) != 0ull) { partial[w.e_first + lane].n_outside = 0; partial[w.e_first + lane].n_in_obstacle = 0; }   // collected anew in the next step
 #pragma unroll
         for (int o = FIELD_WORK_ENTRIES / 2; o > 0; o >>= 1) { c_out += __shfl_xor(c_out, o); c_obs += __shfl_xor(c_obs, o); }
     }
@@ -148,6 +196,25 @@ __global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldWor
         if (lane == 11) bits += c_obs;
     }
     reinterpret_cast<unsigned long long *>(&stats[w.field])[lane] = bits;
+}
+
+// OBS: the batch has obstacle polygons (without them the polygon tests of both phases are compiled out)
+template <int W, bool OBS, bool SPANS>
+__global__ __launch_bounds__(64 * W) void k_plan_sparse_fields(const DevFieldPack *__restrict__ packs, DevConst cst, double *__restrict__ xo, double *__restrict__ yo,
+                                                              double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                                              DevObstacles obs, TilePartial *__restrict__ partial,
+                                                              const TilePartial *__restrict__ totals, fcpp_field_stats *__restrict__ stats)
+{
+    plan_sparse_fields_body<W, OBS, SPANS>(packs, cst, xo, yo, ko, vo, fso, obs, partial, totals, stats);
+}
+// the same held to eight resident wavefronts per SIMD (the excess registers spilled): A/B under FCPP_TUNE=1 FCPP_FW_OCC8=1
+template <int W, bool OBS, bool SPANS>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_plan_sparse_fields_occ8(const DevFieldPack *__restrict__ packs, DevConst cst, double *__restrict__ xo, double *__restrict__ yo,
+                                                              double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
+                                                              DevObstacles obs, TilePartial *__restrict__ partial,
+                                                              const TilePartial *__restrict__ totals, fcpp_field_stats *__restrict__ stats)
+{
+    plan_sparse_fields_body<W, OBS, SPANS>(packs, cst, xo, yo, ko, vo, fso, obs, partial, totals, stats);
 }
 
 // Batch creation: per field of field_work, the closed-form statistics of its quiet runs (their slots, k_run_consts) summed in the order of
@@ -179,15 +246,19 @@ int launch_work_totals(hipStream_t st, int64_t n_work, const DevFieldWork *work,
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldWork *work, const DevWaveTile *wtiles, const DevField *fields,
-                              const DevPrim *prims, const DevConst &cst, const DevObstacles &obs, double *x, double *y, double *kappa, double *v,
-                              uint32_t *fs, TilePartial *partial, int waves, const TilePartial *totals, fcpp_field_stats *stats)
+int launch_plan_sparse_fields(hipStream_t st, int64_t n_work, const DevFieldPack *packs, const DevConst &cst, const DevObstacles &obs, double *x,
+                              double *y, double *kappa, double *v, uint32_t *fs, TilePartial *partial, int waves, const TilePartial *totals,
+                              fcpp_field_stats *stats, bool spans)
 {
     if (n_work <= 0) return 0;
-#define FCPP_FW(W) FCPP_LAUNCH((k_plan_sparse_fields<W>), dim3((unsigned)n_work), dim3(64 * W), 0, st, work, wtiles, fields, prims, cst, x, y, kappa, v, fs, obs, \
-                               partial, totals, stats)
-    if (waves == 4) FCPP_FW(4);
-    else return (int)hipErrorInvalidValue;       // (instances for 5, 6, 8 wavefronts: measured slower than the open list, fcpp_internal.h)
+#define FCPP_FW(K, W, OB, SP) FCPP_LAUNCH((K<W, OB, SP>), dim3((unsigned)n_work), dim3(64 * W), 0, st, packs, cst, x, y, kappa, v, fs, obs, partial, totals, stats)
+    if (waves != 4) return (int)hipErrorInvalidValue;       // (instances for 5, 6, 8 wavefronts: measured slower than the open list, fcpp_internal.h)
+    const bool has_obs = obs.offsets != nullptr;
+    if (tune_int("FCPP_FW_OCC8", 0) && !has_obs && !spans) FCPP_FW(k_plan_sparse_fields_occ8, 4, false, false);
+    else if (has_obs && spans) FCPP_FW(k_plan_sparse_fields, 4, true, true);
+    else if (has_obs) FCPP_FW(k_plan_sparse_fields, 4, true, false);
+    else if (spans) FCPP_FW(k_plan_sparse_fields, 4, false, true);
+    else FCPP_FW(k_plan_sparse_fields, 4, false, false);
 #undef FCPP_FW
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

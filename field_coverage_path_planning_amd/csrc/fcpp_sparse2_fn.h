@@ -81,6 +81,7 @@ __device__ __forceinline__ void sparse2_point(const DevWaveTile &wt, const DevFi
 
 // obs_lds: 2 * OBS_LDS_VERTS doubles of LDS owned by this wavefront (only touched when the field has obstacles); atab: the staged
 // table of atan2_abs_dev (atan_tab_stage); plds: TILE_PRIMS_LDS doubles of LDS owned by this wavefront (stage_tile_prims)
+template <bool PACKED = false>
 __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevField &f, const DevPrim *__restrict__ prims, const DevConst &cst,
                                              const DevObstacles &obs, double *obs_lds, const double *atab, double *plds, double *__restrict__ xo, double *__restrict__ yo,
                                              double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso, SparseAcc &acc)
@@ -95,7 +96,7 @@ __device__ __forceinline__ void sparse_tile2(const DevWaveTile &wt, const DevFie
 #endif
     SP_STAMP_S(9, wt.hb);
     SP_STAMP_S(10, f.n_line);
-    stage_tile_prims(wt, prims, plds, nl);
+    stage_tile_prims<PACKED>(wt, prims, plds, nl);
     int slot_a, slot_b;
     tile_slots2(wt, lane, slot_a, slot_b);
     sparse2_point(wt, f, plds, cst, ra, slot_a, nl, A);

@@ -42,16 +42,27 @@ __device__ __forceinline__ void tile_slots2(const DevWaveTile &wt, int lane, int
     sb = sa + (int)((m >> (p + 1)) & 1ull);
 }
 
+// PACKED: `prims` is the tile's own copy of its primitives (DevFieldPack: nine slots, the tile's first primitive in slot 0), whose address
+// does not depend on the tile record -- the two loads are issued before the record has arrived
+template <bool PACKED = false>
 __device__ __forceinline__ void stage_tile_prims(const DevWaveTile &wt, const DevPrim *__restrict__ prims, double *plds, int nl)
 {
-    if (wt.rel_main >= nl) return;                           // (wave-uniform) no point of layer 2 in this tile
-    int np = 1;
+    const int lane = threadIdx.x & 63;
+    if (PACKED) {
+        const double *src = reinterpret_cast<const double *>(prims);
+        const double v0 = src[lane], v1 = lane + 64 < TILE_PRIMS_MAX * PRIM_DOUBLES ? src[lane + 64] : 0.0;
+        plds[lane] = v0;
+        if (lane + 64 < TILE_PRIMS_MAX * PRIM_DOUBLES) plds[lane + 64] = v1;
+    } else {
+        if (wt.rel_main >= nl) return;                           // (wave-uniform) no point of layer 2 in this tile
+        int np = 1;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) np += wt.thr[k] != 255 ? 1 : 0;
-    const double *src = reinterpret_cast<const double *>(prims + wt.p0);
-    const int lane = threadIdx.x & 63, nw = np * PRIM_DOUBLES;
-    if (lane < nw) plds[lane] = src[lane];
-    if (lane + 64 < nw) plds[lane + 64] = src[lane + 64];
+        for (int k = 0; k < 8; ++k) np += wt.thr[k] != 255 ? 1 : 0;
+        const double *src = reinterpret_cast<const double *>(prims + wt.p0);
+        const int nw = np * PRIM_DOUBLES;
+        if (lane < nw) plds[lane] = src[lane];
+        if (lane + 64 < nw) plds[lane + 64] = src[lane + 64];
+    }
     // the sample index of a point in its primitive is its index in the tile minus tile_starts[slot]: -r0 for the tile's first
     // primitive, the primitive's first point (the record's threshold) for the others
     if (lane < TILE_PRIMS_MAX) {
@@ -93,7 +104,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
     int r = 0;
     DevPrim p;
     double2 tc = make_double2(0.0, 0.0);
-    stage_tile_prims(wt, prims, plds, nl);
+    stage_tile_prims<false>(wt, prims, plds, nl);
     if (in_l2) {
         int slot = 0;
         r = lane + wt.r0;

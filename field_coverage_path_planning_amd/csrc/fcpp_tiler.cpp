@@ -25,7 +25,7 @@ struct BlockTiles {
     std::vector<int32_t> open_wave;              // wave tiles (block-relative indices) of all other fields
     int64_t tile0[PLAN_BLOCK_FIELDS + 1], w0[PLAN_BLOCK_FIELDS + 1];      // a field's records: [tile0[k], tile0[k + 1]) ...
     int64_t stat_cnt[PLAN_BLOCK_FIELDS];         // statistic entries per field
-    int64_t n_runs = 0, quiet_points = 0, wave_points = 0, work_wave_points = 0, span_points = 0, chunk_points = 0, wave_inside = 0;
+    int64_t n_runs = 0, quiet_points = 0, wave_points = 0, work_wave_points = 0, work_span_points = 0, unfusable_work = 0, span_points = 0, chunk_points = 0, wave_inside = 0;
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 };
     // bases in the merged tables
     int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, chunk_base = 0, span_base = 0, cls_base[4] = { 0, 0, 0, 0 }, work_base[4] = { 0, 0, 0, 0 }, open_base = 0;
@@ -336,7 +336,8 @@ struct FieldTiler {
         const int64_t nw = out.w0[k_local + 1] - out.w0[k_local];
         bool general = false;
         for (int64_t i = t0; i < t1 && !general; ++i) general = T[(size_t)i].quiet == 0;
-        if (tc.field_work && tc.wave_points == 128 && !general && nw >= 1 && nw <= std::min(tc.field_work_tiles, FIELD_WORK_TILES) && ne <= FIELD_WORK_ENTRIES) {
+        const bool is_work = tc.field_work && tc.wave_points == 128 && !general && nw >= 1 && nw <= std::min(tc.field_work_tiles, FIELD_WORK_TILES) && ne <= FIELD_WORK_ENTRIES;
+        if (is_work) {
             DevFieldWork w;
             memset(&w, 0, sizeof w);
             w.field = (int32_t)field; w.n_tiles = (int32_t)nw; w.w_first = (int32_t)out.w0[k_local]; w.e_first = (int32_t)stat_mark; w.n_entries = (int32_t)ne;
@@ -351,6 +352,7 @@ struct FieldTiler {
         // line, ...) are cut TOGETHER: a chunk that holds the end of one run and the start of the next is written by one wave through
         // the span decode (kind 4) instead of two partial chunks (measured 4-5 % on the streaming kernel on identical memory).
         const int64_t pass = (int64_t)F.n_line + F.n_turn;
+        int64_t fused_span = 0;
         for (size_t r = 0; r < rv.size();) {
             const DevTile &a = T[(size_t)rv[r].tile];
             size_t r1 = r + 1;
@@ -361,7 +363,13 @@ struct FieldTiler {
                     if (!((tn.quiet == 1 || tn.quiet == 3) && tn.start == a.start + total)) break;
                     total += rv[r1].count;
                 }
+            // the layer-1 span of a field of field work is written by the field's own workgroup (k_plan_sparse_fields): no chunks
             const int64_t g_grp = F.pt_off + a.start;
+            if (is_work && a.quiet == 4 && a.start == 0) {
+                const bool fusable = ((g_grp % TILE_POINTS) + total + TILE_POINTS - 1) / TILE_POINTS <= FUSED_SPAN_CHUNKS;
+                if (!fusable) ++out.unfusable_work;
+                else if (tc.fuse_spans) { fused_span = total; out.work_span_points += total; r = r1; continue; }
+            }
             size_t rc = r;                       // run that holds the current position
             int64_t rc_begin = 0;                // its first point, relative to the group
             for (int64_t done = 0; done < total;) {
@@ -385,6 +393,7 @@ struct FieldTiler {
             }
             r = r1;
         }
+        if (is_work && fused_span > 0) out.work[field_work_class((int)nw)].back().fused_span = (int32_t)fused_span;
     }
 };
 
@@ -411,6 +420,7 @@ void layout_image(ImageLayout &lay)
     take(lay.stat_run, (size_t)lay.n_stat * sizeof(int64_t));
     take(lay.red_paths, (size_t)lay.n_fields * sizeof(int32_t));
     take(lay.field_work, (size_t)lay.n_field_work * sizeof(DevFieldWork));
+    take(lay.field_packs, (size_t)lay.n_field_work * sizeof(DevFieldPack));
     take(lay.open_wave_ids, (size_t)lay.n_open_wave * sizeof(int32_t));
     take(lay.obs_off, lay.n_polys > 0 ? (size_t)(lay.n_polys + 1) * sizeof(int64_t) : 0);
     take(lay.obs_x, (size_t)lay.n_poly_verts * sizeof(double));
@@ -483,7 +493,7 @@ int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys 
         for (int c = 0; c < 4; ++c) { bt.cls_base[c] = lay.n_red[c]; lay.n_red[c] += (int64_t)bt.cls[c].size(); }
         for (int c = 0; c < 4; ++c) { bt.work_base[c] = lay.n_work[c]; lay.n_work[c] += (int64_t)bt.work[c].size(); lay.n_field_work += (int64_t)bt.work[c].size(); }
         bt.open_base = lay.n_open_wave; lay.n_open_wave += (int64_t)bt.open_wave.size();
-        lay.n_runs += bt.n_runs; lay.quiet_points += bt.quiet_points; lay.wave_points += bt.wave_points; lay.work_wave_points += bt.work_wave_points;
+        lay.n_runs += bt.n_runs; lay.quiet_points += bt.quiet_points; lay.wave_points += bt.wave_points; lay.work_wave_points += bt.work_wave_points; lay.work_span_points += bt.work_span_points; lay.unfusable_work += bt.unfusable_work;
         lay.span_points += bt.span_points; lay.chunk_points += bt.chunk_points; lay.wave_inside += bt.wave_inside;
         for (int k = 0; k < 5; ++k) lay.wave_fail[k] += bt.wave_fail[k];
     }
@@ -551,6 +561,33 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         }
     });
     if (n == 0) *at<int64_t>(dst, lay.stat_first) = 0;
+    // the packs of k_plan_sparse_fields: per field of field work its records gathered from the tables above (fcpp_internal.h: DevFieldPack)
+    {
+        const DevFieldWork *fw = at<DevFieldWork>(dst, lay.field_work);
+        const DevWaveTile *wt = at<DevWaveTile>(dst, lay.wtiles);
+        const DevField *fd = at<DevField>(dst, lay.fields);
+        const DevPrim *pr = at<DevPrim>(dst, lay.prims);
+        DevFieldPack *pk = at<DevFieldPack>(dst, lay.field_packs);
+        const int64_t nw = lay.n_field_work, per = 256;
+        WorkerPool::parallel_for((nw + per - 1) / per, [&](int64_t blk) {
+            for (int64_t i = blk * per; i < std::min(nw, (blk + 1) * per); ++i) {
+                DevFieldPack &P = pk[i];
+                memset(&P, 0, sizeof P);
+                P.work = fw[i];
+                P.field = fd[fw[i].field];
+                P.span_points = fw[i].fused_span;
+                for (int t = 0; t < fw[i].n_tiles && t < FIELD_WORK_TILES; ++t) {
+                    const DevWaveTile &w = wt[fw[i].w_first + t];
+                    P.tile[t] = w;
+                    const int nl = (int)w.hb + w.count + w.hf;
+                    if (w.rel_main >= nl) continue;                 // no point of layer 2 in this tile
+                    int np = 1;
+                    for (int k = 0; k < 8; ++k) np += w.thr[k] != 255 ? 1 : 0;
+                    for (int k = 0; k < np && k < PACK_TILE_PRIMS; ++k) P.prims[t][k] = pr[w.p0 + k];
+                }
+            }
+        });
+    }
     // diagnostic (FCPP_CHUNK_SPREAD=S): the ORDER of the chunk lists permuted so that consecutive workgroups write chunks N/S apart
     // instead of neighbours -- which memory the waves in flight cover at any moment (tools/placement_probe.py)
     if (const char *e = getenv("FCPP_CHUNK_SPREAD")) {

@@ -29,13 +29,14 @@ struct TileConsts {
     int wave_points = 128;                    // points per wave tile: 64 (one per lane) or 128 (two per lane, fcpp_sparse2_fn.h)
     bool field_work = true;                   // fields with few wave tiles and nothing else general: planned and reduced by one workgroup (DevFieldWork)
     int field_work_tiles = FIELD_WORK_TILES;  // ... at most this many (<= FIELD_WORK_TILES)
+    bool fuse_spans = true;                   // ... and that workgroup also writes the field's layer-1 span (its chunks are then not in k_plan_quiet's list)
     int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
 };
 
 // the tables of the fused pipeline inside one allocation; all offsets in bytes from the image's start, 256-byte aligned
 struct ImageLayout {
     size_t fields = 0, prims = 0, tiles = 0, wtiles = 0, general_ids = 0, chunks = 0, span_chunks = 0, stat_ids = 0, stat_first = 0,
-           stat_run = 0, red_paths = 0, field_work = 0, open_wave_ids = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
+           stat_run = 0, red_paths = 0, field_work = 0, field_packs = 0, open_wave_ids = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
     size_t upload_bytes = 0;                  // [0, upload_bytes) is built on the host and copied
     size_t partial = 0, red_scratch = 0, field_junc = 0, work_totals = 0, info = 0;      // device-only scratch behind it
     bool info_on_device = false;              // the batch was set up on the device: its fcpp_field_info records live in the slab (info)
@@ -46,6 +47,8 @@ struct ImageLayout {
     int64_t n_polys = 0, n_poly_verts = 0;
     int64_t quiet_points = 0, span_points = 0, chunk_points = 0, wave_points = 0;
     int64_t work_wave_points = 0;             // the part of wave_points in fields of field_work
+    int64_t unfusable_work = 0;               // fields of field work whose span has more than FUSED_SPAN_CHUNKS chunks
+    int64_t work_span_points = 0;             // points of layer-1 spans written by k_plan_sparse_fields (not part of span_points: those are k_plan_quiet's)
     int64_t n_work[4] = { 0, 0, 0, 0 };       // fields of field_work by class (field_work_class: wavefronts of the workgroup); n_field_work = their sum
     int64_t wave_fail[5] = { 0, 0, 0, 0, 0 }; // diagnostics: stretches refused for wave tiles, by reason
     int64_t wave_inside = 0;                  // wave tiles whose outputs the host found inside the geofence

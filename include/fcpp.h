@@ -382,7 +382,7 @@ int fcpp_debug_math_dev(fcpp_ctx *ctx, int fn, int64_t n, const double *a_dev, c
  * 3 wave tiles, 4 general tile ids, 5 chunks, 6 span chunks, 7 statistics entry -> tile, 8 first entry per field, 9 run length per entry,
  * 10 reduction lists, 11 field work, 12 open wave tile ids, 13 connector segments, 14 connector masks, 15 statistics slots (after batch
  * creation: the closed-form statistics of the quiet runs), 16 junction constants, 17 run totals per field of field work, 18-21 obstacle
- * offsets / x / y / bounding boxes.  tests/test_gpu_devplan.py compares the tables of a batch set up on the device with those of the
+ * offsets / x / y / bounding boxes, 22 the packs of k_plan_sparse_fields.  tests/test_gpu_devplan.py compares the tables of a batch set up on the device with those of the
  * same batch set up on the host. */
 int fcpp_batch_debug_table(const fcpp_batch *batch, int table, void *dst, int64_t cap_bytes, int64_t *bytes_out);
 

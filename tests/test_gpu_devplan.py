@@ -14,7 +14,7 @@ from field_coverage_path_planning_amd import workloads as WL
 pytestmark = pytest.mark.gpu
 
 TABLES = ['fields', 'prims', 'tiles', 'wave_tiles', 'general_ids', 'chunks', 'span_chunks', 'stat_ids', 'stat_first', 'stat_run', 'red_paths', 'field_work',
-          'open_wave_ids', 'seg', 'seg_mask', 'partial', 'field_junc', 'work_totals', 'obs_off', 'obs_x', 'obs_y', 'obs_bbox']
+          'open_wave_ids', 'seg', 'seg_mask', 'partial', 'field_junc', 'work_totals', 'obs_off', 'obs_x', 'obs_y', 'obs_bbox', 'field_packs']
 
 
 def _both(table, veh, opt):
