@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun): rocprofv3 passes of every BASELINE configuration through tools/prof_cfg.py.
 #   one --kernel-trace --stats pass, and counter passes in runs of their own (WRITE_SIZE, FETCH_SIZE, two SQ groups),
-#   the program directly after `--`.  Output: gpurun_out/prof_r03/<config>/<pass>/ ; summarised by tools/profiles_summary.py.
+#   the program directly after `--`.  Output: gpurun_out/prof_<round>/<config>/<pass>/ ; summarised by tools/profiles_summary.py.
 #   usage: tools/collect_profiles.sh [config ...]
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/prof_r03
+OUT=$R/gpurun_out/prof_${FCPP_ROUND:-r04}
 CFGS=${*:-cfg1 cfg1_clothoid cfg2_ref cfg2_0.5 cfg2_0.1 cfg3 cfg5}
 cd /tmp && export TMPDIR=/tmp
 for c in $CFGS; do

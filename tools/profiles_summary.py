@@ -12,7 +12,8 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, 'gpurun_out', 'prof_r03')
+ROUND = os.environ.get('FCPP_ROUND', 'r04')
+SRC = os.path.join(REPO, 'gpurun_out', 'prof_' + ROUND)
 DST = os.path.join(REPO, 'profiles')
 STAGE_PREFIX = (('k_plan_quiet<16', 'k_plan_quiet_spans'), ('k_plan_quiet<14', 'k_plan_quiet'), ('k_plan_sparse_fields', 'k_plan_sparse_fields'), ('k_plan_sparse', 'k_plan_sparse'),
                 ('k_plan_fused<', 'k_plan_fused'), ('k_reduce_stats', 'k_reduce_stats'))
@@ -49,7 +50,7 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
                 per[short(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         sel = {k: (v[-steps:] if len(v) > steps else v) for k, v in per.items()}
         grand = sum(sum(v) for v in sel.values()) or 1
-        with open(os.path.join(DST, f'r03_{cfg}_kernel_stats.csv'), 'w', newline='') as fh:
+        with open(os.path.join(DST, f'{ROUND}_{cfg}_kernel_stats.csv'), 'w', newline='') as fh:
             w = csv.writer(fh)
             w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
             for k, v in sorted(sel.items(), key=lambda kv: -sum(kv[1])):
@@ -64,7 +65,7 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
                 acc[key][0] += 1
                 acc[key][1] += float(r['Counter_Value'])
     if acc:
-        with open(os.path.join(DST, f'r03_{cfg}_counters.csv'), 'w', newline='') as fh:
+        with open(os.path.join(DST, f'{ROUND}_{cfg}_counters.csv'), 'w', newline='') as fh:
             w = csv.writer(fh)
             w.writerow(['Kernel', 'Counter', 'Dispatches', 'MeanPerDispatch'])
             for (k, c), (n, s) in sorted(acc.items()):
