@@ -377,6 +377,15 @@ def main():
     # steps of the reference's sampling (0.0855 vs 0.0827 ms on cfg1 x 4096, 0.050 vs 0.047 ms on cfg2; larger steps do not care)
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
+    # the context's output arena, once, at start-up (context creation in the sense of SURVEY.md 8d: an allocation of this size takes the
+    # driver seconds): every configuration's output arrays come out of it, five lanes 24 GiB apart
+    t0 = time.perf_counter()
+    arena = None
+    try:
+        E.get_context(local).reserve_outputs(lane_gib=24.0, pitch_gib=24.0)
+        arena = {'lane_GiB': 24.0, 'pitch_GiB': 24.0, 'reserve_ms': round((time.perf_counter() - t0) * 1e3, 1)}
+    except Exception as ex:          # (a device without the room: the plain layout, reported as such per entry)
+        arena = {'error': str(ex)[:200]}
     # device warm-up, before any step of the bench: a fresh box starts at idle clocks, and the first timed region (the headline: K steps
     # of 0.09 ms) would otherwise carry their ramp (observed once: 0.29 instead of 0.09 ms per step)
     wa = torch.randn(4096, 4096, device=dev)
@@ -488,6 +497,7 @@ def main():
             'rccl_ranks': (dist.get_world_size() if use_dist else 1) if backend == 'nccl' else 0,
             'per_rank_points_per_s': per_rank_rates,
             'host_threads': host_threads,
+            'output_arena': arena,
         }
         out['config']['setup'] = r['batch'].setup_path() if hasattr(r['batch'], 'setup_path') else 'host'
     if rank == 0 and cpu_on:

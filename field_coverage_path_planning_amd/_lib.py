@@ -114,6 +114,8 @@ PROTOTYPES = [
     ('fcpp_ctx_set_setup', C.c_int, [_VP, C.c_int]),
     ('fcpp_malloc', C.c_int, [_VP, C.c_int64, C.POINTER(_VP)]),
     ('fcpp_free', C.c_int, [_VP, _VP]),
+    ('fcpp_ctx_reserve_outputs', C.c_int, [_VP, C.c_int64, C.c_int64]),
+    ('fcpp_ctx_outputs_info', C.c_int, [_VP, c_i64_p, c_i64_p, c_i64_p]),
     ('fcpp_outputs_alloc', C.c_int, [_VP, C.c_int64, C.c_int64] + [C.POINTER(_VP)] * 5),
     ('fcpp_outputs_free', C.c_int, [_VP, _VP]),
     ('fcpp_memcpy_h2d', C.c_int, [_VP, _VP, _VP, C.c_int64]),

@@ -177,7 +177,12 @@ struct fcpp_ctx {
     int setup_mode = FCPP_SETUP_AUTO;
     void *plan_scratch = nullptr; size_t plan_scratch_cap = 0;
     int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values
-    hipEvent_t ev_plan = nullptr; bool ev_plan_set = false;   // the last fill pass (it reads the scratch): the next setup waits for it, on whichever stream
+    hipEvent_t ev_plan = nullptr; bool ev_plan_set = false;
+    // the output arena (fcpp_ctx_reserve_outputs): ONE allocation of 4 x pitch + lane bytes; array k of every batch's outputs lies in lane k
+    // (lanes `pitch` apart), placed first-fit among the live allocations of the lane -- all five arrays of an allocation at the same offset
+    void *arena = nullptr; size_t arena_pitch = 0, arena_lane = 0;
+    struct ArenaBlock { size_t off, len; };
+    std::vector<ArenaBlock> arena_live;             // sorted by off   // the last fill pass (it reads the scratch): the next setup waits for it, on whichever stream
 };
 
 // device pointers of a batch's tables: all inside ONE allocation laid out by the tiler (fcpp_tiler.h: ImageLayout)
@@ -349,6 +354,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->spare) (void)hipFree(c->spare);
     if (c->plan_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->plan_scratch); }
+    if (c->arena) { (void)hipDeviceSynchronize(); (void)hipFree(c->arena); }
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
     c->templates.reset();
@@ -389,29 +395,79 @@ int fcpp_free(fcpp_ctx *c, void *p)
     return FCPP_OK;
 }
 
-// ---- output arrays with the placement rule of DESIGN.md section 4 ("where the five arrays lie"): ONE device allocation, the five arrays
-// FCPP_OUTPUT_PITCH apart.  Measured on MI355X: the streaming kernels write x, y, kappa, v and flagseg side by side, and five write
-// streams that lie within a few GiB of each other in device memory run at 4.6 TB/s, the same streams >= 12-24 GiB apart at 6.3-6.6 TB/s
-// (tools/placement_pitch.py: the class follows the pitch and nothing else).
+// ---- output arrays with the placement rule of DESIGN.md section 4 ("where the five arrays lie").  Measured on MI355X: the streaming kernels
+// write x, y, kappa, v and flagseg side by side, and five write streams that lie within a few GiB of each other in (physical) device
+// memory run at 4.6 TB/s, the same streams >= 12-24 GiB apart at 6.3-6.6 TB/s (tools/placement_pitch.py: the class follows the pitch
+// and nothing else).  The context's ARENA is the remedy that several live batches can share: one allocation made once
+// (fcpp_ctx_reserve_outputs: five lanes `pitch` apart), array k of every fcpp_outputs_alloc in lane k.
+int fcpp_ctx_reserve_outputs(fcpp_ctx *c, int64_t lane_bytes, int64_t pitch_bytes)
+{
+    if (!c || lane_bytes < 0 || pitch_bytes < 0) return fail(FCPP_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->arena) {
+        if (!c->arena_live.empty()) return fail(FCPP_EINVAL, "the output arena has live allocations");
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(c->arena));
+        c->arena = nullptr; c->arena_pitch = c->arena_lane = 0;
+    }
+    size_t pitch = pitch_bytes > 0 ? (size_t)pitch_bytes : (size_t)FCPP_OUTPUT_PITCH;
+    size_t lane = lane_bytes > 0 ? (size_t)lane_bytes : pitch;
+    pitch = (pitch + 4095) / 4096 * 4096; lane = (lane + 4095) / 4096 * 4096;
+    if (lane > pitch) pitch = lane;                      // lanes must not overlap
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t reserve = (size_t)8 << 30;
+    if (free_b < 4 * pitch + lane + reserve) return fail(FCPP_ENOMEM, "not enough free device memory for the output arena (4 x pitch + lane + 8 GiB)");
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, 4 * pitch + lane);
+    if (e != hipSuccess) return fail(FCPP_ENOMEM, std::string("output arena: ") + hipGetErrorString(e));
+    c->arena = p; c->arena_pitch = pitch; c->arena_lane = lane;
+    c->arena_live.clear();
+    return FCPP_OK;
+}
+
+int fcpp_ctx_outputs_info(const fcpp_ctx *c, int64_t *lane_bytes, int64_t *pitch_bytes, int64_t *live_bytes)
+{
+    if (!c) return fail(FCPP_EINVAL, "ctx is NULL");
+    if (lane_bytes) *lane_bytes = (int64_t)c->arena_lane;
+    if (pitch_bytes) *pitch_bytes = (int64_t)c->arena_pitch;
+    if (live_bytes) { size_t s = 0; for (const auto &blk : c->arena_live) s += blk.len; *live_bytes = (int64_t)s; }
+    return FCPP_OK;
+}
+
 int fcpp_outputs_alloc(fcpp_ctx *c, int64_t n_points, int64_t pitch_bytes, double **x, double **y, double **kappa, double **v, uint32_t **flagseg)
 {
     if (!c || n_points < 0 || !x || !y || !kappa || !v || !flagseg) return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     const size_t S = (((size_t)n_points * 8 + 4095) / 4096) * 4096;
-    size_t P = pitch_bytes > 0 ? (size_t)pitch_bytes : (size_t)FCPP_OUTPUT_PITCH;
-    if (pitch_bytes == 0) {      // default: the full pitch if the device has room for it, else as wide as fits, else back to back
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        const size_t reserve = (size_t)8 << 30;
-        if (P < S + ((size_t)1 << 30)) P = S + ((size_t)1 << 30);
-        if (free_b < 4 * P + S + reserve) P = free_b > 5 * S + reserve ? (free_b - reserve - S) / 4 : S;
+    char *b = nullptr;
+    size_t P = 0;
+    if (pitch_bytes == 0 && c->arena && S <= c->arena_lane) {
+        // first fit in the lanes (the same offset in all five): the lowest gap between live allocations that holds the array
+        const size_t need = std::max<size_t>(S, 4096);
+        size_t off = 0;
+        size_t at = 0;
+        for (; at < c->arena_live.size(); ++at) {
+            if (c->arena_live[at].off - off >= need) break;
+            off = c->arena_live[at].off + c->arena_live[at].len;
+        }
+        if (off + need <= c->arena_lane) {
+            c->arena_live.insert(c->arena_live.begin() + (long)at, fcpp_ctx::ArenaBlock{ off, need });
+            b = static_cast<char *>(c->arena) + off;
+            P = c->arena_pitch;
+        }
     }
-    if (P < S) P = S;
-    P = (P / 4096) * 4096;
-    void *slab = nullptr;
-    hipError_t e = hipMalloc(&slab, std::max<size_t>(4 * P + S, 4096));
-    if (e != hipSuccess) return fail(FCPP_ENOMEM, std::string("output arrays: ") + hipGetErrorString(e));
-    char *b = static_cast<char *>(slab);
+    if (!b) {
+        // without an arena (or beyond it): ONE allocation of its own, the arrays pitch_bytes apart -- back to back when no pitch is asked
+        // for (the slow placement class for arrays of GBs, but nothing is taken from the device that the arrays do not need)
+        P = pitch_bytes > 0 ? (size_t)pitch_bytes : S;
+        if (P < S) P = S;
+        P = (P + 4095) / 4096 * 4096;
+        void *slab = nullptr;
+        hipError_t e = hipMalloc(&slab, std::max<size_t>(4 * P + S, 4096));
+        if (e != hipSuccess) return fail(FCPP_ENOMEM, std::string("output arrays: ") + hipGetErrorString(e));
+        b = static_cast<char *>(slab);
+    }
     *x = reinterpret_cast<double *>(b); *y = reinterpret_cast<double *>(b + P); *kappa = reinterpret_cast<double *>(b + 2 * P);
     *v = reinterpret_cast<double *>(b + 3 * P); *flagseg = reinterpret_cast<uint32_t *>(b + 4 * P);
     return FCPP_OK;
@@ -421,7 +477,16 @@ int fcpp_outputs_free(fcpp_ctx *c, double *x)
 {
     if (!c) return fail(FCPP_EINVAL, "ctx is NULL");
     HIPCHK(hipSetDevice(c->device));
-    if (x) { HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipFree(x)); }
+    if (!x) return FCPP_OK;
+    char *p = reinterpret_cast<char *>(x);
+    if (c->arena && p >= static_cast<char *>(c->arena) && p < static_cast<char *>(c->arena) + c->arena_lane) {
+        const size_t off = (size_t)(p - static_cast<char *>(c->arena));
+        for (size_t k = 0; k < c->arena_live.size(); ++k)
+            if (c->arena_live[k].off == off) { c->arena_live.erase(c->arena_live.begin() + (long)k); return FCPP_OK; }
+        return fail(FCPP_EINVAL, "not an allocation of the output arena");
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipFree(x));
     return FCPP_OK;
 }
 

@@ -35,6 +35,19 @@ class Context:
         s = torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.fcpp_ctx_set_stream(self.handle, C.c_void_p(s)))
 
+    def reserve_outputs(self, lane_gib=24.0, pitch_gib=24.0):
+        """Give the context its output ARENA (fcpp_ctx_reserve_outputs): one device allocation of 4 x pitch + lane, made once -- it takes
+        the driver seconds, so it belongs to start-up, not to a plan call -- in which Batch.alloc() then places the five output arrays of
+        every batch a pitch apart (far apart they are written a class faster than back to back).  Any number of live
+        batches share it.  Raises when the device has not that much room."""
+        L.check(self.lib.fcpp_ctx_reserve_outputs(self.handle, int(lane_gib * 2**30), int(pitch_gib * 2**30)))
+
+    def outputs_info(self):
+        """-> (lane bytes, pitch bytes, live bytes per lane) of the output arena; zeros without one"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self.lib.fcpp_ctx_outputs_info(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def set_setup(self, mode):
         """Where batches are set up from now on: 'auto' (on the device where the device planner takes the batch: the reference's sampling,
         no obstacle-aware swaths), 'host', 'device' (fcpp_ctx_set_setup)."""
@@ -275,6 +288,41 @@ def plan_points(specs, vehicle, options, device=None):
     return out
 
 
+class _ArenaArrays:
+    """Five output arrays from the context's arena (fcpp_outputs_alloc), handed to torch as views of the library's memory through the CUDA
+    array interface; the allocation goes back to the arena when the last view is gone."""
+
+    class _View:
+        def __init__(self, owner, ptr, n, typestr):
+            self._owner = owner
+            self.__cuda_array_interface__ = {'shape': (n,), 'typestr': typestr, 'data': (ptr, False), 'version': 2, 'strides': None}
+
+    def __init__(self, ctx, n_points):
+        self.ctx = ctx
+        ptrs = [C.c_void_p() for _ in range(5)]
+        L.check(ctx.lib.fcpp_outputs_alloc(ctx.handle, int(n_points), 0, *[C.byref(q) for q in ptrs]))
+        self.ptrs = [q.value for q in ptrs]
+
+    def tensors(self, n_points):
+        torch = _torch()
+        dev = torch.device('cuda', self.ctx.device)
+        out = []
+        for k, p in enumerate(self.ptrs):
+            v = self._View(self, p, int(n_points), '<f8' if k < 4 else '<i4')
+            t = torch.as_tensor(v, device=dev)
+            t._fcpp_owner = v               # (the view object -- and through it this allocation -- lives as long as the tensor object)
+            out.append(t)
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, 'ptrs', None) and self.ctx.handle:
+                self.ctx.lib.fcpp_outputs_free(self.ctx.handle, C.c_void_p(self.ptrs[0]))
+                self.ptrs = None
+        except Exception:
+            pass
+
+
 class BatchResult:
     """Device-resident result of one batch: SoA tensors + per-field stats."""
 
@@ -366,7 +414,10 @@ class Batch:
           'spread': ONE allocation, the arrays L.OUTPUT_PITCH (24 GiB) + their own size apart (less if the device has less room); the gaps
                     belong to the allocation -- a caller that needs them sub-allocates its own slab with the same rule.
           'plain' : five separate tensors, wherever the allocator puts them (usually back to back: the slow class).
-          'auto'  : 'spread' when the arrays are large enough to matter (>= 512 MiB of output) and the device has the room, else 'plain'.
+          'arena' : from the context's output arena (Context.reserve_outputs(): one allocation made once, five lanes a pitch apart, shared
+                    by all live batches) -- the spread placement without an allocation per batch.
+          'auto'  : 'arena' when the context has one and the arrays are large enough to matter (>= 512 MiB of output), else 'plain'.
+                    (Never 'spread': an allocation of ~100 GiB is not something a default should make.)
         self.layout tells which one was used and the pitch.
 
         best_of > 1 (opt-in, round 2's remedy): `best_of` further candidate sets are allocated ('plain'), the batch's own step is timed on
@@ -398,13 +449,28 @@ class Batch:
             del sets
             torch.cuda.empty_cache()
             return keep
-        if layout not in ('auto', 'plain', 'spread'):
-            raise ValueError("layout: 'auto', 'plain' or 'spread'")
+        if layout not in ('auto', 'plain', 'spread', 'arena'):
+            raise ValueError("layout: 'auto', 'plain', 'spread' or 'arena'")
         n = self.total_points
-        if layout == 'plain' or (layout == 'auto' and 36 * n < self.SPREAD_MIN_BYTES):
+        lane, pitch, _live = self.ctx.outputs_info()
+        if layout == 'arena' or (layout == 'auto' and lane >= 8 * n and 36 * n >= self.SPREAD_MIN_BYTES):
+            # the context's arena (Context.reserve_outputs): array k in lane k, a pitch apart, shared with every other live batch
+            if lane < 8 * n:
+                raise RuntimeError('the context has no output arena of that size: Context.reserve_outputs()')
+            torch = _torch()
+            arr = _ArenaArrays(self.ctx, n)
+            if arr.ptrs[1] - arr.ptrs[0] != pitch:        # (the arena was full: the library fell back to an allocation of its own)
+                self.layout = {'layout': 'plain', 'note': 'the output arena is full'}
+            else:
+                self.layout = {'layout': 'arena', 'pitch_GiB': round(pitch / 2**30, 3), 'lane_GiB': round(lane / 2**30, 3)}
+            x, y, kappa, v, fs = arr.tensors(n)
+            stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=torch.device('cuda', self.ctx.device))
+            return x, y, kappa, v, fs, stats
+        if layout in ('plain', 'auto'):
+            # ('auto' never takes device memory the arrays do not need: the spread placement is the arena's, or an explicit layout='spread')
             self.layout = {'layout': 'plain'}
             return self._alloc_once()
-        return self._alloc_spread(strict=layout == 'spread')
+        return self._alloc_spread(strict=True)
 
     def _alloc_spread(self, strict=False):
         torch = _torch()

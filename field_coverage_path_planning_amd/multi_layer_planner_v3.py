@@ -169,6 +169,7 @@ class TwoLayerPathPlannerV37:
         # planner only runs the kernels again.  Results are copied out, so the caller owns fresh arrays every time (as in the reference).
         if self._batch is None:
             self._batch = E.Batch(self._table, self._veh, self._opt, device=self._device)
+        if self._bufs is None:
             self._bufs = self._batch.alloc()
         batch = self._batch
         res = batch.run(self._bufs)
@@ -220,6 +221,11 @@ class TwoLayerPathPlannerV37:
         if self.verbose:
             print(f"路径规划完成! 总耗时: {result['total_time']:.3f}秒  "
                   f"(main {n_main} pts, headland {n_head} pts)")
+        # the results are host arrays now: a planner keeps device output arrays only while they are small (a second plan of the same
+        # planner then only runs the kernels); the arrays of a densely sampled field -- 36 bytes per point -- go back at once
+        if 36 * batch.total_points > (64 << 20):
+            del res
+            self._bufs = None
         return result
 
     plan = plan_complete_coverage   # README_en.md:274-302

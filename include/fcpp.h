@@ -171,12 +171,20 @@ int fcpp_ctx_set_setup(fcpp_ctx *ctx, int mode);
 /* device memory for hosts without their own allocator (torch users pass tensor pointers instead) */
 int fcpp_malloc(fcpp_ctx *ctx, int64_t bytes, void **dev_ptr);
 int fcpp_free(fcpp_ctx *ctx, void *dev_ptr);
-/* Output arrays for fcpp_batch_run with the placement rule measured on MI355X: the hot kernels write x, y, kappa,
- * v and flagseg side by side, and five write streams within a few GiB of each other in device memory reach 4.6 TB/s where the same
- * streams >= 12-24 GiB apart reach 6.3-6.6 TB/s.  One device allocation, the five arrays pitch_bytes apart (0: FCPP_OUTPUT_PITCH, or
- * as wide as the free device memory allows; small batches -- a few hundred MB of output -- live in the caches and do not care).
- * Free all five with fcpp_outputs_free(ctx, x). */
+/* Output arrays for fcpp_batch_run, and the placement rule measured on MI355X: the hot kernels write x, y, kappa, v
+ * and flagseg side by side, and five write streams within a few GiB of each other in device memory reach 4.6 TB/s where the same streams
+ * >= 12-24 GiB apart reach 6.3-6.6 TB/s (small batches -- a few hundred MB of output -- live in the caches and do not care).
+ *
+ * fcpp_ctx_reserve_outputs gives the context an ARENA for that: ONE device allocation of 4 x pitch + lane bytes, made once (an allocation
+ * of this size takes the driver seconds: it belongs to context creation, not to a plan call), five lanes `pitch_bytes` apart (0:
+ * FCPP_OUTPUT_PITCH) of `lane_bytes` each (0: one pitch).  fcpp_outputs_alloc(pitch_bytes = 0) then places array k in lane k, first fit
+ * among the live allocations -- any number of live batches share the arena, each with its arrays a pitch apart.  Nothing is reserved
+ * unless the caller asks: without an arena (or for arrays larger than a lane) pitch_bytes = 0 gives one allocation with the arrays back to
+ * back, pitch_bytes > 0 one allocation of 4 x pitch + array bytes of the caller's own.  Free all five with fcpp_outputs_free(ctx, x).
+ * fcpp_ctx_reserve_outputs again re-sizes the arena (no live allocations allowed); fcpp_ctx_destroy releases it. */
 #define FCPP_OUTPUT_PITCH ((int64_t)24 << 30)
+int fcpp_ctx_reserve_outputs(fcpp_ctx *ctx, int64_t lane_bytes, int64_t pitch_bytes);
+int fcpp_ctx_outputs_info(const fcpp_ctx *ctx, int64_t *lane_bytes, int64_t *pitch_bytes, int64_t *live_bytes);   /* 0, 0, 0 without an arena */
 int fcpp_outputs_alloc(fcpp_ctx *ctx, int64_t n_points, int64_t pitch_bytes, double **x_dev, double **y_dev, double **kappa_dev,
                        double **v_dev, uint32_t **flagseg_dev);
 int fcpp_outputs_free(fcpp_ctx *ctx, double *x_dev);

@@ -679,3 +679,64 @@ def test_output_layouts_give_the_same_plan():
     del got
     L.check(b.lib.fcpp_outputs_free(b.ctx.handle, ptrs[0]))
     b.close()
+
+
+def test_output_arena_shared_by_live_batches():
+    """Context.reserve_outputs(): ONE allocation, five lanes a pitch apart; every live batch's arrays come out of it (array k in lane k,
+    first fit), give the plan of any other layout bit for bit, and go back when the last tensor is gone.  Nothing is reserved unless
+    asked for: before the reservation 'auto' is 'plain' whatever the size."""
+    import gc
+    import torch
+    ctx = E.get_context()
+    assert ctx.outputs_info() == (0, 0, 0)
+    veh = _veh(DEFAULT_VP)
+    batches = [E.Batch(E.FieldTable.from_rectangles(np.random.default_rng(k).uniform(100, 600, (20, 2))), veh, E.make_options(1, 0.05 * (k + 1))) for k in range(3)]
+    refs = []
+    for b in batches:
+        bufs = b.alloc()
+        assert b.layout['layout'] == 'plain'
+        r = b.run(bufs)
+        refs.append([t.clone() for t in (r.x, r.y, r.kappa, r.v, r.flagseg, r.stats_raw)])
+    del bufs, r
+    ctx.reserve_outputs(lane_gib=1.0, pitch_gib=3.0)
+    try:
+        lane, pitch, live = ctx.outputs_info()
+        assert (lane, pitch, live) == (1 << 30, 3 << 30, 0)
+        held = []
+        for b in batches:
+            bufs = b.alloc(layout='arena')
+            assert b.layout == {'layout': 'arena', 'pitch_GiB': 3.0, 'lane_GiB': 1.0}
+            assert all(bufs[k + 1].data_ptr() - bufs[k].data_ptr() == pitch for k in range(4))
+            held.append(bufs)
+        # three live batches side by side in the lanes, no overlap
+        spans = sorted((h[0].data_ptr(), h[0].data_ptr() + 8 * b.total_points) for h, b in zip(held, batches))
+        assert all(spans[k][1] <= spans[k + 1][0] for k in range(2))
+        assert ctx.outputs_info()[2] >= sum(8 * b.total_points for b in batches)
+        for b, bufs, ref in zip(batches, held, refs):
+            r = b.run(bufs)
+            torch.cuda.synchronize()
+            for a, c in zip(ref, (r.x, r.y, r.kappa, r.v, r.flagseg, r.stats_raw)):
+                assert torch.equal(a, c)
+        # the middle batch's arrays go back; the next allocation of that size or less takes their place (first fit)
+        gone = held[1][0].data_ptr()
+        del r, bufs
+        held[1] = None
+        gc.collect()
+        again = batches[1].alloc(layout='arena')
+        assert again[0].data_ptr() == gone
+        del again, held
+        gc.collect()
+        assert ctx.outputs_info()[2] == 0
+        # an array larger than a lane: a plain allocation of its own, the arena untouched
+        big = E.Batch(E.FieldTable.from_rectangles([[5000.0, 2000.0]]), veh, E.make_options(1, 0.02))
+        assert 8 * big.total_points > lane
+        with pytest.raises(RuntimeError):
+            big.alloc(layout='arena')
+        bufs = big.alloc()
+        assert big.layout['layout'] == 'plain'
+        big.close()
+    finally:
+        gc.collect()
+        L.check(ctx.lib.fcpp_ctx_reserve_outputs(ctx.handle, 4096, 4096))       # (back to next to nothing for the tests that follow)
+    for b in batches:
+        b.close()
