@@ -140,6 +140,8 @@ PROTOTYPES = [
     ('fcpp_speed_plan', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int, C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP,
                                   _VP, _VP, _VP]),
     ('fcpp_verify', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, _VP, _VP]),
+    ('fcpp_validate', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, _VP, C.c_int64, _VP, _VP, _VP, C.POINTER(Polys),
+                               C.POINTER(Polys), _VP, _VP, _VP, _VP]),
     ('fcpp_straight_segments', C.c_int, [_VP, C.c_int64, _VP, C.c_int32, _VP]),
     ('fcpp_corner_turns', C.c_int, [_VP, C.POINTER(Vehicle), C.c_int64, _VP, _VP, _VP, C.c_double, C.c_double, C.c_int32, _VP, _VP]),
     ('fcpp_fresnel', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP]),

@@ -1314,6 +1314,64 @@ int fcpp_verify(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n_paths, const int
     return FCPP_OK;
 }
 
+int fcpp_validate(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_paths, const int64_t *offsets, int64_t total,
+                  const double *x, const double *y, const double *v, const fcpp_polys *field_polys, const fcpp_polys *obstacles,
+                  const int64_t *obstacle_offsets, uint32_t *flags, fcpp_field_stats *stats, const int64_t *offsets_host)
+{
+    if (!c || !veh || !opt || (!offsets && !offsets_host) || !stats || (total > 0 && (!x || !y || !v || !flags))) return fail(FCPP_EINVAL, "bad arguments");
+    if (!isfinite(opt->geofence_tol)) return fail(FCPP_EINVAL, "geofence_tol must be finite");
+    std::string err;
+    int rc = validate_polys(field_polys, err);
+    if (rc == FCPP_OK) rc = validate_polys(obstacles, err);
+    if (rc != FCPP_OK) return fail(rc, err);
+    if (field_polys && field_polys->n_polys != n_paths) return fail(FCPP_ESIZE, "field_polys must hold one polygon per path");
+    const int64_t n_obst = obstacles ? obstacles->n_polys : 0;
+    if (obstacle_offsets) {
+        if (obstacle_offsets[0] < 0 || obstacle_offsets[n_paths] > n_obst) return fail(FCPP_ESIZE, "obstacle_offsets outside the obstacle table");
+        for (int64_t p = 0; p < n_paths; ++p)
+            if (obstacle_offsets[p + 1] < obstacle_offsets[p]) return fail(FCPP_ESIZE, "obstacle_offsets must be non-decreasing");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    DevTiling *dtp = nullptr;
+    rc = make_tiling(c, n_paths, offsets, offsets_host, total, &dtp);
+    if (rc) return rc;
+    DevTiling &dt = *dtp;
+    DevConst cst = const_from_vehicle(*veh);
+    hipStream_t st = c->stream;
+    // curvature, a_lat flags and the metrics of fcpp_verify; then the polygon tests
+    DevBuf<double> kap, vtmp;
+    HIPCHK(kap.alloc((size_t)total));
+    HIPCHK(vtmp.alloc((size_t)total));
+    LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, 0, x, y, v, vtmp.p, kap.p, nullptr));
+    DevObstacles none = { nullptr, nullptr, nullptr, nullptr };
+    LAUNCHCHK(launch_validate(st, dt.n_tiles, dt.tiles.p, dt.paths.p, nullptr, cst, none, x, y, kap.p, v, nullptr, dt.partial.p));
+    LAUNCHCHK(launch_reduce_stats(st, dt.n_paths, dt.partial.p, dt.tile_first.p, nullptr, stats));
+    // the polygon tables: one upload (field vertices, obstacle vertices, their offsets, the per-path obstacle ranges)
+    const int64_t nfv = field_polys && n_paths > 0 ? field_polys->offsets[n_paths] : 0, nov = n_obst > 0 ? obstacles->offsets[n_obst] : 0;
+    std::vector<double> hv;
+    std::vector<int64_t> hi;
+    try {
+        hv.reserve((size_t)(2 * (nfv + nov)));
+        if (nfv) { hv.insert(hv.end(), field_polys->x, field_polys->x + nfv); hv.insert(hv.end(), field_polys->y, field_polys->y + nfv); }
+        if (nov) { hv.insert(hv.end(), obstacles->x, obstacles->x + nov); hv.insert(hv.end(), obstacles->y, obstacles->y + nov); }
+        if (field_polys) hi.insert(hi.end(), field_polys->offsets, field_polys->offsets + n_paths + 1);
+        if (n_obst) hi.insert(hi.end(), obstacles->offsets, obstacles->offsets + n_obst + 1);
+        if (obstacle_offsets && n_obst) hi.insert(hi.end(), obstacle_offsets, obstacle_offsets + n_paths + 1);
+    } catch (const std::bad_alloc &) { return fail(FCPP_ENOMEM, "out of host memory"); }
+    DevBuf<double> dv;
+    DevBuf<int64_t> di;
+    HIPCHK(dv.upload(hv, st));
+    HIPCHK(di.upload(hi, st));
+    const double *fx = dv.p, *fy = dv.p ? dv.p + nfv : nullptr, *ox = dv.p ? dv.p + 2 * nfv : nullptr, *oy = dv.p ? dv.p + 2 * nfv + nov : nullptr;
+    const int64_t *foff = field_polys ? di.p : nullptr;
+    const int64_t *ooff = n_obst ? di.p + (field_polys ? n_paths + 1 : 0) : nullptr;
+    const int64_t *orng = (obstacle_offsets && n_obst) ? ooff + n_obst + 1 : nullptr;
+    LAUNCHCHK(launch_validate_polys(st, dt.n_tiles, dt.tiles.p, dt.paths.p, foff, fx, fy, field_polys ? n_paths : 0, ooff, ox, oy, n_obst, orng,
+                                    opt->geofence_tol, cst.a_lat, x, y, kap.p, v, flags, stats));
+    HIPCHK(hipStreamSynchronize(st));      // (the staging vectors die here)
+    return FCPP_OK;
+}
+
 int fcpp_straight_segments(fcpp_ctx *c, int64_t n_seg, const double *seg, int32_t n_points, double *out)
 {
     if (!c || n_seg < 0 || n_points < 1 || (n_seg > 0 && (!seg || !out))) return fail(FCPP_EINVAL, "bad arguments");

@@ -76,6 +76,11 @@ int launch_scan_apply(hipStream_t st, int64_t n_tiles, const DevTile *tiles, con
 int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths,
                     const DevField *fields, const DevConst &cst, const DevObstacles &obs, const double *x,
                     const double *y, const double *kappa, const double *v, uint32_t *fs, TilePartial *partial);
+// fcpp_validate: geofence / obstacle flags of caller-supplied paths against arbitrary simple polygons (device CSR tables; see k_validate_polys)
+int launch_validate_polys(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const int64_t *field_off, const double *field_x,
+                          const double *field_y, int64_t n_field, const int64_t *obst_off, const double *obst_x, const double *obst_y, int64_t n_obst,
+                          const int64_t *obst_range, double tol, double a_lat, const double *x, const double *y, const double *kappa, const double *v,
+                          uint32_t *flags, fcpp_field_stats *stats);
 // ids / run_count / path_list / group (lanes per path: 8, 64 or 256): see k_reduce_stats; tiles, fields, prims, cst only with run_count
 int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids = nullptr,

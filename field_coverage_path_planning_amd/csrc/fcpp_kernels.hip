@@ -780,6 +780,105 @@ int launch_validate(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const
     return 0;
 }
 
+// ---- fcpp_validate: geofence / obstacle flags of CALLER-SUPPLIED paths against arbitrary simple polygons -----------------------------------
+// One workgroup per tile of one path.  The path's field polygon (polygon p of `field`) and its obstacle polygons are staged in LDS by
+// coalesced loads (up to VAL_LDS_VERTS vertices together; beyond that they are read from global memory), every thread then tests its
+// points: even-odd crossing number against the field polygon, the signed distance to its boundary against the tolerance
+//     s = +dist inside, -dist outside;   FCPP_FLAG_OUTSIDE  <=>  s < -tol
+// (for a convex field and tol >= 0 the half-plane rule of the planner, except in the wedges beyond its corners, where the distance to the
+// corner decides), and the crossing number against every obstacle polygon (FCPP_FLAG_OBSTACLE).  Counts go to stats[p] by integer atomics.
+struct DevPolySet { const int64_t *off; const double *x, *y; int64_t n; };
+__device__ __forceinline__ bool pip_even_odd(double px, double py, const double *vx, const double *vy, int64_t a0, int64_t a1)
+{
+    bool in = false;
+    for (int64_t k = a0, q = a1 - 1; k < a1; q = k++) {
+        const double xi = vx[k], yi = vy[k], xj = vx[q], yj = vy[q];
+        if (((yi > py) != (yj > py)) && (px < (xj - xi) * (py - yi) / (yj - yi) + xi)) in = !in;
+    }
+    return in;
+}
+// squared distance of (px, py) to the polygon's boundary (its segments, the closing one included)
+__device__ __forceinline__ double poly_dist2(double px, double py, const double *vx, const double *vy, int64_t a0, int64_t a1)
+{
+    double best = __builtin_huge_val();
+    for (int64_t k = a0, q = a1 - 1; k < a1; q = k++) {
+        const double ax = vx[q], ay = vy[q], bx = vx[k] - ax, by = vy[k] - ay, wx = px - ax, wy = py - ay;
+        const double len2 = bx * bx + by * by, dot = wx * bx + wy * by;
+        double t = len2 > 0.0 ? dot / len2 : 0.0;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double dx = wx - t * bx, dy = wy - t * by, d2 = dx * dx + dy * dy;
+        if (d2 < best) best = d2;
+    }
+    return best;
+}
+__global__ __launch_bounds__(BLOCK) void k_validate_polys(const DevTile *__restrict__ tiles, const DevPath *__restrict__ paths, DevPolySet field,
+                                                          DevPolySet obst, const int64_t *__restrict__ obst_range, double tol, double a_lat,
+                                                          const double *__restrict__ x, const double *__restrict__ y,
+                                                          const double *__restrict__ kappa, const double *__restrict__ v,
+                                                          uint32_t *__restrict__ flags, fcpp_field_stats *__restrict__ stats)
+{
+    __shared__ double lx[VAL_LDS_VERTS], ly[VAL_LDS_VERTS];
+    const DevTile t = tiles[blockIdx.x];
+    const DevPath p = paths[t.field];
+    // the path's polygons: vertices [f0, f1) of the field set, obstacle polygons [o0, o1)
+    int64_t f0 = 0, f1 = 0, o0 = 0, o1 = 0, ov0 = 0, ov1 = 0;
+    if (field.off && t.field < field.n) { f0 = field.off[t.field]; f1 = field.off[t.field + 1]; }
+    if (obst.off && obst.n > 0) {
+        o0 = obst_range ? obst_range[t.field] : 0; o1 = obst_range ? obst_range[t.field + 1] : obst.n;
+        ov0 = obst.off[o0]; ov1 = obst.off[o1];
+    }
+    const int64_t nf = f1 - f0, no = ov1 - ov0;
+    const bool staged = nf + no <= VAL_LDS_VERTS;
+    if (staged) {
+        for (int k = threadIdx.x; k < (int)nf; k += BLOCK) { lx[k] = field.x[f0 + k]; ly[k] = field.y[f0 + k]; }
+        for (int k = threadIdx.x; k < (int)no; k += BLOCK) { lx[nf + k] = obst.x[ov0 + k]; ly[nf + k] = obst.y[ov0 + k]; }
+        __syncthreads();
+    }
+    const double *fx = staged ? lx : field.x + f0, *fy = staged ? ly : field.y + f0;            // field vertex k at fx[k]
+    const double *ox = staged ? lx + nf : obst.x + ov0, *oy = staged ? ly + nf : obst.y + ov0;   // obstacle vertex (global index k) at ox[k - ov0]
+    const double tol2 = tol * tol;
+    long long nout = 0, nobs = 0;
+    for (int j = threadIdx.x; j < t.count; j += BLOCK) {
+        const int64_t i = t.start + j, g = p.off + i;
+        const double px = x[g], py = y[g];
+        uint32_t fs = 0;
+        if (i > 0 && i < p.n - 1) {          // MLP:1383-1401, as k_validate counts n_viol
+            const double ms = v[g] / 3.6;
+            if (ms * ms * kappa[g] > a_lat) fs |= FCPP_FLAG_ALAT;
+        }
+        if (nf >= 3) {
+            const bool in = pip_even_odd(px, py, fx, fy, 0, nf);
+            bool out;
+            if (in) out = tol < 0.0 && poly_dist2(px, py, fx, fy, 0, nf) < tol2;
+            else out = tol < 0.0 || poly_dist2(px, py, fx, fy, 0, nf) > tol2;
+            if (out) { fs |= FCPP_FLAG_OUTSIDE; ++nout; }
+        }
+        for (int64_t b = o0; b < o1; ++b) {
+            const int64_t a0 = obst.off[b], a1 = obst.off[b + 1];
+            if (a1 - a0 >= 3 && pip_even_odd(px, py, ox, oy, a0 - ov0, a1 - ov0)) { fs |= FCPP_FLAG_OBSTACLE; ++nobs; break; }
+        }
+        flags[g] = fs;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { nout += __shfl_xor(nout, o); nobs += __shfl_xor(nobs, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nout) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[t.field].n_outside), (unsigned long long)nout);
+        if (nobs) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[t.field].n_in_obstacle), (unsigned long long)nobs);
+    }
+}
+
+int launch_validate_polys(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const int64_t *field_off, const double *field_x,
+                          const double *field_y, int64_t n_field, const int64_t *obst_off, const double *obst_x, const double *obst_y, int64_t n_obst,
+                          const int64_t *obst_range, double tol, double a_lat, const double *x, const double *y, const double *kappa, const double *v,
+                          uint32_t *flags, fcpp_field_stats *stats)
+{
+    if (n_tiles <= 0) return 0;
+    const DevPolySet f = { field_off, field_x, field_y, n_field }, o = { obst_off, obst_x, obst_y, n_obst };
+    hipLaunchKernelGGL(k_validate_polys, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, f, o, obst_range, tol, a_lat, x, y, kappa, v, flags, stats);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // Batch creation (fused pipeline): the statistics slots of a batch, one per entry.  The slot of a quiet run gets the run's closed-form
 // length / time / curvature statistics -- geometry and nominal speeds only, the same at every step --, every other slot zeros (wave
 // tiles and general tiles overwrite theirs at every step).

@@ -679,6 +679,46 @@ def verify(x, y, v, vehicle, offsets=None, device=None):
     return out
 
 
+def _polys(polygons):
+    """list of vertex lists -> (L.Polys, keep-alive arrays)"""
+    offs, px, py = [0], [], []
+    for poly in polygons:
+        for (a, b) in poly:
+            px.append(float(a))
+            py.append(float(b))
+        offs.append(len(px))
+    o, ax, ay = np.asarray(offs, dtype=np.int64), np.asarray(px, dtype=np.float64), np.asarray(py, dtype=np.float64)
+    return L.Polys(len(offs) - 1, o.ctypes.data_as(L.c_i64_p), ax.ctypes.data_as(L.c_double_p), ay.ctypes.data_as(L.c_double_p)), [o, ax, ay]
+
+
+def validate(x, y, v, vehicle, field_polygons=None, obstacles=None, obstacle_offsets=None, geofence_tol=1e-6, offsets=None, device=None):
+    """fcpp_validate: lateral-acceleration / geofence / obstacle flags and per-path statistics of caller-supplied paths.
+    field_polygons: one vertex list per path (or None); obstacles: vertex lists; obstacle_offsets: n_paths + 1 indices into them (None: every
+    path against all).  -> (flags uint32 tensor, dict of numpy arrays per path)"""
+    ctx = get_context(device)
+    torch = _torch()
+    dev = torch.device('cuda', ctx.device)
+    x, y, v = _dev_f64(x, dev), _dev_f64(y, dev), _dev_f64(v, dev)
+    off, off_h = _offsets(offsets, x.numel(), dev)
+    n_paths = off.numel() - 1
+    opt = make_options(geofence_tol=geofence_tol)
+    fp, keep1 = _polys(field_polygons) if field_polygons is not None else (None, None)
+    ob, keep2 = _polys(obstacles) if obstacles else (None, None)
+    oo = np.ascontiguousarray(obstacle_offsets, dtype=np.int64) if obstacle_offsets is not None else None
+    flags = torch.empty(x.numel(), dtype=torch.int32, device=dev)
+    stats = torch.zeros((n_paths, L.STATS_WORDS), dtype=torch.int64, device=dev)
+    ctx.bind_stream()
+    L.check(ctx.lib.fcpp_validate(ctx.handle, C.byref(vehicle), C.byref(opt), n_paths, _ptr(off), x.numel(), _ptr(x), _ptr(y), _ptr(v),
+                                  C.byref(fp) if fp is not None else None, C.byref(ob) if ob is not None else None, _host_ptr(oo), _ptr(flags),
+                                  _ptr(stats), _host_ptr(off_h)))
+    raw = stats.cpu().numpy()
+    out = {}
+    for k, (n, _) in enumerate(L.FieldStats._fields_):
+        col = raw[:, k]
+        out[n] = col.view(np.float64).copy() if k < L.STATS_DOUBLES else col.copy()
+    return flags, out
+
+
 def straight_segments(segs, n_points, device=None):
     ctx = get_context(device)
     torch = _torch()

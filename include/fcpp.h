@@ -275,6 +275,22 @@ int fcpp_speed_plan(fcpp_ctx *ctx, const fcpp_vehicle *veh, int clamp, int64_t n
 int fcpp_verify(fcpp_ctx *ctx, const fcpp_vehicle *veh, int64_t n_paths, const int64_t *offsets_dev,
                 int64_t total_points, const double *x_dev, const double *y_dev, const double *v_dev,
                 fcpp_field_stats *stats_dev, const int64_t *offsets_host);
+/* The validator on CALLER-SUPPLIED paths (README_en.md:183 "Electronic Fence Boundary Checking" -- the reference has the
+ * bounds test of its start / end points only, MLP:322-343): per point the lateral-acceleration flag of verify_curvature_constraints
+ * (MLP:1383-1401), the geofence flag against the path's field polygon and the obstacle flag against its obstacle polygons; per path the
+ * statistics of fcpp_verify plus n_outside / n_in_obstacle.  Polygons are arbitrary simple polygons (host CSR tables, copied by the call):
+ *   field_polys (NULL: no geofence): polygon p is the field of path p (n_polys == n_paths; a polygon of < 3 vertices: no geofence for that path).
+ *       A point is FCPP_FLAG_OUTSIDE iff its signed distance to the polygon's boundary (+ inside, - outside; even-odd rule) is below
+ *       -opt->geofence_tol -- for a convex field and a tolerance >= 0 the planner's own rule except beyond the corners, where the distance
+ *       to the corner decides instead of the distances to the two edge lines.
+ *   obstacles (NULL: none) with obstacle_offsets (n_paths + 1 values: path p is tested against the polygons [obstacle_offsets[p],
+ *       obstacle_offsets[p + 1]); NULL: every path against all of them).  A point inside one (even-odd) is FCPP_FLAG_OBSTACLE.
+ * flags_dev: total_points words, overwritten (FCPP_FLAG_ALAT | _OUTSIDE | _OBSTACLE).  Only veh's limits and opt->geofence_tol are read.
+ * offsets_host as for the other standalone operators.  Synchronises. */
+int fcpp_validate(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_paths, const int64_t *offsets_dev,
+                  int64_t total_points, const double *x_dev, const double *y_dev, const double *v_dev, const fcpp_polys *field_polys,
+                  const fcpp_polys *obstacles, const int64_t *obstacle_offsets, uint32_t *flags_dev, fcpp_field_stats *stats_dev,
+                  const int64_t *offsets_host);
 /* numpy.linspace straight segments (MLP:1013-1022, 1313-1355): seg_dev = n_seg x (x0,y0,x1,y1),
  * out_xy_dev = n_seg x n_points x 2 */
 int fcpp_straight_segments(fcpp_ctx *ctx, int64_t n_seg, const double *seg_dev, int32_t n_points,

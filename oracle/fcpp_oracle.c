@@ -423,6 +423,31 @@ int orc_point_in_polygon(double px, double py, const double *xy, int64_t nv)
     return in;
 }
 
+/* Build-defined (no reference code; include/fcpp.h: fcpp_validate): the geofence rule for an arbitrary simple polygon.
+ * signed distance s to the boundary: + inside (even-odd), - outside; returns 1 iff s < -tol */
+static double orc_poly_dist2(double px, double py, const double *xy, int64_t nv)
+{
+    double best = HUGE_VAL;
+    for (int64_t k = 0, q = nv - 1; k < nv; q = k++) {
+        double ax = xy[2 * q], ay = xy[2 * q + 1], bx = xy[2 * k] - ax, by = xy[2 * k + 1] - ay, wx = px - ax, wy = py - ay;
+        double len2 = bx * bx + by * by, dot = wx * bx + wy * by;
+        double t = len2 > 0.0 ? dot / len2 : 0.0;
+        if (t < 0.0) t = 0.0;
+        if (t > 1.0) t = 1.0;
+        double dx = wx - t * bx, dy = wy - t * by, d2 = dx * dx + dy * dy;
+        if (d2 < best) best = d2;
+    }
+    return best;
+}
+int orc_outside_polygon(double px, double py, const double *xy, int64_t nv, double tol)
+{
+    if (nv < 3) return 0;
+    int in = orc_point_in_polygon(px, py, xy, nv);
+    double d2 = orc_poly_dist2(px, py, xy, nv), t2 = tol * tol;
+    if (in) return tol < 0.0 && d2 < t2;
+    return tol < 0.0 || d2 > t2;
+}
+
 /* convex polygon, either orientation: outside if beyond any edge by more than tol */
 int orc_outside_convex(double px, double py, const double *vx, const double *vy, int nv, double tol)
 {

@@ -132,6 +132,8 @@ def lib():
         L.orc_cac_point.argtypes = [C.c_double] * 7 + [c_double_p]
         L.orc_cac_fit_radius.restype = C.c_double
         L.orc_cac_fit_radius.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int]
+        L.orc_outside_polygon.restype = C.c_int
+        L.orc_outside_polygon.argtypes = [C.c_double, C.c_double, c_double_p, C.c_int64, C.c_double]
         L.orc_point_in_polygon.restype = C.c_int
         L.orc_point_in_polygon.argtypes = [C.c_double, C.c_double, c_double_p, C.c_int64]
         c_u32_p = C.POINTER(C.c_uint32)
@@ -286,6 +288,12 @@ def cac_points(x0, y0, th0, dth, R, f, fit, n):
         L.orc_cac_point(x0, y0, th0, dth, Re, f, s[i], _dp(tmp))
         out[i] = tmp
     return out, Re, T
+
+
+def outside_polygon(px, py, poly, tol):
+    """fcpp_validate's geofence rule for an arbitrary simple polygon (build-defined): signed distance to the boundary < -tol"""
+    poly = _f64(poly)
+    return bool(lib().orc_outside_polygon(px, py, _dp(poly), len(poly), float(tol)))
 
 
 def point_in_polygon(px, py, poly):
