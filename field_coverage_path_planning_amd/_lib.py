@@ -150,6 +150,7 @@ PROTOTYPES = [
     ('fcpp_best_connections', C.c_int, [_VP, C.c_int64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ('fcpp_ga_evolve', C.c_int, [_VP, C.c_int32, C.POINTER(GaConfig), _VP, _VP, _VP, _VP, C.POINTER(GaResult)]),
     ('fcpp_cover_grid', C.c_int, [_VP, C.c_int64, C.POINTER(CoverJob), C.c_int64, _VP, _VP, _VP, _VP]),
+    ('fcpp_gather', C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, c_i64_p, _VP, C.c_int]),
     ('fcpp_debug_math', C.c_int, [C.c_int, C.c_int64, _VP, _VP, _VP, _VP]),
     ('fcpp_debug_math_dev', C.c_int, [_VP, C.c_int, C.c_int64, _VP, _VP, _VP, _VP]),
     ('fcpp_batch_debug_table', C.c_int, [_VP, C.c_int, _VP, C.c_int64, c_i64_p]),

@@ -1,5 +1,6 @@
 // fcpp_api.cpp -- the C ABI declared in include/fcpp.h: argument checking, device buffers, launches.
 // No CPU compute path exists here: every operator ends in a HIP kernel launch or fails with FCPP_EHIP.
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
@@ -1553,6 +1554,82 @@ int fcpp_ga_fitness(fcpp_ctx *c, int32_t n_nodes, int64_t pop, const double *D, 
         return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     LAUNCHCHK(launch_ga_fitness(c->stream, n_nodes, pop, D, routes, dist, fit, order_mode));
+    return FCPP_OK;
+}
+
+// ---- the final gather of a sharded job over RCCL -------------------------------------------------------------------------
+// RCCL is not linked: its four entry points are looked up in the process (a caller that holds an ncclComm_t has the library loaded;
+// PyTorch's ROCm wheels bundle their own copy), then by name.
+extern "C++" {
+namespace {
+struct Rccl {
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    int (*send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    bool ok() const { return group_start && group_end && send && recv; }
+};
+const Rccl &rccl()
+{
+    static const Rccl r = [] {
+        Rccl q;
+        auto look = [&](void *h) {
+            q.group_start = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupStart"));
+            q.group_end = reinterpret_cast<int (*)()>(dlsym(h, "ncclGroupEnd"));
+            q.send = reinterpret_cast<int (*)(const void *, size_t, int, int, void *, hipStream_t)>(dlsym(h, "ncclSend"));
+            q.recv = reinterpret_cast<int (*)(void *, size_t, int, int, void *, hipStream_t)>(dlsym(h, "ncclRecv"));
+        };
+        look(RTLD_DEFAULT);
+        for (const char *name : { "librccl.so.1", "librccl.so" }) {
+            if (q.ok()) break;
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) look(h);
+        }
+        return q;
+    }();
+    return r;
+}
+}  // namespace
+}  // extern "C++"
+
+int fcpp_gather(fcpp_ctx *c, void *nccl_comm, int rank, int world, int root, int n_arrays, const void *const *send_dev, const int32_t *elem_bytes,
+                const int64_t *counts_per_rank, void *const *recv_dev, int flags)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || n_arrays < 0 || !counts_per_rank ||
+        (n_arrays > 0 && (!send_dev || !elem_bytes)) || (rank == root && n_arrays > 0 && !recv_dev))
+        return fail(FCPP_EINVAL, "bad arguments");
+    for (int r = 0; r < world; ++r) if (counts_per_rank[r] < 0) return fail(FCPP_ESIZE, "negative count");
+    for (int a = 0; a < n_arrays; ++a) if (elem_bytes[a] <= 0) return fail(FCPP_ESIZE, "element size must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const bool self_through_comm = (flags & 1) != 0;
+    const bool need_comm = world > 1 || (self_through_comm && counts_per_rank[rank] > 0);
+    if (need_comm && (!nccl_comm || !rccl().ok())) return fail(FCPP_EUNSUPPORTED, nccl_comm ? "RCCL (ncclSend / ncclRecv) is not available in this process" : "nccl_comm is NULL");
+    std::vector<int64_t> first((size_t)world + 1, 0);
+    for (int r = 0; r < world; ++r) first[(size_t)r + 1] = first[(size_t)r] + counts_per_rank[r];
+    // one group: the root posts a receive per peer and array straight into the slice of its full array, every peer one send per array --
+    // point to point, each peer over its own xGMI link to the root (no ring, no staging, no concatenation)
+    bool grouped = false;
+#define NCCLCHK(expr) do { const int e_ = (expr); if (e_ != 0) { if (grouped) (void)rccl().group_end(); return fail(FCPP_EHIP, std::string(#expr) + ": RCCL error " + std::to_string(e_)); } } while (0)
+    if (need_comm) { NCCLCHK(rccl().group_start()); grouped = true; }
+    for (int a = 0; a < n_arrays; ++a) {
+        const size_t eb = (size_t)elem_bytes[a];
+        if (rank == root) {
+            char *full = static_cast<char *>(recv_dev[a]);
+            for (int r = 0; r < world; ++r) {
+                const size_t bytes = (size_t)counts_per_rank[r] * eb;
+                if (bytes == 0) continue;
+                char *dst = full + (size_t)first[(size_t)r] * eb;
+                if (r == rank && !self_through_comm) { if (dst != send_dev[a]) HIPCHK(hipMemcpyAsync(dst, send_dev[a], bytes, hipMemcpyDeviceToDevice, st)); }
+                else NCCLCHK(rccl().recv(dst, bytes, /* ncclInt8 */ 0, r, nccl_comm, st));
+            }
+            if (self_through_comm && counts_per_rank[rank] > 0)
+                NCCLCHK(rccl().send(send_dev[a], (size_t)counts_per_rank[rank] * eb, 0, rank, nccl_comm, st));
+        } else if (counts_per_rank[rank] > 0) {
+            NCCLCHK(rccl().send(send_dev[a], (size_t)counts_per_rank[rank] * eb, 0, root, nccl_comm, st));
+        }
+    }
+    if (grouped) { grouped = false; NCCLCHK(rccl().group_end()); }
+#undef NCCLCHK
     return FCPP_OK;
 }
 

@@ -83,8 +83,10 @@ def gather_rows(local_rows, rows_per_rank, dst=0):
         if FORCE_COLLECTIVES and dist.is_initialized():
             return _send_to_self([local_rows])[0]
         return local_rows
+    # ONE batch of point-to-point operations (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd with the nccl backend): the root posts all
+    # its receives together -- posted one by one they are served one after the other -- as gather_arrays does for the point arrays
+    ops, parts = [], []
     if rank == dst:
-        parts, reqs = [], []
         for r in range(ws):
             if r == dst:
                 parts.append(local_rows)
@@ -93,13 +95,13 @@ def gather_rows(local_rows, rows_per_rank, dst=0):
                               device=local_rows.device)
             parts.append(buf)
             if rows_per_rank[r] > 0:
-                reqs.append(dist.irecv(buf, src=r))
-        for q in reqs:
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+    elif local_rows.shape[0] > 0:
+        ops.append(dist.P2POp(dist.isend, local_rows.contiguous(), dst))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return torch.cat(parts, dim=0)
-    if local_rows.shape[0] > 0:
-        dist.send(local_rows.contiguous(), dst=dst)
-    return None
+    return torch.cat(parts, dim=0) if rank == dst else None
 
 
 def gather_arrays(local_arrays, counts_per_rank, dst=0):

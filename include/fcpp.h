@@ -396,6 +396,19 @@ typedef struct fcpp_cover_job {
 int fcpp_cover_grid(fcpp_ctx *ctx, int64_t n_jobs, const fcpp_cover_job *jobs, int64_t n_pts, const double *px_dev,
                     const double *py_dev, uint8_t *grid_dev, int64_t *counts_dev);
 
+/* ---- the final gather of a job sharded over the GPUs of a node ----------------------------------
+ * Fields are independent: every rank plans a contiguous block of them (cut on fcpp_plan_points) with its own context and batch, and the
+ * only exchange is this gather of the blocks' results on one rank.  For each of n_arrays arrays (elem_bytes[a] bytes per element: 8 for
+ * x / y / kappa / v, 4 for flagseg, sizeof(fcpp_field_stats) for the statistics with counts in fields) rank r contributes counts_per_rank[r]
+ * elements from send_dev[a]; the root receives them in rank order into recv_dev[a] (sum of the counts elements; NULL on the other ranks).
+ * One ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the context's stream over the caller's communicator (`nccl_comm`: an
+ * ncclComm_t of RCCL) -- point to point, every peer over its own xGMI link to the root, no ring and no staging copy; the root's own block
+ * is a device-to-device copy (flags bit 0: it, too, goes through the communicator -- a one-GPU test of the RCCL path).  Asynchronous: the
+ * arrays are complete when the stream is.  RCCL is looked up in the process at the first call, not linked: FCPP_EUNSUPPORTED without
+ * it.  (The Python mirror gathers through torch.distributed instead -- sharding.py -- whose process group owns the communicator.) */
+int fcpp_gather(fcpp_ctx *ctx, void *nccl_comm, int rank, int world, int root, int n_arrays, const void *const *send_dev, const int32_t *elem_bytes,
+                const int64_t *counts_per_rank, void *const *recv_dev, int flags);
+
 /* ---- diagnostics (tests/) -----------------------------------------------------------------------
  * The setup's transcendentals (csrc/fcpp_math.h: plain IEEE operations so that host and device agree bit for bit) evaluated on the host /
  * on the device: fn 0 = sin and cos of a -> out0, out1; 1 = atan2(a, b); 2 = acos(a); 3 = hypot(a, b) -> out0.  The _dev variant takes

@@ -107,6 +107,7 @@ int main(int argc, char **argv)
         tc.turn_quiet = pick(4) != 0;
         tc.wave_points = pick(3) ? 128 : 64;
         tc.field_work = pick(4) != 0;
+        tc.fuse_spans = tc.field_work && tt.nu <= TMPL_LDS_SAMPLES && pick(3) != 0;
         const double vm = 15.0 / 3.6;
         tc.two_a = 2 * veh.max_longitudinal_accel; tc.u_cap = vm * vm; tc.c_line = (9.0 / 3.6) * (9.0 / 3.6);
         tc.fence_margin = 1e-7 - opt.geofence_tol;
@@ -114,6 +115,12 @@ int main(int argc, char **argv)
         ImageLayout lay;
         rc = tiler.plan(hp, tc, &polys, lay, err);
         if (rc != FCPP_OK) FAIL("tiler.plan: %s", err.c_str());
+        if (tc.fuse_spans && lay.unfusable_work > 0) {          // all spans of fields of field work are fused, or none (fcpp_api.cpp)
+            tc.fuse_spans = false;
+            rc = tiler.plan(hp, tc, &polys, lay, err);
+            if (rc != FCPP_OK) FAIL("tiler.plan (again): %s", err.c_str());
+            if (lay.work_span_points != 0) FAIL("spans fused although fusing is off");
+        }
         std::vector<unsigned char> img(lay.upload_bytes, 0);
         tiler.fill(hp, &polys, lay, img.data());
         raw = fnv(raw, img.data(), img.size());
@@ -187,6 +194,36 @@ int main(int argc, char **argv)
                 if (c.quiet == 2 && (c.idx0 < F[c.field].prim_first || c.idx0 >= F[c.field].prim_first + F[c.field].prim_count)) FAIL("chunk %lld: primitive", (long long)k);
             }
         }
+        {   // the packs of k_plan_sparse_fields: the field's records gathered, and the span its workgroup writes itself (no chunks for it)
+            const DevFieldWork *FW = reinterpret_cast<const DevFieldWork *>(img.data() + lay.field_work);
+            const DevFieldPack *PK = reinterpret_cast<const DevFieldPack *>(img.data() + lay.field_packs);
+            int64_t fused_pts = 0;
+            for (int64_t k = 0; k < lay.n_field_work; ++k) {
+                const DevFieldPack &pk = PK[k];
+                if (memcmp(&pk.work, &FW[k], sizeof(DevFieldWork)) || memcmp(&pk.field, &F[FW[k].field], sizeof(DevField))) FAIL("pack %lld: work / field record", (long long)k);
+                for (int t = 0; t < FIELD_WORK_TILES; ++t) {
+                    DevWaveTile zero;
+                    memset(&zero, 0, sizeof zero);
+                    const DevWaveTile &want = t < FW[k].n_tiles ? Wt[FW[k].w_first + t] : zero;
+                    if (memcmp(&pk.tile[t], &want, sizeof want)) FAIL("pack %lld: tile %d", (long long)k, t);
+                    if (t < FW[k].n_tiles && (int)want.hb + want.count + want.hf > want.rel_main) {
+                        int np = 1;
+                        for (int q = 0; q < 8; ++q) np += want.thr[q] != 255;
+                        for (int q = 0; q < np; ++q) if (memcmp(&pk.prims[t][q], &P[want.p0 + q], sizeof(DevPrim))) FAIL("pack %lld: tile %d primitive %d", (long long)k, t, q);
+                    }
+                }
+                if (pk.span_points != FW[k].fused_span || pk.span_points < 0) FAIL("pack %lld: span points", (long long)k);
+                if (pk.span_points > 0) {
+                    if (!tc.fuse_spans) FAIL("pack %lld: a fused span although fusing is off", (long long)k);
+                    const int64_t e0 = FW[k].e_first, g0 = F[FW[k].field].pt_off;
+                    if (SR[e0] != pk.span_points || T[SI[e0]].quiet != 4 || T[SI[e0]].start != 0) FAIL("pack %lld: the span's run entry", (long long)k);
+                    if (((g0 % TILE_POINTS) + pk.span_points + TILE_POINTS - 1) / TILE_POINTS > FUSED_SPAN_CHUNKS) FAIL("pack %lld: span of too many chunks", (long long)k);
+                    if (!mark(FW[k].field, 0, pk.span_points, "fused span")) FAIL("pack %lld: fused span", (long long)k);
+                    fused_pts += pk.span_points;
+                }
+            }
+            if (fused_pts != lay.work_span_points) FAIL("fused span points %lld, layout says %lld", (long long)fused_pts, (long long)lay.work_span_points);
+        }
         for (int64_t g = 0; g < total; ++g) if (cover[(size_t)g] != 1) FAIL("point %lld planned %d times", (long long)g, cover[(size_t)g]);
         if (SF[0] != 0 || SF[n] != lay.n_stat) FAIL("stat_first ends");
         int64_t q_pts = 0;
@@ -198,7 +235,7 @@ int main(int argc, char **argv)
                 q_pts += SR[e];
             }
         }
-        if (q_pts != lay.quiet_points || lay.span_points + lay.chunk_points != lay.quiet_points) FAIL("quiet point totals");
+        if (q_pts != lay.quiet_points || lay.span_points + lay.chunk_points + lay.work_span_points != lay.quiet_points) FAIL("quiet point totals");
         {
             std::vector<unsigned char> seen((size_t)n, 0);
             // fields planned and reduced by one workgroup (DevFieldWork) are in no class; their wave tiles are not in the open list

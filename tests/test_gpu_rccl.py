@@ -27,3 +27,14 @@ def test_sharded_job_collectives_over_rccl_on_one_gpu(tmp_path):
         assert g[f'a{k}'].size > 0 and np.array_equal(g[f'a{k}'], g[f'l{k}']), k
     assert np.array_equal(g['fit'], g['fit_local']) and np.array_equal(g['dist'], g['dist_local'])
     assert np.array_equal(g['ring0'], g['ring'][:8]) and np.array_equal(g['ring1'], g['ring'][8:])
+
+
+def test_c_abi_gather_over_a_one_rank_rccl_communicator(tmp_path):
+    """fcpp_gather (include/fcpp.h): ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the context's stream over the caller's communicator --
+    here a one-rank communicator made through ctypes, the rank's own block forced through it (flags = 1)."""
+    out = str(tmp_path / 'gather.npz')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'tests', '_rccl_gather_worker.py'), out], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and 'rccl gather worker OK' in p.stdout, (p.stdout[-3000:], p.stderr[-3000:])
+    g = np.load(out)
+    assert int(g['ok']) == 1 and int(g['n']) > 0
