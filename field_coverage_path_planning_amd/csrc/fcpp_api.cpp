@@ -868,7 +868,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tc.two_a = 2 * b->cst.a_lon; tc.u_cap = b->cst.u_cap; tc.c_line = b->cst.ms_work * b->cst.ms_work;
     // (the device flags a point whose edge function is below -geofence_tol; host and device evaluate a point by the same formulas and
     // differ by roundings of ~1e-12 m: 1e-7 m of slack is five orders of magnitude of safety -- and lets the points that lie ON the boundary,
-    // the ends of the reverse fills, three per field of the metric's size, pass with the default tolerance of 1e-6 m: with the millimetre
+    // the ends of the reverse fills, three per field of the metric's size, pass with the default tolerance of 1e-6 m: with the millimetre of margin
     // of rounds 2-3a those three points sent half of the headline's wave tiles through the geofence test)
     tc.fence_margin = 1e-7 - opt->geofence_tol;
     // (tuning knobs, read once per batch and clamped; both change which kernel plans a stretch or which reduction class a path falls

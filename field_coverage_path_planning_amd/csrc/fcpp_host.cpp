@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <vector>
 
 #include "fcpp_geom.h"
@@ -269,8 +270,19 @@ int validate_polys(const fcpp_polys *polys, std::string &err)
     return FCPP_OK;
 }
 
+static int build_host_plan_impl(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
+                                bool want_device, HostPlan &out, std::string &err);
+
 int build_host_plan(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
                     bool want_device, HostPlan &out, std::string &err)
+{
+    // (the per-block work grows vectors on worker threads: fcpp_parallel.h hands the first std::bad_alloc back to this thread)
+    try { return build_host_plan_impl(veh, opt, n, fields, polys, want_device, out, err); }
+    catch (const std::bad_alloc &) { err = "out of host memory"; return FCPP_ENOMEM; }
+}
+
+static int build_host_plan_impl(const fcpp_vehicle &veh, const fcpp_options &opt, int64_t n, const fcpp_field *fields, const fcpp_polys *polys,
+                                bool want_device, HostPlan &out, std::string &err)
 {
     PlanConsts pc;
     int rc = plan_prepare(veh, opt, pc, out.tt, err);

@@ -91,7 +91,8 @@ struct DevWaveTile {
     int32_t tile;            // the tile's statistics entry = its slot in the partial statistics (the entries of a field lie side by side)
     uint8_t count;           // output lanes ...
     uint8_t hb, hf;          // ... after hb halo lanes and before hf halo lanes (hb + count + hf <= 64)
-    uint8_t inside;          // 1: the host found every output point at least a millimetre inside the field polygon (no geofence test needed)
+    uint8_t inside;          // 1: the tiler found every output point inside every edge of the field polygon by more than the device's test can fire at (fcpp_tilefn.h:
+                             // tiler_inside: 1e-7 m - geofence_tol + 256 ulps of the coordinates): no geofence test needed
     int32_t rel_main;        // gen_main - first: lanes below it are generated from layer 1's closed form (clamped to [-2, 1 << 30])
     int32_t rel_seam;        // n_main - first: the lane of the first point of layer 2 (clamped likewise)
     int32_t rel_last;        // (n_total - 1) - first: the lane of the path's last point (clamped likewise); first == 0 <=> rel_zero == 0

@@ -12,6 +12,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -36,7 +37,8 @@ public:
     }
 
     // fn(k) for k in [0, n_items), every k exactly once; returns when all have finished.  One parallel_for at a time: calls from
-    // several host threads take turns.  fn must not throw.
+    // several host threads take turns.  An exception thrown by fn (std::bad_alloc from a growing vector) is caught where it is thrown,
+    // the remaining items are skipped, every thread is waited for, and the FIRST exception is rethrown in the calling thread.
     static void parallel_for(int64_t n_items, const std::function<void(int64_t)> &fn)
     {
         if (n_items <= 0) return;
@@ -47,6 +49,8 @@ public:
         }
         WorkerPool &p = instance();
         std::lock_guard<std::mutex> turn(p.turn_);
+        p.error_ = nullptr;
+        p.failed_.store(false, std::memory_order_relaxed);
         while ((int)p.n_workers_ < w - 1) {
             std::thread([&p] { p.worker(); }).detach();
             ++p.n_workers_;
@@ -62,29 +66,46 @@ public:
         std::unique_lock<std::mutex> lk(p.m_);
         p.done_.wait(lk, [&] { return p.busy_ == 0; });
         p.fn_ = nullptr;
+        if (p.error_) {
+            std::exception_ptr e = p.error_;
+            p.error_ = nullptr;
+            lk.unlock();
+            std::rethrow_exception(e);
+        }
     }
 
 private:
-    static WorkerPool *&slot()
+    static std::atomic<WorkerPool *> &slot()
     {
-        static WorkerPool *s = nullptr;
+        static std::atomic<WorkerPool *> s{ nullptr };
         return s;
     }
     static WorkerPool &instance()
     {
+        // (no mutex here: a fork()ed child whose parent held one at the time of the fork would wait for it for ever; the pool is published
+        // by one compare-and-swap, a thread that loses the race deletes its copy)
         static std::once_flag once;
-        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { slot() = nullptr; }); });     // (the parent's object leaks in the child)
-        static std::mutex make;
-        std::lock_guard<std::mutex> lk(make);
-        if (!slot()) slot() = new WorkerPool();
-        return *slot();
+        std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { slot().store(nullptr); }); });     // (the parent's object leaks in the child)
+        WorkerPool *p = slot().load(std::memory_order_acquire);
+        if (!p) {
+            WorkerPool *mine = new WorkerPool();
+            if (slot().compare_exchange_strong(p, mine, std::memory_order_acq_rel)) p = mine;
+            else delete mine;
+        }
+        return *p;
     }
     void drain(const std::function<void(int64_t)> &fn, int64_t n_items)
     {
         for (;;) {
             const int64_t k = next_.fetch_add(1, std::memory_order_relaxed);
             if (k >= n_items) break;
-            fn(k);
+            if (failed_.load(std::memory_order_relaxed)) continue;       // (an item has thrown: the rest is skipped, the counter runs out)
+            try { fn(k); }
+            catch (...) {
+                std::lock_guard<std::mutex> lk(m_);
+                if (!error_) error_ = std::current_exception();
+                failed_.store(true, std::memory_order_relaxed);
+            }
         }
     }
     void worker()
@@ -114,6 +135,8 @@ private:
     std::atomic<int64_t> next_{ 0 };
     int n_workers_ = 0, busy_ = 0;
     uint64_t generation_ = 0;
+    std::exception_ptr error_;           // the first exception an item threw (guarded by m_)
+    std::atomic<bool> failed_{ false };
 };
 
 }  // namespace fcpp

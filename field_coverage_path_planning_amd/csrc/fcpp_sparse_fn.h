@@ -192,7 +192,7 @@ __device__ __forceinline__ void sparse_tile(const DevWaveTile &wt, const DevFiel
 
     // ---- 4. validation flags ------------------------------------------------------------------------------------------------------
     bool o_out = false, o_obs = false, o_viol = false;
-    // (wave-uniform: tiles whose output points the host found a millimetre inside the polygon skip the test -- most headland tiles)
+    // (wave-uniform: tiles whose output points the tiler found safely inside the polygon -- tiler_inside, fcpp_tilefn.h -- skip the test: most headland tiles)
     if (!wt.inside && out) {
         const double ntol = -cst.geofence_tol;
         bool o = false;

@@ -65,12 +65,15 @@ FCPP_HD void tiler_point_prim(const DevPrim &q, const Pt2 *tu, const Pt2 *tc, in
     }
 }
 
-// is the point at least `margin` inside every edge of the field polygon?  (the device flags a point whose edge function is below
-// -geofence_tol; margin = 1e-7 - geofence_tol: the device's test of such a point cannot fire)
+// Is the point so far inside every edge of the field polygon that the device's geofence test of it cannot fire?  The device flags a
+// point whose edge function is below -geofence_tol; tiler and kernel evaluate the point by the same formulas and differ by roundings that
+// grow with the coordinates' magnitude (~1e-12 m at 1e3 m, ~1e-9 m at UTM-sized 5e6 m).  margin = 1e-7 - geofence_tol, plus 256 ulps of
+// the point's own coordinates: the slack stays orders of magnitude above those roundings wherever the field lies.
 FCPP_HD bool tiler_inside(const DevField &F, double px, double py, double margin)
 {
+    const double m = margin + 5.684341886080802e-14 * (fabs(px) + fabs(py));      // 256 x 2^-52
     for (int e = 0; e < 4; ++e)
-        if (!(F.ex[e] * px + F.ey[e] * py + F.eo[e] >= margin)) return false;
+        if (!(F.ex[e] * px + F.ey[e] * py + F.eo[e] >= m)) return false;
     return true;
 }
 

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 
 #include "fcpp_geom.h"
 #include "fcpp_parallel.h"
@@ -110,7 +111,7 @@ struct FieldTiler {
             }
         }
         // every output point of [s, s + c) well inside the field polygon?  (host and device evaluate a point with the same formulas;
-        // their roundings differ by ~1e-12 m, the margin is a millimetre: the device's test of such a point cannot fire)
+        // their roundings differ by ~1e-12 m at field-sized coordinates, the margin is 1e-7 m plus 256 ulps of the point: tiler_inside)
         auto all_inside = [&](int64_t s, int64_t c) -> bool {
             for (int64_t i = s; i < s + c; ++i) {
                 if (i < lo - 1 || i >= hi) return false;
@@ -463,6 +464,12 @@ BatchTiler::BatchTiler() : blocks_(new std::vector<BlockTiles>()) {}
 BatchTiler::~BatchTiler() { delete blocks_; }
 
 int BatchTiler::plan(const HostPlan &hp, const TileConsts &tc, const fcpp_polys *polys, ImageLayout &lay, std::string &err)
+{
+    try { return plan_impl(hp, tc, polys, lay, err); }
+    catch (const std::bad_alloc &) { err = "out of host memory"; return FCPP_ENOMEM; }
+}
+
+int BatchTiler::plan_impl(const HostPlan &hp, const TileConsts &tc, const fcpp_polys *polys, ImageLayout &lay, std::string &err)
 {
     const int64_t n = (int64_t)hp.fields.size(), nb = (int64_t)hp.blocks.size();
     std::vector<BlockTiles> &B = *blocks_;

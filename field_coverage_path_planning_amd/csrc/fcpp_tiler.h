@@ -71,6 +71,7 @@ public:
     // phase 2: write the image into `dst` (lay.upload_bytes bytes; pinned host memory in fcpp_batch_create), side by side
     void fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst) const;
 private:
+    int plan_impl(const HostPlan &hp, const TileConsts &tc, const fcpp_polys *polys, ImageLayout &lay, std::string &err);
     std::vector<BlockTiles> *blocks_;
 };
 

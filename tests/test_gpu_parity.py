@@ -217,6 +217,58 @@ def test_geofence_tolerances_vs_oracle():
     assert counts[0] > counts[1] > counts[2] >= counts[3] and counts[0] > 0, counts
 
 
+def test_fields_far_from_the_origin_vs_oracle():
+    """UTM-sized coordinates (~5e6 m, where a double resolves 1e-9 m): coordinates within 5e-8 m of the oracle, every integer equal, and the
+    geofence flags equal -- with the default tolerance exactly, with tolerance 0 wherever a point is farther than a micrometre from the
+    boundary (ON it, rounding decides in the oracle as in the library).  The tiler's "inside by a margin" shortcut (DevWaveTile.inside,
+    fcpp_tilefn.h: tiler_inside) scales its margin with the coordinates, so it cannot hide a flag here either."""
+    rng = np.random.default_rng(41)
+    shift = np.array([5.2e6, 4.1e6])
+    specs, ofs, quads = [], [], []
+    for k in range(10):
+        w, h = rng.uniform(120, 700, 2)
+        q = np.array([[0, 0], [w, 0], [w, h], [0, h]], dtype=np.float64)
+        if k % 2:
+            q[2:, 0] += rng.uniform(-0.3, 0.3) * h
+            rot = rng.uniform(-0.7, 0.7)
+            q = q @ np.array([[np.cos(rot), np.sin(rot)], [-np.sin(rot), np.cos(rot)]])
+        q = q + shift
+        verts = [(float(a), float(b)) for a, b in q]
+        specs.append(E.FieldSpec(field_vertices=verts))
+        ofs.append(orc.make_field(verts=verts))
+        quads.append(q)
+    for tol in (1e-6, 0.0):
+        o = E.make_options(geofence_tol=tol)
+        for setup in ('device', 'host'):
+            E.get_context().set_setup(setup)
+            try:
+                batch = E.Batch(specs, _veh(DEFAULT_VP), o)
+            finally:
+                E.get_context().set_setup('auto')
+            res = batch.run()
+            x, y, v, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.flagseg).view(np.uint32)
+            for i, of in enumerate(ofs):
+                rc, p = orc.plan_field(of, orc.Vehicle.make(DEFAULT_VP), orc.Options.make(geofence_tol=tol))
+                info = batch.info[i]
+                assert rc == info.status == 0 and (info.n_main, info.n_head, info.n_swaths) == (p.n_main, p.n_head, p.n_swaths)
+                sl = res.field_slice(i)
+                np.testing.assert_allclose(np.column_stack([x[sl], y[sl]]), p.xy, rtol=0, atol=5e-8)
+                np.testing.assert_allclose(v[sl], p.v, rtol=0, atol=1e-4)
+                kinds = ~np.uint32(L.FLAG_OUTSIDE)
+                assert np.array_equal(fs[sl] & kinds, p.flagseg & kinds)
+                # signed distance of every point to the nearest edge line (relative coordinates: no cancellation)
+                q = quads[i] - shift
+                rel = p.xy - shift
+                cr = lambda a, b: a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+                sgn = 1.0 if cr(q[1] - q[0], q[2] - q[1]) > 0 else -1.0
+                d = np.min([sgn * cr(q[(e + 1) % 4] - q[e], rel - q[e]) / np.linalg.norm(q[(e + 1) % 4] - q[e]) for e in range(4)], axis=0)
+                sure = np.abs(d + tol) > 1e-6
+                assert np.array_equal((fs[sl] & L.FLAG_OUTSIDE)[sure], (p.flagseg & L.FLAG_OUTSIDE)[sure]), (tol, setup, i)
+                if tol > 0:
+                    assert np.array_equal(fs[sl], p.flagseg), (setup, i)
+            batch.close()
+
+
 def _clip_fields():
     """fields whose obstacles sit inside the work area, away from the swath lines' end zones: a rectangle with a square, a triangle
     and a pentagon (the last two side by side on the same swaths), and a tilted parallelogram with two obstacles"""
