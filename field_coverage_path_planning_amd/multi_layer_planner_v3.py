@@ -106,6 +106,29 @@ class QuadPolygon:
 
 _SHAPES = {0: 'rectangle', 1: 'parallelogram', 2: 'other'}
 
+_RING_ORDER_WARNED = False
+RING_ORDER_CHECK = '''from shapely.geometry import Polygon
+v = [(0, 0), (500, 0), (500, 200), (0, 200)]
+ring = list(Polygon(v).buffer(-1.6).exterior.coords)[:-1]
+# ring[0] ~ (1.6, 1.6) and ring[1] ~ (498.4, 1.6): ring_order=0   (as the vertices: LL, LR, UR, UL)
+# ring[0] ~ (1.6, 1.6) and ring[1] ~ (1.6, 198.4): ring_order=1   (the other way round: LL, UL, UR, LR)'''
+
+
+def _warn_ring_order_once():
+    """The order in which Shapely lists the inset corners of a headland loop (MLP:964-972) is a GEOS fact the reference neither documents nor
+    tests, and its corner formulas index that list (MLP:1049-1060).  Both orders are pinned to the reference's own code (tests/golden:
+    cw_*); which one a given Shapely / GEOS emits cannot be observed here (no Shapely in this build's environment), so for fields given by
+    vertices the caller should say -- once per process this reminds them how to find out."""
+    global _RING_ORDER_WARNED
+    if _RING_ORDER_WARNED:
+        return
+    _RING_ORDER_WARNED = True
+    import warnings
+    warnings.warn("TwoLayerPathPlannerV37(field_vertices=...) without ring_order=: the headland loops are built in the order of the field's "
+                  "vertices (ring_order=0, the intent the reference documents at MLP:957); the reference itself takes the order from "
+                  "Shapely's buffer(-d).exterior.coords, which this build cannot observe.  With Shapely at hand, check once:\n" + RING_ORDER_CHECK +
+                  "\nand pass ring_order=0 or 1 explicitly (INTEGRATION.md, 'Ring order of the inset corners').", stacklevel=3)
+
 
 class TwoLayerPathPlannerV37:
     """两层路径规划器 V3.7 (MLP:42-61) -- HIP-backed."""
@@ -116,7 +139,7 @@ class TwoLayerPathPlannerV37:
                  end_point: Tuple[float, float] = None, *, vehicle: VehicleParams = None, verbose: bool = False,
                  turn_model: str = 'arc', sample_spacing: float = 0.0, clothoid_frac: float = 0.5,
                  clothoid_fit: int = 1, geofence_tol: float = 1e-6, coverage_resolution: float = 0.1, device: int = None,
-                 avoid_obstacles: bool = False, ring_order: int = 0):
+                 avoid_obstacles: bool = False, ring_order: int = None):
         if vehicle_params is None:
             vehicle_params = vehicle if vehicle is not None else VehicleParams()   # README_en.md:274-302 uses vehicle=
         self.vehicle = vehicle_params
@@ -127,6 +150,8 @@ class TwoLayerPathPlannerV37:
         self._spec = E.FieldSpec(field_length, field_width, field_vertices, self.obstacles, start_point, end_point)
         self._batch = self._bufs = None
         self._veh = E.make_vehicle(self.vehicle)
+        self._ring_order_given = ring_order is not None
+        ring_order = 0 if ring_order is None else int(ring_order)
         self._opt = E.make_options(L.TURN_CLOTHOID if str(turn_model).lower().startswith('cloth') else L.TURN_ARC,
                                    sample_spacing, clothoid_frac, clothoid_fit, geofence_tol, avoid_obstacles, ring_order)
         # _process_field_input (MLP:109-135): ValueError when no field is given
@@ -149,6 +174,8 @@ class TwoLayerPathPlannerV37:
         self.main_work_pattern = "U型往复" if (aspect > 3.0 or aspect >= 1.5) else "Ω型跨行"
         self.start_point = tuple(map(float, start_point)) if (start_point is not None and info.start_kept) else None
         self.end_point = tuple(map(float, end_point)) if (end_point is not None and info.end_kept) else None
+        if field_vertices is not None and info.shape != 0 and not self._ring_order_given:
+            _warn_ring_order_once()
         if verbose:
             print(f"[V3.7.0/fcpp] 初始化完成: 形状={self.field_shape}, 田头宽度={self.headland_width:.1f}m, "
                   f"障碍物={len(self.obstacles)}")

@@ -165,7 +165,17 @@ def test_planner_constructor_surface(golden_plans):
     with pytest.raises(ValueError):
         TwoLayerPathPlannerV37(VehicleParams())
     g = golden_plans
-    pp = TwoLayerPathPlannerV37(VehicleParams(), field_vertices=[tuple(v) for v in g['verts_para_75/verts']])
+    # a field given by vertices, not a rectangle, no ring_order: one warning per process that tells how to find the order GEOS emits
+    M._RING_ORDER_WARNED = False
+    with pytest.warns(UserWarning, match='ring_order'):
+        pp = TwoLayerPathPlannerV37(VehicleParams(), field_vertices=[tuple(v) for v in g['verts_para_75/verts']])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                  # (said once; an explicit choice never warns)
+        TwoLayerPathPlannerV37(VehicleParams(), field_vertices=[tuple(v) for v in g['verts_para_75/verts']])
+        M._RING_ORDER_WARNED = False
+        TwoLayerPathPlannerV37(VehicleParams(), field_vertices=[tuple(v) for v in g['verts_para_75/verts']], ring_order=1)
+        TwoLayerPathPlannerV37(VehicleParams(), field_length=500, field_width=200)
     assert pp.field_shape == 'parallelogram'
     assert np.allclose([pp.field_length, pp.field_width], g['verts_para_75/field_LH'])
     assert abs(pp.field_polygon.area - 400 * 160) < 1e-6
