@@ -14,6 +14,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <utility>
 #include <new>
 #include <vector>
 
@@ -23,6 +25,69 @@
 #include "fcpp_planfn.h"
 
 namespace fcpp {
+
+namespace {
+// Area of { p in [0, 2R]^2 : dist(p, polyline) <= W/2 } for the 30-point quarter arc (0,0) -> (R, R) of MLP:1124-1141 (corner 0; the other
+// corners are its mirror images): column by column -- a vertical line meets every capsule (segment + radius) in one interval, the
+// intervals of a column are merged and clipped to the square -- with the midpoint rule over 32768 columns (error far below 1e-6 m^2).
+double corner_cover_area(double R, double W)
+{
+    static std::mutex mu;
+    static double last_R[2] = { -1.0, -1.0 }, last_W[2] = { -1.0, -1.0 }, last_area[2] = { 0.0, 0.0 };
+    static int next = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (int q = 0; q < 2; ++q) if (R == last_R[q] && W == last_W[q]) return last_area[q];
+    }
+    const int NP = 30, NCOL = 32768;
+    const double r = W / 2, side = 2 * R, dx = side / NCOL;
+    double px[NP], py[NP];
+    for (int k = 0; k < NP; ++k) { const double th = kHalfPi * k / (NP - 1); px[k] = R * (1 - cos(th)); py[k] = R * sin(th); }
+    double area = 0.0;
+    std::pair<double, double> iv[NP];
+    for (int j = 0; j < NCOL; ++j) {
+        const double x = (j + 0.5) * dx;
+        int ni = 0;
+        for (int k = 0; k + 1 < NP; ++k) {
+            double lo = HUGE_VAL, hi = -HUGE_VAL;
+            const double ax = px[k], ay = py[k], bx = px[k + 1], by = py[k + 1];
+            for (int e = 0; e < 2; ++e) {            // the two end discs
+                const double cx = e ? bx : ax, cy = e ? by : ay, h2 = r * r - (x - cx) * (x - cx);
+                if (h2 >= 0) { const double h = sqrt(h2); lo = std::min(lo, cy - h); hi = std::max(hi, cy + h); }
+            }
+            // the rectangle between them: 0 <= t <= 1 and |n| <= r, both linear in y
+            const double ex = bx - ax, ey = by - ay, len = sqrt(ex * ex + ey * ey);
+            if (len > 0) {
+                double l2 = -HUGE_VAL, h2 = HUGE_VAL;
+                auto clip = [&](double a0, double a1, double lo_v, double hi_v) {      // lo_v <= a0 + a1 y <= hi_v
+                    if (a1 == 0) { if (a0 < lo_v || a0 > hi_v) { l2 = HUGE_VAL; h2 = -HUGE_VAL; } return; }
+                    double y0 = (lo_v - a0) / a1, y1 = (hi_v - a0) / a1;
+                    if (y0 > y1) std::swap(y0, y1);
+                    l2 = std::max(l2, y0); h2 = std::min(h2, y1);
+                };
+                clip(((x - ax) * ex - ay * ey) / (len * len), ey / (len * len), 0.0, 1.0);      // t(y)
+                clip((-(x - ax) * ey - ay * ex) / len, ex / len, -r, r);                         // n(y)
+                if (l2 <= h2) { lo = std::min(lo, l2); hi = std::max(hi, h2); }
+            }
+            lo = std::max(lo, 0.0); hi = std::min(hi, side);
+            if (lo < hi) iv[ni++] = { lo, hi };
+        }
+        std::sort(iv, iv + ni);
+        double covered = 0.0, cur_lo = 0.0, cur_hi = -1.0;
+        for (int q = 0; q < ni; ++q) {
+            if (cur_hi < cur_lo) { cur_lo = iv[q].first; cur_hi = iv[q].second; }
+            else if (iv[q].first <= cur_hi) cur_hi = std::max(cur_hi, iv[q].second);
+            else { covered += cur_hi - cur_lo; cur_lo = iv[q].first; cur_hi = iv[q].second; }
+        }
+        if (cur_hi >= cur_lo) covered += cur_hi - cur_lo;
+        area += covered * dx;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    last_R[next] = R; last_W[next] = W; last_area[next] = area;
+    next ^= 1;
+    return area;
+}
+}  // namespace
 
 int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c, TurnTemplates &tt, std::string &err)
 {
@@ -63,6 +128,19 @@ int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c
     // gap.area > 0.1 (MLP:1070): 2R x 2R square minus the arc buffered by W/2.  The buffer's area is at
     // most (pi R/2) W + pi W^2/4, so the decision is certain when this lower bound exceeds 0.1.
     c.gap_lb = 4 * R * R - (kPi * R / 2 * W + kPi * W * W / 4);
+    // Where the bound does not decide (wide implements on a tight radius: W >~ 1.6 R) the area itself does: the gap is the square minus
+    // the 30-point arc buffered by W/2, the same for every corner of every field (the formulas are axis-aligned, MLP:1101-1148) -- its
+    // exact area by integration, once per (R, W).  GEOS buffers with polygonal round parts, inscribed in the exact ones: with 8 segments
+    // per quarter circle or more (Shapely's default is 16) its buffer contains the exact buffer of radius (W/2) cos(pi/32), so
+    //     gap(W/2)  <=  GEOS' gap  <=  gap((W/2) cos(pi/32))
+    // and `gap.area > 0.1` (MLP:1070) is certain unless 0.1 lies between the two (FCPP_EUNSUPPORTED then, as before for the whole regime).
+    c.gap_area = c.gap_lb;
+    c.gap_decision = 1;
+    if (!(c.gap_lb > 0.1)) {
+        const double gap_lo = 4 * R * R - corner_cover_area(R, W), gap_hi = 4 * R * R - corner_cover_area(R, W * 0.99518472667219693);
+        c.gap_area = gap_lo;
+        c.gap_decision = gap_lo > 0.1 + 1e-6 ? 1 : (gap_hi < 0.1 - 1e-6 ? 0 : -1);
+    }
     c.nt_corner = ds > 0 ? n_for_length(c.len_corner, ds) : 15;
     c.arc_step = lin_step(0.0, kHalfPi, c.nt_corner);
     {

@@ -168,6 +168,8 @@ struct PlanConsts {
     double W, R, ds;
     int32_t clip, cloth;
     double Re_pi, Re_half, len_uturn, len_corner, gap_lb;
+    double gap_area;                  // area of the corner gap (MLP:1086-1152) where the lower bound does not decide; else gap_lb
+    int32_t gap_decision, _pad0;      // `gap.area > 0.1` (MLP:1070): 1 yes, 0 no, -1 within what GEOS' polygonal buffer leaves open
     double turn_end_pi;               // U-turn: arcs pi, clothoid total length
     double half_T;                    // corner turn, clothoid: total length
     // the last two samples of a corner turn (the reverse fill leaves along their chord): for arcs cos and sin of their angles, for the
@@ -368,9 +370,10 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
             }
             FCPP_PUSH(p);
             // reverse fill (MLP:1043, 224-242, 1066-1082, 1154-1218)
-            const bool add_rev = (loop == 0) && (in.corner_angles[nxt] >= 60);
+            const bool want_rev = (loop == 0) && (in.corner_angles[nxt] >= 60);       // MLP:1043
+            if (want_rev && pc.gap_decision < 0) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
+            const bool add_rev = want_rev && pc.gap_decision > 0;                     // MLP:1070: gap.area > 0.1
             if (add_rev) {
-                if (!(pc.gap_lb > 0.1)) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
                 const double tx = e1[0] - e2[0], ty = e1[1] - e2[1];
                 const double nrm = sqrt(tx * tx + ty * ty);
                 double dx = -1.0, dy = 0.0;

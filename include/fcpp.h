@@ -34,7 +34,8 @@ enum {
     FCPP_OK = 0,
     FCPP_EINVAL = -1,       /* the reference's ValueError: no field given / headland wider than field (MLP:135,597-598) */
     FCPP_EHEADLAND = -2,    /* a headland loop's inset polygon is empty (MLP:967-969 followed by the vstack at :939) */
-    FCPP_EUNSUPPORTED = -3, /* not a convex quadrilateral, or a regime only GEOS could decide */
+    FCPP_EUNSUPPORTED = -3, /* not a convex quadrilateral, or a decision only GEOS could take: the corner-gap test `gap.area > 0.1` (MLP:1070) where
+                               0.1 m^2 lies between the areas for the exact and for GEOS' polygonal buffer -- a band of ~0.04 m of working width */
     FCPP_EHIP = -4,         /* HIP runtime failure / no device */
     FCPP_ENOMEM = -5,
     FCPP_ESIZE = -6         /* negative / inconsistent sizes */

@@ -448,6 +448,49 @@ int orc_outside_polygon(double px, double py, const double *xy, int64_t nv, doub
     return tol < 0.0 || d2 > t2;
 }
 
+/* MLP:1086-1152 / :1070: is the area of (2R x 2R square at the corner) - (30-point quarter arc buffered by W/2) above 0.1 m^2?
+ * 1 yes, 0 no, -1 not decidable without GEOS (its buffer's round parts are polygons inscribed in the exact ones: with >= 8 segments per
+ * quarter circle the buffer lies between the exact buffers of radius (W/2) cos(pi/32) and W/2).  Independent of the library's column
+ * integration: rigorous bounds from a 2000 x 2000 grid of cells of side h -- a cell whose CENTRE is farther than r + h/sqrt2 from the
+ * polyline is uncovered as a whole (lower bound of the gap for radius r), a cell with any uncovered point has its centre farther than
+ * r - h/sqrt2 (upper bound). */
+static double orc_corner_gap_sampled(double R, double r)
+{
+    enum { NP = 30, NG = 2000 };
+    double px[NP], py[NP];
+    for (int k = 0; k < NP; ++k) { double th = (M_PI / 2) * k / (NP - 1); px[k] = R * (1 - cos(th)); py[k] = R * sin(th); }
+    const double h = 2 * R / NG, r2 = r * r;
+    long uncovered = 0;
+    for (int j = 0; j < NG; ++j)
+        for (int i = 0; i < NG; ++i) {
+            double x = (i + 0.5) * h, y = (j + 0.5) * h;
+            int cov = 0;
+            for (int k = 0; k + 1 < NP && !cov; ++k) {
+                double ex = px[k + 1] - px[k], ey = py[k + 1] - py[k], wx = x - px[k], wy = y - py[k];
+                double t = (wx * ex + wy * ey) / (ex * ex + ey * ey);
+                if (t < 0) t = 0;
+                if (t > 1) t = 1;
+                double dx = wx - t * ex, dy = wy - t * ey;
+                cov = dx * dx + dy * dy <= r2;
+            }
+            uncovered += !cov;
+        }
+    return uncovered * h * h;
+}
+int orc_corner_gap_decision(double R, double W)
+{
+    static double cR = -1, cW = -1;
+    static int cD = 0;
+    double gap_lb = 4 * R * R - (M_PI * R / 2 * W + M_PI * W * W / 4);
+    if (gap_lb > 0.1) return 1;
+    if (R == cR && W == cW) return cD;
+    const double hs = (2 * R / 2000) * 0.70710678118654757;
+    double lo = orc_corner_gap_sampled(R, W / 2 + hs), hi = orc_corner_gap_sampled(R, (W / 2) * cos(M_PI / 32) - hs);
+    int d = lo > 0.1 ? 1 : (hi < 0.1 ? 0 : -1);
+    cR = R; cW = W; cD = d;
+    return d;
+}
+
 /* convex polygon, either orientation: outside if beyond any edge by more than tol */
 int orc_outside_convex(double px, double py, const double *vx, const double *vy, int nv, double tol)
 {
@@ -877,9 +920,11 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
                         ORC_KIND_CORNER | lp | ((uint32_t)nxt << ORC_INDEX_SHIFT));
                 /* MLP:1043, 224-242, 1066-1082 */
                 int add_rev = (loop == 0) && (out->corner_angles[nxt] >= 60);
-                /* gap.area > 0.1 (MLP:1070): lower bound 4R^2 - (pi R W/2 + pi W^2/4), GEOS unpinned */
-                double gap_lb = 4 * R * R - (M_PI * R / 2 * W + M_PI * W * W / 4);
-                if (add_rev && gap_lb > 0.1 && nt >= 2) {
+                /* gap.area > 0.1 (MLP:1070): certain from the lower bound 4R^2 - (pi R W/2 + pi W^2/4), else from the gap's own area
+                 * (orc_corner_gap_decision); a decision GEOS' polygonal buffer leaves open fails the field (unsupported) */
+                int gap_yes = add_rev ? orc_corner_gap_decision(R, W) : 0;
+                if (add_rev && gap_yes < 0) { free(tb); free(pb.xy); free(pb.v); free(pb.fs); return -3; }
+                if (add_rev && gap_yes > 0 && nt >= 2) {
                     double rl;
                     int64_t nr = orc_reverse_path(tb + 2 * (nt - 1), tb + 2 * (nt - 2), L, H, R, ds, &rl, NULL);
                     double *rb = (double *)malloc((size_t)nr * 2 * sizeof(double));

@@ -121,6 +121,7 @@ void orc_cac_point(double x0, double y0, double th0, double dth, double Re, doub
                    double *out_xy);
 double orc_cac_fit_radius(double dth, double R, double f, int fit);
 int orc_point_in_polygon(double px, double py, const double *poly_xy, int64_t nv);  /* even-odd */
+int orc_corner_gap_decision(double R, double W);   /* MLP:1070 `gap.area > 0.1`: 1 / 0 / -1 (undecidable without GEOS) */
 int orc_outside_polygon(double px, double py, const double *poly_xy, int64_t nv, double tol);  /* fcpp_validate's geofence rule (build-defined) */
 int orc_outside_convex(double px, double py, const double *vx, const double *vy, int nv, double tol);
 

@@ -179,3 +179,22 @@ def test_planner_constructor_surface(golden_plans):
     assert pp.field_shape == 'parallelogram'
     assert np.allclose([pp.field_length, pp.field_width], g['verts_para_75/field_LH'])
     assert abs(pp.field_polygon.area - 400 * 160) < 1e-6
+
+
+def test_corner_gap_decision_where_the_lower_bound_does_not_decide():
+    """`gap.area > 0.1` (MLP:1070) for wide implements on a tight radius (W >~ 1.6 R), where the analytic lower bound of the gap is negative:
+    decided from the gap's own area -- the library integrates it column by column, the oracle bounds it rigorously on a grid, both against
+    what GEOS' polygonal buffer can differ by -- and refused (FCPP_EUNSUPPORTED) only in the narrow band where that difference decides."""
+    spec = E.FieldSpec(field_length=600.0, field_width=400.0)
+    seen = set()
+    for W, R in ((6.0, 3.0), (7.8, 3.0), (8.4, 3.0), (10.0, 3.0), (24.0, 8.0), (12.0, 8.0), (4.0, 2.2), (3.2, 8.0)):
+        info = E.plan_count([spec], E.make_vehicle(working_width=W, min_turn_radius=R), E.make_options())[0]
+        rc, p = orc.plan_field(orc.make_field(L=600.0, H=400.0), orc.Vehicle.make(np.array([W, R, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85])), orc.Options.make())
+        assert info.status == rc == 0, (W, R)
+        assert list(info.n_reverse) == p.n_reverse and (info.n_main, info.n_head) == (p.n_main, p.n_head), (W, R)
+        seen.add(info.n_reverse[1] > 0)
+    assert seen == {True, False}
+    # inside the band the field is refused, by both
+    info = E.plan_count([spec], E.make_vehicle(working_width=8.06, min_turn_radius=3.0), E.make_options())[0]
+    rc, _ = orc.plan_field(orc.make_field(L=600.0, H=400.0), orc.Vehicle.make(np.array([8.06, 3.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85])), orc.Options.make())
+    assert info.status == L.EUNSUPPORTED and rc == L.EUNSUPPORTED
