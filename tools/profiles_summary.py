@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_r03/<config>/ (tools/collect_profiles.sh) -> profiles/: per configuration
-    r03_<config>_kernel_stats.csv : the rocprofv3 --kernel-trace --stats summary rows of the fcpp kernels (calls, total / average ns)
-    r03_<config>_counters.csv     : per kernel and counter, the mean value per launch (WRITE_SIZE, FETCH_SIZE, SQ_*)
+"""gpurun_out/prof_<round>/<config>/ (tools/collect_profiles.sh) -> profiles/: per configuration
+    <round>_<config>_kernel_stats.csv : the rocprofv3 --kernel-trace --stats summary rows of the fcpp kernels (calls, total / average ns)
+    <round>_<config>_counters.csv     : per kernel and counter, the mean value per launch (WRITE_SIZE, FETCH_SIZE, SQ_*)
 and profiles/traffic.json: HBM bytes per launch = WRITE_SIZE KiB x 1024 + 2 x FETCH_SIZE KiB x 1024 (the gfx950 FETCH_SIZE correction
 of MI355X_MICROARCH.md, section HBM), keyed '<bench stage name>|<config>' as bench.py looks it up."""
 import collections
@@ -27,7 +27,7 @@ def stage_of(kernel):
 
 
 def short(name):
-    return name.split('(')[0].replace('void ', '').replace('fcpp::', '').strip()
+    return name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('fcpp::', '').strip()
 
 
 traffic = {}
@@ -81,7 +81,7 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
                 notes[key] = {'kernel': k, 'WRITE_SIZE_KB_per_launch': wkb, 'FETCH_SIZE_KB_per_launch': fkb}
     print(cfg, 'stats' if stats else 'NO stats', len(acc), 'counter rows')
 traffic['_notes'] = {
-    'source': 'rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, separate passes, program directly after `--` (tools/collect_profiles.sh), round 3',
+    'source': 'rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, separate passes, program directly after `--` (tools/collect_profiles.sh), ' + ROUND,
     'units': 'bytes per kernel launch = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md section HBM)',
     'detail': notes}
 json.dump(traffic, open(os.path.join(DST, 'traffic.json'), 'w'), indent=1)
