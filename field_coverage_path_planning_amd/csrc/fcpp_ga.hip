@@ -124,44 +124,91 @@ __device__ __forceinline__ int wave_argmax(double f, int idx, double &wf)
 // one wavefront, one pair of offspring.  lds: 4 n genes + n presence bytes + 128 candidate indices of this wavefront, s_w: two ints of it
 __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s_w, int n, int pop, const double *__restrict__ D,
                                         const int32_t *__restrict__ cur, const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
-                                        double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg, int gen)
+                                        double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg, int gen, int conv)
 {
     int32_t *const P[2] = { lds, lds + n }, *const Cc[2] = { lds + 2 * n, lds + 3 * n };
     unsigned char *const present = reinterpret_cast<unsigned char *>(lds + 4 * n);
     const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
-    // The two tournaments (GA:189-194): k distinct candidates each, the FIRST maximum wins (np.argmax).  Lanes 0 and 1 draw the
-    // candidates (the stream of draws and the rejection of repeats are sequential) into LDS -- a per-lane array indexed at run time
-    // would live in scratch memory, a memory round trip per look-up -- then ALL lanes fetch the candidates' fitness at once and
-    // the winner is the first lane that holds the maximum.
-    int32_t *const s_cand = lds + GA_PAIR_LDS_HEAD(n);          // 2 x 64 candidate indices of this wavefront
-    if (lane < 2) {
-        int nc = 0;
-        U4 blk = { { 0, 0, 0, 0 } };
-        for (uint32_t j = 0; nc < cfg.tournament_size; ++j) {
-            if ((j & 3u) == 0u) blk = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(1 + lane), j >> 2, k0, k1);
-            const uint32_t word = (j & 3u) == 0u ? blk.w[0] : ((j & 3u) == 1u ? blk.w[1] : ((j & 3u) == 2u ? blk.w[2] : blk.w[3]));
-            const int c = (int)(word % (uint32_t)pop);
-            bool dup = false;
-            for (int q = 0; q < nc; ++q) dup |= s_cand[64 * lane + q] == c;
-            if (!dup) { s_cand[64 * lane + nc] = c; ++nc; }
+    // The two tournaments (GA:189-194): k distinct candidates each, the FIRST maximum wins (np.argmax).
+    // Fast path (k <= 8): every random number of the pair comes from ONE Philox evaluation of the wavefront -- lanes 0-15 the first 16
+    // draws of tournament 1 (draw j = word j & 3 of block j >> 2 of its stream), lanes 16-31 those of tournament 2, lanes 32 / 33 / 34
+    // the crossover's block and the two mutations' -- instead of five evaluations one after the other.  A draw is a candidate unless an
+    // EARLIER draw of its tournament has the same value (which is what the sequential rejection of repeats amounts to), the first k of them
+    // play; the candidates' fitness is fetched by their own lanes, and the winner is the first lane holding the maximum.  Fewer than k
+    // distinct values among 16 draws (tiny populations): the sequential path below.
+    int w0 = -1, w1 = -1;
+    U4 X = { { 0, 0, 0, 0 } }, M = { { 0, 0, 0, 0 } };
+    bool fast = cfg.tournament_size <= 8;
+    if (fast) {
+        const int k = cfg.tournament_size, grp = lane >> 4, j = lane & 15;
+        const U4 blk = philox((uint32_t)gen, (uint32_t)pair, grp == 0 ? 1u : (grp == 1 ? 2u : 3u + (uint32_t)j), grp < 2 ? (uint32_t)(j >> 2) : 0u, k0, k1);
+        const uint32_t word = (j & 3) == 0 ? blk.w[0] : ((j & 3) == 1 ? blk.w[1] : ((j & 3) == 2 ? blk.w[2] : blk.w[3]));
+        const int c = (int)(word % (uint32_t)pop);
+        bool dup = false;
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            const int v0 = __builtin_amdgcn_readlane(c, i), v1 = __builtin_amdgcn_readlane(c, 16 + i);
+            dup |= j > i && c == (grp == 0 ? v0 : v1);
+        }
+        const bool first = grp < 2 && !dup;
+        const unsigned long long fm = __ballot(first);
+        const unsigned g0 = (unsigned)(fm & 0xffffull), g1 = (unsigned)((fm >> 16) & 0xffffull);
+        if (__popc(g0) >= k && __popc(g1) >= k) {
+            const unsigned mine = grp == 0 ? g0 : g1;
+            const bool sel = first && __popc(mine & ((1u << j) - 1u)) < k;
+            const double f = sel ? cur_fit[c] : 0.0;                 // (both tournaments' loads in flight together)
+            double m0, m1;
+            (void)wave_argmax(f, (sel && grp == 0) ? lane : -1, m0);  // (only the maximum is used: the FIRST lane holding it wins)
+            (void)wave_argmax(f, (sel && grp == 1) ? lane : -1, m1);
+            const unsigned long long b0 = __ballot(sel && grp == 0 && f == m0), b1 = __ballot(sel && grp == 1 && f == m1);
+            w0 = __builtin_amdgcn_readlane(c, (int)__ffsll((long long)b0) - 1);
+            w1 = __builtin_amdgcn_readlane(c, (int)__ffsll((long long)b1) - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                X.w[q] = (uint32_t)__builtin_amdgcn_readlane((int)blk.w[q], 32);
+                const uint32_t ma = (uint32_t)__builtin_amdgcn_readlane((int)blk.w[q], 33), mb = (uint32_t)__builtin_amdgcn_readlane((int)blk.w[q], 34);
+                M.w[q] = lane == 0 ? ma : mb;
+            }
+        } else {
+            fast = false;
         }
     }
-    wsync();
-    {
-        const int k = cfg.tournament_size;
-        const int c0 = lane < k ? s_cand[lane] : -1, c1 = lane < k ? s_cand[64 + lane] : -1;
-        const double f0 = c0 >= 0 ? cur_fit[c0] : 0.0, f1 = c1 >= 0 ? cur_fit[c1] : 0.0;      // (both tournaments' loads in flight together)
-        double m0, m1;
-        (void)wave_argmax(f0, c0 >= 0 ? lane : -1, m0);          // (only the maximum is used: the FIRST lane holding it wins)
-        (void)wave_argmax(f1, c1 >= 0 ? lane : -1, m1);
-        const unsigned long long b0 = __ballot(c0 >= 0 && f0 == m0), b1 = __ballot(c1 >= 0 && f1 == m1);
-        if (lane == 0) { s_w[0] = s_cand[__ffsll((long long)b0) - 1]; s_w[1] = s_cand[64 + __ffsll((long long)b1) - 1]; }
+    if (!fast) {
+        // Lanes 0 and 1 draw the candidates (the stream of draws and the rejection of repeats are sequential) into LDS -- a per-lane
+        // array indexed at run time would live in scratch memory, a memory round trip per look-up -- then ALL lanes fetch the candidates'
+        // fitness at once.
+        int32_t *const s_cand = lds + GA_PAIR_LDS_HEAD(n);          // 2 x 64 candidate indices of this wavefront
+        if (lane < 2) {
+            int nc = 0;
+            U4 blk = { { 0, 0, 0, 0 } };
+            for (uint32_t j = 0; nc < cfg.tournament_size; ++j) {
+                if ((j & 3u) == 0u) blk = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(1 + lane), j >> 2, k0, k1);
+                const uint32_t word = (j & 3u) == 0u ? blk.w[0] : ((j & 3u) == 1u ? blk.w[1] : ((j & 3u) == 2u ? blk.w[2] : blk.w[3]));
+                const int c = (int)(word % (uint32_t)pop);
+                bool dup = false;
+                for (int q = 0; q < nc; ++q) dup |= s_cand[64 * lane + q] == c;
+                if (!dup) { s_cand[64 * lane + nc] = c; ++nc; }
+            }
+        }
+        wsync();
+        {
+            const int k = cfg.tournament_size;
+            const int c0 = lane < k ? s_cand[lane] : -1, c1 = lane < k ? s_cand[64 + lane] : -1;
+            const double f0 = c0 >= 0 ? cur_fit[c0] : 0.0, f1 = c1 >= 0 ? cur_fit[c1] : 0.0;      // (both tournaments' loads in flight together)
+            double m0, m1;
+            (void)wave_argmax(f0, c0 >= 0 ? lane : -1, m0);
+            (void)wave_argmax(f1, c1 >= 0 ? lane : -1, m1);
+            const unsigned long long b0 = __ballot(c0 >= 0 && f0 == m0), b1 = __ballot(c1 >= 0 && f1 == m1);
+            if (lane == 0) { s_w[0] = s_cand[__ffsll((long long)b0) - 1]; s_w[1] = s_cand[64 + __ffsll((long long)b1) - 1]; }
+        }
+        wsync();
+        w0 = __builtin_amdgcn_readfirstlane(s_w[0]); w1 = __builtin_amdgcn_readfirstlane(s_w[1]);
+        X = philox((uint32_t)gen, (uint32_t)pair, 3u, 0u, k0, k1);
+        if (lane < 2) M = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(4 + lane), 0u, k0, k1);
     }
-    wsync();
-    const int32_t *p1g = cur + (int64_t)s_w[0] * n, *p2g = cur + (int64_t)s_w[1] * n;
+    const int32_t *p1g = cur + (int64_t)w0 * n, *p2g = cur + (int64_t)w1 * n;
     for (int i = lane; i < n; i += 64) { P[0][i] = p1g[i]; P[1][i] = p2g[i]; }
     wsync();
-    const U4 X = philox((uint32_t)gen, (uint32_t)pair, 3u, 0u, k0, k1);
     if (unit(X.w[0], X.w[1]) < cfg.crossover_rate) {      // GA:207
         int i, j;
         two_positions(X.w[2], X.w[3], n, i, j);
@@ -173,7 +220,6 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
         wsync();
     }
     if (lane < 2) {      // GA:246-250
-        const U4 M = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(4 + lane), 0u, k0, k1);
         if (unit(M.w[0], M.w[1]) < cfg.mutation_rate) {
             int i, j;
             two_positions(M.w[2], M.w[3], n, i, j);
@@ -198,28 +244,36 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
                 dd[c][b] = (rowok[c] && k < n) ? D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]] : 0.0;
             }
         }
+        if (conv) return;                  // (the run has converged: nothing is written)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (!rowok[c]) continue;
-            const int row = 2 * pair + c;
-            const int32_t *ch = Cc[c];
-            for (int i = lane; i < n; i += 64) nxt[(int64_t)row * n + i] = ch[i];
-            double total = 0.0;
+        for (int c = 0; c < 2; ++c)
+            if (rowok[c]) for (int i = lane; i < n; i += 64) nxt[(int64_t)(2 * pair + c) * n + i] = Cc[c][i];
+        // (the two children's sums are independent chains of dependent additions: interleaved, each hides the other's latency)
+        double total[2] = { 0.0, 0.0 };
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int m = min(64, n - 64 * b);
-                const int dh = __double2hiint(dd[c][b]), dl = __double2loint(dd[c][b]);
-                if (m == 64) {              // a full chunk: 64 constant lane indices, no loop bookkeeping between the dependent additions
+        for (int b = 0; b < 4; ++b) {
+            const int m = min(64, n - 64 * b);
+            const int dh0 = __double2hiint(dd[0][b]), dl0 = __double2loint(dd[0][b]), dh1 = __double2hiint(dd[1][b]), dl1 = __double2loint(dd[1][b]);
+            if (m == 64) {              // a full chunk: 64 constant lane indices, no loop bookkeeping between the dependent additions
 #pragma unroll
-                    for (int l = 0; l < 64; ++l) total += __hiloint2double(__builtin_amdgcn_readlane(dh, l), __builtin_amdgcn_readlane(dl, l));
-                } else {
-                    for (int l = 0; l < m; ++l) total += __hiloint2double(__builtin_amdgcn_readlane(dh, l), __builtin_amdgcn_readlane(dl, l));
+                for (int l = 0; l < 64; ++l) {
+                    total[0] += __hiloint2double(__builtin_amdgcn_readlane(dh0, l), __builtin_amdgcn_readlane(dl0, l));
+                    total[1] += __hiloint2double(__builtin_amdgcn_readlane(dh1, l), __builtin_amdgcn_readlane(dl1, l));
+                }
+            } else {
+                for (int l = 0; l < m; ++l) {
+                    total[0] += __hiloint2double(__builtin_amdgcn_readlane(dh0, l), __builtin_amdgcn_readlane(dl0, l));
+                    total[1] += __hiloint2double(__builtin_amdgcn_readlane(dh1, l), __builtin_amdgcn_readlane(dl1, l));
                 }
             }
-            if (lane == 0) { nxt_dist[row] = total; nxt_fit[row] = 1.0 / (total + 1e-6); }
+        }
+        if (lane < 2 && (lane == 0 ? rowok[0] : rowok[1])) {
+            const double t = lane == 0 ? total[0] : total[1];
+            nxt_dist[2 * pair + lane] = t; nxt_fit[2 * pair + lane] = 1.0 / (t + 1e-6);
         }
         return;
     }
+    if (conv) return;
     for (int c = 0; c < 2; ++c) {
         const int row = 2 * pair + c;
         if (!rowok[c]) continue;
@@ -245,8 +299,9 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
 {
     extern __shared__ int32_t lds[];                    // 4 n genes + n presence bytes (sized by the launcher: small tours -> many waves per CU)
     __shared__ int s_w[2];
-    if (state->converged) return;
-    ga_pair(threadIdx.x, blockIdx.x, lds, s_w, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen);
+    // (the flag is asked for first and looked at last, before anything is written: its round trip runs beside the pair's own loads)
+    const int conv = __atomic_load_n(&state->converged, __ATOMIC_RELAXED);
+    ga_pair(threadIdx.x, blockIdx.x, lds, s_w, n, pop, D, cur, cur_fit, nxt, nxt_fit, nxt_dist, cfg, gen, conv);
 }
 
 static constexpr int GA_LDS_POP = 6144;      // 48 KiB of fitness values cached in LDS
@@ -272,12 +327,16 @@ __device__ __forceinline__ void block_best(double &f, int &i, double *s_f, int *
     for (int w = 1; w < SW; ++w) if (better(s_f[w], s_i[w], f, i)) { f = s_f[w]; i = s_i[w]; }
 }
 
-// one workgroup of SB threads.  s_fit: pop doubles of LDS when pop <= GA_LDS_POP
+// one workgroup of SB threads.  s_fit: pop doubles of LDS when pop <= GA_LDS_POP.  ROLE 0: statistics and best-so-far bookkeeping, then
+// the elites (one workgroup does both: k_ga_stats_elite); 1: the bookkeeping alone; 2: the elites alone -- the two are independent chains
+// over the same fitness values (the elites of a generation in which convergence is found go, like its children, to the buffer that is
+// not the result), so k_ga_generation gives each a workgroup of its own and a generation costs the longer one, not their sum.
+template <int ROLE>
 __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, const int32_t *__restrict__ cur, const double *__restrict__ cur_fit,
                                                const double *__restrict__ cur_dist, int32_t *__restrict__ nxt,
                                                double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg,
                                                int gen, GaState *__restrict__ state, int32_t *__restrict__ best_route,
-                                               double *__restrict__ hist)
+                                               double *__restrict__ hist, int conv)
 {
     __shared__ double s_f[SW], s_sum[SB];
     __shared__ int s_i[SW], s_pick[64];
@@ -290,10 +349,15 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
     int bi = 0x7fffffff;
     for (int i = tid; i < pop; i += SB) {
         const double f = cur_fit[i];
-        if (cached) s_fit[i] = f;
+        if (cached && ROLE != 1) s_fit[i] = f;
         acc += f;
         if (f > bf || (f == bf && i < bi)) { bf = f; bi = i; }
     }
+    if (ROLE == 2) {
+        if (gen + 1 >= cfg.max_generations) return;
+        __syncthreads();                  // the fitness values are in LDS
+    }
+    if (ROLE != 2) {
     s_sum[tid] = acc;
     __syncthreads();
     for (int o = SB / 2; o >= 64; o >>= 1) {
@@ -326,7 +390,8 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
     __syncthreads();
     if (s_copy >= 0)
         for (int k = tid; k < n; k += SB) best_route[k] = cur[(int64_t)s_copy * n + k];
-    if (s_stop || gen + 1 >= cfg.max_generations) return;
+    if (ROLE == 1 || s_stop || gen + 1 >= cfg.max_generations) return;
+    }
     // elites of this population for the next generation (GA:254-268): the t-th best in the order (fitness, index) goes to row
     // pop - 1 - t.
     auto better = [](double af, int ai, double cf, int ci) { return ai >= 0 && (ci < 0 || af > cf || (af == cf && ai > ci)); };
@@ -395,6 +460,7 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
             }
             if (!__syncthreads_or(deeper)) break;
         }
+        if (conv) return;
         for (int q = tid; q < E * n; q += SB) {
             const int t = q / n, k = q - t * n;
             nxt[(int64_t)(pop - 1 - t) * n + k] = cur[(int64_t)s_pick[t] * n + k];
@@ -420,6 +486,7 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
             if (tid == 0) s_pick[t - t0] = idx;
         }
         __syncthreads();
+        if (conv) return;
         for (int q = tid; q < nt * n; q += SB) {
             const int t = q / n, k = q - t * n;
             nxt[(int64_t)(pop - 1 - (t0 + t)) * n + k] = cur[(int64_t)s_pick[t] * n + k];
@@ -437,11 +504,11 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
 {
     extern __shared__ double s_fit_dyn[];  // the population's fitness, read once (pop <= GA_LDS_POP; otherwise re-read from global)
     if (state->converged) return;
-    ga_stats_elite(s_fit_dyn, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen, state, best_route, hist);
+    ga_stats_elite<0>(s_fit_dyn, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen, state, best_route, hist, 0);
 }
 
 // One generation in ONE launch (small tours): population `cur` -> its statistics and best-so-far bookkeeping (generation index
-// gen - 1, the last workgroup), its elites into the last rows of `nxt` (the same workgroup), and its children into the other rows
+// gen - 1, workgroup 0), its elites into the last rows of `nxt` (workgroup 1), and its children into the other rows
 // (generation index gen; GA_PAIRS_PER_WG wavefronts = pairs per workgroup).  The two roles read the same population and write
 // disjoint rows, so they need no order between them; a generation then costs the longer role, not the sum of two launches.
 // stats_gen == -2: no bookkeeping role (never used); pairs_gen < 0: no children (the final population's statistics).
@@ -454,16 +521,23 @@ __global__ __launch_bounds__(SB) void k_ga_generation(int n, int pop, const doub
 {
     extern __shared__ double dyn_lds[];
     __shared__ int s_w[GA_PAIRS_PER_WG][2];
-    if (state->converged) return;           // (the children of the generation in which convergence is found go to the buffer that is not the result)
-    if (blockIdx.x == gridDim.x - 1) {
-        ga_stats_elite(dyn_lds, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen - 1, state, best_route, hist);
+    // (the children of the generation in which convergence is found go to the buffer that is not the result; the pairs and the elites
+    // ask for the flag first and look at it last, before anything is written: its round trip runs beside their own loads)
+    const int conv = __atomic_load_n(&state->converged, __ATOMIC_RELAXED);
+    if (blockIdx.x == 0) {
+        if (conv) return;
+        ga_stats_elite<1>(dyn_lds, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen - 1, state, best_route, hist, 0);
+        return;
+    }
+    if (blockIdx.x == 1) {
+        ga_stats_elite<2>(dyn_lds, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen - 1, state, best_route, hist, conv);
         return;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * GA_PAIRS_PER_WG + wave;
+    const int pair = (blockIdx.x - 2) * GA_PAIRS_PER_WG + wave;
     if (wave >= GA_PAIRS_PER_WG || pair >= pop / 2 || gen >= cfg.max_generations) return;
     ga_pair(lane, pair, reinterpret_cast<int32_t *>(dyn_lds) + (size_t)wave * pair_lds_ints, s_w[wave], n, pop, D, cur, cur_fit, nxt, nxt_fit,
-            nxt_dist, cfg, gen);
+            nxt_dist, cfg, gen, conv);
 }
 
 // precondition of fcpp_ga_evolve: every row of `routes` is a permutation of 0 .. n-1.  One wavefront per chromosome marks its genes
@@ -534,7 +608,7 @@ int launch_ga_generation(hipStream_t st, int n, int pop, const double *D, const 
 {
     const size_t pl = ga_pair_lds_ints(n);
     const size_t lds = std::max(pl * sizeof(int32_t) * GA_PAIRS_PER_WG, (size_t)pop * sizeof(double));
-    const unsigned blocks = (unsigned)((pop / 2 + GA_PAIRS_PER_WG - 1) / GA_PAIRS_PER_WG) + 1u;
+    const unsigned blocks = (unsigned)((pop / 2 + GA_PAIRS_PER_WG - 1) / GA_PAIRS_PER_WG) + 2u;
     hipLaunchKernelGGL(k_ga_generation, dim3(blocks), dim3(SB), lds, st, n, pop, D, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen,
                        (int)pl, state, best_route, hist);
     hipError_t e = hipGetLastError();
