@@ -53,32 +53,32 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// child = keep[a:b] in place, the other positions from b on (wrapping) take donor's genes in the order they appear from
-// position b on, skipping the genes already present (GA:225-237)
-__device__ __forceinline__ void ox_child(const int32_t *keep, const int32_t *donor, int n, int a, int b, int32_t *child,
-                                         unsigned char *present, int lane)
+// Order crossover of both children at once (GA:225-237): child c keeps parent c's genes [a, b) in place; its other positions, from b on
+// (wrapping), take the OTHER parent's genes in the order they appear from position b on, skipping the genes already present.  The two
+// children are independent: done side by side, each LDS round trip serves both.  pres0 / pres1: n zero bytes each on entry.
+__device__ __forceinline__ void ox_children(const int32_t *P0, const int32_t *P1, int n, int a, int b, int32_t *C0, int32_t *C1,
+                                            unsigned char *pres0, unsigned char *pres1, int lane)
 {
-    for (int g = lane; g < n; g += 64) present[g] = 0;
+    for (int i = a + lane; i < b; i += 64) {
+        const int32_t g0 = P0[i], g1 = P1[i];
+        C0[i] = g0; pres0[g0] = 1; C1[i] = g1; pres1[g1] = 1;
+    }
     wsync();
-    for (int i = a + lane; i < b; i += 64) { const int32_t g = keep[i]; child[i] = g; present[g] = 1; }
-    wsync();
-    int base = 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int base0 = 0, base1 = 0;
     for (int q0 = 0; q0 < n; q0 += 64) {
         const int q = q0 + lane;
-        int32_t gene = 0;
-        bool fr = false;
+        int32_t e0 = 0, e1 = 0;
+        bool f0 = false, f1 = false;
         if (q < n) {
             int src = b + q; if (src >= n) src -= n;
-            gene = donor[src];
-            fr = !present[gene];
+            e0 = P1[src]; e1 = P0[src];
+            f0 = !pres0[e0]; f1 = !pres1[e1];
         }
-        const unsigned long long m = __ballot(fr);
-        if (fr) {
-            int pos = b + base + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos >= n) pos -= n;
-            child[pos] = gene;
-        }
-        base += __popcll(m);
+        const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+        if (f0) { int pos = b + base0 + __popcll(m0 & below); if (pos >= n) pos -= n; C0[pos] = e0; }
+        if (f1) { int pos = b + base1 + __popcll(m1 & below); if (pos >= n) pos -= n; C1[pos] = e1; }
+        base0 += __popcll(m0); base1 += __popcll(m1);
     }
     wsync();
 }
@@ -119,16 +119,19 @@ __device__ __forceinline__ int wave_argmax(double f, int idx, double &wf)
     return wi;
 }
 
-// int32 words of a wavefront's LDS slice before its 2 x 64 tournament candidates: 4 n genes + n presence bytes, rounded to 16 bytes
-#define GA_PAIR_LDS_HEAD(n) ((((size_t)(n) * 4 * sizeof(int32_t) + (size_t)(((n) + 3) & ~3) + 15) / 16) * 4)
+// int32 words of a wavefront's LDS slice before its 2 x 64 tournament candidates: 4 n genes + 2 n presence bytes (one set per child),
+// rounded to 16 bytes
+#define GA_PAIR_LDS_HEAD(n) ((((size_t)(n) * 4 * sizeof(int32_t) + (size_t)(2 * (n)) + 15) / 16) * 4)
 // one wavefront, one pair of offspring.  lds: 4 n genes + n presence bytes + 128 candidate indices of this wavefront, s_w: two ints of it
 __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s_w, int n, int pop, const double *__restrict__ D,
                                         const int32_t *__restrict__ cur, const double *__restrict__ cur_fit, int32_t *__restrict__ nxt,
                                         double *__restrict__ nxt_fit, double *__restrict__ nxt_dist, const fcpp_ga_config &cfg, int gen, int conv)
 {
     int32_t *const P[2] = { lds, lds + n }, *const Cc[2] = { lds + 2 * n, lds + 3 * n };
-    unsigned char *const present = reinterpret_cast<unsigned char *>(lds + 4 * n);
+    unsigned char *const pres0 = reinterpret_cast<unsigned char *>(lds + 4 * n), *const pres1 = pres0 + n;
     const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
+    // (the crossover's presence marks are cleared now, long before they are needed; the slice is a multiple of 16 bytes)
+    for (int w = lane; w < (2 * n + 3) / 4; w += 64) lds[4 * n + w] = 0;
     // The two tournaments (GA:189-194): k distinct candidates each, the FIRST maximum wins (np.argmax).
     // Fast path (k <= 8): every random number of the pair comes from ONE Philox evaluation of the wavefront -- lanes 0-15 the first 16
     // draws of tournament 1 (draw j = word j & 3 of block j >> 2 of its stream), lanes 16-31 those of tournament 2, lanes 32 / 33 / 34
@@ -213,8 +216,7 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
         int i, j;
         two_positions(X.w[2], X.w[3], n, i, j);
         const int a = min(i, j), b = max(i, j);
-        ox_child(P[0], P[1], n, a, b, Cc[0], present, lane);
-        ox_child(P[1], P[0], n, a, b, Cc[1], present, lane);
+        ox_children(P[0], P[1], n, a, b, Cc[0], Cc[1], pres0, pres1, lane);
     } else {
         for (int i = lane; i < n; i += 64) { Cc[0][i] = P[0][i]; Cc[1][i] = P[1][i]; }
         wsync();
@@ -227,12 +229,28 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
         }
     }
     wsync();
-    // the children's rows and tour lengths (GA:174-181).  The matrix entries of BOTH children are asked for first (tours of up to
-    // 256 nodes: four loads in flight instead of four round trips one after the other), then each child's terms are added left to
-    // right, as the reference's loop adds them: lane l's term through v_readlane (a scalar lane index: no trip through the LDS
-    // crossbar, whose latency the dependent additions would pay one after the other).
+    // The children's rows and tour lengths (GA:174-181).  The matrix entries of BOTH children are asked for first (tours of up to 256
+    // nodes: eight loads in flight instead of eight round trips), the rows are stored, and the terms go to LDS -- over the parents' and
+    // children's genes, which nobody needs any more -- where lane c adds child c's terms left to right, as the reference's loop adds
+    // them: one LDS read and one addition per term, both children by the same instructions.  (Handing lane l's term to the sum through
+    // v_readlane cost four instructions per term and child: 55 cycles per step of the two chains, 3.3 of a generation's 15 us.)
     const int nchunk = (n + 63) >> 6;
     const bool rowok[2] = { 2 * pair < pop - cfg.elite_size, 2 * pair + 1 < pop - cfg.elite_size };     // an elite takes the other rows (GA:266)
+    double *const S = reinterpret_cast<double *>(lds);             // 2 n doubles = the 4 n gene words
+    auto sum_left_to_right = [&](const double *t, int m) -> double {
+        double total = 0.0;
+        int l = 0;
+        for (; l + 16 <= m; l += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = t[l + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) total += v[u];
+        }
+        for (; l < m; ++l) total += t[l];
+        return total;
+    };
+    if (conv) return;                      // (the run has converged: nothing is written)
     if (nchunk <= 4) {
         double dd[2][4];
 #pragma unroll
@@ -244,51 +262,39 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
                 dd[c][b] = (rowok[c] && k < n) ? D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]] : 0.0;
             }
         }
-        if (conv) return;                  // (the run has converged: nothing is written)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
             if (rowok[c]) for (int i = lane; i < n; i += 64) nxt[(int64_t)(2 * pair + c) * n + i] = Cc[c][i];
-        // (the two children's sums are independent chains of dependent additions: interleaved, each hides the other's latency)
-        double total[2] = { 0.0, 0.0 };
+        wsync();                           // every lane has read its genes
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int m = min(64, n - 64 * b);
-            const int dh0 = __double2hiint(dd[0][b]), dl0 = __double2loint(dd[0][b]), dh1 = __double2hiint(dd[1][b]), dl1 = __double2loint(dd[1][b]);
-            if (m == 64) {              // a full chunk: 64 constant lane indices, no loop bookkeeping between the dependent additions
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int l = 0; l < 64; ++l) {
-                    total[0] += __hiloint2double(__builtin_amdgcn_readlane(dh0, l), __builtin_amdgcn_readlane(dl0, l));
-                    total[1] += __hiloint2double(__builtin_amdgcn_readlane(dh1, l), __builtin_amdgcn_readlane(dl1, l));
-                }
-            } else {
-                for (int l = 0; l < m; ++l) {
-                    total[0] += __hiloint2double(__builtin_amdgcn_readlane(dh0, l), __builtin_amdgcn_readlane(dl0, l));
-                    total[1] += __hiloint2double(__builtin_amdgcn_readlane(dh1, l), __builtin_amdgcn_readlane(dl1, l));
-                }
-            }
-        }
+            for (int b = 0; b < 4; ++b) { const int k = 64 * b + lane; if (k < n) S[c * n + k] = dd[c][b]; }
+        wsync();
         if (lane < 2 && (lane == 0 ? rowok[0] : rowok[1])) {
-            const double t = lane == 0 ? total[0] : total[1];
+            const double t = sum_left_to_right(S + lane * n, n);
             nxt_dist[2 * pair + lane] = t; nxt_fit[2 * pair + lane] = 1.0 / (t + 1e-6);
         }
         return;
     }
-    if (conv) return;
+    // long tours: child 0's terms go over the parents' genes, child 1's over them again once child 0's sum is taken (its terms would lie
+    // over the children's genes, which its own look-ups still read)
     for (int c = 0; c < 2; ++c) {
         const int row = 2 * pair + c;
         if (!rowok[c]) continue;
         const int32_t *ch = Cc[c];
         for (int i = lane; i < n; i += 64) nxt[(int64_t)row * n + i] = ch[i];
-        double total = 0.0;
+        double *const T = reinterpret_cast<double *>(lds);         // n doubles = P[0] | P[1]
         for (int base = 0; base < n; base += 64) {
             const int k = base + lane;
-            double d = 0.0;
-            if (k < n) d = D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]];
-            const int m = min(64, n - base);
-            for (int l = 0; l < m; ++l)
-                total += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), l), __builtin_amdgcn_readlane(__double2loint(d), l));
+            if (k < n) T[k] = D[(int64_t)ch[k] * n + ch[k + 1 == n ? 0 : k + 1]];
         }
-        if (lane == 0) { nxt_dist[row] = total; nxt_fit[row] = 1.0 / (total + 1e-6); }
+        wsync();
+        if (lane == 0) {
+            const double t = sum_left_to_right(T, n);
+            nxt_dist[row] = t; nxt_fit[row] = 1.0 / (t + 1e-6);
+        }
+        wsync();                           // (the sum is taken before the next child's terms overwrite it)
     }
 }
 
