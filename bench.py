@@ -125,7 +125,7 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     2. the timed region: `reps` x K steps bracketed by fence() (barrier + synchronize), median reported, per-kernel HIP events recorded
        inside it on a sample of the steps.
     The output arrays come from Batch.alloc() with its default layout rule ('auto': large batches get the five arrays >= 24 GiB apart
-    inside one allocation, DESIGN.md section 4; reported per entry as output_arrays).  calibrate > 1 (opt-in, reported beside the primary figure, never as it):
+    inside one allocation, DESIGN.md section 2; reported per entry as output_arrays).  calibrate > 1 (opt-in, reported beside the primary figure, never as it):
     Batch.alloc(best_of=calibrate) picks the fastest of `calibrate` further candidate sets under the batch's own step.
     stats_of(i, batch): the stats tensor step i writes (default: the one of alloc()); after_step(i, res): called after step i has
     been enqueued."""
@@ -410,7 +410,7 @@ def main():
     work_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(work_stream)
     # the context's output arena, once, at start-up (context creation in the sense of SURVEY.md 8d: an allocation of this size takes the
-    # driver seconds): every configuration's output arrays come out of it, five lanes 24 GiB apart (DESIGN.md section 4)
+    # driver seconds): every configuration's output arrays come out of it, five lanes 24 GiB apart (DESIGN.md section 2)
     t0 = time.perf_counter()
     arena = None
     try:

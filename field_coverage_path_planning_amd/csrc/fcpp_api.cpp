@@ -396,7 +396,7 @@ int fcpp_free(fcpp_ctx *c, void *p)
     return FCPP_OK;
 }
 
-// ---- output arrays with the placement rule of DESIGN.md section 4 ("where the five arrays lie").  Measured on MI355X: the streaming kernels
+// ---- output arrays with the placement rule of DESIGN.md section 2 (HISTORY.md "Where the five arrays lie").  Measured on MI355X: the streaming kernels
 // write x, y, kappa, v and flagseg side by side, and five write streams that lie within a few GiB of each other in (physical) device
 // memory run at 4.6 TB/s, the same streams >= 12-24 GiB apart at 6.3-6.6 TB/s (tools/placement_pitch.py: the class follows the pitch
 // and nothing else).  The context's ARENA is the remedy that several live batches can share: one allocation made once

@@ -1,4 +1,4 @@
-// fcpp_tiler.cpp -- see fcpp_tiler.h.  The cutting rules are those of DESIGN.md section 4 (pipeline B): quiet zones of straight
+// fcpp_tiler.cpp -- see fcpp_tiler.h.  The cutting rules are those of DESIGN.md section 5 and HISTORY.md (pipeline B): quiet zones of straight
 // primitives, layer-1 spans, wave tiles with host-sized halos, general tiles for the rest.
 #include "fcpp_tiler.h"
 

@@ -38,7 +38,7 @@ class Context:
     def reserve_outputs(self, lane_gib=24.0, pitch_gib=24.0):
         """Give the context its output ARENA (fcpp_ctx_reserve_outputs): one device allocation of 4 x pitch + lane, made once -- it takes
         the driver seconds, so it belongs to start-up, not to a plan call -- in which Batch.alloc() then places the five output arrays of
-        every batch a pitch apart (DESIGN.md section 4: far apart they are written a class faster than back to back).  Any number of live
+        every batch a pitch apart (DESIGN.md section 2: far apart they are written a class faster than back to back).  Any number of live
         batches share it.  Raises when the device has not that much room."""
         L.check(self.lib.fcpp_ctx_reserve_outputs(self.handle, int(lane_gib * 2**30), int(pitch_gib * 2**30)))
 
@@ -410,7 +410,7 @@ class Batch:
 
         layout: where the five arrays lie in device memory.  The hot kernels write them side by side, and on MI355X five write streams
         that lie within a few GiB of each other reach 4.6 TB/s where the same streams 12-24 GiB or more apart reach 6.3-6.6 TB/s
-        (tools/placement_pitch.py: the speed class follows the pitch between the arrays, nothing else).
+        (HISTORY.md; tools/placement_pitch.py: the speed class follows the pitch between the arrays, nothing else).
           'spread': ONE allocation, the arrays L.OUTPUT_PITCH (24 GiB) + their own size apart (less if the device has less room); the gaps
                     belong to the allocation -- a caller that needs them sub-allocates its own slab with the same rule.
           'plain' : five separate tensors, wherever the allocator puts them (usually back to back: the slow class).

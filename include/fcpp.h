@@ -172,7 +172,7 @@ int fcpp_ctx_set_setup(fcpp_ctx *ctx, int mode);
 /* device memory for hosts without their own allocator (torch users pass tensor pointers instead) */
 int fcpp_malloc(fcpp_ctx *ctx, int64_t bytes, void **dev_ptr);
 int fcpp_free(fcpp_ctx *ctx, void *dev_ptr);
-/* Output arrays for fcpp_batch_run, and the placement rule measured on MI355X (DESIGN.md section 4): the hot kernels write x, y, kappa, v
+/* Output arrays for fcpp_batch_run, and the placement rule measured on MI355X (DESIGN.md section 2): the hot kernels write x, y, kappa, v
  * and flagseg side by side, and five write streams within a few GiB of each other in device memory reach 4.6 TB/s where the same streams
  * >= 12-24 GiB apart reach 6.3-6.6 TB/s (small batches -- a few hundred MB of output -- live in the caches and do not care).
  *

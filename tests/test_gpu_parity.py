@@ -686,7 +686,7 @@ def test_standalone_operators_on_ragged_paths():
 
 
 def test_output_layouts_give_the_same_plan():
-    """Batch.alloc(layout=...) and alloc(best_of=K) only choose WHERE the output arrays lie (DESIGN.md section 4: five write streams
+    """Batch.alloc(layout=...) and alloc(best_of=K) only choose WHERE the output arrays lie (DESIGN.md section 2: five write streams
     far apart in device memory run a class faster than the same streams back to back); the plan is the same bit for bit.  Also the C
     ABI's fcpp_outputs_alloc: one allocation, the arrays a pitch apart."""
     import ctypes as C

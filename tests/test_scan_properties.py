@@ -1,4 +1,4 @@
-"""Property tests (hypothesis) of the reformulation the kernels rest on (DESIGN.md section 4, "Sweeps as scans"; SURVEY.md section 4, item 4):
+"""Property tests (hypothesis) of the reformulation the kernels rest on (DESIGN.md section 5, "Sweeps as scans"; SURVEY.md section 4, item 4):
 the reference's two sequential sweeps (MLP:538-589, restated in oracle/fcpp_oracle.c: orc_smooth_speed_profile) equal
     u = min(forward scan of u0, backward scan of u0),   u = (v / 3.6)^2,
 where a point is the map u -> min(c, u + w), w = 2a|dp| (+inf for a skipped step), and maps compose associatively
