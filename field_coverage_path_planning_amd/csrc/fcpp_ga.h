@@ -13,6 +13,9 @@ struct GaState {
     int32_t generations;    // generation + 1 of the last completed generation
     int32_t converged;
     int32_t _pad;
+    // fitness of the last (elite_size-th) elite of the previous generation: elitism carries the elites over, so the elites of the
+    // next population are among its last elite_size rows and the members strictly above this value (0 before the first selection: everybody)
+    double elite_thr;
 };
 
 constexpr int GA_MAX_NODES = 2048;

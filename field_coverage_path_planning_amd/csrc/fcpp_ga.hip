@@ -312,6 +312,7 @@ __global__ __launch_bounds__(64) void k_ga_pairs(int n, int pop, const double *_
 
 static constexpr int GA_LDS_POP = 6144;      // 48 KiB of fitness values cached in LDS
 static constexpr int SB = 1024, SW = SB / 64; // the bookkeeping kernel: one workgroup
+static constexpr int GA_ELITE_CAND = 256;     // candidates the short elite selection ranks
 
 // block-wide reduction of (value, index) pairs with a caller-supplied "a is better than b": shuffles inside the waves, one
 // LDS exchange across them.  Every thread returns the winner.
@@ -350,6 +351,7 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
     const int tid = threadIdx.x;
     const bool cached = pop <= GA_LDS_POP;
     const double *__restrict__ fitv = cached ? s_fit : cur_fit;
+    const double thr_prev = ROLE != 1 ? state->elite_thr : 0.0;      // (asked for first, used after the fitness values have arrived)
     // first argmax (np.argmax, GA:66 / GA:91) and the mean (GA:107) in a fixed order: SB strided partial sums, then a binary tree
     double bf = -1.0, acc = 0.0;
     int bi = 0x7fffffff;
@@ -401,6 +403,52 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
     // elites of this population for the next generation (GA:254-268): the t-th best in the order (fitness, index) goes to row
     // pop - 1 - t.
     auto better = [](double af, int ai, double cf, int ci) { return ai >= 0 && (ci < 0 || af > cf || (af == cf && ai > ci)); };
+    if (cached && cfg.elite_size >= 1 && cfg.elite_size <= 64) {
+        // The short way: the elites of the previous generation were carried over into the last E rows, so E members reach the fitness
+        // of its last elite (thr_prev), and a member that does not exceed it loses to every one of them (equal fitness: the larger
+        // index wins, and theirs are the largest).  The candidates are therefore the last E rows plus the members strictly above
+        // thr_prev -- normally a few children; in a population that has collapsed into copies of one tour, none.  They are gathered in
+        // LDS (in any order: the elitism's order is total), every candidate counts the candidates that precede it, and rank t < E is
+        // pick t.  More than GA_ELITE_CAND candidates (the first selection of a run: thr_prev = 0; many copies of the better elites):
+        // the selection below.
+        __shared__ double q_f[GA_ELITE_CAND];
+        __shared__ int q_i[GA_ELITE_CAND];
+        __shared__ int q_n;
+        const int E = cfg.elite_size;
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+        for (int i = tid; i < pop; i += SB) {
+            const double f = s_fit[i];
+            if (f > thr_prev || i >= pop - E) {
+                const int pos = atomicAdd(&q_n, 1);
+                if (pos < GA_ELITE_CAND) { q_f[pos] = f; q_i[pos] = i; }
+            }
+        }
+        __syncthreads();
+        const int C = q_n;
+        if (C >= E && C <= GA_ELITE_CAND) {
+            if (tid < C) {
+                const double f = q_f[tid];
+                const int i = q_i[tid];
+                int rank = 0;
+                for (int u = 0; u < C; ++u) {
+                    const double uf = q_f[u];
+                    const int ui = q_i[u];
+                    rank += (uf > f || (uf == f && ui > i)) ? 1 : 0;
+                }
+                if (rank < E) s_pick[rank] = i;
+                if (rank == E - 1 && !conv) state->elite_thr = f;
+            }
+            __syncthreads();
+            if (conv) return;
+            for (int q = tid; q < E * n; q += SB) {
+                const int t = q / n, k = q - t * n;
+                nxt[(int64_t)(pop - 1 - t) * n + k] = cur[(int64_t)s_pick[t] * n + k];
+            }
+            if (tid < E) { const int src = s_pick[tid], row = pop - 1 - tid; nxt_fit[row] = fitv[src]; nxt_dist[row] = cur_dist[src]; }
+            return;
+        }
+    }
     if (cached && cfg.elite_size <= 64) {
         // Up to 64 elites, the population in LDS: every wavefront lists the best of ITS 1/16 of the population -- rounds of a wave-wide
         // arg-max, all wavefronts at once -- and the lists are merged by rank.  The global top elite_size are among the per-wave ones, and the order (fitness, then the larger
@@ -467,6 +515,7 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
             if (!__syncthreads_or(deeper)) break;
         }
         if (conv) return;
+        if (tid == 0 && E >= 1) state->elite_thr = fitv[s_pick[E - 1]];
         for (int q = tid; q < E * n; q += SB) {
             const int t = q / n, k = q - t * n;
             nxt[(int64_t)(pop - 1 - t) * n + k] = cur[(int64_t)s_pick[t] * n + k];
