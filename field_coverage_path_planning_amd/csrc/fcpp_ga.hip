@@ -567,7 +567,8 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
 // (generation index gen; GA_PAIRS_PER_WG wavefronts = pairs per workgroup).  The two roles read the same population and write
 // disjoint rows, so they need no order between them; a generation then costs the longer role, not the sum of two launches.
 // stats_gen == -2: no bookkeeping role (never used); pairs_gen < 0: no children (the final population's statistics).
-static constexpr int GA_PAIRS_PER_WG = SB / 64;
+static constexpr int GA_PAIRS_PER_WG = 8;       // of the workgroup's 16 wavefronts (the others leave at once): 2048 pairs = 256 workgroups, one per compute unit, two
+                                                // pair wavefronts per SIMD -- with sixteen pairs per workgroup half the chip idled while four wavefronts shared every SIMD of the other half
 __global__ __launch_bounds__(SB) void k_ga_generation(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
                                                       const double *__restrict__ cur_fit, const double *__restrict__ cur_dist,
                                                       int32_t *__restrict__ nxt, double *__restrict__ nxt_fit, double *__restrict__ nxt_dist,
