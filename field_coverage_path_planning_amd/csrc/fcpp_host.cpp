@@ -166,6 +166,18 @@ int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c
     tt.nu = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(c.len_uturn, ds) : 20, INT32_MAX);
     tt.nc = (int32_t)std::min<int64_t>(ds > 0 ? n_for_length(c.len_corner, ds) : 15, INT32_MAX);
     tt.u_end = c.cloth ? sh_pi.T * c.Re_pi : kPi; tt.u_step = lin_step(0.0, tt.u_end, tt.nu); tt.u_Re = c.Re_pi;
+    // the zone a U-turn occupies beyond the end of its line (the reference's half circle about (max_x, y): 2 R along the line, R above
+    // it; the clothoid turn: its shape's extents, sampled at 257 parameter values as the oracle samples its own)
+    c.uturn_dx = 2.0 * R; c.uturn_h = R;
+    if (c.cloth) {
+        double mx = 0.0, my = 0.0;
+        for (int k = 0; k <= 256; ++k) {
+            double X, Y;
+            cac_unit_point(sh_pi, sh_pi.T * (double)k / 256.0, X, Y);
+            mx = std::max(mx, X); my = std::max(my, Y);
+        }
+        c.uturn_dx = c.Re_pi * my; c.uturn_h = c.Re_pi * mx;
+    }
     tt.c_end = c.cloth ? sh_half.T * c.Re_half : kHalfPi; tt.c_step = lin_step(0.0, tt.c_end, tt.nc); tt.c_Re = c.Re_half;
     return FCPP_OK;
 }
@@ -187,7 +199,7 @@ struct HostSink {
         const fcpp_vehicle &veh = pc.veh;
         const double W = pc.W, R = pc.R, ds = pc.ds;
         const bool cloth = pc.cloth != 0, rotated = fr.rotated != 0;
-        const double rot = fr.rot, ccx = fr.ccx, ccy = fr.ccy, lsx = fr.lsx, lex = fr.lex, min_x = fr.min_x, max_x = fr.max_x, min_y = fr.min_y, max_y = fr.max_y;
+        const double rot = fr.rot, ccx = fr.ccx, ccy = fr.ccy, lsx = fr.lsx, lex = fr.lex, min_y = fr.min_y, max_y = fr.max_y;
         const int64_t P = fr.P, n_turn = fr.n_turn;
         struct Box { double x0, y0, x1, y1; };
         std::vector<Box> boxes;
@@ -243,12 +255,44 @@ struct HostSink {
             pr.a[4] = lin_step(ax, bx, np); pr.a[5] = lin_step(ay, by, np);
             push1(pr);
         };
+        // End zones (round 4).  The turn after a pass starts where its line ends and occupies uturn_dx beyond that end and uturn_h above
+        // the line.  A box that meets the turn's zone, or either line within it, moves the turn inwards until the zone is free (again
+        // if the moved zone meets another box); both passes end / start there, and the strip beyond stays unworked instead of the field
+        // being refused.  clip_lo / clip_hi: every pass's line ends (frame x).  The free ends -- start of the first pass, end of the
+        // last -- are not moved.
+        auto pass_y = [&](int64_t idx) { return min_y + (double)(fr.reverse_order ? (P - 1 - idx) : idx) * W; };
+        auto pass_left = [&](int64_t idx) { return fr.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1); };
+        std::vector<double> clip_lo((size_t)P, lo), clip_hi((size_t)P, hi);
+        if (lsx < lex && !boxes.empty()) {
+            const double DX = pc.uturn_dx, H = pc.uturn_h;
+            for (int64_t idx = 0; idx + 1 < P; ++idx) {
+                const double ya = pass_y(idx), yb = pass_y(idx + 1), ylo = std::min(ya, yb), yhi = std::max(ya + H, yb);
+                const bool right = !pass_left(idx);
+                double x = right ? hi : lo;
+                for (bool moved = true; moved;) {
+                    moved = false;
+                    for (const Box &b : boxes) {
+                        if (!(b.y0 < yhi - 1e-9 && b.y1 > ylo + 1e-9)) continue;
+                        if (right ? (b.x1 > x - 1e-9 && b.x0 < x + DX + 1e-9 && b.x0 - DX - 1e-6 < x)
+                                  : (b.x0 < x + 1e-9 && b.x1 > x - DX - 1e-9 && b.x1 + DX + 1e-6 > x)) {
+                            x = right ? b.x0 - DX - 1e-6 : b.x1 + DX + 1e-6;
+                            moved = true;
+                        }
+                    }
+                }
+                if (right) clip_hi[(size_t)idx] = clip_hi[(size_t)idx + 1] = x;
+                else clip_lo[(size_t)idx] = clip_lo[(size_t)idx + 1] = x;
+            }
+        }
         std::vector<int> blk;
         for (int64_t idx = 0; idx < P && !unsupported; ++idx) {
             const int64_t pi = fr.reverse_order ? (P - 1 - idx) : idx;
             const double y = min_y + (double)pi * W;
             const bool go_left = fr.start_from_right ? ((idx & 1) == 0) : ((idx & 1) == 1);
-            const double xs = go_left ? lex : lsx, xe = go_left ? lsx : lex;
+            const double lo = clip_lo[(size_t)idx], hi = clip_hi[(size_t)idx];       // (this pass's own line)
+            const bool ordered = lsx < lex;                                           // (else: a work area narrower than 2 R, lines as before)
+            if (ordered && !(hi - lo > 1e-9)) { unsupported = true; break; }
+            const double xs = ordered ? (go_left ? hi : lo) : (go_left ? lex : lsx), xe = ordered ? (go_left ? lo : hi) : (go_left ? lsx : lex);
             blk.clear();
             for (size_t k = 0; k < boxes.size(); ++k)
                 if (boxes[k].y0 < y && y < boxes[k].y1 && boxes[k].x1 > lo && boxes[k].x0 < hi) blk.push_back((int)k);
@@ -280,7 +324,9 @@ struct HostSink {
                 pr.kind = PRIM_UTURN; pr.n = (int32_t)n_turn; pr.v_nom = veh.headland_turn_speed_kmh;
                 pr.fs = FCPP_KIND_UTURN | ((uint32_t)pi << FCPP_INDEX_SHIFT);
                 pr.form = (turn_right ? 1 : 0) | (rotated ? 2 : 0) | (cloth ? 4 : 0);
-                pr.a[0] = cloth ? (turn_right ? (max_x - R) : (min_x + R)) : (turn_right ? max_x : min_x);
+                // (the turn starts where the line ends: the field's own end zone, or one moved inwards by a box)
+                const double xt = ordered ? (turn_right ? hi : lo) : (turn_right ? lex : lsx);
+                pr.a[0] = cloth ? xt : (turn_right ? xt + R : xt - R);
                 pr.a[1] = y;
                 pr.a[2] = rc; pr.a[3] = rs; pr.a[4] = ccx; pr.a[5] = ccy;
                 push1(pr);

@@ -168,6 +168,7 @@ struct PlanConsts {
     double W, R, ds;
     int32_t clip, cloth;
     double Re_pi, Re_half, len_uturn, len_corner, gap_lb;
+    double uturn_dx, uturn_h;     // extent of a U-turn beyond its line end along the line / above the line (obstacle-aware swaths: its zone)
     double gap_area;                  // area of the corner gap (MLP:1086-1152) where the lower bound does not decide; else gap_lb
     int32_t gap_decision, _pad0;      // `gap.area > 0.1` (MLP:1070): 1 yes, 0 no, -1 within what GEOS' polygonal buffer leaves open
     double turn_end_pi;               // U-turn: arcs pi, clothoid total length

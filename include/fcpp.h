@@ -84,9 +84,13 @@ enum { FCPP_RING_AS_VERTICES = 0, FCPP_RING_REVERSED = 1 };
  * 0.5 m, at least 2 points per leg).  The legs run on the boundary of their own box and the boxes are disjoint: no leg enters another
  * obstacle.  The side is the closer one (top or bottom) unless it lies outside the y-range of the main work area (the detour would
  * enter the headland), then the other; a box with room on neither side is refused.  Sub-swaths and legs are numpy.linspace runs
- * between their end points in field coordinates; U-turns are unchanged.  A field where a box reaches a swath line's end zone (within
- * 1e-9 of line_start_x / line_end_x) or leaves no side to pass is refused with FCPP_EUNSUPPORTED (its status; the other fields of the
- * batch are planned).  The headland loops are not re-routed. */
+ * between their end points in field coordinates.
+ * End zones (round 4): the turn after a pass starts where its line ends and occupies a zone beyond that end -- the reference's half
+ * circle about (max_x, y): 2 R along the line and R above it; the clothoid turn: the extents of its shape.  A box that meets that zone,
+ * or either of the two lines within it, moves the turn inwards until the zone is free (again if the moved zone meets another box): both
+ * passes end / start there, the U-turn is the same shape translated, and the strip beyond stays unworked.  Only the free ends -- the
+ * start of the first pass, the end of the last -- are not moved: a box there, or one that leaves no side to pass, refuses the field
+ * with FCPP_EUNSUPPORTED (its status; the other fields of the batch are planned).  The headland loops are not re-routed. */
 enum { FCPP_OBSTACLES_FLAG = 0, FCPP_OBSTACLES_AVOID = 1 };
 
 /* ---- one field = one planner instance (ctor arguments, MLP:63-72) ---------------------- */

@@ -779,14 +779,51 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
                     } else ++j;
                 }
         }
-        double lo = lsx < lex ? lsx : lex, hi = lsx < lex ? lex : lsx;
+        double lo0 = lsx < lex ? lsx : lex, hi0 = lsx < lex ? lex : lsx;
         int unsupported = 0;
         double *tb = (double *)malloc((size_t)n_turn * 2 * sizeof(double));
+        /* End zones (round 4): the turn after a pass starts where its line ends and occupies DX beyond that end and H above the line
+         * (the reference's half circle about (max_x, y): 2 R and R; the clothoid turn: the extents of its shape at 257 samples).  A box
+         * that meets the turn's zone, or either line within it, moves the turn inwards until the zone is free (again if the moved zone
+         * meets another box); both passes end / start there.  The free ends (start of the first pass, end of the last) are not moved. */
+        double DX = 2.0 * R, H = R;
+        if (opt->turn_model != 0) {
+            double *sb = (double *)malloc(257 * 2 * sizeof(double));
+            cac_sample(0.0, 0.0, M_PI / 2, -M_PI, R, opt, 257, sb);
+            DX = 0.0; H = 0.0;
+            for (int q = 0; q < 257; ++q) { if (sb[2 * q] > DX) DX = sb[2 * q]; if (sb[2 * q + 1] > H) H = sb[2 * q + 1]; }
+            free(sb);
+        }
+        double *clip_lo = (double *)malloc((size_t)(P > 0 ? P : 1) * 2 * sizeof(double)), *clip_hi = clip_lo + (P > 0 ? P : 1);
+        for (int64_t q = 0; q < P; ++q) { clip_lo[q] = lo0; clip_hi[q] = hi0; }
+        if (lsx < lex && nbox > 0)
+            for (int64_t idx = 0; idx + 1 < P; ++idx) {
+                int64_t ia = reverse_order ? (P - 1 - idx) : idx, ib = reverse_order ? (P - 2 - idx) : idx + 1;
+                double ya = min_y + (double)ia * W, yb = min_y + (double)ib * W, ylo = ya < yb ? ya : yb, yhi = ya + H > yb ? ya + H : yb;
+                int gl = start_from_right ? (idx % 2 == 0) : (idx % 2 == 1), right = !gl;
+                double x = right ? hi0 : lo0;
+                for (int moved = 1; moved;) {
+                    moved = 0;
+                    for (int k = 0; k < nbox; ++k) {
+                        if (!(by0[k] < yhi - 1e-9 && by1[k] > ylo + 1e-9)) continue;
+                        if (right ? (bx1[k] > x - 1e-9 && bx0[k] < x + DX + 1e-9 && bx0[k] - DX - 1e-6 < x)
+                                  : (bx0[k] < x + 1e-9 && bx1[k] > x - DX - 1e-9 && bx1[k] + DX + 1e-6 > x)) {
+                            x = right ? bx0[k] - DX - 1e-6 : bx1[k] + DX + 1e-6;
+                            moved = 1;
+                        }
+                    }
+                }
+                if (right) clip_hi[idx] = clip_hi[idx + 1] = x;
+                else clip_lo[idx] = clip_lo[idx + 1] = x;
+            }
         for (int64_t idx = 0; idx < P && !unsupported; ++idx) {
             int64_t i = reverse_order ? (P - 1 - idx) : idx;
             double y = min_y + (double)i * W;
             int go_left = start_from_right ? (idx % 2 == 0) : (idx % 2 == 1);
-            double xs = go_left ? lex : lsx, xe = go_left ? lsx : lex;
+            int ordered = lsx < lex;
+            double lo = clip_lo[idx], hi = clip_hi[idx];
+            if (ordered && !(hi - lo > 1e-9)) { unsupported = 1; break; }
+            double xs = ordered ? (go_left ? hi : lo) : (go_left ? lex : lsx), xe = ordered ? (go_left ? lo : hi) : (go_left ? lsx : lex);
             uint32_t swath = ORC_KIND_SWATH | ((uint32_t)i << ORC_INDEX_SHIFT), detour = ORC_KIND_DETOUR | ((uint32_t)i << ORC_INDEX_SHIFT);
             /* the boxes this line runs into, in travel order */
             int m = 0;
@@ -843,15 +880,16 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             if (unsupported) break;
             if (idx < P - 1) {
                 int turn_right = !go_left;
-                if (opt->turn_model == 0) arc_uturn(y, turn_right, min_x, max_x, R, n_turn, tb);
-                else if (turn_right) cac_sample(max_x - R, y, M_PI / 2, -M_PI, R, opt, n_turn, tb);
-                else cac_sample(min_x + R, y, M_PI / 2, M_PI, R, opt, n_turn, tb);
+                /* the turn starts where the line ends: the field's own end zone, or one moved inwards by a box */
+                double xt = ordered ? (turn_right ? hi : lo) : (turn_right ? lex : lsx);
+                if (opt->turn_model == 0) arc_uturn(y, turn_right, turn_right ? min_x : xt - R, turn_right ? xt + R : max_x, R, n_turn, tb);
+                else cac_sample(xt, y, M_PI / 2, turn_right ? -M_PI : M_PI, R, opt, n_turn, tb);
                 if (rotated)
                     for (int64_t q = 0; q < n_turn; ++q) orc_rotate_point(tb[2 * q], tb[2 * q + 1], rot, ccx, ccy, tb + 2 * q);
                 pb_push(&pb, tb, n_turn, veh->headland_turn_speed_kmh, ORC_KIND_UTURN | ((uint32_t)i << ORC_INDEX_SHIFT));
             }
         }
-        free(tb); free(ord); free(bx0);
+        free(tb); free(ord); free(bx0); free(clip_lo);
         if (unsupported) { free(pb.xy); free(pb.v); free(pb.fs); return -3; }
     } else {
         double lsx = min_x + R, lex = max_x - R;

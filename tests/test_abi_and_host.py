@@ -113,7 +113,9 @@ def test_plan_count_with_obstacle_aware_swaths_vs_oracle():
     """obstacle_mode = AVOID (include/fcpp.h): the host-side sizing -- sub-swaths, detour legs, U-turns as primitives --
     gives the oracle's point counts, and the same refusals."""
     rect_obs = [[(150.0, 60.0), (170.0, 60.0), (170.0, 80.0), (150.0, 80.0)], [(240.0, 120.0), (262.0, 124.0), (249.0, 141.0)]]
+    # (a box that reaches into the lines' end zone: since round 4 the turns beside it move inwards and the passes end / start there)
     near_end = [[(10.0, 100.0), (30.0, 100.0), (30.0, 120.0), (10.0, 120.0)]]
+    first_end = [[(5.0, 5.0), (30.0, 5.0), (30.0, 25.0), (5.0, 25.0)]]                       # at the FREE end of the first pass: refused
     # (round 2's review: a second obstacle just above the first -- the two grown boxes overlap and are passed as one)
     stacked = [[(240.0, 23.5), (260.0, 23.5), (260.0, 24.4), (240.0, 24.4)], [(245.0, 25.9), (255.0, 25.9), (255.0, 26.4), (245.0, 26.4)]]
     wall = [[(200.0, 5.0), (210.0, 5.0), (210.0, 215.0), (200.0, 215.0)]]                    # no side to pass: refused
@@ -121,7 +123,8 @@ def test_plan_count_with_obstacle_aware_swaths_vs_oracle():
              (dict(field_length=400.0, field_width=220.0, obstacles=near_end), dict(L=400.0, H=220.0, obstacles=near_end)),
              (dict(field_length=300.0, field_width=150.0), dict(L=300.0, H=150.0)),
              (dict(field_length=500.0, field_width=200.0, obstacles=stacked), dict(L=500.0, H=200.0, obstacles=stacked)),
-             (dict(field_length=400.0, field_width=220.0, obstacles=wall), dict(L=400.0, H=220.0, obstacles=wall))]
+             (dict(field_length=400.0, field_width=220.0, obstacles=wall), dict(L=400.0, H=220.0, obstacles=wall)),
+             (dict(field_length=400.0, field_width=220.0, obstacles=first_end), dict(L=400.0, H=220.0, obstacles=first_end))]
     for tm, sp in ((0, 0.0), (0, 0.5), (1, 0.25)):
         infos = E.plan_count([E.FieldSpec(**a) for a, _ in cases], E.make_vehicle(), E.make_options(tm, sp, avoid_obstacles=True))
         base = E.plan_count([E.FieldSpec(**a) for a, _ in cases], E.make_vehicle(), E.make_options(tm, sp))
@@ -130,7 +133,12 @@ def test_plan_count_with_obstacle_aware_swaths_vs_oracle():
             assert rc == infos[k].status, (tm, sp, k)
             if rc == 0:
                 assert (infos[k].n_main, infos[k].n_head) == (p.n_main, p.n_head)
-        assert infos[1].status == L.EUNSUPPORTED and base[1].status == 0 and infos[3].status == 0 and infos[4].status == L.EUNSUPPORTED
+        assert infos[1].status == 0 and base[1].status == 0 and infos[3].status == 0 and infos[4].status == L.EUNSUPPORTED
+        assert infos[5].status == L.EUNSUPPORTED and base[5].status == 0
+        if sp > 0:
+            assert infos[1].n_main < base[1].n_main                     # the clipped passes are shorter
+        rc, p = orc.plan_field(orc.make_field(**cases[1][1]), orc.Vehicle.make(), orc.Options.make(tm, 1, sp, 0.5, 1e-6, 1))
+        assert rc == 0 and p.n_in_obstacle == 0
         rc, p = orc.plan_field(orc.make_field(**cases[3][1]), orc.Vehicle.make(), orc.Options.make(tm, 1, sp, 0.5, 1e-6, 1))
         assert rc == 0 and p.n_in_obstacle == 0                      # (the oracle validates its own path: nothing inside an obstacle)
         assert infos[0].n_main > base[0].n_main and infos[2].n_main == base[2].n_main      # detours add points; no obstacles: none

@@ -315,10 +315,10 @@ def test_obstacle_aware_swaths_vs_oracle(opt):
 
 
 def test_obstacle_aware_swaths_edge_cases():
-    """An obstacle box that reaches a swath line's end zone, or one that leaves no side to pass (it spans the work area's whole
+    """An obstacle box at the free end of the first pass, or one that leaves no side to pass (it spans the work area's whole
     y-range): FCPP_EUNSUPPORTED for that field only (library and oracle agree).  Two boxes that overlap are merged into one and driven
     around together.  A field without obstacles plans as without the option (unrotated: coordinates and segment words bit for bit)."""
-    near_end = [[(10.0, 100.0), (30.0, 100.0), (30.0, 120.0), (10.0, 120.0)]]
+    near_end = [[(5.0, 5.0), (30.0, 5.0), (30.0, 25.0), (5.0, 25.0)]]
     overlap = [[(150.0, 60.0), (170.0, 60.0), (170.0, 80.0), (150.0, 80.0)], [(165.0, 65.0), (190.0, 65.0), (190.0, 85.0), (165.0, 85.0)]]
     wall = [[(200.0, 5.0), (210.0, 5.0), (210.0, 215.0), (200.0, 215.0)]]
     specs = [E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=near_end),
@@ -342,6 +342,43 @@ def test_obstacle_aware_swaths_edge_cases():
         for a in ('kappa', 'v'):      # (the closed-form U-turns of the plain mode take curvature from the turn shape itself)
             np.testing.assert_allclose(_np(getattr(r1, a))[sl], _np(getattr(r0, a)), rtol=0, atol=1e-9, err_msg=a)
         b.close(); b0.close()
+
+
+@pytest.mark.parametrize('opt', [dict(), dict(sample_spacing=0.5), dict(turn_model=1, sample_spacing=0.25), dict(turn_model=1)])
+def test_obstacles_in_the_end_zones_move_the_turns(opt):
+    """Round 4 (include/fcpp.h, obstacle-aware swaths): a box that reaches into the lines' end zone -- where the turns are -- no longer
+    refuses the field: the turns beside it move inwards until their zone is free, the passes end / start there.  Left and right ends,
+    two boxes behind each other (the moved zone meets the second one), a rotated field; whole path against the oracle, no point of
+    the path inside an obstacle, and the clipped passes are shorter than the plain ones."""
+    left = [[(12.0, 100.0), (30.0, 100.0), (30.0, 120.0), (12.0, 120.0)]]
+    right = [[(372.0, 60.0), (386.0, 60.0), (386.0, 75.0), (372.0, 75.0)]]
+    chain = [[(372.0, 140.0), (386.0, 140.0), (386.0, 150.0), (372.0, 150.0)], [(340.0, 143.0), (350.0, 143.0), (350.0, 147.0), (340.0, 147.0)]]
+    both = left + right + chain + [[(200.0, 100.0), (215.0, 100.0), (215.0, 110.0), (200.0, 110.0)]]
+    rot = 0.25
+    c, s = np.cos(rot), np.sin(rot)
+    tilt = lambda pts: [(float(x * c - y * s), float(x * s + y * c)) for x, y in pts]
+    verts = tilt([(0.0, 0.0), (400.0, 0.0), (400.0, 220.0), (0.0, 220.0)])
+    tilted = [tilt(o) for o in left + right]
+    layouts = [left, right, chain, both]
+    specs = [E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=o) for o in layouts] + [E.FieldSpec(field_vertices=verts, obstacles=tilted)]
+    ofs = [orc.make_field(L=400.0, H=220.0, obstacles=o) for o in layouts] + [orc.make_field(verts=verts, obstacles=tilted)]
+    ds = opt.get('sample_spacing', 0.0) or 0.5
+    k_tol = max(K_TOL, 4e-12 / ds ** 2)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(opt, avoid_obstacles=True), xy_tol=1e-9, k_tol=k_tol, v_tol=max(V_TOL, 200 * k_tol))
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(avoid_obstacles=True, **opt))
+    assert all(i.status == 0 for i in b.info)
+    res = b.run()
+    assert int(res.stats()['n_in_obstacle'].sum()) == 0
+    if opt.get('sample_spacing', 0.0) > 0:
+        b0 = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**opt))
+        assert all(a.n_main < p.n_main + 200 for a, p in zip(b.info, b0.info))
+        x = _np(res.x)[res.field_slice(1)]
+        fs = _np(res.flagseg).view(np.uint32)[res.field_slice(1)]
+        sw = (fs & L.KIND_MASK) == L.KIND_SWATH
+        near = sw & (np.abs(_np(res.y)[res.field_slice(1)] - 67.0) < 8.0)
+        assert x[near].max() < 372.0 - 1.6 and x[sw].max() > 380.0          # passes beside the box stop before it, the others run to the end
+        b0.close()
+    b.close()
 
 
 def test_detours_never_cross_another_obstacle():
