@@ -36,6 +36,9 @@ struct DevSink {
     __device__ void push(const DevPrim &p) { if (n < cap) base[n] = p; ++n; }
     __device__ void truncate(int64_t m) { n = m; }
     __device__ int clipped_layer1(const PlanConsts &, const fcpp_field &, const Layer1Frame &, int64_t &) { return FCPP_EUNSUPPORTED; }
+    __device__ int headland_straight(const PlanConsts &, const Quad &, const DevPrim &, int64_t &) { return FCPP_EUNSUPPORTED; }
+    __device__ bool box_meets_square(double, double, double) const { return false; }
+    __device__ bool box_meets_segment(double, double, double, double) const { return false; }
 };
 
 __global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, const fcpp_field *__restrict__ fin, fcpp_field_info *__restrict__ info,

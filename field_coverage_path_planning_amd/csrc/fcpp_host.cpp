@@ -193,6 +193,146 @@ struct HostSink {
     void push(const DevPrim &p) { if (prims) prims->push_back(p); ++n; }
     void truncate(int64_t m) { if (prims) prims->resize((size_t)m); n = m; }
 
+    // obstacle-aware swaths: the field's merged grown boxes in the frame of layer 1 and that frame (set by clipped_layer1, used by layer 2)
+    struct Box { double x0, y0, x1, y1; };
+    std::vector<Box> boxes;
+    bool fr_rotated = false;
+    double fr_c = 1.0, fr_s = 0.0, fr_cx = 0.0, fr_cy = 0.0;
+    void to_frame(double &x, double &y) const { if (fr_rotated) rotate_point(x, y, fr_c, -fr_s, fr_cx, fr_cy, x, y); }
+    void to_world(double &x, double &y) const { if (fr_rotated) rotate_point(x, y, fr_c, fr_s, fr_cx, fr_cy, x, y); }
+
+    // parameter range [t0, t1] of the frame segment a + t d, t in [0, 1], inside box b, and the faces it enters / leaves through
+    // (0: x0, 1: x1, 2: y0, 3: y1); false: no proper crossing (touching does not count)
+    static bool seg_box(const Box &b, double ax, double ay, double dx, double dy, double &t0, double &t1, int &f0, int &f1)
+    {
+        t0 = 0.0; t1 = 1.0; f0 = f1 = -1;
+        const double a[2] = { ax, ay }, d[2] = { dx, dy }, lo[2] = { b.x0, b.y0 }, hi[2] = { b.x1, b.y1 };
+        for (int k = 0; k < 2; ++k) {
+            if (fabs(d[k]) < 1e-300) { if (!(a[k] > lo[k] && a[k] < hi[k])) return false; continue; }
+            double ta = (lo[k] - a[k]) / d[k], tb = (hi[k] - a[k]) / d[k];
+            int fa = 2 * k, fb = 2 * k + 1;
+            if (ta > tb) { std::swap(ta, tb); std::swap(fa, fb); }
+            if (ta > t0) { t0 = ta; f0 = fa; }
+            if (tb < t1) { t1 = tb; f1 = fb; }
+        }
+        return t1 - t0 > 1e-12;
+    }
+    bool box_meets_square(double wx, double wy, double half) const      // a world point's square of half-size `half` in the frame
+    {
+        to_frame(wx, wy);
+        for (const Box &b : boxes)
+            if (b.x0 < wx + half && b.x1 > wx - half && b.y0 < wy + half && b.y1 > wy - half) return true;
+        return false;
+    }
+    bool box_meets_segment(double ax, double ay, double bx, double by) const
+    {
+        to_frame(ax, ay); to_frame(bx, by);
+        double t0, t1; int f0, f1;
+        for (const Box &b : boxes)
+            if (seg_box(b, ax, ay, bx - ax, by - ay, t0, t1, f0, f1)) return true;
+        return false;
+    }
+
+    // Round 4: a headland straight (proto: the straight as the plain mode pushes it, a[0..3] = its end points) that crosses grown boxes
+    // is cut at every box and led around it along the box's boundary -- the shorter way whose corners stay at least W/2 inside the
+    // field -- as detour legs; the pieces of the straight keep its sample density.  A box over an end of the straight (where the corner
+    // turns are) or one with no way around inside the field refuses the field.
+    int headland_straight(const PlanConsts &pc, const Quad &q, const DevPrim &proto, int64_t &pos)
+    {
+        auto push1 = [&](DevPrim &pr) { pr.start = pos; pos += pr.n; flag_degenerate(pr); push(pr); };
+        if (boxes.empty()) { DevPrim pr = proto; push1(pr); return FCPP_OK; }
+        const double W = pc.W, ds = pc.ds;
+        double ax = proto.a[0], ay = proto.a[1], bx = proto.a[2], by = proto.a[3];
+        const double len_total = sqrt((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
+        to_frame(ax, ay); to_frame(bx, by);
+        const double dx = bx - ax, dy = by - ay;
+        struct Hit { double t0, t1; int f0, f1, box; };
+        std::vector<Hit> hits;
+        for (size_t k = 0; k < boxes.size(); ++k) {
+            Hit h;
+            if (seg_box(boxes[k], ax, ay, dx, dy, h.t0, h.t1, h.f0, h.f1)) { h.box = (int)k; hits.push_back(h); }
+        }
+        if (hits.empty()) { DevPrim pr = proto; push1(pr); return FCPP_OK; }
+        std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.t0 < b.t0; });
+        // the field polygon's inward edge normals (world), for "at least W/2 inside"
+        double cx, cy;
+        const double sgn = area_centroid(q, cx, cy) > 0 ? 1.0 : -1.0;
+        auto inside_margin = [&](double wx, double wy) {
+            for (int i = 0; i < 4; ++i) {
+                const int j = (i + 1) & 3;
+                const double ex = q.x[j] - q.x[i], ey = q.y[j] - q.y[i], ln = sqrt(ex * ex + ey * ey);
+                if (((-ey / ln * sgn) * (wx - q.x[i]) + (ex / ln * sgn) * (wy - q.y[i])) < W / 2 - 1e-6) return false;
+            }
+            return true;
+        };
+        bool fail = false;
+        const double step0 = len_total / 19.0;
+        auto push_line = [&](double x0, double y0, double x1, double y1, bool detour) {
+            const double len = sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));
+            int64_t np;
+            if (ds > 0) np = n_for_length(len, ds);
+            else np = std::max<int64_t>(2, (int64_t)(len / (detour ? 0.5 : step0)) + 1);
+            if (np > INT32_MAX) { fail = true; return; }
+            to_world(x0, y0); to_world(x1, y1);
+            DevPrim pr = proto;
+            pr.kind = PRIM_LINSPACE; pr.n = (int32_t)np;
+            if (detour) { pr.v_nom = pc.veh.headland_turn_speed_kmh; pr.fs = (proto.fs & ~(uint32_t)FCPP_KIND_MASK) | FCPP_KIND_DETOUR; }
+            pr.a[0] = x0; pr.a[1] = y0; pr.a[2] = x1; pr.a[3] = y1;
+            pr.a[4] = lin_step(x0, x1, np); pr.a[5] = lin_step(y0, y1, np);
+            push1(pr);
+        };
+        double px = ax, py = ay;
+        for (const Hit &h : hits) {
+            if (!(h.t0 > 1e-9 && h.t1 < 1.0 - 1e-9) || h.f0 < 0 || h.f1 < 0) return FCPP_EUNSUPPORTED;
+            const Box &b = boxes[(size_t)h.box];
+            double e0x = ax + h.t0 * dx, e0y = ay + h.t0 * dy, e1x = ax + h.t1 * dx, e1y = ay + h.t1 * dy;
+            auto snap = [&](int face, double &x, double &y) {
+                if (face == 0) x = b.x0; else if (face == 1) x = b.x1; else if (face == 2) y = b.y0; else y = b.y1;
+                x = std::min(std::max(x, b.x0), b.x1); y = std::min(std::max(y, b.y0), b.y1);
+            };
+            snap(h.f0, e0x, e0y); snap(h.f1, e1x, e1y);
+            // perimeter coordinate, counter-clockwise from (x0, y0): faces in that order are y0 (2), x1 (1), y1 (3), x0 (0)
+            const double w = b.x1 - b.x0, hh = b.y1 - b.y0, per = 2 * (w + hh);
+            auto peri = [&](int face, double x, double y) {
+                return face == 2 ? x - b.x0 : (face == 1 ? w + (y - b.y0) : (face == 3 ? w + hh + (b.x1 - x) : 2 * w + hh + (b.y1 - y)));
+            };
+            const double s0 = peri(h.f0, e0x, e0y), s1 = peri(h.f1, e1x, e1y);
+            const double cs[4] = { 0.0, w, w + hh, 2 * w + hh };                       // corners (x0,y0), (x1,y0), (x1,y1), (x0,y1)
+            const double cxs[4] = { b.x0, b.x1, b.x1, b.x0 }, cys[4] = { b.y0, b.y0, b.y1, b.y1 };
+            double best_len = HUGE_VAL;
+            std::vector<int> best;
+            bool best_ccw = true;
+            for (int dir = 0; dir < 2; ++dir) {
+                // corners strictly between s0 and s1 going counter-clockwise (dir 0) / clockwise (dir 1)
+                const double span = dir == 0 ? fmod(s1 - s0 + per, per) : fmod(s0 - s1 + per, per);
+                std::vector<std::pair<double, int>> cc;
+                for (int c = 0; c < 4; ++c) {
+                    const double off = dir == 0 ? fmod(cs[c] - s0 + per, per) : fmod(s0 - cs[c] + per, per);
+                    if (off > 1e-9 && off < span - 1e-9) cc.push_back({ off, c });
+                }
+                std::sort(cc.begin(), cc.end());
+                bool ok = true;
+                for (auto &pc2 : cc) { double wx = cxs[pc2.second], wy = cys[pc2.second]; to_world(wx, wy); if (!inside_margin(wx, wy)) ok = false; }
+                if (!ok) continue;
+                if (span < best_len - 1e-9) {
+                    best_len = span; best.clear();
+                    for (auto &pc2 : cc) best.push_back(pc2.second);
+                    best_ccw = dir == 0;
+                }
+            }
+            (void)best_ccw;
+            if (best_len == HUGE_VAL) return FCPP_EUNSUPPORTED;
+            push_line(px, py, e0x, e0y, false);
+            double lx = e0x, ly = e0y;
+            for (int c : best) { push_line(lx, ly, cxs[c], cys[c], true); lx = cxs[c]; ly = cys[c]; }
+            push_line(lx, ly, e1x, e1y, true);
+            px = e1x; py = e1y;
+            if (fail) return FCPP_ESIZE;
+        }
+        push_line(px, py, bx, by, false);
+        return fail ? FCPP_ESIZE : FCPP_OK;
+    }
+
     // obstacle-aware swaths (include/fcpp.h): layer 1 as a list of primitives -- sub-swaths, detour legs, U-turns
     int clipped_layer1(const PlanConsts &pc, const fcpp_field &f, const Layer1Frame &fr, int64_t &n_main)
     {
@@ -201,10 +341,10 @@ struct HostSink {
         const bool cloth = pc.cloth != 0, rotated = fr.rotated != 0;
         const double rot = fr.rot, ccx = fr.ccx, ccy = fr.ccy, lsx = fr.lsx, lex = fr.lex, min_y = fr.min_y, max_y = fr.max_y;
         const int64_t P = fr.P, n_turn = fr.n_turn;
-        struct Box { double x0, y0, x1, y1; };
-        std::vector<Box> boxes;
+        boxes.clear();
         double rc, rs;
         fc_sincos(rot, rs, rc);
+        fr_rotated = rotated; fr_c = rc; fr_s = rs; fr_cx = ccx; fr_cy = ccy;
         const double ca = rc, sa = -rs;
         bool bad_obs = f.n_obstacles < 0 || (f.n_obstacles > 0 && (!polys || f.obstacle_first < 0 || f.obstacle_first + f.n_obstacles > polys->n_polys));
         for (int k = 0; k < f.n_obstacles && !bad_obs; ++k) {

@@ -193,6 +193,8 @@ struct Layer1Frame {
 // prim_first = sink.size() at entry); the field's primitives go to `sink`:
 //     int64_t size() ; void push(const DevPrim &) ; void truncate(int64_t) ;
 //     int clipped_layer1(const PlanConsts &, const fcpp_field &, const Layer1Frame &, int64_t &n_main)   (obstacle-aware swaths: FCPP_OK or the field's error)
+//     int headland_straight(const PlanConsts &, const Quad &, const DevPrim &, int64_t &pos), bool box_meets_square(x, y, half),
+//     bool box_meets_segment(ax, ay, bx, by)                                                                (obstacle-aware swaths, layer 2)
 // A field that raises gets in.status < 0 and no points.  -> points of the field.
 template <class Sink>
 FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_field_info &in, DevField &df, Sink &sink)
@@ -347,7 +349,11 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
             p.fs = FCPP_KIND_HEAD_STRAIGHT | lp | ((uint32_t)cur << FCPP_INDEX_SHIFT);
             p.a[0] = c.x[cur]; p.a[1] = c.y[cur]; p.a[2] = c.x[nxt]; p.a[3] = c.y[nxt];
             p.a[4] = lin_step(c.x[cur], c.x[nxt], ns); p.a[5] = lin_step(c.y[cur], c.y[nxt], ns);
-            FCPP_PUSH(p);
+            if (clip) {       // obstacle-aware: the straight is led around the boxes it crosses (include/fcpp.h); the turn at its end must be free
+                const int rcode = sink.headland_straight(pc, q, p, pos);
+                if (rcode == FCPP_OK && i < 3 && sink.box_meets_square(c.x[nxt], c.y[nxt], 2.0 * R)) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
+                if (rcode != FCPP_OK) { bad = true; in.status = rcode; break; }
+            } else FCPP_PUSH(p);
             last_head[0] = c.x[nxt]; last_head[1] = c.y[nxt];
             if (i == 3) break;
             // corner turn at `nxt` (MLP:1024-1063 / 1580-1608)
@@ -380,6 +386,7 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
                 double dx = -1.0, dy = 0.0;
                 if (nrm > 1e-6) { dx = -tx / nrm; dy = -ty / nrm; }
                 const double len = distance_to_boundary(e1[0], e1[1], dx, dy, L, H, R);
+                if (clip && sink.box_meets_segment(e1[0], e1[1], e1[0] + len * dx, e1[1] + len * dy)) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
                 int64_t nr;
                 if (ds > 0) nr = n_for_length(len, ds);
                 else { nr = (int64_t)(len / 0.5); if (nr < 10) nr = 10; }

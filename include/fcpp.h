@@ -90,7 +90,12 @@ enum { FCPP_RING_AS_VERTICES = 0, FCPP_RING_REVERSED = 1 };
  * or either of the two lines within it, moves the turn inwards until the zone is free (again if the moved zone meets another box): both
  * passes end / start there, the U-turn is the same shape translated, and the strip beyond stays unworked.  Only the free ends -- the
  * start of the first pass, the end of the last -- are not moved: a box there, or one that leaves no side to pass, refuses the field
- * with FCPP_EUNSUPPORTED (its status; the other fields of the batch are planned).  The headland loops are not re-routed. */
+ * with FCPP_EUNSUPPORTED (its status; the other fields of the batch are planned).
+ * Headland (round 4): a headland straight that crosses a grown box is cut at the box and led around it along the box's boundary -- from
+ * where it enters to where it leaves, the shorter way whose box corners stay at least W/2 inside the field -- as FCPP_KIND_DETOUR legs
+ * carrying the loop's FCPP_FLAG_HEADLAND; the pieces of the straight keep its sample density (length / 19 per step at the reference's
+ * sampling).  A box over an end of a straight or within 2 R of a loop corner (where the corner turns are), across a reverse fill, or
+ * with no way around inside the field refuses the field. */
 enum { FCPP_OBSTACLES_FLAG = 0, FCPP_OBSTACLES_AVOID = 1 };
 
 /* ---- one field = one planner instance (ctor arguments, MLP:63-72) ---------------------- */

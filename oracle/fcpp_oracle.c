@@ -627,6 +627,154 @@ static double turn_length(double dth, double R, const orc_options *o)
     return orc_cac_length(dth, Re, o->clothoid_frac);
 }
 
+/* ---- BUILD-DEFINED (round 4): obstacle-aware headland.  Boxes in the frame of layer 1 (rotated by -rot about (ccx, ccy)). ---- */
+static void to_frame2(double *x, double *y, int rotated, double rot, double ccx, double ccy)
+{
+    if (rotated) { double o[2]; orc_rotate_point(*x, *y, -rot, ccx, ccy, o); *x = o[0]; *y = o[1]; }
+}
+static void to_world2(double *x, double *y, int rotated, double rot, double ccx, double ccy)
+{
+    if (rotated) { double o[2]; orc_rotate_point(*x, *y, rot, ccx, ccy, o); *x = o[0]; *y = o[1]; }
+}
+/* parameter range of a + t d, t in [0, 1], inside the box and the faces it enters / leaves through (0: x0, 1: x1, 2: y0, 3: y1) */
+static int seg_box(double x0, double y0, double x1, double y1, double ax, double ay, double dx, double dy, double *t0, double *t1, int *f0, int *f1)
+{
+    double a[2] = { ax, ay }, d[2] = { dx, dy }, lo[2] = { x0, y0 }, hi[2] = { x1, y1 };
+    *t0 = 0.0; *t1 = 1.0; *f0 = *f1 = -1;
+    for (int k = 0; k < 2; ++k) {
+        if (fabs(d[k]) < 1e-300) { if (!(a[k] > lo[k] && a[k] < hi[k])) return 0; continue; }
+        double ta = (lo[k] - a[k]) / d[k], tb = (hi[k] - a[k]) / d[k];
+        int fa = 2 * k, fb = 2 * k + 1;
+        if (ta > tb) { double t = ta; ta = tb; tb = t; int f = fa; fa = fb; fb = f; }
+        if (ta > *t0) { *t0 = ta; *f0 = fa; }
+        if (tb < *t1) { *t1 = tb; *f1 = fb; }
+    }
+    return *t1 - *t0 > 1e-12;
+}
+static int box_meets_square(double wx, double wy, double half, int nbox, const double *bx0, const double *by0, const double *bx1, const double *by1,
+                            int rotated, double rot, double ccx, double ccy)
+{
+    to_frame2(&wx, &wy, rotated, rot, ccx, ccy);
+    for (int k = 0; k < nbox; ++k)
+        if (bx0[k] < wx + half && bx1[k] > wx - half && by0[k] < wy + half && by1[k] > wy - half) return 1;
+    return 0;
+}
+static int box_meets_segment(double ax, double ay, double bx, double by, int nbox, const double *bx0, const double *by0, const double *bx1,
+                             const double *by1, int rotated, double rot, double ccx, double ccy)
+{
+    double t0, t1; int f0, f1;
+    to_frame2(&ax, &ay, rotated, rot, ccx, ccy); to_frame2(&bx, &by, rotated, rot, ccx, ccy);
+    for (int k = 0; k < nbox; ++k)
+        if (seg_box(bx0[k], by0[k], bx1[k], by1[k], ax, ay, bx - ax, by - ay, &t0, &t1, &f0, &f1)) return 1;
+    return 0;
+}
+/* a headland straight A -> B (world) cut at every box it crosses and led around it along the box's boundary -- the shorter way whose
+ * corners stay at least W/2 inside the field -- as detour legs; the pieces of the straight keep its sample density (len / 19 at the
+ * reference's sampling).  0, or -3: a box over an end of the straight, or no way around inside the field. */
+static int headland_straight_around(pbuf *pb, double wax, double way, double wbx, double wby, int nbox, const double *bx0, const double *by0,
+                                    const double *bx1, const double *by1, int rotated, double rot, double ccx, double ccy, const double *vx,
+                                    const double *vy, double W, double ds, const orc_vehicle *veh, uint32_t fs_straight, int64_t ns_plain)
+{
+    double len_total = sqrt((wbx - wax) * (wbx - wax) + (wby - way) * (wby - way)), step0 = len_total / 19.0;
+    double ax = wax, ay = way, bx = wbx, by = wby;
+    to_frame2(&ax, &ay, rotated, rot, ccx, ccy); to_frame2(&bx, &by, rotated, rot, ccx, ccy);
+    double dx = bx - ax, dy = by - ay;
+    double *ht0 = (double *)malloc((size_t)(nbox + 1) * 2 * sizeof(double)), *ht1 = ht0 + nbox + 1;
+    int *hf = (int *)malloc((size_t)(nbox + 1) * 3 * sizeof(int)), *hf0 = hf, *hf1 = hf + nbox + 1, *hb = hf + 2 * (nbox + 1);
+    int nh = 0;
+    for (int k = 0; k < nbox; ++k) {
+        double t0, t1; int f0, f1;
+        if (seg_box(bx0[k], by0[k], bx1[k], by1[k], ax, ay, dx, dy, &t0, &t1, &f0, &f1)) {
+            int j = nh++;
+            while (j > 0 && ht0[j - 1] > t0) { ht0[j] = ht0[j - 1]; ht1[j] = ht1[j - 1]; hf0[j] = hf0[j - 1]; hf1[j] = hf1[j - 1]; hb[j] = hb[j - 1]; --j; }
+            ht0[j] = t0; ht1[j] = t1; hf0[j] = f0; hf1[j] = f1; hb[j] = k;
+        }
+    }
+    if (nh == 0) {                     /* no box in the way: the straight as the plain mode samples it */
+        int64_t ns = ns_plain;
+        double *sb = (double *)malloc((size_t)ns * 2 * sizeof(double));
+        orc_straight(wax, way, wbx, wby, ns, sb);
+        pb_push(pb, sb, ns, veh->max_headland_speed_kmh, fs_straight);
+        free(sb); free(ht0); free(hf);
+        return 0;
+    }
+    uint32_t fs_detour = (fs_straight & ~(uint32_t)ORC_KIND_MASK) | ORC_KIND_DETOUR;
+    /* orientation of the field polygon, for "at least W/2 inside" */
+    double area2 = 0.0;
+    for (int i = 0; i < 4; ++i) { int j = (i + 1) % 4; area2 += vx[i] * vy[j] - vx[j] * vy[i]; }
+    double sgn = area2 > 0 ? 1.0 : -1.0;
+    int rc = 0;
+    double px = ax, py = ay;
+#define ORC_LEG(X0, Y0, X1, Y1, DET) do { \
+        double x0_ = (X0), y0_ = (Y0), x1_ = (X1), y1_ = (Y1); \
+        double len_ = sqrt((x1_ - x0_) * (x1_ - x0_) + (y1_ - y0_) * (y1_ - y0_)); \
+        int64_t np_; \
+        if (ds > 0) np_ = n_for_length(len_, ds); \
+        else { np_ = (int64_t)(len_ / ((DET) ? 0.5 : step0)) + 1; if (np_ < 2) np_ = 2; } \
+        to_world2(&x0_, &y0_, rotated, rot, ccx, ccy); to_world2(&x1_, &y1_, rotated, rot, ccx, ccy); \
+        double *lb_ = (double *)malloc((size_t)np_ * 2 * sizeof(double)); \
+        orc_straight(x0_, y0_, x1_, y1_, np_, lb_); \
+        pb_push(pb, lb_, np_, (DET) ? veh->headland_turn_speed_kmh : veh->max_headland_speed_kmh, (DET) ? fs_detour : fs_straight); \
+        free(lb_); \
+    } while (0)
+    for (int h = 0; h < nh && rc == 0; ++h) {
+        if (!(ht0[h] > 1e-9 && ht1[h] < 1.0 - 1e-9) || hf0[h] < 0 || hf1[h] < 0) { rc = -3; break; }
+        int k = hb[h];
+        double X0 = bx0[k], Y0 = by0[k], X1 = bx1[k], Y1 = by1[k];
+        double e0x = ax + ht0[h] * dx, e0y = ay + ht0[h] * dy, e1x = ax + ht1[h] * dx, e1y = ay + ht1[h] * dy;
+        double *ex[2] = { &e0x, &e1x }, *ey[2] = { &e0y, &e1y };
+        int ef[2] = { hf0[h], hf1[h] };
+        for (int e = 0; e < 2; ++e) {
+            if (ef[e] == 0) *ex[e] = X0; else if (ef[e] == 1) *ex[e] = X1; else if (ef[e] == 2) *ey[e] = Y0; else *ey[e] = Y1;
+            if (*ex[e] < X0) *ex[e] = X0;
+            if (*ex[e] > X1) *ex[e] = X1;
+            if (*ey[e] < Y0) *ey[e] = Y0;
+            if (*ey[e] > Y1) *ey[e] = Y1;
+        }
+        double w = X1 - X0, hh = Y1 - Y0, per = 2 * (w + hh), sp[2];
+        for (int e = 0; e < 2; ++e)
+            sp[e] = ef[e] == 2 ? *ex[e] - X0 : (ef[e] == 1 ? w + (*ey[e] - Y0) : (ef[e] == 3 ? w + hh + (X1 - *ex[e]) : 2 * w + hh + (Y1 - *ey[e])));
+        double cs[4] = { 0.0, w, w + hh, 2 * w + hh }, cxs[4] = { X0, X1, X1, X0 }, cys[4] = { Y0, Y0, Y1, Y1 };
+        double best_len = HUGE_VAL;
+        int best[4], nbest = 0;
+        for (int dir = 0; dir < 2; ++dir) {
+            double span = dir == 0 ? fmod(sp[1] - sp[0] + per, per) : fmod(sp[0] - sp[1] + per, per);
+            double off[4];
+            int cc[4], ncc = 0;
+            for (int c = 0; c < 4; ++c) {
+                double o = dir == 0 ? fmod(cs[c] - sp[0] + per, per) : fmod(sp[0] - cs[c] + per, per);
+                if (o > 1e-9 && o < span - 1e-9) {
+                    int j = ncc++;
+                    while (j > 0 && off[j - 1] > o) { off[j] = off[j - 1]; cc[j] = cc[j - 1]; --j; }
+                    off[j] = o; cc[j] = c;
+                }
+            }
+            int ok = 1;
+            for (int q = 0; q < ncc; ++q) {
+                double wx = cxs[cc[q]], wy = cys[cc[q]];
+                to_world2(&wx, &wy, rotated, rot, ccx, ccy);
+                for (int i = 0; i < 4; ++i) {
+                    int j = (i + 1) % 4;
+                    double gx = vx[j] - vx[i], gy = vy[j] - vy[i], ln = sqrt(gx * gx + gy * gy);
+                    if (((-gy / ln * sgn) * (wx - vx[i]) + (gx / ln * sgn) * (wy - vy[i])) < W / 2 - 1e-6) ok = 0;
+                }
+            }
+            if (!ok) continue;
+            if (span < best_len - 1e-9) { best_len = span; nbest = ncc; for (int q = 0; q < ncc; ++q) best[q] = cc[q]; }
+        }
+        if (best_len == HUGE_VAL) { rc = -3; break; }
+        ORC_LEG(px, py, e0x, e0y, 0);
+        double lx = e0x, ly = e0y;
+        for (int q = 0; q < nbest; ++q) { ORC_LEG(lx, ly, cxs[best[q]], cys[best[q]], 1); lx = cxs[best[q]]; ly = cys[best[q]]; }
+        ORC_LEG(lx, ly, e1x, e1y, 1);
+        px = e1x; py = e1y;
+    }
+    if (rc == 0) ORC_LEG(px, py, bx, by, 0);
+#undef ORC_LEG
+    free(ht0); free(hf);
+    return rc;
+}
+
 /* MLP:720-789 with the reference's 2-point lines / 20-point arcs */
 int64_t orc_u_pattern(double min_x, double min_y, double max_x, double max_y, int reverse_order,
                       int start_from_right, const orc_vehicle *veh, double *xy, double *v, int64_t cap)
@@ -734,6 +882,8 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
     out->reverse_order = reverse_order; out->start_from_right = start_from_right;
 
     pbuf pb; memset(&pb, 0, sizeof(pb));
+    double *bx0 = NULL, *by0 = NULL, *bx1 = NULL, *by1 = NULL;      /* obstacle-aware swaths: the merged grown boxes, frame of layer 1 */
+    int nbox = 0;
     if (opt->obstacle_mode == 1) {
         /* ---- BUILD-DEFINED: obstacle-aware swaths (include/fcpp.h, fcpp_options.obstacle_mode).  Every obstacle = the bounding box
          * of its vertices in the frame of layer 1, grown by W/2; a swath line strictly inside a box's y-range is clipped at the box and
@@ -745,9 +895,8 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
         out->n_swaths = (int32_t)P;
         int64_t n_turn = ds > 0 ? n_for_length(turn_length(M_PI, R, opt), ds) : 20;
         int nb = f->n_obstacles;
-        double *bx0 = (double *)malloc((size_t)(nb + 1) * 4 * sizeof(double)), *by0 = bx0 + nb + 1, *bx1 = by0 + nb + 1, *by1 = bx1 + nb + 1;
+        bx0 = (double *)malloc((size_t)(nb + 1) * 4 * sizeof(double)); by0 = bx0 + nb + 1; bx1 = by0 + nb + 1; by1 = bx1 + nb + 1;
         int *ord = (int *)malloc((size_t)(nb + 1) * sizeof(int));
-        int nbox = 0;
         for (int k = 0; k < nb; ++k) {
             int64_t a0 = f->obs_offsets[k], a1 = f->obs_offsets[k + 1];
             if (a1 <= a0) continue;
@@ -889,8 +1038,8 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
                 pb_push(&pb, tb, n_turn, veh->headland_turn_speed_kmh, ORC_KIND_UTURN | ((uint32_t)i << ORC_INDEX_SHIFT));
             }
         }
-        free(tb); free(ord); free(bx0); free(clip_lo);
-        if (unsupported) { free(pb.xy); free(pb.v); free(pb.fs); return -3; }
+        free(tb); free(ord); free(clip_lo);
+        if (unsupported) { free(bx0); free(pb.xy); free(pb.v); free(pb.fs); return -3; }
     } else {
         double lsx = min_x + R, lex = max_x - R;
         int64_t P = (int64_t)((max_y - min_y) / W) + 1;
@@ -930,7 +1079,7 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
         double offset = W / 2 + loop * W;                                        /* MLP:924 */
         double cx4[4], cy4[4];
         if (!inset_convex(vx, vy, 4, offset, cx4, cy4) || poly_abs_area(cx4, cy4, 4) < 1.0) {
-            free(pb.xy); free(pb.v); free(pb.fs);
+            free(bx0); free(pb.xy); free(pb.v); free(pb.fs);
             return -2;                                                           /* MLP:967-969 then :939 */
         }
         if (opt->ring_order == 1) {       /* the ring lists the corners the other way round from the same first vertex: 0, 3, 2, 1 */
@@ -944,11 +1093,19 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             int cur = (sci + i) % 4, nxt = (sci + i + 1) % 4;
             double len = hypot(cx4[nxt] - cx4[cur], cy4[nxt] - cy4[cur]);
             int64_t ns = ds > 0 ? n_for_length(len, ds) : 20;
+            if (nbox > 0) {
+                /* BUILD-DEFINED (round 4): the straight is led around the grown boxes it crosses; the corner turn at its end must be free */
+                int rcode = headland_straight_around(&pb, cx4[cur], cy4[cur], cx4[nxt], cy4[nxt], nbox, bx0, by0, bx1, by1, rotated, rot, ccx, ccy,
+                                                     vx, vy, W, ds, veh, ORC_KIND_HEAD_STRAIGHT | lp | ((uint32_t)cur << ORC_INDEX_SHIFT), ns);
+                if (rcode == 0 && i < 3 && box_meets_square(cx4[nxt], cy4[nxt], 2.0 * R, nbox, bx0, by0, bx1, by1, rotated, rot, ccx, ccy)) rcode = -3;
+                if (rcode != 0) { free(bx0); free(pb.xy); free(pb.v); free(pb.fs); return rcode; }
+            } else {
             double *sb = (double *)malloc((size_t)ns * 2 * sizeof(double));
             orc_straight(cx4[cur], cy4[cur], cx4[nxt], cy4[nxt], ns, sb);
             pb_push(&pb, sb, ns, veh->max_headland_speed_kmh,
                     ORC_KIND_HEAD_STRAIGHT | lp | ((uint32_t)cur << ORC_INDEX_SHIFT));
             free(sb);
+            }
             if (i < 3) {
                 int64_t nt = ds > 0 ? n_for_length(turn_length(M_PI / 2, R, opt), ds) : 15;
                 double *tb = (double *)malloc((size_t)nt * 2 * sizeof(double));
@@ -961,12 +1118,16 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
                 /* gap.area > 0.1 (MLP:1070): certain from the lower bound 4R^2 - (pi R W/2 + pi W^2/4), else from the gap's own area
                  * (orc_corner_gap_decision); a decision GEOS' polygonal buffer leaves open fails the field (unsupported) */
                 int gap_yes = add_rev ? orc_corner_gap_decision(R, W) : 0;
-                if (add_rev && gap_yes < 0) { free(tb); free(pb.xy); free(pb.v); free(pb.fs); return -3; }
+                if (add_rev && gap_yes < 0) { free(bx0); free(tb); free(pb.xy); free(pb.v); free(pb.fs); return -3; }
                 if (add_rev && gap_yes > 0 && nt >= 2) {
                     double rl;
                     int64_t nr = orc_reverse_path(tb + 2 * (nt - 1), tb + 2 * (nt - 2), L, H, R, ds, &rl, NULL);
                     double *rb = (double *)malloc((size_t)nr * 2 * sizeof(double));
                     orc_reverse_path(tb + 2 * (nt - 1), tb + 2 * (nt - 2), L, H, R, ds, &rl, rb);
+                    if (nbox > 0 && box_meets_segment(rb[0], rb[1], rb[2 * (nr - 1)], rb[2 * (nr - 1) + 1], nbox, bx0, by0, bx1, by1, rotated, rot, ccx, ccy)) {
+                        free(rb); free(bx0); free(tb); free(pb.xy); free(pb.v); free(pb.fs);
+                        return -3;
+                    }
                     pb_push(&pb, rb, nr, 2.5, ORC_KIND_REVERSE | lp | ((uint32_t)nxt << ORC_INDEX_SHIFT));
                     out->n_reverse[nxt] = (int32_t)nr;
                     free(rb);
@@ -975,6 +1136,7 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             }
         }
     }
+    free(bx0);
     int64_t N = pb.n, n_head = N - n_main;
     out->n_head = n_head;
 

@@ -381,6 +381,43 @@ def test_obstacles_in_the_end_zones_move_the_turns(opt):
     b.close()
 
 
+@pytest.mark.parametrize('opt', [dict(), dict(sample_spacing=0.5), dict(turn_model=1, sample_spacing=0.25), dict(turn_model=1)])
+def test_headland_loops_go_around_obstacles(opt):
+    """Round 4 (include/fcpp.h, obstacle-aware swaths): an obstacle that reaches into the headland no longer leaves loop points inside it:
+    every headland straight that crosses a grown box is cut there and led around the box along its boundary (detour legs with the
+    headland flag), the shorter way that stays W/2 inside the field.  Boxes beside the right edge, below the top edge, both, one in a
+    tilted parallelogram (the straights cross the box askew and leave through another face); a box in a corner's turn zone is
+    refused.  Whole path against the oracle; no point of the path inside an obstacle."""
+    right = [[(385.0, 60.0), (395.0, 60.0), (395.0, 75.0), (385.0, 75.0)]]
+    top = [[(150.0, 205.0), (170.0, 205.0), (170.0, 214.0), (150.0, 214.0)]]
+    corner = [[(385.0, 200.0), (395.0, 200.0), (395.0, 215.0), (385.0, 215.0)]]
+    rot = 0.3
+    c, s = np.cos(rot), np.sin(rot)
+    tilt = lambda pts: [(float(x * c - y * s), float(x * s + y * c)) for x, y in pts]
+    verts = tilt([(0.0, 0.0), (500.0, 0.0), (560.0, 260.0), (60.0, 260.0)])
+    para_obs = [tilt([(52.0, 150.0), (61.0, 150.0), (61.0, 162.0), (52.0, 162.0)]), tilt([(300.0, 4.0), (318.0, 4.0), (318.0, 9.0), (300.0, 9.0)])]
+    layouts = [right, top, right + top, corner]
+    specs = [E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=o) for o in layouts] + [E.FieldSpec(field_vertices=verts, obstacles=para_obs)]
+    ofs = [orc.make_field(L=400.0, H=220.0, obstacles=o) for o in layouts] + [orc.make_field(verts=verts, obstacles=para_obs)]
+    ds = opt.get('sample_spacing', 0.0) or 0.5
+    k_tol = max(K_TOL, 4e-12 / ds ** 2)
+    _compare_with_oracle(specs, ofs, DEFAULT_VP, dict(opt, avoid_obstacles=True), xy_tol=1e-9, k_tol=k_tol, v_tol=max(V_TOL, 200 * k_tol))
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(avoid_obstacles=True, **opt))
+    assert [i.status for i in b.info] == [0, 0, 0, L.EUNSUPPORTED, 0]
+    res = b.run()
+    st = res.stats()
+    fs = _np(res.flagseg).view(np.uint32)
+    assert int(st['n_in_obstacle'].sum()) == 0 and int((fs & L.FLAG_OBSTACLE != 0).sum()) == 0
+    for k in (0, 1, 2, 4):          # detour legs that belong to the headland
+        f = fs[res.field_slice(k)]
+        assert int((((f & L.KIND_MASK) == L.KIND_DETOUR) & ((f & L.FLAG_HEADLAND) != 0)).sum()) > 0, k
+    if opt.get('sample_spacing', 0.0) > 0:
+        b0 = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**opt))
+        assert int(b0.run().stats()['n_in_obstacle'].sum()) > 0          # the plain mode drives its loops through them
+        b0.close()
+    b.close()
+
+
 def test_detours_never_cross_another_obstacle():
     """Found by review in round 2: an obstacle just above another one -- the detour around the first ran through the second and the
     field still came back OK.  Grown boxes that overlap are now merged, a leg runs on the boundary of its own (merged) box, and a side
