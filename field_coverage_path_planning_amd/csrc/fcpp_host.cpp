@@ -184,6 +184,98 @@ int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c
 
 namespace {
 
+// ---- obstacle-aware swaths, round 4: the W/2-grown POLYGON of an obstacle (frame of layer 1) -----------------------------------------
+// Convex hull of the vertices (counter-clockwise), every edge moved W/2 outwards, neighbours joined at their mitre point -- a convex
+// polygon that contains every point within W/2 of the hull -- and clipped to the obstacle's grown bounding box (so that it stays inside
+// the box the merging rule reasons about).  Empty: no polygon (fewer than three hull vertices), the box is used.
+struct GPt { double x, y; };
+static std::vector<GPt> grown_polygon(std::vector<GPt> pts, double half, double x0, double y0, double x1, double y1)
+{
+    std::vector<GPt> none;
+    std::sort(pts.begin(), pts.end(), [](const GPt &a, const GPt &b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+    const size_t n = pts.size();
+    if (n < 3) return none;
+    auto cross = [](const GPt &o, const GPt &a, const GPt &b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
+    std::vector<GPt> h(2 * n);
+    size_t k = 0;
+    for (size_t i = 0; i < n; ++i) { while (k >= 2 && cross(h[k - 2], h[k - 1], pts[i]) <= 0) --k; h[k++] = pts[i]; }
+    for (size_t i = n - 1, t = k + 1; i > 0; --i) { while (k >= t && cross(h[k - 2], h[k - 1], pts[i - 1]) <= 0) --k; h[k++] = pts[i - 1]; }
+    h.resize(k - 1);
+    const size_t m = h.size();
+    if (m < 3) return none;
+    std::vector<GPt> nrm(m), g(m);
+    for (size_t i = 0; i < m; ++i) {
+        const GPt &a = h[i], &b = h[(i + 1) % m];
+        const double dx = b.x - a.x, dy = b.y - a.y, ln = sqrt(dx * dx + dy * dy);
+        if (!(ln > 0)) return none;
+        nrm[i] = { dy / ln, -dx / ln };                       // outward of a counter-clockwise polygon
+    }
+    for (size_t i = 0; i < m; ++i) {
+        const GPt &n0 = nrm[(i + m - 1) % m], &n1 = nrm[i];
+        const double den = 1.0 + (n0.x * n1.x + n0.y * n1.y);
+        if (!(den > 1e-12)) return none;
+        g[i] = { h[i].x + half * (n0.x + n1.x) / den, h[i].y + half * (n0.y + n1.y) / den };
+    }
+    // Sutherland-Hodgman against x >= x0, x <= x1, y >= y0, y <= y1
+    for (int side = 0; side < 4; ++side) {
+        std::vector<GPt> out;
+        // (a vertex ON the box -- every vertex of an axis-parallel rectangle's polygon -- is inside whichever way its last bit fell)
+        auto inside = [&](const GPt &p) { return side == 0 ? p.x >= x0 - 1e-9 : (side == 1 ? p.x <= x1 + 1e-9 : (side == 2 ? p.y >= y0 - 1e-9 : p.y <= y1 + 1e-9)); };
+        auto cut = [&](const GPt &a, const GPt &b) {
+            GPt r;
+            if (side < 2) { const double xc = side == 0 ? x0 : x1; r.x = xc; r.y = a.y + (b.y - a.y) * ((xc - a.x) / (b.x - a.x)); }
+            else { const double yc = side == 2 ? y0 : y1; r.y = yc; r.x = a.x + (b.x - a.x) * ((yc - a.y) / (b.y - a.y)); }
+            return r;
+        };
+        for (size_t i = 0; i < g.size(); ++i) {
+            const GPt &a = g[i], &b = g[(i + 1) % g.size()];
+            const bool ia = inside(a), ib = inside(b);
+            if (ia) out.push_back(a);
+            if (ia != ib) out.push_back(cut(a, b));
+        }
+        g.swap(out);
+        if (g.size() < 3) return none;
+    }
+    // vertices closer than 1e-7 to their predecessor are one vertex
+    std::vector<GPt> u;
+    for (const GPt &p : g)
+        if (u.empty() || fabs(p.x - u.back().x) + fabs(p.y - u.back().y) > 1e-7) u.push_back(p);
+    while (u.size() > 1 && fabs(u.front().x - u.back().x) + fabs(u.front().y - u.back().y) <= 1e-7) u.pop_back();
+    if (u.size() < 3) return none;
+    return u;
+}
+// The way around a grown polygon g (counter-clockwise, convex) for a line at height y travelling left or right: where the line meets
+// the polygon (false: it passes clear of it) and the vertices of the upper / lower chain from the near point to the far point.
+static bool polygon_chains(const std::vector<GPt> &g, double y, bool go_left, double &nearx, double &farx, std::vector<GPt> &upper, std::vector<GPt> &lower)
+{
+    const size_t m = g.size();
+    int eu = -1, ed = -1;            // the edge that crosses the line going up (on the right of a ccw polygon) / going down (on the left)
+    double xu = 0, xd = 0;
+    for (size_t j = 0; j < m; ++j) {
+        const GPt &a = g[j], &b = g[(j + 1) % m];
+        if ((a.y < y) == (b.y < y)) continue;
+        const double x = a.x + (b.x - a.x) * ((y - a.y) / (b.y - a.y));
+        if (a.y < y) { eu = (int)j; xu = x; } else { ed = (int)j; xd = x; }
+    }
+    if (eu < 0 || ed < 0) return false;
+    // counter-clockwise from the up-crossing (right side, x = xu): the upper vertices g[eu + 1 .. ed], then from the down-crossing (left
+    // side, x = xd) the lower vertices g[ed + 1 .. eu]
+    std::vector<GPt> up_ccw, lo_ccw;
+    for (size_t j = ((size_t)eu + 1) % m;; j = (j + 1) % m) { up_ccw.push_back(g[j]); if (j == (size_t)ed) break; }
+    for (size_t j = ((size_t)ed + 1) % m;; j = (j + 1) % m) { lo_ccw.push_back(g[j]); if (j == (size_t)eu) break; }
+    upper.clear(); lower.clear();
+    if (go_left) {                   // from the right (xu) to the left (xd): upper chain counter-clockwise, lower chain clockwise
+        nearx = xu; farx = xd;
+        upper = up_ccw;
+        lower.assign(lo_ccw.rbegin(), lo_ccw.rend());
+    } else {
+        nearx = xd; farx = xu;
+        upper.assign(up_ccw.rbegin(), up_ccw.rend());
+        lower = lo_ccw;
+    }
+    return true;
+}
+
 // the host's primitive sink: a block's list; with obstacle-aware swaths also the field's obstacle polygons
 struct HostSink {
     std::vector<DevPrim> *prims;      // NULL: sizes only (fcpp_plan_count)
@@ -196,6 +288,7 @@ struct HostSink {
     // obstacle-aware swaths: the field's merged grown boxes in the frame of layer 1 and that frame (set by clipped_layer1, used by layer 2)
     struct Box { double x0, y0, x1, y1; };
     std::vector<Box> boxes;
+    std::vector<std::vector<GPt>> gpoly;      // per box: the grown polygon of its obstacle (empty: merged boxes, or no polygon)
     bool fr_rotated = false;
     double fr_c = 1.0, fr_s = 0.0, fr_cx = 0.0, fr_cy = 0.0;
     void to_frame(double &x, double &y) const { if (fr_rotated) rotate_point(x, y, fr_c, -fr_s, fr_cx, fr_cy, x, y); }
@@ -341,7 +434,7 @@ struct HostSink {
         const bool cloth = pc.cloth != 0, rotated = fr.rotated != 0;
         const double rot = fr.rot, ccx = fr.ccx, ccy = fr.ccy, lsx = fr.lsx, lex = fr.lex, min_y = fr.min_y, max_y = fr.max_y;
         const int64_t P = fr.P, n_turn = fr.n_turn;
-        boxes.clear();
+        boxes.clear(); gpoly.clear();
         double rc, rs;
         fc_sincos(rot, rs, rc);
         fr_rotated = rotated; fr_c = rc; fr_s = rs; fr_cx = ccx; fr_cy = ccy;
@@ -351,14 +444,17 @@ struct HostSink {
             const int64_t a0 = polys->offsets[f.obstacle_first + k], a1 = polys->offsets[f.obstacle_first + k + 1];
             if (a1 <= a0) continue;
             Box b = { HUGE_VAL, HUGE_VAL, -HUGE_VAL, -HUGE_VAL };
+            std::vector<GPt> pts;
             for (int64_t q2 = a0; q2 < a1; ++q2) {
                 double ox = polys->x[q2], oy = polys->y[q2];
                 if (!(isfinite(ox) && isfinite(oy))) { bad_obs = true; break; }
                 if (rotated) rotate_point(ox, oy, ca, sa, ccx, ccy, ox, oy);
                 b.x0 = std::min(b.x0, ox); b.x1 = std::max(b.x1, ox); b.y0 = std::min(b.y0, oy); b.y1 = std::max(b.y1, oy);
+                pts.push_back({ ox, oy });
             }
             b.x0 -= W / 2; b.y0 -= W / 2; b.x1 += W / 2; b.y1 += W / 2;
             boxes.push_back(b);
+            gpoly.push_back(bad_obs ? std::vector<GPt>() : grown_polygon(pts, W / 2, b.x0, b.y0, b.x1, b.y1));
         }
         if (bad_obs) return FCPP_ESIZE;
         // grown boxes that overlap or touch become ONE box (their bounding box), until no two do: the boxes are then disjoint,
@@ -372,6 +468,7 @@ struct HostSink {
                     if (a.x0 <= b.x1 + 1e-9 && b.x0 <= a.x1 + 1e-9 && a.y0 <= b.y1 + 1e-9 && b.y0 <= a.y1 + 1e-9) {
                         a.x0 = std::min(a.x0, b.x0); a.y0 = std::min(a.y0, b.y0); a.x1 = std::max(a.x1, b.x1); a.y1 = std::max(a.y1, b.y1);
                         boxes.erase(boxes.begin() + (long)j);
+                        gpoly[i].clear(); gpoly.erase(gpoly.begin() + (long)j);      // (merged boxes are passed as a box)
                         merged = true;
                     } else ++j;
                 }
@@ -445,6 +542,35 @@ struct HostSink {
                 if (!(b.x0 > lo + 1e-9 && b.x1 < hi - 1e-9) || !(go_left ? nearx < cur - 1e-9 : nearx > cur + 1e-9)) { unsupported = true; break; }
                 // over the nearer side (top or bottom) if that keeps the detour inside the work area's y-range, else over the
                 // other one; a box that leaves room on neither side cannot be driven around
+                const std::vector<GPt> &g = gpoly[(size_t)blk[k]];
+                if (!g.empty()) {
+                    // Round 4: along the obstacle's W/2-grown POLYGON -- the swath is worked up to the polygon, not to its box, and the way
+                    // around is the shorter of its upper and lower chain that stays inside the work area's y-range (never longer than
+                    // the box's three legs; a line that passes clear of the polygon is not interrupted at all)
+                    double pnear, pfar;
+                    std::vector<GPt> upper, lower;
+                    if (!polygon_chains(g, y, go_left, pnear, pfar, upper, lower)) continue;
+                    auto chain_len = [&](const std::vector<GPt> &c) {
+                        double l = 0, qx = pnear, qy = y;
+                        for (const GPt &p : c) { l += sqrt((p.x - qx) * (p.x - qx) + (p.y - qy) * (p.y - qy)); qx = p.x; qy = p.y; }
+                        return l + sqrt((pfar - qx) * (pfar - qx) + (y - qy) * (y - qy));
+                    };
+                    bool top_ok = true, bot_ok = true;
+                    for (const GPt &p : upper) top_ok = top_ok && p.y <= max_y + 1e-9;
+                    for (const GPt &p : lower) bot_ok = bot_ok && p.y >= min_y - 1e-9;
+                    if (!top_ok && !bot_ok) { unsupported = true; break; }
+                    const bool take_top = top_ok && (!bot_ok || chain_len(upper) <= chain_len(lower));
+                    const std::vector<GPt> &c = take_top ? upper : lower;
+                    push_line(cur, y, pnear, y, FCPP_KIND_SWATH, pi, veh.max_work_speed_kmh, false);
+                    double qx = pnear, qy = y;
+                    for (const GPt &p : c) {
+                        if (fabs(p.x - qx) + fabs(p.y - qy) > 1e-9) push_line(qx, qy, p.x, p.y, FCPP_KIND_DETOUR, pi, veh.headland_turn_speed_kmh, true);
+                        qx = p.x; qy = p.y;
+                    }
+                    push_line(qx, qy, pfar, y, FCPP_KIND_DETOUR, pi, veh.headland_turn_speed_kmh, true);
+                    cur = pfar;
+                    continue;
+                }
                 const bool top_ok = b.y1 <= max_y + 1e-9, bot_ok = b.y0 >= min_y - 1e-9;
                 const bool want_top = b.y1 - y <= y - b.y0;
                 if (!top_ok && !bot_ok) { unsupported = true; break; }

@@ -78,13 +78,17 @@ enum { FCPP_RING_AS_VERTICES = 0, FCPP_RING_REVERSED = 1 };
  * working_width / 2 and taken out of the work area).  Build-defined -- the reference has no code for it.  In the frame of layer 1
  * (MLP:686-687) every obstacle is represented by the bounding box of its vertices grown by W/2 on every side; grown boxes that overlap
  * or touch are merged into their common bounding box until no two do, so the boxes are disjoint.  A swath line whose y lies strictly
- * inside a box is CLIPPED at the box: the vehicle works up to the box's near side, drives three straight legs around it -- along
- * the near side to the box's top or bottom, along that side, and back along the far side to the line -- and resumes the swath
- * (segment kind FCPP_KIND_DETOUR, nominal speed headland_turn_speed_kmh; sampled like the reverse fills at the reference's sampling:
- * 0.5 m, at least 2 points per leg).  The legs run on the boundary of their own box and the boxes are disjoint: no leg enters another
- * obstacle.  The side is the closer one (top or bottom) unless it lies outside the y-range of the main work area (the detour would
- * enter the headland), then the other; a box with room on neither side is refused.  Sub-swaths and legs are numpy.linspace runs
- * between their end points in field coordinates.
+ * inside a box is CLIPPED there and led around the obstacle (segment kind FCPP_KIND_DETOUR, nominal speed headland_turn_speed_kmh; legs
+ * sampled like the reverse fills at the reference's sampling: 0.5 m, at least 2 points per leg):
+ *   - an obstacle whose box was not merged: along its W/2-grown POLYGON (round 4) -- the convex hull of its vertices, every edge moved
+ *     W/2 outwards, neighbours joined at their mitre point, clipped to the grown box; it contains every point within W/2 of the hull.
+ *     The swath is worked up to where its line meets the polygon, the way around is the shorter of the polygon's upper and lower chain
+ *     between the two meeting points that stays inside the y-range of the main work area (never longer than the box's three legs), and a
+ *     line that passes clear of the polygon is not interrupted;
+ *   - merged boxes: three straight legs along the box -- up or down its near side, along its top or bottom (the closer one unless it lies
+ *     outside the y-range of the main work area), back along its far side.
+ * The legs stay inside their own box and the boxes are disjoint: no leg enters another obstacle.  A box (or polygon) with room on neither
+ * side is refused.  Sub-swaths and legs are numpy.linspace runs between their end points in field coordinates.
  * End zones (round 4): the turn after a pass starts where its line ends and occupies a zone beyond that end -- the reference's half
  * circle about (max_x, y): 2 R along the line and R above it; the clothoid turn: the extents of its shape.  A box that meets that zone,
  * or either of the two lines within it, moves the turn inwards until the zone is free (again if the moved zone meets another box): both

@@ -775,6 +775,123 @@ static int headland_straight_around(pbuf *pb, double wax, double way, double wbx
     return rc;
 }
 
+/* ---- BUILD-DEFINED (round 4): the W/2-grown POLYGON of an obstacle in the frame of layer 1.  Convex hull of the vertices
+ * (counter-clockwise, Andrew's monotone chain), every edge moved `half` outwards, neighbours joined at their mitre point, the result
+ * clipped to the obstacle's grown bounding box (Sutherland-Hodgman).  -> vertices written to g (capacity 2 n + 8), 0: no polygon. ---- */
+static int cmp_xy(const void *a, const void *b)
+{
+    const double *p = (const double *)a, *q = (const double *)b;
+    if (p[0] != q[0]) return p[0] < q[0] ? -1 : 1;
+    if (p[1] != q[1]) return p[1] < q[1] ? -1 : 1;
+    return 0;
+}
+static double cross3(const double *o, const double *a, const double *b) { return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]); }
+static int grown_polygon(double *pts /* n x 2, sorted in place */, int n, double half, double x0, double y0, double x1, double y1, double *g)
+{
+    if (n < 3) return 0;
+    qsort(pts, (size_t)n, 2 * sizeof(double), cmp_xy);
+    double *h = (double *)malloc((size_t)(2 * n + 2) * 2 * sizeof(double));
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        while (k >= 2 && cross3(h + 2 * (k - 2), h + 2 * (k - 1), pts + 2 * i) <= 0) --k;
+        h[2 * k] = pts[2 * i]; h[2 * k + 1] = pts[2 * i + 1]; ++k;
+    }
+    for (int i = n - 2, t = k + 1; i >= 0; --i) {
+        while (k >= t && cross3(h + 2 * (k - 2), h + 2 * (k - 1), pts + 2 * i) <= 0) --k;
+        h[2 * k] = pts[2 * i]; h[2 * k + 1] = pts[2 * i + 1]; ++k;
+    }
+    int m = k - 1;
+    if (m < 3) { free(h); return 0; }
+    double *nrm = (double *)malloc((size_t)m * 2 * sizeof(double));
+    double *a = (double *)malloc((size_t)(2 * n + 8) * 2 * sizeof(double)), *b = (double *)malloc((size_t)(2 * n + 8) * 2 * sizeof(double));
+    int ok = 1, na = m;
+    for (int i = 0; i < m && ok; ++i) {
+        int j = (i + 1) % m;
+        double dx = h[2 * j] - h[2 * i], dy = h[2 * j + 1] - h[2 * i + 1], ln = sqrt(dx * dx + dy * dy);
+        if (!(ln > 0)) ok = 0;
+        else { nrm[2 * i] = dy / ln; nrm[2 * i + 1] = -dx / ln; }
+    }
+    for (int i = 0; i < m && ok; ++i) {
+        int j = (i + m - 1) % m;
+        double den = 1.0 + (nrm[2 * j] * nrm[2 * i] + nrm[2 * j + 1] * nrm[2 * i + 1]);
+        if (!(den > 1e-12)) ok = 0;
+        else { a[2 * i] = h[2 * i] + half * (nrm[2 * j] + nrm[2 * i]) / den; a[2 * i + 1] = h[2 * i + 1] + half * (nrm[2 * j + 1] + nrm[2 * i + 1]) / den; }
+    }
+    for (int side = 0; side < 4 && ok; ++side) {
+        int nb = 0;
+        for (int i = 0; i < na; ++i) {
+            const double *p = a + 2 * i, *q = a + 2 * ((i + 1) % na);
+            /* (a vertex ON the box is inside whichever way its last bit fell) */
+            int ip = side == 0 ? p[0] >= x0 - 1e-9 : (side == 1 ? p[0] <= x1 + 1e-9 : (side == 2 ? p[1] >= y0 - 1e-9 : p[1] <= y1 + 1e-9));
+            int iq = side == 0 ? q[0] >= x0 - 1e-9 : (side == 1 ? q[0] <= x1 + 1e-9 : (side == 2 ? q[1] >= y0 - 1e-9 : q[1] <= y1 + 1e-9));
+            if (ip) { b[2 * nb] = p[0]; b[2 * nb + 1] = p[1]; ++nb; }
+            if (ip != iq) {
+                if (side < 2) { double xc = side == 0 ? x0 : x1; b[2 * nb] = xc; b[2 * nb + 1] = p[1] + (q[1] - p[1]) * ((xc - p[0]) / (q[0] - p[0])); }
+                else { double yc = side == 2 ? y0 : y1; b[2 * nb + 1] = yc; b[2 * nb] = p[0] + (q[0] - p[0]) * ((yc - p[1]) / (q[1] - p[1])); }
+                ++nb;
+            }
+        }
+        double *t = a; a = b; b = t;
+        na = nb;
+        if (na < 3) ok = 0;
+    }
+    int ng = 0;
+    if (ok) {                          /* vertices closer than 1e-7 to their predecessor are one vertex */
+        for (int i = 0; i < na; ++i)
+            if (ng == 0 || fabs(a[2 * i] - g[2 * (ng - 1)]) + fabs(a[2 * i + 1] - g[2 * (ng - 1) + 1]) > 1e-7) { g[2 * ng] = a[2 * i]; g[2 * ng + 1] = a[2 * i + 1]; ++ng; }
+        while (ng > 1 && fabs(g[0] - g[2 * (ng - 1)]) + fabs(g[1] - g[2 * (ng - 1) + 1]) <= 1e-7) --ng;
+        if (ng < 3) ng = 0;
+    }
+    free(h); free(nrm); free(a); free(b);
+    return ng;
+}
+/* where a line at height y meets the polygon g (m vertices, counter-clockwise, convex) and the vertices of the upper / lower chain from
+ * the near point to the far point of a pass travelling left or right; 0: the line passes clear of the polygon */
+static int polygon_chains(const double *g, int m, double y, int go_left, double *nearx, double *farx, double *upper, int *nu, double *lower, int *nl)
+{
+    int eu = -1, ed = -1;
+    double xu = 0, xd = 0;
+    for (int j = 0; j < m; ++j) {
+        const double *a = g + 2 * j, *b = g + 2 * ((j + 1) % m);
+        if ((a[1] < y) == (b[1] < y)) continue;
+        double x = a[0] + (b[0] - a[0]) * ((y - a[1]) / (b[1] - a[1]));
+        if (a[1] < y) { eu = j; xu = x; } else { ed = j; xd = x; }
+    }
+    if (eu < 0 || ed < 0) return 0;
+    int cu = 0, cl = 0;
+    /* counter-clockwise: after the up-crossing (right side) the upper vertices g[eu + 1 .. ed], after the down-crossing the lower ones */
+    for (int j = (eu + 1) % m;; j = (j + 1) % m) { upper[2 * cu] = g[2 * j]; upper[2 * cu + 1] = g[2 * j + 1]; ++cu; if (j == ed) break; }
+    for (int j = (ed + 1) % m;; j = (j + 1) % m) { lower[2 * cl] = g[2 * j]; lower[2 * cl + 1] = g[2 * j + 1]; ++cl; if (j == eu) break; }
+    if (go_left) {                     /* right to left: upper chain as listed, lower chain reversed */
+        *nearx = xu; *farx = xd;
+        for (int i = 0; i < cl / 2; ++i) for (int c = 0; c < 2; ++c) { double t = lower[2 * i + c]; lower[2 * i + c] = lower[2 * (cl - 1 - i) + c]; lower[2 * (cl - 1 - i) + c] = t; }
+    } else {
+        *nearx = xd; *farx = xu;
+        for (int i = 0; i < cu / 2; ++i) for (int c = 0; c < 2; ++c) { double t = upper[2 * i + c]; upper[2 * i + c] = upper[2 * (cu - 1 - i) + c]; upper[2 * (cu - 1 - i) + c] = t; }
+    }
+    *nu = cu; *nl = cl;
+    return 1;
+}
+/* one leg of a pass in obstacle-aware mode: a numpy.linspace run between its end points in FIELD coordinates */
+static void avoid_leg(pbuf *pb, double ax, double ay, double bxx, double byy, int is_detour, uint32_t fs, double ds, int rotated, double rot, double ccx,
+                      double ccy, const orc_vehicle *veh)
+{
+    double len = sqrt((bxx - ax) * (bxx - ax) + (byy - ay) * (byy - ay));
+    int64_t np;
+    if (ds > 0) np = n_for_length(len, ds);
+    else if (is_detour) { np = (int64_t)(len / 0.5) + 1; if (np < 2) np = 2; }
+    else np = 2;
+    if (rotated) {
+        double o[2];
+        orc_rotate_point(ax, ay, rot, ccx, ccy, o); ax = o[0]; ay = o[1];
+        orc_rotate_point(bxx, byy, rot, ccx, ccy, o); bxx = o[0]; byy = o[1];
+    }
+    double *lb = (double *)malloc((size_t)np * 2 * sizeof(double));
+    orc_straight(ax, ay, bxx, byy, np, lb);
+    pb_push(pb, lb, np, is_detour ? veh->headland_turn_speed_kmh : veh->max_work_speed_kmh, fs);
+    free(lb);
+}
+
 /* MLP:720-789 with the reference's 2-point lines / 20-point arcs */
 int64_t orc_u_pattern(double min_x, double min_y, double max_x, double max_y, int reverse_order,
                       int start_from_right, const orc_vehicle *veh, double *xy, double *v, int64_t cap)
@@ -897,10 +1014,14 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
         int nb = f->n_obstacles;
         bx0 = (double *)malloc((size_t)(nb + 1) * 4 * sizeof(double)); by0 = bx0 + nb + 1; bx1 = by0 + nb + 1; by1 = bx1 + nb + 1;
         int *ord = (int *)malloc((size_t)(nb + 1) * sizeof(int));
+        /* per box the W/2-grown polygon of its obstacle (round 4; gn = 0: merged boxes or no polygon -- passed as a box) */
+        double **gp = (double **)calloc((size_t)(nb + 1), sizeof(double *));
+        int *gn = (int *)calloc((size_t)(nb + 1), sizeof(int)), gmax = 8;
         for (int k = 0; k < nb; ++k) {
             int64_t a0 = f->obs_offsets[k], a1 = f->obs_offsets[k + 1];
             if (a1 <= a0) continue;
             double x0 = HUGE_VAL, y0 = HUGE_VAL, x1 = -HUGE_VAL, y1 = -HUGE_VAL;
+            double *pts = (double *)malloc((size_t)(a1 - a0) * 2 * sizeof(double));
             for (int64_t q = a0; q < a1; ++q) {
                 double o[2] = { f->obs_xy[2 * q], f->obs_xy[2 * q + 1] };
                 if (rotated) orc_rotate_point(o[0], o[1], -rot, ccx, ccy, o);
@@ -908,8 +1029,13 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
                 if (o[0] > x1) x1 = o[0];
                 if (o[1] < y0) y0 = o[1];
                 if (o[1] > y1) y1 = o[1];
+                pts[2 * (q - a0)] = o[0]; pts[2 * (q - a0) + 1] = o[1];
             }
             bx0[nbox] = x0 - W / 2; by0[nbox] = y0 - W / 2; bx1[nbox] = x1 + W / 2; by1[nbox] = y1 + W / 2;
+            gp[nbox] = (double *)malloc((size_t)(2 * (a1 - a0) + 8) * 2 * sizeof(double));
+            gn[nbox] = grown_polygon(pts, (int)(a1 - a0), W / 2, bx0[nbox], by0[nbox], bx1[nbox], by1[nbox], gp[nbox]);
+            if (2 * (int)(a1 - a0) + 8 > gmax) gmax = 2 * (int)(a1 - a0) + 8;
+            free(pts);
             ++nbox;
         }
         /* grown boxes that overlap or touch become one box (their bounding box), until no two do (include/fcpp.h) */
@@ -922,7 +1048,9 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
                         if (by0[j] < by0[i]) by0[i] = by0[j];
                         if (bx1[j] > bx1[i]) bx1[i] = bx1[j];
                         if (by1[j] > by1[i]) by1[i] = by1[j];
-                        for (int q = j; q + 1 < nbox; ++q) { bx0[q] = bx0[q + 1]; by0[q] = by0[q + 1]; bx1[q] = bx1[q + 1]; by1[q] = by1[q + 1]; }
+                        gn[i] = 0; free(gp[j]);
+                        for (int q = j; q + 1 < nbox; ++q) { bx0[q] = bx0[q + 1]; by0[q] = by0[q + 1]; bx1[q] = bx1[q + 1]; by1[q] = by1[q + 1]; gp[q] = gp[q + 1]; gn[q] = gn[q + 1]; }
+                        gp[nbox - 1] = NULL;
                         --nbox;
                         merged = 1;
                     } else ++j;
@@ -985,47 +1113,54 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             }
             /* legs of the pass: (ax, ay) -> (bx, by) in the frame, kind */
             double cur = xs;
-            for (int a = 0; a <= m && !unsupported; ++a) {
-                double legs[4][4];
-                uint32_t kinds[4];
-                int nleg = 0;
-                if (a < m) {
-                    int k = ord[a];
-                    double nearx = go_left ? bx1[k] : bx0[k], farx = go_left ? bx0[k] : bx1[k];
-                    if (!(bx0[k] > lo + 1e-9 && bx1[k] < hi - 1e-9) || !(go_left ? nearx < cur - 1e-9 : nearx > cur + 1e-9)) { unsupported = 1; break; }
-                    /* the nearer side if it keeps the detour inside the work area's y-range, else the other; neither: refused */
-                    int top_ok = by1[k] <= max_y + 1e-9, bot_ok = by0[k] >= min_y - 1e-9, want_top = by1[k] - y <= y - by0[k];
+            double *upper = (double *)malloc((size_t)gmax * 4 * sizeof(double)), *lower = upper + 2 * gmax;
+            for (int a = 0; a < m && !unsupported; ++a) {
+                int k = ord[a];
+                double nearx = go_left ? bx1[k] : bx0[k], farx = go_left ? bx0[k] : bx1[k];
+                if (!(bx0[k] > lo + 1e-9 && bx1[k] < hi - 1e-9) || !(go_left ? nearx < cur - 1e-9 : nearx > cur + 1e-9)) { unsupported = 1; break; }
+                if (gn[k] > 0) {
+                    /* round 4: along the obstacle's W/2-grown polygon -- the swath is worked up to the polygon, the way around is the shorter of
+                     * its upper and lower chain that stays inside the work area's y-range; a line that passes clear of it is not interrupted */
+                    double pnear, pfar;
+                    int nu, nl;
+                    if (!polygon_chains(gp[k], gn[k], y, go_left, &pnear, &pfar, upper, &nu, lower, &nl)) continue;
+                    int top_ok = 1, bot_ok = 1;
+                    for (int q = 0; q < nu; ++q) if (!(upper[2 * q + 1] <= max_y + 1e-9)) top_ok = 0;
+                    for (int q = 0; q < nl; ++q) if (!(lower[2 * q + 1] >= min_y - 1e-9)) bot_ok = 0;
                     if (!top_ok && !bot_ok) { unsupported = 1; break; }
-                    double ys = (want_top ? top_ok : !bot_ok) ? by1[k] : by0[k];
-                    double L4[4][4] = { { cur, y, nearx, y }, { nearx, y, nearx, ys }, { nearx, ys, farx, ys }, { farx, ys, farx, y } };
-                    memcpy(legs, L4, sizeof(L4));
-                    kinds[0] = swath; kinds[1] = kinds[2] = kinds[3] = detour;
-                    nleg = 4;
-                    cur = farx;
-                } else {
-                    legs[0][0] = cur; legs[0][1] = y; legs[0][2] = xe; legs[0][3] = y;
-                    kinds[0] = swath;
-                    nleg = 1;
-                }
-                for (int l = 0; l < nleg; ++l) {
-                    double ax = legs[l][0], ay = legs[l][1], bxx = legs[l][2], byy = legs[l][3];
-                    double len = sqrt((bxx - ax) * (bxx - ax) + (byy - ay) * (byy - ay));
-                    int is_detour = kinds[l] == detour;
-                    int64_t np;
-                    if (ds > 0) np = n_for_length(len, ds);
-                    else if (is_detour) { np = (int64_t)(len / 0.5) + 1; if (np < 2) np = 2; }
-                    else np = 2;
-                    if (rotated) {
-                        double o[2];
-                        orc_rotate_point(ax, ay, rot, ccx, ccy, o); ax = o[0]; ay = o[1];
-                        orc_rotate_point(bxx, byy, rot, ccx, ccy, o); bxx = o[0]; byy = o[1];
+                    double lens[2];
+                    for (int w = 0; w < 2; ++w) {
+                        const double *c = w == 0 ? upper : lower;
+                        int nc = w == 0 ? nu : nl;
+                        double l = 0, qx = pnear, qy = y;
+                        for (int q = 0; q < nc; ++q) { l += sqrt((c[2 * q] - qx) * (c[2 * q] - qx) + (c[2 * q + 1] - qy) * (c[2 * q + 1] - qy)); qx = c[2 * q]; qy = c[2 * q + 1]; }
+                        lens[w] = l + sqrt((pfar - qx) * (pfar - qx) + (y - qy) * (y - qy));
                     }
-                    double *lb = (double *)malloc((size_t)np * 2 * sizeof(double));
-                    orc_straight(ax, ay, bxx, byy, np, lb);
-                    pb_push(&pb, lb, np, is_detour ? veh->headland_turn_speed_kmh : veh->max_work_speed_kmh, kinds[l]);
-                    free(lb);
+                    int take_top = top_ok && (!bot_ok || lens[0] <= lens[1]);
+                    const double *c = take_top ? upper : lower;
+                    int nc = take_top ? nu : nl;
+                    avoid_leg(&pb, cur, y, pnear, y, 0, swath, ds, rotated, rot, ccx, ccy, veh);
+                    double qx = pnear, qy = y;
+                    for (int q = 0; q < nc; ++q) {
+                        if (fabs(c[2 * q] - qx) + fabs(c[2 * q + 1] - qy) > 1e-9) avoid_leg(&pb, qx, qy, c[2 * q], c[2 * q + 1], 1, detour, ds, rotated, rot, ccx, ccy, veh);
+                        qx = c[2 * q]; qy = c[2 * q + 1];
+                    }
+                    avoid_leg(&pb, qx, qy, pfar, y, 1, detour, ds, rotated, rot, ccx, ccy, veh);
+                    cur = pfar;
+                    continue;
                 }
+                /* the nearer side if it keeps the detour inside the work area's y-range, else the other; neither: refused */
+                int top_ok = by1[k] <= max_y + 1e-9, bot_ok = by0[k] >= min_y - 1e-9, want_top = by1[k] - y <= y - by0[k];
+                if (!top_ok && !bot_ok) { unsupported = 1; break; }
+                double ys = (want_top ? top_ok : !bot_ok) ? by1[k] : by0[k];
+                avoid_leg(&pb, cur, y, nearx, y, 0, swath, ds, rotated, rot, ccx, ccy, veh);
+                avoid_leg(&pb, nearx, y, nearx, ys, 1, detour, ds, rotated, rot, ccx, ccy, veh);
+                avoid_leg(&pb, nearx, ys, farx, ys, 1, detour, ds, rotated, rot, ccx, ccy, veh);
+                avoid_leg(&pb, farx, ys, farx, y, 1, detour, ds, rotated, rot, ccx, ccy, veh);
+                cur = farx;
             }
+            free(upper);
+            if (!unsupported) avoid_leg(&pb, cur, y, xe, y, 0, swath, ds, rotated, rot, ccx, ccy, veh);
             if (unsupported) break;
             if (idx < P - 1) {
                 int turn_right = !go_left;
@@ -1039,6 +1174,8 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
             }
         }
         free(tb); free(ord); free(clip_lo);
+        for (int k = 0; k <= nb; ++k) free(gp[k]);
+        free(gp); free(gn);
         if (unsupported) { free(bx0); free(pb.xy); free(pb.v); free(pb.fs); return -3; }
     } else {
         double lsx = min_x + R, lex = max_x - R;

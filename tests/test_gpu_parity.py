@@ -285,7 +285,7 @@ def _clip_fields():
     # a multiple of 0.5 m long up to the rounding of the rotation into the frame of layer 1 and back -- a count that hinges on the last bit of a
     # sine is as platform-dependent here as the reference's own int((max_y - min_y) / W); the library takes its
     # setup's sine / cosine from csrc/fcpp_math.h, the oracle from the platform libm)
-    para_obs = [tilt([(200.0, 100.33), (230.0, 100.33), (230.0, 125.27), (200.0, 125.27)]), tilt([(340.0, 150.03), (365.0, 160.0), (350.0, 185.07)])]
+    para_obs = [tilt([(200.0, 100.33), (230.07, 100.33), (230.07, 125.27), (200.0, 125.27)]), tilt([(340.0, 150.03), (365.0, 160.0), (350.0, 185.07)])]
     specs.append(E.FieldSpec(field_vertices=verts, obstacles=para_obs))
     ofs.append(orc.make_field(verts=verts, obstacles=para_obs))
     return specs, ofs
@@ -307,6 +307,31 @@ def test_obstacle_aware_swaths_vs_oracle(opt):
     assert int(st['n_in_obstacle'].sum()) == 0 and int((fs & L.FLAG_OBSTACLE != 0).sum()) == 0
     assert int(((fs & L.KIND_MASK) == L.KIND_DETOUR).sum()) > 0
     assert all(i.status == 0 for i in b.info)
+    # Round 4: the detours follow the obstacles' W/2-grown POLYGONS.  Field 0 (unrotated; square, triangle, pentagon): every detour point
+    # keeps W/2 from every obstacle, and a pass near the triangle's apex leaves its line for a much shorter stretch than the box is wide.
+    W = DEFAULT_VP[0]
+    sl = res.field_slice(0)
+    x0, y0, f0 = _np(res.x)[sl], _np(res.y)[sl], fs[sl]
+    det = ((f0 & L.KIND_MASK) == L.KIND_DETOUR) & ((f0 & L.FLAG_HEADLAND) == 0)
+
+    def dist_to_polygon(px, py, poly):
+        q = np.asarray(poly, dtype=np.float64)
+        d = np.full(px.shape, np.inf)
+        for a, c in zip(q, np.roll(q, -1, axis=0)):
+            e = c - a
+            t = np.clip(((px - a[0]) * e[0] + (py - a[1]) * e[1]) / (e @ e), 0.0, 1.0)
+            d = np.minimum(d, np.hypot(px - (a[0] + t * e[0]), py - (a[1] + t * e[1])))
+        return d
+    for poly in specs[0].obstacles:
+        assert dist_to_polygon(x0[det], y0[det], poly).min() >= W / 2 - 1e-6
+    tri = np.asarray(specs[0].obstacles[1])
+    sw = (f0 & L.KIND_MASK) == L.KIND_SWATH
+    pass_y = np.unique(np.round(y0[sw], 6))
+    in_box = pass_y[(pass_y > tri[:, 1].min() - W / 2) & (pass_y < tri[:, 1].max() + W / 2)]
+    near = det & (x0 > tri[:, 0].min() - W) & (x0 < tri[:, 0].max() + W) & (y0 > tri[:, 1].min() - W) & (y0 < tri[:, 1].max() + W)
+    # (the swath is worked up to the polygon, not to its box: near the triangle's apex the detours begin well inside the box's x-range)
+    spans = [np.ptp(x0[near & ((f0 >> L.INDEX_SHIFT) == k)]) for k in np.unique(f0[near] >> L.INDEX_SHIFT)]
+    assert len(spans) == len(in_box) and min(spans) < (np.ptp(tri[:, 0]) + W) - 6.0, (spans, np.ptp(tri[:, 0]) + W)
     b.close()
     if opt.get('sample_spacing', 0.0) > 0:
         b0 = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**opt))
@@ -395,7 +420,8 @@ def test_headland_loops_go_around_obstacles(opt):
     c, s = np.cos(rot), np.sin(rot)
     tilt = lambda pts: [(float(x * c - y * s), float(x * s + y * c)) for x, y in pts]
     verts = tilt([(0.0, 0.0), (500.0, 0.0), (560.0, 260.0), (60.0, 260.0)])
-    para_obs = [tilt([(52.0, 150.0), (61.0, 150.0), (61.0, 162.0), (52.0, 162.0)]), tilt([(300.0, 4.0), (318.0, 4.0), (318.0, 9.0), (300.0, 9.0)])]
+    # (sides off the half-metre grid of the detour legs' sample counts, as in _clip_fields)
+    para_obs = [tilt([(52.0, 150.13), (61.07, 150.13), (61.07, 162.41), (52.0, 162.41)]), tilt([(300.0, 4.0), (318.03, 4.0), (318.03, 9.17), (300.0, 9.17)])]
     layouts = [right, top, right + top, corner]
     specs = [E.FieldSpec(field_length=400.0, field_width=220.0, obstacles=o) for o in layouts] + [E.FieldSpec(field_vertices=verts, obstacles=para_obs)]
     ofs = [orc.make_field(L=400.0, H=220.0, obstacles=o) for o in layouts] + [orc.make_field(verts=verts, obstacles=para_obs)]
