@@ -67,7 +67,7 @@ struct DevPlanTables {
 
 // the device tiler's LDS window over a field's general stretch (it slides), and the most primitives a field may have (8-bit indices in
 // that window); a batch whose vehicle needs more (31+ headland loops) is set up on the host
-constexpr int DEVPLAN_WINDOW = 640;
+constexpr int DEVPLAN_WINDOW = 576;
 constexpr int DEVPLAN_PRIMS_CAP = 255;
 constexpr int DEVPLAN_KEEP_TILES = 8;
 
