@@ -151,7 +151,7 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     mid = sorted(warm, key=lambda r: r['ms'])[(len(warm) - 1) // 2]
     end_to_end = {'ms': mid['ms'], 'points_per_s': n_points / (mid['ms'] * 1e-3), 'create_ms': mid['create_ms'],
                   'alloc_run_sync_ms': mid['alloc_run_sync_ms'], 'setup_ms': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mid['setup_ms'].items()},
-                  'first_ms': e2e[0]['ms'], 'all_ms': [round(r['ms'], 3) for r in e2e], 'reps': len(e2e),
+                  'first_ms': e2e[0]['ms'], 'all_ms': [round(r['ms'], 3) for r in e2e[:16]], 'reps': len(e2e),
                   'what': 'fresh batch in a warm context: engine.Batch(table) [fcpp_batch_create: host plan + tiler + image + one H2D copy] + output '
                           'arrays + one step + stream drained; median of the repetitions after the first; the reference times this call '
                           '(plan_complete_coverage, MLP:387-465)'}
@@ -491,8 +491,11 @@ def main():
                 pending[-1].wait()
         fence()
 
+    # (the plan call end to end 200 times, ~50 ms: enough repetitions for a median that means something at 0.25 ms a call.  The timed
+    # region that follows is SHORT -- K = 20 steps of ~0.06 ms -- and reads ~10 % slower than the sustained rate of the same step, which the
+    # device reaches only after some 20 ms of uninterrupted steps: tools/short_region.py, profiles/r04_short_region.log)
     r = run_planner(E, torch, E.FieldTable.from_rectangles(LH1), E.make_options(), args.steps, args.warmup, mode=args.mode, fence=fence_headline,
-                    after_step=count_and_gather, stats_of=stats_slot if use_dist else None)
+                    after_step=count_and_gather, stats_of=stats_slot if use_dist else None, e2e_reps=200)
     dt = allmax(r['dt'])
     total_points = allsum(r['points'])
     e2e_ms = allmax(r['end_to_end']['ms'])
@@ -570,7 +573,8 @@ def main():
         if 'cfg1_clothoid' in want:
             e = planner_config('cfg1_clothoid', f'cfg1 x {args.fields}, clothoid turns (line-clothoid-arc-clothoid-line) at the reference\'s sample counts',
                                T1, E.make_options(1, 0.0), args.steps, args.warmup,
-                               lambda k: orc.make_field(L=500.0, H=200.0), len(LH1), orc.Options.make(1, 1, 0.0, 0.5), what='500 x 200 m fields, clothoid, reference sampling')
+                               lambda k: orc.make_field(L=500.0, H=200.0), len(LH1), orc.Options.make(1, 1, 0.0, 0.5), what='500 x 200 m fields, clothoid, reference sampling',
+                               e2e_reps=200)
             # (BASELINE.json's metric names the clothoid sampler: the same batch with clothoid turns, at top level beside the pinned arc model)
             out['value_clothoid'], out['ms_per_step_clothoid'], out['value_end_to_end_clothoid'] = e['value'], e['ms_per_step'], e['value_end_to_end']
         if 'cfg1_clothoid_dense' in want:
@@ -589,7 +593,7 @@ def main():
             planner_config(key, wl, T2, E.make_options(tm, sp), st_, wu,
                            lambda k: orc.make_field(L=float(LH2[k, 0]), H=float(LH2[k, 1])), len(LH2), orc.Options.make(tm, 1, sp, 0.5),
                            what=f'cfg2 fields, {"arcs, reference sampling" if sp == 0 else f"clothoid, {sp} m"}', calibrate=args.calibrate if sp > 0 else 0,
-                           e2e_reps=5 if sp == 0 else 3)
+                           e2e_reps=200 if sp == 0 else 3)
         if 'cfg3' in want:
             (L3, H3), obst = WL.cfg3_field()
 

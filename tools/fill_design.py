@@ -37,8 +37,8 @@ sub['G_MS'], sub['G_V'] = g(g4.get('ms_total', g4.get('ms_per_step'))), sci(g4['
 cb = d['cpu_baseline']
 sub['CPU'] = f'{sci(cb["value"])} ({sci(cb["single_core_value"])} on one thread)'
 al = json.load(open(os.path.join(REPO, 'profiles', f'{ROUND}_arena_live.json')))
-sub['ARENA'] = ', '.join(f'{k} {al["ms_solo"][k]:.3f} ms alone, {al["ms_all_alive"][k]:.3f} ms with all three alive' for k in al['ms_solo']) + \
-    f' ({al["device_GiB_held_by_process"]} GiB of device memory held by the process)'
+sub['ARENA'] = ', '.join(f'{k} {al["ms_solo"][k]:.3f} / {al["ms_all_alive"][k]:.3f}' for k in al['ms_solo']) + \
+    f' ms alone / with all three alive ({al["device_GiB_held_by_process"]} GiB held by the process)'
 tj = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json')))
 pts = {'k_plan_sparse_fields|cfg1': 6926336, 'k_plan_quiet_spans|cfg5': 240011750, 'k_plan_quiet|cfg2_0.1': None}
 tr = []

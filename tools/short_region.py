@@ -54,6 +54,27 @@ for k in (20, 200, 2000):
             batch.set_profiling(False)
         out[f'K{k}_{name}'] = r
         print(f'K{k}_{name}', json.dumps(r), flush=True)
+# bench.py's own region: HIP events around the K launches, five regions back to back -- each region's time, in order
+for trial in range(3):
+    t = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(20):
+            batch.run(bufs)
+        e1.record()
+        torch.cuda.synchronize()
+        t.append(((time.perf_counter() - t0) / 20 * 1e6, e0.elapsed_time(e1) / 20 * 1e3))
+    print('K20 with events around the region, 5 in a row (wall, events):', [(round(a, 1), round(b, 1)) for a, b in t], flush=True)
+    t = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(20):
+            batch.run(bufs)
+        torch.cuda.synchronize()
+        t.append((time.perf_counter() - t0) / 20 * 1e6)
+    print('K20 without events, 5 in a row:', [round(a, 1) for a in t], flush=True)
 # where the five arrays lie: plain tensors (above), the context's arena (five lanes 24 GiB apart), plain tensors again with the arena held
 ctx = E.get_context()
 ctx.reserve_outputs(24.0, 24.0)
