@@ -60,7 +60,8 @@ struct DevField {
     int32_t prim_first, prim_count;   // headland primitives
     // validator
     int32_t obs_first, obs_count;     // obstacle polygons (batch polygon table)
-    int32_t _pad;
+    int32_t span_inside;              // 1: the bounding box of layer 1's lines and U-turns lies inside the geofence with the tiler's margin --
+                                      // no point of its closed-form span can be flagged, the span kernels skip the four edge tests per point
     double ex[4], ey[4], eo[4];       // field edges as inward unit normals: inside <=> ex*px + ey*py + eo >= -tol
 };
 

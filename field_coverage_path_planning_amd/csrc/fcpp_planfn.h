@@ -425,6 +425,25 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
             df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
         }
     }
+    if (!clip && lsx < lex) {
+        // Do layer 1's lines and U-turns all lie inside the geofence?  Their bounding box in the frame -- the lines' ends plus a U-turn's
+        // extent beyond them on either side, the passes' heights plus a U-turn's height (clothoid turns: 0.1 % of R for what the extents'
+        // sampling may have missed) -- is convex like the field: inside iff its four corners are, with the tiler's margin (fcpp_tilefn.h: tiler_inside).
+        const double slack = cloth ? 1e-3 * R : 0.0;       // (the reference's half circle: 2 R and R exactly -- its far end lies ON the field's edge when the headland is R wide)
+        const double ext = pc.uturn_dx + slack, hgt = pc.uturn_h + slack;
+        const double bx[2] = { lsx - ext, lex + ext }, by[2] = { min_y, min_y + (double)(P - 1) * W + hgt };
+        const double margin = 1e-7 - opt.geofence_tol;
+        bool in = true;
+        for (int cxi = 0; cxi < 2; ++cxi)
+            for (int cyi = 0; cyi < 2; ++cyi) {
+                double px = bx[cxi], py = by[cyi];
+                if (rotated) { const double tx = px - ccx, ty = py - ccy; px = (tx * rc - ty * rs) + ccx; py = (tx * rs + ty * rc) + ccy; }
+                const double m = margin + 5.684341886080802e-14 * (fabs(px) + fabs(py));      // (256 ulps of the coordinates)
+                for (int e = 0; e < 4; ++e)
+                    if (!(df.ex[e] * px + df.ey[e] * py + df.eo[e] >= m)) in = false;
+            }
+        df.span_inside = in ? 1 : 0;
+    }
     return pos;
 #undef FCPP_FAIL
 }

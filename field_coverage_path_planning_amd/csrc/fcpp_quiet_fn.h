@@ -130,6 +130,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
         double e2x = q.ex[2], e2y = q.ey[2], e2o = q.eo[2], e3x = q.ex[3], e3y = q.ey[3], e3o = q.eo[3];
         double ntl = ntol;
         int n_obs = q.obs_count;
+        const bool fence = q.span_inside == 0;      // (wave-uniform: a span that lies inside the geofence as a whole is not tested point by point)
         FCPP_PIN(per); FCPP_PIN(nl); FCPP_PIN(last); FCPP_PIN(n_pass); FCPP_PIN(idx_base); FCPP_PIN(rev); FCPP_PIN(sfr); FCPP_PIN(rotated);
         FCPP_PIN(xr); FCPP_PIN(xl); FCPP_PIN(k_last); FCPP_PIN(k_start); FCPP_PIN(min_y); FCPP_PIN(Wd); FCPP_PIN(lstep); FCPP_PIN(lex); FCPP_PIN(lsx);
         FCPP_PIN(v_work); FCPP_PIN(v_turn); FCPP_PIN(n_obs);
@@ -193,10 +194,12 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
             sample(dq1, off1, px1, py1, k1, v1, f1);
             off1 += (int)step_r; dq1 += (int)step_q;
             if (off1 >= per) { off1 -= per; ++dq1; }
-            const bool o0 = has0 && outside_s(px0, py0), o1 = has1 && outside_s(px1, py1);      // turns may leave the field: every point is tested
-            nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
-            f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
-            f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
+            if (fence) {
+                const bool o0 = has0 && outside_s(px0, py0), o1 = has1 && outside_s(px1, py1);  // turns may leave the field: every point is tested
+                nout += (o0 ? 1 : 0) + (o1 ? 1 : 0);
+                f0 |= o0 ? FCPP_FLAG_OUTSIDE : 0u;
+                f1 |= o1 ? FCPP_FLAG_OUTSIDE : 0u;
+            }
             if (OBS && n_obs > 0) {
                 // bounding box of the wave's points of this pass, then the culled polygon tests
                 double mnx = has0 ? px0 : (has1 ? px1 : FCPP_INF), mxx = has0 ? px0 : (has1 ? px1 : -FCPP_INF);
