@@ -203,7 +203,7 @@ static std::vector<GPt> grown_polygon(std::vector<GPt> pts, double half, double 
     h.resize(k - 1);
     const size_t m = h.size();
     if (m < 3) return none;
-    std::vector<GPt> nrm(m), g(m);
+    std::vector<GPt> nrm(m), g;
     for (size_t i = 0; i < m; ++i) {
         const GPt &a = h[i], &b = h[(i + 1) % m];
         const double dx = b.x - a.x, dy = b.y - a.y, ln = sqrt(dx * dx + dy * dy);
@@ -213,8 +213,14 @@ static std::vector<GPt> grown_polygon(std::vector<GPt> pts, double half, double 
     for (size_t i = 0; i < m; ++i) {
         const GPt &n0 = nrm[(i + m - 1) % m], &n1 = nrm[i];
         const double den = 1.0 + (n0.x * n1.x + n0.y * n1.y);
-        if (!(den > 1e-12)) return none;
-        g[i] = { h[i].x + half * (n0.x + n1.x) / den, h[i].y + half * (n0.y + n1.y) / den };
+        if (den >= 0.5) g.push_back({ h[i].x + half * (n0.x + n1.x) / den, h[i].y + half * (n0.y + n1.y) / den });     // mitre (turn <= 120 degrees)
+        else {
+            // a sharp vertex (a needle's tip: the mitre point runs away and loses its digits): a square cap -- the incoming offset
+            // line carried `half` beyond the vertex, the outgoing one begun `half` before it; the chord between them stays >= half
+            // away from the vertex for every turn up to 180 degrees.  (edge direction = outward normal turned by +90 degrees)
+            g.push_back({ h[i].x + half * (n0.x - n0.y), h[i].y + half * (n0.y + n0.x) });
+            g.push_back({ h[i].x + half * (n1.x + n1.y), h[i].y + half * (n1.y - n1.x) });
+        }
     }
     // Sutherland-Hodgman against x >= x0, x <= x1, y >= y0, y <= y1
     for (int side = 0; side < 4; ++side) {

@@ -81,7 +81,8 @@ enum { FCPP_RING_AS_VERTICES = 0, FCPP_RING_REVERSED = 1 };
  * inside a box is CLIPPED there and led around the obstacle (segment kind FCPP_KIND_DETOUR, nominal speed headland_turn_speed_kmh; legs
  * sampled like the reverse fills at the reference's sampling: 0.5 m, at least 2 points per leg):
  *   - an obstacle whose box was not merged: along its W/2-grown POLYGON (round 4) -- the convex hull of its vertices, every edge moved
- *     W/2 outwards, neighbours joined at their mitre point, clipped to the grown box; it contains every point within W/2 of the hull.
+ *     W/2 outwards, neighbours joined at their mitre point (a corner sharper than 60 degrees: a square cap W/2 beyond it), clipped to the
+ *     grown box; it contains every point within W/2 of the hull.
  *     The swath is worked up to where its line meets the polygon, the way around is the shorter of the polygon's upper and lower chain
  *     between the two meeting points that stays inside the y-range of the main work area (never longer than the box's three legs), and a
  *     line that passes clear of the polygon is not interrupted;

@@ -804,18 +804,25 @@ static int grown_polygon(double *pts /* n x 2, sorted in place */, int n, double
     if (m < 3) { free(h); return 0; }
     double *nrm = (double *)malloc((size_t)m * 2 * sizeof(double));
     double *a = (double *)malloc((size_t)(2 * n + 8) * 2 * sizeof(double)), *b = (double *)malloc((size_t)(2 * n + 8) * 2 * sizeof(double));
-    int ok = 1, na = m;
+    int ok = 1, na = 0;
     for (int i = 0; i < m && ok; ++i) {
         int j = (i + 1) % m;
         double dx = h[2 * j] - h[2 * i], dy = h[2 * j + 1] - h[2 * i + 1], ln = sqrt(dx * dx + dy * dy);
         if (!(ln > 0)) ok = 0;
         else { nrm[2 * i] = dy / ln; nrm[2 * i + 1] = -dx / ln; }
     }
+    na = 0;
     for (int i = 0; i < m && ok; ++i) {
         int j = (i + m - 1) % m;
-        double den = 1.0 + (nrm[2 * j] * nrm[2 * i] + nrm[2 * j + 1] * nrm[2 * i + 1]);
-        if (!(den > 1e-12)) ok = 0;
-        else { a[2 * i] = h[2 * i] + half * (nrm[2 * j] + nrm[2 * i]) / den; a[2 * i + 1] = h[2 * i + 1] + half * (nrm[2 * j + 1] + nrm[2 * i + 1]) / den; }
+        double n0x = nrm[2 * j], n0y = nrm[2 * j + 1], n1x = nrm[2 * i], n1y = nrm[2 * i + 1];
+        double den = 1.0 + (n0x * n1x + n0y * n1y);
+        if (den >= 0.5) { a[2 * na] = h[2 * i] + half * (n0x + n1x) / den; a[2 * na + 1] = h[2 * i + 1] + half * (n0y + n1y) / den; ++na; }   /* mitre */
+        else {
+            /* a sharp vertex: a square cap -- the incoming offset line carried `half` beyond the vertex, the outgoing one begun `half`
+             * before it (edge direction = outward normal turned by +90 degrees); the chord stays >= half away from the vertex */
+            a[2 * na] = h[2 * i] + half * (n0x - n0y); a[2 * na + 1] = h[2 * i + 1] + half * (n0y + n0x); ++na;
+            a[2 * na] = h[2 * i] + half * (n1x + n1y); a[2 * na + 1] = h[2 * i + 1] + half * (n1y - n1x); ++na;
+        }
     }
     for (int side = 0; side < 4 && ok; ++side) {
         int nb = 0;
