@@ -627,6 +627,90 @@ static double turn_length(double dth, double R, const orc_options *o)
     return orc_cac_length(dth, Re, o->clothoid_frac);
 }
 
+/* ---- MLP:599-609 + 288, 696, 710: with obstacles the work area is main_boundary.difference(unary_union(obs.buffer(W / 2))) and the
+ * rotation centre of a rotated field is THAT polygon's centroid.  GEOS is not available here; restated for the case that can be written
+ * down exactly: every obstacle convex, its buffer inside the main boundary, the grown bounding boxes pairwise disjoint -- then
+ *     centroid = (A_b c_b - sum A_k c_k) / (A_b - sum A_k)
+ * with A_k, c_k of GEOS' POLYGONAL buffer of obstacle k: the polygon, a W/2-wide rectangle on every edge, and at every vertex a fan of
+ * nSegs = int(theta / (pi / 32) + 0.5) equal triangles over the exterior angle theta (Shapely's default 16 segments per quadrant;
+ * OffsetSegmentGenerator::addDirectedFillet).  Any other case: the main boundary's own centroid (returns 0) -- parity unpinned either way. */
+int orc_difference_centroid(const double *mx, const double *my, const orc_field *f, double r, double *cx, double *cy)
+{
+    double cbx, cby, Ab = fabs(poly_area_centroid(mx, my, 4, &cbx, &cby));
+    int nb = f->n_obstacles;
+    if (nb <= 0) return 0;
+    double area2 = 0.0;
+    for (int i = 0; i < 4; ++i) { int j = (i + 1) % 4; area2 += mx[i] * my[j] - mx[j] * my[i]; }
+    double sgn = area2 > 0 ? 1.0 : -1.0;
+    double *bb = (double *)malloc((size_t)nb * 4 * sizeof(double));
+    double sumA = 0.0, sumAx = 0.0, sumAy = 0.0;
+    int ok = 1, nk = 0;
+    const double quantum = M_PI / 2 / 16;
+    for (int k = 0; k < nb && ok; ++k) {
+        int64_t a0 = f->obs_offsets[k], a1 = f->obs_offsets[k + 1];
+        int n = (int)(a1 - a0);
+        if (n <= 0) continue;
+        if (n < 3) { ok = 0; break; }
+        const double *q = f->obs_xy + 2 * a0;
+        double a2 = 0.0;
+        for (int i = 0; i < n; ++i) { int j = (i + 1) % n; a2 += q[2 * i] * q[2 * j + 1] - q[2 * j] * q[2 * i + 1]; }
+        if (a2 == 0.0) { ok = 0; break; }
+        int rev = a2 < 0;                                   /* walk counter-clockwise */
+#define OBV(i, c) q[2 * (rev ? (n - 1 - ((i) % n)) : ((i) % n)) + (c)]
+        double A = 0.0, Ax = 0.0, Ay = 0.0;               /* accumulated area and first moments of the buffered polygon */
+        double x0 = HUGE_VAL, y0 = HUGE_VAL, x1 = -HUGE_VAL, y1 = -HUGE_VAL;
+        for (int i = 0; i < n && ok; ++i) {
+            double px = OBV(i, 0), py = OBV(i, 1), qx = OBV(i + 1, 0), qy = OBV(i + 1, 1), sx = OBV(i + 2, 0), sy = OBV(i + 2, 1);
+            if (px < x0) x0 = px;
+            if (px > x1) x1 = px;
+            if (py < y0) y0 = py;
+            if (py > y1) y1 = py;
+            /* the polygon itself: fan from the origin */
+            double cr = px * qy - qx * py;
+            A += cr / 2; Ax += cr * (px + qx) / 6; Ay += cr * (py + qy) / 6;
+            double ex = qx - px, ey = qy - py, L = sqrt(ex * ex + ey * ey);
+            if (!(L > 0)) { ok = 0; break; }
+            double nx = ey / L, ny = -ex / L;                /* outward normal of a counter-clockwise polygon */
+            /* the rectangle on edge p -> q */
+            A += L * r; Ax += L * r * ((px + qx) / 2 + nx * r / 2); Ay += L * r * ((py + qy) / 2 + ny * r / 2);
+            /* the fan at vertex q between this edge's normal and the next one's */
+            double fx = sx - qx, fy = sy - qy, L2 = sqrt(fx * fx + fy * fy);
+            if (!(L2 > 0)) { ok = 0; break; }
+            double mx2 = fy / L2, my2 = -fx / L2;
+            double crs = nx * my2 - ny * mx2, dt = nx * mx2 + ny * my2;
+            if (crs < -1e-12) { ok = 0; break; }              /* not convex */
+            double th = atan2(crs < 0 ? 0.0 : crs, dt);
+            int ns = (int)(th / quantum + 0.5);
+            if (ns < 1) ns = 1;
+            double a0n = atan2(ny, nx);
+            for (int t = 0; t < ns; ++t) {
+                double u0 = a0n + th * t / ns, u1 = a0n + th * (t + 1) / ns;
+                double ax = qx + r * cos(u0), ay = qy + r * sin(u0), bx = qx + r * cos(u1), by = qy + r * sin(u1);
+                double ta = ((ax - qx) * (by - qy) - (bx - qx) * (ay - qy)) / 2;
+                A += ta; Ax += ta * (qx + ax + bx) / 3; Ay += ta * (qy + ay + by) / 3;
+                /* the buffer must lie inside the main boundary */
+                for (int e = 0; e < 4; ++e) {
+                    int j = (e + 1) % 4;
+                    double gx = mx[j] - mx[e], gy = my[j] - my[e];
+                    if (sgn * (gx * (ay - my[e]) - gy * (ax - mx[e])) < 0 || sgn * (gx * (by - my[e]) - gy * (bx - mx[e])) < 0) ok = 0;
+                }
+            }
+        }
+#undef OBV
+        if (!ok) break;
+        bb[4 * nk] = x0 - r; bb[4 * nk + 1] = y0 - r; bb[4 * nk + 2] = x1 + r; bb[4 * nk + 3] = y1 + r;
+        for (int o = 0; o < nk; ++o)
+            if (bb[4 * o] <= bb[4 * nk + 2] && bb[4 * nk] <= bb[4 * o + 2] && bb[4 * o + 1] <= bb[4 * nk + 3] && bb[4 * nk + 1] <= bb[4 * o + 3]) ok = 0;
+        ++nk;
+        sumA += A; sumAx += Ax; sumAy += Ay;
+    }
+    free(bb);
+    if (!ok || nk == 0 || !(Ab - sumA > 0.5 * Ab)) return 0;
+    *cx = (Ab * cbx - sumAx) / (Ab - sumA);
+    *cy = (Ab * cby - sumAy) / (Ab - sumA);
+    return 1;
+}
+
 /* ---- BUILD-DEFINED (round 4): obstacle-aware headland.  Boxes in the frame of layer 1 (rotated by -rot about (ccx, ccy)). ---- */
 static void to_frame2(double *x, double *y, int rotated, double rot, double ccx, double ccy)
 {
@@ -982,6 +1066,7 @@ int orc_plan_field(const orc_field *f, const orc_vehicle *veh, const orc_options
     double ccx = 0, ccy = 0, rx[4], ry[4], sx = f->start_x, sy = f->start_y;
     if (rotated) {
         poly_area_centroid(mx, my, 4, &ccx, &ccy);
+        orc_difference_centroid(mx, my, f, W / 2, &ccx, &ccy);      /* MLP:599-609: the work area minus the grown obstacles */
         for (int i = 0; i < 4; ++i) {
             double o[2];
             orc_rotate_point(mx[i], my[i], -rot, ccx, ccy, o);

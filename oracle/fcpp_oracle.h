@@ -122,6 +122,9 @@ void orc_cac_point(double x0, double y0, double th0, double dth, double Re, doub
 double orc_cac_fit_radius(double dth, double R, double f, int fit);
 int orc_point_in_polygon(double px, double py, const double *poly_xy, int64_t nv);  /* even-odd */
 int orc_corner_gap_decision(double R, double W);   /* MLP:1070 `gap.area > 0.1`: 1 / 0 / -1 (undecidable without GEOS) */
+/* MLP:599-609, 288: centroid of main_boundary.difference(union of the obstacles' W/2 buffers) for convex obstacles inside the boundary
+ * with disjoint grown boxes (GEOS' polygonal buffer restated); 0 = the case is not covered, *cx / *cy untouched */
+int orc_difference_centroid(const double *mx, const double *my, const orc_field *f, double r, double *cx, double *cy);
 int orc_outside_polygon(double px, double py, const double *poly_xy, int64_t nv, double tol);  /* fcpp_validate's geofence rule (build-defined) */
 int orc_outside_convex(double px, double py, const double *vx, const double *vy, int nv, double tol);
 

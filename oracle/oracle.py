@@ -296,6 +296,19 @@ def outside_polygon(px, py, poly, tol):
     return bool(lib().orc_outside_polygon(px, py, _dp(poly), len(poly), float(tol)))
 
 
+def difference_centroid(main_quad, field, r):
+    """MLP:599-609, 288: centroid of the main boundary minus the obstacles' W/2 buffers (oracle restatement of GEOS' polygonal buffer);
+    -> (covered, cx, cy)"""
+    q = _f64(main_quad)
+    mx, my = _f64(q[:, 0]), _f64(q[:, 1])
+    cx, cy = C.c_double(0.0), C.c_double(0.0)
+    fn = lib().orc_difference_centroid
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    ok = fn(_dp(mx), _dp(my), C.byref(field), float(r), C.byref(cx), C.byref(cy))
+    return bool(ok), cx.value, cy.value
+
+
 def point_in_polygon(px, py, poly):
     poly = _f64(poly)
     return bool(lib().orc_point_in_polygon(px, py, _dp(poly), len(poly)))

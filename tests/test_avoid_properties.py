@@ -55,3 +55,79 @@ def test_random_obstacle_polygons_clearance_and_host_sizing():
             for poly in obs:
                 assert _dist_to_polygon(p.xy[det, 0], p.xy[det, 1], poly).min() >= W / 2 - 1e-6, trial
     assert accepted >= 110 and accepted + refused == 160
+
+
+def _shoelace(p):
+    x, y = p[:, 0], p[:, 1]
+    xn, yn = np.roll(x, -1), np.roll(y, -1)
+    cr = x * yn - xn * y
+    a = cr.sum() / 2
+    return a, ((x + xn) * cr).sum() / (6 * a), ((y + yn) * cr).sum() / (6 * a)
+
+
+def _geos_like_buffer(poly, r, quad_segs=16):
+    """the outline GEOS' buffer gives a convex polygon (offset edges joined by fillets of int(theta / (pi / 2 / quad_segs) + 0.5) chords)"""
+    p = np.asarray(poly, dtype=np.float64)
+    if _shoelace(p)[0] < 0:
+        p = p[::-1]
+    n, out = len(p), []
+    for i in range(n):
+        a, b, c = p[i], p[(i + 1) % n], p[(i + 2) % n]
+        e, f = b - a, c - b
+        n0, n1 = np.array([e[1], -e[0]]) / np.hypot(*e), np.array([f[1], -f[0]]) / np.hypot(*f)
+        out += [a + r * n0, b + r * n0]
+        th = np.arctan2(n0[0] * n1[1] - n0[1] * n1[0], n0 @ n1)
+        ns = max(1, int(th / (np.pi / 2 / quad_segs) + 0.5))
+        a0 = np.arctan2(n0[1], n0[0])
+        out += [b + r * np.array([np.cos(a0 + th * t / ns), np.sin(a0 + th * t / ns)]) for t in range(1, ns)]
+    return np.array(out)
+
+
+def test_rotation_centre_of_a_work_area_with_obstacles():
+    """MLP:599-609, 288, 696, 710: with obstacles a rotated field turns about the centroid of main_boundary.difference(union of the
+    obstacles' W/2 buffers).  The oracle's restatement (orc_difference_centroid; the library's HostSink::difference_centroid is the same
+    arithmetic, compared point by point in the GPU parity tests) against an independent construction: the buffer's outline vertex by vertex
+    as GEOS lays it, areas and centroids by the shoelace formula.  Cases the restatement does not cover leave the plain centroid."""
+    rng = np.random.default_rng(5)
+    main = np.array([(8.0, 8.0), (392.0, 8.0), (392.0, 212.0), (8.0, 212.0)])
+    ab, bx, by = _shoelace(main)
+    for trial in range(40):
+        obs = []
+        for k in range(int(rng.integers(1, 4))):
+            cx, cy, r0, n = 60.0 + 110.0 * k + rng.uniform(0, 40), rng.uniform(40, 170), rng.uniform(3, 14), int(rng.integers(3, 8))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+            poly = [(cx + r0 * np.cos(t), cy + r0 * np.sin(t)) for t in ang]          # on a circle: convex
+            obs.append(poly[::-1] if rng.integers(0, 2) else poly)                   # either orientation
+        f = orc.make_field(L=400.0, H=220.0, obstacles=obs)
+        ok, cx, cy = orc.difference_centroid(main, f, 1.6)
+        hulls_ok = all(abs(_shoelace(np.asarray(o))[0]) > 1e-9 for o in obs)
+        assert ok and hulls_ok
+        sa = sx = sy = 0.0
+        for o in obs:
+            a, x, y = _shoelace(_geos_like_buffer(o, 1.6))
+            sa += a; sx += a * x; sy += a * y
+        assert abs(cx - (ab * bx - sx) / (ab - sa)) < 1e-9 and abs(cy - (ab * by - sy) / (ab - sa)) < 1e-9
+        assert np.hypot(cx - bx, cy - by) > 1e-4          # (the shift is far above the parity tolerance: it matters)
+    star = [(100.0, 100.0), (120.0, 100.0), (110.0, 105.0), (120.0, 120.0), (100.0, 120.0)]            # not convex
+    edge = [(2.0, 100.0), (12.0, 100.0), (12.0, 110.0), (2.0, 110.0)]                                  # its buffer leaves the main boundary
+    twins = [[(100.0, 100.0), (110.0, 100.0), (110.0, 110.0), (100.0, 110.0)], [(112.0, 100.0), (120.0, 100.0), (120.0, 110.0), (112.0, 110.0)]]
+    for obs in ([star], [edge], twins):
+        ok, _, _ = orc.difference_centroid(main, orc.make_field(L=400.0, H=220.0, obstacles=obs), 1.6)
+        assert not ok
+    # ... and it does NOT matter where that centre lies: layer 1 is laid out from the bounds of the rotated boundary and rotated back about
+    # the same point, world = q + R(theta) o for every centre (the centre cancels).  The oracle turns a rotated field with obstacles about
+    # the differenced area's centroid, as the reference does; the library (csrc/fcpp_planfn.h) about the main boundary's own -- the same
+    # path to rounding, here oracle against oracle and in the GPU parity tests library against oracle.
+    rot = 0.3
+    c, s = np.cos(rot), np.sin(rot)
+    tilt = lambda pts: [(float(x * c - y * s), float(x * s + y * c)) for x, y in pts]
+    verts = tilt([(0.0, 0.0), (400.0, 0.0), (400.0, 220.0), (0.0, 220.0)])
+    ob = [tilt([(150.0, 60.0), (170.0, 60.0), (170.0, 80.0), (150.0, 80.0)])]
+    inset = np.asarray(tilt([(8.0, 8.0), (392.0, 8.0), (392.0, 212.0), (8.0, 212.0)]))
+    ok, cx, cy = orc.difference_centroid(inset, orc.make_field(verts=verts, obstacles=ob), 1.6)
+    assert ok and np.hypot(cx - inset[:, 0].mean(), cy - inset[:, 1].mean()) > 0.05          # the centre moves by centimetres ...
+    for start in (None, (5.0, 150.0)):
+        rc0, p0 = orc.plan_field(orc.make_field(verts=verts, start=start), orc.Vehicle.make(), orc.Options.make())
+        rc1, p1 = orc.plan_field(orc.make_field(verts=verts, obstacles=ob, start=start), orc.Vehicle.make(), orc.Options.make())
+        assert rc0 == 0 and rc1 == 0 and (p0.n_main, p0.n_head) == (p1.n_main, p1.n_head)
+        assert np.abs(p1.xy - p0.xy).max() < 1e-10                                            # ... the path by nothing
