@@ -3,7 +3,8 @@
 
 One "step" = one pass of the whole hot path (sample every path point, curvature, curvature clamp, forward/backward speed
 sweeps, a_lat / geofence / obstacle validation, per-field metrics) over one batch of synthetic fields whose descriptors are
-already resident in HBM: `value` / `ms_per_step` (the median of REPS repetitions of the K-step region).
+already resident in HBM: `value` / `ms_per_step` (the median of REPS repetitions of the K-step region; REPS_SHORT for steps that write
+less than 1 GB: see below).
 
 The reference times the whole plan call (plan_complete_coverage, MLP:387-465: field setup + generation): `value_end_to_end` /
 `end_to_end` report that for a whole batch -- a FRESH batch created (fcpp_batch_create: host plan, tiler, one H2D copy), its output
@@ -109,7 +110,13 @@ def cpu_baseline_fields(make_ofield, n_fields, oopt, budget_s, what):
 
 
 # ---- one planner configuration on this rank --------------------------------------------------------------------------------------
-REPS = 5          # repetitions of the K-step timed region; the median is reported (a 20-step region of the headline is 1.8 ms long)
+REPS = 5          # repetitions of the K-step timed region; the median is reported
+# A K = 20 region of the sparse configurations is ~1 ms long -- shorter than the device's clock / power transient after a load sets in
+# (tools/short_region.py, profiles/r04_short_region.log: regions 3-6 of a series read 5-10 % slower than the first two and than everything
+# from the tenth on).  Steps that write < 1 GB are therefore timed over REPS_SHORT regions (25 x K steps, ~30 ms): every region is K steps
+# bracketed as the contract says, all of them are listed in bench_detail.json (timed_region), the median is `value`.
+REPS_SHORT = 25
+SHORT_STEP_BYTES = 1 << 30
 
 
 def median(v):
@@ -147,6 +154,8 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
         st = batch.setup_times()
         e2e.append({'ms': (t2 - t0) * 1e3, 'create_ms': (t1 - t0) * 1e3, 'alloc_run_sync_ms': (t2 - t1) * 1e3, 'setup_ms': st})
     n_points = batch.total_points
+    if reps == REPS and BYTES_PER_POINT * n_points < SHORT_STEP_BYTES:
+        reps = REPS_SHORT
     warm = e2e[1:] or e2e                 # (the first repetition of a process pays the context's pinned staging memory and the allocator)
     mid = sorted(warm, key=lambda r: r['ms'])[(len(warm) - 1) // 2]
     end_to_end = {'ms': mid['ms'], 'points_per_s': n_points / (mid['ms'] * 1e-3), 'create_ms': mid['create_ms'],
@@ -314,6 +323,7 @@ def compact_line(out):
     the step as [ms per launch, points per launch, its own fraction]) and `cpu_baseline`, plus one short row per configuration.  The full
     record (per-configuration entries with their setup splits, timed regions, notes) is bench_detail.json."""
     rf, cfg = out['roofline'], out['config']
+    tr = out.get('timed_region') or {}
     kern = {}
     for name, ms in rf['all_kernels_ms'].items():
         pts = rf['all_kernels_points'].get(name, 0)
@@ -332,6 +342,8 @@ def compact_line(out):
         'cpu_baseline': None, 'value_end_to_end': _r(out.get('value_end_to_end'), 6), 'end_to_end_ms': _r(out['end_to_end']['ms'], 5),
         'value_clothoid': _r(out.get('value_clothoid'), 6), 'rccl_ranks': out.get('rccl_ranks'), 'per_rank_points_per_s': out.get('per_rank_points_per_s'),
         'host_threads': out.get('host_threads'), 'detail': 'bench_detail.json',
+        # (every region is K steps between two fences; their number and the spread ride along, each one's value is in the detail file)
+        'timed_regions': {'n': tr.get('reps'), 'reported': 'median', 'min_ms': _r(min(tr['ms_per_step_each_rep']), 5), 'max_ms': _r(max(tr['ms_per_step_each_rep']), 5)} if tr.get('ms_per_step_each_rep') else None,
     }
     if out.get('forced_dist'):
         c['forced_dist'] = True
