@@ -467,7 +467,7 @@ def main():
     # stream (a collective per 0.1 ms step would cost more host time than the step's kernels take), double-buffered: while one half of
     # the ring travels, the steps fill the other.
     LH1 = WL.cfg1_batch(args.fields)
-    GATHER_EVERY = 8
+    GATHER_EVERY = 20
     pending = []
     ring = gather_bufs = None
     steps_done = [0]
