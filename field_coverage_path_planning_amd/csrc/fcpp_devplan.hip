@@ -206,9 +206,9 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     int64_t c_tiles = 0, c_wave = 0, c_general = 0, c_stat = 0, c_span = 0, c_work = 0, c_open = 0, c_runs = 0, c_span_pts = 0, c_wave_pts = 0,
             c_work_wave_pts = 0, c_wave_inside = 0, c_work_span_pts = 0, c_span_f = 0, c_unfusable = 0;
     int cls = 0;
-    int64_t tile_base = 0, wave_base = 0, general_base = 0, stat_base = 0, span_base = 0, prim_base = 0;
+    int64_t wave_base = 0, general_base = 0, stat_base = 0, span_base = 0, prim_base = 0;
     if (FILL) {
-        tile_base = base_of(PC_TILES); wave_base = base_of(PC_WAVE); general_base = base_of(PC_GENERAL); stat_base = base_of(PC_STAT);
+        wave_base = base_of(PC_WAVE); general_base = base_of(PC_GENERAL); stat_base = base_of(PC_STAT);
         span_base = base_of(tc.fuse_spans ? PC_SPAN_F : PC_SPAN); prim_base = base_of(PC_PRIMS);
     }
     const int prim_count = F.prim_count;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                     }
                     wt.out_base = pt_off + first;
                     wt.tile += (int32_t)stat_base;
-                    T.tiles[tile_base + span_k + lane] = t;
+                    T.tiles[stat_base + (span_k > 0 ? 1 : 0) + lane] = t;
                     T.wtiles[wave_base + lane] = wt;
                     my_wt = wt;
                 }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                         wt.r0 = (int32_t)(first - (n_main + L.pstart[pa]));
                         for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
                     }
-                    if (FILL) { T.tiles[tile_base + span_k + ordinal] = t; T.wtiles[wave_base + ordinal] = wt; }
+                    if (FILL) { T.tiles[stat_base + (span_k > 0 ? 1 : 0) + ordinal] = t; T.wtiles[wave_base + ordinal] = wt; }
                     else { keep_tiles[field * DEVPLAN_KEEP_TILES + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_TILES + ordinal] = wt; }
                 }
                 inside_cnt += all_in ? 1 : 0;
@@ -418,8 +418,8 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                     t.field = (int32_t)field; t.start = st; t.count = (int32_t)cnt; t.quiet = 0;
                     t.stat_tile = (int32_t)(stat_base + (span_k > 0 ? 1 : 0) + j);
                     t.idx0 = l1 ? (int32_t)(st / per) : 0; t.off0 = l1 ? (int32_t)(st % per) : 0;
-                    T.tiles[tile_base + span_k + j] = t;
-                    T.general_ids[general_base + j] = (int32_t)(tile_base + span_k + j);
+                    T.tiles[stat_base + (span_k > 0 ? 1 : 0) + j] = t;
+                    T.general_ids[general_base + j] = (int32_t)(stat_base + (span_k > 0 ? 1 : 0) + j);
                 }
             }
         }
@@ -447,12 +447,11 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             if (FILL && fused_span > 0) c_span = 0;          // (no chunk records for a fused span)
             if (FILL) {
                 const int64_t bs = S / span_k, rem = S % span_k;
-                for (int64_t j = lane; j < span_k; j += 64) {
-                    const int64_t st = j * bs + (j < rem ? j : rem);
+                if (lane == 0) {          // (the device's tile table keeps one tile per statistics entry: of the span's run, the first)
                     DevTile t;
-                    t.field = (int32_t)field; t.start = st; t.count = (int32_t)(bs + (j < rem ? 1 : 0)); t.quiet = 4; t.stat_tile = 0;
-                    t.idx0 = (int32_t)(st / per); t.off0 = (int32_t)(st % per);
-                    T.tiles[tile_base + j] = t;
+                    t.field = (int32_t)field; t.start = 0; t.count = (int32_t)(bs + (rem > 0 ? 1 : 0)); t.quiet = 4; t.stat_tile = 0;
+                    t.idx0 = 0; t.off0 = 0;
+                    T.tiles[stat_base] = t;
                 }
                 const int64_t c_first = (S < TILE_POINTS - (g0 % TILE_POINTS)) ? S : TILE_POINTS - (g0 % TILE_POINTS);
                 for (int64_t j = lane; j < c_span; j += 64) {
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                 }
             }
         }
-        c_tiles = span_k + n_wave + n_general;
+        c_tiles = (span_k > 0 ? 1 : 0) + n_wave + n_general;      // (the tile table holds one tile per statistics entry: of a span, the first)
         c_wave = n_wave; c_general = n_general;
         c_stat = (span_k > 0 ? 1 : 0) + n_wave + n_general;
     }
@@ -510,10 +509,10 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
         for (int k = lane; k < nwords; k += 64) pd[k] = ps[k];
     }
     // entries in path order: the span's run, then the wave tiles / general tiles
-    if (span_k > 0 && lane == 0) { T.stat_ids[stat_base] = (int32_t)tile_base; T.stat_run[stat_base] = S; }
+    if (span_k > 0 && lane == 0) { T.stat_ids[stat_base] = (int32_t)stat_base; T.stat_run[stat_base] = S; }
     {
         const int64_t e0 = stat_base + (span_k > 0 ? 1 : 0), nt = n_wave + n_general;
-        for (int64_t j = lane; j < nt; j += 64) { T.stat_ids[e0 + j] = (int32_t)(tile_base + span_k + j); T.stat_run[e0 + j] = 0; }
+        for (int64_t j = lane; j < nt; j += 64) { T.stat_ids[e0 + j] = (int32_t)(e0 + j); T.stat_run[e0 + j] = 0; }
     }
     if (lane == 0) {
         T.stat_first[field] = stat_base;
@@ -586,7 +585,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             tl.field = (int32_t)field; tl.start = 0; tl.count = 0; tl.quiet = 4; tl.stat_tile = 0; tl.idx0 = 0; tl.off0 = 0;
             FieldStatView fv;
             fv.n_line = F.n_line; fv.n_turn = F.n_turn; fv.reverse_order = F.reverse_order; fv.line_step = F.line_step; fv.n_main = F.n_main; fv.junc = junc;
-            const DevRun run = { (int32_t)tile_base, 0, S };
+            const DevRun run = { (int32_t)stat_base, 0, S };
             tp = quiet_run_partial(run, tl, fv, T.prims, cst);
             tp.n_viol = tp.n_outside = tp.n_in_obstacle = tp.n_adjusted = 0;
         }

@@ -495,7 +495,9 @@ int BatchTiler::plan_impl(const HostPlan &hp, const TileConsts &tc, const fcpp_p
         BlockTiles &bt = B[(size_t)b];
         bt.tile_base = lay.n_tiles; bt.wave_base = lay.n_wave; bt.general_base = lay.n_general; bt.stat_base = lay.n_stat;
         bt.chunk_base = lay.n_chunks; bt.span_base = lay.n_span_chunks;
-        lay.n_tiles += (int64_t)bt.tiles.size(); lay.n_wave += (int64_t)bt.wtiles.size(); lay.n_general += (int64_t)bt.general_ids.size();
+        // (the device's tile table holds ONE tile per statistics entry -- a general tile, a wave tile, or the FIRST tile of a quiet run, which is
+        // all the kernels ever read of a run: at dense sampling the other tiles of the runs were half of the image)
+        lay.n_tiles += (int64_t)bt.stat_ids.size(); lay.n_wave += (int64_t)bt.wtiles.size(); lay.n_general += (int64_t)bt.general_ids.size();
         lay.n_stat += (int64_t)bt.stat_ids.size(); lay.n_chunks += (int64_t)bt.chunks.size(); lay.n_span_chunks += (int64_t)bt.span_chunks.size();
         for (int c = 0; c < 4; ++c) { bt.cls_base[c] = lay.n_red[c]; lay.n_red[c] += (int64_t)bt.cls[c].size(); }
         for (int c = 0; c < 4; ++c) { bt.work_base[c] = lay.n_work[c]; lay.n_work[c] += (int64_t)bt.work[c].size(); lay.n_field_work += (int64_t)bt.work[c].size(); }
@@ -523,15 +525,16 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         const int64_t nf = pb.f1 - pb.f0;
         memcpy(at<DevField>(dst, lay.fields) + pb.f0, hp.fields.data() + pb.f0, (size_t)nf * sizeof(DevField));
         if (!pb.prims.empty()) memcpy(at<DevPrim>(dst, lay.prims) + pb.prim_base, pb.prims.data(), pb.prims.size() * sizeof(DevPrim));
-        const int32_t tb = (int32_t)bt.tile_base, sb = (int32_t)bt.stat_base;
-        DevTile *td = at<DevTile>(dst, lay.tiles) + bt.tile_base;
-        for (size_t k = 0; k < bt.tiles.size(); ++k) { td[k] = bt.tiles[k]; if (td[k].quiet == 0) td[k].stat_tile += sb; }      // general tiles: their statistics entry
+        const int32_t sb = (int32_t)bt.stat_base;
+        // the tile of statistics entry e lies in slot e (bt.stat_ids: the entry's tile among the block's tiles)
+        DevTile *td = at<DevTile>(dst, lay.tiles) + bt.stat_base;
+        for (size_t e = 0; e < bt.stat_ids.size(); ++e) { td[e] = bt.tiles[(size_t)bt.stat_ids[e]]; if (td[e].quiet == 0) td[e].stat_tile += sb; }   // general tiles: their statistics entry
         DevWaveTile *w = at<DevWaveTile>(dst, lay.wtiles) + bt.wave_base;
         for (size_t k = 0; k < bt.wtiles.size(); ++k) { w[k] = bt.wtiles[k]; w[k].tile += sb; }
         int32_t *g = at<int32_t>(dst, lay.general_ids) + bt.general_base;
-        for (size_t k = 0; k < bt.general_ids.size(); ++k) g[k] = bt.general_ids[k] + tb;
+        for (size_t k = 0; k < bt.general_ids.size(); ++k) g[k] = bt.tiles[(size_t)bt.general_ids[k]].stat_tile + sb;      // (a general tile's slot = its entry)
         int32_t *si = at<int32_t>(dst, lay.stat_ids) + bt.stat_base;
-        for (size_t k = 0; k < bt.stat_ids.size(); ++k) si[k] = bt.stat_ids[k] + tb;
+        for (size_t k = 0; k < bt.stat_ids.size(); ++k) si[k] = sb + (int32_t)k;
         if (!bt.stat_run.empty()) memcpy(at<int64_t>(dst, lay.stat_run) + bt.stat_base, bt.stat_run.data(), bt.stat_run.size() * sizeof(int64_t));
         DevTile *c = at<DevTile>(dst, lay.chunks) + bt.chunk_base;
         for (size_t k = 0; k < bt.chunks.size(); ++k) { c[k] = bt.chunks[k]; c[k].stat_tile += sb; }
