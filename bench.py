@@ -343,7 +343,8 @@ def compact_line(out):
         'value_clothoid': _r(out.get('value_clothoid'), 6), 'rccl_ranks': out.get('rccl_ranks'), 'per_rank_points_per_s': out.get('per_rank_points_per_s'),
         'host_threads': out.get('host_threads'), 'detail': 'bench_detail.json',
         # (every region is K steps between two fences; their number and the spread ride along, each one's value is in the detail file)
-        'timed_regions': {'n': tr.get('reps'), 'reported': 'median', 'min_ms': _r(min(tr['ms_per_step_each_rep']), 5), 'max_ms': _r(max(tr['ms_per_step_each_rep']), 5)} if tr.get('ms_per_step_each_rep') else None,
+        'timed_regions': {'n': tr.get('reps'), 'reported': 'median', 'first_ms': _r(tr['ms_per_step_each_rep'][0], 5), 'min_ms': _r(min(tr['ms_per_step_each_rep']), 5),
+                          'max_ms': _r(max(tr['ms_per_step_each_rep']), 5)} if tr.get('ms_per_step_each_rep') else None,
     }
     if out.get('forced_dist'):
         c['forced_dist'] = True
