@@ -879,6 +879,9 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     tc.field_work = tune_int("FCPP_FIELD_WORK", 1) != 0;
     tc.field_work_tiles = std::max(1, std::min(tune_int("FCPP_FIELD_WORK_TILES", FIELD_WORK_TILES), FIELD_WORK_TILES));
     tc.fuse_spans = tc.field_work && ts.tt.nu <= TMPL_LDS_SAMPLES && tune_int("FCPP_FUSE_SPANS", 1) != 0;
+    // the chunk lists are expanded on the device from the host's chunk groups; FCPP_HOST_CHUNKS=1 (the checker, tests/test_gpu_devplan.py) and
+    // the FCPP_CHUNK_SPREAD diagnostic keep the host's own lists
+    tc.device_chunks = !(getenv("FCPP_HOST_CHUNKS") && atoi(getenv("FCPP_HOST_CHUNKS")) != 0) && !getenv("FCPP_CHUNK_SPREAD");
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);
@@ -931,6 +934,8 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     if (n_fields > 0) {
         b->cst.field_junc = b->t.field_junc;
         LAUNCHCHK(launch_field_junctions(st, n_fields, b->t.fields, b->cst, b->t.field_junc));
+        LAUNCHCHK(launch_expand_chunks(st, lay.n_chunk_groups, reinterpret_cast<const DevChunkGroup *>(static_cast<unsigned char *>(b->slab) + lay.chunk_groups),
+                                       b->t.tiles, b->t.fields, b->t.chunks, b->t.span_chunks));
         // the statistics slots: closed-form statistics of the quiet runs (the same at every step), zeros elsewhere
         LAUNCHCHK(launch_run_consts(st, lay.n_stat, b->t.stat_ids, b->t.stat_run, b->t.tiles, b->t.fields, b->t.prims, b->cst, b->t.partial));
         LAUNCHCHK(launch_work_totals(st, lay.n_field_work, b->t.field_work, b->t.stat_run, b->t.partial, b->t.work_totals));

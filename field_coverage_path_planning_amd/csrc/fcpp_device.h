@@ -89,6 +89,9 @@ int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, co
                         void *scratch = nullptr,       // scratch: 64 x 104 bytes per path of the list (group 256 only: sliced reduction)
                         int clear_counts = 0);         // fused pipeline: entries lie side by side (no ids), flag counts of run slots are cleared
 // batch creation: closed-form statistics of the quiet runs into their slots, zeros into the others (see k_run_consts)
+// the chunk lists of k_plan_quiet from the host's chunk groups (host-built images; see k_expand_chunks)
+int launch_expand_chunks(hipStream_t st, int64_t n_segments, const DevChunkGroup *groups, const DevTile *tiles, const DevField *fields,
+                         DevTile *chunks, DevTile *span_chunks);
 int launch_run_consts(hipStream_t st, int64_t n_entries, const int32_t *ids, const int64_t *run_count, const DevTile *tiles, const DevField *fields,
                       const DevPrim *prims, const DevConst &cst, TilePartial *partial);
 int launch_build_templates(hipStream_t st, const TurnTemplates &tt, const CacShape *shapes, void *tu, void *tc);

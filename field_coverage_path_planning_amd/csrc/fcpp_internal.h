@@ -74,6 +74,24 @@ struct DevTile {
     int32_t stat_tile;   // general tiles and quiet chunks: the statistics entry (slot of `partial`) that collects this tile's / chunk's results
 };
 
+// A chunk group = consecutive quiet runs of one field whose points are cut TOGETHER on 512-point boundaries of the batch arrays (one run;
+// or the swath lines and U-turns of layer 1 that follow each other).  The host lists the groups -- in SEGMENTS of at most
+// CHUNK_SEGMENT chunks, each with the places its records go to -- and the device expands them into the chunk records of k_plan_quiet
+// (k_expand_chunks, a wavefront per segment): at dense sampling the records are most of the batch's image, the segments a hundredth.
+constexpr int CHUNK_SEGMENT = 256;
+struct DevChunkGroup {
+    int32_t field;
+    int32_t e0;          // statistics entry of the group's first run (its tile = tiles[e0], tiles[e0 + k].start = where run k begins)
+    int32_t n_runs;
+    int32_t j0, n;       // this segment: chunks [j0, j0 + n) of the group
+    int32_t _pad;
+    int64_t g0;          // the group's first point in the batch arrays
+    int64_t total;       // points of the group
+    int64_t chunk_base;  // where the segment's records go: those that lie in one run of a straight / U-turn primitive (list `chunks`) ...
+    int64_t span_base;   // ... and those of layer-1 spans or across runs (list `span_chunks`), each list in chunk order
+};
+static_assert(sizeof(DevChunkGroup) == 56, "layout of the image");
+
 // A quiet run = one quiet zone of a straight primitive (consecutive quiet tiles).  Its points are STORED by chunks cut on
 // 512-point boundaries of the batch arrays (aligned 1 KiB stores), its length / time statistics are one closed form for the
 // whole run, credited to the run's first tile -- so the statistics do not depend on where the field sits in the batch.

@@ -911,6 +911,67 @@ int launch_run_consts(hipStream_t st, int64_t n_entries, const int32_t *ids, con
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// The chunk lists of k_plan_quiet from the chunk groups the host listed (fcpp_tiler.cpp: derive_field, whose loop this is, with the same
+// integer arithmetic).  A wavefront per SEGMENT of a group (at most CHUNK_SEGMENT chunks), a lane per chunk: chunk j of a group begins
+// c_first + (j - 1) 512 points into it (the group is cut on 512-point boundaries of the batch arrays), the run it begins in is found in
+// the runs' first tiles (tiles[e0 + k].start: a binary search), and its record is that run's tile with the chunk's start, count and
+// statistics entry; a chunk of a layer-1 span, or one that holds the end of one run and the start of the next, goes to the span list
+// with (pass, offset in the pass) of its first point.  Either list keeps chunk order: places by ballot.
+__global__ __launch_bounds__(64) void k_expand_chunks(int64_t n_segments, const DevChunkGroup *__restrict__ groups, const DevTile *__restrict__ tiles,
+                                                      const DevField *__restrict__ fields, DevTile *__restrict__ chunks, DevTile *__restrict__ span_chunks)
+{
+    if ((int64_t)blockIdx.x >= n_segments) return;
+    const DevChunkGroup g = groups[blockIdx.x];
+    const int lane = threadIdx.x;
+    const DevField &F = fields[g.field];
+    const int64_t pass = (int64_t)F.n_line + F.n_turn;
+    const DevTile a = tiles[g.e0];
+    const int64_t room0 = TILE_POINTS - (g.g0 % TILE_POINTS), c_first = g.total < room0 ? g.total : room0;
+    int64_t nc = 0, ns = 0;
+    for (int it = 0; it < g.n; it += 64) {
+        const int64_t j = (int64_t)g.j0 + it + lane;
+        const bool on = it + lane < g.n;
+        bool span = false;
+        DevTile ch = a;
+        if (on) {
+            const int64_t done = j == 0 ? 0 : c_first + (j - 1) * TILE_POINTS;
+            const int64_t left = g.total - done;
+            const int64_t c = j == 0 ? c_first : (left < TILE_POINTS ? left : TILE_POINTS);
+            // the run that holds the chunk's first point: the last one that begins at or before it
+            const int64_t at = a.start + done;
+            int lo = 0, hi = g.n_runs - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tiles[g.e0 + mid].start <= at) lo = mid; else hi = mid - 1; }
+            const DevTile tr = tiles[g.e0 + lo];
+            const int64_t rc_begin = tr.start - a.start;
+            const int64_t rc_end = lo + 1 < g.n_runs ? tiles[g.e0 + lo + 1].start - a.start : g.total;
+            ch = tr;
+            ch.start = at; ch.count = (int32_t)c; ch.stat_tile = g.e0 + lo;
+            const bool one_run = done + c <= rc_end;
+            if (one_run && tr.quiet != 4) ch.off0 = (int32_t)(tr.off0 + (done - rc_begin));
+            else {
+                ch.quiet = 4;
+                ch.idx0 = (int32_t)(at / pass); ch.off0 = (int32_t)(at % pass);
+            }
+            span = ch.quiet == 4;
+        }
+        const unsigned long long ms = __ballot(on && span), mc = __ballot(on && !span), below = (1ull << lane) - 1ull;
+        if (on) {
+            if (span) span_chunks[g.span_base + ns + __popcll(ms & below)] = ch;
+            else chunks[g.chunk_base + nc + __popcll(mc & below)] = ch;
+        }
+        ns += __popcll(ms); nc += __popcll(mc);
+    }
+}
+
+int launch_expand_chunks(hipStream_t st, int64_t n_segments, const DevChunkGroup *groups, const DevTile *tiles, const DevField *fields,
+                         DevTile *chunks, DevTile *span_chunks)
+{
+    if (n_segments <= 0) return 0;
+    hipLaunchKernelGGL(k_expand_chunks, dim3((unsigned)n_segments), dim3(64), 0, st, n_segments, groups, tiles, fields, chunks, span_chunks);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // group = lanes per path: 8, 64, or 256 (a workgroup per path)
 int launch_reduce_stats(hipStream_t st, int64_t n_list, TilePartial *partial, const int64_t *tile_first,
                         const unsigned long long *n_adjusted, fcpp_field_stats *stats, const int32_t *ids, const int64_t *run_count,

@@ -20,7 +20,9 @@ struct BlockTiles {
     std::vector<DevWaveTile> wtiles;
     std::vector<int32_t> general_ids, stat_ids;
     std::vector<int64_t> stat_run;
-    std::vector<DevTile> chunks, span_chunks;
+    std::vector<DevTile> chunks, span_chunks;        // (TileConsts.device_chunks: empty -- the device expands `groups`; n_chunk_rec / n_span_rec count the records)
+    std::vector<DevChunkGroup> groups;               // e0 / chunk_base / span_base block-relative
+    int64_t n_chunk_rec = 0, n_span_rec = 0, group_base = 0;
     std::vector<int32_t> cls[4];                 // fields (batch-wide indices) by reduction class
     std::vector<DevFieldWork> work[4];           // fields planned and reduced by one workgroup, by the size of that workgroup (w_first / e_first block-relative)
     std::vector<int32_t> open_wave;              // wave tiles (block-relative indices) of all other fields
@@ -371,9 +373,20 @@ struct FieldTiler {
                 if (!fusable) ++out.unfusable_work;
                 else if (tc.fuse_spans) { fused_span = total; out.work_span_points += total; r = r1; continue; }
             }
+            // device_chunks: the records are written by the device (k_expand_chunks: the arithmetic of the loop below); the host lists the
+            // group in segments of CHUNK_SEGMENT chunks and counts the records of either list so that every segment knows where its go
+            const size_t seg_mark = out.groups.size();
+            int64_t jj = 0;                      // chunk index inside the group
             size_t rc = r;                       // run that holds the current position
             int64_t rc_begin = 0;                // its first point, relative to the group
-            for (int64_t done = 0; done < total;) {
+            for (int64_t done = 0; done < total; ++jj) {
+                if (tc.device_chunks && jj % CHUNK_SEGMENT == 0) {
+                    DevChunkGroup grp;
+                    memset(&grp, 0, sizeof grp);
+                    grp.field = (int32_t)field; grp.e0 = rv[r].entry; grp.n_runs = (int32_t)(r1 - r); grp.g0 = g_grp; grp.total = total;
+                    grp.j0 = (int32_t)jj; grp.chunk_base = out.n_chunk_rec; grp.span_base = out.n_span_rec;
+                    out.groups.push_back(grp);
+                }
                 const int64_t g = g_grp + done;
                 // (also for the short spans of sparse sampling, where one chunk in eight is partial: near-equal chunks from the span's
                 // start, i.e. 12 % fewer waves with unaligned stores, took 1.81 instead of 1.50 ms on cfg5)
@@ -388,10 +401,11 @@ struct FieldTiler {
                     ch.quiet = 4;
                     ch.idx0 = (int32_t)(ch.start / pass); ch.off0 = (int32_t)(ch.start % pass);
                 }
-                if (ch.quiet == 4) { out.span_chunks.push_back(ch); out.span_points += c; }
-                else { out.chunks.push_back(ch); out.chunk_points += c; }
+                if (ch.quiet == 4) { if (tc.device_chunks) ++out.n_span_rec; else out.span_chunks.push_back(ch); out.span_points += c; }
+                else { if (tc.device_chunks) ++out.n_chunk_rec; else out.chunks.push_back(ch); out.chunk_points += c; }
                 done += c;
             }
+            for (size_t q = seg_mark; q < out.groups.size(); ++q) out.groups[q].n = (int32_t)std::min<int64_t>(CHUNK_SEGMENT, jj - out.groups[q].j0);
             r = r1;
         }
         if (is_work && fused_span > 0) out.work[field_work_class((int)nw)].back().fused_span = (int32_t)fused_span;
@@ -414,8 +428,12 @@ void layout_image(ImageLayout &lay)
     take(lay.tiles, (size_t)lay.n_tiles * sizeof(DevTile));
     take(lay.wtiles, (size_t)lay.n_wave * sizeof(DevWaveTile));
     take(lay.general_ids, (size_t)lay.n_general * sizeof(int32_t));
-    take(lay.chunks, (size_t)lay.n_chunks * sizeof(DevTile));
-    take(lay.span_chunks, (size_t)lay.n_span_chunks * sizeof(DevTile));
+    // (chunk lists the device expands from chunk groups lie behind the uploaded part; lists the host -- or the device tiler -- writes lie here)
+    if (lay.n_chunk_groups == 0) {
+        take(lay.chunks, (size_t)lay.n_chunks * sizeof(DevTile));
+        take(lay.span_chunks, (size_t)lay.n_span_chunks * sizeof(DevTile));
+    }
+    take(lay.chunk_groups, (size_t)lay.n_chunk_groups * sizeof(DevChunkGroup));
     take(lay.stat_ids, (size_t)lay.n_stat * sizeof(int32_t));
     take(lay.stat_first, (size_t)(lay.n_fields + 1) * sizeof(int64_t));
     take(lay.stat_run, (size_t)lay.n_stat * sizeof(int64_t));
@@ -430,6 +448,10 @@ void layout_image(ImageLayout &lay)
     take(lay.seg, (size_t)lay.n_fields * 8 * sizeof(double));
     take(lay.seg_mask, (size_t)lay.n_fields * 2 * sizeof(int32_t));
     lay.upload_bytes = o;
+    if (lay.n_chunk_groups > 0) {
+        take(lay.chunks, (size_t)lay.n_chunks * sizeof(DevTile));
+        take(lay.span_chunks, (size_t)lay.n_span_chunks * sizeof(DevTile));
+    }
     take(lay.partial, (size_t)lay.n_stat * sizeof(TilePartial));      // one slot per statistics entry
     take(lay.red_scratch, (size_t)lay.n_red[3] * 64 * 104);
     take(lay.field_junc, (size_t)lay.n_fields * 2 * sizeof(double));
@@ -498,7 +520,9 @@ int BatchTiler::plan_impl(const HostPlan &hp, const TileConsts &tc, const fcpp_p
         // (the device's tile table holds ONE tile per statistics entry -- a general tile, a wave tile, or the FIRST tile of a quiet run, which is
         // all the kernels ever read of a run: at dense sampling the other tiles of the runs were half of the image)
         lay.n_tiles += (int64_t)bt.stat_ids.size(); lay.n_wave += (int64_t)bt.wtiles.size(); lay.n_general += (int64_t)bt.general_ids.size();
-        lay.n_stat += (int64_t)bt.stat_ids.size(); lay.n_chunks += (int64_t)bt.chunks.size(); lay.n_span_chunks += (int64_t)bt.span_chunks.size();
+        lay.n_stat += (int64_t)bt.stat_ids.size();
+        lay.n_chunks += tc.device_chunks ? bt.n_chunk_rec : (int64_t)bt.chunks.size(); lay.n_span_chunks += tc.device_chunks ? bt.n_span_rec : (int64_t)bt.span_chunks.size();
+        bt.group_base = lay.n_chunk_groups; lay.n_chunk_groups += (int64_t)bt.groups.size();
         for (int c = 0; c < 4; ++c) { bt.cls_base[c] = lay.n_red[c]; lay.n_red[c] += (int64_t)bt.cls[c].size(); }
         for (int c = 0; c < 4; ++c) { bt.work_base[c] = lay.n_work[c]; lay.n_work[c] += (int64_t)bt.work[c].size(); lay.n_field_work += (int64_t)bt.work[c].size(); }
         bt.open_base = lay.n_open_wave; lay.n_open_wave += (int64_t)bt.open_wave.size();
@@ -536,10 +560,15 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         int32_t *si = at<int32_t>(dst, lay.stat_ids) + bt.stat_base;
         for (size_t k = 0; k < bt.stat_ids.size(); ++k) si[k] = sb + (int32_t)k;
         if (!bt.stat_run.empty()) memcpy(at<int64_t>(dst, lay.stat_run) + bt.stat_base, bt.stat_run.data(), bt.stat_run.size() * sizeof(int64_t));
-        DevTile *c = at<DevTile>(dst, lay.chunks) + bt.chunk_base;
-        for (size_t k = 0; k < bt.chunks.size(); ++k) { c[k] = bt.chunks[k]; c[k].stat_tile += sb; }
-        DevTile *cs = at<DevTile>(dst, lay.span_chunks) + bt.span_base;
-        for (size_t k = 0; k < bt.span_chunks.size(); ++k) { cs[k] = bt.span_chunks[k]; cs[k].stat_tile += sb; }
+        if (lay.n_chunk_groups > 0) {
+            DevChunkGroup *gr = at<DevChunkGroup>(dst, lay.chunk_groups) + bt.group_base;
+            for (size_t k = 0; k < bt.groups.size(); ++k) { gr[k] = bt.groups[k]; gr[k].e0 += sb; gr[k].chunk_base += bt.chunk_base; gr[k].span_base += bt.span_base; }
+        } else {
+            DevTile *c = at<DevTile>(dst, lay.chunks) + bt.chunk_base;
+            for (size_t k = 0; k < bt.chunks.size(); ++k) { c[k] = bt.chunks[k]; c[k].stat_tile += sb; }
+            DevTile *cs = at<DevTile>(dst, lay.span_chunks) + bt.span_base;
+            for (size_t k = 0; k < bt.span_chunks.size(); ++k) { cs[k] = bt.span_chunks[k]; cs[k].stat_tile += sb; }
+        }
         int64_t *sf = at<int64_t>(dst, lay.stat_first);
         int64_t run = bt.stat_base;
         for (int64_t k = 0; k < nf; ++k) { sf[pb.f0 + k] = run; run += bt.stat_cnt[k]; }
@@ -600,7 +629,7 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
     }
     // diagnostic (FCPP_CHUNK_SPREAD=S): the ORDER of the chunk lists permuted so that consecutive workgroups write chunks N/S apart
     // instead of neighbours -- which memory the waves in flight cover at any moment (tools/placement_probe.py)
-    if (const char *e = getenv("FCPP_CHUNK_SPREAD")) {
+    if (const char *e = lay.n_chunk_groups == 0 ? getenv("FCPP_CHUNK_SPREAD") : nullptr) {     // (host-written lists only: fcpp_api.cpp)
         const int64_t S = atoll(e);
         for (int pass = 0; pass < 2 && S > 1; ++pass) {
             DevTile *L = at<DevTile>(dst, pass ? lay.span_chunks : lay.chunks);

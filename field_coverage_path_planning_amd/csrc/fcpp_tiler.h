@@ -31,17 +31,19 @@ struct TileConsts {
     int field_work_tiles = FIELD_WORK_TILES;  // ... at most this many (<= FIELD_WORK_TILES)
     bool fuse_spans = true;                   // ... and that workgroup also writes the field's layer-1 span (its chunks are then not in k_plan_quiet's list)
     int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
+    bool device_chunks = false;               // the chunk lists of k_plan_quiet are expanded on the device from chunk groups (fcpp_batch_create; false: written by the host, the checker)
 };
 
 // the tables of the fused pipeline inside one allocation; all offsets in bytes from the image's start, 256-byte aligned
 struct ImageLayout {
     size_t fields = 0, prims = 0, tiles = 0, wtiles = 0, general_ids = 0, chunks = 0, span_chunks = 0, stat_ids = 0, stat_first = 0,
-           stat_run = 0, red_paths = 0, field_work = 0, field_packs = 0, open_wave_ids = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
+           stat_run = 0, red_paths = 0, field_work = 0, field_packs = 0, open_wave_ids = 0, chunk_groups = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
     size_t upload_bytes = 0;                  // [0, upload_bytes) is built on the host and copied
     size_t partial = 0, red_scratch = 0, field_junc = 0, work_totals = 0, info = 0;      // device-only scratch behind it
     bool info_on_device = false;              // the batch was set up on the device: its fcpp_field_info records live in the slab (info)
     size_t total_bytes = 0;
     int64_t n_fields = 0, n_prims = 0, n_tiles = 0, n_wave = 0, n_general = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_stat = 0;
+    int64_t n_chunk_groups = 0;               // host-built images: the chunk lists are expanded on the device from this many groups (0: the lists are in the image)
     int64_t n_red[4] = { 0, 0, 0, 0 };       // fields reduced by k_reduce_stats, by class (fields of field_work are in none)
     int64_t n_field_work = 0, n_open_wave = 0;  // fields planned AND reduced by one workgroup each / wave tiles of the other fields
     int64_t n_polys = 0, n_poly_verts = 0;

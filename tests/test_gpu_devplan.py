@@ -175,3 +175,48 @@ def test_malformed_obstacle_ranges_are_refused_by_the_device_path():
             E.Batch(t, E.make_vehicle(), E.make_options())
     finally:
         E.get_context().set_setup('auto')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('opt', [dict(sample_spacing=0.5), dict(turn_model=1, sample_spacing=0.2), dict(turn_model=1, sample_spacing=0.1, clothoid_frac=0.3),
+                                 dict(), dict(sample_spacing=0.7, avoid_obstacles=True)])
+def test_chunk_lists_expanded_on_the_device_equal_the_hosts(opt):
+    """Host-built images (dense sampling, obstacle-aware swaths, fields beyond the device planner) carry chunk GROUPS; the chunk lists of
+    k_plan_quiet are expanded from them on the device (k_expand_chunks).  FCPP_HOST_CHUNKS=1 keeps the host's own lists: every table of the
+    two batches -- the two chunk lists among them -- byte for byte, and the results of a step bit for bit."""
+    import torch
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_parity import _random_fields, DEFAULT_VP, _veh
+    specs, _ = _random_fields(21, 10, with_points=True)
+    specs2, _ = _random_fields(22, 6, para=True, with_obstacles=True)
+    o = E.make_options(**opt)
+    ctx = E.get_context()
+    ctx.set_setup('host')
+    try:
+        bd = E.Batch(specs + specs2, _veh(DEFAULT_VP), o)
+        os.environ['FCPP_HOST_CHUNKS'] = '1'
+        try:
+            bh = E.Batch(specs + specs2, _veh(DEFAULT_VP), o)
+        finally:
+            del os.environ['FCPP_HOST_CHUNKS']
+    finally:
+        ctx.set_setup('auto')
+    assert bd.total_points == bh.total_points and bd.stage_points() == bh.stage_points()
+    n_chunk_bytes = 0
+    for k, name in enumerate(TABLES):
+        a, b = bd.debug_table(k), bh.debug_table(k)
+        if name == 'red_paths':          # (room for every field; only the fields k_reduce_stats reduces are listed)
+            used = 4 * sum(bd.reduce_classes())
+            a, b = a[:used], b[:used]
+        assert a.size == b.size and np.array_equal(a, b), (name, a.size, b.size)
+        if name in ('chunks', 'span_chunks'):
+            n_chunk_bytes += a.size
+    if opt.get('sample_spacing', 0.0) > 0:
+        assert n_chunk_bytes > 0
+        assert bd.setup_times()['image_bytes'] < bh.setup_times()['image_bytes']          # the lists no longer travel
+    rd, rh = bd.run(), bh.run()
+    torch.cuda.synchronize()
+    for name in ('x', 'y', 'kappa', 'v', 'flagseg', 'stats_raw'):
+        assert torch.equal(getattr(rd, name), getattr(rh, name)), name
+    bd.close(); bh.close()
