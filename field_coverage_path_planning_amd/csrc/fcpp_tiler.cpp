@@ -202,10 +202,14 @@ struct FieldTiler {
     }
     // near-equal quiet tiles of at most TILE_POINTS - 2 points (the kernel stores aligned PAIRS; a tile that starts on an
     // odd global index needs one pair more than half its points)
+    // (Only the FIRST of those tiles is ever read -- by the device as the run's tile, by derive_field as the run's start -- so only it is
+    // made: its count as before, the run's length in its stat_tile until the image is written (fill: zero there, as the device tiler has it).
+    // At dense sampling the other tiles were most of the tiler's time.)
     void emit_quiet(int64_t zs, int64_t Z, int kind, int64_t i0, int64_t o0)
     {
         const int64_t cap = TILE_POINTS - 2, k = (Z + cap - 1) / cap, base = Z / k, rem = Z % k;
-        for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(zs, c, kind, i0, o0); zs += c; o0 += c; }
+        emit(zs, base + (rem > 0 ? 1 : 0), kind, i0, o0);
+        out.tiles.back().stat_tile = (int32_t)Z;
     }
     int64_t need_for(double c_nom, double step_len) const { return tiler_need_for(c_nom, step_len, tc.two_a); }
 
@@ -248,9 +252,8 @@ struct FieldTiler {
             int64_t first_idx = 0;
             const bool span = turn_quiet && P >= 2 && n_line - need1 < 64 && (P - 1) * per < (int64_t)0x7fffffff;
             if (span) {
-                const int64_t S = (P - 1) * per, cap = TILE_POINTS - 2, k = (S + cap - 1) / cap, base = S / k, rem = S % k;
-                int64_t a = 0;
-                for (int64_t i = 0; i < k; ++i) { const int64_t c = base + (i < rem ? 1 : 0); emit(a, c, 4, a / per, a % per); a += c; }
+                const int64_t S = (P - 1) * per;
+                emit_quiet(0, S, 4, 0, 0);
                 pos = S; first_idx = P - 1;
             }
             for (int64_t idx = first_idx; idx < P; ++idx) {
@@ -316,15 +319,8 @@ struct FieldTiler {
             out.stat_run.push_back(0);
             if (!a.quiet) { a.stat_tile = entry; out.general_ids.push_back((int32_t)i); ++i; continue; }
             if (a.quiet == 5) { out.wtiles[(size_t)w_next++].tile = entry; out.wave_points += a.count; ++i; continue; }
-            // the run: quiet tiles that continue each other on the same straight
-            int64_t cnt = a.count, j = i + 1;
-            for (; j < t1; ++j) {
-                const DevTile &tj = T[(size_t)j];
-                const bool cont = tj.quiet == a.quiet && tj.start == a.start + cnt &&
-                                  (a.quiet == 4 || (tj.idx0 == a.idx0 && (int64_t)tj.off0 == (int64_t)a.off0 + cnt));
-                if (!cont) break;
-                cnt += tj.count;
-            }
+            // the run: one quiet zone = one tile (emit_quiet), its length in the tile's stat_tile
+            const int64_t cnt = a.stat_tile, j = i + 1;
             rv.push_back({ i, cnt, entry });
             out.stat_run.back() = cnt;
             out.quiet_points += cnt;
@@ -552,7 +548,11 @@ void BatchTiler::fill(const HostPlan &hp, const fcpp_polys *polys, const ImageLa
         const int32_t sb = (int32_t)bt.stat_base;
         // the tile of statistics entry e lies in slot e (bt.stat_ids: the entry's tile among the block's tiles)
         DevTile *td = at<DevTile>(dst, lay.tiles) + bt.stat_base;
-        for (size_t e = 0; e < bt.stat_ids.size(); ++e) { td[e] = bt.tiles[(size_t)bt.stat_ids[e]]; if (td[e].quiet == 0) td[e].stat_tile += sb; }   // general tiles: their statistics entry
+        for (size_t e = 0; e < bt.stat_ids.size(); ++e) {
+            td[e] = bt.tiles[(size_t)bt.stat_ids[e]];
+            if (td[e].quiet == 0) td[e].stat_tile += sb;            // general tiles: their statistics entry
+            else if (td[e].quiet != 5) td[e].stat_tile = 0;         // quiet runs: (the host kept the run's length there)
+        }
         DevWaveTile *w = at<DevWaveTile>(dst, lay.wtiles) + bt.wave_base;
         for (size_t k = 0; k < bt.wtiles.size(); ++k) { w[k] = bt.wtiles[k]; w[k].tile += sb; }
         int32_t *g = at<int32_t>(dst, lay.general_ids) + bt.general_base;
