@@ -369,20 +369,50 @@ struct FieldTiler {
                 if (!fusable) ++out.unfusable_work;
                 else if (tc.fuse_spans) { fused_span = total; out.work_span_points += total; r = r1; continue; }
             }
-            // device_chunks: the records are written by the device (k_expand_chunks: the arithmetic of the loop below); the host lists the
-            // group in segments of CHUNK_SEGMENT chunks and counts the records of either list so that every segment knows where its go
-            const size_t seg_mark = out.groups.size();
-            int64_t jj = 0;                      // chunk index inside the group
+            // device_chunks: the records are written by the device (k_expand_chunks: the arithmetic of the loop further below); the host lists
+            // the group in segments of CHUNK_SEGMENT chunks and counts the records of either list so that every segment knows where its go
+            if (tc.device_chunks) {
+                // ... without walking the chunks: chunk j of the group begins c_first + (j - 1) 512 points into it, and the only chunks that go
+                // to the span list are those of a layer-1 span and those with a run boundary strictly inside -- found from the run
+                // boundaries, O(runs) instead of O(points / 512) (a 5000 x 2000 m field at 0.05 m: 800 runs, 123 000 chunks)
+                const int64_t room0 = TILE_POINTS - (g_grp % TILE_POINTS), c_first = std::min(total, room0);
+                const int64_t J = total <= c_first ? 1 : 1 + (total - c_first + TILE_POINTS - 1) / TILE_POINTS;
+                auto chunk_of = [&](int64_t d) { return d < c_first ? (int64_t)0 : 1 + (d - c_first) / TILE_POINTS; };
+                auto chunk_start = [&](int64_t j) { return j == 0 ? (int64_t)0 : c_first + (j - 1) * TILE_POINTS; };
+                auto chunk_count = [&](int64_t j) { return j == 0 ? c_first : std::min<int64_t>(TILE_POINTS, total - chunk_start(j)); };
+                const bool all_span = a.quiet == 4;
+                int64_t spans = 0, span_pts = 0, next_j0 = 0, last_span = -1;
+                auto segments_upto = [&](int64_t j_incl) {       // the segments that begin at or before chunk j_incl: `spans` span chunks lie before them
+                    for (; next_j0 <= j_incl && next_j0 < J; next_j0 += CHUNK_SEGMENT) {
+                        const int64_t before = all_span ? next_j0 : spans;
+                        DevChunkGroup grp;
+                        memset(&grp, 0, sizeof grp);
+                        grp.field = (int32_t)field; grp.e0 = rv[r].entry; grp.n_runs = (int32_t)(r1 - r); grp.g0 = g_grp; grp.total = total;
+                        grp.j0 = (int32_t)next_j0; grp.n = (int32_t)std::min<int64_t>(CHUNK_SEGMENT, J - next_j0);
+                        grp.chunk_base = out.n_chunk_rec + (next_j0 - before); grp.span_base = out.n_span_rec + before;
+                        out.groups.push_back(grp);
+                    }
+                };
+                if (all_span) { spans = J; span_pts = total; }
+                else {
+                    int64_t B = 0;
+                    for (size_t k = r; k + 1 < r1; ++k) {
+                        B += rv[k].count;                              // where run k + 1 begins
+                        const int64_t jb = chunk_of(B);
+                        if (B == chunk_start(jb) || jb == last_span) continue;
+                        segments_upto(jb);
+                        ++spans; span_pts += chunk_count(jb); last_span = jb;
+                    }
+                }
+                segments_upto(J - 1);
+                out.n_span_rec += spans; out.n_chunk_rec += J - spans;
+                out.span_points += span_pts; out.chunk_points += total - span_pts;
+                r = r1;
+                continue;
+            }
             size_t rc = r;                       // run that holds the current position
             int64_t rc_begin = 0;                // its first point, relative to the group
-            for (int64_t done = 0; done < total; ++jj) {
-                if (tc.device_chunks && jj % CHUNK_SEGMENT == 0) {
-                    DevChunkGroup grp;
-                    memset(&grp, 0, sizeof grp);
-                    grp.field = (int32_t)field; grp.e0 = rv[r].entry; grp.n_runs = (int32_t)(r1 - r); grp.g0 = g_grp; grp.total = total;
-                    grp.j0 = (int32_t)jj; grp.chunk_base = out.n_chunk_rec; grp.span_base = out.n_span_rec;
-                    out.groups.push_back(grp);
-                }
+            for (int64_t done = 0; done < total;) {
                 const int64_t g = g_grp + done;
                 // (also for the short spans of sparse sampling, where one chunk in eight is partial: near-equal chunks from the span's
                 // start, i.e. 12 % fewer waves with unaligned stores, took 1.81 instead of 1.50 ms on cfg5)
@@ -397,11 +427,10 @@ struct FieldTiler {
                     ch.quiet = 4;
                     ch.idx0 = (int32_t)(ch.start / pass); ch.off0 = (int32_t)(ch.start % pass);
                 }
-                if (ch.quiet == 4) { if (tc.device_chunks) ++out.n_span_rec; else out.span_chunks.push_back(ch); out.span_points += c; }
-                else { if (tc.device_chunks) ++out.n_chunk_rec; else out.chunks.push_back(ch); out.chunk_points += c; }
+                if (ch.quiet == 4) { out.span_chunks.push_back(ch); out.span_points += c; }
+                else { out.chunks.push_back(ch); out.chunk_points += c; }
                 done += c;
             }
-            for (size_t q = seg_mark; q < out.groups.size(); ++q) out.groups[q].n = (int32_t)std::min<int64_t>(CHUNK_SEGMENT, jj - out.groups[q].j0);
             r = r1;
         }
         if (is_work && fused_span > 0) out.work[field_work_class((int)nw)].back().fused_span = (int32_t)fused_span;
