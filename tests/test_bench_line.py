@@ -23,6 +23,7 @@ def _fake_out(n_configs=12):
            'scaling': 'weak', 'vs_baseline': 3000.0, 'vs_baseline_of': 'cpu_baseline.value of this run', 'dtype': 'f64', 'data': 'synthetic',
            'value_end_to_end': 6.7e9, 'end_to_end': e2e,
            'config': {'workload': 'w' * 700, 'turn_model': 'arc (reference, pinned)', 'points_per_gpu_step': r['points'], 'fields_per_gpu': 4096, 'setup': 'device'},
+           'timed_region': {'reps': 25, 'steps_per_rep': 20, 'ms_per_step_each_rep': [0.0563, 0.0565, 0.0594] + [0.0545] * 22, 'reported': 'median'},
            'roofline': bench.roofline_of(r, 'cfg1'), 'value_clothoid': 1.0e11, 'rccl_ranks': 1, 'per_rank_points_per_s': [1.08e11] * 8, 'host_threads': 16,
            'cpu_baseline': {'value': 3.3e7, 'unit': 'points/s', 'cores': 16, 'kind': 'port', 'single_core_value': 5e6, 'sample': 's' * 600}}
     out['configs'] = [{'name': f'cfg_with_a_long_name_{k}', 'workload': 'v' * 500, 'ms_per_step': 1.9255567982327193, 'value': 141933305343.59515,
@@ -46,6 +47,8 @@ def test_compact_line_is_short_and_complete():
     assert d['cpu_baseline']['cores'] == 16 and d['cpu_baseline']['kind'] == 'port' and len(d['cpu_baseline']['sample']) <= 160
     assert d['vs_baseline'] == 3000.0 and len(d['config']['workload']) <= 200
     assert len(d['configs']) == 13 and d['configs']['columns'][0] == 'ms_per_step'
+    # every region is K steps between two fences; their number, the first one's own value and the spread ride along
+    assert d['timed_regions'] == {'n': 25, 'reported': 'median', 'first_ms': 0.0563, 'min_ms': 0.0545, 'max_ms': 0.0594}
 
 
 def test_compact_line_drops_optional_parts_before_it_grows_past_the_limit():
