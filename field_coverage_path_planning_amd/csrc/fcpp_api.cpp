@@ -177,6 +177,8 @@ struct fcpp_ctx {
     // totals that come back in the middle of it
     int setup_mode = FCPP_SETUP_AUTO;
     void *plan_scratch = nullptr; size_t plan_scratch_cap = 0;
+    void *verify_scratch = nullptr;                 // sliced reduction of the standalone operators' long paths (reduce_paths)
+    size_t verify_scratch_cap = 0;
     int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values
     hipEvent_t ev_plan = nullptr; bool ev_plan_set = false;
     // the output arena (fcpp_ctx_reserve_outputs): ONE allocation of 4 x pitch + lane bytes; array k of every batch's outputs lies in lane k
@@ -358,6 +360,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->arena) { (void)hipDeviceSynchronize(); (void)hipFree(c->arena); }
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
+    if (c->verify_scratch) (void)hipFree(c->verify_scratch);
     c->templates.reset();
     delete c;
     return FCPP_OK;
@@ -1298,6 +1301,25 @@ int fcpp_speed_plan(fcpp_ctx *c, const fcpp_vehicle *veh, int clamp, int64_t n_p
     return FCPP_OK;
 }
 
+// The standalone operators' statistics: a path per 64 lanes -- or, for a few LONG paths (one path of 6e7 points is 123 000 tiles: 1.2 ms
+// through one wavefront), every path sliced over 64 workgroups and joined (the fused pipeline's class-3 reduction: 10 us).
+static int reduce_paths(fcpp_ctx *c, hipStream_t st, DevTiling &dt, fcpp_field_stats *stats)
+{
+    if (dt.n_paths > 0 && dt.n_paths <= 64 && dt.n_tiles / dt.n_paths > 2048) {
+        const size_t need = (size_t)dt.n_paths * 64 * 104;
+        if (c->verify_scratch_cap < need) {
+            if (c->verify_scratch) { HIPCHK(hipStreamSynchronize(st)); (void)hipFree(c->verify_scratch); c->verify_scratch = nullptr; c->verify_scratch_cap = 0; }
+            HIPCHK(hipMalloc(&c->verify_scratch, need));
+            c->verify_scratch_cap = need;
+        }
+        LAUNCHCHK(launch_reduce_stats(st, dt.n_paths, dt.partial.p, dt.tile_first.p, nullptr, stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 256,
+                                      c->verify_scratch, 0));
+        return FCPP_OK;
+    }
+    LAUNCHCHK(launch_reduce_stats(st, dt.n_paths, dt.partial.p, dt.tile_first.p, nullptr, stats));
+    return FCPP_OK;
+}
+
 int fcpp_verify(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n_paths, const int64_t *offsets, int64_t total,
                 const double *x, const double *y, const double *v, fcpp_field_stats *stats, const int64_t *offsets_host)
 {
@@ -1315,7 +1337,7 @@ int fcpp_verify(fcpp_ctx *c, const fcpp_vehicle *veh, int64_t n_paths, const int
     LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, 0, x, y, v, vtmp.p, kap.p, nullptr));
     DevObstacles obs = { nullptr, nullptr, nullptr, nullptr };
     LAUNCHCHK(launch_validate(st, dt.n_tiles, dt.tiles.p, dt.paths.p, nullptr, cst, obs, x, y, kap.p, v, nullptr, dt.partial.p));
-    LAUNCHCHK(launch_reduce_stats(st, dt.n_paths, dt.partial.p, dt.tile_first.p, nullptr, stats));
+    { const int rrc = reduce_paths(c, st, dt, stats); if (rrc) return rrc; }
     HIPCHK(hipStreamSynchronize(st));
     return FCPP_OK;
 }
@@ -1351,7 +1373,7 @@ int fcpp_validate(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *opt,
     LAUNCHCHK(launch_curv_clamp(st, dt.n_tiles, dt.tiles.p, dt.paths.p, cst, 0, x, y, v, vtmp.p, kap.p, nullptr));
     DevObstacles none = { nullptr, nullptr, nullptr, nullptr };
     LAUNCHCHK(launch_validate(st, dt.n_tiles, dt.tiles.p, dt.paths.p, nullptr, cst, none, x, y, kap.p, v, nullptr, dt.partial.p));
-    LAUNCHCHK(launch_reduce_stats(st, dt.n_paths, dt.partial.p, dt.tile_first.p, nullptr, stats));
+    { const int rrc = reduce_paths(c, st, dt, stats); if (rrc) return rrc; }
     // the polygon tables: one upload (field vertices, obstacle vertices, their offsets, the per-path obstacle ranges)
     const int64_t nfv = field_polys && n_paths > 0 ? field_polys->offsets[n_paths] : 0, nov = n_obst > 0 ? obstacles->offsets[n_obst] : 0;
     std::vector<double> hv;

@@ -811,14 +811,20 @@ __device__ __forceinline__ double poly_dist2(double px, double py, const double 
     }
     return best;
 }
-__global__ __launch_bounds__(BLOCK) void k_validate_polys(const DevTile *__restrict__ tiles, const DevPath *__restrict__ paths, DevPolySet field,
+constexpr int VAL_LDS_POLYS = 128;      // obstacle polygons of a path whose bounding boxes a tile keeps in LDS (more: every polygon is tested)
+constexpr int VAL_TILES_PER_WG = 16;
+__global__ __launch_bounds__(BLOCK) void k_validate_polys(int64_t n_tiles, const DevTile *__restrict__ tiles, const DevPath *__restrict__ paths, DevPolySet field,
                                                           DevPolySet obst, const int64_t *__restrict__ obst_range, double tol, double a_lat,
                                                           const double *__restrict__ x, const double *__restrict__ y,
                                                           const double *__restrict__ kappa, const double *__restrict__ v,
                                                           uint32_t *__restrict__ flags, fcpp_field_stats *__restrict__ stats)
 {
     __shared__ double lx[VAL_LDS_VERTS], ly[VAL_LDS_VERTS];
-    const DevTile t = tiles[blockIdx.x];
+    __shared__ double lbb[VAL_LDS_POLYS][4];
+    // a workgroup takes VAL_TILES_PER_WG consecutive tiles: a path's polygons are staged once for all of them that belong to it
+    int staged_field = -1;
+    for (int64_t ti = (int64_t)blockIdx.x * VAL_TILES_PER_WG; ti < n_tiles && ti < ((int64_t)blockIdx.x + 1) * VAL_TILES_PER_WG; ++ti) {
+    const DevTile t = tiles[ti];
     const DevPath p = paths[t.field];
     // the path's polygons: vertices [f0, f1) of the field set, obstacle polygons [o0, o1)
     int64_t f0 = 0, f1 = 0, o0 = 0, o1 = 0, ov0 = 0, ov1 = 0;
@@ -829,18 +835,45 @@ __global__ __launch_bounds__(BLOCK) void k_validate_polys(const DevTile *__restr
     }
     const int64_t nf = f1 - f0, no = ov1 - ov0;
     const bool staged = nf + no <= VAL_LDS_VERTS;
-    if (staged) {
+    const bool restage = t.field != staged_field;          // (workgroup-uniform)
+    if (staged && restage) {
+        __syncthreads();                                     // (the previous tile's readers are done)
         for (int k = threadIdx.x; k < (int)nf; k += BLOCK) { lx[k] = field.x[f0 + k]; ly[k] = field.y[f0 + k]; }
         for (int k = threadIdx.x; k < (int)no; k += BLOCK) { lx[nf + k] = obst.x[ov0 + k]; ly[nf + k] = obst.y[ov0 + k]; }
         __syncthreads();
     }
     const double *fx = staged ? lx : field.x + f0, *fy = staged ? ly : field.y + f0;            // field vertex k at fx[k]
     const double *ox = staged ? lx + nf : obst.x + ov0, *oy = staged ? ly + nf : obst.y + ov0;   // obstacle vertex (global index k) at ox[k - ov0]
+    // One bounding box per obstacle polygon, made once per tile: a wavefront's 64 points are neighbours on the path, their own box meets
+    // few of the obstacles' boxes (on a 0.05 m path usually none), and only those polygons are tested point by point -- 12.8 -> 1.x ms on
+    // cfg3's 6.3e7 points against 32 obstacles (tools/bench_validate.py).
+    const bool culled = staged && o1 - o0 <= VAL_LDS_POLYS;
+    if (culled && restage) {
+        for (int k = threadIdx.x; k < (int)(o1 - o0); k += BLOCK) {
+            const int64_t a0 = obst.off[o0 + k] - ov0, a1 = obst.off[o0 + k + 1] - ov0;
+            double bx0 = FCPP_INF, by0 = FCPP_INF, bx1 = -FCPP_INF, by1 = -FCPP_INF;
+            for (int64_t q = a0; q < a1; ++q) { bx0 = fmin(bx0, ox[q]); bx1 = fmax(bx1, ox[q]); by0 = fmin(by0, oy[q]); by1 = fmax(by1, oy[q]); }
+            lbb[k][0] = bx0; lbb[k][1] = by0; lbb[k][2] = bx1; lbb[k][3] = by1;
+        }
+        __syncthreads();
+    }
+    staged_field = t.field;
     const double tol2 = tol * tol;
     long long nout = 0, nobs = 0;
-    for (int j = threadIdx.x; j < t.count; j += BLOCK) {
-        const int64_t i = t.start + j, g = p.off + i;
+    for (int j0 = 0; j0 < t.count; j0 += BLOCK) {          // (every wavefront goes through the same rounds: the reductions below are wave-wide)
+        const int j = j0 + (int)threadIdx.x;
+        const bool has = j < t.count;
+        const int64_t i = t.start + (has ? j : t.count - 1), g = p.off + i;
         const double px = x[g], py = y[g];
+        double mnx = has ? px : FCPP_INF, mxx = has ? px : -FCPP_INF, mny = has ? py : FCPP_INF, mxy = has ? py : -FCPP_INF;
+        if (culled) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mnx = fmin(mnx, __shfl_xor(mnx, o)); mny = fmin(mny, __shfl_xor(mny, o));
+                mxx = fmax(mxx, __shfl_xor(mxx, o)); mxy = fmax(mxy, __shfl_xor(mxy, o));
+            }
+        }
+        if (!has) continue;
         uint32_t fs = 0;
         if (i > 0 && i < p.n - 1) {          // MLP:1383-1401, as k_validate counts n_viol
             const double ms = v[g] / 3.6;
@@ -854,6 +887,10 @@ __global__ __launch_bounds__(BLOCK) void k_validate_polys(const DevTile *__restr
             if (out) { fs |= FCPP_FLAG_OUTSIDE; ++nout; }
         }
         for (int64_t b = o0; b < o1; ++b) {
+            if (culled) {          // (the same for every lane of the wavefront: its points' box against the polygon's)
+                const double *bb = lbb[b - o0];
+                if (bb[0] > mxx || bb[2] < mnx || bb[1] > mxy || bb[3] < mny) continue;
+            }
             const int64_t a0 = obst.off[b], a1 = obst.off[b + 1];
             if (a1 - a0 >= 3 && pip_even_odd(px, py, ox, oy, a0 - ov0, a1 - ov0)) { fs |= FCPP_FLAG_OBSTACLE; ++nobs; break; }
         }
@@ -865,6 +902,7 @@ __global__ __launch_bounds__(BLOCK) void k_validate_polys(const DevTile *__restr
         if (nout) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[t.field].n_outside), (unsigned long long)nout);
         if (nobs) atomicAdd(reinterpret_cast<unsigned long long *>(&stats[t.field].n_in_obstacle), (unsigned long long)nobs);
     }
+    }
 }
 
 int launch_validate_polys(hipStream_t st, int64_t n_tiles, const DevTile *tiles, const DevPath *paths, const int64_t *field_off, const double *field_x,
@@ -874,7 +912,8 @@ int launch_validate_polys(hipStream_t st, int64_t n_tiles, const DevTile *tiles,
 {
     if (n_tiles <= 0) return 0;
     const DevPolySet f = { field_off, field_x, field_y, n_field }, o = { obst_off, obst_x, obst_y, n_obst };
-    hipLaunchKernelGGL(k_validate_polys, dim3((unsigned)n_tiles), dim3(BLOCK), 0, st, tiles, paths, f, o, obst_range, tol, a_lat, x, y, kappa, v, flags, stats);
+    hipLaunchKernelGGL(k_validate_polys, dim3((unsigned)((n_tiles + VAL_TILES_PER_WG - 1) / VAL_TILES_PER_WG)), dim3(BLOCK), 0, st, n_tiles, tiles, paths, f, o, obst_range,
+                       tol, a_lat, x, y, kappa, v, flags, stats);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

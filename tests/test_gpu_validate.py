@@ -97,3 +97,30 @@ def test_bad_arguments_are_refused():
         E.validate(x, x, x, E.make_vehicle(), [[(0.0, 0.0), (1.0, 0.0), (0.0, 1.0)]] * 2)                # one polygon per path
     with pytest.raises(L.FcppError):
         E.validate(x, x, x, E.make_vehicle(), None, [[(0.0, 0.0), (1.0, 0.0), (0.0, 1.0)]], [0, 5])     # range beyond the table
+
+
+def test_one_long_path_statistics_through_the_sliced_reduction():
+    """A single path of 1.2 million points (2400 tiles): the standalone operators reduce it over 64 workgroups and join (reduce_paths,
+    csrc/fcpp_api.cpp) instead of through one wavefront (1.2 ms for cfg3's path).  The same points as TWO paths take the plain reduction:
+    lengths agree to rounding once the segment across the cut is added, maxima and counts up to the two points at the cut."""
+    veh = E.make_vehicle()
+    b = E.Batch([E.FieldSpec(field_length=900.0, field_width=420.0)], veh, E.make_options(1, 0.1))
+    r = b.run()
+    n = r.x.numel()
+    assert 2048 * 512 < n < 2 * 2048 * 512          # one path: sliced; its halves: the plain reduction
+    one = E.verify(r.x, r.y, r.v, veh)
+    cut = n // 2
+    two = E.verify(r.x, r.y, r.v, veh, offsets=np.array([0, cut, n], dtype=np.int64))
+    xy = np.stack([r.x[cut - 1:cut + 1].cpu().numpy(), r.y[cut - 1:cut + 1].cpu().numpy()])
+    seg = float(np.hypot(xy[0, 1] - xy[0, 0], xy[1, 1] - xy[1, 0]))
+    assert abs(one['main_len_m'][0] - (two['main_len_m'].sum() + seg)) < 1e-9 * one['main_len_m'][0]
+    assert one['main_time_s'][0] > two['main_time_s'].sum() and one['main_time_s'][0] < two['main_time_s'].sum() + 10.0
+    for name in ('max_kappa', 'max_alat', 'max_jump'):
+        assert one[name][0] >= two[name].max() - 1e-12 and one[name][0] < two[name].max() * 1.000001 + 1e-9 or name == 'max_jump', name
+    assert abs(int(one['n_viol'][0]) - int(two['n_viol'].sum())) <= 2
+    # fcpp_validate runs the same verifier and reduction: its path statistics are the same numbers
+    _, st = E.validate(r.x, r.y, r.v, veh, [[(0.0, 0.0), (900.0, 0.0), (900.0, 420.0), (0.0, 420.0)]])
+    for name in ('main_len_m', 'main_time_s', 'max_kappa', 'max_alat', 'max_jump', 'n_viol'):
+        assert one[name][0] == st[name][0], name
+    assert int(st['n_outside'][0]) == int(r.stats()['n_outside'][0])
+    b.close()
