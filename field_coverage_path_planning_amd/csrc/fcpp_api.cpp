@@ -179,7 +179,8 @@ struct fcpp_ctx {
     void *plan_scratch = nullptr; size_t plan_scratch_cap = 0;
     void *verify_scratch = nullptr;                 // sliced reduction of the standalone operators' long paths (reduce_paths)
     size_t verify_scratch_cap = 0;
-    int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values
+    int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values: the scans of the counting phase write them here
+    int64_t plan_gen = 0;                           // generation number of the last counting phase (PlanFlag, fcpp_devplan.h)
     hipEvent_t ev_plan = nullptr; bool ev_plan_set = false;
     // the output arena (fcpp_ctx_reserve_outputs): ONE allocation of 4 x pitch + lane bytes; array k of every batch's outputs lies in lane k
     // (lanes `pitch` apart), placed first-fit among the live allocations of the lane -- all five arrays of an allocation at the same offset
@@ -525,7 +526,10 @@ int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_
     return FCPP_OK;
 }
 
-namespace { int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, DevPlanScratch &s, std::string &err); }
+namespace {
+int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, DevPlanScratch &s, std::string &err);
+int device_fields(const fcpp_field *fields, int64_t n_fields, hipStream_t st, const DevPlanScratch &s, const fcpp_field *&dev, std::string &err);
+}
 
 // Sizing for a sharded job: points per field.  On the device for the batches the device planner takes (k_plan_fields without primitives,
 // the counts copied back), else on the host's cores.
@@ -552,8 +556,9 @@ int fcpp_plan_points(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *o
     hipStream_t st = c->stream;
     DevPlanScratch s;
     if ((rc = plan_scratch(c, n_fields, pc.max_prims, st, s, err)) != FCPP_OK) return fail(rc, err);
-    HIPCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
-    LAUNCHCHK(launch_devplan_points(st, n_fields, pc, s));
+    const fcpp_field *dev_fields = nullptr;
+    if ((rc = device_fields(fields, n_fields, st, s, dev_fields, err)) != FCPP_OK) return fail(rc, err);
+    LAUNCHCHK(launch_devplan_points(st, n_fields, pc, s, dev_fields));
     HIPCHK(hipMemcpyAsync(points_out, s.counts + (int64_t)PC_POINTS * n_fields, (size_t)n_fields * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return FCPP_OK;
@@ -653,14 +658,37 @@ int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, D
         const size_t want = need + need / 4;
         if (hipMalloc(&c->plan_scratch, want) != hipSuccess) { (void)hipGetLastError(); err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
         c->plan_scratch_cap = want;
+        // (the flags live at the start of the allocation and are never cleared again: they hold generation numbers)
+        DEVCHK(hipMemsetAsync(c->plan_scratch, 0, (PC_COLS + PF_COUNT) * sizeof(int64_t), st));
     }
-    if (!c->plan_totals_host) DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipHostMallocDefault));
+    if (!c->plan_totals_host)
+        DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
     unsigned char *sb = static_cast<unsigned char *>(c->plan_scratch);
     s.fields_in = reinterpret_cast<fcpp_field *>(sb + (size_t)off.fields_in); s.info = reinterpret_cast<fcpp_field_info *>(sb + (size_t)off.info);
     s.fields_tmp = reinterpret_cast<DevField *>(sb + (size_t)off.fields_tmp); s.prims_tmp = reinterpret_cast<DevPrim *>(sb + (size_t)off.prims_tmp);
     s.counts = reinterpret_cast<int64_t *>(sb + (size_t)off.counts); s.bases = reinterpret_cast<int64_t *>(sb + (size_t)off.bases);
     s.blk_sums = reinterpret_cast<int64_t *>(sb + (size_t)off.blk_sums); s.totals = reinterpret_cast<int64_t *>(sb + (size_t)off.totals);
     s.keep_tiles = reinterpret_cast<DevTile *>(sb + (size_t)off.keep_tiles); s.keep_wtiles = reinterpret_cast<DevWaveTile *>(sb + (size_t)off.keep_wtiles);
+    return FCPP_OK;
+}
+
+// The field records as the device reaches them.  Records in pinned host memory (hipHostMalloc / hipHostRegister: a torch tensor with
+// pin_memory, engine.FieldTable) are read by k_plan_fields where they lie -- the kernel's first load is the transfer, 128 bytes per
+// thread, and no copy command goes before it; anything else is copied to the scratch first.  The callers drain the stream before they return, so
+// the caller's memory is not touched afterwards either way.
+int device_fields(const fcpp_field *fields, int64_t n_fields, hipStream_t st, const DevPlanScratch &s, const fcpp_field *&dev, std::string &err)
+{
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    void *dp = nullptr;
+    if (hipPointerGetAttributes(&at, fields) == hipSuccess && at.type == hipMemoryTypeHost &&
+        hipHostGetDevicePointer(&dp, const_cast<fcpp_field *>(fields), 0) == hipSuccess && dp) {
+        dev = static_cast<const fcpp_field *>(dp);
+        return FCPP_OK;
+    }
+    (void)hipGetLastError();          // (pageable memory: "invalid value" on some runtimes, hipMemoryTypeUnregistered on others)
+    DEVCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
+    dev = s.fields_in;
     return FCPP_OK;
 }
 
@@ -700,7 +728,8 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     t0 = std::chrono::steady_clock::now();
     DevPlanScratch s;
     if ((rc = plan_scratch(c, n_fields, pc.max_prims, st, s, err)) != FCPP_OK) return rc;
-    DEVCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
+    const fcpp_field *dev_fields = nullptr;
+    if ((rc = device_fields(fields, n_fields, st, s, dev_fields, err)) != FCPP_OK) return rc;
 
     DevTileConsts tc;
     tc.tu = reinterpret_cast<const Pt2 *>(ts.tmpl_u.p); tc.tc = reinterpret_cast<const Pt2 *>(ts.tmpl_c.p);
@@ -711,14 +740,14 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     tc.fence_margin = 1e-7 - opt.geofence_tol;
     tc.reduce_wg_max = 1024;
     const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
-    int lrc = launch_devplan_count(st, n_fields, pc, tc, s, n_polys, obstacles != nullptr);
-    if (lrc) { err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    tc.gen = ++c->plan_gen;
     int64_t *tot = c->plan_totals_host;
-    DEVCHK(hipMemcpyAsync(tot, s.totals, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    DEVCHK(hipStreamSynchronize(st));
+    int lrc = launch_devplan_count(st, n_fields, pc, tc, s, dev_fields, n_polys, obstacles != nullptr, tot);
+    if (lrc) { err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    DEVCHK(hipStreamSynchronize(st));        // (the last scan has written the totals and the flags to `tot`)
     tm.host_plan_ms = ms_since(t0);          // (the plan and the counting pass, on the device)
-    if (tot[PC_COLS + PF_BAD_OBSTACLES]) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
-    if (tot[PC_COLS + PF_FALLBACK]) { err = "a field beyond the device planner's limits (general stretch, primitives)"; return kNotOnDevice; }
+    if (tot[PC_COLS + PF_BAD_OBSTACLES] == tc.gen) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
+    if (tot[PC_COLS + PF_FALLBACK] == tc.gen) { err = "a field beyond the device planner's limits (general stretch, primitives)"; return kNotOnDevice; }
     if (tot[PC_POINTS] > kCountCap) { err = "batch too large"; return FCPP_ESIZE; }
     if (tot[PC_PRIMS] > ((int64_t)1 << 26)) { err = "too many path primitives in one batch: split the batch"; return FCPP_ESIZE; }
     if (tot[PC_TILES] > INT32_MAX) { err = "too many tiles in one batch: split the batch"; return FCPP_ESIZE; }

@@ -27,7 +27,8 @@ enum PlanCol : int {
 };
 // (PC_SPAN: span chunks when no span is fused; PC_SPAN_F: when every fusable span is; PC_UNFUSABLE: fields of field work whose span has too
 // many chunks to be fused -- the host fuses all or none, k_tile_fields<true> is told which: DevTileConsts.fuse_spans)
-// totals[PC_COLS + k]: flags the kernels raise
+// totals[PC_COLS + k]: flags the kernels raise -- a flag holds the generation number (DevTileConsts.gen, counted up by the context) of the
+// last counting phase that raised it, so nothing has to be cleared between batches: raised in this phase <=> flag == gen
 enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_COUNT = 2 };
 
 // what the device tiler needs to know about the batch (TileConsts of fcpp_tiler.h with the templates on the device)
@@ -37,11 +38,12 @@ struct DevTileConsts {
     int32_t turn_quiet, wave_factor, field_work_tiles, max_prims, fuse_spans, _pad;
     double two_a, u_cap, c_line, fence_margin;
     int64_t reduce_wg_max;
+    int64_t gen;                  // this counting phase's generation number (> 0)
 };
 
 // the device planner's scratch: one allocation the context keeps (grow-only); all pointers device
 struct DevPlanScratch {
-    fcpp_field *fields_in;        // n (copied from the host)
+    fcpp_field *fields_in;        // n (copied from the host, unless the device reads the caller's pinned records where they lie)
     fcpp_field_info *info;        // n (copied back)
     DevField *fields_tmp;         // n: pt_off / prim_first still relative to the field
     DevPrim *prims_tmp;           // n x max_prims
@@ -71,11 +73,13 @@ constexpr int DEVPLAN_WINDOW = 576;
 constexpr int DEVPLAN_PRIMS_CAP = 255;
 constexpr int DEVPLAN_KEEP_TILES = 8;
 
-// phase 1: plan + count.  Enqueues k_plan_fields, the scans and the counting pass; afterwards totals[] holds the sums and the flags.
-int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, int64_t n_polys,
-                         int check_obstacles);
+// phase 1: plan + count.  Enqueues k_plan_fields, the scans and the counting pass; afterwards totals[] holds the sums and the flags, and so
+// does totals_host (pinned host memory the device can write, or null) once the stream has got there: the scans write it themselves.
+// fields: the records as the device reaches them (s.fields_in after a copy, or the caller's pinned memory).
+int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, const fcpp_field *fields,
+                         int64_t n_polys, int check_obstacles, int64_t *totals_host);
 // sizing only (fcpp_plan_points): k_plan_fields without primitives; counts[PC_POINTS][field] = points of the field
-int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s);
+int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s, const fcpp_field *fields);
 // phase 2: the tables.  `bases` / `totals` as phase 1 left them.
 int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevConst &cst, const DevPlanScratch &s, const DevPlanTables &t);
 // fcpp_math.h on the device (tests): fn 0 sincos, 1 atan2(a, b), 2 acos(a), 3 hypot(a, b)

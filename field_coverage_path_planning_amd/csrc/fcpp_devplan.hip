@@ -12,6 +12,7 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t r = off; off = (off + bytes + 255) & ~(size_t)255; return r; };
     const size_t nn = (size_t)(n > 0 ? n : 1), nblk = (nn + 1023) / 1024;
+    o->totals = reinterpret_cast<int64_t *>(take((PC_COLS + PF_COUNT) * sizeof(int64_t)));      // (first: the flags keep their place whatever n is)
     o->fields_in = reinterpret_cast<fcpp_field *>(take(nn * sizeof(fcpp_field)));
     o->info = reinterpret_cast<fcpp_field_info *>(take(nn * sizeof(fcpp_field_info)));
     o->fields_tmp = reinterpret_cast<DevField *>(take(nn * sizeof(DevField)));
@@ -19,7 +20,6 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
     o->counts = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
     o->bases = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
     o->blk_sums = reinterpret_cast<int64_t *>(take(nblk * PC_COLS * sizeof(int64_t)));
-    o->totals = reinterpret_cast<int64_t *>(take((PC_COLS + PF_COUNT) * sizeof(int64_t)));
     o->keep_tiles = reinterpret_cast<DevTile *>(take(nn * DEVPLAN_KEEP_TILES * sizeof(DevTile)));
     o->keep_wtiles = reinterpret_cast<DevWaveTile *>(take(nn * DEVPLAN_KEEP_TILES * sizeof(DevWaveTile)));
     return off;
@@ -43,20 +43,28 @@ struct DevSink {
 
 __global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, const fcpp_field *__restrict__ fin, fcpp_field_info *__restrict__ info,
                                                     DevField *__restrict__ ftmp, DevPrim *__restrict__ ptmp, int64_t *__restrict__ counts,
-                                                    int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles, int count_only)
+                                                    int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles, int count_only, int64_t gen)
 {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const fcpp_field f = fin[i];
     // the field's obstacle range must lie inside the batch's polygon table: the kernels of a step index it
     if (check_obstacles && (f.n_obstacles < 0 || f.obstacle_first < 0 || (f.n_obstacles > 0 && f.obstacle_first + f.n_obstacles > n_polys)))
-        atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_BAD_OBSTACLES), 1ull);
+        atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_BAD_OBSTACLES), (unsigned long long)gen);
     DevSink sink{ count_only ? nullptr : ptmp + i * pc.max_prims, count_only ? 0 : pc.max_prims, 0 };
     const int64_t npts = plan_field_t(pc, f, info[i], ftmp[i], sink);
     counts[(int64_t)PC_POINTS * n + i] = npts;
     if (count_only) return;
     counts[(int64_t)PC_PRIMS * n + i] = ftmp[i].prim_count;
-    if (sink.n > pc.max_prims) atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), 1ull);
+    if (sink.n > pc.max_prims) atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), (unsigned long long)gen);
+}
+
+// a column's total to the host's copy; the flags (generation numbers, see PlanFlag) with the first column of the last scan
+__device__ __forceinline__ void publish_total(const int64_t *totals, int64_t *mirror, int col, int64_t value, bool flags)
+{
+    if (!mirror) return;
+    mirror[col] = value;
+    if (flags) for (int k = 0; k < PF_COUNT; ++k) mirror[PC_COLS + k] = totals[PC_COLS + k];
 }
 
 // ---- exclusive scans of count columns [c0, c1) over the fields -------------------------------------------------------------------------
@@ -93,7 +101,8 @@ __global__ __launch_bounds__(256) void k_scan_block_sums(int64_t n, int c0, cons
     if (threadIdx.x == 0) blk_sums[(int64_t)col * nblk + blockIdx.x] = tot;
 }
 // phase B: one workgroup per column scans the block sums in place (exclusive) and writes the column's total
-__global__ __launch_bounds__(256) void k_scan_block_bases(int c0, int64_t *__restrict__ blk_sums, int64_t nblk, int64_t *__restrict__ totals)
+__global__ __launch_bounds__(256) void k_scan_block_bases(int c0, int64_t *__restrict__ blk_sums, int64_t nblk, int64_t *__restrict__ totals,
+                                                          int64_t *__restrict__ mirror, int with_flags)
 {
     __shared__ int64_t lds[4];
     const int col = c0 + blockIdx.x;
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void k_scan_block_bases(int c0, int64_t *__res
         if (i < nblk) blk_sums[(int64_t)col * nblk + i] = carry + inc - v;
         carry += tot;
     }
-    if (threadIdx.x == 0) totals[col] = carry;
+    if (threadIdx.x == 0) { totals[col] = carry; publish_total(totals, mirror, col, carry, with_flags && blockIdx.x == 0); }
 }
 // phase C: exclusive scan inside each block of 1024 fields + the block's base; grid (blocks, columns)
 __global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int64_t *__restrict__ counts, const int64_t *__restrict__ blk_sums,
@@ -125,7 +134,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int
 }
 
 // small batches: one workgroup per column walks the fields in chunks of 1024 -- one launch instead of three
-__global__ __launch_bounds__(256) void k_scan_small(int64_t n, int c0, const int64_t *__restrict__ counts, int64_t *__restrict__ bases, int64_t *__restrict__ totals)
+__global__ __launch_bounds__(256) void k_scan_small(int64_t n, int c0, const int64_t *__restrict__ counts, int64_t *__restrict__ bases, int64_t *__restrict__ totals,
+                                                    int64_t *__restrict__ mirror, int with_flags)
 {
     __shared__ int64_t lds[4];
     const int col = c0 + blockIdx.x;
@@ -141,20 +151,22 @@ __global__ __launch_bounds__(256) void k_scan_small(int64_t n, int c0, const int
         for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
         carry += tot;
     }
-    if (threadIdx.x == 0) totals[col] = carry;
+    if (threadIdx.x == 0) { totals[col] = carry; publish_total(totals, mirror, col, carry, with_flags && blockIdx.x == 0); }
 }
 
-int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s)
+// mirror: the totals' copy in the host's pinned memory (or null), written by the scans themselves -- no copy command behind them;
+// with_flags: the flags the earlier kernels raised go along (the last scan of the counting phase)
+int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s, int64_t *mirror, int with_flags)
 {
     const int64_t nblk = (n + 1023) / 1024;
     const int nc = c1 - c0;
     if (nblk <= 8) {
-        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.bases, s.totals);
+        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags);
         const hipError_t e0 = hipGetLastError();
         return e0 == hipSuccess ? 0 : (int)e0;
     }
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk);
-    hipLaunchKernelGGL(k_scan_block_bases, dim3((unsigned)nc), dim3(256), 0, st, c0, s.blk_sums, nblk, s.totals);
+    hipLaunchKernelGGL(k_scan_block_bases, dim3((unsigned)nc), dim3(256), 0, st, c0, s.blk_sums, nblk, s.totals, mirror, with_flags);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk, s.bases);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -167,6 +179,14 @@ int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch 
 // (or one general stretch when the turns are not closed form), the general stretch cut into wave tiles with halos sized from the
 // path's own step lengths -- the points evaluated lane-parallel into LDS, the greedy cut walked wave-uniformly -- or, when a wave tile
 // cannot be formed, into general tiles of up to 512 points.
+// Diagnostic build only (-DFCPP_DIAG_TILE: `make diag-tile`, tools/diag_tile.py; never shipped): 10 ns time stamps of the phases of field
+// 1000's counting pass.
+#ifdef FCPP_DIAG_TILE
+__device__ unsigned long long g_tile_stamps[40];
+#define TSTAMP(k) do { if (!FILL && field == 1000 && lane == 0 && (k) < 40) g_tile_stamps[k] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
 constexpr int TW_WAVES = 2;                                             // fields per workgroup
 constexpr int TW_NW = DEVPLAN_WINDOW;                                   // points of the LDS window that slides along a general stretch
 constexpr int TW_LDS_PRIMS = 32;                                        // primitives of a field staged in LDS (more: read where they lie)
@@ -194,6 +214,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t field = (int64_t)blockIdx.x * TW_WAVES + wave;
     if (field >= n) return;
+    TSTAMP(0);
     TileWaveLds &L = lds_all[wave];
     const DevField &F = ftmp[field];
     const DevPrim *prims = ptmp + field * tc.max_prims;
@@ -215,6 +236,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     const int64_t prim_index0 = prim_base;           // batch-wide index of the field's first primitive (fill pass)
 
     bool fallback = false, is_work = false;
+    TSTAMP(1);
     int64_t S = 0, span_k = 0, fused_span = 0;
     int64_t n_wave = 0, n_general = 0;
     // fill pass, lane t: the field's t-th wave tile as written (t < DEVPLAN_KEEP_TILES), its first primitive within the field and the
@@ -287,6 +309,8 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             const DevPrim *const wprims = lds_prims ? reinterpret_cast<const DevPrim *>(L.prim_words) : prims;
             const Pt2 *const wtu = lds_tmpl ? L.tmpl : tc.tu, *const wtc = lds_tmpl ? L.tmpl + tc.nu : tc.tc;
             wave_sync();                                     // the starts (and the staged records) are in LDS
+            const int32_t my_pstart = lane < prim_count ? L.pstart[lane] : INT32_MAX;       // (fields of at most 64 primitives: their starts, a lane each)
+            TSTAMP(2);
             int64_t win0 = 0, win1 = -1;                     // window = path points [win0, win1)
             auto dist = [&](int64_t i) -> double { return L.d[i - win0 - 1]; };
             auto prim_of = [&](int64_t i) -> int { return (int)L.pidx[i - win0]; };
@@ -306,32 +330,68 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                         const int w = w_base + lane;
                         const bool valid = w < nwin;
                         const int64_t i = win0 + (valid ? w : nwin - 1);
-                        double px, py;
+                        double px = 0.0, py = 0.0;
                         int pk = 0;
+#ifdef FCPP_DIAG_TILE
+#define WSTAMP(k) do { if (w_base == 128) TSTAMP(k); } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+                        WSTAMP(24);
+                        const int64_t i_last = win0 + ((w_base + 63 < nwin) ? w_base + 63 : nwin - 1);      // (wave-uniform)
                         if (i < gen_main) {
-                            const int64_t idx = i / per, off = i - idx * per;
+                            int64_t idx, off;
+                            if (i_last < ((int64_t)1 << 31)) { const uint32_t q32 = (uint32_t)i / (uint32_t)per; idx = q32; off = (int64_t)((uint32_t)i - q32 * (uint32_t)per); }
+                            else { idx = i / per; off = i - idx * per; }
                             tiler_point_main(F, wtu, idx, off, px, py);
-                        } else {
-                            const int32_t rel = (int32_t)(i - n_main);
-                            int lo_k = 0, hi_k = prim_count - 1;
-                            while (lo_k < hi_k) { const int m = (lo_k + hi_k + 1) >> 1; if (L.pstart[m] <= rel) lo_k = m; else hi_k = m - 1; }
-                            pk = lo_k;
-                            const DevPrim q = wprims[pk];
-                            tiler_point_prim(q, wtu, wtc, i - q.start, px, py);
                         }
+                        if (i_last >= gen_main) {
+                            // layer 2: the primitives this round's points lie in, one after the other (wave-uniform: a handful per
+                            // round) -- every lane's primitive is the last one that starts at or before its point, as a search per lane finds it
+                            const int64_t i_first = win0 + w_base;
+                            const int32_t rel = (int32_t)(i - n_main);
+                            const int32_t rel_lo = i_first > n_main ? (int32_t)(i_first - n_main) : 0, rel_hi = (int32_t)(i_last - n_main);
+                            // every lane's primitive = the last one that starts at or before its point: the first point's by one ballot
+                            // over the starts (a lane each), the few that start inside the round counted in; fields of more than 64
+                            // primitives search per lane
+                            if (prim_count <= 64) {
+                                int k = __popcll(__ballot(my_pstart <= rel_lo)) - 1;
+                                if (k < 0) k = 0;
+                                pk = k;
+                                for (++k; k < prim_count; ++k) {
+                                    const int32_t st_k = __builtin_amdgcn_readlane(my_pstart, k);
+                                    if (st_k > rel_hi) break;
+                                    pk += rel >= st_k ? 1 : 0;
+                                }
+                            } else {
+                                int lo_k = 0, hi_k = prim_count - 1;
+                                while (lo_k < hi_k) { const int m = (lo_k + hi_k + 1) >> 1; if (L.pstart[m] <= rel) lo_k = m; else hi_k = m - 1; }
+                                pk = lo_k;
+                            }
+                            WSTAMP(25);
+                            if (i >= gen_main) {
+                                const DevPrim q = wprims[pk];
+                                tiler_point_prim(q, wtu, wtc, (int)(i - q.start), px, py);
+                            } else pk = 0;
+                        }
+                        WSTAMP(26);
                         double qx = __shfl_up(px, 1), qy = __shfl_up(py, 1);
                         if (lane == 0) { qx = cx; qy = cy; }
                         cx = __shfl(px, 63); cy = __shfl(py, 63);
                         if (valid) {
                             if (w >= 1) { const double dx = px - qx, dy = py - qy; L.d[w - 1] = sqrt(dx * dx + dy * dy); }
+                            WSTAMP(27);
                             L.pidx[w] = (uint8_t)pk;
                             L.ins[w] = tiler_inside(F, px, py, tc.fence_margin) ? 1 : 0;
                         }
+                        WSTAMP(28);
                     }
                     wave_sync();
                 }
                 // ---- one step of the greedy cut, wave-uniform
+                TSTAMP(3 + 4 * (int)ordinal);
                 const int Hb = tiler_back_halo(dist, s, tc.two_a, cap);
+                TSTAMP(4 + 4 * (int)ordinal);
                 if (Hb < 0) { refused = true; break; }
                 const int64_t cmax = (b - s < WAVE_LANES - Hb) ? b - s : WAVE_LANES - Hb;
                 const int64_t first0 = s - Hb;
@@ -357,6 +417,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                     }
                 }
                 if (c < (b - s < 8 ? b - s : 8)) { refused = true; break; }
+                TSTAMP(5 + 4 * (int)ordinal);
                 const int64_t first = s - Hb, last = s + c - 1 + Hf;
                 // every output point inside the geofence with the margin?
                 bool all_in = true;
@@ -398,12 +459,14 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
                     if (FILL) { T.tiles[stat_base + (span_k > 0 ? 1 : 0) + ordinal] = t; T.wtiles[wave_base + ordinal] = wt; }
                     else { keep_tiles[field * DEVPLAN_KEEP_TILES + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_TILES + ordinal] = wt; }
                 }
+                TSTAMP(6 + 4 * (int)ordinal);
                 inside_cnt += all_in ? 1 : 0;
                 wave_pts += c;
                 ++ordinal;
                 s += c;
             }
             if (!refused) { n_wave = ordinal; c_wave_pts = wave_pts; c_wave_inside = inside_cnt; }
+            TSTAMP(36);
         }
         if (G > 0 && n_wave == 0 && !fallback) {
             // general tiles of at most 512 points, near-equal
@@ -472,8 +535,9 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     const int64_t ne = c_stat;
     if (is_work) { c_work = 1; c_work_wave_pts = c_wave_pts; }
     else { c_open = n_wave; cls = tiler_reduce_class(ne, tc.reduce_wg_max); }
-    if (fallback && lane == 0) atomicOr(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), 1ull);
+    if (fallback && lane == 0) atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), (unsigned long long)tc.gen);
 
+    TSTAMP(37);
     if (!FILL) {
         if (lane == 0) {
             int64_t *c = counts + field;
@@ -485,6 +549,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             c[(int64_t)PC_WORK_WAVE_PTS * n] = c_work_wave_pts; c[(int64_t)PC_WAVE_INSIDE * n] = c_wave_inside;
             c[(int64_t)PC_WORK_SPAN_PTS * n] = c_work_span_pts; c[(int64_t)PC_SPAN_F * n] = c_span_f; c[(int64_t)PC_UNFUSABLE * n] = c_unfusable;
         }
+        TSTAMP(38);
         return;
     }
 
@@ -636,28 +701,34 @@ __global__ void k_debug_math(int fn, int64_t n, const double *__restrict__ a, co
 
 }  // namespace
 
-int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, int64_t n_polys, int check_obstacles)
+int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, const fcpp_field *fields,
+                         int64_t n_polys, int check_obstacles, int64_t *totals_host)
 {
     if (n <= 0) return 0;
-    hipError_t e = hipMemsetAsync(s.totals, 0, (PC_COLS + PF_COUNT) * sizeof(int64_t), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, s.fields_in, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
-                       n_polys, check_obstacles, 0);
-    int rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s);
+    hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                       n_polys, check_obstacles, 0, tc.gen);
+    int rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s, totals_host, 0);
     if (rc) return rc;
     hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, DevConst(), s.fields_tmp, s.prims_tmp,
                        s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
-    rc = launch_scan(st, n, PC_TILES, PC_COLS, s);
+    rc = launch_scan(st, n, PC_TILES, PC_COLS, s, totals_host, 1);
     if (rc) return rc;
-    e = hipGetLastError();
+    const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
-int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s)
+#ifdef FCPP_DIAG_TILE
+extern "C" __attribute__((visibility("default"))) int fcpp_diag_tile_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof g_tile_stamps);
+}
+#endif
+
+int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s, const fcpp_field *fields)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, s.fields_in, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
-                       (int64_t)0, 0, 1);
+    hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                       (int64_t)0, 0, 1, (int64_t)0);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -38,12 +38,18 @@ FCPP_HD void tiler_point_main(const DevField &F, const Pt2 *tu, int64_t idx, int
     }
 }
 
-// sample r of primitive q (the formulas of eval_prim, fcpp_pointfn.h, on the template copies)
-FCPP_HD void tiler_point_prim(const DevPrim &q, const Pt2 *tu, const Pt2 *tc, int64_t r, double &px, double &py)
+// sample r of primitive q (the formulas of eval_prim, fcpp_pointfn.h, on the template copies).  Index: int64_t on the host, int on the
+// device (r < q.n, an int32: the same values -- the conversion to double is exact either way -- with one instruction instead of a sequence)
+template <class Index>
+FCPP_HD void tiler_point_prim(const DevPrim &q, const Pt2 *tu, const Pt2 *tc, Index r, double &px, double &py)
 {
-    if (q.kind == PRIM_LINSPACE) { px = linspace_at(q.a[0], q.a[2], q.a[4], q.n, r); py = linspace_at(q.a[1], q.a[3], q.a[5], q.n, r); }
+    auto lin = [&](double a, double b, double step) -> double {
+        if (sizeof(Index) == 4) return linspace_at32(a, b, step, q.n, (int)r);
+        return linspace_at(a, b, step, q.n, (int64_t)r);
+    };
+    if (q.kind == PRIM_LINSPACE) { px = lin(q.a[0], q.a[2], q.a[4]); py = lin(q.a[1], q.a[3], q.a[5]); }
     else if (q.kind == PRIM_POINT) { px = q.a[0]; py = q.a[1]; }
-    else if (q.kind == PRIM_RAY) { const double t = linspace_at(0.0, q.a[4], q.a[5], q.n, r); px = q.a[0] + t * q.a[2]; py = q.a[1] + t * q.a[3]; }
+    else if (q.kind == PRIM_RAY) { const double t = lin(0.0, q.a[4], q.a[5]); px = q.a[0] + t * q.a[2]; py = q.a[1] + t * q.a[3]; }
     else if (q.kind == PRIM_UTURN) {
         const Pt2 t = tu[r];
         const bool turn_right = q.form & 1;

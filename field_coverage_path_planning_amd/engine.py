@@ -138,6 +138,8 @@ class FieldTable:
 
     def __init__(self, rec, poly_offsets=None, poly_x=None, poly_y=None):
         self.rec = rec
+        self._pinned = None         # the pinned buffer the records live in after pin()
+        self._cargs = None
         self.poly_offsets = np.zeros(1, dtype=np.int64) if poly_offsets is None else np.ascontiguousarray(poly_offsets, dtype=np.int64)
         self.poly_x = np.zeros(0, dtype=np.float64) if poly_x is None else np.ascontiguousarray(poly_x, dtype=np.float64)
         self.poly_y = np.zeros(0, dtype=np.float64) if poly_y is None else np.ascontiguousarray(poly_y, dtype=np.float64)
@@ -148,7 +150,22 @@ class FieldTable:
     def __getitem__(self, sl):
         if not isinstance(sl, slice):
             raise TypeError('a FieldTable is sliced, not indexed')
-        return FieldTable(self.rec[sl], self.poly_offsets, self.poly_x, self.poly_y)
+        t = FieldTable(self.rec[sl], self.poly_offsets, self.poly_x, self.poly_y)
+        t._pinned = self._pinned    # (a slice of pinned records is pinned, and keeps the buffer alive)
+        return t
+
+    def pin(self):
+        """Moves the records into pinned host memory (once; needs a GPU): fcpp_batch_create / fcpp_plan_points then let the device read
+        them where they lie instead of copying them first -- for a table that is planned more than once, or built in place.  -> self"""
+        if self._pinned is None:
+            torch = _torch()
+            dt = _field_dtype()
+            n = len(self)
+            buf = torch.empty(max(n, 1) * dt.itemsize, dtype=torch.uint8, pin_memory=True)
+            rec = buf.numpy().view(dt)[:n]
+            rec[...] = self.rec
+            self.rec, self._pinned, self._cargs = rec, buf, None
+        return self
 
     @staticmethod
     def _points(rec, name, pts):
@@ -219,10 +236,12 @@ class FieldTable:
 
     def c_args(self):
         """-> (fcpp_field pointer, fcpp_polys, objects to keep alive during the call)"""
-        rec = np.ascontiguousarray(self.rec)
-        polys = L.Polys(len(self.poly_offsets) - 1, self.poly_offsets.ctypes.data_as(L.c_i64_p), self.poly_x.ctypes.data_as(L.c_double_p),
-                        self.poly_y.ctypes.data_as(L.c_double_p))
-        return C.cast(C.c_void_p(rec.ctypes.data), C.POINTER(L.Field)), polys, [rec, self.poly_offsets, self.poly_x, self.poly_y]
+        if self._cargs is None:     # (the records are not written after construction: the pointers are made once)
+            rec = np.ascontiguousarray(self.rec)
+            polys = L.Polys(len(self.poly_offsets) - 1, self.poly_offsets.ctypes.data_as(L.c_i64_p), self.poly_x.ctypes.data_as(L.c_double_p),
+                            self.poly_y.ctypes.data_as(L.c_double_p))
+            self._cargs = (C.cast(C.c_void_p(rec.ctypes.data), C.POINTER(L.Field)), polys, [rec, self.poly_offsets, self.poly_x, self.poly_y])
+        return self._cargs
 
 
 def as_table(specs):
@@ -464,7 +483,7 @@ class Batch:
             else:
                 self.layout = {'layout': 'arena', 'pitch_GiB': round(pitch / 2**30, 3), 'lane_GiB': round(lane / 2**30, 3)}
             x, y, kappa, v, fs = arr.tensors(n)
-            stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=torch.device('cuda', self.ctx.device))
+            stats = torch.empty((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=torch.device('cuda', self.ctx.device))
             return x, y, kappa, v, fs, stats
         if layout in ('plain', 'auto'):
             # ('auto' never takes device memory the arrays do not need: the spread placement is the arena's, or an explicit layout='spread')
@@ -497,7 +516,7 @@ class Batch:
             return self._alloc_once()
         x, y, kappa, v = (slab[k * P: k * P + 8 * n].view(torch.float64) for k in range(4))
         fs = slab[4 * P: 4 * P + 4 * n].view(torch.int32)
-        stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
+        stats = torch.empty((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
         self.layout = {'layout': 'spread', 'pitch_GiB': round(P / 2**30, 3), 'allocation_GiB': round((4 * P + S) / 2**30, 3)}
         return x, y, kappa, v, fs, stats
 
@@ -510,7 +529,9 @@ class Batch:
         kappa = torch.empty(n, dtype=torch.float64, device=dev)
         v = torch.empty(n, dtype=torch.float64, device=dev)
         fs = torch.empty(n, dtype=torch.int32, device=dev)
-        stats = torch.zeros((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
+        # (not cleared: fcpp_batch_run writes every field's row, zeros for a field that raised -- a fill kernel here would sit in the
+        # stream in front of the step)
+        stats = torch.empty((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
         return x, y, kappa, v, fs, stats
 
     def _check_buffers(self, buffers):

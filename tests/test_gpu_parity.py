@@ -892,3 +892,40 @@ def test_output_arena_shared_by_live_batches():
         L.check(ctx.lib.fcpp_ctx_reserve_outputs(ctx.handle, 4096, 4096))       # (back to next to nothing for the tests that follow)
     for b in batches:
         b.close()
+
+
+@pytest.mark.parametrize('opt', [dict(), dict(sample_spacing=0.5)])
+def test_statistics_rows_are_written_whatever_the_buffer_held(opt):
+    """fcpp_batch_run writes every field's statistics row -- rows of fields that raise included (zeros) -- in both pipelines: the caller's
+    buffer need not be cleared."""
+    import torch
+    specs = [E.FieldSpec(field_length=500.0, field_width=200.0), E.FieldSpec(field_length=15.0, field_width=200.0),
+             E.FieldSpec(field_length=100.0, field_width=80.0), E.FieldSpec(field_length=10.0, field_width=10.0)]
+    b = E.Batch(specs, _veh(DEFAULT_VP), E.make_options(**opt))
+    for mode in (1, 0):
+        bufs = list(b.alloc())
+        clean = _np(b.run(tuple(bufs), mode=mode).stats_raw).copy()
+        bufs[5] = torch.full_like(bufs[5], 0x5a5a5a5a5a5a5a5a)
+        dirty = _np(b.run(tuple(bufs), mode=mode).stats_raw).copy()
+        assert np.array_equal(clean, dirty)
+        assert not clean[1].any() and not clean[3].any() and clean[0].any()
+    b.close()
+
+
+def test_pinned_field_tables_are_read_where_they_lie():
+    """A FieldTable in pinned host memory (pin()) is not copied before the device plans it; slices of it included.  Same batch as from
+    pageable records."""
+    rng = np.random.default_rng(7)
+    LH = rng.uniform(100.0, 600.0, size=(300, 2))
+    plain = E.FieldTable.from_rectangles(LH)
+    pinned = E.FieldTable.from_rectangles(LH).pin()
+    assert pinned._pinned is not None and np.array_equal(plain.rec, pinned.rec)
+    veh = _veh(DEFAULT_VP)
+    for sl in (slice(0, 300), slice(37, 201)):
+        a, c = E.Batch(plain[sl], veh), E.Batch(pinned[sl], veh)
+        assert a.total_points == c.total_points and np.array_equal(E.plan_points(plain[sl], veh, E.make_options()), E.plan_points(pinned[sl], veh, E.make_options()))
+        ra, rc_ = a.run(), c.run()
+        for u, w in ((ra.x, rc_.x), (ra.y, rc_.y), (ra.v, rc_.v), (ra.kappa, rc_.kappa), (ra.flagseg, rc_.flagseg), (ra.stats_raw, rc_.stats_raw)):
+            assert np.array_equal(_np(u), _np(w))
+        assert np.array_equal(a.info.array, c.info.array)
+        a.close(); c.close()
