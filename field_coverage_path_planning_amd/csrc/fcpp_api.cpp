@@ -735,7 +735,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     tc.tu = reinterpret_cast<const Pt2 *>(ts.tmpl_u.p); tc.tc = reinterpret_cast<const Pt2 *>(ts.tmpl_c.p);
     tc.nu = ts.tt.nu; tc.nc = ts.tt.nc;
     tc.turn_quiet = turn_quiet; tc.wave_factor = 24; tc.field_work_tiles = FIELD_WORK_TILES; tc.max_prims = pc.max_prims;
-    tc.fuse_spans = ts.tt.nu <= TMPL_LDS_SAMPLES; tc._pad = 0;
+    tc.fuse_spans = ts.tt.nu <= TMPL_LDS_SAMPLES; tc.no_bases = 0;
     tc.two_a = 2 * b->cst.a_lon; tc.u_cap = b->cst.u_cap; tc.c_line = b->cst.ms_work * b->cst.ms_work;
     tc.fence_margin = 1e-7 - opt.geofence_tol;
     tc.reduce_wg_max = 1024;

@@ -35,7 +35,8 @@ enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_COUNT = 2 };
 struct DevTileConsts {
     const Pt2 *tu, *tc;           // the batch's U-turn / corner templates (device)
     int32_t nu, nc;
-    int32_t turn_quiet, wave_factor, field_work_tiles, max_prims, fuse_spans, _pad;
+    int32_t turn_quiet, wave_factor, field_work_tiles, max_prims, fuse_spans;
+    int32_t no_bases;             // counting pass of a small batch: the fields' point offsets are not known yet (ONE scan, after the pass)
     double two_a, u_cap, c_line, fence_margin;
     int64_t reduce_wg_max;
     int64_t gen;                  // this counting phase's generation number (> 0)
@@ -73,6 +74,9 @@ constexpr int DEVPLAN_WINDOW = 576;
 constexpr int DEVPLAN_PRIMS_CAP = 255;
 constexpr int DEVPLAN_KEEP_TILES = 8;
 
+// Small batches (at most 8192 fields) are counted WITHOUT the fields' point offsets: what depends on a span's alignment in the batch arrays
+// -- its chunk count, hence whether its field's workgroup can write it (PC_SPAN, PC_SPAN_F, PC_WORK_SPAN_PTS, PC_UNFUSABLE) -- is derived by the
+// one scan that follows the pass, from the offsets it has just computed (span_counts): one launch and one scan fewer in front of the pass.
 // phase 1: plan + count.  Enqueues k_plan_fields, the scans and the counting pass; afterwards totals[] holds the sums and the flags, and so
 // does totals_host (pinned host memory the device can write, or null) once the stream has got there: the scans write it themselves.
 // fields: the records as the device reaches them (s.fields_in after a copy, or the caller's pinned memory).

@@ -133,20 +133,77 @@ __global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int
     for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
 }
 
-// small batches: one workgroup per column walks the fields in chunks of 1024 -- one launch instead of three
-__global__ __launch_bounds__(256) void k_scan_small(int64_t n, int c0, const int64_t *__restrict__ counts, int64_t *__restrict__ bases, int64_t *__restrict__ totals,
-                                                    int64_t *__restrict__ mirror, int with_flags)
+// what depends on where a field's span lies in the batch arrays (pt_off): its 512-point chunks, whether its field's own workgroup can write
+// it (at most FUSED_SPAN_CHUNKS of them), the alternatives the host chooses between once it has the totals
+__device__ __forceinline__ void span_counts(int64_t pt_off, int64_t S, bool is_work, bool fuse_possible, int64_t &c_span, int64_t &c_span_f,
+                                            int64_t &c_work_span_pts, int64_t &c_unfusable)
 {
-    __shared__ int64_t lds[4];
+    c_span = c_span_f = c_work_span_pts = c_unfusable = 0;
+    if (S <= 0) return;
+    const int64_t n_chunks = ((pt_off % TILE_POINTS) + S + TILE_POINTS - 1) / TILE_POINTS;
+    const bool fusable = is_work && n_chunks <= FUSED_SPAN_CHUNKS;
+    const int64_t fused = (fusable && fuse_possible) ? S : 0;
+    c_span = n_chunks; c_span_f = fused > 0 ? 0 : n_chunks; c_work_span_pts = fused; c_unfusable = (is_work && !fusable) ? 1 : 0;
+}
+
+// small batches: one workgroup of 1024 threads per column walks the fields in chunks of 4096 -- one launch instead of three, and one
+// pass for the headline's 4096 fields.  derive: the columns that depend on the fields' point offsets (span_counts) are made here, by
+// their own workgroups, from the offsets (a scan of PC_POINTS of their own), the spans' lengths (PC_SPAN_PTS) and PC_WORK.
+__global__ __launch_bounds__(1024) void k_scan_small(int64_t n, int c0, int64_t *__restrict__ counts, int64_t *__restrict__ bases, int64_t *__restrict__ totals,
+                                                     int64_t *__restrict__ mirror, int with_flags, int derive, int fuse_possible)
+{
+    __shared__ int64_t lds[16];
     const int col = c0 + blockIdx.x;
-    int64_t carry = 0;
-    for (int64_t b0 = 0; b0 < n; b0 += 1024) {
-        const int64_t base = b0 + (int64_t)threadIdx.x * 4;
-        int64_t v[4], s = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // exclusive scan over the workgroup's 4096 elements (four a thread): -> the base of the thread's first, tot = the chunk's sum
+    auto scan4 = [&](const int64_t (&v)[4], int64_t &tot) -> int64_t {
+        const int64_t s = v[0] + v[1] + v[2] + v[3];
+        int64_t inc = s;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? counts[(int64_t)col * n + base + k] : 0; s += v[k]; }
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) lds[wave] = inc;
+        __syncthreads();
+        int64_t pre = 0, t = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int64_t x = lds[q]; if (q < wave) pre += x; t += x; }
+        __syncthreads();
+        tot = t;
+        return inc + pre - s;
+    };
+    const bool derived = derive && (col == PC_SPAN || col == PC_SPAN_F || col == PC_WORK_SPAN_PTS || col == PC_UNFUSABLE);
+    int64_t carry = 0, carry_pts = 0;
+    for (int64_t b0 = 0; b0 < n; b0 += 4096) {
+        const int64_t base = b0 + (int64_t)threadIdx.x * 4;
+        int64_t v[4];
+        if (derived) {
+            int64_t pts[4], S[4], work[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = base + k < n;
+                pts[k] = in ? counts[(int64_t)PC_POINTS * n + base + k] : 0;
+                S[k] = in ? counts[(int64_t)PC_SPAN_PTS * n + base + k] : 0;
+                work[k] = in ? counts[(int64_t)PC_WORK * n + base + k] : 0;
+            }
+            int64_t tot_pts;
+            int64_t off = scan4(pts, tot_pts) + carry_pts;
+            carry_pts += tot_pts;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int64_t c_span, c_span_f, c_wsp, c_unf;
+                span_counts(off, S[k], work[k] != 0, fuse_possible != 0, c_span, c_span_f, c_wsp, c_unf);
+                v[k] = col == PC_SPAN ? c_span : (col == PC_SPAN_F ? c_span_f : (col == PC_WORK_SPAN_PTS ? c_wsp : c_unf));
+                if (base + k < n) counts[(int64_t)col * n + base + k] = v[k];
+                off += pts[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = base + k < n ? counts[(int64_t)col * n + base + k] : 0;
+        }
         int64_t tot;
-        int64_t run = wg_incl_scan(s, lds, tot) - s + carry;
+        int64_t run = scan4(v, tot) + carry;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
         carry += tot;
@@ -156,12 +213,12 @@ __global__ __launch_bounds__(256) void k_scan_small(int64_t n, int c0, const int
 
 // mirror: the totals' copy in the host's pinned memory (or null), written by the scans themselves -- no copy command behind them;
 // with_flags: the flags the earlier kernels raised go along (the last scan of the counting phase)
-int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s, int64_t *mirror, int with_flags)
+int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s, int64_t *mirror, int with_flags, int derive = 0, int fuse_possible = 0)
 {
     const int64_t nblk = (n + 1023) / 1024;
     const int nc = c1 - c0;
     if (nblk <= 8) {
-        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags);
+        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(1024), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags, derive, fuse_possible);
         const hipError_t e0 = hipGetLastError();
         return e0 == hipSuccess ? 0 : (int)e0;
     }
@@ -182,10 +239,12 @@ int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch 
 // Diagnostic build only (-DFCPP_DIAG_TILE: `make diag-tile`, tools/diag_tile.py; never shipped): 10 ns time stamps of the phases of field
 // 1000's counting pass.
 #ifdef FCPP_DIAG_TILE
-__device__ unsigned long long g_tile_stamps[40];
+__device__ unsigned long long g_tile_stamps[40], g_fill_stamps[40];
 #define TSTAMP(k) do { if (!FILL && field == 1000 && lane == 0 && (k) < 40) g_tile_stamps[k] = wall_clock64(); } while (0)
+#define FSTAMP(k) do { if (FILL && field == 1000 && lane == 0 && (k) < 40) g_fill_stamps[k] = wall_clock64(); } while (0)
 #else
 #define TSTAMP(k) do { } while (0)
+#define FSTAMP(k) do { } while (0)
 #endif
 constexpr int TW_WAVES = 2;                                             // fields per workgroup
 constexpr int TW_NW = DEVPLAN_WINDOW;                                   // points of the LDS window that slides along a general stretch
@@ -205,7 +264,7 @@ struct TileWaveLds {
 __device__ __forceinline__ int32_t clampi(int64_t v) { return (int32_t)(v < -2 ? -2 : (v > ((int64_t)1 << 30) ? ((int64_t)1 << 30) : v)); }
 
 template <bool FILL>
-__global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTileConsts tc, DevConst cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
+__global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, DevTileConsts tc, DevConst cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
                                                               fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
                                                               const int64_t *__restrict__ bases, int64_t *__restrict__ totals,
                                                               DevTile *__restrict__ keep_tiles, DevWaveTile *__restrict__ keep_wtiles, DevPlanTables T)
@@ -215,13 +274,15 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     const int64_t field = (int64_t)blockIdx.x * TW_WAVES + wave;
     if (field >= n) return;
     TSTAMP(0);
+    FSTAMP(0);
     TileWaveLds &L = lds_all[wave];
     const DevField &F = ftmp[field];
     const DevPrim *prims = ptmp + field * tc.max_prims;
     const int64_t n_total = F.n_total;
     auto base_of = [&](int col) -> int64_t { return bases[(int64_t)col * n + field]; };
-    const int64_t pt_off = base_of(PC_POINTS);       // (scanned before either pass)
-    if (!FILL && lane == 0) info[field].point_offset = pt_off;
+    // (scanned before either pass -- except before the counting pass of a small batch: tc.no_bases, see span_counts)
+    const bool no_bases = !FILL && tc.no_bases != 0;
+    const int64_t pt_off = no_bases ? 0 : base_of(PC_POINTS);
 
     // the field's counts (count pass) / positions (fill pass)
     int64_t c_tiles = 0, c_wave = 0, c_general = 0, c_stat = 0, c_span = 0, c_work = 0, c_open = 0, c_runs = 0, c_span_pts = 0, c_wave_pts = 0,
@@ -234,9 +295,28 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     }
     const int prim_count = F.prim_count;
     const int64_t prim_index0 = prim_base;           // batch-wide index of the field's first primitive (fill pass)
+    // fill pass: everything it copies out of the scratch -- the field's descriptor, its fcpp_field_info, its primitives, a word per lane and
+    // round -- is requested here, before the cut: the copies further down then wait for nothing (they were a chain of six round trips)
+    constexpr int NFW = (int)(sizeof(DevField) / 8), NIW = (int)(sizeof(fcpp_field_info) / 8), PWD = (int)(sizeof(DevPrim) / 8), PF_ROUNDS = 7;
+    static_assert(sizeof(DevField) % 8 == 0 && sizeof(DevPrim) % 8 == 0 && sizeof(fcpp_field_info) % 8 == 0 && NFW <= 64 && NIW <= 64, "copied as 8-byte words, a lane each");
+    unsigned long long fw = 0, iw = 0, pw[PF_ROUNDS];
+    const int nwords_p = prim_count * PWD;
+    if (FILL) {
+        if (lane < NFW) fw = reinterpret_cast<const unsigned long long *>(&F)[lane];
+        if (lane < NIW) iw = reinterpret_cast<const unsigned long long *>(&info[field])[lane];
+#pragma unroll
+        for (int j = 0; j < PF_ROUNDS; ++j) { const int k = lane + 64 * j; pw[j] = k < nwords_p ? reinterpret_cast<const unsigned long long *>(prims)[k] : 0ull; }
+        // (pt_off and prim_first become batch-wide: patched by the lane that holds their word)
+        constexpr int W_PT = (int)(offsetof(DevField, pt_off) / 8), W_PF = (int)(offsetof(DevField, prim_first) / 8);
+        constexpr bool PF_HI = (offsetof(DevField, prim_first) % 8) != 0;
+        if (lane == W_PT) fw = (unsigned long long)pt_off;
+        if (lane == (int)(offsetof(fcpp_field_info, point_offset) / 8)) iw = (unsigned long long)pt_off;      // (the planner left it 0)
+        if (lane == W_PF) fw = PF_HI ? ((fw & 0xffffffffull) | ((unsigned long long)(uint32_t)prim_base << 32)) : ((fw & 0xffffffff00000000ull) | (unsigned long long)(uint32_t)prim_base);
+    }
 
     bool fallback = false, is_work = false;
     TSTAMP(1);
+    FSTAMP(1);
     int64_t S = 0, span_k = 0, fused_span = 0;
     int64_t n_wave = 0, n_general = 0;
     // fill pass, lane t: the field's t-th wave tile as written (t < DEVPLAN_KEEP_TILES), its first primitive within the field and the
@@ -296,15 +376,33 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             const int64_t lo_all = (a - WAVE_HALO_MAX - 2 > 1) ? a - WAVE_HALO_MAX - 2 : 1;
             const int64_t hi_all = (b + WAVE_HALO_MAX + 2 < n_total) ? b + WAVE_HALO_MAX + 2 : n_total;
             const int64_t n_main = F.n_main;
-            for (int k = lane; k < prim_count; k += 64) L.pstart[k] = (int32_t)(prims[k].start - n_main);
             const bool lds_prims = prim_count <= TW_LDS_PRIMS, lds_tmpl = tc.nu + tc.nc <= TW_LDS_TMPL;
-            if (lds_prims) {
+            if (lds_prims && lds_tmpl) {
+                // the usual field: starts, records and templates requested together, then stored -- one round trip to memory, not three
+                static_assert(TW_LDS_PRIMS <= 64 && TW_LDS_TMPL <= 64 && TW_LDS_PRIMS * (sizeof(DevPrim) / 8) <= 6 * 64, "a lane each / six words a lane");
                 const unsigned long long *src = reinterpret_cast<const unsigned long long *>(prims);
-                for (int k = lane; k < prim_count * (int)(sizeof(DevPrim) / 8); k += 64) L.prim_words[k] = src[k];
-            }
-            if (lds_tmpl) {
-                for (int k = lane; k < tc.nu; k += 64) L.tmpl[k] = tc.tu[k];
-                for (int k = lane; k < tc.nc; k += 64) L.tmpl[tc.nu + k] = tc.tc[k];
+                const int nw = prim_count * (int)(sizeof(DevPrim) / 8);
+                const int64_t st = lane < prim_count ? prims[lane].start : 0;
+                unsigned long long w6[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const int k = lane + 64 * j; w6[j] = k < nw ? src[k] : 0ull; }
+                Pt2 tp = { 0.0, 0.0 };
+                if (lane < tc.nu) tp = tc.tu[lane];
+                else if (lane < tc.nu + tc.nc) tp = tc.tc[lane - tc.nu];
+                if (lane < prim_count) L.pstart[lane] = (int32_t)(st - n_main);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const int k = lane + 64 * j; if (k < nw) L.prim_words[k] = w6[j]; }
+                if (lane < tc.nu + tc.nc) L.tmpl[lane] = tp;
+            } else {
+                for (int k = lane; k < prim_count; k += 64) L.pstart[k] = (int32_t)(prims[k].start - n_main);
+                if (lds_prims) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(prims);
+                    for (int k = lane; k < prim_count * (int)(sizeof(DevPrim) / 8); k += 64) L.prim_words[k] = src[k];
+                }
+                if (lds_tmpl) {
+                    for (int k = lane; k < tc.nu; k += 64) L.tmpl[k] = tc.tu[k];
+                    for (int k = lane; k < tc.nc; k += 64) L.tmpl[tc.nu + k] = tc.tc[k];
+                }
             }
             const DevPrim *const wprims = lds_prims ? reinterpret_cast<const DevPrim *>(L.prim_words) : prims;
             const Pt2 *const wtu = lds_tmpl ? L.tmpl : tc.tu, *const wtc = lds_tmpl ? L.tmpl + tc.nu : tc.tc;
@@ -498,15 +596,10 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
         if (span_k > 0) {
             c_runs = 1; c_span_pts = S;
             const int64_t g0 = pt_off;                           // the span starts the path
-            const int64_t n_chunks = ((g0 % TILE_POINTS) + S + TILE_POINTS - 1) / TILE_POINTS;
             // (counting pass: fuse_spans = fusing is possible for this batch, both alternatives are counted; fill pass: the host's
             // decision -- all fields of field work have fusable spans, or nothing is fused)
-            const bool fusable = is_work && n_chunks <= FUSED_SPAN_CHUNKS;
-            fused_span = (fusable && tc.fuse_spans) ? S : 0;
-            c_span = n_chunks;
-            c_span_f = fused_span > 0 ? 0 : n_chunks;
-            c_work_span_pts = fused_span;
-            c_unfusable = (is_work && !fusable) ? 1 : 0;
+            if (!no_bases) span_counts(g0, S, is_work, tc.fuse_spans != 0, c_span, c_span_f, c_work_span_pts, c_unfusable);
+            fused_span = c_work_span_pts;
             if (FILL && fused_span > 0) c_span = 0;          // (no chunk records for a fused span)
             if (FILL) {
                 const int64_t bs = S / span_k, rem = S % span_k;
@@ -538,41 +631,39 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
     if (fallback && lane == 0) atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), (unsigned long long)tc.gen);
 
     TSTAMP(37);
+    FSTAMP(2);
     if (!FILL) {
         if (lane == 0) {
             int64_t *c = counts + field;
             c[(int64_t)PC_TILES * n] = c_tiles; c[(int64_t)PC_WAVE * n] = c_wave; c[(int64_t)PC_GENERAL * n] = c_general; c[(int64_t)PC_STAT * n] = c_stat;
-            c[(int64_t)PC_SPAN * n] = c_span; c[(int64_t)PC_WORK * n] = c_work; c[(int64_t)PC_OPEN * n] = c_open;
+            c[(int64_t)PC_WORK * n] = c_work; c[(int64_t)PC_OPEN * n] = c_open;
+            if (!no_bases) { c[(int64_t)PC_SPAN * n] = c_span; c[(int64_t)PC_WORK_SPAN_PTS * n] = c_work_span_pts; c[(int64_t)PC_SPAN_F * n] = c_span_f; c[(int64_t)PC_UNFUSABLE * n] = c_unfusable; }
             c[(int64_t)PC_CLS0 * n] = (!is_work && cls == 0) ? 1 : 0; c[(int64_t)PC_CLS1 * n] = (!is_work && cls == 1) ? 1 : 0;
             c[(int64_t)PC_CLS2 * n] = (!is_work && cls == 2) ? 1 : 0; c[(int64_t)PC_CLS3 * n] = (!is_work && cls == 3) ? 1 : 0;
             c[(int64_t)PC_RUNS * n] = c_runs; c[(int64_t)PC_SPAN_PTS * n] = c_span_pts; c[(int64_t)PC_WAVE_PTS * n] = c_wave_pts;
             c[(int64_t)PC_WORK_WAVE_PTS * n] = c_work_wave_pts; c[(int64_t)PC_WAVE_INSIDE * n] = c_wave_inside;
-            c[(int64_t)PC_WORK_SPAN_PTS * n] = c_work_span_pts; c[(int64_t)PC_SPAN_F * n] = c_span_f; c[(int64_t)PC_UNFUSABLE * n] = c_unfusable;
         }
         TSTAMP(38);
         return;
     }
 
     // ---- fill pass: the field's descriptor and primitives at their final places, the statistics entries, the work lists
+    const bool lds_pack = prim_count <= TW_LDS_PRIMS;        // the pack's copies of the primitives come out of LDS
     {
-        // (8-byte words: DevField and DevPrim are arrays of them)
-        static_assert(sizeof(DevField) % 8 == 0 && sizeof(DevPrim) % 8 == 0, "copied as 8-byte words");
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&F);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(&T.fields[field]);
-        // (pt_off and prim_first become batch-wide: patched by the lane that copies their word)
-        constexpr int W_PT = (int)(offsetof(DevField, pt_off) / 8), W_PF = (int)(offsetof(DevField, prim_first) / 8);
-        constexpr bool PF_HI = (offsetof(DevField, prim_first) % 8) != 0;
-        for (int k = lane; k < (int)(sizeof(DevField) / 8); k += 64) {
-            unsigned long long v = src[k];
-            if (k == W_PT) v = (unsigned long long)pt_off;
-            if (k == W_PF) v = PF_HI ? ((v & 0xffffffffull) | ((unsigned long long)(uint32_t)prim_base << 32)) : ((v & 0xffffffff00000000ull) | (unsigned long long)(uint32_t)prim_base);
-            dst[k] = v;
-        }
+        if (lane < NFW) dst[lane] = fw;
         const unsigned long long *ps = reinterpret_cast<const unsigned long long *>(prims);
         unsigned long long *pd = reinterpret_cast<unsigned long long *>(T.prims + prim_base);
-        const int nwords = prim_count * (int)(sizeof(DevPrim) / 8);
-        for (int k = lane; k < nwords; k += 64) pd[k] = ps[k];
+        if (lds_pack) wave_sync();                           // (a field cut again above has read its primitives from there)
+#pragma unroll
+        for (int j = 0; j < PF_ROUNDS; ++j) {
+            const int k = lane + 64 * j;
+            if (k < nwords_p) { pd[k] = pw[j]; if (lds_pack) L.prim_words[k] = pw[j]; }
+        }
+        for (int k = lane + 64 * PF_ROUNDS; k < nwords_p; k += 64) pd[k] = ps[k];
+        if (lds_pack) wave_sync();
     }
+    FSTAMP(3);
     // entries in path order: the span's run, then the wave tiles / general tiles
     if (span_k > 0 && lane == 0) { T.stat_ids[stat_base] = (int32_t)stat_base; T.stat_run[stat_base] = S; }
     {
@@ -599,16 +690,25 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             for (int k = 0; k < cls; ++k) cls_first += totals[PC_CLS0 + k];
             T.red_paths[cls_first + base_of(PC_CLS0 + cls)] = (int32_t)field;
         }
-        // connector segments (MLP:1313-1355): approach rows [0, n), departure rows [n, 2n)
-        const fcpp_field_info &in = info[field];
-        const bool okf = in.status == FCPP_OK;
-        double *sg = T.seg + field * 4;
-        sg[0] = in.approach_from[0]; sg[1] = in.approach_from[1]; sg[2] = in.approach_to[0]; sg[3] = in.approach_to[1];
-        T.seg_mask[field] = okf && in.start_kept;
-        double *q = T.seg + (n + field) * 4;
-        q[0] = in.departure_from[0]; q[1] = in.departure_from[1]; q[2] = in.departure_to[0]; q[3] = in.departure_to[1];
-        T.seg_mask[n + field] = okf && in.end_kept;
     }
+    {
+        // connector segments (MLP:1313-1355): approach rows [0, n), departure rows [n, 2n) -- out of the lanes' words of fcpp_field_info
+        constexpr int W_AF = (int)(offsetof(fcpp_field_info, approach_from) / 8), W_DF = (int)(offsetof(fcpp_field_info, departure_from) / 8);
+        constexpr int W_ST = (int)(offsetof(fcpp_field_info, status) / 8), W_SK = (int)(offsetof(fcpp_field_info, start_kept) / 8), W_EK = (int)(offsetof(fcpp_field_info, end_kept) / 8);
+        static_assert(offsetof(fcpp_field_info, approach_to) == offsetof(fcpp_field_info, approach_from) + 16 &&
+                      offsetof(fcpp_field_info, departure_to) == offsetof(fcpp_field_info, departure_from) + 16, "four doubles each");
+        auto i32_of = [&](int w, bool hi) -> int32_t { const unsigned long long v = __shfl(iw, w); return (int32_t)(hi ? (v >> 32) : (v & 0xffffffffull)); };
+        const int32_t status = i32_of(W_ST, offsetof(fcpp_field_info, status) % 8 != 0);
+        const int32_t start_kept = i32_of(W_SK, offsetof(fcpp_field_info, start_kept) % 8 != 0), end_kept = i32_of(W_EK, offsetof(fcpp_field_info, end_kept) % 8 != 0);
+        const bool okf = status == FCPP_OK;
+        // lanes 0..3: the approach's four doubles, lanes 4..7: the departure's
+        const unsigned long long cw = __shfl(iw, lane < 4 ? W_AF + lane : W_DF + (lane & 3));
+        unsigned long long *sg = reinterpret_cast<unsigned long long *>(T.seg);
+        if (lane < 4) sg[field * 4 + lane] = cw;
+        else if (lane < 8) sg[(n + field) * 4 + (lane - 4)] = cw;
+        if (lane == 0) { T.seg_mask[field] = okf && start_kept; T.seg_mask[n + field] = okf && end_kept; }
+    }
+    FSTAMP(4);
     if (!is_work) {
         const int64_t ob = base_of(PC_OPEN);
         for (int64_t j = lane; j < n_wave; j += 64) T.open_wave_ids[ob + j] = (int32_t)(wave_base + j);
@@ -618,25 +718,19 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
         DevFieldPack &P = T.field_packs[base_of(PC_WORK)];
         if (lane < FIELD_WORK_TILES) P.tile[lane] = my_wt;               // (lanes without a tile hold zeros)
         {
-            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&F);
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(&P.field);
-            constexpr int W_PT = (int)(offsetof(DevField, pt_off) / 8), W_PF = (int)(offsetof(DevField, prim_first) / 8);
-            constexpr bool PF_HI = (offsetof(DevField, prim_first) % 8) != 0;
-            for (int k = lane; k < (int)(sizeof(DevField) / 8); k += 64) {
-                unsigned long long v = src[k];
-                if (k == W_PT) v = (unsigned long long)pt_off;
-                if (k == W_PF) v = PF_HI ? ((v & 0xffffffffull) | ((unsigned long long)(uint32_t)prim_base << 32)) : ((v & 0xffffffff00000000ull) | (unsigned long long)(uint32_t)prim_base);
-                dst[k] = v;
-            }
+            if (lane < NFW) dst[lane] = fw;
         }
-        constexpr int PW = (int)(sizeof(DevPrim) / 8), TW = PACK_TILE_PRIMS * PW;     // 8-byte words per primitive / per tile's copy
+        constexpr int PW = PWD, TW = PACK_TILE_PRIMS * PW;     // 8-byte words per primitive / per tile's copy
         const unsigned long long *psrc = reinterpret_cast<const unsigned long long *>(prims);
         unsigned long long *pdst = reinterpret_cast<unsigned long long *>(&P.prims[0][0]);
         for (int t = 0; t < FIELD_WORK_TILES; ++t) {
             const int p0 = __shfl(my_p0_rel, t), np = __shfl(my_np, t);
-            for (int k = lane; k < TW; k += 64) pdst[t * TW + k] = (k / PW < np) ? psrc[(int64_t)p0 * PW + k] : 0ull;
+            for (int k = lane; k < TW; k += 64)
+                pdst[t * TW + k] = (k / PW < np) ? (lds_pack ? L.prim_words[p0 * PW + k] : psrc[(int64_t)p0 * PW + k]) : 0ull;
         }
     }
+    FSTAMP(5);
     // ---- what the host path computes with three more launches after its copy (k_field_junctions, k_run_consts, k_work_totals), per field:
     // the junction after a U-turn, the closed-form statistics of the field's span in its slot (zeros in the slots of its tiles), and for a
     // field of field work the sum of its runs' statistics
@@ -654,6 +748,7 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
             tp = quiet_run_partial(run, tl, fv, T.prims, cst);
             tp.n_viol = tp.n_outside = tp.n_in_obstacle = tp.n_adjusted = 0;
         }
+        FSTAMP(6);
         static_assert(sizeof(TilePartial) == 13 * 8, "thirteen 8-byte components");
         // slots: entry 0 = the span's (when there is one), the others zero
         unsigned long long *slots = reinterpret_cast<unsigned long long *>(T.partial + stat_base);
@@ -683,10 +778,10 @@ __global__ __launch_bounds__(64 * TW_WAVES) void k_tile_fields(int64_t n, DevTil
         }
         // the field's fcpp_field_info stays with the batch (fcpp_batch_info copies it back when asked)
         static_assert(sizeof(fcpp_field_info) % 8 == 0, "copied as 8-byte words");
-        const unsigned long long *is = reinterpret_cast<const unsigned long long *>(&info[field]);
         unsigned long long *id = reinterpret_cast<unsigned long long *>(&T.info[field]);
-        for (int k = lane; k < (int)(sizeof(fcpp_field_info) / 8); k += 64) id[k] = is[k];
+        if (lane < NIW) id[lane] = iw;
     }
+    FSTAMP(7);
 }
 
 __global__ void k_debug_math(int fn, int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o0, double *__restrict__ o1)
@@ -707,10 +802,24 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
                        n_polys, check_obstacles, 0, tc.gen);
-    int rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s, totals_host, 0);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, DevConst(), s.fields_tmp, s.prims_tmp,
+    // small batches: the counting pass goes without the fields' point offsets, ONE scan follows it (span_counts); large ones: a scan of
+    // points and primitives, the pass, a scan of its columns
+    const bool one_scan = (n + 1023) / 1024 <= 8;
+    DevTileConsts tcc = tc;
+    tcc.no_bases = one_scan ? 1 : 0;
+    int rc = 0;
+    if (!one_scan) {
+        rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s, totals_host, 0);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
                        s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
+    if (one_scan) {
+        rc = launch_scan(st, n, PC_POINTS, PC_COLS, s, totals_host, 1, 1, tc.fuse_spans);
+        if (rc) return rc;
+        const hipError_t e1 = hipGetLastError();
+        return e1 == hipSuccess ? 0 : (int)e1;
+    }
     rc = launch_scan(st, n, PC_TILES, PC_COLS, s, totals_host, 1);
     if (rc) return rc;
     const hipError_t e = hipGetLastError();
@@ -721,6 +830,10 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
 extern "C" __attribute__((visibility("default"))) int fcpp_diag_tile_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof g_tile_stamps);
+}
+extern "C" __attribute__((visibility("default"))) int fcpp_diag_fill_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_stamps), sizeof g_fill_stamps);
 }
 #endif
 

@@ -17,6 +17,9 @@ for r in range(5):
     out = (C.c_uint64 * 40)()
     rc = L.load().fcpp_diag_tile_stamps(out)
     st = list(out)
+    out2 = (C.c_uint64 * 40)()
+    L.load().fcpp_diag_fill_stamps(out2)
+    fs = list(out2)
     b.close()
 names = {0: 'entry', 1: 'field read', 2: 'staged', 36: 'cut done', 37: 'decisions', 38: 'counts written'}
 for k in range(4):
@@ -27,3 +30,10 @@ for k in sorted(names, key=lambda k: st[k]):
     if st[k]:
         print(f'{names[k]:24s} +{(st[k] - prev) * 10:6d} ns   at {(st[k] - t0) * 10:6d} ns')
         prev = st[k]
+
+print('fill pass of the same field:')
+fn = {0: 'entry', 1: 'field read', 2: 'cut / kept tiles / span', 3: 'field + primitives copied', 4: 'entries, work record, connectors', 5: 'pack', 6: 'junction + span statistics', 7: 'slots, totals, info'}
+prev = fs[0]
+for k in sorted(fn):
+    print(f'{fn[k]:36s} +{(fs[k] - prev) * 10:6d} ns   at {(fs[k] - fs[0]) * 10:6d} ns')
+    prev = fs[k]
