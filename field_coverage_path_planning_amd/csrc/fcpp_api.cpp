@@ -558,7 +558,10 @@ int fcpp_plan_points(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *o
     if ((rc = plan_scratch(c, n_fields, pc.max_prims, st, s, err)) != FCPP_OK) return fail(rc, err);
     const fcpp_field *dev_fields = nullptr;
     if ((rc = device_fields(fields, n_fields, st, s, dev_fields, err)) != FCPP_OK) return fail(rc, err);
-    LAUNCHCHK(launch_devplan_points(st, n_fields, pc, s, dev_fields));
+    {   // (whatever was launched may still be reading the caller's pinned records: drained before an error goes back)
+        const int lrc = launch_devplan_points(st, n_fields, pc, s, dev_fields);
+        if (lrc) { (void)hipStreamSynchronize(st); return fail(FCPP_EHIP, std::string("launch_devplan_points: ") + hipGetErrorString((hipError_t)lrc)); }
+    }
     HIPCHK(hipMemcpyAsync(points_out, s.counts + (int64_t)PC_POINTS * n_fields, (size_t)n_fields * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return FCPP_OK;
@@ -743,7 +746,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     tc.gen = ++c->plan_gen;
     int64_t *tot = c->plan_totals_host;
     int lrc = launch_devplan_count(st, n_fields, pc, tc, s, dev_fields, n_polys, obstacles != nullptr, tot);
-    if (lrc) { err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    if (lrc) { (void)hipStreamSynchronize(st); err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }   // (drained: the caller's pinned records may still be read)
     DEVCHK(hipStreamSynchronize(st));        // (the last scan has written the totals and the flags to `tot`)
     tm.host_plan_ms = ms_since(t0);          // (the plan and the counting pass, on the device)
     if (tot[PC_COLS + PF_BAD_OBSTACLES] == tc.gen) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
