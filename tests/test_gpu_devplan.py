@@ -92,6 +92,14 @@ def test_parallelograms_tables_equal_the_hosts():
     _compare(*_both(E.FieldTable.from_vertices(V[:777]), E.make_vehicle(), E.make_options(ring_order=1)), 'cfg5 ring 1')
 
 
+def test_a_batch_beyond_the_one_scan_limit_equals_the_hosts():
+    """More than 8192 fields: the counting pass runs behind a scan of its own (points, primitives) and the three-kernel scans; at most
+    8192: one scan after the pass derives what depends on the spans' alignment.  Both against the host's tables."""
+    V = WL.cfg5_parallelograms(9001)
+    _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(), E.make_options()), 'cfg5 x 9001')
+    _compare(*_both(E.FieldTable.from_vertices(V[:8192]), E.make_vehicle(), E.make_options()), 'cfg5 x 8192')
+
+
 def _random_quads(rng, n):
     """convex quadrilaterals of every shape class, some too small to plan (they raise: status < 0), some degenerate"""
     out = np.empty((n, 4, 2))
