@@ -137,12 +137,22 @@ class FieldTable:
     slice shares the polygon table."""
 
     def __init__(self, rec, poly_offsets=None, poly_x=None, poly_y=None):
+        self._cargs = None
         self.rec = rec
         self._pinned = None         # the pinned buffer the records live in after pin()
-        self._cargs = None
         self.poly_offsets = np.zeros(1, dtype=np.int64) if poly_offsets is None else np.ascontiguousarray(poly_offsets, dtype=np.int64)
         self.poly_x = np.zeros(0, dtype=np.float64) if poly_x is None else np.ascontiguousarray(poly_x, dtype=np.float64)
         self.poly_y = np.zeros(0, dtype=np.float64) if poly_y is None else np.ascontiguousarray(poly_y, dtype=np.float64)
+
+    @property
+    def rec(self):
+        """the fcpp_field records (a numpy record array; written in place they stay what the library reads)"""
+        return self._rec
+
+    @rec.setter
+    def rec(self, value):
+        self._rec = value
+        self._cargs = None          # (the pointers c_args() made are another array's)
 
     def __len__(self):
         return int(self.rec.shape[0])
