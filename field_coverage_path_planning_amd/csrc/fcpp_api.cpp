@@ -182,6 +182,7 @@ struct fcpp_ctx {
     int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values: the scans of the counting phase write them here
     int64_t plan_gen = 0;                           // generation number of the last counting phase (PlanFlag, fcpp_devplan.h)
     hipEvent_t ev_plan = nullptr; bool ev_plan_set = false;
+    hipEvent_t ev_totals = nullptr;                 // behind the counting phase's last scan (a speculative setup waits for it, not for the stream)
     // the output arena (fcpp_ctx_reserve_outputs): ONE allocation of 4 x pitch + lane bytes; array k of every batch's outputs lies in lane k
     // (lanes `pitch` apart), placed first-fit among the live allocations of the lane -- all five arrays of an allocation at the same offset
     void *arena = nullptr; size_t arena_pitch = 0, arena_lane = 0;
@@ -360,6 +361,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->plan_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->plan_scratch); }
     if (c->arena) { (void)hipDeviceSynchronize(); (void)hipFree(c->arena); }
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->ev_totals) (void)hipEventDestroy(c->ev_totals);
     if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
     if (c->verify_scratch) (void)hipFree(c->verify_scratch);
     c->templates.reset();
@@ -745,38 +747,21 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
     tc.gen = ++c->plan_gen;
     int64_t *tot = c->plan_totals_host;
-    int lrc = launch_devplan_count(st, n_fields, pc, tc, s, dev_fields, n_polys, obstacles != nullptr, tot);
-    if (lrc) { (void)hipStreamSynchronize(st); err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }   // (drained: the caller's pinned records may still be read)
-    DEVCHK(hipStreamSynchronize(st));        // (the last scan has written the totals and the flags to `tot`)
-    tm.host_plan_ms = ms_since(t0);          // (the plan and the counting pass, on the device)
-    if (tot[PC_COLS + PF_BAD_OBSTACLES] == tc.gen) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
-    if (tot[PC_COLS + PF_FALLBACK] == tc.gen) { err = "a field beyond the device planner's limits (general stretch, primitives)"; return kNotOnDevice; }
-    if (tot[PC_POINTS] > kCountCap) { err = "batch too large"; return FCPP_ESIZE; }
-    if (tot[PC_PRIMS] > ((int64_t)1 << 26)) { err = "too many path primitives in one batch: split the batch"; return FCPP_ESIZE; }
-    if (tot[PC_TILES] > INT32_MAX) { err = "too many tiles in one batch: split the batch"; return FCPP_ESIZE; }
-
-    // the image's layout from the totals, the allocation, the obstacle table
-    t0 = std::chrono::steady_clock::now();
+    // ---- the tables' layout.  SPECULATIVE for small batches (at most 8192 fields: the counting phase's one-scan form): laid out by per-field
+    // CAPACITIES before anything has run, so that the fill pass can be enqueued right behind the last scan -- the host then waits for the
+    // totals (they size the output arrays and the steps' launches) while the fill pass already runs, instead of the device waiting for the
+    // host's round trip in between.  A field beyond the capacities (PF_OVER_CAPACITY: more than eight wave tiles, a span of more than
+    // sixteen chunks: big fields, many headland loops) makes the fill pass a no-op; the tables are then laid out from the totals and filled
+    // again, as for large batches.  Within a table the records lie packed either way: only where each table begins differs.
     ImageLayout &lay = b->lay;
-    lay = ImageLayout();
-    lay.n_fields = n_fields; lay.n_prims = tot[PC_PRIMS]; lay.wave_tile_points = 128;
-    lay.n_tiles = tot[PC_TILES]; lay.n_wave = tot[PC_WAVE]; lay.n_general = tot[PC_GENERAL]; lay.n_stat = tot[PC_STAT];
-    // the spans of fields of field work are written by the fields' own workgroups (k_plan_sparse_fields) when ALL of them are short enough for
-    // that -- the span launch of such a batch disappears -- and by k_plan_quiet otherwise (a mix loses: measured on cfg2 at the reference's
-    // sampling, a third of its spans fusable, 0.0435 instead of 0.0392 ms)
-    const bool fuse = tc.fuse_spans && tot[PC_UNFUSABLE] == 0 && tot[PC_WORK_SPAN_PTS] > 0;
-    tc.fuse_spans = fuse;
-    lay.n_chunks = 0; lay.n_span_chunks = fuse ? tot[PC_SPAN_F] : tot[PC_SPAN]; lay.n_runs = tot[PC_RUNS];
-    for (int k = 0; k < 4; ++k) lay.n_red[k] = tot[PC_CLS0 + k];
-    lay.n_work[0] = tot[PC_WORK]; lay.n_field_work = tot[PC_WORK]; lay.n_open_wave = tot[PC_OPEN];
-    lay.quiet_points = tot[PC_SPAN_PTS]; lay.span_points = tot[PC_SPAN_PTS] - (fuse ? tot[PC_WORK_SPAN_PTS] : 0); lay.work_span_points = fuse ? tot[PC_WORK_SPAN_PTS] : 0; lay.chunk_points = 0; lay.wave_points = tot[PC_WAVE_PTS];
-    lay.work_wave_points = tot[PC_WORK_WAVE_PTS]; lay.wave_inside = tot[PC_WAVE_INSIDE];
-    lay.n_polys = n_polys; lay.n_poly_verts = n_polys > 0 ? obstacles->offsets[n_polys] : 0;
-    lay.info_on_device = true;
-    layout_image(lay);
-    if ((rc = take_slab(c, b, err)) != FCPP_OK) return rc;
-    bind_tables(b);
-    if (lay.n_polys > 0) {
+    auto common_layout = [&](ImageLayout &l) {
+        l = ImageLayout();
+        l.n_fields = n_fields; l.wave_tile_points = 128; l.n_chunks = 0;
+        l.n_polys = n_polys; l.n_poly_verts = n_polys > 0 ? obstacles->offsets[n_polys] : 0;
+        l.info_on_device = true;
+    };
+    auto upload_obstacles = [&]() -> int {
+        if (lay.n_polys <= 0) return FCPP_OK;
         // (the obstacle part of the image through the context's pinned staging memory, pageable when that cannot be had)
         const size_t o0 = lay.obs_off, o1 = lay.seg;
         std::vector<unsigned char> tmp;
@@ -793,22 +778,95 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         fill_obstacles(obstacles, lay, img);
         DEVCHK(hipMemcpyAsync(static_cast<unsigned char *>(b->slab) + o0, img + o0, o1 - o0, hipMemcpyHostToDevice, st));
         if (!tmp.empty()) DEVCHK(hipStreamSynchronize(st));
-    }
-    tm.image_ms = ms_since(t0);
-    tm.image_bytes = (int64_t)((size_t)n_fields * sizeof(fcpp_field) + (lay.n_polys > 0 ? lay.seg - lay.obs_off : 0));
-
-    // the tables, then the per-batch constants of the steps as on the host path
-    t0 = std::chrono::steady_clock::now();
+        return FCPP_OK;
+    };
     DevPlanTables T;
-    T.fields = b->t.fields; T.prims = b->t.prims; T.tiles = b->t.tiles; T.wtiles = b->t.wave_tiles; T.general_ids = b->t.general_ids;
-    T.span_chunks = b->t.span_chunks; T.stat_ids = b->t.stat_ids; T.stat_first = b->t.stat_first; T.stat_run = b->t.stat_run;
-    T.red_paths = b->t.red_paths; T.field_work = b->t.field_work; T.field_packs = b->t.field_packs; T.open_wave_ids = b->t.open_wave_ids; T.seg = b->t.seg; T.seg_mask = b->t.seg_mask;
-    T.partial = b->t.partial; T.field_junc = b->t.field_junc; T.work_totals = b->t.work_totals;
-    T.info = reinterpret_cast<fcpp_field_info *>(static_cast<unsigned char *>(b->slab) + lay.info);
-    b->cst.field_junc = b->t.field_junc;
-    // (the fill pass also computes what the host path launches k_field_junctions, k_run_consts and k_work_totals for, field by field)
-    lrc = launch_devplan_fill(st, n_fields, tc, b->cst, s, T);
-    if (lrc) { err = std::string("launch_devplan_fill: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }
+    auto launch_fill = [&]() -> int {
+        bind_tables(b);
+        T.fields = b->t.fields; T.prims = b->t.prims; T.tiles = b->t.tiles; T.wtiles = b->t.wave_tiles; T.general_ids = b->t.general_ids;
+        T.span_chunks = b->t.span_chunks; T.stat_ids = b->t.stat_ids; T.stat_first = b->t.stat_first; T.stat_run = b->t.stat_run;
+        T.red_paths = b->t.red_paths; T.field_work = b->t.field_work; T.field_packs = b->t.field_packs; T.open_wave_ids = b->t.open_wave_ids; T.seg = b->t.seg; T.seg_mask = b->t.seg_mask;
+        T.partial = b->t.partial; T.field_junc = b->t.field_junc; T.work_totals = b->t.work_totals;
+        T.info = reinterpret_cast<fcpp_field_info *>(static_cast<unsigned char *>(b->slab) + lay.info);
+        b->cst.field_junc = b->t.field_junc;
+        // (the fill pass also computes what the host path launches k_field_junctions, k_run_consts and k_work_totals for, field by field)
+        const int frc = launch_devplan_fill(st, n_fields, tc, b->cst, s, T);
+        if (frc) { err = std::string("launch_devplan_fill: ") + hipGetErrorString((hipError_t)frc); return FCPP_EHIP; }
+        return FCPP_OK;
+    };
+    const bool exact_only = getenv("FCPP_SETUP_EXACT") != nullptr;              // (the checker of the speculative layout: tests/test_gpu_devplan.py)
+    bool spec = (n_fields + 1023) / 1024 <= 8 && !exact_only;
+    if (spec) {
+        common_layout(lay);
+        const int64_t K = DEVPLAN_KEEP_TILES;
+        lay.n_prims = n_fields * pc.max_prims;
+        lay.n_tiles = lay.n_stat = n_fields * (1 + K); lay.n_wave = lay.n_general = lay.n_open_wave = n_fields * K;
+        lay.n_span_chunks = n_fields * SPEC_SPAN_CHUNKS; lay.n_runs = n_fields;
+        lay.n_red[0] = n_fields; lay.n_work[0] = lay.n_field_work = n_fields;
+        layout_image(lay);
+        if (lay.total_bytes > ((size_t)1 << 30)) spec = false;
+    }
+    tc.speculative = spec ? 1 : 0; tc._pad = 0;
+    if (spec) {
+        if ((rc = take_slab(c, b, err)) != FCPP_OK) return rc;
+        bind_tables(b);
+        if ((rc = upload_obstacles()) != FCPP_OK) return rc;
+    }
+    int lrc = launch_devplan_count(st, n_fields, pc, tc, s, dev_fields, n_polys, obstacles != nullptr, tot);
+    if (lrc) { (void)hipStreamSynchronize(st); err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }   // (drained: the caller's pinned records may still be read)
+    if (spec) {
+        if (!c->ev_totals) DEVCHK(hipEventCreateWithFlags(&c->ev_totals, hipEventDisableTiming));
+        DEVCHK(hipEventRecord(c->ev_totals, st));
+        if ((rc = launch_fill()) != FCPP_OK) { (void)hipStreamSynchronize(st); return rc; }
+        DEVCHK(hipEventSynchronize(c->ev_totals));      // (the last scan has written the totals and the flags to `tot`; the fill pass runs on)
+    } else {
+        DEVCHK(hipStreamSynchronize(st));
+    }
+    tm.host_plan_ms = ms_since(t0);          // (the plan and the counting pass, on the device)
+    if (tot[PC_COLS + PF_BAD_OBSTACLES] == tc.gen) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
+    if (tot[PC_COLS + PF_FALLBACK] == tc.gen) { err = "a field beyond the device planner's limits (general stretch, primitives)"; return kNotOnDevice; }
+    if (tot[PC_POINTS] > kCountCap) { err = "batch too large"; return FCPP_ESIZE; }
+    if (tot[PC_PRIMS] > ((int64_t)1 << 26)) { err = "too many path primitives in one batch: split the batch"; return FCPP_ESIZE; }
+    if (tot[PC_TILES] > INT32_MAX) { err = "too many tiles in one batch: split the batch"; return FCPP_ESIZE; }
+
+    // the spans of fields of field work are written by the fields' own workgroups (k_plan_sparse_fields) when ALL of them are short enough for
+    // that -- the span launch of such a batch disappears -- and by k_plan_quiet otherwise (a mix loses: measured on cfg2 at the reference's
+    // sampling, a third of its spans fusable, 0.0435 instead of 0.0392 ms)
+    t0 = std::chrono::steady_clock::now();
+    const bool fuse = tc.fuse_spans && tot[PC_UNFUSABLE] == 0 && tot[PC_WORK_SPAN_PTS] > 0;
+    auto counts_from_totals = [&](ImageLayout &l) {
+        l.n_prims = tot[PC_PRIMS];
+        l.n_tiles = tot[PC_TILES]; l.n_wave = tot[PC_WAVE]; l.n_general = tot[PC_GENERAL]; l.n_stat = tot[PC_STAT];
+        l.n_span_chunks = fuse ? tot[PC_SPAN_F] : tot[PC_SPAN]; l.n_runs = tot[PC_RUNS];
+        for (int k = 0; k < 4; ++k) l.n_red[k] = tot[PC_CLS0 + k];
+        l.n_work[0] = tot[PC_WORK]; l.n_field_work = tot[PC_WORK]; l.n_open_wave = tot[PC_OPEN];
+        l.quiet_points = tot[PC_SPAN_PTS]; l.span_points = tot[PC_SPAN_PTS] - (fuse ? tot[PC_WORK_SPAN_PTS] : 0); l.work_span_points = fuse ? tot[PC_WORK_SPAN_PTS] : 0; l.chunk_points = 0; l.wave_points = tot[PC_WAVE_PTS];
+        l.work_wave_points = tot[PC_WORK_WAVE_PTS]; l.wave_inside = tot[PC_WAVE_INSIDE];
+    };
+    if (spec && tot[PC_COLS + PF_OVER_CAPACITY] != tc.gen) {
+        counts_from_totals(lay);             // (the tables begin where the capacities put them; what they hold is what the totals say)
+        tm.image_ms = ms_since(t0);
+    } else {
+        // the image's layout from the totals, the allocation, the obstacle table, the fill pass
+        ImageLayout ex;
+        common_layout(ex);
+        counts_from_totals(ex);
+        layout_image(ex);
+        if (b->slab && b->slab_bytes < ex.total_bytes) {       // (a speculative slab that is too small: its fill pass was a no-op, but it is in the stream)
+            DEVCHK(hipStreamSynchronize(st));
+            (void)hipFree(b->slab); b->slab = nullptr; b->slab_bytes = 0;
+        }
+        lay = ex;
+        if (!b->slab && (rc = take_slab(c, b, err)) != FCPP_OK) return rc;
+        bind_tables(b);
+        if ((rc = upload_obstacles()) != FCPP_OK) return rc;
+        tm.image_ms = ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        tc.speculative = 0;
+        tc.fuse_spans = fuse;
+        if ((rc = launch_fill()) != FCPP_OK) return rc;
+    }
+    tm.image_bytes = (int64_t)((size_t)n_fields * sizeof(fcpp_field) + (lay.n_polys > 0 ? lay.seg - lay.obs_off : 0));
     DEVCHK(hipEventRecord(c->ev_plan, st));
     c->ev_plan_set = true;
     // fcpp_field_info stays on the device until somebody asks (fcpp_batch_info); the stream is NOT drained: a step enqueued next runs

@@ -29,7 +29,10 @@ enum PlanCol : int {
 // many chunks to be fused -- the host fuses all or none, k_tile_fields<true> is told which: DevTileConsts.fuse_spans)
 // totals[PC_COLS + k]: flags the kernels raise -- a flag holds the generation number (DevTileConsts.gen, counted up by the context) of the
 // last counting phase that raised it, so nothing has to be cleared between batches: raised in this phase <=> flag == gen
-enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_COUNT = 2 };
+enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_OVER_CAPACITY = 2, PF_COUNT = 3 };
+// (PF_OVER_CAPACITY: a speculative setup -- tables laid out by per-field capacities, the fill pass enqueued before the host has the totals
+// -- met a field beyond them: SPEC_* below; the host then lays the tables out from the totals and fills them again)
+constexpr int SPEC_SPAN_CHUNKS = 16;         // span chunks per field a speculative layout has room for (tiles: 1 + DEVPLAN_KEEP_TILES, wave / general tiles: DEVPLAN_KEEP_TILES)
 
 // what the device tiler needs to know about the batch (TileConsts of fcpp_tiler.h with the templates on the device)
 struct DevTileConsts {
@@ -37,6 +40,8 @@ struct DevTileConsts {
     int32_t nu, nc;
     int32_t turn_quiet, wave_factor, field_work_tiles, max_prims, fuse_spans;
     int32_t no_bases;             // counting pass of a small batch: the fields' point offsets are not known yet (ONE scan, after the pass)
+    int32_t speculative, _pad;    // the tables are laid out by capacities: the counting pass and the scan watch them, the fill pass decides
+                                  // the fusing of spans itself and does nothing when a flag of this generation is up
     double two_a, u_cap, c_line, fence_margin;
     int64_t reduce_wg_max;
     int64_t gen;                  // this counting phase's generation number (> 0)

@@ -60,11 +60,12 @@ __global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, co
 }
 
 // a column's total to the host's copy; the flags (generation numbers, see PlanFlag) with the first column of the last scan
-__device__ __forceinline__ void publish_total(const int64_t *totals, int64_t *mirror, int col, int64_t value, bool flags)
+__device__ __forceinline__ void publish_total(const int64_t *totals, int64_t *mirror, int col, int64_t value, bool flags, bool over_elsewhere = false)
 {
     if (!mirror) return;
     mirror[col] = value;
-    if (flags) for (int k = 0; k < PF_COUNT; ++k) mirror[PC_COLS + k] = totals[PC_COLS + k];
+    // (over_elsewhere: PF_OVER_CAPACITY may still be raised by the workgroup of PC_SPAN in this very launch -- that one publishes it)
+    if (flags) for (int k = 0; k < PF_COUNT; ++k) if (!(over_elsewhere && k == PF_OVER_CAPACITY)) mirror[PC_COLS + k] = totals[PC_COLS + k];
 }
 
 // ---- exclusive scans of count columns [c0, c1) over the fields -------------------------------------------------------------------------
@@ -150,9 +151,10 @@ __device__ __forceinline__ void span_counts(int64_t pt_off, int64_t S, bool is_w
 // pass for the headline's 4096 fields.  derive: the columns that depend on the fields' point offsets (span_counts) are made here, by
 // their own workgroups, from the offsets (a scan of PC_POINTS of their own), the spans' lengths (PC_SPAN_PTS) and PC_WORK.
 __global__ __launch_bounds__(1024) void k_scan_small(int64_t n, int c0, int64_t *__restrict__ counts, int64_t *__restrict__ bases, int64_t *__restrict__ totals,
-                                                     int64_t *__restrict__ mirror, int with_flags, int derive, int fuse_possible)
+                                                     int64_t *__restrict__ mirror, int with_flags, int derive, int fuse_possible, int64_t spec_gen)
 {
     __shared__ int64_t lds[16];
+    int over = 0;                        // (spec_gen > 0: a speculative setup -- a span of more chunks than its layout has room for raises PF_OVER_CAPACITY)
     const int col = c0 + blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // exclusive scan over the workgroup's 4096 elements (four a thread): -> the base of the thread's first, tot = the chunk's sum
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(1024) void k_scan_small(int64_t n, int c0, int64_t 
                 int64_t c_span, c_span_f, c_wsp, c_unf;
                 span_counts(off, S[k], work[k] != 0, fuse_possible != 0, c_span, c_span_f, c_wsp, c_unf);
                 v[k] = col == PC_SPAN ? c_span : (col == PC_SPAN_F ? c_span_f : (col == PC_WORK_SPAN_PTS ? c_wsp : c_unf));
+                if (col == PC_SPAN && c_span > SPEC_SPAN_CHUNKS) over = 1;
                 if (base + k < n) counts[(int64_t)col * n + base + k] = v[k];
                 off += pts[k];
             }
@@ -208,17 +211,29 @@ __global__ __launch_bounds__(1024) void k_scan_small(int64_t n, int c0, int64_t 
         for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
         carry += tot;
     }
-    if (threadIdx.x == 0) { totals[col] = carry; publish_total(totals, mirror, col, carry, with_flags && blockIdx.x == 0); }
+    const bool spec_span = derive && spec_gen > 0 && col == PC_SPAN;
+    if (spec_span) over = __syncthreads_or(over);
+    if (threadIdx.x == 0) {
+        totals[col] = carry;
+        publish_total(totals, mirror, col, carry, with_flags && blockIdx.x == 0, derive && spec_gen > 0);
+        if (spec_span) {
+            unsigned long long *flag = reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_OVER_CAPACITY);
+            if (over) atomicMax(flag, (unsigned long long)spec_gen);
+            const int64_t v = over ? spec_gen : totals[PC_COLS + PF_OVER_CAPACITY];      // (the counting pass may have raised it)
+            if (mirror) mirror[PC_COLS + PF_OVER_CAPACITY] = v;
+        }
+    }
 }
 
 // mirror: the totals' copy in the host's pinned memory (or null), written by the scans themselves -- no copy command behind them;
 // with_flags: the flags the earlier kernels raised go along (the last scan of the counting phase)
-int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s, int64_t *mirror, int with_flags, int derive = 0, int fuse_possible = 0)
+int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s, int64_t *mirror, int with_flags, int derive = 0, int fuse_possible = 0,
+                int64_t spec_gen = 0)
 {
     const int64_t nblk = (n + 1023) / 1024;
     const int nc = c1 - c0;
     if (nblk <= 8) {
-        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(1024), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags, derive, fuse_possible);
+        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(1024), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags, derive, fuse_possible, spec_gen);
         const hipError_t e0 = hipGetLastError();
         return e0 == hipSuccess ? 0 : (int)e0;
     }
@@ -280,6 +295,14 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
     const DevPrim *prims = ptmp + field * tc.max_prims;
     const int64_t n_total = F.n_total;
     auto base_of = [&](int col) -> int64_t { return bases[(int64_t)col * n + field]; };
+    // a speculative fill pass does nothing when the counting phase raised a flag: the host sets the batch up again (or elsewhere)
+    if (FILL && tc.speculative) {
+        bool up = false;
+        for (int k = 0; k < PF_COUNT; ++k) up = up || totals[PC_COLS + k] == tc.gen;
+        if (up) return;
+    }
+    // (speculative: the fusing of spans is the host's rule applied here -- all fields of field work have fusable spans, or nothing is fused)
+    const bool fuse_spans = (FILL && tc.speculative) ? (tc.fuse_spans != 0 && totals[PC_UNFUSABLE] == 0 && totals[PC_WORK_SPAN_PTS] > 0) : tc.fuse_spans != 0;
     // (scanned before either pass -- except before the counting pass of a small batch: tc.no_bases, see span_counts)
     const bool no_bases = !FILL && tc.no_bases != 0;
     const int64_t pt_off = no_bases ? 0 : base_of(PC_POINTS);
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
     int64_t wave_base = 0, general_base = 0, stat_base = 0, span_base = 0, prim_base = 0;
     if (FILL) {
         wave_base = base_of(PC_WAVE); general_base = base_of(PC_GENERAL); stat_base = base_of(PC_STAT);
-        span_base = base_of(tc.fuse_spans ? PC_SPAN_F : PC_SPAN); prim_base = base_of(PC_PRIMS);
+        span_base = base_of(fuse_spans ? PC_SPAN_F : PC_SPAN); prim_base = base_of(PC_PRIMS);
     }
     const int prim_count = F.prim_count;
     const int64_t prim_index0 = prim_base;           // batch-wide index of the field's first primitive (fill pass)
@@ -598,7 +621,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             const int64_t g0 = pt_off;                           // the span starts the path
             // (counting pass: fuse_spans = fusing is possible for this batch, both alternatives are counted; fill pass: the host's
             // decision -- all fields of field work have fusable spans, or nothing is fused)
-            if (!no_bases) span_counts(g0, S, is_work, tc.fuse_spans != 0, c_span, c_span_f, c_work_span_pts, c_unfusable);
+            if (!no_bases) span_counts(g0, S, is_work, fuse_spans, c_span, c_span_f, c_work_span_pts, c_unfusable);
             fused_span = c_work_span_pts;
             if (FILL && fused_span > 0) c_span = 0;          // (no chunk records for a fused span)
             if (FILL) {
@@ -629,6 +652,8 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
     if (is_work) { c_work = 1; c_work_wave_pts = c_wave_pts; }
     else { c_open = n_wave; cls = tiler_reduce_class(ne, tc.reduce_wg_max); }
     if (fallback && lane == 0) atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), (unsigned long long)tc.gen);
+    if (!FILL && tc.speculative && lane == 0 && (c_tiles > 1 + DEVPLAN_KEEP_TILES || c_wave > DEVPLAN_KEEP_TILES || c_general > DEVPLAN_KEEP_TILES || c_span > SPEC_SPAN_CHUNKS))
+        atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_OVER_CAPACITY), (unsigned long long)tc.gen);
 
     TSTAMP(37);
     FSTAMP(2);
@@ -815,7 +840,7 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
     hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
                        s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
     if (one_scan) {
-        rc = launch_scan(st, n, PC_POINTS, PC_COLS, s, totals_host, 1, 1, tc.fuse_spans);
+        rc = launch_scan(st, n, PC_POINTS, PC_COLS, s, totals_host, 1, 1, tc.fuse_spans, tc.speculative ? tc.gen : 0);
         if (rc) return rc;
         const hipError_t e1 = hipGetLastError();
         return e1 == hipSuccess ? 0 : (int)e1;

@@ -29,11 +29,21 @@ class Context:
         h = C.c_void_p()
         L.check(self.lib.fcpp_ctx_create(self.device, C.byref(h)))
         self.handle = h
+        self._bound = None          # the stream handle the library was last given
+        self._arena = None          # (lane, pitch) of the output arena, asked once
 
     def bind_stream(self):
         torch = _torch()
         s = torch.cuda.current_stream(self.device).cuda_stream
-        L.check(self.lib.fcpp_ctx_set_stream(self.handle, C.c_void_p(s)))
+        if s != self._bound:        # (only this method sets the library's stream)
+            L.check(self.lib.fcpp_ctx_set_stream(self.handle, C.c_void_p(s)))
+            self._bound = s
+
+    def arena(self):
+        """-> (lane bytes, pitch bytes) of the output arena, (0, 0) without one; asked once (reserve_outputs asks again)"""
+        if self._arena is None:
+            self._arena = self.outputs_info()[:2]
+        return self._arena
 
     def reserve_outputs(self, lane_gib=24.0, pitch_gib=24.0):
         """Give the context its output ARENA (fcpp_ctx_reserve_outputs): one device allocation of 4 x pitch + lane, made once -- it takes
@@ -41,6 +51,7 @@ class Context:
         every batch a pitch apart (far apart they are written a class faster than back to back).  Any number of live
         batches share it.  Raises when the device has not that much room."""
         L.check(self.lib.fcpp_ctx_reserve_outputs(self.handle, int(lane_gib * 2**30), int(pitch_gib * 2**30)))
+        self._arena = None
 
     def outputs_info(self):
         """-> (lane bytes, pitch bytes, live bytes per lane) of the output arena; zeros without one"""
@@ -393,6 +404,7 @@ class Batch:
                                            self.n_fields, arr, C.byref(polys), C.byref(h)))
         self.handle = h
         self._info = None
+        self._token = object()      # marks the buffers alloc() makes for this batch
         tot = C.c_int64()
         L.check(self.lib.fcpp_batch_info(self.handle, None, C.byref(tot)))
         self.total_points = tot.value
@@ -481,7 +493,7 @@ class Batch:
         if layout not in ('auto', 'plain', 'spread', 'arena'):
             raise ValueError("layout: 'auto', 'plain', 'spread' or 'arena'")
         n = self.total_points
-        lane, pitch, _live = self.ctx.outputs_info()
+        lane, pitch = self.ctx.arena()
         if layout == 'arena' or (layout == 'auto' and lane >= 8 * n and 36 * n >= self.SPREAD_MIN_BYTES):
             # the context's arena (Context.reserve_outputs): array k in lane k, a pitch apart, shared with every other live batch
             if lane < 8 * n:
@@ -494,12 +506,20 @@ class Batch:
                 self.layout = {'layout': 'arena', 'pitch_GiB': round(pitch / 2**30, 3), 'lane_GiB': round(lane / 2**30, 3)}
             x, y, kappa, v, fs = arr.tensors(n)
             stats = torch.empty((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=torch.device('cuda', self.ctx.device))
-            return x, y, kappa, v, fs, stats
+            return self._trusted((x, y, kappa, v, fs, stats))
         if layout in ('plain', 'auto'):
             # ('auto' never takes device memory the arrays do not need: the spread placement is the arena's, or an explicit layout='spread')
             self.layout = {'layout': 'plain'}
-            return self._alloc_once()
-        return self._alloc_spread(strict=True)
+            return self._trusted(self._alloc_once())
+        return self._trusted(self._alloc_spread(strict=True))
+
+    def _trusted(self, buffers):
+        """buffers alloc() has just made carry this batch's token: run() does not check them again (no reference to them is kept here:
+        they go back to the allocator / the arena when the caller drops them)"""
+        tok = self._token
+        for t in buffers:
+            t._fcpp_ok = tok
+        return buffers
 
     def _alloc_spread(self, strict=False):
         torch = _torch()
@@ -534,10 +554,9 @@ class Batch:
         torch = _torch()
         dev = torch.device('cuda', self.ctx.device)
         n = self.total_points
-        x = torch.empty(n, dtype=torch.float64, device=dev)
-        y = torch.empty(n, dtype=torch.float64, device=dev)
-        kappa = torch.empty(n, dtype=torch.float64, device=dev)
-        v = torch.empty(n, dtype=torch.float64, device=dev)
+        # (the four float64 arrays: rows of one allocation, each on a 512-byte boundary -- one call to the allocator instead of four)
+        npad = (n + 63) // 64 * 64
+        x, y, kappa, v = torch.empty((4, npad), dtype=torch.float64, device=dev)[:, :n].unbind(0)
         fs = torch.empty(n, dtype=torch.int32, device=dev)
         # (not cleared: fcpp_batch_run writes every field's row, zeros for a field that raised -- a fill kernel here would sit in the
         # stream in front of the step)
@@ -567,7 +586,11 @@ class Batch:
         """Enqueue the hot path on torch's current stream; returns a BatchResult (asynchronous)."""
         if buffers is None:
             buffers = self.alloc()
-        self._check_buffers(buffers)
+        tok = self._token
+        for t in buffers:
+            if getattr(t, '_fcpp_ok', None) is not tok:
+                self._check_buffers(buffers)
+                break
         x, y, kappa, v, fs, stats = buffers
         self._last_mode = 1 if int(mode) >= 1 else 0
         self.ctx.bind_stream()

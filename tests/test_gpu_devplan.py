@@ -92,6 +92,22 @@ def test_parallelograms_tables_equal_the_hosts():
     _compare(*_both(E.FieldTable.from_vertices(V[:777]), E.make_vehicle(), E.make_options(ring_order=1)), 'cfg5 ring 1')
 
 
+def test_speculative_and_exact_layouts_build_the_same_tables():
+    """Small batches are laid out by per-field capacities and filled before the host has the totals (fcpp_api.cpp: try_device_setup);
+    FCPP_SETUP_EXACT lays them out from the totals as large batches are.  Both against the host's tables -- the headline's fields (within
+    the capacities), cfg2's (spans of up to fourteen chunks), and a vehicle with ten headland loops (beyond them: the fill pass runs twice)."""
+    cases = [(E.FieldTable.from_rectangles(WL.cfg1_batch(300)), E.make_vehicle()), (E.FieldTable.from_rectangles(WL.cfg2_rectangles()), E.make_vehicle()),
+             (E.FieldTable.from_rectangles(WL.cfg2_rectangles()[:200]), E.make_vehicle(working_width=0.8))]
+    for table, veh in cases:
+        for exact in (False, True):
+            if exact:
+                os.environ['FCPP_SETUP_EXACT'] = '1'
+            try:
+                _compare(*_both(table, veh, E.make_options()), f'exact={exact}')
+            finally:
+                os.environ.pop('FCPP_SETUP_EXACT', None)
+
+
 def test_a_batch_beyond_the_one_scan_limit_equals_the_hosts():
     """More than 8192 fields: the counting pass runs behind a scan of its own (points, primitives) and the three-kernel scans; at most
     8192: one scan after the pass derives what depends on the spans' alignment.  Both against the host's tables."""

@@ -23,12 +23,14 @@ int main(int argc, char **argv)
     const int which = argc > 1 ? atoi(argv[1]) : 0, n = argc > 2 ? atoi(argv[2]) : (which ? 65536 : 4096), reps = argc > 3 ? atoi(argv[3]) : 5;
     fcpp_vehicle veh = { 3.2, 8.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85 };
     fcpp_options opt = { 0, 1, 0.0, 0.5, 1e-6, 0, 0 };
+    if (argc > 4) opt.sample_spacing = atof(argv[4]);          // (which = 2: cfg2-like random rectangles, e.g. at 0.5 m)
     std::vector<fcpp_field> fields((size_t)n);
     std::mt19937_64 rng(65536);
     auto U = [&](double a, double b) { return a + (b - a) * (double)(rng() >> 11) * (1.0 / 9007199254740992.0); };
     for (int i = 0; i < n; ++i) {
         fcpp_field f = {};
         if (which == 0) { f.vx[1] = 500; f.vx[2] = 500; f.vy[2] = 200; f.vy[3] = 200; }
+        else if (which == 2) { const double L = U(100, 1000), H = U(100, 1000); f.vx[1] = L; f.vx[2] = L; f.vy[2] = H; f.vy[3] = H; }
         else {
             const double L = U(100, 1000), H = U(100, 1000), ang = U(60, 120) * kPi / 180, rot = U(-kPi / 4, kPi / 4), sx = H / tan(ang);
             const double qx[4] = { 0, L, L + sx, sx }, qy[4] = { 0, 0, H, H };
@@ -37,7 +39,7 @@ int main(int argc, char **argv)
         }
         fields[(size_t)i] = f;
     }
-    printf("threads %d, %d fields (%s)\n", WorkerPool::width(), n, which ? "random parallelograms" : "equal 500 x 200 m rectangles");
+    printf("threads %d, %d fields (%s), sample_spacing %g\n", WorkerPool::width(), n, which == 2 ? "random rectangles" : (which ? "random parallelograms" : "equal 500 x 200 m rectangles"), opt.sample_spacing);
     std::vector<unsigned char> img;
     for (int rep = 0; rep < reps; ++rep) {
         HostPlan hp;
@@ -52,6 +54,7 @@ int main(int argc, char **argv)
         TileConsts tc;
         tc.tu = tu.data(); tc.tc = tcn.data(); tc.nu = tt.nu; tc.nc = tt.nc; tc.templates_ok = true; tc.turn_quiet = true;
         tc.two_a = 3.0; tc.u_cap = (15 / 3.6) * (15 / 3.6); tc.c_line = 2.5 * 2.5;
+        tc.device_chunks = getenv("FCPP_HOST_CHUNKS") == nullptr;       // (as fcpp_batch_create: the device expands the chunk lists)
         t0 = std::chrono::steady_clock::now();
         BatchTiler tiler;
         ImageLayout lay;
