@@ -204,10 +204,12 @@ class TwoLayerPathPlannerV37:
         n_main, n_head = info.n_main, info.n_head
         # coverage of the headland ring by the headland path, straight from the device arrays (MLP:884, 1357-1371)
         coverage_rate = self._coverage_rate_dev(res.x[n_main:], res.y[n_main:], self._headland_area())
-        x, y = res.x.cpu().numpy(), res.y.cpu().numpy()
-        v, kappa, fs = res.v.cpu().numpy(), res.kappa.cpu().numpy(), res.flagseg.cpu().numpy().view(np.uint32)
+        # (one copy for the four float64 arrays, one for the two connectors: every copy to the host is a synchronisation of its own)
+        import torch
+        x, y, kappa, v = torch.stack((res.x, res.y, res.kappa, res.v)).cpu().numpy()
+        fs = res.flagseg.cpu().numpy().view(np.uint32)
         st = {k: a[0] for k, a in res.stats().items()}
-        ap, dp = ap.cpu().numpy()[0], dp.cpu().numpy()[0]
+        ap, dp = torch.cat((ap, dp)).cpu().numpy()
         path = np.column_stack([x, y])
         main_len, head_len = st['main_len_m'], st['head_len_m']
         main_pre, head_pre = st['main_time_pre_s'], st['head_time_pre_s']
