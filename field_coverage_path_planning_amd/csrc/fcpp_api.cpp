@@ -708,7 +708,11 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     if (n_fields <= 0) { err = "empty batch"; return kNotOnDevice; }
     // (a handful of fields: the device's chain of five dependent launches costs ~110 us whatever the batch, the host's plan + tiler + one copy
     // ~65 us + 3 us per field -- a single 500 x 200 m planner's plan call 0.49 -> 0.44 ms)
-    if (c->setup_mode == FCPP_SETUP_AUTO && n_fields < 16) { err = "a handful of fields: set up by the host"; return kNotOnDevice; }
+    {
+        const char *e = getenv("FCPP_SMALL_BATCH");          // (fields below which `auto` takes the host: 0 sends every batch it can take to the device -- tools/fuzz_parity.py)
+        const int64_t small = e ? atoll(e) : 16;
+        if (c->setup_mode == FCPP_SETUP_AUTO && n_fields < small) { err = "a handful of fields: set up by the host"; return kNotOnDevice; }
+    }
     if (opt.sample_spacing != 0.0) { err = "sample_spacing > 0 (the device planner takes the reference's sampling)"; return kNotOnDevice; }
     if (opt.obstacle_mode != FCPP_OBSTACLES_FLAG) { err = "obstacle-aware swaths are planned on the host"; return kNotOnDevice; }
     if (tune_enabled()) { err = "FCPP_TUNE: the tuning knobs are the host tiler's"; return kNotOnDevice; }
