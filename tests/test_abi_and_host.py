@@ -206,3 +206,25 @@ def test_corner_gap_decision_where_the_lower_bound_does_not_decide():
     info = E.plan_count([spec], E.make_vehicle(working_width=8.06, min_turn_radius=3.0), E.make_options())[0]
     rc, _ = orc.plan_field(orc.make_field(L=600.0, H=400.0), orc.Vehicle.make(np.array([8.06, 3.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85])), orc.Options.make())
     assert info.status == L.EUNSUPPORTED and rc == L.EUNSUPPORTED
+
+
+def test_field_table_argument_pointers_follow_the_records():
+    """FieldTable.c_args() is made once per table (a plan call's 7 us): records written IN PLACE are what the library reads, new records
+    (table.rec = ...) drop the cached pointers, a slice has pointers of its own."""
+    import ctypes as C
+    t = E.FieldTable.from_rectangles([[500.0, 200.0], [100.0, 80.0], [300.0, 120.0]])
+    veh, opt = E.make_vehicle(), E.make_options()
+    a = t.c_args()
+    assert t.c_args() is a
+    n0 = [i.n_main for i in E.plan_count(t, veh, opt)]
+    t.rec['vx'][0, 1] = t.rec['vx'][0, 2] = 100.0            # field 0 becomes 100 x 80 m, in place
+    t.rec['vy'][0, 2] = t.rec['vy'][0, 3] = 80.0
+    assert t.c_args() is a
+    n1 = [i.n_main for i in E.plan_count(t, veh, opt)]
+    assert n1[0] == n0[1] and n1[1:] == n0[1:]
+    t.rec = t.rec[::-1].copy()
+    assert t.c_args() is not a
+    assert [i.n_main for i in E.plan_count(t, veh, opt)] == n1[::-1]
+    s = t[1:]
+    assert C.addressof(s.c_args()[0].contents) == C.addressof(t.c_args()[0].contents) + C.sizeof(L.Field)
+    assert [i.n_main for i in E.plan_count(s, veh, opt)] == n1[::-1][1:]
