@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <random>
 #include <string>
@@ -40,6 +41,16 @@ int main(int argc, char **argv)
         fields[(size_t)i] = f;
     }
     printf("threads %d, %d fields (%s), sample_spacing %g\n", WorkerPool::width(), n, which == 2 ? "random rectangles" : (which ? "random parallelograms" : "equal 500 x 200 m rectangles"), opt.sample_spacing);
+    {   // what a parallel_for costs when its items do nothing (the pool's wake-up and hand-back): 16 items, median of 200 calls
+        std::vector<double> us;
+        for (int k = 0; k < 200; ++k) {
+            auto t0 = std::chrono::steady_clock::now();
+            WorkerPool::parallel_for(16, [](int64_t) {});
+            us.push_back(ms(t0) * 1e3);
+        }
+        std::sort(us.begin(), us.end());
+        printf("parallel_for of 16 empty items: median %.1f us, 90 %% %.1f us\n", us[100], us[180]);
+    }
     std::vector<unsigned char> img;
     for (int rep = 0; rep < reps; ++rep) {
         HostPlan hp;
