@@ -816,7 +816,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
     """cfg5: 65 536 parallelograms through sharding.plan_sharded -- one block of fields per rank, cut on the analytic point counts."""
     V = WL.cfg5_parallelograms()
     t0 = time.perf_counter()
-    table = E.FieldTable.from_vertices(V)
+    table = E.FieldTable.from_vertices(V).pin()        # (records in pinned host memory: the device reads them where they lie)
     t_table = (time.perf_counter() - t0) * 1e3
     veh, opt = E.make_vehicle(), E.make_options()
     # ---- the job end to end, E2E_REPS times: sizing of all fields (every rank, threaded, no collective), this rank's fresh batch, its
@@ -828,7 +828,8 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
             batch = bufs = res = None
         fence()
         t0 = time.perf_counter()
-        counts = E.plan_points(table, veh, opt, device=dev.index)      # sizing of ALL fields, on this rank's GPU (fcpp_plan_points)
+        # sizing of ALL fields, on this rank's GPU (fcpp_plan_points): what the ranks cut their blocks on -- one rank has nothing to cut
+        counts = E.plan_points(table, veh, opt, device=dev.index) if world > 1 else None
         t1 = time.perf_counter()
         res = S.plan_sharded(table, veh, opt, device=dev.index, counts=counts)          # this rank's batch + buffers + one step + stats gather
         torch.cuda.synchronize()
@@ -891,7 +892,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
     t_with_gather = allmax(time.perf_counter() - t0)
     entry = None
     if rank == 0:
-        total = int(counts.sum())
+        total = int(counts.sum()) if counts is not None else int(batch.total_points)
         st = res.stats()
         assert res.stats_all.shape[0] == len(table) and int(st['n_viol'].sum()) == 0
         if resg.points_all is not None:
@@ -915,7 +916,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
                                 'setup_ms': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mid['setup_ms'].items()},
                                 'first_ms': e2e[0]['ms'], 'all_ms': [round(r['ms'], 3) for r in e2e], 'table_from_vertices_ms': t_table,
                                 'what': 'the sharded job from the field table to the gathered stats, fresh batch in a warm context (max over ranks): '
-                                        'fcpp_plan_points over all fields on every rank\'s own GPU (no collective) + this rank\'s engine.Batch (set up on the device) + '
+                                        'with more than one rank fcpp_plan_points over all fields on every rank\'s own GPU (no collective; one rank has nothing to cut) + this rank\'s engine.Batch (set up on the device) + '
                                         'output arrays + one step + stats gather; median of the repetitions after the first'},
                  'setup_ms': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mid['setup_ms'].items()},
                  'ms_per_job_with_stats_gather': dt_job / steps * 1e3,

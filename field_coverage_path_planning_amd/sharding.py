@@ -181,15 +181,18 @@ def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1
     import torch
     options = options or E.make_options()
     rank, ws = world()
-    if counts is None:
-        if infos is None and compute is None:
-            counts = E.plan_points(specs, vehicle, options, device=device)
-        else:
-            if infos is None:
-                infos = E.plan_count(specs, vehicle, options)
-            counts = infos.counts() if hasattr(infos, 'counts') else np.asarray([i.n_main + i.n_head for i in infos], dtype=np.int64)
-    counts = np.asarray(counts, dtype=np.int64)
-    blocks = partition_by_points(counts, ws)
+    if counts is None and infos is None and compute is None and ws == 1:
+        blocks = [(0, len(specs))]        # one rank: nothing to cut, nothing to size (res.counts stays None: batch.info.counts() has them)
+    else:
+        if counts is None:
+            if infos is None and compute is None:
+                counts = E.plan_points(specs, vehicle, options, device=device)
+            else:
+                if infos is None:
+                    infos = E.plan_count(specs, vehicle, options)
+                counts = infos.counts() if hasattr(infos, 'counts') else np.asarray([i.n_main + i.n_head for i in infos], dtype=np.int64)
+        counts = np.asarray(counts, dtype=np.int64)
+        blocks = partition_by_points(counts, ws)
     lo, hi = blocks[rank]
     local, arrays = None, None
     if compute is not None:
@@ -208,10 +211,10 @@ def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1
     stats_all = gather_rows(_comm_tensor(stats_local), [b[1] - b[0] for b in blocks], dst=0)
     points_all = None
     if gather_points:
-        per_rank = [int(np.sum(counts[a:b])) for a, b in blocks]
+        per_rank = [int(np.sum(counts[a:b])) for a, b in blocks] if counts is not None else [int(batch.total_points) if batch is not None else 0]
         points_all = gather_arrays([_comm_tensor(a) for a in arrays], per_rank, dst=0)
     res = ShardedResult((lo, hi), local, stats_all, infos, blocks, points_all, batch)
-    res.counts = counts           # points per field of the whole batch
+    res.counts = counts           # points per field of the whole batch (None: one rank planned everything without sizing)
     return res
 
 
