@@ -265,11 +265,12 @@ constexpr int TW_WAVES = 2;                                             // field
 constexpr int TW_NW = DEVPLAN_WINDOW;                                   // points of the LDS window that slides along a general stretch
 constexpr int TW_LDS_PRIMS = 32;                                        // primitives of a field staged in LDS (more: read where they lie)
 constexpr int TW_LDS_TMPL = 36;                                         // turn template samples staged in LDS (U-turn + corner; more: ditto)
+template <bool STAGE>
 struct TileWaveLds {
     double d[TW_NW];              // d[i - lo] = |p_i - p_(i-1)|
     // the field's primitives and the batch's turn templates, staged once: a window point's evaluation then waits on LDS, not on a
     // dependent read from device memory per 64 points (22 of the counting pass's 72 thousand cycles per field)
-    unsigned long long prim_words[TW_LDS_PRIMS * (sizeof(DevPrim) / 8)];
+    unsigned long long prim_words[STAGE ? TW_LDS_PRIMS * (sizeof(DevPrim) / 8) : 1];
     Pt2 tmpl[TW_LDS_TMPL];
     int32_t pstart[DEVPLAN_PRIMS_CAP + 1];   // start of primitive k relative to n_main
     uint8_t pidx[TW_NW];          // primitive (index within the field) of window point w; 0 in layer 1
@@ -278,19 +279,19 @@ struct TileWaveLds {
 
 __device__ __forceinline__ int32_t clampi(int64_t v) { return (int32_t)(v < -2 ? -2 : (v > ((int64_t)1 << 30) ? ((int64_t)1 << 30) : v)); }
 
-template <bool FILL>
+template <bool FILL, bool STAGE>
 __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, DevTileConsts tc, DevConst cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
                                                               fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
                                                               const int64_t *__restrict__ bases, int64_t *__restrict__ totals,
                                                               DevTile *__restrict__ keep_tiles, DevWaveTile *__restrict__ keep_wtiles, DevPlanTables T)
 {
-    __shared__ TileWaveLds lds_all[TW_WAVES];
+    __shared__ TileWaveLds<STAGE> lds_all[TW_WAVES];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t field = (int64_t)blockIdx.x * TW_WAVES + wave;
     if (field >= n) return;
     TSTAMP(0);
     FSTAMP(0);
-    TileWaveLds &L = lds_all[wave];
+    TileWaveLds<STAGE> &L = lds_all[wave];
     const DevField &F = ftmp[field];
     const DevPrim *prims = ptmp + field * tc.max_prims;
     const int64_t n_total = F.n_total;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             const int64_t lo_all = (a - WAVE_HALO_MAX - 2 > 1) ? a - WAVE_HALO_MAX - 2 : 1;
             const int64_t hi_all = (b + WAVE_HALO_MAX + 2 < n_total) ? b + WAVE_HALO_MAX + 2 : n_total;
             const int64_t n_main = F.n_main;
-            const bool lds_prims = prim_count <= TW_LDS_PRIMS, lds_tmpl = tc.nu + tc.nc <= TW_LDS_TMPL;
+            const bool lds_prims = STAGE && prim_count <= TW_LDS_PRIMS, lds_tmpl = tc.nu + tc.nc <= TW_LDS_TMPL;
             if (lds_prims && lds_tmpl) {
                 // the usual field: starts, records and templates requested together, then stored -- one round trip to memory, not three
                 static_assert(TW_LDS_PRIMS <= 64 && TW_LDS_TMPL <= 64 && TW_LDS_PRIMS * (sizeof(DevPrim) / 8) <= 6 * 64, "a lane each / six words a lane");
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
     }
 
     // ---- fill pass: the field's descriptor and primitives at their final places, the statistics entries, the work lists
-    const bool lds_pack = prim_count <= TW_LDS_PRIMS;        // the pack's copies of the primitives come out of LDS
+    const bool lds_pack = STAGE && prim_count <= TW_LDS_PRIMS;        // the pack's copies of the primitives come out of LDS
     {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(&T.fields[field]);
         if (lane < NFW) dst[lane] = fw;
@@ -837,8 +838,14 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
         rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s, totals_host, 0);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_tile_fields<false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
-                       s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
+    // (more fields than one round of wavefronts takes -- 4 per SIMD x 1024 SIMDs with the primitives staged in LDS: they are not staged, five
+    // wavefronts per SIMD instead of four; cfg5's 65 536 fields: plan + count 1.30 -> 1.07 ms)
+    if (n <= 4096)
+        hipLaunchKernelGGL((k_tile_fields<false, true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
+                           s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
+    else
+        hipLaunchKernelGGL((k_tile_fields<false, false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
+                           s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
     if (one_scan) {
         rc = launch_scan(st, n, PC_POINTS, PC_COLS, s, totals_host, 1, 1, tc.fuse_spans, tc.speculative ? tc.gen : 0);
         if (rc) return rc;
@@ -874,7 +881,7 @@ int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const
 int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevConst &cst, const DevPlanScratch &s, const DevPlanTables &t)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL((k_tile_fields<true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, cst, s.fields_tmp, s.prims_tmp,
+    hipLaunchKernelGGL((k_tile_fields<true, true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, cst, s.fields_tmp, s.prims_tmp,
                        s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, t);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
