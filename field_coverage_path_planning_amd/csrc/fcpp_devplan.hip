@@ -271,7 +271,7 @@ struct TileWaveLds {
     // the field's primitives and the batch's turn templates, staged once: a window point's evaluation then waits on LDS, not on a
     // dependent read from device memory per 64 points (22 of the counting pass's 72 thousand cycles per field)
     unsigned long long prim_words[STAGE ? TW_LDS_PRIMS * (sizeof(DevPrim) / 8) : 1];
-    Pt2 tmpl[TW_LDS_TMPL];
+    Pt2 tmpl[STAGE ? TW_LDS_TMPL : 1];
     int32_t pstart[DEVPLAN_PRIMS_CAP + 1];   // start of primitive k relative to n_main
     uint8_t pidx[TW_NW];          // primitive (index within the field) of window point w; 0 in layer 1
     uint8_t ins[TW_NW];           // window point w lies inside the geofence with the host's margin
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             const int64_t lo_all = (a - WAVE_HALO_MAX - 2 > 1) ? a - WAVE_HALO_MAX - 2 : 1;
             const int64_t hi_all = (b + WAVE_HALO_MAX + 2 < n_total) ? b + WAVE_HALO_MAX + 2 : n_total;
             const int64_t n_main = F.n_main;
-            const bool lds_prims = STAGE && prim_count <= TW_LDS_PRIMS, lds_tmpl = tc.nu + tc.nc <= TW_LDS_TMPL;
+            const bool lds_prims = STAGE && prim_count <= TW_LDS_PRIMS, lds_tmpl = STAGE && tc.nu + tc.nc <= TW_LDS_TMPL;
             if (lds_prims && lds_tmpl) {
                 // the usual field: starts, records and templates requested together, then stored -- one round trip to memory, not three
                 static_assert(TW_LDS_PRIMS <= 64 && TW_LDS_TMPL <= 64 && TW_LDS_PRIMS * (sizeof(DevPrim) / 8) <= 6 * 64, "a lane each / six words a lane");
