@@ -170,6 +170,7 @@ struct fcpp_ctx {
     // up to kStageMax; larger images go through a pageable buffer), and the last destroyed batch's device allocation is kept for the
     // next one (up to kSpareMax): a caller that plans batch after batch allocates nothing after the first
     void *stage = nullptr; size_t stage_cap = 0;
+    hipEvent_t ev_stage = nullptr; bool ev_stage_set = false;    // behind the last asynchronous copy out of `stage` (the device-side setup's obstacle table)
     void *spare = nullptr; size_t spare_cap = 0;
     std::shared_ptr<TemplateSet> templates;         // the last batch's turn templates
     fcpp_setup_times last_setup = {};
@@ -186,8 +187,9 @@ struct fcpp_ctx {
     // the output arena (fcpp_ctx_reserve_outputs): ONE allocation of 4 x pitch + lane bytes; array k of every batch's outputs lies in lane k
     // (lanes `pitch` apart), placed first-fit among the live allocations of the lane -- all five arrays of an allocation at the same offset
     void *arena = nullptr; size_t arena_pitch = 0, arena_lane = 0;
-    struct ArenaBlock { size_t off, len; };
-    std::vector<ArenaBlock> arena_live;             // sorted by off   // the last fill pass (it reads the scratch): the next setup waits for it, on whichever stream
+    struct ArenaBlock { size_t off, len; hipStream_t last = nullptr; bool used = false; };      // last: the stream of the last fcpp_batch_run that wrote the block
+    std::vector<ArenaBlock> arena_live;             // sorted by off
+    std::vector<hipEvent_t> ev_pool;                // setup events of destroyed batches (fcpp_batch::ev_setup), reused: no event is created per plan call
 };
 
 // device pointers of a batch's tables: all inside ONE allocation laid out by the tiler (fcpp_tiler.h: ImageLayout)
@@ -231,7 +233,12 @@ struct fcpp_batch {
     // current stream): fcpp_batch_destroy drains them all before the tables go back to the context as the next batch's allocation
     std::vector<hipStream_t> used_streams;
     void note_stream(hipStream_t s) { if (std::find(used_streams.begin(), used_streams.end(), s) == used_streams.end()) used_streams.push_back(s); }
-    ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
+    // the device-side setup returns with its last kernels still in the stream it was enqueued on: whoever reads the tables on ANOTHER stream
+    // (a caller that re-binds the context's stream between create and run) waits for this event first
+    hipStream_t setup_stream = nullptr;
+    hipEvent_t ev_setup = nullptr;
+    hipError_t wait_setup(hipStream_t s) const { return (ev_setup && s != setup_stream) ? hipStreamWaitEvent(s, ev_setup, 0) : hipSuccess; }
+    ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); if (ev_setup) (void)hipEventDestroy(ev_setup); }
 };
 
 namespace {
@@ -356,12 +363,14 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     free_paths_cache(c);
+    if (c->ev_stage) { if (c->ev_stage_set) (void)hipEventSynchronize(c->ev_stage); (void)hipEventDestroy(c->ev_stage); }
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->spare) (void)hipFree(c->spare);
     if (c->plan_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->plan_scratch); }
     if (c->arena) { (void)hipDeviceSynchronize(); (void)hipFree(c->arena); }
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev_totals) (void)hipEventDestroy(c->ev_totals);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
     if (c->verify_scratch) (void)hipFree(c->verify_scratch);
     c->templates.reset();
@@ -459,7 +468,7 @@ int fcpp_outputs_alloc(fcpp_ctx *c, int64_t n_points, int64_t pitch_bytes, doubl
             off = c->arena_live[at].off + c->arena_live[at].len;
         }
         if (off + need <= c->arena_lane) {
-            c->arena_live.insert(c->arena_live.begin() + (long)at, fcpp_ctx::ArenaBlock{ off, need });
+            c->arena_live.insert(c->arena_live.begin() + (long)at, fcpp_ctx::ArenaBlock{ off, need, nullptr, false });
             b = static_cast<char *>(c->arena) + off;
             P = c->arena_pitch;
         }
@@ -489,7 +498,14 @@ int fcpp_outputs_free(fcpp_ctx *c, double *x)
     if (c->arena && p >= static_cast<char *>(c->arena) && p < static_cast<char *>(c->arena) + c->arena_lane) {
         const size_t off = (size_t)(p - static_cast<char *>(c->arena));
         for (size_t k = 0; k < c->arena_live.size(); ++k)
-            if (c->arena_live[k].off == off) { c->arena_live.erase(c->arena_live.begin() + (long)k); return FCPP_OK; }
+            if (c->arena_live[k].off == off) {
+                // (steps that write the block may still be queued on the stream they ran on, and first fit may hand the same offset to a
+                // batch on another stream at once: the block goes back only when that stream has finished with it -- a query when it is idle)
+                const fcpp_ctx::ArenaBlock blk = c->arena_live[k];
+                if (blk.used && hipStreamQuery(blk.last) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamSynchronize(blk.last)); }
+                c->arena_live.erase(c->arena_live.begin() + (long)k);
+                return FCPP_OK;
+            }
         return fail(FCPP_EINVAL, "not an allocation of the output arena");
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -769,22 +785,29 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     };
     auto upload_obstacles = [&]() -> int {
         if (lay.n_polys <= 0) return FCPP_OK;
-        // (the obstacle part of the image through the context's pinned staging memory, pageable when that cannot be had)
-        const size_t o0 = lay.obs_off, o1 = lay.seg;
+        // (the obstacle region of the image -- it alone, offsets rebased -- through the context's pinned staging memory, pageable when that
+        // cannot be had; the copy out of the staging memory is asynchronous: ev_stage orders the next writer of that memory behind it)
+        const size_t o0 = lay.obs_off, o1 = lay.seg, nb = o1 - o0;
         std::vector<unsigned char> tmp;
         unsigned char *img = nullptr;
-        if (o1 <= kStageMax) {
-            if (c->stage_cap < o1) {
+        if (nb <= kStageMax) {
+            if (c->ev_stage_set) { DEVCHK(hipEventSynchronize(c->ev_stage)); c->ev_stage_set = false; }
+            if (c->stage_cap < nb) {
                 if (c->stage) { (void)hipHostFree(c->stage); c->stage = nullptr; c->stage_cap = 0; }
-                if (hipHostMalloc(&c->stage, o1 + o1 / 4, hipHostMallocDefault) == hipSuccess) c->stage_cap = o1 + o1 / 4;
+                if (hipHostMalloc(&c->stage, nb + nb / 4, hipHostMallocDefault) == hipSuccess) c->stage_cap = nb + nb / 4;
                 else { c->stage = nullptr; (void)hipGetLastError(); }
             }
-            if (c->stage_cap >= o1) img = static_cast<unsigned char *>(c->stage);
+            if (c->stage_cap >= nb) img = static_cast<unsigned char *>(c->stage);
         }
-        if (!img) { try { tmp.resize(o1); } catch (const std::bad_alloc &) { err = "out of host memory"; return FCPP_ENOMEM; } img = tmp.data(); }
-        fill_obstacles(obstacles, lay, img);
-        DEVCHK(hipMemcpyAsync(static_cast<unsigned char *>(b->slab) + o0, img + o0, o1 - o0, hipMemcpyHostToDevice, st));
+        if (!img) { try { tmp.resize(nb); } catch (const std::bad_alloc &) { err = "out of host memory"; return FCPP_ENOMEM; } img = tmp.data(); }
+        fill_obstacles(obstacles, lay, img, o0);
+        DEVCHK(hipMemcpyAsync(static_cast<unsigned char *>(b->slab) + o0, img, nb, hipMemcpyHostToDevice, st));
         if (!tmp.empty()) DEVCHK(hipStreamSynchronize(st));
+        else {
+            if (!c->ev_stage) DEVCHK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
+            DEVCHK(hipEventRecord(c->ev_stage, st));
+            c->ev_stage_set = true;
+        }
         return FCPP_OK;
     };
     DevPlanTables T;
@@ -876,6 +899,10 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     tm.image_bytes = (int64_t)((size_t)n_fields * sizeof(fcpp_field) + (lay.n_polys > 0 ? lay.seg - lay.obs_off : 0));
     DEVCHK(hipEventRecord(c->ev_plan, st));
     c->ev_plan_set = true;
+    if (!c->ev_pool.empty()) { b->ev_setup = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else DEVCHK(hipEventCreateWithFlags(&b->ev_setup, hipEventDisableTiming));
+    DEVCHK(hipEventRecord(b->ev_setup, st));
+    b->setup_stream = st;
     // fcpp_field_info stays on the device until somebody asks (fcpp_batch_info); the stream is NOT drained: a step enqueued next runs
     // right behind the setup
     b->info_dev = T.info;
@@ -1008,6 +1035,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     unsigned char *img = nullptr;
     std::vector<unsigned char> pageable;
     if (lay.upload_bytes <= kStageMax) {
+        if (c->ev_stage_set) { HIPCHK(hipEventSynchronize(c->ev_stage)); c->ev_stage_set = false; }
         if (c->stage_cap < lay.upload_bytes) {
             if (c->stage) { (void)hipHostFree(c->stage); c->stage = nullptr; c->stage_cap = 0; }
             const size_t want = std::min(kStageMax, std::max<size_t>(lay.upload_bytes + lay.upload_bytes / 4, (size_t)1 << 20));
@@ -1094,6 +1122,14 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
     b->note_stream(st);
+    HIPCHK(b->wait_setup(st));
+    if (fcpp_ctx *c = b->ctx; c->arena && x) {      // output arrays from the context's arena: their block remembers the stream that writes it (fcpp_outputs_free)
+        const char *p = reinterpret_cast<const char *>(x), *a0 = static_cast<const char *>(c->arena);
+        if (p >= a0 && p < a0 + c->arena_lane) {
+            const size_t off = (size_t)(p - a0);
+            for (auto &blk : c->arena_live) if (off >= blk.off && off < blk.off + blk.len) { blk.last = st; blk.used = true; break; }
+        }
+    }
     if (mode == 0 && !b->til0_built) {      // the staged pipeline's own tiling: plain tiles of at most TILE_POINTS points
         { const int rc = ensure_info(b); if (rc) return rc; }
         Tiling t0;
@@ -1276,6 +1312,7 @@ int fcpp_batch_connectors(fcpp_batch *b, double *approach_xy, double *departure_
     HIPCHK(hipSetDevice(b->ctx->device));
     hipStream_t st = b->ctx->stream;
     b->note_stream(st);
+    HIPCHK(b->wait_setup(st));
     if (approach_xy) LAUNCHCHK(launch_straight(st, b->n_fields, b->t.seg, 50, b->t.seg_mask, approach_xy));
     if (departure_xy)
         LAUNCHCHK(launch_straight(st, b->n_fields, b->t.seg + 4 * b->n_fields, 50, b->t.seg_mask + b->n_fields, departure_xy));
@@ -1298,6 +1335,7 @@ int fcpp_batch_destroy(fcpp_batch *b)
         } else (void)hipFree(b->slab);
         b->slab = nullptr;
     }
+    if (b->ev_setup && c->ev_pool.size() < 64) { c->ev_pool.push_back(b->ev_setup); b->ev_setup = nullptr; }
     delete b;
     return FCPP_OK;
 }
@@ -1734,6 +1772,13 @@ int fcpp_gather(fcpp_ctx *c, void *nccl_comm, int rank, int world, int root, int
     // point to point, each peer over its own xGMI link to the root (no ring, no staging, no concatenation)
     bool grouped = false;
 #define NCCLCHK(expr) do { const int e_ = (expr); if (e_ != 0) { if (grouped) (void)rccl().group_end(); return fail(FCPP_EHIP, std::string(#expr) + ": RCCL error " + std::to_string(e_)); } } while (0)
+    // (the root's own block: a plain copy, enqueued BEFORE the group opens -- an error return inside an open group would leave the communicator in group mode)
+    if (rank == root && !self_through_comm && counts_per_rank[rank] > 0)
+        for (int a = 0; a < n_arrays; ++a) {
+            const size_t eb = (size_t)elem_bytes[a];
+            char *dst = static_cast<char *>(recv_dev[a]) + (size_t)first[(size_t)rank] * eb;
+            if (dst != send_dev[a]) HIPCHK(hipMemcpyAsync(dst, send_dev[a], (size_t)counts_per_rank[rank] * eb, hipMemcpyDeviceToDevice, st));
+        }
     if (need_comm) { NCCLCHK(rccl().group_start()); grouped = true; }
     for (int a = 0; a < n_arrays; ++a) {
         const size_t eb = (size_t)elem_bytes[a];
@@ -1743,7 +1788,7 @@ int fcpp_gather(fcpp_ctx *c, void *nccl_comm, int rank, int world, int root, int
                 const size_t bytes = (size_t)counts_per_rank[r] * eb;
                 if (bytes == 0) continue;
                 char *dst = full + (size_t)first[(size_t)r] * eb;
-                if (r == rank && !self_through_comm) { if (dst != send_dev[a]) HIPCHK(hipMemcpyAsync(dst, send_dev[a], bytes, hipMemcpyDeviceToDevice, st)); }
+                if (r == rank && !self_through_comm) continue;
                 else NCCLCHK(rccl().recv(dst, bytes, /* ncclInt8 */ 0, r, nccl_comm, st));
             }
             if (self_through_comm && counts_per_rank[rank] > 0)
@@ -1800,6 +1845,7 @@ int fcpp_batch_debug_table(const fcpp_batch *b, int table, void *dst, int64_t ca
     if (cap < (int64_t)len[table]) return fail(FCPP_ESIZE, "buffer too small");
     if (len[table] == 0 || n == 0) return FCPP_OK;
     HIPCHK(hipSetDevice(b->ctx->device));
+    for (hipStream_t s : b->used_streams) HIPCHK(hipStreamSynchronize(s));          // (the setup's stream is one of them)
     HIPCHK(hipStreamSynchronize(b->ctx->stream));
     HIPCHK(hipMemcpy(dst, static_cast<const unsigned char *>(b->slab) + off[table], len[table], hipMemcpyDeviceToHost));
     return FCPP_OK;

@@ -486,16 +486,16 @@ void layout_image(ImageLayout &lay)
 }
 
 // the batch's obstacle polygons (CSR) and one bounding box per polygon
-void fill_obstacles(const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst)
+void fill_obstacles(const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst, size_t rebase)
 {
     if (lay.n_polys > 0) {
         const int64_t np = lay.n_polys, nv = lay.n_poly_verts;
-        memcpy(at<int64_t>(dst, lay.obs_off), polys->offsets, (size_t)(np + 1) * sizeof(int64_t));
+        memcpy(at<int64_t>(dst, lay.obs_off - rebase), polys->offsets, (size_t)(np + 1) * sizeof(int64_t));
         if (nv > 0) {
-            memcpy(at<double>(dst, lay.obs_x), polys->x, (size_t)nv * sizeof(double));
-            memcpy(at<double>(dst, lay.obs_y), polys->y, (size_t)nv * sizeof(double));
+            memcpy(at<double>(dst, lay.obs_x - rebase), polys->x, (size_t)nv * sizeof(double));
+            memcpy(at<double>(dst, lay.obs_y - rebase), polys->y, (size_t)nv * sizeof(double));
         }
-        double *bb = at<double>(dst, lay.obs_bbox);
+        double *bb = at<double>(dst, lay.obs_bbox - rebase);
         for (int64_t k = 0; k < np; ++k) {
             double mnx = HUGE_VAL, mny = HUGE_VAL, mxx = -HUGE_VAL, mxy = -HUGE_VAL;
             for (int64_t q = polys->offsets[k]; q < polys->offsets[k + 1]; ++q) {

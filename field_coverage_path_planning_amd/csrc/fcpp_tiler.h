@@ -59,7 +59,8 @@ struct ImageLayout {
 
 // offsets of the tables from their counts; the obstacle part of the image (both also used by the device-side setup, fcpp_api.cpp)
 void layout_image(ImageLayout &lay);
-void fill_obstacles(const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst);
+// (rebase: dst holds the image from byte `rebase` on -- the obstacle region alone when rebase = lay.obs_off)
+void fill_obstacles(const fcpp_polys *polys, const ImageLayout &lay, unsigned char *dst, size_t rebase = 0);
 
 struct BlockTiles;      // a block's records before the merge (fcpp_tiler.cpp)
 

@@ -257,12 +257,18 @@ class FieldTable:
 
     def c_args(self):
         """-> (fcpp_field pointer, fcpp_polys, objects to keep alive during the call)"""
-        if self._cargs is None:     # (the records are not written after construction: the pointers are made once)
-            rec = np.ascontiguousarray(self.rec)
-            polys = L.Polys(len(self.poly_offsets) - 1, self.poly_offsets.ctypes.data_as(L.c_i64_p), self.poly_x.ctypes.data_as(L.c_double_p),
-                            self.poly_y.ctypes.data_as(L.c_double_p))
-            self._cargs = (C.cast(C.c_void_p(rec.ctypes.data), C.POINTER(L.Field)), polys, [rec, self.poly_offsets, self.poly_x, self.poly_y])
-        return self._cargs
+        if self._cargs is not None:
+            return self._cargs
+        # (the pointers are kept only when they point INTO self.rec: in-place writes to the records then stay what the library reads.  A
+        # non-contiguous view -- table[::2] -- is copied here, at every call, so that writes made since the last one are seen)
+        contiguous = self.rec.flags.c_contiguous
+        rec = self.rec if contiguous else np.ascontiguousarray(self.rec)
+        polys = L.Polys(len(self.poly_offsets) - 1, self.poly_offsets.ctypes.data_as(L.c_i64_p), self.poly_x.ctypes.data_as(L.c_double_p),
+                        self.poly_y.ctypes.data_as(L.c_double_p))
+        cargs = (C.cast(C.c_void_p(rec.ctypes.data), C.POINTER(L.Field)), polys, [rec, self.poly_offsets, self.poly_x, self.poly_y])
+        if contiguous:
+            self._cargs = cargs
+        return cargs
 
 
 def as_table(specs):

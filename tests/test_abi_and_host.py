@@ -228,3 +228,11 @@ def test_field_table_argument_pointers_follow_the_records():
     s = t[1:]
     assert C.addressof(s.c_args()[0].contents) == C.addressof(t.c_args()[0].contents) + C.sizeof(L.Field)
     assert [i.n_main for i in E.plan_count(s, veh, opt)] == n1[::-1][1:]
+    # a stepped slice is not contiguous: its records are copied for the call, at EVERY call -- in-place writes made in between are seen
+    u = t[::2]
+    assert not u.rec.flags.c_contiguous and u.c_args() is not u.c_args()
+    m0 = [i.n_main for i in E.plan_count(u, veh, opt)]
+    assert m0 == n1[::-1][::2]
+    u.rec['vx'][1, 1] = u.rec['vx'][1, 2] = 300.0             # the view's field 1 (the table's field 2) becomes 300 x 120 m
+    u.rec['vy'][1, 2] = u.rec['vy'][1, 3] = 120.0
+    assert [i.n_main for i in E.plan_count(u, veh, opt)] == [m0[0], n0[2]]
