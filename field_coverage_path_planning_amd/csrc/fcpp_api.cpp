@@ -80,6 +80,7 @@ DevConst make_const(const fcpp_vehicle &veh, const fcpp_options &opt)
     c.tmpl_n = 0; c.tmpl_nc = 1;
     c.turn_kappa_last[0] = c.turn_kappa_last[1] = c.turn_len = c.turn_time = 0.0;
     c.turn_max_kappa[0] = c.turn_max_kappa[1] = c.turn_max_jump[0] = c.turn_max_jump[1] = 0.0;
+    c.turn_jump[0] = c.turn_jump[1] = 0.0;
     return c;
 }
 
@@ -151,7 +152,20 @@ struct TemplateSet {
     double clothoid_frac = 0.0;
     DevBuf<CacShape> shapes;                       // [0] 180-degree, [1] 90-degree clothoid-arc-clothoid unit shapes
     DevBuf<double2> tmpl_u, tmpl_c, tmpl_u_dk;     // sampled turn templates (fcpp_fused.hip), (segment length, curvature) per U-turn sample
-    std::vector<double2> h_tu, h_tc, h_dk;         // host copies
+    DevBuf<double2> tmpl_c_dk;                     // the same per corner-turn sample (the closed-form cut's chord table, fcpp_cutfn.h)
+    std::vector<double2> h_tu, h_tc, h_dk, h_dkc;  // host copies
+    double tc_lo[2] = { 0.0, 0.0 }, tc_hi[2] = { 0.0, 0.0 };      // the corner template's box (from h_tc; template_box())
+    bool box_done = false;
+    void template_box()                            // (needs the host copies: after the stream that fetched them has been drained)
+    {
+        if (box_done) return;
+        for (int d = 0; d < 2; ++d) { tc_lo[d] = 0.0; tc_hi[d] = 0.0; }
+        for (size_t k = 0; k < h_tc.size(); ++k) {
+            tc_lo[0] = std::min(tc_lo[0], h_tc[k].x); tc_hi[0] = std::max(tc_hi[0], h_tc[k].x);
+            tc_lo[1] = std::min(tc_lo[1], h_tc[k].y); tc_hi[1] = std::max(tc_hi[1], h_tc[k].y);
+        }
+        box_done = true;
+    }
     bool same(const TurnTemplates &o, double frac) const { return memcmp(&tt, &o, sizeof tt) == 0 && clothoid_frac == frac; }
 };
 }  // namespace
@@ -289,6 +303,7 @@ static bool closed_form_turns(const fcpp_vehicle &veh, const TurnTemplates &tt, 
         const double k_first_max = fabs(2 * atan2_fd(jx * 0.0 - jy * -1.0, jx * -1.0 + jy * 0.0) / dj);
         if (k_last * q_t * q_t >= lim || k_first_max * q_w * q_w >= lim) return false;
         c.turn_kappa_last[v] = k_last;
+        c.turn_jump[v] = dj;
         c.turn_max_kappa[v] = std::max(maxk, k_last);
         c.turn_max_jump[v] = std::max(std::max(maxj, fabs(dk[(size_t)nu - 2].y - (nu >= 3 ? dk[(size_t)nu - 3].y : 0.0))), fabs(k_last - dk[(size_t)nu - 2].y));
     }
@@ -298,6 +313,34 @@ static bool closed_form_turns(const fcpp_vehicle &veh, const TurnTemplates &tt, 
 }
 
 static void free_paths_cache(fcpp_ctx *c);
+
+// the constants of the closed-form cut (fcpp_cutfn.h) for a batch: the templates and their chord tables as the HOST copies or as the device
+// arrays (the same values), the rest from the batch's constants (closed_form_turns has run)
+static CutConsts make_cut_consts(TemplateSet &ts, bool device, bool turn_quiet, int wave_factor, double two_a, double u_cap, double c_line,
+                                 double fence_margin, const DevConst &cst)
+{
+    CutConsts cc;
+    memset(&cc, 0, sizeof cc);
+    ts.template_box();
+    if (device) {
+        cc.tu = reinterpret_cast<const Pt2 *>(ts.tmpl_u.p); cc.tc = reinterpret_cast<const Pt2 *>(ts.tmpl_c.p);
+        cc.dk_u = reinterpret_cast<const Pt2 *>(ts.tmpl_u_dk.p); cc.dk_c = reinterpret_cast<const Pt2 *>(ts.tmpl_c_dk.p);
+    } else {
+        cc.tu = reinterpret_cast<const Pt2 *>(ts.h_tu.data()); cc.tc = reinterpret_cast<const Pt2 *>(ts.h_tc.data());
+        cc.dk_u = reinterpret_cast<const Pt2 *>(ts.h_dk.data()); cc.dk_c = reinterpret_cast<const Pt2 *>(ts.h_dkc.data());
+    }
+    cc.nu = ts.tt.nu; cc.nc = ts.tt.nc; cc.turn_quiet = turn_quiet ? 1 : 0; cc.wave_factor = wave_factor;
+    cc.two_a = two_a; cc.u_cap = u_cap; cc.c_line = c_line; cc.fence_margin = fence_margin;
+    cc.jump[0] = cst.turn_jump[0]; cc.jump[1] = cst.turn_jump[1];
+    for (int d = 0; d < 2; ++d) { cc.tc_lo[d] = ts.tc_lo[d]; cc.tc_hi[d] = ts.tc_hi[d]; }
+    // the shortest chord of either template (host copies of the device's chord tables: the same values whichever side cuts)
+    cc.u_step_min = cc.c_step_min = HUGE_VAL;
+    for (size_t k = 1; k < ts.h_dk.size(); ++k) cc.u_step_min = std::min(cc.u_step_min, ts.h_dk[k].x);
+    for (size_t k = 1; k < ts.h_dkc.size(); ++k) cc.c_step_min = std::min(cc.c_step_min, ts.h_dkc[k].x);
+    if (ts.h_dk.size() < 2) cc.u_step_min = 0.0;
+    if (ts.h_dkc.size() < 2) cc.c_step_min = 0.0;
+    return cc;
+}
 
 extern "C" {
 
@@ -601,14 +644,19 @@ static int get_templates(fcpp_ctx *c, const TurnTemplates &tt, const fcpp_option
     HIPCHK(ts->tmpl_u.alloc((size_t)nu));
     HIPCHK(ts->tmpl_c.alloc((size_t)nc));
     HIPCHK(ts->tmpl_u_dk.alloc((size_t)nu));
+    HIPCHK(ts->tmpl_c_dk.alloc((size_t)nc));
     LAUNCHCHK(launch_build_templates(st, tt, ts->shapes.p, ts->tmpl_u.p, ts->tmpl_c.p));
     LAUNCHCHK(launch_build_template_metrics(st, nu, ts->tmpl_u.p, ts->tmpl_u_dk.p));
-    ts->h_tu.resize((size_t)nu); ts->h_tc.resize((size_t)nc); ts->h_dk.resize((size_t)nu);
+    LAUNCHCHK(launch_build_template_metrics(st, nc, ts->tmpl_c.p, ts->tmpl_c_dk.p));
+    ts->h_tu.resize((size_t)nu); ts->h_tc.resize((size_t)nc); ts->h_dk.resize((size_t)nu); ts->h_dkc.resize((size_t)nc);
     if (nu > 0) {
         HIPCHK(hipMemcpyAsync(ts->h_tu.data(), ts->tmpl_u.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(ts->h_dk.data(), ts->tmpl_u_dk.p, (size_t)nu * sizeof(double2), hipMemcpyDeviceToHost, st));
     }
-    if (nc > 0) HIPCHK(hipMemcpyAsync(ts->h_tc.data(), ts->tmpl_c.p, (size_t)nc * sizeof(double2), hipMemcpyDeviceToHost, st));
+    if (nc > 0) {
+        HIPCHK(hipMemcpyAsync(ts->h_tc.data(), ts->tmpl_c.p, (size_t)nc * sizeof(double2), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(ts->h_dkc.data(), ts->tmpl_c_dk.p, (size_t)nc * sizeof(double2), hipMemcpyDeviceToHost, st));
+    }
     out = ts;
     fresh = true;
     return FCPP_OK;
@@ -767,6 +815,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     tc.two_a = 2 * b->cst.a_lon; tc.u_cap = b->cst.u_cap; tc.c_line = b->cst.ms_work * b->cst.ms_work;
     tc.fence_margin = 1e-7 - opt.geofence_tol;
     tc.reduce_wg_max = 1024;
+    tc.cut = make_cut_consts(*b->templates, true, turn_quiet, tc.wave_factor, tc.two_a, tc.u_cap, tc.c_line, tc.fence_margin, b->cst);
     const int64_t n_polys = obstacles ? obstacles->n_polys : 0;
     tc.gen = ++c->plan_gen;
     int64_t *tot = c->plan_totals_host;
@@ -836,7 +885,8 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         layout_image(lay);
         if (lay.total_bytes > ((size_t)1 << 30)) spec = false;
     }
-    tc.speculative = spec ? 1 : 0; tc._pad = 0;
+    tc.speculative = spec ? 1 : 0;
+    tc.closed_cut = getenv("FCPP_WINDOW_CUT") ? 0 : 1;          // (FCPP_WINDOW_CUT=1: round 4's cut on both sides -- the A/B of the two cuts)
     if (spec) {
         if ((rc = take_slab(c, b, err)) != FCPP_OK) return rc;
         bind_tables(b);
@@ -1009,6 +1059,10 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     // the chunk lists are expanded on the device from the host's chunk groups; FCPP_HOST_CHUNKS=1 (the checker, tests/test_gpu_devplan.py) and
     // the FCPP_CHUNK_SPREAD diagnostic keep the host's own lists
     tc.device_chunks = !(getenv("FCPP_HOST_CHUNKS") && atoi(getenv("FCPP_HOST_CHUNKS")) != 0) && !getenv("FCPP_CHUNK_SPREAD");
+    // the reference's sampling: the general stretch of every field with a closed-form span is cut in closed form (fcpp_cutfn.h), as the device
+    // planner cuts it -- host-built and device-built tables stay equal byte for byte
+    tc.closed_cut = opt->sample_spacing == 0.0 && opt->obstacle_mode == FCPP_OBSTACLES_FLAG && tc.wave_points == CUT_WAVE_LANES && !getenv("FCPP_WINDOW_CUT");
+    tc.cut = make_cut_consts(*b->templates, false, turn_quiet, tc.wave_factor, tc.two_a, tc.u_cap, tc.c_line, tc.fence_margin, b->cst);
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);

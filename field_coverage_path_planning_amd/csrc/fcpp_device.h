@@ -33,6 +33,7 @@ struct DevConst {
     double turn_kappa_last[2];        // curvature at the turn's last sample (its stencil spans the jump to the next swath line)
     double turn_len, turn_time;       // sum of the turn's segment lengths, and that over the nominal turn speed
     double turn_max_kappa[2], turn_max_jump[2];
+    double turn_jump[2];              // length of the jump from the turn's last sample to the next line's first point (the closed-form cut: fcpp_cutfn.h)
     const double2 *field_junc;        // per field: (curvature of the first point of a line that follows a U-turn, length of the jump from the turn's end)
     const double2 *tmpl_u_dk;         // per U-turn sample k: (|t_k - t_(k-1)|, curvature at t_k), the shape's own segment lengths / curvatures
 };

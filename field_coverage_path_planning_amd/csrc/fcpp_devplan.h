@@ -17,6 +17,7 @@
 #include "fcpp_internal.h"
 #include "fcpp_planfn.h"
 #include "fcpp_tilefn.h"
+#include "fcpp_cutfn.h"
 
 namespace fcpp {
 
@@ -40,11 +41,13 @@ struct DevTileConsts {
     int32_t nu, nc;
     int32_t turn_quiet, wave_factor, field_work_tiles, max_prims, fuse_spans;
     int32_t no_bases;             // counting pass of a small batch: the fields' point offsets are not known yet (ONE scan, after the pass)
-    int32_t speculative, _pad;    // the tables are laid out by capacities: the counting pass and the scan watch them, the fill pass decides
+    int32_t speculative;          // the tables are laid out by capacities: the counting pass and the scan watch them, the fill pass decides
                                   // the fusing of spans itself and does nothing when a flag of this generation is up
+    int32_t closed_cut;           // the general stretches of fields with a closed-form span are cut in closed form (fcpp_cutfn.h); 0: by the window cut of round 4
     double two_a, u_cap, c_line, fence_margin;
     int64_t reduce_wg_max;
     int64_t gen;                  // this counting phase's generation number (> 0)
+    CutConsts cut;                // the closed-form cut (fcpp_cutfn.h), templates and chord tables on the device
 };
 
 // the device planner's scratch: one allocation the context keeps (grow-only); all pointers device

@@ -1,6 +1,7 @@
 // fcpp_devplan.hip -- batch setup on the device, see fcpp_devplan.h.  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <string.h>
 
 #include "fcpp_devplan.h"
 #include "fcpp_quiet_fn.h"
@@ -273,6 +274,8 @@ struct TileWaveLds {
     unsigned long long prim_words[STAGE ? TW_LDS_PRIMS * (sizeof(DevPrim) / 8) : 1];
     Pt2 tmpl[STAGE ? TW_LDS_TMPL : 1];
     int32_t pstart[DEVPLAN_PRIMS_CAP + 1];   // start of primitive k relative to n_main
+    CutPrim cut[CUT_PRIMS_MAX];   // the closed-form cut's records of the field's primitives (fcpp_cutfn.h)
+    Pt2 cut_tmpl[TW_LDS_TMPL];    // ... and its copies of the batch's turn templates (U-turn, corner)
     uint8_t pidx[TW_NW];          // primitive (index within the field) of window point w; 0 in layer 1
     uint8_t ins[TW_NW];           // window point w lies inside the geofence with the host's margin
 };
@@ -390,6 +393,110 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                     T.wtiles[wave_base + lane] = wt;
                     my_wt = wt;
                 }
+            }
+        }
+        // ---- round 5: the general stretch of a field with a closed-form span is cut IN CLOSED FORM (fcpp_cutfn.h, the function the host
+        // tiler runs): the step lengths the halos are sized from are the primitives' own steps and the distances between their end points
+        // -- the primitives a lane each, then the tiles of a candidate cut a lane each -- no point of the stretch is evaluated
+        if (use_wave && tc.closed_cut != 0 && a == cut_span_points(F, tc.cut) && cut_applies(F, tc.cut, a)) {
+            use_wave = false;
+            const int64_t n_main = F.n_main;
+            TSTAMP(10);
+            // the templates and their chord tables through LDS (a halo walk reads a chord per step: from device memory every step was a round
+            // trip of its own), requested together with the primitives' records
+            CutConsts lc = tc.cut;
+            const int nt_all = tc.cut.nu + tc.cut.nc;
+            const bool cut_staged = nt_all <= TW_LDS_TMPL;
+            Pt2 tp = { 0.0, 0.0 };
+            if (cut_staged && lane < nt_all) tp = lane < tc.cut.nu ? tc.cut.tu[lane] : tc.cut.tc[lane - tc.cut.nu];
+            // 1. the primitives' records
+            bool p_ok = true;
+            double ex = 0.0, ey = 0.0, fx = 0.0, fy = 0.0;
+            DevPrim q;
+            memset(&q, 0, sizeof q);
+            if (lane < prim_count) q = prims[lane];
+            TSTAMP(15);
+            if (cut_staged) {
+                if (lane < nt_all) L.cut_tmpl[lane] = tp;
+                lc.tu = L.cut_tmpl; lc.tc = L.cut_tmpl + tc.cut.nu;
+                wave_sync();
+            }
+            TSTAMP(16);
+            if (lane < prim_count) {
+                cut_prim_end(q, lc, false, fx, fy);
+                TSTAMP(17);
+                ex = fx; ey = fy;
+                if (q.n > 1) cut_prim_end(q, lc, true, ex, ey);
+            }
+            TSTAMP(11);
+            double px = __shfl_up(ex, 1), py = __shfl_up(ey, 1);          // the point before a primitive's first: its predecessor's last ...
+            if (lane == 0) cut_main_end(F, lc, px, py);                    // ... or the last point of layer 1
+            if (lane < prim_count) {
+                L.cut[lane] = cut_prim_rec(q, F, lc, px, py, fx, fy, ex, ey, p_ok);
+                L.pstart[lane] = (int32_t)(q.start - n_main);
+            }
+            const bool prims_ok = __ballot(lane < prim_count && !p_ok) == 0ull;
+            wave_sync();
+            TSTAMP(12);
+            // 2. the cut: candidate cuts of T near-equal tiles, the tiles of one a lane each; the decisions of cut_field, taken on the first
+            // tile (in path order) that does not fit
+            struct CutView { const CutPrim *p; __device__ const CutPrim &operator()(int k) const { return p[k]; } };
+            const CutView pv{ L.cut };
+            const double cap = tiler_halo_cap(tc.u_cap);
+            const int32_t G32 = (int32_t)G;
+            int nt = 0, Hb = 0, Hf = 0;
+            int64_t s = 0, c = 0;
+            bool in = false;
+            if (prims_ok)
+                for (int32_t T = cut_first_T(G32); cut_T_possible(G32, T); ++T) {
+                    int code = 0;
+                    if (lane < T) { s = a + cut_tile_start(G32, T, lane); c = cut_tile_count(G32, T, lane); code = cut_tile_eval(F, lc, pv, prim_count, cap, s, c, Hb, Hf, in); }
+                    const unsigned long long bad = __ballot(code != 0);
+                    if (bad == 0ull) { nt = (int)T; break; }
+                    if (__shfl(code, __builtin_ctzll(bad)) == 1) break;           // a halo too long: the general kernel's
+                }
+            TSTAMP(13);
+            if (nt == 0) refused = true;
+            else {
+                // the last primitive that starts at or before point i >= n_main: the starts a lane each, one ballot per tile and question
+                const int32_t my_start = lane < prim_count ? (int32_t)(q.start - n_main) : INT32_MAX;
+                const int64_t first_l = s - Hb, last_l = s + c - 1 + Hf;
+                int pa_l = 0, pb_l = 0, pf_l = 0;
+                for (int t = 0; t < nt; ++t) {
+                    const int64_t f_t = __shfl(first_l, t), l_t = __shfl(last_l, t);
+                    const int32_t rf = (int32_t)((f_t > gen_main ? f_t : gen_main) - n_main), rl = (int32_t)(l_t - n_main), r1 = (int32_t)(f_t - n_main);
+                    const int a_t = __popcll(__ballot(my_start <= rf)) - 1, b_t = __popcll(__ballot(my_start <= rl)) - 1, f1_t = __popcll(__ballot(my_start <= r1)) - 1;
+                    if (lane == t) { pa_l = a_t < 0 ? 0 : a_t; pb_l = b_t < 0 ? 0 : b_t; pf_l = f1_t < 0 ? 0 : f1_t; }
+                }
+                const int64_t wave_pts = G;
+                const int64_t inside_cnt = __popcll(__ballot(lane < nt && in));
+                if (lane < nt && (FILL || lane < DEVPLAN_KEEP_TILES)) {
+                    const int64_t first = s - Hb, last = s + c - 1 + Hf;
+                    const int64_t p_base = FILL ? prim_index0 : 0;
+                    DevTile t;
+                    t.field = (int32_t)field; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
+                    if (first < gen_main) { const uint32_t q32 = (uint32_t)first / (uint32_t)per; t.idx0 = (int32_t)q32; t.off0 = (int32_t)((uint32_t)first - q32 * (uint32_t)per); }   // (first < 2^31: cut_applies)
+                    else { t.idx0 = (int32_t)(p_base + pf_l); t.off0 = 0; }
+                    DevWaveTile wt;
+                    memset(&wt, 0, sizeof wt);
+                    wt.out_base = (FILL ? pt_off : 0) + first; wt.field = (int32_t)field;
+                    wt.tile = (int32_t)((FILL ? stat_base : 0) + (span_k > 0 ? 1 : 0) + lane);
+                    wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = in ? 1 : 0;
+                    wt.rel_main = clampi(gen_main - first); wt.rel_seam = clampi(n_main - first); wt.rel_last = clampi(n_total - 1 - first);
+                    wt.rel_zero = clampi(-first);
+                    wt.idx0 = t.idx0; wt.off0 = t.off0;
+                    for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
+                    if (last >= gen_main) {
+                        const int pa = pa_l, pb = pb_l;
+                        wt.p0 = (int32_t)(p_base + pa);
+                        wt.r0 = (int32_t)(first - (n_main + L.pstart[pa]));
+                        for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
+                    }
+                    if (FILL) { T.tiles[stat_base + (span_k > 0 ? 1 : 0) + lane] = t; T.wtiles[wave_base + lane] = wt; }
+                    else { keep_tiles[field * DEVPLAN_KEEP_TILES + lane] = t; keep_wtiles[field * DEVPLAN_KEEP_TILES + lane] = wt; }
+                }
+                n_wave = nt; c_wave_pts = wave_pts; c_wave_inside = inside_cnt;
+                TSTAMP(14);
             }
         }
         if (use_wave) {

@@ -315,6 +315,19 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
     df.reverse_order = reverse_order; df.start_from_right = start_from_right; df.rotated = rotated;
     df.turn_model = opt.turn_model;
 
+    {   // geofence half-planes: inside <=> ex*px + ey*py + eo >= -tol   (before layer 2: the sink of the device planner tests the primitives it
+        // is handed against them, fcpp_cutfn.h)
+        double cx, cy;
+        const double sgn = area_centroid(q, cx, cy) > 0 ? 1.0 : -1.0;
+        for (int i = 0; i < 4; ++i) {
+            int j = (i + 1) & 3;
+            double ex = q.x[j] - q.x[i], ey = q.y[j] - q.y[i];
+            double ln = sqrt(ex * ex + ey * ey);
+            df.ex[i] = -ey / ln * sgn; df.ey[i] = ex / ln * sgn;
+            df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
+        }
+    }
+
     // ---- layer 2 (MLP:898-1084)
     const int num_loops = (int)ceil(hw / W);
     in.n_loops = num_loops;
@@ -414,17 +427,6 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
     df.n_total = pos;
     df.prim_count = (int32_t)(sink.size() - df.prim_first);
     df.obs_first = (int32_t)f.obstacle_first; df.obs_count = f.n_obstacles;
-    {   // geofence half-planes: inside <=> ex*px + ey*py + eo >= -tol
-        double cx, cy;
-        const double sgn = area_centroid(q, cx, cy) > 0 ? 1.0 : -1.0;
-        for (int i = 0; i < 4; ++i) {
-            int j = (i + 1) & 3;
-            double ex = q.x[j] - q.x[i], ey = q.y[j] - q.y[i];
-            double ln = sqrt(ex * ex + ey * ey);
-            df.ex[i] = -ey / ln * sgn; df.ey[i] = ex / ln * sgn;
-            df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
-        }
-    }
     if (!clip && lsx < lex) {
         // Do layer 1's lines and U-turns all lie inside the geofence?  Their bounding box in the frame -- the lines' ends plus a U-turn's
         // extent beyond them on either side, the passes' heights plus a U-turn's height (clothoid turns: 0.1 % of R for what the extents'

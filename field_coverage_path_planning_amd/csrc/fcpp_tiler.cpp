@@ -180,6 +180,55 @@ struct FieldTiler {
         return true;
     }
 
+    // The same stretch cut in closed form (fcpp_cutfn.h; the device planner runs the same function): the field's general stretch
+    // [S, n_total) at the reference's sampling.  false: the stretch stays with the general kernel.
+    std::vector<CutPrim> cprims;
+    struct PrimView { const CutPrim *p; const CutPrim &operator()(int k) const { return p[k]; } };
+    bool wave_tiles_closed(int64_t a)
+    {
+        const DevField &F = *f;
+        const int64_t n = F.n_total;
+        cprims.resize((size_t)prim_count);
+        bool ok = true;
+        double lx, ly;
+        cut_main_end(F, tc.cut, lx, ly);
+        for (int k = 0; k < prim_count; ++k) cprims[(size_t)k] = cut_prim_info(prims[k], F, tc.cut, lx, ly, ok);
+        FieldCut fc;
+        fc.n_tiles = 0; fc.status = CUT_GENERAL;
+        if (ok) cut_field(F, tc.cut, PrimView{ cprims.data() }, prim_count, a, fc);
+        if (fc.status != CUT_OK) { ++out.wave_fail[0]; return false; }
+        for (int k = 0; k < fc.n_tiles; ++k) {
+            const CutTile &ct = fc.t[k];
+            const int64_t s = ct.s, c = ct.c;
+            const int Hb = ct.hb, Hf = ct.hf;
+            const int64_t first = s - Hb, last = s + c - 1 + Hf;
+            DevTile t;
+            t.field = (int32_t)p; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
+            if (first < F.gen_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
+            else { t.idx0 = prim_index0 + prim_of(first); t.off0 = 0; }
+            DevWaveTile wt;
+            memset(&wt, 0, sizeof wt);
+            auto clampi = [](int64_t v) { return (int32_t)std::max<int64_t>(-2, std::min<int64_t>(v, (int64_t)1 << 30)); };
+            wt.out_base = F.pt_off + first; wt.field = (int32_t)p; wt.tile = (int32_t)out.tiles.size();
+            wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = ct.inside;
+            wt.rel_main = clampi(F.gen_main - first); wt.rel_seam = clampi(F.n_main - first); wt.rel_last = clampi(n - 1 - first);
+            wt.rel_zero = clampi(-first);
+            wt.idx0 = t.idx0; wt.off0 = t.off0;
+            for (int q = 0; q < 8; ++q) wt.thr[q] = 255;
+            if (last >= F.gen_main) {
+                const int64_t fl2 = std::max<int64_t>(first, F.gen_main);
+                const int pa = prim_of(fl2), pb = prim_of(last);
+                wt.p0 = prim_index0 + pa;
+                wt.r0 = (int32_t)(first - prims[pa].start);
+                for (int q = pa + 1; q <= pb; ++q) wt.thr[q - pa - 1] = (uint8_t)(prims[q].start - first);
+            }
+            out.wave_inside += wt.inside;
+            out.wtiles.push_back(wt);
+            out.tiles.push_back(t);
+        }
+        return true;
+    }
+
     void emit(int64_t s, int64_t cnt, int kind, int64_t i0, int64_t o0)
     {
         DevTile t;
@@ -191,7 +240,10 @@ struct FieldTiler {
     {
         const int64_t len = b - a;
         if (len <= 0) return;
-        if (wave_ok && wave_tiles(a, b)) return;
+        // (a field of the closed-form cut: its one general stretch [span, n_total) -- cut as the device planner cuts it, or left to the general kernel)
+        const bool closed = tc.closed_cut && tc.wave_points == CUT_WAVE_LANES && b == f->n_total && a == cut_span_points(*f, tc.cut) && cut_applies(*f, tc.cut, a);
+        if (closed) { if (wave_ok && wave_tiles_closed(a)) return; }
+        else if (wave_ok && wave_tiles(a, b)) return;
         const int64_t k = (len + TILE_POINTS - 1) / TILE_POINTS, base = len / k, rem = len % k;
         for (int64_t i = 0; i < k; ++i) {
             const int64_t c = base + (i < rem ? 1 : 0);

@@ -14,6 +14,7 @@
 
 #include "fcpp_internal.h"
 #include "fcpp_tilefn.h"
+#include "fcpp_cutfn.h"
 
 namespace fcpp {
 
@@ -31,6 +32,8 @@ struct TileConsts {
     int field_work_tiles = FIELD_WORK_TILES;  // ... at most this many (<= FIELD_WORK_TILES)
     bool fuse_spans = true;                   // ... and that workgroup also writes the field's layer-1 span (its chunks are then not in k_plan_quiet's list)
     int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
+    bool closed_cut = false;                  // reference sampling: the general stretch of a field with a closed-form span is cut by fcpp_cutfn.h (as the device planner cuts it)
+    CutConsts cut = {};                       // ... with these constants (host copies of the templates and their chord tables)
     bool device_chunks = false;               // the chunk lists of k_plan_quiet are expanded on the device from chunk groups (fcpp_batch_create; false: written by the host, the checker)
 };
 

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -38,7 +39,7 @@ int main(int argc, char **argv)
     auto U = [&](double a, double b) { return a + (b - a) * (double)(rng() >> 11) * (1.0 / 9007199254740992.0); };
     auto pick = [&](int n) { return (int)(rng() % (uint64_t)n); };
     uint64_t raw = 1469598103934665603ull, sem = raw;
-    int64_t fields_ok = 0, fields_refused = 0, tiles_total = 0, wave_total = 0, shared = 0;
+    int64_t fields_ok = 0, fields_refused = 0, tiles_total = 0, wave_total = 0, shared = 0, closed_tiles = 0, halo_diff = 0;
     for (int round = 0; round < rounds; ++round) {
         fcpp_vehicle veh = { 3.2, 8.0, 9.0, 15.0, 4.0, 2.0, 1.5, 0.85 };
         if (pick(3) == 0) { veh.working_width = U(1.0, 8.0); veh.min_turn_radius = U(3.0, 15.0); veh.max_longitudinal_accel = U(0.1, 3.0); }
@@ -111,6 +112,33 @@ int main(int argc, char **argv)
         const double vm = 15.0 / 3.6;
         tc.two_a = 2 * veh.max_longitudinal_accel; tc.u_cap = vm * vm; tc.c_line = (9.0 / 3.6) * (9.0 / 3.6);
         tc.fence_margin = 1e-7 - opt.geofence_tol;
+        // the closed-form cut (fcpp_cutfn.h) at the reference's sampling, as fcpp_batch_create switches it on; its constants as the library makes
+        // them: chord tables of the templates (k_build_template_metrics), the jump from a turn's last sample to the next line (closed_form_turns)
+        std::vector<Pt2> dku((size_t)tt.nu), dkc((size_t)tt.nc);
+        for (int k = 1; k < tt.nu; ++k) { const double dx = tu[(size_t)k].x - tu[(size_t)k - 1].x, dy = tu[(size_t)k].y - tu[(size_t)k - 1].y; dku[(size_t)k] = { sqrt(dx * dx + dy * dy), 0.0 }; }
+        for (int k = 1; k < tt.nc; ++k) { const double dx = tcn[(size_t)k].x - tcn[(size_t)k - 1].x, dy = tcn[(size_t)k].y - tcn[(size_t)k - 1].y; dkc[(size_t)k] = { sqrt(dx * dx + dy * dy), 0.0 }; }
+        tc.closed_cut = opt.sample_spacing == 0.0 && opt.obstacle_mode == FCPP_OBSTACLES_FLAG && tc.wave_points == CUT_WAVE_LANES && pick(5) != 0;
+        {
+            CutConsts &cc = tc.cut;
+            memset(&cc, 0, sizeof cc);
+            cc.tu = tu.data(); cc.tc = tcn.data(); cc.dk_u = dku.data(); cc.dk_c = dkc.data(); cc.nu = tt.nu; cc.nc = tt.nc;
+            cc.turn_quiet = tc.turn_quiet; cc.wave_factor = tc.wave_factor; cc.two_a = tc.two_a; cc.u_cap = tc.u_cap; cc.c_line = tc.c_line; cc.fence_margin = tc.fence_margin;
+            if (tt.nu >= 1) {
+                const bool arc = tt.turn_model == FCPP_TURN_ARC;
+                const Pt2 tl = tu[(size_t)tt.nu - 1];
+                for (int v = 0; v < 2; ++v) {
+                    const double jx = arc ? (-tt.R + tl.x) : -tl.x, jy = (v == 0 ? veh.working_width : -veh.working_width) - tl.y;
+                    cc.jump[v] = sqrt(jx * jx + jy * jy);
+                }
+            }
+            cc.u_step_min = tt.nu >= 2 ? HUGE_VAL : 0.0; cc.c_step_min = tt.nc >= 2 ? HUGE_VAL : 0.0;
+            for (int k = 1; k < tt.nu; ++k) cc.u_step_min = std::min(cc.u_step_min, dku[(size_t)k].x);
+            for (int k = 1; k < tt.nc; ++k) cc.c_step_min = std::min(cc.c_step_min, dkc[(size_t)k].x);
+            for (int k = 0; k < tt.nc; ++k) {
+                cc.tc_lo[0] = std::min(cc.tc_lo[0], tcn[(size_t)k].x); cc.tc_hi[0] = std::max(cc.tc_hi[0], tcn[(size_t)k].x);
+                cc.tc_lo[1] = std::min(cc.tc_lo[1], tcn[(size_t)k].y); cc.tc_hi[1] = std::max(cc.tc_hi[1], tcn[(size_t)k].y);
+            }
+        }
         BatchTiler tiler;
         ImageLayout lay;
         rc = tiler.plan(hp, tc, &polys, lay, err);
@@ -176,6 +204,50 @@ int main(int argc, char **argv)
                 for (int q = 0; q < 8 && w.thr[q] != 255; ++q) {
                     if (P[w.p0 + 1 + q].start != first + w.thr[q]) FAIL("wave tile %lld: threshold %d", (long long)k, q);
                     if (w.thr[q] < 1 || w.thr[q] >= 128 || (q > 0 && w.thr[q] <= w.thr[q - 1])) FAIL("wave tile %lld: thresholds not strictly ascending in [1, 128)", (long long)k);
+                }
+            }
+        }
+        if (tc.closed_cut) {
+            // The halos of the closed-form cut against the path's own points: every wave tile's halos must be what the halo walks of
+            // fcpp_tilefn.h give on the EVALUATED step lengths (the formulas of the kernels), and a tile that says `inside` must have every output
+            // point inside the geofence with the tiler's margin.
+            const double cap = tiler_halo_cap(tc.u_cap);
+            for (int64_t k = 0; k < lay.n_wave; ++k) {
+                const DevWaveTile &w = Wt[k];
+                const DevField &f = F[w.field];
+                if (!(cut_applies(f, tc.cut, cut_span_points(f, tc.cut)))) continue;
+                ++closed_tiles;
+                const DevPrim *fp = P + f.prim_first;
+                const int64_t per = (int64_t)f.n_line + f.n_turn;
+                auto point = [&](int64_t i, double &x, double &y) {
+                    if (i < f.gen_main) { tiler_point_main(f, tu.data(), i / per, i % per, x, y); return; }
+                    int a = 0, b = f.prim_count - 1;
+                    while (a < b) { const int m = (a + b + 1) >> 1; if (fp[m].start <= i) a = m; else b = m - 1; }
+                    tiler_point_prim(fp[a], tu.data(), tcn.data(), i - fp[a].start, x, y);
+                };
+                auto dist = [&](int64_t i) { double x0, y0, x1, y1; point(i - 1, x0, y0); point(i, x1, y1); return sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0)); };
+                const int64_t first = w.out_base - f.pt_off, s0 = first + w.hb, e0 = s0 + w.count - 1;
+                const int hb = tiler_back_halo(dist, s0, tc.two_a, cap), hf = tiler_fwd_halo(dist, e0, f.n_total, tc.two_a, cap);
+                if (hb != w.hb || hf != w.hf) {
+                    ++halo_diff;
+                    // a halo SHORTER than the path's own step lengths ask for would let the sweeps carry speeds into the outputs: never
+                    if (hb < 0 || hf < 0 || w.hb < hb || w.hf < hf) FAIL("wave tile %lld of field %d: halos %d / %d, the evaluated path asks for %d / %d", (long long)k, w.field, w.hb, w.hf, hb, hf);
+                }
+                if (w.inside)
+                    for (int64_t i = s0; i <= e0; ++i) { double x, y; point(i, x, y); if (!tiler_inside(f, x, y, tc.fence_margin)) FAIL("wave tile %lld says inside, point %lld is not", (long long)k, (long long)i); }
+                // the closed-form step lengths themselves, point by point over the tile
+                {
+                    std::vector<CutPrim> cp((size_t)f.prim_count);
+                    bool ok = true;
+                    double lx, ly;
+                    cut_main_end(f, tc.cut, lx, ly);
+                    for (int q = 0; q < f.prim_count; ++q) cp[(size_t)q] = cut_prim_info(fp[q], f, tc.cut, lx, ly, ok);
+                    struct PV { const CutPrim *p; const CutPrim &operator()(int q) const { return p[q]; } } pv{ cp.data() };
+                    CutDist<PV> cd(f, tc.cut, pv, f.prim_count);
+                    for (int64_t i = std::max<int64_t>(first, 1); i < first + w.hb + w.count + w.hf; ++i) {
+                        const double a = dist(i), c = cd(i);
+                        if (fabs(a - c) > 1e-9 * (1.0 + a)) FAIL("step %lld of field %d: evaluated %.17g, closed form %.17g", (long long)i, w.field, a, c);
+                    }
                 }
             }
         }
@@ -310,7 +382,8 @@ int main(int argc, char **argv)
             }
         }
     }
-    printf("rounds %d fields %lld refused %lld shared %lld tiles %lld wave %lld raw %llu semantic %llu\n", rounds, (long long)fields_ok,
-           (long long)fields_refused, (long long)shared, (long long)tiles_total, (long long)wave_total, (unsigned long long)raw, (unsigned long long)sem);
+    printf("rounds %d fields %lld refused %lld shared %lld tiles %lld wave %lld raw %llu semantic %llu closed_tiles %lld halo_diff %lld\n", rounds, (long long)fields_ok,
+           (long long)fields_refused, (long long)shared, (long long)tiles_total, (long long)wave_total, (unsigned long long)raw, (unsigned long long)sem,
+           (long long)closed_tiles, (long long)halo_diff);
     return 0;
 }

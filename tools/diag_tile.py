@@ -24,6 +24,8 @@ for r in range(5):
 names = {0: 'entry', 1: 'field read', 2: 'staged', 36: 'cut done', 37: 'decisions', 38: 'counts written'}
 for k in range(4):
     names[3 + 4 * k] = f'tile {k}: window'; names[4 + 4 * k] = f'tile {k}: back halo'; names[5 + 4 * k] = f'tile {k}: candidates'; names[6 + 4 * k] = f'tile {k}: record'
+names.update({10: 'closed cut: begin', 11: 'closed cut: primitive ends', 12: 'closed cut: primitive records', 13: 'closed cut: tiles cut', 14: 'closed cut: tile records'})
+names.update({15: 'closed cut: loads issued', 16: 'closed cut: templates staged', 17: 'closed cut: first points'})
 names.update({24: 'round 2: begin', 25: 'round 2: search', 26: 'round 2: point', 27: 'round 2: distance', 28: 'round 2: inside'})
 t0, prev = st[0], st[0]
 for k in sorted(names, key=lambda k: st[k]):

@@ -1,18 +1,31 @@
 #!/usr/bin/env python3
-"""The headline plan call (4096 fields of 500 x 200 m) end to end, repeated: wall time of create / alloc+run+sync, median over the
-repetitions after the first.  Usage: python tools/trace_create.py [reps]"""
+"""A plan call end to end, repeated: wall time of create / alloc / run / sync, median over the repetitions after the first.
+Usage: python tools/trace_create.py [reps] [headline|cfg2_ref|cfg5|cfg1_clothoid]   (FCPP_NO_PIN=1: pageable field records)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from field_coverage_path_planning_amd import engine as E
+from field_coverage_path_planning_amd import workloads as WL
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-LH = np.tile(np.array([[500.0, 200.0]]), (4096, 1))
-table = E.FieldTable.from_rectangles(LH)
+what = sys.argv[2] if len(sys.argv) > 2 else 'headline'
+opt = E.make_options()
+if what == 'cfg2_ref':
+    table = E.FieldTable.from_rectangles(WL.cfg2_rectangles())
+elif what == 'cfg5':
+    table = E.FieldTable.from_vertices(WL.cfg5_parallelograms())
+else:
+    table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (4096, 1)))
+    if what == 'cfg1_clothoid':
+        opt = E.make_options(1, 0.0)
 if not os.environ.get('FCPP_NO_PIN'):
     table.pin()
-veh, opt = E.make_vehicle(), E.make_options()
+if os.environ.get('FCPP_ARENA', '1') != '0':
+    E.get_context().reserve_outputs(lane_gib=24.0, pitch_gib=24.0)
+veh = E.make_vehicle()
+stream = torch.cuda.Stream()
+torch.cuda.set_stream(stream)
 rows = []
 batch = None
 for r in range(reps):
@@ -31,5 +44,5 @@ for r in range(reps):
     rows.append([(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3])
 a = np.array(rows[1:])
 med = np.median(a, axis=0)
-print("median ms: create %.4f alloc %.4f run_enqueue %.4f sync %.4f total %.4f" % tuple(med))
-print("setup_times", batch.setup_times())
+print("%s: median ms: create %.4f alloc %.4f run_enqueue %.4f sync %.4f total %.4f" % ((what,) + tuple(med)))
+print("setup_times", batch.setup_times(), 'points', batch.total_points)
