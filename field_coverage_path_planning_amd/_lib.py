@@ -125,6 +125,8 @@ PROTOTYPES = [
     ('fcpp_plan_points', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field), C.POINTER(Polys), c_i64_p]),
     ('fcpp_batch_create', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field),
                                     C.POINTER(Polys), C.POINTER(_VP)]),
+    ('fcpp_batch_plan', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field), C.POINTER(Polys), _VP,
+                                  C.POINTER(_VP)] + [C.POINTER(_VP)] * 5 + [c_i64_p]),
     ('fcpp_batch_info', C.c_int, [_VP, C.POINTER(FieldInfo), c_i64_p]),
     ('fcpp_batch_setup_times', C.c_int, [_VP, C.POINTER(SetupTimes)]),
     ('fcpp_batch_run', C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int]),
@@ -179,7 +181,7 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.fcpp_abi_version() != 4:
+        if lib.fcpp_abi_version() != 5:
             raise ImportError('libfcpp.so ABI version mismatch')
         _lib = lib
     return _lib

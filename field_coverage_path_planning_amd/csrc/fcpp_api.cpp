@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <new>
@@ -728,10 +729,10 @@ int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, D
         if (hipMalloc(&c->plan_scratch, want) != hipSuccess) { (void)hipGetLastError(); err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
         c->plan_scratch_cap = want;
         // (the flags live at the start of the allocation and are never cleared again: they hold generation numbers)
-        DEVCHK(hipMemsetAsync(c->plan_scratch, 0, (PC_COLS + PF_COUNT) * sizeof(int64_t), st));
+        DEVCHK(hipMemsetAsync(c->plan_scratch, 0, PLAN_TOTALS * sizeof(int64_t), st));
     }
     if (!c->plan_totals_host)
-        DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, (PC_COLS + PF_COUNT) * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        { DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, PLAN_TOTALS * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent)); memset(c->plan_totals_host, 0, PLAN_TOTALS * sizeof(int64_t)); }
     unsigned char *sb = static_cast<unsigned char *>(c->plan_scratch);
     s.fields_in = reinterpret_cast<fcpp_field *>(sb + (size_t)off.fields_in); s.info = reinterpret_cast<fcpp_field_info *>(sb + (size_t)off.info);
     s.fields_tmp = reinterpret_cast<DevField *>(sb + (size_t)off.fields_tmp); s.prims_tmp = reinterpret_cast<DevPrim *>(sb + (size_t)off.prims_tmp);
@@ -898,7 +899,19 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         if (!c->ev_totals) DEVCHK(hipEventCreateWithFlags(&c->ev_totals, hipEventDisableTiming));
         DEVCHK(hipEventRecord(c->ev_totals, st));
         if ((rc = launch_fill()) != FCPP_OK) { (void)hipStreamSynchronize(st); return rc; }
-        DEVCHK(hipEventSynchronize(c->ev_totals));      // (the last scan has written the totals and the flags to `tot`; the fill pass runs on)
+        // (the last scan has written the totals and the flags to `tot`, then the phase's generation number to tot[PX_DONE]: polled -- a word
+        // of the host's own pinned memory, there a microsecond after the kernel wrote it -- with the event as the fallback; the fill pass runs on)
+        {
+            volatile int64_t *done = tot + PX_DONE;
+            const auto t_poll = std::chrono::steady_clock::now();
+            bool seen = false;
+            for (int spin = 0; !seen; ++spin) {
+                seen = *done == tc.gen;
+                if (!seen && (spin & 1023) == 1023 && ms_since(t_poll) > 2.0) break;
+            }
+            if (!seen) DEVCHK(hipEventSynchronize(c->ev_totals));
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
     } else {
         DEVCHK(hipStreamSynchronize(st));
     }
@@ -1287,6 +1300,33 @@ int fcpp_batch_run(fcpp_batch *b, double *x, double *y, double *kappa, double *v
     STAGE(6, launch_reduce_stats(st, t.n_paths, t.partial.p, t.tile_first.p, t.n_adj.p, stats));
 #undef STAGE
     if (ev) ++b->prof_runs;
+    return FCPP_OK;
+}
+
+int fcpp_batch_plan(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
+                    const fcpp_polys *obstacles, fcpp_field_stats *stats, fcpp_batch **batch, double **x, double **y, double **kappa, double **v,
+                    uint32_t **fs, int64_t *total_points)
+{
+    if (!batch || !x || !y || !kappa || !v || !fs || (n_fields > 0 && !stats)) return fail(FCPP_EINVAL, "bad arguments");
+    *batch = nullptr; *x = *y = *kappa = *v = nullptr; *fs = nullptr;
+    fcpp_batch *b = nullptr;
+    int rc = fcpp_batch_create(c, veh, opt, n_fields, fields, obstacles, &b);
+    if (rc != FCPP_OK) return rc;
+    const int64_t total = b->hp.total_points;
+    rc = fcpp_outputs_alloc(c, total, 0, x, y, kappa, v, fs);
+    if (rc == FCPP_OK) {
+        rc = fcpp_batch_run(b, *x, *y, *kappa, *v, *fs, stats, 1);
+        if (rc != FCPP_OK) { const std::string keep = g_err; (void)hipStreamSynchronize(c->stream); (void)fcpp_outputs_free(c, *x); g_err = keep; }
+    }
+    if (rc != FCPP_OK) {
+        const std::string keep = g_err;
+        (void)fcpp_batch_destroy(b);
+        *x = *y = *kappa = *v = nullptr; *fs = nullptr;
+        g_err = keep;
+        return rc;
+    }
+    *batch = b;
+    if (total_points) *total_points = total;
     return FCPP_OK;
 }
 

@@ -31,6 +31,10 @@ enum PlanCol : int {
 // totals[PC_COLS + k]: flags the kernels raise -- a flag holds the generation number (DevTileConsts.gen, counted up by the context) of the
 // last counting phase that raised it, so nothing has to be cleared between batches: raised in this phase <=> flag == gen
 enum PlanFlag : int { PF_FALLBACK = 0, PF_BAD_OBSTACLES = 1, PF_OVER_CAPACITY = 2, PF_COUNT = 3 };
+// behind the flags: [PX_ARRIVED] the columns of the counting phase's last scan that have published their totals (device only), [PX_DONE] the
+// generation number of the phase whose totals are complete -- written to the host's copy by the last column to arrive: the host polls it
+// (a word in its own pinned memory) instead of waiting for an event
+constexpr int PX_ARRIVED = PC_COLS + PF_COUNT, PX_DONE = PC_COLS + PF_COUNT + 1, PLAN_TOTALS = PC_COLS + PF_COUNT + 2;
 // (PF_OVER_CAPACITY: a speculative setup -- tables laid out by per-field capacities, the fill pass enqueued before the host has the totals
 // -- met a field beyond them: SPEC_* below; the host then lays the tables out from the totals and fills them again)
 constexpr int SPEC_SPAN_CHUNKS = 16;         // span chunks per field a speculative layout has room for (tiles: 1 + DEVPLAN_KEEP_TILES, wave / general tiles: DEVPLAN_KEEP_TILES)
@@ -58,7 +62,7 @@ struct DevPlanScratch {
     DevPrim *prims_tmp;           // n x max_prims
     int64_t *counts, *bases;      // PC_COLS x n
     int64_t *blk_sums;            // PC_COLS x blocks of 1024 fields
-    int64_t *totals;              // PC_COLS + PF_COUNT
+    int64_t *totals;              // PLAN_TOTALS
     // the counting pass keeps the first DEVPLAN_KEEP_TILES wave tiles of every field (records with field-relative indices): the fill pass
     // copies and rebases them instead of cutting the field again (fields with more are cut again)
     DevTile *keep_tiles;          // n x DEVPLAN_KEEP_TILES

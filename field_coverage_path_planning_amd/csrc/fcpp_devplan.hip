@@ -13,7 +13,7 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t r = off; off = (off + bytes + 255) & ~(size_t)255; return r; };
     const size_t nn = (size_t)(n > 0 ? n : 1), nblk = (nn + 1023) / 1024;
-    o->totals = reinterpret_cast<int64_t *>(take((PC_COLS + PF_COUNT) * sizeof(int64_t)));      // (first: the flags keep their place whatever n is)
+    o->totals = reinterpret_cast<int64_t *>(take(PLAN_TOTALS * sizeof(int64_t)));      // (first: the flags keep their place whatever n is)
     o->fields_in = reinterpret_cast<fcpp_field *>(take(nn * sizeof(fcpp_field)));
     o->info = reinterpret_cast<fcpp_field_info *>(take(nn * sizeof(fcpp_field_info)));
     o->fields_tmp = reinterpret_cast<DevField *>(take(nn * sizeof(DevField)));
@@ -69,6 +69,19 @@ __device__ __forceinline__ void publish_total(const int64_t *totals, int64_t *mi
     if (flags) for (int k = 0; k < PF_COUNT; ++k) if (!(over_elsewhere && k == PF_OVER_CAPACITY)) mirror[PC_COLS + k] = totals[PC_COLS + k];
 }
 
+// the last scan of a counting phase: a column's workgroup has published its total; the last one to arrive tells the host (PX_DONE)
+__device__ __forceinline__ void publish_done(int64_t *totals, int64_t *mirror, int n_cols, int64_t done_gen)
+{
+    if (!mirror || done_gen <= 0) return;
+    __threadfence_system();
+    const unsigned long long arrived = atomicAdd(reinterpret_cast<unsigned long long *>(totals + PX_ARRIVED), 1ull);
+    if (arrived == (unsigned long long)(n_cols - 1)) {
+        totals[PX_ARRIVED] = 0;
+        __threadfence_system();
+        reinterpret_cast<volatile int64_t *>(mirror)[PX_DONE] = done_gen;
+    }
+}
+
 // ---- exclusive scans of count columns [c0, c1) over the fields -------------------------------------------------------------------------
 // inclusive scan of v over the 256 threads of the workgroup; total = the workgroup's sum
 __device__ __forceinline__ int64_t wg_incl_scan(int64_t v, int64_t *lds /* 4 */, int64_t &total)
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(256) void k_scan_block_sums(int64_t n, int c0, cons
 }
 // phase B: one workgroup per column scans the block sums in place (exclusive) and writes the column's total
 __global__ __launch_bounds__(256) void k_scan_block_bases(int c0, int64_t *__restrict__ blk_sums, int64_t nblk, int64_t *__restrict__ totals,
-                                                          int64_t *__restrict__ mirror, int with_flags)
+                                                          int64_t *__restrict__ mirror, int with_flags, int64_t done_gen)
 {
     __shared__ int64_t lds[4];
     const int col = c0 + blockIdx.x;
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256) void k_scan_block_bases(int c0, int64_t *__res
         if (i < nblk) blk_sums[(int64_t)col * nblk + i] = carry + inc - v;
         carry += tot;
     }
-    if (threadIdx.x == 0) { totals[col] = carry; publish_total(totals, mirror, col, carry, with_flags && blockIdx.x == 0); }
+    if (threadIdx.x == 0) { totals[col] = carry; publish_total(totals, mirror, col, carry, with_flags && blockIdx.x == 0); if (with_flags) publish_done(totals, mirror, (int)gridDim.x, done_gen); }
 }
 // phase C: exclusive scan inside each block of 1024 fields + the block's base; grid (blocks, columns)
 __global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int64_t *__restrict__ counts, const int64_t *__restrict__ blk_sums,
@@ -152,7 +165,7 @@ __device__ __forceinline__ void span_counts(int64_t pt_off, int64_t S, bool is_w
 // pass for the headline's 4096 fields.  derive: the columns that depend on the fields' point offsets (span_counts) are made here, by
 // their own workgroups, from the offsets (a scan of PC_POINTS of their own), the spans' lengths (PC_SPAN_PTS) and PC_WORK.
 __global__ __launch_bounds__(1024) void k_scan_small(int64_t n, int c0, int64_t *__restrict__ counts, int64_t *__restrict__ bases, int64_t *__restrict__ totals,
-                                                     int64_t *__restrict__ mirror, int with_flags, int derive, int fuse_possible, int64_t spec_gen)
+                                                     int64_t *__restrict__ mirror, int with_flags, int derive, int fuse_possible, int64_t spec_gen, int64_t done_gen)
 {
     __shared__ int64_t lds[16];
     int over = 0;                        // (spec_gen > 0: a speculative setup -- a span of more chunks than its layout has room for raises PF_OVER_CAPACITY)
@@ -223,23 +236,24 @@ __global__ __launch_bounds__(1024) void k_scan_small(int64_t n, int c0, int64_t 
             const int64_t v = over ? spec_gen : totals[PC_COLS + PF_OVER_CAPACITY];      // (the counting pass may have raised it)
             if (mirror) mirror[PC_COLS + PF_OVER_CAPACITY] = v;
         }
+        if (with_flags) publish_done(totals, mirror, (int)gridDim.x, done_gen);
     }
 }
 
 // mirror: the totals' copy in the host's pinned memory (or null), written by the scans themselves -- no copy command behind them;
 // with_flags: the flags the earlier kernels raised go along (the last scan of the counting phase)
 int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch &s, int64_t *mirror, int with_flags, int derive = 0, int fuse_possible = 0,
-                int64_t spec_gen = 0)
+                int64_t spec_gen = 0, int64_t done_gen = 0)
 {
     const int64_t nblk = (n + 1023) / 1024;
     const int nc = c1 - c0;
     if (nblk <= 8) {
-        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(1024), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags, derive, fuse_possible, spec_gen);
+        hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(1024), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags, derive, fuse_possible, spec_gen, done_gen);
         const hipError_t e0 = hipGetLastError();
         return e0 == hipSuccess ? 0 : (int)e0;
     }
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk);
-    hipLaunchKernelGGL(k_scan_block_bases, dim3((unsigned)nc), dim3(256), 0, st, c0, s.blk_sums, nblk, s.totals, mirror, with_flags);
+    hipLaunchKernelGGL(k_scan_block_bases, dim3((unsigned)nc), dim3(256), 0, st, c0, s.blk_sums, nblk, s.totals, mirror, with_flags, done_gen);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk, s.bases);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -954,12 +968,12 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
         hipLaunchKernelGGL((k_tile_fields<false, false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
                            s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
     if (one_scan) {
-        rc = launch_scan(st, n, PC_POINTS, PC_COLS, s, totals_host, 1, 1, tc.fuse_spans, tc.speculative ? tc.gen : 0);
+        rc = launch_scan(st, n, PC_POINTS, PC_COLS, s, totals_host, 1, 1, tc.fuse_spans, tc.speculative ? tc.gen : 0, tc.gen);
         if (rc) return rc;
         const hipError_t e1 = hipGetLastError();
         return e1 == hipSuccess ? 0 : (int)e1;
     }
-    rc = launch_scan(st, n, PC_TILES, PC_COLS, s, totals_host, 1);
+    rc = launch_scan(st, n, PC_TILES, PC_COLS, s, totals_host, 1, 0, 0, 0, tc.gen);
     if (rc) return rc;
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -223,11 +223,16 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
     const double L = f.from_vertices ? (bmaxx - bminx) : q.x[1];
     const double H = f.from_vertices ? (bmaxy - bminy) : q.y[2];
     in.field_length = L; in.field_width = H;
+    // (what the function reads again further down -- corner angles, the geofence edges, the field's status -- is kept in locals: read back
+    // through `in` / `df` on the device every such value is a round trip to memory behind all the stores issued before it)
     bool all90 = true;
+    double cang[4];
     for (int i = 0; i < 4; ++i) {
-        in.corner_angles[i] = corner_angle(q, i);
-        if (!(fabs(in.corner_angles[i] - 90) < 1.0)) all90 = false;
+        cang[i] = corner_angle(q, i);
+        in.corner_angles[i] = cang[i];
+        if (!(fabs(cang[i] - 90) < 1.0)) all90 = false;
     }
+    int fail_status = 0;
     in.shape = all90 ? 0 : (is_parallelogram(q) ? 1 : 2);
     const double hw = R;
     in.headland_width = hw;
@@ -291,7 +296,8 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
     in.n_swaths = (int32_t)P;
     int64_t n_main = P * n_line + (P - 1) * n_turn;
     df.gen_main = n_main;
-    df.prim_first = (int32_t)sink.size();
+    const int32_t prim_first = (int32_t)sink.size();
+    df.prim_first = prim_first;
     if (clip) {
         // ---- obstacle-aware swaths (include/fcpp.h): layer 1 as a list of primitives -- sub-swaths, detour legs, U-turns
         Layer1Frame fr;
@@ -315,6 +321,7 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
     df.reverse_order = reverse_order; df.start_from_right = start_from_right; df.rotated = rotated;
     df.turn_model = opt.turn_model;
 
+    double gex[4], gey[4], geo[4];
     {   // geofence half-planes: inside <=> ex*px + ey*py + eo >= -tol   (before layer 2: the sink of the device planner tests the primitives it
         // is handed against them, fcpp_cutfn.h)
         double cx, cy;
@@ -323,8 +330,9 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
             int j = (i + 1) & 3;
             double ex = q.x[j] - q.x[i], ey = q.y[j] - q.y[i];
             double ln = sqrt(ex * ex + ey * ey);
-            df.ex[i] = -ey / ln * sgn; df.ey[i] = ex / ln * sgn;
-            df.eo[i] = -(df.ex[i] * q.x[i] + df.ey[i] * q.y[i]);
+            gex[i] = -ey / ln * sgn; gey[i] = ex / ln * sgn;
+            geo[i] = -(gex[i] * q.x[i] + gey[i] * q.y[i]);
+            df.ex[i] = gex[i]; df.ey[i] = gey[i]; df.eo[i] = geo[i];
         }
     }
 
@@ -364,8 +372,8 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
             p.a[4] = lin_step(c.x[cur], c.x[nxt], ns); p.a[5] = lin_step(c.y[cur], c.y[nxt], ns);
             if (clip) {       // obstacle-aware: the straight is led around the boxes it crosses (include/fcpp.h); the turn at its end must be free
                 const int rcode = sink.headland_straight(pc, q, p, pos);
-                if (rcode == FCPP_OK && i < 3 && sink.box_meets_square(c.x[nxt], c.y[nxt], 2.0 * R)) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
-                if (rcode != FCPP_OK) { bad = true; in.status = rcode; break; }
+                if (rcode == FCPP_OK && i < 3 && sink.box_meets_square(c.x[nxt], c.y[nxt], 2.0 * R)) { bad = true; fail_status = FCPP_EUNSUPPORTED; break; }
+                if (rcode != FCPP_OK) { bad = true; fail_status = rcode; break; }
             } else FCPP_PUSH(p);
             last_head[0] = c.x[nxt]; last_head[1] = c.y[nxt];
             if (i == 3) break;
@@ -390,8 +398,9 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
             }
             FCPP_PUSH(p);
             // reverse fill (MLP:1043, 224-242, 1066-1082, 1154-1218)
-            const bool want_rev = (loop == 0) && (in.corner_angles[nxt] >= 60);       // MLP:1043
-            if (want_rev && pc.gap_decision < 0) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
+            const double ang_nxt = nxt == 0 ? cang[0] : (nxt == 1 ? cang[1] : (nxt == 2 ? cang[2] : cang[3]));
+            const bool want_rev = (loop == 0) && (ang_nxt >= 60);       // MLP:1043
+            if (want_rev && pc.gap_decision < 0) { bad = true; fail_status = FCPP_EUNSUPPORTED; break; }
             const bool add_rev = want_rev && pc.gap_decision > 0;                     // MLP:1070: gap.area > 0.1
             if (add_rev) {
                 const double tx = e1[0] - e2[0], ty = e1[1] - e2[1];
@@ -399,7 +408,7 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
                 double dx = -1.0, dy = 0.0;
                 if (nrm > 1e-6) { dx = -tx / nrm; dy = -ty / nrm; }
                 const double len = distance_to_boundary(e1[0], e1[1], dx, dy, L, H, R);
-                if (clip && sink.box_meets_segment(e1[0], e1[1], e1[0] + len * dx, e1[1] + len * dy)) { bad = true; in.status = FCPP_EUNSUPPORTED; break; }
+                if (clip && sink.box_meets_segment(e1[0], e1[1], e1[0] + len * dx, e1[1] + len * dy)) { bad = true; fail_status = FCPP_EUNSUPPORTED; break; }
                 int64_t nr;
                 if (ds > 0) nr = n_for_length(len, ds);
                 else { nr = (int64_t)(len / 0.5); if (nr < 10) nr = 10; }
@@ -414,7 +423,7 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
         }
     }
 #undef FCPP_PUSH
-    if (bad) FCPP_FAIL(in.status ? in.status : FCPP_EHEADLAND);
+    if (bad) FCPP_FAIL(fail_status ? fail_status : FCPP_EHEADLAND);
     in.n_head = pos - n_main;
     if (has_start) {   // MLP:437-441
         in.approach_from[0] = f.start_x; in.approach_from[1] = f.start_y;
@@ -425,7 +434,7 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
         in.departure_to[0] = f.end_x; in.departure_to[1] = f.end_y;
     }
     df.n_total = pos;
-    df.prim_count = (int32_t)(sink.size() - df.prim_first);
+    df.prim_count = (int32_t)(sink.size() - prim_first);
     df.obs_first = (int32_t)f.obstacle_first; df.obs_count = f.n_obstacles;
     if (!clip && lsx < lex) {
         // Do layer 1's lines and U-turns all lie inside the geofence?  Their bounding box in the frame -- the lines' ends plus a U-turn's
@@ -442,7 +451,7 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
                 if (rotated) { const double tx = px - ccx, ty = py - ccy; px = (tx * rc - ty * rs) + ccx; py = (tx * rs + ty * rc) + ccy; }
                 const double m = margin + 5.684341886080802e-14 * (fabs(px) + fabs(py));      // (256 ulps of the coordinates)
                 for (int e = 0; e < 4; ++e)
-                    if (!(df.ex[e] * px + df.ey[e] * py + df.eo[e] >= m)) in = false;
+                    if (!(gex[e] * px + gey[e] * py + geo[e] >= m)) in = false;
             }
         df.span_inside = in ? 1 : 0;
     }

@@ -343,11 +343,13 @@ class _ArenaArrays:
             self._owner = owner
             self.__cuda_array_interface__ = {'shape': (n,), 'typestr': typestr, 'data': (ptr, False), 'version': 2, 'strides': None}
 
-    def __init__(self, ctx, n_points):
+    def __init__(self, ctx, n_points, ptrs=None):
         self.ctx = ctx
-        ptrs = [C.c_void_p() for _ in range(5)]
-        L.check(ctx.lib.fcpp_outputs_alloc(ctx.handle, int(n_points), 0, *[C.byref(q) for q in ptrs]))
-        self.ptrs = [q.value for q in ptrs]
+        if ptrs is None:
+            ptrs = [C.c_void_p() for _ in range(5)]
+            L.check(ctx.lib.fcpp_outputs_alloc(ctx.handle, int(n_points), 0, *[C.byref(q) for q in ptrs]))
+            ptrs = [q.value for q in ptrs]
+        self.ptrs = list(ptrs)          # (given: arrays the library has already allocated -- fcpp_batch_plan -- which this object now owns)
 
     def tensors(self, n_points):
         torch = _torch()
@@ -415,6 +417,45 @@ class Batch:
         L.check(self.lib.fcpp_batch_info(self.handle, None, C.byref(tot)))
         self.total_points = tot.value
         self._last_mode = 1
+
+    @classmethod
+    def plan(cls, specs, vehicle, options=None, device=None):
+        """The reference's plan call for a whole batch in ONE library call (fcpp_batch_plan: plan_complete_coverage, MLP:387-465, sets a new
+        field up and generates its path): batch creation, its output arrays (from the context's arena when it has one) and one step, with
+        no Python between them.  -> (Batch, BatchResult), asynchronous like run(); the buffers of the result serve further run() calls."""
+        torch = _torch()
+        self = cls.__new__(cls)
+        self.ctx = get_context(device)
+        self.lib = self.ctx.lib
+        self.vehicle = vehicle
+        self.options = options or make_options()
+        self.n_fields = len(specs)
+        arr, polys, _keep = pack_fields(specs)
+        self.pack_ms = 0.0
+        self._info = None
+        self._token = object()
+        self._last_mode = 1
+        dev = torch.device('cuda', self.ctx.device)
+        stats = torch.empty((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
+        self.ctx.bind_stream()
+        h = C.c_void_p()
+        ptrs = [C.c_void_p() for _ in range(5)]
+        tot = C.c_int64()
+        L.check(self.lib.fcpp_batch_plan(self.ctx.handle, C.byref(self.vehicle), C.byref(self.options), self.n_fields, arr, C.byref(polys),
+                                         _ptr(stats), C.byref(h), *[C.byref(q) for q in ptrs], C.byref(tot)))
+        self.handle = h
+        self.total_points = n = tot.value
+        owner = _ArenaArrays(self.ctx, n, [q.value or 0 for q in ptrs])
+        if n > 0:
+            x, y, kappa, v, fs = owner.tensors(n)
+        else:
+            x, y, kappa, v = (torch.empty(0, dtype=torch.float64, device=dev) for _ in range(4))
+            fs = torch.empty(0, dtype=torch.int32, device=dev)
+            x._fcpp_owner = owner
+        lane, pitch = self.ctx.arena()
+        self.layout = {'layout': 'arena' if (n > 0 and pitch and owner.ptrs[1] - owner.ptrs[0] == pitch) else 'plain', 'one_call': True}
+        bufs = self._trusted((x, y, kappa, v, fs, stats))
+        return self, BatchResult(self, *bufs)
 
     @property
     def info(self):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fcpp_abi_version() == 4
+    assert lib.fcpp_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

@@ -244,3 +244,48 @@ def test_chunk_lists_expanded_on_the_device_equal_the_hosts(opt):
     for name in ('x', 'y', 'kappa', 'v', 'flagseg', 'stats_raw'):
         assert torch.equal(getattr(rd, name), getattr(rh, name)), name
     bd.close(); bh.close()
+
+
+def test_one_call_plan_equals_create_alloc_run():
+    """Batch.plan (fcpp_batch_plan: creation, output arrays and one step in ONE library call) = Batch() + alloc() + run(), bit for bit; with
+    the arrays from the context's output arena and from an allocation of their own; the batch serves further steps on the same arrays."""
+    import torch
+    rng = np.random.default_rng(21)
+    LH = rng.uniform(100.0, 1000.0, size=(1500, 2))
+    LH[7] = (15.0, 200.0)                                   # a field that raises (MLP:597-598): zero points, zero statistics
+    table = E.FieldTable.from_rectangles(LH)
+    veh = E.make_vehicle()
+
+    def bits(t):
+        return t.view(torch.int64) if t.dtype == torch.float64 else t
+
+    for opt in (E.make_options(), E.make_options(1, 0.0), E.make_options(1, 0.5)):
+        ref_b = E.Batch(table, veh, opt)
+        ref = ref_b.run()
+        torch.cuda.synchronize()
+        want = [t.clone() for t in (ref.x, ref.y, ref.kappa, ref.v, ref.flagseg, ref.stats_raw)]
+        ref_b.close()
+        saved = E._contexts.get(0)
+        for arena in (False, True):
+            if arena:                                       # a context of its own with a small arena (the shared one stays as it is)
+                E._contexts[0] = E.Context(0)
+                E._contexts[0].reserve_outputs(lane_gib=0.25, pitch_gib=0.25)
+            try:
+                b, r = E.Batch.plan(table, veh, opt)
+                fits = 8 * want[0].numel() <= (1 << 28)           # (arrays beyond a lane get an allocation of their own)
+                assert b.layout['layout'] == ('arena' if arena and fits else 'plain') and b.total_points == want[0].numel()
+                torch.cuda.synchronize()
+                for got, w in zip((r.x, r.y, r.kappa, r.v, r.flagseg, r.stats_raw), want):
+                    assert torch.equal(bits(got), bits(w))
+                r.x.zero_()
+                r2 = b.run((r.x, r.y, r.kappa, r.v, r.flagseg, r.stats_raw))
+                torch.cuda.synchronize()
+                assert torch.equal(bits(r2.x), bits(want[0])) and torch.equal(r2.stats_raw, want[5])
+                assert b.info[7].status == E.L.EINVAL and b.info[8].n_main > 0
+                b.close()
+                del r, r2
+            finally:
+                if arena:
+                    del E._contexts[0]
+                    if saved is not None:
+                        E._contexts[0] = saved

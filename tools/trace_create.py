@@ -28,21 +28,28 @@ stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
 rows = []
 batch = None
+one_call = os.environ.get('FCPP_ONE_CALL', '1') != '0'
+one_call = os.environ.get('FCPP_ONE_CALL', '1') != '0'
 for r in range(reps):
     if batch is not None:
         batch.close()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    batch = E.Batch(table, veh, opt)
-    t1 = time.perf_counter()
-    bufs = batch.alloc()
-    t2 = time.perf_counter()
-    batch.run(bufs, mode=1)
-    t3 = time.perf_counter()
+    if one_call:
+        batch, res = E.Batch.plan(table, veh, opt)
+        t1 = t2 = t3 = time.perf_counter()
+    else:
+        batch = E.Batch(table, veh, opt)
+        t1 = time.perf_counter()
+        bufs = batch.alloc()
+        t2 = time.perf_counter()
+        batch.run(bufs, mode=1)
+        t3 = time.perf_counter()
     torch.cuda.synchronize()
     t4 = time.perf_counter()
+    res = bufs = None
     rows.append([(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t4 - t0) * 1e3])
 a = np.array(rows[1:])
 med = np.median(a, axis=0)
-print("%s: median ms: create %.4f alloc %.4f run_enqueue %.4f sync %.4f total %.4f" % ((what,) + tuple(med)))
+print(("one call " if one_call else "three calls ") + "%s: median ms: create %.4f alloc %.4f run_enqueue %.4f sync %.4f total %.4f" % ((what,) + tuple(med)))
 print("setup_times", batch.setup_times(), 'points', batch.total_points)
