@@ -1,6 +1,7 @@
 // fcpp_devplan.hip -- batch setup on the device, see fcpp_devplan.h.  gfx950 only.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "fcpp_devplan.h"
@@ -58,6 +59,404 @@ __global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, co
     if (count_only) return;
     counts[(int64_t)PC_PRIMS * n + i] = ftmp[i].prim_count;
     if (sink.n > pc.max_prims) atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), (unsigned long long)gen);
+}
+
+// ---- k_plan_fields16: the same plan, SIXTEEN lanes per field (round 5).  plan_field_t is a chain of some 5000 dependent instructions
+// per field -- four corner angles, four mitre directions, an inset per headland loop, eight primitives per loop -- and one thread per
+// field walks it alone (35 us for any batch up to 64 x 1024 fields: 64 wavefronts on 1024 SIMDs).  Here a field is a ROW of sixteen
+// lanes = four quads: lane i of a quad owns vertex / edge / side i of the quadrilateral, quad l the headland loop l (four loops at a
+// time), neighbours come by lane moves inside the quad.  Every value is computed by the same float64 operations in the same order as in
+// plan_field_t (sums over the four vertices run 0, 1, 2, 3 on gathered values): the records are equal byte for byte to the host's
+// (tests/test_gpu_devplan.py), and FCPP_PLAN_SERIAL=1 keeps the one-thread kernel as the A/B.
+namespace p16 {
+__device__ __forceinline__ double qget(double v, int k) { return __shfl(v, (int)((threadIdx.x & ~3u) | (unsigned)k)); }          // lane k of this lane's quad
+__device__ __forceinline__ int qgeti(int v, int k) { return __shfl(v, (int)((threadIdx.x & ~3u) | (unsigned)k)); }
+__device__ __forceinline__ double rget(double v, int k) { return __shfl(v, (int)((threadIdx.x & ~15u) | (unsigned)k)); }         // lane k of this lane's row
+__device__ __forceinline__ int rgeti(int v, int k) { return __shfl(v, (int)((threadIdx.x & ~15u) | (unsigned)k)); }
+__device__ __forceinline__ unsigned qballot(bool p) { return (unsigned)((__ballot(p) >> (threadIdx.x & 60u)) & 0xFull); }     // this quad's four bits
+__device__ __forceinline__ unsigned rballot(bool p) { return (unsigned)((__ballot(p) >> (threadIdx.x & 48u)) & 0xFFFFull); }  // this row's sixteen bits
+// s = 0; s += v[0]; ... s += v[3] over the quad's four values, as the host's loops add them
+__device__ __forceinline__ double qsum_seq(double v) { double s = 0.0; s += qget(v, 0); s += qget(v, 1); s += qget(v, 2); s += qget(v, 3); return s; }
+__device__ __forceinline__ double qmin_seq(double v) { double m = qget(v, 0); for (int k = 1; k < 4; ++k) m = hmin(m, qget(v, k)); return m; }
+__device__ __forceinline__ double qmax_seq(double v) { double m = qget(v, 0); for (int k = 1; k < 4; ++k) m = hmax(m, qget(v, k)); return m; }
+// area_centroid of the quad's polygon (px, py = this lane's vertex)
+__device__ __forceinline__ double area_centroid_q(double px, double py, int i, double &cx, double &cy)
+{
+    const double nx = qget(px, (i + 1) & 3), ny = qget(py, (i + 1) & 3);
+    const double cr = px * ny - nx * py;
+    double a = qsum_seq(cr);
+    const double sx = qsum_seq((px + nx) * cr), sy = qsum_seq((py + ny) * cr);
+    a *= 0.5;
+    if (fabs(a) < 1e-300) { cx = qget(px, 0); cy = qget(py, 0); return 0.0; }
+    cx = sx / (6.0 * a); cy = sy / (6.0 * a);
+    return a;
+}
+}  // namespace p16
+
+__global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, const fcpp_field *__restrict__ fin, fcpp_field_info *__restrict__ info,
+                                                      DevField *__restrict__ ftmp, DevPrim *__restrict__ ptmp, int64_t *__restrict__ counts,
+                                                      int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles, int64_t gen)
+{
+    using namespace p16;
+    const int lane = threadIdx.x, l16 = lane & 15, i = lane & 3, lp = l16 >> 2;
+    const int64_t field = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    if (field >= n) return;
+    const fcpp_field f = fin[field];
+    if (check_obstacles && l16 == 0 && (f.n_obstacles < 0 || f.obstacle_first < 0 || (f.n_obstacles > 0 && f.obstacle_first + f.n_obstacles > n_polys)))
+        atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_BAD_OBSTACLES), (unsigned long long)gen);
+    const fcpp_vehicle &veh = pc.veh;
+    const fcpp_options &opt = pc.opt;
+    const double W = pc.W, R = pc.R, ds = pc.ds;
+    const bool cloth = pc.cloth != 0;
+    // The two records are written where they go, by the row's lane 0, as plan_field_t writes them through its references: zeroed first
+    // (all sixteen lanes, a few words each), then member by member in the function's order -- a field that raises keeps what had been
+    // written before it did.  (Held in registers until the end they were 130 of them per lane: the kernel ran out, 50 us instead of 35.)
+    fcpp_field_info &in = info[field];
+    DevField &df = ftmp[field];
+    {
+        static_assert(sizeof(fcpp_field_info) % 8 == 0 && sizeof(DevField) % 8 == 0, "zeroed as 8-byte words");
+        unsigned long long *zi = reinterpret_cast<unsigned long long *>(&in), *zd = reinterpret_cast<unsigned long long *>(&df);
+        for (int w = l16; w < (int)(sizeof(fcpp_field_info) / 8); w += 16) zi[w] = 0ull;
+        for (int w = l16; w < (int)(sizeof(DevField) / 8); w += 16) zd[w] = 0ull;
+    }
+    const bool w0 = l16 == 0;          // the lane that writes the records
+    DevPrim *const pbase = ptmp + field * pc.max_prims;
+    // the function's exit
+    auto finish = [&](int64_t npts, int32_t prim_count, int32_t n_pushed) {
+        if (w0) {
+            counts[(int64_t)PC_POINTS * n + field] = npts;
+            counts[(int64_t)PC_PRIMS * n + field] = prim_count;
+            if (n_pushed > pc.max_prims) atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_FALLBACK), (unsigned long long)gen);
+        }
+    };
+#define P16_FAIL(code) do { if (w0) { in.status = (code); in.n_main = in.n_head = 0; in.n_reverse[0] = in.n_reverse[1] = in.n_reverse[2] = in.n_reverse[3] = 0; \
+                                      df.n_main = df.n_total = 0; df.gen_main = 0; df.prim_first = 0; df.prim_count = 0; } finish(0, 0, 0); return; } while (0)
+    // this lane's vertex i and its neighbours
+    const double qx = i == 0 ? f.vx[0] : (i == 1 ? f.vx[1] : (i == 2 ? f.vx[2] : f.vx[3]));
+    const double qy = i == 0 ? f.vy[0] : (i == 1 ? f.vy[1] : (i == 2 ? f.vy[2] : f.vy[3]));
+    const int in1 = (i + 1) & 3, ip1 = (i + 3) & 3, io = (i + 2) & 3;
+    const double xn = qget(qx, in1), yn = qget(qy, in1), xp = qget(qx, ip1), yp = qget(qy, ip1), xo = qget(qx, io), yo = qget(qy, io);
+    {
+        const bool fin_i = isfinite(qx) && isfinite(qy);
+        // is_convex: cr_i over (i, j = i + 1, k = i + 2)
+        const double cr = (xn - qx) * (yo - yn) - (yn - qy) * (xo - xn);
+        const int pos = __popc(qballot(cr > 0)), neg = __popc(qballot(cr < 0));
+        const bool convex = (pos == 0 || neg == 0) && (pos + neg) > 0;
+        if (qballot(fin_i) != 0xFu || !convex) P16_FAIL(FCPP_EUNSUPPORTED);
+    }
+    // ---- __init__ (MLP:109-135, 137-163, 310, 322-343)
+    const double bminx = qmin_seq(qx), bmaxx = qmax_seq(qx), bminy = qmin_seq(qy), bmaxy = qmax_seq(qy);
+    const double L = f.from_vertices ? (bmaxx - bminx) : f.vx[1];
+    const double H = f.from_vertices ? (bmaxy - bminy) : f.vy[2];
+    if (w0) { in.field_length = L; in.field_width = H; }
+    double cang;
+    {   // corner_angle(q, i)
+        const double v1x = xp - qx, v1y = yp - qy, v2x = xn - qx, v2y = yn - qy;
+        double c = (v1x * v2x + v1y * v2y) / (sqrt(v1x * v1x + v1y * v1y) * sqrt(v2x * v2x + v2y * v2y));
+        c = hmin(1.0, hmax(-1.0, c));
+        cang = fc_acos(c) * (180.0 / kPi);
+    }
+    const double cang0 = qget(cang, 0), cang1 = qget(cang, 1), cang2 = qget(cang, 2), cang3 = qget(cang, 3);
+    if (w0) { in.corner_angles[0] = cang0; in.corner_angles[1] = cang1; in.corner_angles[2] = cang2; in.corner_angles[3] = cang3; }
+    const bool all90 = qballot(fabs(cang - 90) < 1.0) == 0xFu;
+    bool is_par;
+    {   // is_parallelogram: edge k against edge k + 2, k = 0, 1 (this lane: its own edge against the opposite one)
+        const double ex = xn - qx, ey = yn - qy, ox = xp - xo, oy = yp - yo;
+        const double cross = fabs(ex * oy - ey * ox);
+        const double na = sqrt(ex * ex + ey * ey), nb = sqrt(ox * ox + oy * oy);
+        const bool ok = cross < 0.01 * (na * nb);
+        is_par = (qballot(ok) & 3u) == 3u;
+    }
+    if (w0) { in.shape = all90 ? 0 : (is_par ? 1 : 2); }
+    const double hw = R;
+    if (w0) { in.headland_width = hw; }
+    const bool has_start = f.has_start && (0 <= f.start_x && f.start_x <= L && 0 <= f.start_y && f.start_y <= H);
+    const bool has_end = f.has_end && (0 <= f.end_x && f.end_x <= L && 0 <= f.end_y && f.end_y <= H);
+    if (w0) { in.start_kept = has_start; in.end_kept = has_end; }
+    // ---- start corner (MLP:345-385)
+    int sci = 0;
+    if (has_start) {
+        const double cxs = (i == 0 || i == 3) ? hw / 2 : L - hw / 2, cys = i < 2 ? hw / 2 : H - hw / 2;
+        const double dx = cxs - f.start_x, dy = cys - f.start_y;
+        const double d = sqrt(dx * dx + dy * dy);
+        double best = 0;
+        for (int k = 0; k < 4; ++k) { const double dk = qget(d, k); if (k == 0 || dk < best) { best = dk; sci = k; } }
+    }
+    if (w0) { in.start_corner = sci; }
+    // ---- layer 1 frame (MLP:591-611, 670-718): mitre_of(q), inset by hw
+    double acx, acy;
+    const double sgn = area_centroid_q(qx, qy, i, acx, acy) > 0 ? 1.0 : -1.0;
+    double m_sx, m_sy, m_den;
+    {
+        const double ex = xn - qx, ey = yn - qy;
+        const double ln = fc_hypot(ex, ey);
+        const double nx = -ey / ln * sgn, ny = ex / ln * sgn;
+        const double nxp = qget(nx, ip1), nyp = qget(ny, ip1);
+        m_den = 1.0 + (nxp * nx + nyp * ny);
+        m_sx = nxp + nx; m_sy = nyp + ny;
+    }
+    // inset(q, mit, d): this lane's vertex; false = empty
+    auto inset_q = [&](double d, double &ox, double &oy) -> bool {
+        ox = qx + d * m_sx / m_den;
+        oy = qy + d * m_sy / m_den;
+        const double ex = xn - qx, ey = yn - qy;
+        const double oxn = qget(ox, in1), oyn = qget(oy, in1);
+        return qballot((oxn - ox) * ex + (oyn - oy) * ey <= 0) == 0u;
+    };
+    double mqx, mqy;
+    {
+        const bool ok = inset_q(hw, mqx, mqy);
+        double cx, cy;
+        const double ar = fabs(area_centroid_q(mqx, mqy, i, cx, cy));
+        if (!ok || ar < 1.0) P16_FAIL(FCPP_EINVAL);
+    }
+    const double e0x = f.vx[1] - f.vx[0], e0y = f.vy[1] - f.vy[0];
+    const double rot = (e0x == 0.0 && e0y == 0.0) ? 0.0 : atan2_fd(e0y, e0x);
+    if (w0) { in.rotation_angle = rot; }
+    const bool rotated = fabs(rot) > 0.01;
+    if (w0) { in.rotated = rotated; }
+    double rc, rs;
+    fc_sincos(rot, rs, rc);
+    double ccx = 0, ccy = 0, sx = f.start_x, sy = f.start_y;
+    double rqx = mqx, rqy = mqy;
+    if (rotated) {
+        area_centroid_q(mqx, mqy, i, ccx, ccy);
+        rotate_point(mqx, mqy, rc, -rs, ccx, ccy, rqx, rqy);
+        if (has_start) rotate_point(sx, sy, rc, -rs, ccx, ccy, sx, sy);
+    }
+    const double min_x = qmin_seq(rqx), max_x = qmax_seq(rqx), min_y = qmin_seq(rqy), max_y = qmax_seq(rqy);
+    int reverse_order = 0, start_from_right = 0;   // MLP:631-668
+    if (has_start) {
+        if (sy > (min_y + max_y) / 2) reverse_order = 1;
+        if (sx > (min_x + max_x) / 2) start_from_right = 1;
+    }
+    if (w0) { in.reverse_order = reverse_order; in.start_from_right = start_from_right; }
+    // ---- layer 1 sizes (MLP:736-739)
+    const double lsx = min_x + R, lex = max_x - R;
+    const double Pd = (max_y - min_y) / W;
+    const int64_t P = Pd < (double)INT32_MAX ? (int64_t)Pd + 1 : (int64_t)INT32_MAX + 1;
+    const int64_t n_line = ds > 0 ? n_for_length(fabs(lex - lsx), ds) : 2;
+    const int64_t n_turn = ds > 0 ? n_for_length(pc.len_uturn, ds) : 20;
+    if (P >= ((int64_t)1 << (32 - FCPP_INDEX_SHIFT)) || n_line + n_turn > INT32_MAX - 2 * TILE_POINTS) P16_FAIL(FCPP_ESIZE);
+    if (w0) { in.n_swaths = (int32_t)P; }
+    const int64_t n_main = P * n_line + (P - 1) * n_turn;
+    if (w0) { df.gen_main = n_main; }
+    if (w0) { df.prim_first = 0; }
+    if (w0) { in.n_main = n_main; }
+    if (w0) { df.n_main = n_main; }
+    if (w0) { df.lsx = lsx; df.lex = lex; df.line_step = lin_step(lsx, lex, n_line); }
+    if (w0) { df.min_x = min_x; df.max_x = max_x; df.min_y = min_y; df.W = W; df.R = R; }
+    if (w0) { df.turn_end = pc.turn_end_pi; }
+    if (w0) { df.turn_step = lin_step(0.0, pc.turn_end_pi, n_turn); }
+    if (w0) { df.turn_Re = pc.Re_pi; }
+    if (w0) { df.rot_cos = rc; df.rot_sin = rs; df.rot_cx = ccx; df.rot_cy = ccy; }
+    if (w0) { df.v_work = veh.max_work_speed_kmh; df.v_turn = veh.headland_turn_speed_kmh; }
+    if (w0) { df.P = (int32_t)P; df.n_line = (int32_t)n_line; df.n_turn = (int32_t)n_turn; }
+    if (w0) { df.reverse_order = reverse_order; df.start_from_right = start_from_right; df.rotated = rotated; }
+    if (w0) { df.turn_model = opt.turn_model; }
+    // geofence half-planes: edge i
+    double gex, gey, geo;
+    {
+        const double ex = xn - qx, ey = yn - qy;
+        const double ln = sqrt(ex * ex + ey * ey);
+        gex = -ey / ln * sgn; gey = ex / ln * sgn;
+        geo = -(gex * qx + gey * qy);
+    }
+    const double gex0 = qget(gex, 0), gex1 = qget(gex, 1), gex2 = qget(gex, 2), gex3 = qget(gex, 3);
+    const double gey0 = qget(gey, 0), gey1 = qget(gey, 1), gey2 = qget(gey, 2), gey3 = qget(gey, 3);
+    const double geo0 = qget(geo, 0), geo1 = qget(geo, 1), geo2 = qget(geo, 2), geo3 = qget(geo, 3);
+    if (w0) { df.ex[0] = gex0; df.ex[1] = gex1; df.ex[2] = gex2; df.ex[3] = gex3; }
+    if (w0) { df.ey[0] = gey0; df.ey[1] = gey1; df.ey[2] = gey2; df.ey[3] = gey3; }
+    if (w0) { df.eo[0] = geo0; df.eo[1] = geo1; df.eo[2] = geo2; df.eo[3] = geo3; }
+
+    // ---- layer 2 (MLP:898-1084): quad lp = loop l0 + lp, lane i = side i of the loop (its straight, then the turn at its end)
+    const int num_loops = (int)ceil(hw / W);
+    if (w0) { in.n_loops = num_loops; }
+    int64_t pos = n_main;
+    int32_t prim_pos = 0;
+    double first_head0 = 0, first_head1 = 0, last_head0 = 0, last_head1 = 0;
+    int32_t nrev0 = 0, nrev1 = 0, nrev2 = 0, nrev3 = 0;
+    const int64_t nt = pc.nt_corner;
+    for (int l0 = 0; l0 < num_loops; l0 += 4) {
+        const int loop = l0 + lp;
+        const bool act = loop < num_loops;
+        const double offset = W / 2 + loop * W;
+        double cx, cy;
+        bool inset_ok = inset_q(offset, cx, cy);
+        {
+            double tx, ty;
+            const double ar = fabs(area_centroid_q(cx, cy, i, tx, ty));
+            if (ar < 1.0) inset_ok = false;
+        }
+        if (opt.ring_order == FCPP_RING_REVERSED) {      // ring lists 0, 3, 2, 1
+            const int src = i == 1 ? 3 : (i == 3 ? 1 : i);
+            const double tx = qget(cx, src), ty = qget(cy, src);
+            cx = tx; cy = ty;
+        }
+        const int cur = (sci + i) & 3, nxt = (sci + i + 1) & 3;
+        const double ccurx = qget(cx, cur), ccury = qget(cy, cur), cnxx = qget(cx, nxt), cnxy = qget(cy, nxt);
+        const uint32_t lpw = FCPP_FLAG_HEADLAND | ((uint32_t)(loop * 8) << FCPP_INDEX_SHIFT);
+        int64_t ns = 20;
+        if (ds > 0) ns = n_for_length(fc_hypot(cnxx - ccurx, cnxy - ccury), ds);
+        // failures, in the order plan_field_t meets them: the loop's inset, then side by side the counts, the gap decision
+        int fcode = 0;                                       // 1: FCPP_EHEADLAND, 2: FCPP_EUNSUPPORTED
+        if (act) {
+            if (!inset_ok) fcode = 1;
+            else if (ns > INT32_MAX || nt > INT32_MAX) fcode = 1;
+        }
+        // the turn at this side's end and its reverse fill
+        const double ang_nxt = nxt == 0 ? cang0 : (nxt == 1 ? cang1 : (nxt == 2 ? cang2 : cang3));
+        const bool has_turn = act && i < 3;
+        const bool want_rev = has_turn && loop == 0 && ang_nxt >= 60;       // MLP:1043
+        if (act && fcode == 0 && want_rev && pc.gap_decision < 0) fcode = 2;
+        const bool add_rev = want_rev && pc.gap_decision > 0;
+        double e1x = 0, e1y = 0, e2x = 0, e2y = 0;
+        if (has_turn) {
+            if (!cloth) {
+                corner_arc_point(nxt, cnxx, cnxy, R, pc.arc_c1, pc.arc_s1, e1x, e1y);
+                corner_arc_point(nxt, cnxx, cnxy, R, pc.arc_c2, pc.arc_s2, e2x, e2y);
+            } else {
+                const int qd = corner_quadrant(nxt);
+                cac_world_from_unit(pc.cac_u1x, pc.cac_u1y, cnxx, cnxy, qd, pc.Re_half, e1x, e1y);
+                cac_world_from_unit(pc.cac_u2x, pc.cac_u2y, cnxx, cnxy, qd, pc.Re_half, e2x, e2y);
+            }
+        }
+        double rdx = -1.0, rdy = 0.0, rlen = 0.0;
+        int64_t nr = 0;
+        if (add_rev) {
+            const double tx = e1x - e2x, ty = e1y - e2y;
+            const double nrm = sqrt(tx * tx + ty * ty);
+            if (nrm > 1e-6) { rdx = -tx / nrm; rdy = -ty / nrm; }
+            rlen = distance_to_boundary(e1x, e1y, rdx, rdy, L, H, R);
+            if (ds > 0) nr = n_for_length(rlen, ds);
+            else { nr = (int64_t)(rlen / 0.5); if (nr < 10) nr = 10; }
+        }
+        // the first failure in path order decides (rows of a chunk are loops in order, lanes of a quad sides in order); within a side the
+        // order is inset (whole loop: its lane 0 first), counts, gap -- one code per lane, the lowest lane wins
+        {
+            const unsigned bad = rballot(fcode != 0);
+            if (bad != 0u) {
+                const int first = __builtin_ctz(bad);
+                // (a loop whose inset is bad: all four lanes carry code 1, the quad's lane 0 is the first of them)
+                const int code = rgeti(fcode, first);
+                P16_FAIL(code == 2 ? FCPP_EUNSUPPORTED : FCPP_EHEADLAND);
+            }
+        }
+        // points and primitives of this lane's side, in path order: [ start point (side 0) ] straight [ turn [ reverse fill ] ]
+        const int64_t my_pts = act ? ((i == 0 ? 1 : 0) + ns + (has_turn ? nt : 0) + (add_rev ? nr : 0)) : 0;
+        const int32_t my_prims = act ? ((i == 0 ? 1 : 0) + 1 + (has_turn ? 1 : 0) + (add_rev ? 1 : 0)) : 0;
+        // exclusive prefix over the row's lanes in path order (four steps of a scan inside the row), and the chunk's totals
+        int64_t pts_incl = my_pts;
+        int32_t prims_incl = my_prims;
+        for (int d = 1; d < 16; d <<= 1) {
+            const int src = (lane & ~15) | ((l16 - d) & 15);
+            const int64_t pv = ((int64_t)__shfl((int)(pts_incl >> 32), src) << 32) | (uint32_t)__shfl((int)(pts_incl & 0xffffffff), src);
+            const int32_t qv = __shfl(prims_incl, src);
+            if (l16 >= d) { pts_incl += pv; prims_incl += qv; }
+        }
+        const int64_t pts_before = pts_incl - my_pts;
+        const int32_t prims_before = prims_incl - my_prims;
+        const int64_t pts_chunk = ((int64_t)rgeti((int)(pts_incl >> 32), 15) << 32) | (uint32_t)rgeti((int)(pts_incl & 0xffffffff), 15);
+        const int32_t prims_chunk = rgeti(prims_incl, 15);
+        const double sxp = qget(cx, sci), syp = qget(cy, sci);          // the loop's start point (a lane move: outside the branches of single lanes)
+        if (act) {
+            int64_t at = pos + pts_before;
+            int32_t pat = prim_pos + prims_before;
+            auto put = [&](DevPrim &p) { p.start = at; at += p.n; flag_degenerate(p); if (pat < pc.max_prims) pbase[pat] = p; ++pat; };
+            DevPrim p;
+            if (i == 0) {
+                memset(&p, 0, sizeof(p));
+                p.kind = PRIM_POINT; p.n = 1; p.v_nom = veh.max_headland_speed_kmh;
+                p.fs = FCPP_KIND_HEAD_START | lpw | ((uint32_t)sci << FCPP_INDEX_SHIFT);
+                p.a[0] = sxp; p.a[1] = syp;
+                put(p);
+            }
+            memset(&p, 0, sizeof(p));
+            p.kind = PRIM_LINSPACE; p.n = (int32_t)ns; p.v_nom = veh.max_headland_speed_kmh;
+            p.fs = FCPP_KIND_HEAD_STRAIGHT | lpw | ((uint32_t)cur << FCPP_INDEX_SHIFT);
+            p.a[0] = ccurx; p.a[1] = ccury; p.a[2] = cnxx; p.a[3] = cnxy;
+            p.a[4] = lin_step(ccurx, cnxx, ns); p.a[5] = lin_step(ccury, cnxy, ns);
+            put(p);
+            if (has_turn) {
+                memset(&p, 0, sizeof(p));
+                p.n = (int32_t)nt; p.v_nom = veh.headland_turn_speed_kmh;
+                p.fs = FCPP_KIND_CORNER | lpw | ((uint32_t)nxt << FCPP_INDEX_SHIFT);
+                if (!cloth) {
+                    p.kind = PRIM_ARC; p.form = nxt;
+                    p.a[0] = cnxx; p.a[1] = cnxy; p.a[2] = R; p.a[3] = kHalfPi;
+                    p.a[4] = pc.arc_step;
+                } else {
+                    const int qd = corner_quadrant(nxt);
+                    p.kind = PRIM_CAC; p.form = qd;
+                    p.a[0] = cnxx; p.a[1] = cnxy; p.a[2] = qd * kHalfPi; p.a[3] = -kHalfPi;
+                    p.a[4] = pc.Re_half; p.a[5] = pc.cac_step; p.a[6] = pc.half_T;
+                }
+                put(p);
+                if (add_rev) {
+                    memset(&p, 0, sizeof(p));
+                    p.kind = PRIM_RAY; p.n = (int32_t)nr; p.v_nom = 2.5;   // MLP:1080
+                    p.fs = FCPP_KIND_REVERSE | lpw | ((uint32_t)nxt << FCPP_INDEX_SHIFT);
+                    p.a[0] = e1x; p.a[1] = e1y; p.a[2] = rdx; p.a[3] = rdy; p.a[4] = rlen;
+                    p.a[5] = lin_step(0.0, rlen, nr);
+                    put(p);
+                }
+            }
+        }
+        // what the row's lane 0 needs of this chunk: the reverse-fill counts (loop 0), the first and the last point of the headland
+#ifdef FCPP_DBG16
+        if (field == 12 && l16 < 4) printf("lane %d i %d loop %d nxt %d ang %.3f add_rev %d nr %d act %d\n", l16, i, loop, nxt, ang_nxt, (int)add_rev, (int)nr, (int)act);
+#endif
+        if (l0 == 0) {
+            const int my_nr = (add_rev && loop == 0) ? (int)nr : 0;
+            // the corner c is turned at the end of side j = (c - sci - 1) & 3 of loop 0 (the row's lane j); side 3 has no turn
+            const int j0 = (3 - sci) & 3, j1 = (4 - sci) & 3, j2 = (5 - sci) & 3, j3 = (6 - sci) & 3;
+            const int v0 = rgeti(my_nr, j0), v1 = rgeti(my_nr, j1), v2 = rgeti(my_nr, j2), v3 = rgeti(my_nr, j3);
+            nrev0 = j0 < 3 ? v0 : 0; nrev1 = j1 < 3 ? v1 : 0; nrev2 = j2 < 3 ? v2 : 0; nrev3 = j3 < 3 ? v3 : 0;
+            first_head0 = rget(cx, sci); first_head1 = rget(cy, sci);          // loop 0's quad is the row's first
+        }
+        {
+            const int last_l = (num_loops - 1) - l0;         // the last loop's quad in this chunk, if it is here
+            if (last_l >= 0 && last_l < 4) { last_head0 = rget(cnxx, last_l * 4 + 3); last_head1 = rget(cnxy, last_l * 4 + 3); }
+        }
+        pos += pts_chunk;
+        prim_pos += prims_chunk;
+    }
+    if (w0) { in.n_reverse[0] = nrev0; in.n_reverse[1] = nrev1; in.n_reverse[2] = nrev2; in.n_reverse[3] = nrev3; }
+#ifdef FCPP_DBG16
+    if (field == 12 && l16 < 4) printf("lane %d sci %d nrev %d %d %d %d\n", l16, sci, nrev0, nrev1, nrev2, nrev3);
+#endif
+    if (w0) { in.n_head = pos - n_main; }
+    if (w0 && has_start) {   // MLP:437-441
+        if (w0) { in.approach_from[0] = f.start_x; in.approach_from[1] = f.start_y; }
+        if (w0) { in.approach_to[0] = first_head0; in.approach_to[1] = first_head1; }
+    }
+    if (w0 && has_end) {     // MLP:443-447
+        if (w0) { in.departure_from[0] = last_head0; in.departure_from[1] = last_head1; }
+        if (w0) { in.departure_to[0] = f.end_x; in.departure_to[1] = f.end_y; }
+    }
+    if (w0) { df.n_total = pos; }
+    if (w0) { df.prim_count = prim_pos; }
+    if (w0) { df.obs_first = (int32_t)f.obstacle_first; df.obs_count = f.n_obstacles; }
+    if (lsx < lex) {
+        // layer 1's bounding box inside the geofence?  (plan_field_t: four corners x four edges; here corner i = this lane's, edges in order)
+        const double slack = cloth ? 1e-3 * R : 0.0;
+        const double ext = pc.uturn_dx + slack, hgt = pc.uturn_h + slack;
+        const double bx0 = lsx - ext, bx1 = lex + ext, by0 = min_y, by1 = min_y + (double)(P - 1) * W + hgt;
+        const double margin = 1e-7 - opt.geofence_tol;
+        // (corner order of the host's loops: cxi major, cyi minor -- any order gives the same conjunction)
+        double px = (i >> 1) ? bx1 : bx0, py = (i & 1) ? by1 : by0;
+        if (rotated) { const double tx = px - ccx, ty = py - ccy; px = (tx * rc - ty * rs) + ccx; py = (tx * rs + ty * rc) + ccy; }
+        const double m = margin + 5.684341886080802e-14 * (fabs(px) + fabs(py));
+        bool inb = true;
+        if (!(gex0 * px + gey0 * py + geo0 >= m)) inb = false;
+        if (!(gex1 * px + gey1 * py + geo1 >= m)) inb = false;
+        if (!(gex2 * px + gey2 * py + geo2 >= m)) inb = false;
+        if (!(gex3 * px + gey3 * py + geo3 >= m)) inb = false;
+        const bool all_in = qballot(inb) == 0xFu;
+        if (w0) df.span_inside = all_in ? 1 : 0;
+    }
+    finish(pos, prim_pos, prim_pos);
+#undef P16_FAIL
 }
 
 // a column's total to the host's copy; the flags (generation numbers, see PlanFlag) with the first column of the last scan
@@ -947,8 +1346,18 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
                          int64_t n_polys, int check_obstacles, int64_t *totals_host)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
-                       n_polys, check_obstacles, 0, tc.gen);
+    // (sixteen lanes per field; FCPP_PLAN_SERIAL=1 -- read once -- keeps the one-thread-per-field kernel: the A/B and the checker of the two)
+    // Sixteen lanes per field cut the LATENCY of a plan (23 instead of 35 us for 4096 fields) at more wavefronts (a field's row holds 217
+    // vector registers: two wavefronts per SIMD): up to 8192 fields -- one round of them -- it wins, beyond that the one-thread kernel's
+    // 64 fields per wavefront do (cfg5's 65 536 fields: 103 us against 170).
+    static const int plan_mode = getenv("FCPP_PLAN_SERIAL") ? 1 : (getenv("FCPP_PLAN_ROWS") ? 2 : 0);
+    const bool plan_serial = plan_mode == 1 || (plan_mode == 0 && n > 8192);
+    if (plan_serial)
+        hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                           n_polys, check_obstacles, 0, tc.gen);
+    else
+        hipLaunchKernelGGL(k_plan_fields16, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                           n_polys, check_obstacles, tc.gen);
     // small batches: the counting pass goes without the fields' point offsets, ONE scan follows it (span_counts); large ones: a scan of
     // points and primitives, the pass, a scan of its columns
     const bool one_scan = (n + 1023) / 1024 <= 8;
