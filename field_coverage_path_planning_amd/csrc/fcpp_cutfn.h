@@ -88,10 +88,18 @@ FCPP_HD bool cut_applies(const DevField &F, const CutConsts &cc, int64_t S)
     return F.n_turn == cc.nu && (double)cc.wave_factor * cc.two_a * fabs(F.line_step) >= cc.u_cap;
 }
 
-// last point of a primitive / its first point (the formulas of tiler_point_prim: the same values as a point-by-point evaluation)
+// first / last point of a primitive: the values tiler_point_prim gives for samples 0 and n - 1, kind by kind without its sample
+// arithmetic -- a straight's ends are in its record, a ray's last point is origin + length x direction (numpy.linspace ends on `stop`),
+// a turn's are the template's first / last sample through the quadrant formulas (only they go through tiler_point_prim)
 FCPP_HD void cut_prim_end(const DevPrim &q, const CutConsts &cc, bool last, double &x, double &y)
 {
-    tiler_point_prim(q, cc.tu, cc.tc, last ? (int)q.n - 1 : 0, x, y);
+    const bool turn = q.kind == PRIM_ARC || q.kind == PRIM_CAC || q.kind == PRIM_UTURN;
+    if (turn || (q.form & 8)) { tiler_point_prim(q, cc.tu, cc.tc, last ? (int)q.n - 1 : 0, x, y); return; }
+    x = q.a[0]; y = q.a[1];
+    if (last && q.n > 1) {
+        if (q.kind == PRIM_LINSPACE) { x = q.a[2]; y = q.a[3]; }
+        else if (q.kind == PRIM_RAY) { x = q.a[0] + q.a[4] * q.a[2]; y = q.a[1] + q.a[4] * q.a[3]; }
+    }
 }
 
 // One primitive's record from its own end points (fx, fy) / (ex, ey) (cut_prim_end) and the point before its first (px, py).  F: the field's
@@ -285,24 +293,23 @@ FCPP_HD int cut_fwd_halo(const DevField &F, const CutConsts &cc, const PV &pv, i
     }
 }
 
-// One tile of a candidate cut: outputs [s, s + c).  -> 0: it fits (Hb, Hf, inside set); 1: the stretch cannot be cut into wave tiles at all (a
-// halo beyond WAVE_HALO_MAX lanes: more tiles do not help); 2: the tile does not fit (too many lanes or primitives: more, smaller tiles may)
+// One tile of a candidate cut: outputs [s, s + c), e = s + c - 1; (kj, rj): the segment and offset of point s - 1 (unused when s == 0),
+// (ke, re): of point e (cut_locate).  -> 0: it fits (Hb, Hf, inside set); 1: the stretch cannot be cut into wave tiles at all (a halo beyond
+// WAVE_HALO_MAX lanes: more tiles do not help); 2: the tile does not fit (too many lanes or primitives: more, smaller tiles may)
 template <class PV>
-FCPP_HD int cut_tile_eval(const DevField &F, const CutConsts &cc, const PV &pv, int np, double cap, int64_t s, int64_t c, int &Hb, int &Hf, bool &in)
+FCPP_HD int cut_tile_eval_at(const DevField &F, const CutConsts &cc, const PV &pv, int np, double cap, int64_t s, int64_t c, int kj, int32_t rj, int ke, int32_t re,
+                             int &Hb, int &Hf, bool &in)
 {
     const int64_t n = F.n_total, e = s + c - 1;
-    int ka = 0, kb = 0, ko = 0, ke = 0;          // the segments of the tile's first point, last point, first output, last output
-    int32_t r = 0;
+    int ka = 0, kb = ke, ko = 0;                 // the segments of the tile's first point, last point, first output
     Hb = 0;
     if (s > 0) {
-        const int kj = cut_locate(F, pv, np, s - 1, r);
-        ko = r + 1 < cut_seg(F, cc, pv, kj).n ? kj : kj + 1;           // (the first output is the next point)
-        Hb = cut_back_halo(F, cc, pv, kj, r, cap, ka);
-    } else ko = cut_locate(F, pv, np, s, r);
+        ko = rj + 1 < cut_seg(F, cc, pv, kj).n ? kj : kj + 1;          // (the first output is the next point)
+        Hb = cut_back_halo(F, cc, pv, kj, rj, cap, ka);
+    } else ko = F.n_main > 0 ? -1 : 0;
     if (Hb < 0) return 1;
-    ke = cut_locate(F, pv, np, e, r);
-    Hf = 0; kb = ke;
-    if (e != n - 1) Hf = cut_fwd_halo(F, cc, pv, np, ke, r, cap, kb);
+    Hf = 0;
+    if (e != n - 1) Hf = cut_fwd_halo(F, cc, pv, np, ke, re, cap, kb);
     if (Hf < 0) return 1;
     if (Hb + c + Hf > CUT_WAVE_LANES) return 2;
     if (Hb == 0) ka = ko;
@@ -311,6 +318,14 @@ FCPP_HD int cut_tile_eval(const DevField &F, const CutConsts &cc, const PV &pv, 
     if (ko < 0) in = F.span_inside != 0;                               // outputs of layer 1: the last line (the span's test covers every line)
     for (int q = ko > 0 ? ko : 0; q <= ke; ++q) in = in && pv(q).inside != 0;
     return 0;
+}
+template <class PV>
+FCPP_HD int cut_tile_eval(const DevField &F, const CutConsts &cc, const PV &pv, int np, double cap, int64_t s, int64_t c, int &Hb, int &Hf, bool &in)
+{
+    int32_t rj = 0, re = 0;
+    const int kj = s > 0 ? cut_locate(F, pv, np, s - 1, rj) : 0;
+    const int ke = cut_locate(F, pv, np, s + c - 1, re);
+    return cut_tile_eval_at(F, cc, pv, np, cap, s, c, kj, rj, ke, re, Hb, Hf, in);
 }
 // the candidate cuts: T near-equal tiles, T = cut_first_T(G), + 1, ... up to CUT_TILES_MAX; tile t of T: outputs [a + cut_tile_start, + cut_tile_count)
 // (32-bit: a field of this cut has at most CUT_TILES_MAX x 128 general points)

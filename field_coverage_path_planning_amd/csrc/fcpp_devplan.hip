@@ -403,9 +403,6 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
             }
         }
         // what the row's lane 0 needs of this chunk: the reverse-fill counts (loop 0), the first and the last point of the headland
-#ifdef FCPP_DBG16
-        if (field == 12 && l16 < 4) printf("lane %d i %d loop %d nxt %d ang %.3f add_rev %d nr %d act %d\n", l16, i, loop, nxt, ang_nxt, (int)add_rev, (int)nr, (int)act);
-#endif
         if (l0 == 0) {
             const int my_nr = (add_rev && loop == 0) ? (int)nr : 0;
             // the corner c is turned at the end of side j = (c - sci - 1) & 3 of loop 0 (the row's lane j); side 3 has no turn
@@ -422,9 +419,6 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         prim_pos += prims_chunk;
     }
     if (w0) { in.n_reverse[0] = nrev0; in.n_reverse[1] = nrev1; in.n_reverse[2] = nrev2; in.n_reverse[3] = nrev3; }
-#ifdef FCPP_DBG16
-    if (field == 12 && l16 < 4) printf("lane %d sci %d nrev %d %d %d %d\n", l16, sci, nrev0, nrev1, nrev2, nrev3);
-#endif
     if (w0) { in.n_head = pos - n_main; }
     if (w0 && has_start) {   // MLP:437-441
         if (w0) { in.approach_from[0] = f.start_x; in.approach_from[1] = f.start_y; }
@@ -857,13 +851,29 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             const CutView pv{ L.cut };
             const double cap = tiler_halo_cap(tc.u_cap);
             const int32_t G32 = (int32_t)G;
+            const int32_t cut_start = lane < prim_count ? (int32_t)(q.start - n_main) : INT32_MAX;      // this lane's primitive's first point
             int nt = 0, Hb = 0, Hf = 0;
             int64_t s = 0, c = 0;
             bool in = false;
             if (prims_ok)
                 for (int32_t T = cut_first_T(G32); cut_T_possible(G32, T); ++T) {
                     int code = 0;
-                    if (lane < T) { s = a + cut_tile_start(G32, T, lane); c = cut_tile_count(G32, T, lane); code = cut_tile_eval(F, lc, pv, prim_count, cap, s, c, Hb, Hf, in); }
+                    if (lane < T) { s = a + cut_tile_start(G32, T, lane); c = cut_tile_count(G32, T, lane); }
+                    // the segments of the points s - 1 and s + c - 1 of every tile: the primitives' starts a lane each, a ballot per tile and point
+                    int kj = 0, ke = 0;
+                    int32_t rj = 0, re = 0;
+                    for (int t = 0; t < T; ++t) {
+                        const int64_t j_t = __shfl(s, t) - 1, e_t = __shfl(s + c - 1, t);
+                        const int32_t relj = (int32_t)(j_t - n_main), rele = (int32_t)(e_t - n_main);
+                        const int a_t = __popcll(__ballot(cut_start <= relj)) - 1, b_t = __popcll(__ballot(cut_start <= rele)) - 1;
+                        if (lane == t) { kj = a_t; ke = b_t; }
+                    }
+                    if (lane < T) {
+                        const int64_t Sl = ((int64_t)F.P - 1) * per, j = s - 1, e = s + c - 1;
+                        if (j < Sl) { kj = -2; rj = (int32_t)(j - (Sl - F.n_turn)); } else if (j < n_main) { kj = -1; rj = (int32_t)(j - Sl); } else rj = (int32_t)(j - n_main) - L.cut[kj < 0 ? 0 : kj].start_rel;
+                        if (e < Sl) { ke = -2; re = (int32_t)(e - (Sl - F.n_turn)); } else if (e < n_main) { ke = -1; re = (int32_t)(e - Sl); } else re = (int32_t)(e - n_main) - L.cut[ke < 0 ? 0 : ke].start_rel;
+                        code = cut_tile_eval_at(F, lc, pv, prim_count, cap, s, c, kj, rj, ke, re, Hb, Hf, in);
+                    }
                     const unsigned long long bad = __ballot(code != 0);
                     if (bad == 0ull) { nt = (int)T; break; }
                     if (__shfl(code, __builtin_ctzll(bad)) == 1) break;           // a halo too long: the general kernel's
@@ -1347,11 +1357,9 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
 {
     if (n <= 0) return 0;
     // (sixteen lanes per field; FCPP_PLAN_SERIAL=1 -- read once -- keeps the one-thread-per-field kernel: the A/B and the checker of the two)
-    // Sixteen lanes per field cut the LATENCY of a plan (23 instead of 35 us for 4096 fields) at more wavefronts (a field's row holds 217
-    // vector registers: two wavefronts per SIMD): up to 8192 fields -- one round of them -- it wins, beyond that the one-thread kernel's
-    // 64 fields per wavefront do (cfg5's 65 536 fields: 103 us against 170).
-    static const int plan_mode = getenv("FCPP_PLAN_SERIAL") ? 1 : (getenv("FCPP_PLAN_ROWS") ? 2 : 0);
-    const bool plan_serial = plan_mode == 1 || (plan_mode == 0 && n > 8192);
+    // Sixteen lanes per field cut the latency of a plan (23 instead of 35 us for 4096 fields) and, four fields per wavefront, its stores are
+    // denser (cfg5's 65 536 fields: 170 us against 230 for the one-thread kernel); FCPP_PLAN_SERIAL=1 keeps the latter (the A/B, the checker)
+    static const bool plan_serial = getenv("FCPP_PLAN_SERIAL") != nullptr;
     if (plan_serial)
         hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
                            n_polys, check_obstacles, 0, tc.gen);
