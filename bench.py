@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- validated path points/sec of the HIP hot path on MI355X.
 
-One "step" = one pass of the whole hot path (sample every path point, curvature, curvature clamp, forward/backward speed
-sweeps, a_lat / geofence / obstacle validation, per-field metrics) over one batch of synthetic fields whose descriptors are
-already resident in HBM: `value` / `ms_per_step` (the median of REPS repetitions of the K-step region; REPS_SHORT for steps that write
-less than 1 GB: see below).
+One "step" = one PLAN CALL of the reference for a whole batch: plan_complete_coverage (MLP:387-465) sets a NEW field up and generates its
+path in one call, and so does a step here (round 5) -- `engine.Batch.plan(table)` = fcpp_batch_plan: the batch's setup on the device, its
+output arrays, the whole hot path (sample every path point, curvature, curvature clamp, forward/backward speed sweeps, a_lat / geofence /
+obstacle validation, per-field metrics) -- and the stream drained; the field records (128 B per field) lie in pinned host memory and are
+read by the device where they lie.  `value` / `ms_per_step`: the median of REPS_SHORT regions of K such calls, each region bracketed by
+barrier + synchronize.
 
-The reference times the whole plan call (plan_complete_coverage, MLP:387-465: field setup + generation): `value_end_to_end` /
-`end_to_end` report that for a whole batch -- a FRESH batch created (fcpp_batch_create: host plan, tiler, one H2D copy), its output
-arrays allocated, one step run and the stream drained, in a warm context -- with `setup_ms` split into pack / host_plan / templates /
-tiler / image / h2d, for the headline and for every configuration.
+`value_step` / `ms_step` is what rounds 1-4 reported as `value`: the hot path re-run on a batch that is already set up (the kernels alone,
+inputs resident in HBM) -- the figure the kernels' roofline fractions refer to.  `end_to_end` (diagnostic) splits a plan call made through
+the three separate entries (create / alloc / run) into its parts, with `setup_ms` = pack / host_plan / templates / tiler / image / h2d.
 
 Headline (the workload BASELINE.json's metric names): a batch of 4096 fields of 500 x 200 m (BASELINE.json configs[0], the
 reference's own case) per GPU, planned in the reference's own model -- circular arcs at the reference's sampling (2 points per
@@ -41,6 +42,11 @@ if REPO not in sys.path:
 BYTES_PER_POINT = 36          # x, y, kappa, v as float64 + one uint32 flag/segment word
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = 'validated path points/sec (Clothoid+speed+geofence) on 500x200m field batch'      # BASELINE.json, verbatim
+# the secondary ceiling: float64 vector issue.  A vector instruction of a 64-wide wavefront occupies its SIMD for 4 cycles;
+# MI355X: 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).  valu_frac = vector instructions of a launch x 4 cycles / (1024 SIMDs x clock
+# x kernel time); the instruction counts are the SQ_INSTS_VALU counters of the committed profiles (profiles/valu.json), the time is this run's.
+SIMDS, CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 4
+VALU_BOUND_KERNELS = ('k_plan_sparse', 'k_plan_sparse_fields', 'k_plan_fused')      # bound by float64 vector issue (profiles/*_counter_table.txt); the quiet kernels by HBM
 
 
 def parse_args():
@@ -51,7 +57,7 @@ def parse_args():
     ap.add_argument('--fields', type=int, default=4096, help='fields of 500 x 200 m per GPU in the headline batch')
     ap.add_argument('--mode', type=int, default=1, help='1 = fused pipeline (default), 0 = staged pipeline')
     ap.add_argument('--configs', default='all',
-                    help="'all', 'none' or a comma list of: cfg1_clothoid,cfg1_clothoid_dense,cfg2_ref,cfg2_0.5,cfg2_0.1,cfg3,cfg3_avoid,cfg4,cfg5,single_field")
+                    help="'all', 'none' or a comma list of: cfg1_clothoid,cfg1_x16384,cfg1_clothoid_dense,cfg2_ref,cfg2_0.5,cfg2_0.1,cfg3,cfg3_avoid,cfg4,cfg5,single_field")
     ap.add_argument('--calibrate', type=int, default=0, help='opt-in: also report the dense configs and cfg5 with Batch.alloc(best_of=N) output arrays (never the primary figure)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=8.0, help='seconds of CPU baseline for the headline (the other configs get 3 s each)')
@@ -109,6 +115,29 @@ def cpu_baseline_fields(make_ofield, n_fields, oopt, budget_s, what):
                       f'{t1:.1f} s) through oracle/fcpp_oracle.c (sequential C restatement of the reference loops, gcc -O2)'}
 
 
+def cpu_baseline_python(orc, budget_s):
+    """The per-point stages of the hot path (curvature, clamp, sweeps, metrics, verifier: SURVEY.md 8a rows 10-14) the way the reference runs
+    them -- one Python iteration per path point with numpy scalars (oracle/py_loops.py, pinned bit for bit to the reference's own outputs in
+    tests/golden) -- and as whole-array numpy, on ONE core, on the reference's own 500 x 200 m path (1691 points): SURVEY.md 8d's CPU baseline,
+    measured on this box in this run."""
+    import numpy as np
+    from oracle import py_loops as PL
+    rc, p = orc.plan_field(orc.make_field(L=500.0, H=200.0))
+    assert rc == 0
+    kind = p.flagseg & 7
+    nominal = np.select([kind == 0, kind == 1, kind == 2, kind == 3, kind == 4, kind == 5], [9.0, 4.0, 15.0, 15.0, 4.0, 2.5]).astype(np.float64)
+
+    class V:
+        max_lateral_accel, safety_factor, max_longitudinal_accel = 2.0, 0.85, 1.5
+    loops, n1, t1 = PL.time_stages(p.xy, nominal, V, 'loops', budget_s / 2)
+    vec, n2, t2 = PL.time_stages(p.xy, nominal, V, 'numpy', budget_s / 2)
+    v_loops, _ = PL.speed_plan_loops(p.xy, nominal, V)
+    assert float(np.abs(v_loops - p.v).max()) < 1e-9
+    return {'python_loops_value': loops, 'numpy_value': vec, 'python_cores': 1,
+            'python_sample': f'curvature + clamp + sweeps + metrics + verifier of the 1691-point path of a 500 x 200 m field: {n1} passes with per-point Python loops '
+                             f'({t1:.1f} s), {n2} as whole-array numpy ({t2:.1f} s), one core (oracle/py_loops.py)'}
+
+
 # ---- one planner configuration on this rank --------------------------------------------------------------------------------------
 REPS = 5          # repetitions of the K-step timed region; the median is reported
 # A K = 20 region of the sparse configurations is ~1 ms long -- shorter than the device's clock / power transient after a load sets in
@@ -124,7 +153,32 @@ def median(v):
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
-def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=None, after_step=None, stats_of=None, reps=REPS, e2e_reps=5):
+def fresh_regions(E, torch, table, veh, opt, steps, reps, fence, after_call=None):
+    """`reps` regions of `steps` FRESH plan calls (engine.Batch.plan: fcpp_batch_plan + the stream drained; the previous call's batch and
+    arrays are released inside the region, as a caller in a loop releases them) -> (seconds per region, points per call)"""
+    dts, batch, res, n_points, k = [], None, None, 0, 0
+    for _ in range(max(1, reps)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if batch is not None:
+                batch.close()
+            res = None
+            batch, res = E.Batch.plan(table, veh, opt)
+            if after_call:
+                after_call(k, res)
+            k += 1
+            torch.cuda.synchronize()
+        fence()
+        dts.append(time.perf_counter() - t0)
+        n_points = batch.total_points
+    if batch is not None:
+        batch.close()
+    return dts, n_points
+
+
+def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=None, after_step=None, stats_of=None, reps=REPS, e2e_reps=5,
+                fresh_steps=0, fresh_reps=0, after_fresh=None):
     """-> dict(points, ms_per_step, kernels {name: ms}, dominant kernel + its points, end_to_end, batch, bufs, res).
 
     1. the plan call end to end, e2e_reps times: a fresh batch from `table` (engine.FieldTable), its output arrays, one step, the stream
@@ -173,6 +227,13 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     n_points = batch.total_points
     if reps == REPS and BYTES_PER_POINT * n_points < SHORT_STEP_BYTES:
         reps = REPS_SHORT
+    # the plan call as ONE library call, K of them per region (the headline's `value`; every configuration's `value_fresh`)
+    fresh = None
+    if fresh_steps > 0:
+        fw, _ = fresh_regions(E, torch, table, veh, opt, min(fresh_steps, 5), 1, fence)          # (warm-up: the arena, the spare allocations)
+        fdts, fpts = fresh_regions(E, torch, table, veh, opt, fresh_steps, fresh_reps or reps, fence, after_fresh)
+        assert fpts == n_points
+        fresh = {'dts': fdts, 'steps': fresh_steps, 'ms_per_call': median(fdts) / fresh_steps * 1e3}
     warm = e2e[1:] or e2e                 # (the first repetition of a process pays the context's pinned staging memory and the allocator)
     mid = sorted(warm, key=lambda r: r['ms'])[(len(warm) - 1) // 2]
     end_to_end = {'ms': mid['ms'], 'points_per_s': n_points / (mid['ms'] * 1e-3), 'create_ms': mid['create_ms'],
@@ -263,7 +324,8 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     dom_points = stage_points[dom]
     return {'stage_points': stage_points, 'prof_runs': prof_runs, 'points': n_points, 'dt': dt, 'dts': dts, 'ms_per_step': dt / steps * 1e3, 'kernels': kernels,
             'dominant': dom, 'dominant_points': dom_points, 'quiet_points': q_pts, 'general_points': g_pts, 'batch': batch, 'bufs': bufs, 'res': res,
-            'calibrated': calibrated, 'end_to_end': end_to_end, 'steps': steps, 'kernel_timing': kernel_timing, 'layout': getattr(batch, 'layout', None)}
+            'calibrated': calibrated, 'end_to_end': end_to_end, 'steps': steps, 'kernel_timing': kernel_timing, 'layout': getattr(batch, 'layout', None),
+            'fresh': fresh}
 
 
 def roofline_of(r, traffic_key=None):
@@ -289,7 +351,17 @@ def roofline_of(r, traffic_key=None):
         note = ('the wave-tile kernels are bound by fp64 vector issue and dependent loads, not by HBM (profiles/*_counter_table.txt); '
                 'the step-level figure is step_frac')
     step_achieved = BYTES_PER_POINT * r['points'] / (r['ms_per_step'] * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'note': note,
+    valu, valu_src = {}, None
+    vpath = os.path.join(REPO, 'profiles', 'valu.json')
+    if traffic_key and os.path.exists(vpath):
+        vj = json.load(open(vpath))
+        for k, ms in r['kernels'].items():
+            insts = vj.get(f'{k}|{traffic_key}')
+            if insts and ms > 0:
+                valu[k] = insts * VALU_CYCLES / (SIMDS * CLOCK_HZ * ms * 1e-3)
+        valu_src = 'profiles/valu.json (SQ_INSTS_VALU per launch of the committed rocprofv3 --pmc pass) x 4 cycles / (1024 SIMDs x 2.4 GHz x this run\'s kernel time)'
+    bound = 'valu_f64' if dom in VALU_BOUND_KERNELS else 'hbm'
+    return {'bound': bound, 'valu_frac': valu.get(dom), 'valu_fracs': valu or None, 'valu_source': valu_src if valu else None, 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'note': note,
             'traffic': traffic, 'traffic_source': 'profiles/traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of the builder\'s profiling run; a constant, not measured in this run)' if traffic is not None or step_traffic is not None else None,
             'kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
             'kernel_points_per_launch': dom_points, 'all_kernels_ms': r['kernels'], 'all_kernels_points': r['stage_points'],
@@ -309,6 +381,14 @@ def config_entry(name, workload, r, cpu=None, extra=None, traffic_key=None):
          'value_end_to_end': r['end_to_end']['points_per_s'], 'end_to_end': r['end_to_end'], 'setup_ms': r['end_to_end']['setup_ms'],
          'output_arrays': r['layout'],
          'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'roofline': roofline_of(r, traffic_key or name), 'cpu_baseline': cpu}
+    if r.get('fresh'):
+        e['ms_fresh'] = r['fresh']['ms_per_call']
+        e['value_fresh'] = r['points'] / (r['fresh']['ms_per_call'] * 1e-3)
+        e['fresh_region'] = {'reps': len(r['fresh']['dts']), 'calls_per_rep': r['fresh']['steps'],
+                             'ms_per_call_each_rep': [round(d / r['fresh']['steps'] * 1e3, 5) for d in r['fresh']['dts']], 'reported': 'median',
+                             'what': 'a plan call = engine.Batch.plan(table) [fcpp_batch_plan] + the stream drained'}
+    else:
+        e['ms_fresh'], e['value_fresh'] = r['end_to_end']['ms'], r['end_to_end']['points_per_s']
     if r.get('calibrated'):
         e['calibrated'] = r['calibrated']
     if extra:
@@ -316,8 +396,9 @@ def config_entry(name, workload, r, cpu=None, extra=None, traffic_key=None):
     return e
 
 
-# the reference's own cost, measured in the build container on one core with Shapely stubbed out:
-# constants with provenance, reported beside the C port so that the bench line carries what the reference really costs
+# the reference's own cost as PUBLISHED / measured once in the build container: constants with
+# provenance, kept in the detail file only.  What the reference's loops cost ON THIS BOX is measured in every run: cpu_baseline.python_loops_value
+# (oracle/py_loops.py: the per-point Python loops of MLP:490-504, 558-587, 1383-1408 restated, pinned bit for bit to the reference's outputs).
 REFERENCE_MEASURED = {
     'plan_points_per_s': 6.1e4, 'plan_ms_500x200': 27.6, 'published_plan_ms_500x200': 46.0, 'published_points_per_s': 3.7e4,
     'ga_chromosomes_per_s': 3.9e4, 'ga_other_operators_s_per_generation': 0.38,
@@ -339,30 +420,35 @@ def _r(v, nd=6):
 
 
 def compact_line(out):
-    """The last stdout line: BASELINE.json's metric on the headline workload with `roofline` (the step's fraction as `frac`, every kernel of
-    the step as [ms per launch, points per launch, its own fraction]) and `cpu_baseline`, plus one short row per configuration.  The full
-    record (per-configuration entries with their setup splits, timed regions, notes) is bench_detail.json."""
+    """The last stdout line: BASELINE.json's metric on the headline workload -- `value` = the fresh plan call, `value_step` = the hot path on a
+    batch already set up -- with `roofline` (the dominant kernel: its own launch duration and fraction, what bounds it, the call's fraction
+    as `end_to_end_frac`; every kernel of the step as [ms per launch, points per launch, HBM fraction]) and `cpu_baseline`, plus one short
+    row per configuration.  The full record (per-configuration entries with their setup splits, timed regions, notes) is bench_detail.json."""
     rf, cfg = out['roofline'], out['config']
     tr = out.get('timed_region') or {}
     kern = {}
     for name, ms in rf['all_kernels_ms'].items():
         pts = rf['all_kernels_points'].get(name, 0)
-        if ms > 0 and name != 'k_reduce_stats' or (name == 'k_reduce_stats' and ms > 0):
+        if ms > 0:
             kern[name] = [_r(ms, 5), int(pts), _r(BYTES_PER_POINT * pts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if name != 'k_reduce_stats' else None]
     c = {
         'metric': out['metric'], 'value': _r(out['value'], 7), 'unit': out['unit'], 'n_gpus': out['n_gpus'], 'steps': out['steps'], 'warmup': out['warmup'],
         'ms_per_step': _r(out['ms_per_step'], 6), 'higher_is_better': True, 'scaling': out['scaling'], 'vs_baseline': out.get('vs_baseline'),
         'vs_baseline_of': out.get('vs_baseline_of'), 'dtype': 'f64', 'data': 'synthetic',
+        'step': 'one plan call (fcpp_batch_plan: setup on the device + output arrays + the hot path) + stream drained',
+        'value_step': _r(out.get('value_step'), 6), 'ms_step': _r(out.get('ms_step'), 5),
         'config': {'workload': cfg['workload'][:200], 'turn_model': cfg['turn_model'], 'points_per_gpu_step': cfg['points_per_gpu_step'],
                    'fields_per_gpu': cfg['fields_per_gpu'], 'setup': cfg.get('setup')},
-        'roofline': {'bound': 'hbm', 'kernel': rf['step_kernels'], 'frac': _r(rf['step_frac'], 4), 'achieved': _r(rf['step_achieved'], 6), 'peak': HBM_PEAK_GBS,
-                     'unit': 'GB/s', 'kernel_ms': _r(out['ms_per_step'], 6), 'algorithmic_bytes_per_launch': BYTES_PER_POINT * cfg['points_per_gpu_step'],
-                     'traffic': rf.get('step_traffic'), 'traffic_source': rf.get('traffic_source'), 'step_frac': _r(rf['step_frac'], 4),
-                     'dominant_kernel': rf['kernel'], 'dominant_frac': _r(rf['frac'], 4), 'kernel_timing': (rf.get('kernel_timing') or '')[:120], 'kernels': kern},
-        'cpu_baseline': None, 'value_end_to_end': _r(out.get('value_end_to_end'), 6), 'end_to_end_ms': _r(out['end_to_end']['ms'], 5),
-        'value_clothoid': _r(out.get('value_clothoid'), 6), 'rccl_ranks': out.get('rccl_ranks'), 'per_rank_points_per_s': out.get('per_rank_points_per_s'),
+        'roofline': {'bound': rf['bound'], 'kernel': rf['kernel'], 'frac': _r(rf['frac'], 4), 'achieved': _r(rf['achieved'], 6), 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'kernel_ms': _r(rf['kernel_ms'], 5), 'algorithmic_bytes_per_launch': rf['algorithmic_bytes_per_launch'],
+                     'valu_frac': _r(rf.get('valu_frac'), 3), 'traffic': rf.get('traffic'), 'traffic_source': (rf.get('traffic_source') or '')[:60] or None,
+                     'step_frac': _r(rf['step_frac'], 4), 'end_to_end_frac': _r(out.get('end_to_end_frac'), 4),
+                     'kernel_timing': (rf.get('kernel_timing') or '')[:100], 'kernels': kern},
+        'cpu_baseline': None, 'end_to_end_ms': _r(out['end_to_end']['ms'], 5),
+        'value_clothoid': _r(out.get('value_clothoid'), 6), 'value_step_clothoid': _r(out.get('value_step_clothoid'), 6), 'frac_clothoid': _r(out.get('frac_clothoid'), 3),
+        'rccl_ranks': out.get('rccl_ranks'), 'per_rank_points_per_s': out.get('per_rank_points_per_s'),
         'host_threads': out.get('host_threads'), 'detail': 'bench_detail.json',
-        # (every region is K steps between two fences; their number and the spread ride along, each one's value is in the detail file)
+        # (every region is K plan calls between two fences; their number and the spread ride along, each one's value is in the detail file)
         'timed_regions': {'n': tr.get('reps'), 'reported': 'median', 'first_ms': _r(tr['ms_per_step_each_rep'][0], 5), 'min_ms': _r(min(tr['ms_per_step_each_rep']), 5),
                           'max_ms': _r(max(tr['ms_per_step_each_rep']), 5)} if tr.get('ms_per_step_each_rep') else None,
     }
@@ -370,15 +456,16 @@ def compact_line(out):
         c['forced_dist'] = True
     cb = out.get('cpu_baseline')
     if cb:
-        c['cpu_baseline'] = {'value': _r(cb['value'], 5), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:160],
-                             'single_core_value': _r(cb.get('single_core_value'), 5)}
+        c['cpu_baseline'] = {'value': _r(cb['value'], 5), 'unit': cb['unit'], 'cores': cb['cores'], 'kind': cb['kind'], 'sample': cb['sample'][:120],
+                             'single_core_value': _r(cb.get('single_core_value'), 5), 'python_loops_value': _r(cb.get('python_loops_value'), 4),
+                             'numpy_value': _r(cb.get('numpy_value'), 4), 'python_cores': cb.get('python_cores')}
     rows = {}
     for e in out.get('configs', []):
         rr = e.get('roofline') or {}
         cpu = e.get('cpu_baseline') or {}
-        rows[e['name']] = [_r(e.get('ms_per_step', e.get('ms_total')), 5), _r(e.get('value'), 5), _r(rr.get('step_frac', rr.get('frac')), 3),
-                           _r((e.get('end_to_end') or {}).get('ms'), 4), _r(cpu.get('value'), 4)]
-    c['configs'] = {'columns': ['ms_per_step', 'value', 'step_frac', 'end_to_end_ms', 'cpu_baseline_value'], **rows}
+        rows[e['name']] = [_r(e.get('ms_fresh'), 4), _r(e.get('value_fresh'), 4), _r(e.get('ms_per_step', e.get('ms_total')), 5),
+                           _r(rr.get('step_frac', rr.get('frac')), 3), _r(cpu.get('value'), 4)]
+    c['configs'] = {'columns': ['ms_plan_call', 'value_plan_call', 'ms_step', 'step_frac', 'cpu_baseline_value'], **rows}
     line = json.dumps(c, separators=(',', ':'))
     for drop in ('per_rank_points_per_s', 'configs'):          # (never needed so far: a guard, not a plan)
         if len(line) <= COMPACT_LIMIT:
@@ -479,7 +566,7 @@ def main():
         return float(t.item())
 
     want = args.configs.split(',') if args.configs not in ('all', 'none') else (
-        ['cfg1_clothoid', 'cfg1_clothoid_dense', 'cfg2_ref', 'cfg2_0.5', 'cfg2_0.1', 'cfg3', 'cfg3_avoid', 'cfg4', 'cfg5', 'single_field'] if args.configs == 'all' else [])
+        ['cfg1_clothoid', 'cfg1_x16384', 'cfg1_clothoid_dense', 'cfg2_ref', 'cfg2_0.5', 'cfg2_0.1', 'cfg3', 'cfg3_avoid', 'cfg4', 'cfg5', 'single_field'] if args.configs == 'all' else [])
     cpu_on = world == 1 and not args.no_cpu_baseline
 
     # ---- headline: 4096 x (500 x 200 m) per GPU, arcs at the reference's sampling (the pinned mode) ------------------------------
@@ -524,17 +611,24 @@ def main():
                 pending[-1].wait()
         fence()
 
-    # (the plan call end to end 200 times, ~50 ms: enough repetitions for a median that means something at 0.25 ms a call.  The timed
-    # region that follows is SHORT -- K = 20 steps of ~0.06 ms -- and reads ~10 % slower than the sustained rate of the same step, which the
-    # device reaches only after some 20 ms of uninterrupted steps: tools/short_region.py, profiles/r04_short_region.log)
+    # `value`: regions of K FRESH plan calls (Batch.plan + the stream drained), REPS_SHORT of them; `value_step`: the same regions of K steps on
+    # the batch that is already set up, with the kernel's own launch duration by HIP events (what the roofline fraction refers to).  With
+    # several ranks the per-field stats of every call go to rank 0 as before (a device copy into the ring, a gather per GATHER_EVERY calls).
+    def after_fresh(k, res):
+        if use_dist:
+            stats_slot(k, res.batch).copy_(res.stats_raw)
+        count_and_gather(k, res)
+
     r = run_planner(E, torch, E.FieldTable.from_rectangles(LH1), E.make_options(), args.steps, args.warmup, mode=args.mode, fence=fence_headline,
-                    after_step=count_and_gather, stats_of=stats_slot if use_dist else None, e2e_reps=200)
+                    after_step=count_and_gather, stats_of=stats_slot if use_dist else None, e2e_reps=50, fresh_steps=args.steps, fresh_reps=REPS_SHORT,
+                    after_fresh=after_fresh)
     dt = allmax(r['dt'])
+    fresh_dt = allmax(median(r['fresh']['dts']))
     total_points = allsum(r['points'])
     e2e_ms = allmax(r['end_to_end']['ms'])
-    # every rank's own rate (its points x K / its own time of the K-step region), so that the scaling run checks itself
+    # every rank's own rate (its points x K / its own time of the K-call region), so that the scaling run checks itself
     rates = torch.zeros(world, dtype=torch.float64, device=cdev)
-    rates[rank] = r['points'] * args.steps / r['dt']
+    rates[rank] = r['points'] * args.steps / median(r['fresh']['dts'])
     if use_dist:
         dist.all_reduce(rates)
     per_rank_rates = [float(f'{v:.5g}') for v in rates.cpu().tolist()]
@@ -543,25 +637,33 @@ def main():
         st = r['res'].stats()
         assert int(st['n_viol'].sum()) == 0 and np.isfinite(st['main_len_m']).all()
         assert (r['batch'].info[0].n_main, r['batch'].info[0].n_head) == (1256, 435)          # README_en.md:206-207
+        fresh_ms = fresh_dt / args.steps * 1e3
         out = {
-            'metric': METRIC, 'value': total_points * args.steps / dt, 'unit': 'points/s',
-            'n_gpus': world, **({'forced_dist': 'one-rank RCCL process group, collectives addressed to the rank itself (FCPP_BENCH_FORCE_DIST=1)'} if force_dist else {}), 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'metric': METRIC, 'value': total_points * args.steps / fresh_dt, 'unit': 'points/s',
+            'n_gpus': world, **({'forced_dist': 'one-rank RCCL process group, collectives addressed to the rank itself (FCPP_BENCH_FORCE_DIST=1)'} if force_dist else {}), 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': fresh_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'timed_region': timed_region_of(r),
-            # the plan call as the reference times it (MLP:387-465: setup + generation), for the whole job: the slowest rank's fresh batch
+            'step': 'one plan call of the reference for the whole batch (plan_complete_coverage, MLP:387-465: a NEW field set up and its path generated): '
+                    'engine.Batch.plan(table) = fcpp_batch_plan (the setup on the device, the output arrays from the context\'s arena, the hot path) + the stream drained; '
+                    'field records in pinned host memory, read by the device where they lie',
+            'timed_region': {'reps': len(r['fresh']['dts']), 'steps_per_rep': args.steps, 'ms_per_step_each_rep': [round(d / args.steps * 1e3, 5) for d in r['fresh']['dts']],
+                             'reported': 'median'},
+            # the hot path on the batch that is set up (rounds 1-4's `value`): K steps per region, the kernels alone
+            'value_step': total_points * args.steps / dt, 'ms_step': dt / args.steps * 1e3, 'timed_region_step': timed_region_of(r),
+            'end_to_end_frac': BYTES_PER_POINT * r['points'] / (fresh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # the same call through the three separate entries (create / alloc / run), split into its parts
             'value_end_to_end': total_points / (e2e_ms * 1e-3), 'end_to_end': r['end_to_end'], 'setup_ms': r['end_to_end']['setup_ms'],
             'config': {
-                'workload': f'cfg1 x {args.fields}: batch of {args.fields} fields of 500 x 200 m per GPU (BASELINE.json configs[0], README_en.md:199-215), '
-                            f'default VehicleParams, the reference\'s own model: circular-arc turns at the reference\'s sampling '
-                            f'(2 / 20 / 15 / 20 points per line / U-turn / corner / headland side), 1691 points per field -- the mode pinned to '
-                            f'the reference\'s outputs; the clothoid variants of the same batch are configs[cfg1_clothoid*] below and value_clothoid',
+                'workload': f'cfg1 x {args.fields}: {args.fields} fields of 500 x 200 m per GPU, ARC turns (the reference\'s own model, pinned to its outputs) at the '
+                            f'reference\'s sampling, 1691 points per field; a step = one fresh plan call of the batch '
+                            f'(BASELINE.json configs[0], README_en.md:199-215; default VehicleParams; 2 / 20 / 15 / 20 points per line / U-turn / corner / headland side); '
+                            f'the clothoid turn model on the same batch: value_clothoid, configs[cfg1_clothoid*]',
                 'turn_model': 'arc (reference, pinned)', 'points_per_gpu_step': r['points'], 'fields_per_gpu': args.fields,
                 'pipeline': 'staged (7 kernels)' if args.mode == 0 else 'fused: k_plan_quiet (closed-form runs and spans) + k_plan_sparse / k_plan_sparse_fields (wave tiles, two points per lane; the latter also reduces its fields) + k_plan_fused (all other tiles) + k_reduce_stats',
                 'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'output_arrays': r['layout'],
             },
             'roofline': roofline_of(r, 'cfg1'),
             'cpu_baseline': None,
-            'reference_measured': REFERENCE_MEASURED,
+            'reference_published': REFERENCE_MEASURED,
             'rccl_ranks': (dist.get_world_size() if use_dist else 1) if backend == 'nccl' else 0,
             'per_rank_points_per_s': per_rank_rates,
             'host_threads': host_threads,
@@ -572,10 +674,10 @@ def main():
         import oracle as orc
         out['cpu_baseline'] = cpu_baseline_fields(lambda k: orc.make_field(L=float(LH1[k, 0]), H=float(LH1[k, 1])), len(LH1), orc.Options.make(),
                                                   args.cpu_budget, '500 x 200 m fields, arcs, reference sampling')
-        # BASELINE.md publishes no points/s figure for this metric: the ratio is against the CPU baseline of THIS run (the C port of the
-        # reference's loops on the box's own cores), and says so
-        out['vs_baseline'] = out['value'] / out['cpu_baseline']['value']
-        out['vs_baseline_of'] = 'cpu_baseline.value of this run (BASELINE.md has no published points/s)'
+        out['cpu_baseline'].update(cpu_baseline_python(orc, args.cpu_budget / 2))
+        # BASELINE.md publishes no points/s figure for this metric: vs_baseline stays null; the ratio against this run's own CPU baseline (the C
+        # port of the reference's loops on the box's cores) rides along under its own name
+        out['vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
     r['batch'].close()
     del r
     torch.cuda.empty_cache()
@@ -584,15 +686,19 @@ def main():
     configs = []
 
     def planner_config(name, workload, table, opt, steps, warmup, make_ofield=None, n_ofields=0, oopt=None, calibrate=0, what='', extra_fn=None,
-                       budget=3.0, e2e_reps=5, cpu_fn=None):
-        rr = run_planner(E, torch, table, opt, steps, warmup, calibrate=calibrate, fence=fence, e2e_reps=e2e_reps)
+                       budget=3.0, e2e_reps=5, cpu_fn=None, traffic_key=None):
+        # (the plan call as one library call: `steps` calls per region for the configurations at the reference's sampling -- 0.1-0.2 ms a call --,
+        # a few calls for the dense ones -- milliseconds each)
+        sparse = e2e_reps >= 100
+        rr = run_planner(E, torch, table, opt, steps, warmup, calibrate=calibrate, fence=fence, e2e_reps=min(e2e_reps, 20),
+                         fresh_steps=steps if sparse else 3, fresh_reps=REPS_SHORT if sparse else 3)
         cpu = None
         if rank == 0 and cpu_on and cpu_fn is not None:
             cpu = cpu_fn()
         elif rank == 0 and cpu_on and make_ofield is not None:
             cpu = cpu_baseline_fields(make_ofield, n_ofields, oopt, budget, what)
         extra = extra_fn(rr) if extra_fn else None
-        entry = config_entry(name, workload, rr, cpu, extra) if rank == 0 else None
+        entry = config_entry(name, workload, rr, cpu, extra, traffic_key) if rank == 0 else None
         if entry is not None:
             configs.append(entry)
         rr['batch'].close()
@@ -609,7 +715,13 @@ def main():
                                lambda k: orc.make_field(L=500.0, H=200.0), len(LH1), orc.Options.make(1, 1, 0.0, 0.5), what='500 x 200 m fields, clothoid, reference sampling',
                                e2e_reps=200)
             # (BASELINE.json's metric names the clothoid sampler: the same batch with clothoid turns, at top level beside the pinned arc model)
-            out['value_clothoid'], out['ms_per_step_clothoid'], out['value_end_to_end_clothoid'] = e['value'], e['ms_per_step'], e['value_end_to_end']
+            out['value_clothoid'], out['ms_per_step_clothoid'] = e['value_fresh'], e['ms_fresh']
+            out['value_step_clothoid'], out['ms_step_clothoid'], out['frac_clothoid'] = e['value'], e['ms_per_step'], e['roofline']['frac']
+        if 'cfg1_x16384' in want:
+            # the headline's fields, four times as many: 1 GB of output per step -- beyond the 256 MiB Infinity Cache that the headline's 249 MB fit into
+            T16 = E.FieldTable.from_rectangles(WL.cfg1_batch(16384))
+            planner_config('cfg1_x16384', 'cfg1 x 16384: the headline\'s fields, 16 384 of them (1.0 GB of output per step: beyond the 256 MiB Infinity Cache)',
+                           T16, E.make_options(), args.steps, args.warmup, e2e_reps=100, traffic_key='cfg1')
         if 'cfg1_clothoid_dense' in want:
             planner_config('cfg1_clothoid_dense', f'cfg1 x {args.fields}, clothoid turns, uniform 0.1 m sample spacing',
                            T1, E.make_options(1, 0.1), max(3, args.steps // 20), 2,
@@ -804,7 +916,7 @@ def run_cfg4(E, torch, WL, cpu_on):
             'value': evals / dt, 'unit': 'chromosome evaluations/s', 'dtype': 'f64', 'gathers_per_s': evals * 128 / dt,
             'best_distance_m': float(res.best_distance),
             'fitness_only': {'ms_501_launches': dtf * 1e3, 'chromosomes_per_s': evals / dtf, 'gathers_per_s': evals * 128 / dtf},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_ga_generation', 'achieved': evals * bytes_per_chrom / dt / 1e9, 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'latency', 'kernel': 'k_ga_generation', 'achieved': evals * bytes_per_chrom / dt / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': evals * bytes_per_chrom / dt / 1e9 / HBM_PEAK_GBS, 'traffic': None,
                          'note': 'algorithmic HBM bytes per chromosome = 4 n + 8 = 520 B (SURVEY.md 8d): the loop is bound by the latency of its 501 '
                                  'dependent launches, each as long as one workgroup\'s bookkeeping chain (D and the population live in L2 / LDS), not by HBM; '
@@ -911,7 +1023,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
                  'n_gpus': world, 'scaling': 'strong', 'points': total, 'output_arrays': getattr(batch, 'layout', None),
                  'ms_per_step': dt_dev / steps * 1e3, 'value': total * steps / dt_dev, 'unit': 'points/s', 'dtype': 'f64',
                  'timed_region': {'reps': len(dts), 'steps_per_rep': steps, 'ms_per_step_each_rep': [round(d / steps * 1e3, 5) for d in dts], 'reported': 'median (rank 0 shown)'},
-                 'value_end_to_end': total / (mid['ms'] * 1e-3),
+                 'value_end_to_end': total / (mid['ms'] * 1e-3), 'ms_fresh': mid['ms'], 'value_fresh': total / (mid['ms'] * 1e-3),
                  'end_to_end': {'ms': mid['ms'], 'points_per_s': total / (mid['ms'] * 1e-3), 'count_ms': mid['count_ms'], 'plan_sharded_ms': mid['plan_sharded_ms'],
                                 'setup_ms': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in mid['setup_ms'].items()},
                                 'first_ms': e2e[0]['ms'], 'all_ms': [round(r['ms'], 3) for r in e2e], 'table_from_vertices_ms': t_table,
@@ -926,7 +1038,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
                                         'note': 'one plan_sharded(gather_points=True): every peer sends its x, y, kappa, v, flagseg block straight into '
                                                 'the root\'s arrays (dist.batch_isend_irecv)'},
                  'quiet_points': q_pts, 'general_points': g_pts,
-                 'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                 'roofline': {'bound': 'valu_f64' if dom in VALU_BOUND_KERNELS else 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                               'traffic': traffic5 if world == 1 else None, 'algorithmic_bytes_per_launch': BYTES_PER_POINT * dom_points,
                               'kernel_ms': kernels[dom], 'kernel_points_per_launch': dom_points, 'all_kernels_ms': kernels, 'all_kernels_points': stage_points,
                               'rank': 0, 'step_frac': BYTES_PER_POINT * total / (dt_dev / steps) / 1e9 / HBM_PEAK_GBS / world},

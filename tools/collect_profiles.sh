@@ -5,7 +5,7 @@
 #   usage: tools/collect_profiles.sh [config ...]
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/prof_${FCPP_ROUND:-r04}
+OUT=$R/gpurun_out/prof_${FCPP_ROUND:-r05}
 CFGS=${*:-cfg1 cfg1_clothoid cfg2_ref cfg2_0.5 cfg2_0.1 cfg3 cfg5}
 cd /tmp && export TMPDIR=/tmp
 for c in $CFGS; do

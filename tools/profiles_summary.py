@@ -2,7 +2,7 @@
 """gpurun_out/prof_<round>/<config>/ (tools/collect_profiles.sh) -> profiles/: per configuration
     <round>_<config>_kernel_stats.csv : the rocprofv3 --kernel-trace --stats summary rows of the fcpp kernels (calls, total / average ns)
     <round>_<config>_counters.csv     : per kernel and counter, the mean value per launch (WRITE_SIZE, FETCH_SIZE, SQ_*)
-and profiles/traffic.json: HBM bytes per launch = WRITE_SIZE KiB x 1024 + 2 x FETCH_SIZE KiB x 1024 (the gfx950 FETCH_SIZE correction
+profiles/valu.json (vector instructions per launch, SQ_INSTS_VALU) and profiles/traffic.json: HBM bytes per launch = WRITE_SIZE KiB x 1024 + 2 x FETCH_SIZE KiB x 1024 (the gfx950 FETCH_SIZE correction
 of MI355X_MICROARCH.md, section HBM), keyed '<bench stage name>|<config>' as bench.py looks it up."""
 import collections
 import csv
@@ -12,7 +12,7 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get('FCPP_ROUND', 'r04')
+ROUND = os.environ.get('FCPP_ROUND', 'r05')
 SRC = os.path.join(REPO, 'gpurun_out', 'prof_' + ROUND)
 DST = os.path.join(REPO, 'profiles')
 STAGE_PREFIX = (('k_plan_quiet<16', 'k_plan_quiet_spans'), ('k_plan_quiet<14', 'k_plan_quiet'), ('k_plan_sparse_fields', 'k_plan_sparse_fields'), ('k_plan_sparse', 'k_plan_sparse'),
@@ -32,6 +32,7 @@ def short(name):
 
 traffic = {}
 notes = {}
+valu = {}
 for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
     cfg = os.path.basename(cdir)
     # kernel statistics over the LAST `timed_steps` dispatches of every kernel of the trace (tools/prof_cfg.py prints the count): the
@@ -79,9 +80,15 @@ for cdir in sorted(glob.glob(os.path.join(SRC, '*'))):
                     continue
                 traffic[key] = wkb * 1024 + 2 * fkb * 1024
                 notes[key] = {'kernel': k, 'WRITE_SIZE_KB_per_launch': wkb, 'FETCH_SIZE_KB_per_launch': fkb}
+        # vector instructions per launch (all wavefronts): bench.py's valu_frac = this x 4 cycles / (1024 SIMDs x clock x its own kernel time)
+        for k in sorted({k for k, _ in acc}):
+            if stage_of(k) and (k, 'SQ_INSTS_VALU') in acc and f'{stage_of(k)}|{cfg}' not in valu:
+                valu[f'{stage_of(k)}|{cfg}'] = acc[(k, 'SQ_INSTS_VALU')][1] / acc[(k, 'SQ_INSTS_VALU')][0]
     print(cfg, 'stats' if stats else 'NO stats', len(acc), 'counter rows')
 traffic['_notes'] = {
     'source': 'rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE, separate passes, program directly after `--` (tools/collect_profiles.sh), ' + ROUND,
     'units': 'bytes per kernel launch = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md section HBM)',
     'detail': notes}
 json.dump(traffic, open(os.path.join(DST, 'traffic.json'), 'w'), indent=1)
+valu['_notes'] = {'source': 'rocprofv3 --pmc SQ_INSTS_VALU ... (tools/collect_profiles.sh), ' + ROUND, 'units': 'vector instructions per kernel launch, summed over its wavefronts'}
+json.dump(valu, open(os.path.join(DST, 'valu.json'), 'w'), indent=1)
