@@ -22,8 +22,8 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
     o->counts = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
     o->bases = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
     o->blk_sums = reinterpret_cast<int64_t *>(take(nblk * PC_COLS * sizeof(int64_t)));
-    o->keep_tiles = reinterpret_cast<DevTile *>(take(nn * DEVPLAN_KEEP_TILES * sizeof(DevTile)));
-    o->keep_wtiles = reinterpret_cast<DevWaveTile *>(take(nn * DEVPLAN_KEEP_TILES * sizeof(DevWaveTile)));
+    o->keep_tiles = reinterpret_cast<DevTile *>(take(nn * DEVPLAN_KEEP_ROWS * sizeof(DevTile)));
+    o->keep_wtiles = reinterpret_cast<DevWaveTile *>(take(nn * DEVPLAN_KEEP_ROWS * sizeof(DevWaveTile)));
     return off;
 }
 
@@ -675,14 +675,16 @@ constexpr int TW_LDS_PRIMS = 32;                                        // primi
 constexpr int TW_LDS_TMPL = 36;                                         // turn template samples staged in LDS (U-turn + corner; more: ditto)
 template <bool STAGE>
 struct TileWaveLds {
-    double d[TW_NW];              // d[i - lo] = |p_i - p_(i-1)|
+    double d[TW_NW];              // d[i - lo] = |p_i - p_(i-1)|   (the window cut; the closed-form cut keeps its records of the field's primitives
+                                  // and its copies of the turn templates in the same bytes: cut_rows / cut_tmpl below)
+    static_assert(sizeof(double) * TW_NW >= sizeof(CutPrim) * CUT_PRIMS_MAX + sizeof(Pt2) * TW_LDS_TMPL, "the closed-form cut's LDS fits the window's");
+    __device__ CutPrim *cut_rows() { return reinterpret_cast<CutPrim *>(d); }
+    __device__ Pt2 *cut_tmpl() { return reinterpret_cast<Pt2 *>(reinterpret_cast<unsigned char *>(d) + sizeof(CutPrim) * CUT_PRIMS_MAX); }
     // the field's primitives and the batch's turn templates, staged once: a window point's evaluation then waits on LDS, not on a
     // dependent read from device memory per 64 points (22 of the counting pass's 72 thousand cycles per field)
     unsigned long long prim_words[STAGE ? TW_LDS_PRIMS * (sizeof(DevPrim) / 8) : 1];
     Pt2 tmpl[STAGE ? TW_LDS_TMPL : 1];
     int32_t pstart[DEVPLAN_PRIMS_CAP + 1];   // start of primitive k relative to n_main
-    CutPrim cut[CUT_PRIMS_MAX];   // the closed-form cut's records of the field's primitives (fcpp_cutfn.h)
-    Pt2 cut_tmpl[TW_LDS_TMPL];    // ... and its copies of the batch's turn templates (U-turn, corner)
     uint8_t pidx[TW_NW];          // primitive (index within the field) of window point w; 0 in layer 1
     uint8_t ins[TW_NW];           // window point w lies inside the geofence with the host's margin
 };
@@ -778,13 +780,13 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         if (FILL && use_wave) {
             const int64_t cw = counts[(int64_t)PC_WAVE * n + field];
             if (cw == 0) { use_wave = false; refused = true; }
-            else if (cw <= DEVPLAN_KEEP_TILES) {
+            else if (cw <= DEVPLAN_KEEP_TILES || (tc.closed_cut != 0 && a == cut_span_points(F, tc.cut) && cut_applies(F, tc.cut, a))) {       // (a closed-form cut: every tile was kept)
                 // the counting pass kept this field's wave tiles: copy them, indices made batch-wide
                 use_wave = false;
                 n_wave = cw;
                 if (lane < cw) {
-                    DevTile t = keep_tiles[field * DEVPLAN_KEEP_TILES + lane];
-                    DevWaveTile wt = keep_wtiles[field * DEVPLAN_KEEP_TILES + lane];
+                    DevTile t = keep_tiles[field * DEVPLAN_KEEP_ROWS + lane];
+                    DevWaveTile wt = keep_wtiles[field * DEVPLAN_KEEP_ROWS + lane];
                     const int64_t first = wt.out_base;                       // (kept relative to the field)
                     const int nl = (int)wt.hb + wt.count + wt.hf;
                     if (first >= gen_main) { t.idx0 += (int32_t)prim_index0; wt.idx0 = t.idx0; }
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         // ---- round 5: the general stretch of a field with a closed-form span is cut IN CLOSED FORM (fcpp_cutfn.h, the function the host
         // tiler runs): the step lengths the halos are sized from are the primitives' own steps and the distances between their end points
         // -- the primitives a lane each, then the tiles of a candidate cut a lane each -- no point of the stretch is evaluated
-        if (use_wave && tc.closed_cut != 0 && a == cut_span_points(F, tc.cut) && cut_applies(F, tc.cut, a)) {
+        if (!FILL && use_wave && tc.closed_cut != 0 && a == cut_span_points(F, tc.cut) && cut_applies(F, tc.cut, a)) {
             use_wave = false;
             const int64_t n_main = F.n_main;
             TSTAMP(10);
@@ -824,8 +826,8 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             if (lane < prim_count) q = prims[lane];
             TSTAMP(15);
             if (cut_staged) {
-                if (lane < nt_all) L.cut_tmpl[lane] = tp;
-                lc.tu = L.cut_tmpl; lc.tc = L.cut_tmpl + tc.cut.nu;
+                if (lane < nt_all) L.cut_tmpl()[lane] = tp;
+                lc.tu = L.cut_tmpl(); lc.tc = L.cut_tmpl() + tc.cut.nu;
                 wave_sync();
             }
             TSTAMP(16);
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             double px = __shfl_up(ex, 1), py = __shfl_up(ey, 1);          // the point before a primitive's first: its predecessor's last ...
             if (lane == 0) cut_main_end(F, lc, px, py);                    // ... or the last point of layer 1
             if (lane < prim_count) {
-                L.cut[lane] = cut_prim_rec(q, F, lc, px, py, fx, fy, ex, ey, p_ok);
+                L.cut_rows()[lane] = cut_prim_rec(q, F, lc, px, py, fx, fy, ex, ey, p_ok);
                 L.pstart[lane] = (int32_t)(q.start - n_main);
             }
             const bool prims_ok = __ballot(lane < prim_count && !p_ok) == 0ull;
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             // 2. the cut: candidate cuts of T near-equal tiles, the tiles of one a lane each; the decisions of cut_field, taken on the first
             // tile (in path order) that does not fit
             struct CutView { const CutPrim *p; __device__ const CutPrim &operator()(int k) const { return p[k]; } };
-            const CutView pv{ L.cut };
+            const CutView pv{ L.cut_rows() };
             const double cap = tiler_halo_cap(tc.u_cap);
             const int32_t G32 = (int32_t)G;
             const int32_t cut_start = lane < prim_count ? (int32_t)(q.start - n_main) : INT32_MAX;      // this lane's primitive's first point
@@ -870,8 +872,8 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                     }
                     if (lane < T) {
                         const int64_t Sl = ((int64_t)F.P - 1) * per, j = s - 1, e = s + c - 1;
-                        if (j < Sl) { kj = -2; rj = (int32_t)(j - (Sl - F.n_turn)); } else if (j < n_main) { kj = -1; rj = (int32_t)(j - Sl); } else rj = (int32_t)(j - n_main) - L.cut[kj < 0 ? 0 : kj].start_rel;
-                        if (e < Sl) { ke = -2; re = (int32_t)(e - (Sl - F.n_turn)); } else if (e < n_main) { ke = -1; re = (int32_t)(e - Sl); } else re = (int32_t)(e - n_main) - L.cut[ke < 0 ? 0 : ke].start_rel;
+                        if (j < Sl) { kj = -2; rj = (int32_t)(j - (Sl - F.n_turn)); } else if (j < n_main) { kj = -1; rj = (int32_t)(j - Sl); } else rj = (int32_t)(j - n_main) - L.cut_rows()[kj < 0 ? 0 : kj].start_rel;
+                        if (e < Sl) { ke = -2; re = (int32_t)(e - (Sl - F.n_turn)); } else if (e < n_main) { ke = -1; re = (int32_t)(e - Sl); } else re = (int32_t)(e - n_main) - L.cut_rows()[ke < 0 ? 0 : ke].start_rel;
                         code = cut_tile_eval_at(F, lc, pv, prim_count, cap, s, c, kj, rj, ke, re, Hb, Hf, in);
                     }
                     const unsigned long long bad = __ballot(code != 0);
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                 }
                 const int64_t wave_pts = G;
                 const int64_t inside_cnt = __popcll(__ballot(lane < nt && in));
-                if (lane < nt && (FILL || lane < DEVPLAN_KEEP_TILES)) {
+                if (lane < nt) {
                     const int64_t first = s - Hb, last = s + c - 1 + Hf;
                     const int64_t p_base = FILL ? prim_index0 : 0;
                     DevTile t;
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                         for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
                     }
                     if (FILL) { T.tiles[stat_base + (span_k > 0 ? 1 : 0) + lane] = t; T.wtiles[wave_base + lane] = wt; }
-                    else { keep_tiles[field * DEVPLAN_KEEP_TILES + lane] = t; keep_wtiles[field * DEVPLAN_KEEP_TILES + lane] = wt; }
+                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + lane] = t; keep_wtiles[field * DEVPLAN_KEEP_ROWS + lane] = wt; }
                 }
                 n_wave = nt; c_wave_pts = wave_pts; c_wave_inside = inside_cnt;
                 TSTAMP(14);
@@ -1109,7 +1111,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                         for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
                     }
                     if (FILL) { T.tiles[stat_base + (span_k > 0 ? 1 : 0) + ordinal] = t; T.wtiles[wave_base + ordinal] = wt; }
-                    else { keep_tiles[field * DEVPLAN_KEEP_TILES + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_TILES + ordinal] = wt; }
+                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_ROWS + ordinal] = wt; }
                 }
                 TSTAMP(6 + 4 * (int)ordinal);
                 inside_cnt += all_in ? 1 : 0;
