@@ -127,6 +127,7 @@ PROTOTYPES = [
                                     C.POINTER(Polys), C.POINTER(_VP)]),
     ('fcpp_batch_plan', C.c_int, [_VP, C.POINTER(Vehicle), C.POINTER(Options), C.c_int64, C.POINTER(Field), C.POINTER(Polys), _VP,
                                   C.POINTER(_VP)] + [C.POINTER(_VP)] * 5 + [c_i64_p]),
+    ('fcpp_batch_own_stats', C.c_int, [_VP, C.POINTER(_VP)]),
     ('fcpp_batch_info', C.c_int, [_VP, C.POINTER(FieldInfo), c_i64_p]),
     ('fcpp_batch_setup_times', C.c_int, [_VP, C.POINTER(SetupTimes)]),
     ('fcpp_batch_run', C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int]),

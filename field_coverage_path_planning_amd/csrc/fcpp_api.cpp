@@ -1307,7 +1307,7 @@ int fcpp_batch_plan(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *op
                     const fcpp_polys *obstacles, fcpp_field_stats *stats, fcpp_batch **batch, double **x, double **y, double **kappa, double **v,
                     uint32_t **fs, int64_t *total_points)
 {
-    if (!batch || !x || !y || !kappa || !v || !fs || (n_fields > 0 && !stats)) return fail(FCPP_EINVAL, "bad arguments");
+    if (!batch || !x || !y || !kappa || !v || !fs) return fail(FCPP_EINVAL, "bad arguments");
     *batch = nullptr; *x = *y = *kappa = *v = nullptr; *fs = nullptr;
     fcpp_batch *b = nullptr;
     int rc = fcpp_batch_create(c, veh, opt, n_fields, fields, obstacles, &b);
@@ -1315,6 +1315,7 @@ int fcpp_batch_plan(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *op
     const int64_t total = b->hp.total_points;
     rc = fcpp_outputs_alloc(c, total, 0, x, y, kappa, v, fs);
     if (rc == FCPP_OK) {
+        if (!stats && b->slab) stats = reinterpret_cast<fcpp_field_stats *>(static_cast<unsigned char *>(b->slab) + b->lay.own_stats);
         rc = fcpp_batch_run(b, *x, *y, *kappa, *v, *fs, stats, 1);
         if (rc != FCPP_OK) { const std::string keep = g_err; (void)hipStreamSynchronize(c->stream); (void)fcpp_outputs_free(c, *x); g_err = keep; }
     }
@@ -1327,6 +1328,13 @@ int fcpp_batch_plan(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *op
     }
     *batch = b;
     if (total_points) *total_points = total;
+    return FCPP_OK;
+}
+
+int fcpp_batch_own_stats(const fcpp_batch *b, fcpp_field_stats **stats)
+{
+    if (!b || !stats) return fail(FCPP_EINVAL, "bad arguments");
+    *stats = b->slab ? reinterpret_cast<fcpp_field_stats *>(static_cast<unsigned char *>(b->slab) + b->lay.own_stats) : nullptr;
     return FCPP_OK;
 }
 

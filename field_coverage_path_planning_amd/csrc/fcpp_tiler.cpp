@@ -534,6 +534,7 @@ void layout_image(ImageLayout &lay)
     take(lay.field_junc, (size_t)lay.n_fields * 2 * sizeof(double));
     take(lay.work_totals, (size_t)lay.n_field_work * sizeof(TilePartial));   // per field of field_work: the statistics of its quiet runs, summed once
     take(lay.info, lay.info_on_device ? (size_t)lay.n_fields * sizeof(fcpp_field_info) : 0);   // device-side setup: fcpp_field_info, copied back on demand
+    take(lay.own_stats, (size_t)lay.n_fields * sizeof(fcpp_field_stats));       // fcpp_batch_plan(stats_dev = NULL): the batch's own statistics records
     lay.total_bytes = o;
 }
 

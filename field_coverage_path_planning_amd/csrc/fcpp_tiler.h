@@ -42,7 +42,7 @@ struct ImageLayout {
     size_t fields = 0, prims = 0, tiles = 0, wtiles = 0, general_ids = 0, chunks = 0, span_chunks = 0, stat_ids = 0, stat_first = 0,
            stat_run = 0, red_paths = 0, field_work = 0, field_packs = 0, open_wave_ids = 0, chunk_groups = 0, obs_off = 0, obs_x = 0, obs_y = 0, obs_bbox = 0, seg = 0, seg_mask = 0;
     size_t upload_bytes = 0;                  // [0, upload_bytes) is built on the host and copied
-    size_t partial = 0, red_scratch = 0, field_junc = 0, work_totals = 0, info = 0;      // device-only scratch behind it
+    size_t partial = 0, red_scratch = 0, field_junc = 0, work_totals = 0, info = 0, own_stats = 0;      // device-only scratch behind it (own_stats: fcpp_batch_plan's statistics records when the caller brings none)
     bool info_on_device = false;              // the batch was set up on the device: its fcpp_field_info records live in the slab (info)
     size_t total_bytes = 0;
     int64_t n_fields = 0, n_prims = 0, n_tiles = 0, n_wave = 0, n_general = 0, n_chunks = 0, n_span_chunks = 0, n_runs = 0, n_stat = 0;

@@ -371,6 +371,24 @@ class _ArenaArrays:
             pass
 
 
+class _StatsView:
+    """The statistics records a batch keeps in its own device allocation (fcpp_batch_own_stats), handed to torch through the CUDA array
+    interface; the batch's close() waits for the last tensor made from this view."""
+
+    def __init__(self, batch, ptr, n_words):
+        self._batch = batch
+        self.__cuda_array_interface__ = {'shape': (n_words,), 'typestr': '<i8', 'data': (ptr, False), 'version': 2, 'strides': None}
+
+    def __del__(self):
+        try:
+            b = self._batch
+            b._stats_views = 0
+            if getattr(b, '_close_pending', False):
+                b.close()
+        except Exception:
+            pass
+
+
 class BatchResult:
     """Device-resident result of one batch: SoA tensors + per-field stats."""
 
@@ -436,15 +454,26 @@ class Batch:
         self._token = object()
         self._last_mode = 1
         dev = torch.device('cuda', self.ctx.device)
-        stats = torch.empty((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
         self.ctx.bind_stream()
         h = C.c_void_p()
         ptrs = [C.c_void_p() for _ in range(5)]
         tot = C.c_int64()
+        # (no statistics records of ours: the batch's own, inside its device allocation -- nothing is allocated in front of the call)
         L.check(self.lib.fcpp_batch_plan(self.ctx.handle, C.byref(self.vehicle), C.byref(self.options), self.n_fields, arr, C.byref(polys),
-                                         _ptr(stats), C.byref(h), *[C.byref(q) for q in ptrs], C.byref(tot)))
+                                         None, C.byref(h), *[C.byref(q) for q in ptrs], C.byref(tot)))
         self.handle = h
         self.total_points = n = tot.value
+        sp = C.c_void_p()
+        L.check(self.lib.fcpp_batch_own_stats(h, C.byref(sp)))
+        if self.n_fields > 0 and sp.value:
+            # (a view of the batch's own memory: while a tensor made from it is alive, close() only marks the batch -- the tables are
+            # released when the last such tensor is gone)
+            sv = _StatsView(self, sp.value, self.n_fields * L.STATS_WORDS)
+            stats = torch.as_tensor(sv, device=dev).view(self.n_fields, L.STATS_WORDS)
+            stats._fcpp_owner = sv
+            self._stats_views = 1
+        else:
+            stats = torch.empty((self.n_fields, L.STATS_WORDS), dtype=torch.int64, device=dev)
         owner = _ArenaArrays(self.ctx, n, [q.value or 0 for q in ptrs])
         if n > 0:
             x, y, kappa, v, fs = owner.tensors(n)
@@ -696,6 +725,9 @@ class Batch:
 
     def close(self):
         if getattr(self, 'handle', None):
+            if getattr(self, '_stats_views', 0):        # (a result of plan() still reads the batch's own statistics records)
+                self._close_pending = True
+                return
             self.lib.fcpp_batch_destroy(self.handle)
             self.handle = None
 

@@ -255,12 +255,15 @@ int fcpp_batch_run(fcpp_batch *batch, double *x_dev, double *y_dev, double *kapp
  * one call, and so does this -- fcpp_batch_create, output arrays for the batch's points (fcpp_outputs_alloc(pitch_bytes = 0): from the
  * context's arena when it has one, else an allocation of their own; released with fcpp_outputs_free(ctx, *x_dev)) and one fcpp_batch_run
  * (mode 1), with nothing of the caller's between the three: the step is enqueued the moment the setup's totals have sized the arrays.
- * stats_dev: n_fields records of the caller's.  Asynchronous like fcpp_batch_run: the arrays are complete when the context's stream is.
+ * stats_dev: n_fields records of the caller's, or NULL: the batch's own (fcpp_batch_own_stats; they live as long as the batch).
+ * Asynchronous like fcpp_batch_run: the arrays are complete when the context's stream is.
  * The batch stays valid for further fcpp_batch_run calls on the same arrays (or others) until fcpp_batch_destroy.  On an error nothing is
  * left allocated.  bench.py's headline step is this call + the stream drained. */
 int fcpp_batch_plan(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
                     const fcpp_polys *obstacles, fcpp_field_stats *stats_dev, fcpp_batch **batch, double **x_dev, double **y_dev,
                     double **kappa_dev, double **v_dev, uint32_t **flagseg_dev, int64_t *total_points);
+/* the statistics records a batch keeps for callers that bring none (n_fields records inside the batch's own device allocation) */
+int fcpp_batch_own_stats(const fcpp_batch *batch, fcpp_field_stats **stats_dev);
 /* _generate_approach_path / _generate_departure_path (MLP:1313-1355): 50 points each, AoS (x,y) per
  * field at [field*100 .. +100); rows of fields without a kept start/end point are left untouched. */
 int fcpp_batch_connectors(fcpp_batch *batch, double *approach_xy_dev, double *departure_xy_dev);
