@@ -104,10 +104,28 @@ def gather_rows(local_rows, rows_per_rank, dst=0):
     return torch.cat(parts, dim=0) if rank == dst else None
 
 
-def gather_arrays(local_arrays, counts_per_rank, dst=0):
+def arena_point_arrays(total, like):
+    """The root's full point arrays (x, y, kappa, v: float64, flagseg: int32) out of the context's OUTPUT ARENA when `like` -- this rank's
+    five arrays -- live on a device whose context has one with room: the gathered arrays then lie a pitch apart like every batch's own
+    (DESIGN.md section 2), instead of back to back wherever the allocator puts them.  -> list of five tensors, or None."""
+    import torch
+    if len(like) != 5 or not all(a.is_cuda for a in like) or [a.dtype for a in like] != [torch.float64] * 4 + [torch.int32]:
+        return None
+    ctx = E.get_context(like[0].device.index)
+    lane, pitch = ctx.arena()
+    if lane < 8 * int(total) or total <= 0:
+        return None
+    arr = E._ArenaArrays(ctx, int(total))
+    if arr.ptrs[1] - arr.ptrs[0] != pitch:          # (the arena was full: the library's own allocation -- fine, but no better than torch's)
+        return None
+    return arr.tensors(int(total))
+
+
+def gather_arrays(local_arrays, counts_per_rank, dst=0, alloc=None):
     """Optional gather of the point arrays: every rank holds 1-D tensors of its own block (x, y, kappa, v,
     flagseg, ...: the same list, in the same order, on every rank; counts_per_rank[r] elements each on rank r).  The root
-    allocates each full array once and receives every peer's block straight into its slice -- one batch of point-to-point
+    allocates each full array once -- alloc(total, local_arrays) -> list of tensors or None: the caller's allocator, e.g.
+    arena_point_arrays -- and receives every peer's block straight into its slice -- one batch of point-to-point
     transfers (ncclGroupStart / ncclSend / ncclRecv with the nccl backend: each peer crosses its own xGMI link to the root,
     no ring, no staging copy, no concatenation).  -> list of full tensors on `dst`, None elsewhere."""
     import torch
@@ -121,8 +139,9 @@ def gather_arrays(local_arrays, counts_per_rank, dst=0):
     ops, out = [], None
     if rank == dst:
         out = []
-        for a in local_arrays:
-            full = torch.empty(int(starts[-1]), dtype=a.dtype, device=a.device)
+        given = alloc(int(starts[-1]), local_arrays) if alloc is not None else None
+        for k, a in enumerate(local_arrays):
+            full = given[k] if given is not None else torch.empty(int(starts[-1]), dtype=a.dtype, device=a.device)
             full[int(starts[dst]):int(starts[dst + 1])] = a[:int(counts_per_rank[dst])]
             for r in range(ws):
                 if r != dst and counts_per_rank[r] > 0:
@@ -212,7 +231,8 @@ def plan_sharded(specs, vehicle, options=None, device=None, compute=None, mode=1
     points_all = None
     if gather_points:
         per_rank = [int(np.sum(counts[a:b])) for a, b in blocks] if counts is not None else [int(batch.total_points) if batch is not None else 0]
-        points_all = gather_arrays([_comm_tensor(a) for a in arrays], per_rank, dst=0)
+        # (the root's full arrays out of the output arena when the transfers carry device tensors: RCCL; the gloo rehearsal gathers on the host)
+        points_all = gather_arrays([_comm_tensor(a) for a in arrays], per_rank, dst=0, alloc=arena_point_arrays)
     res = ShardedResult((lo, hi), local, stats_all, infos, blocks, points_all, batch)
     res.counts = counts           # points per field of the whole batch (None: one rank planned everything without sizing)
     return res

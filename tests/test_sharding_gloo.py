@@ -105,11 +105,12 @@ def test_sharded_stats_equal_single_process(tmp_path, world_size):
     assert np.array_equal(sharded, single)          # byte-identical for any shard count
 
 
-@pytest.mark.parametrize('world_size', [2, 4])
+@pytest.mark.parametrize('world_size', [2, 4, 8])
 def test_sharded_point_arrays_equal_single_process(tmp_path, world_size):
     """The optional gather of the point arrays (direct sends into the root's slices, dist.batch_isend_irecv): the root's arrays are
-    byte-identical to one process planning every field; world_size 4 over 5 fields leaves blocks of one field (and possibly none)."""
-    n_fields = 5 if world_size == 4 else 9
+    byte-identical to one process planning every field; world_size 4 over 5 fields leaves blocks of one field (and possibly none);
+    world_size 8 over 21 fields: the cut and both gathers of a whole node's ranks (the eight-way job itself needs an eight-GPU node)."""
+    n_fields = 5 if world_size == 4 else (21 if world_size == 8 else 9)
     out = str(tmp_path / 'points.npz')
     port = 31500 + (os.getpid() % 2000) + world_size
     mp.spawn(_worker_points, args=(world_size, port, n_fields, out), nprocs=world_size, join=True)
