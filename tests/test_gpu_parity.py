@@ -929,3 +929,41 @@ def test_pinned_field_tables_are_read_where_they_lie():
             assert np.array_equal(_np(u), _np(w))
         assert np.array_equal(a.info.array, c.info.array)
         a.close(); c.close()
+
+
+def test_obstacle_aware_swaths_on_the_half_metre_grid_the_fragile_case():
+    """The FRAGILE twin of _clip_fields' tilted parallelogram (round 5; the main case keeps its obstacles off the grid): obstacle sides on multiples
+    of 0.1 m, so that some detour leg is a multiple of 0.5 m long up to the rounding of the rotation into the frame of layer 1 and back, and
+    its sample count int(len / 0.5) + 1 hinges on the last bit of a sine -- the library's (csrc/fcpp_math.h) or the oracle's (libm), as the
+    reference's own int((max_y - min_y) / W) does (tests/test_oracle_vs_golden.py: the fields the reference decides).  What must hold whichever
+    way the bits fall: the same sequence of path segments (kind, layer, swath / corner index), every segment of the same length except detour
+    legs, which may differ by one sample; no point inside an obstacle; and where the counts do agree, the whole path to the usual tolerances."""
+    rot = 0.3
+    c, s = np.cos(rot), np.sin(rot)
+    tilt = lambda pts: [(float(x * c - y * s), float(x * s + y * c)) for x, y in pts]
+    verts = tilt([(0.0, 0.0), (500.0, 0.0), (560.0, 260.0), (60.0, 260.0)])
+    para_obs = [tilt([(200.0, 100.0), (230.0, 100.0), (230.0, 125.0), (200.0, 125.0)]), tilt([(340.0, 150.0), (365.0, 160.0), (350.0, 185.0)])]
+    spec, of = E.FieldSpec(field_vertices=verts, obstacles=para_obs), orc.make_field(verts=verts, obstacles=para_obs)
+    o = E.make_options(avoid_obstacles=True)
+    b = E.Batch([spec], _veh(DEFAULT_VP), o)
+    res = b.run()
+    fs = _np(res.flagseg).view(np.uint32)
+    rc, p = orc.plan_field(of, orc.Vehicle.make(DEFAULT_VP), orc.Options.make(o.turn_model, o.clothoid_fit, o.sample_spacing, o.clothoid_frac, o.geofence_tol, o.obstacle_mode, o.ring_order))
+    assert rc == 0 and b.info[0].status == 0 and b.info[0].n_swaths == p.n_swaths
+    assert int(res.stats()['n_in_obstacle'][0]) == 0 and p.n_in_obstacle == 0
+
+    def segments(words):
+        key = words & ~np.uint32(L.FLAG_ALAT | L.FLAG_OUTSIDE | L.FLAG_OBSTACLE)
+        cut = np.flatnonzero(np.diff(key.astype(np.int64)) != 0) + 1
+        starts = np.concatenate([[0], cut])
+        return key[starts], np.diff(np.concatenate([starts, [len(key)]]))
+
+    ka, na = segments(fs)
+    kb, nb = segments(p.flagseg)
+    if np.array_equal(ka, kb) and np.array_equal(na, nb):
+        _compare_with_oracle([spec], [of], DEFAULT_VP, dict(avoid_obstacles=True), xy_tol=1e-9, k_tol=max(K_TOL, 4e-12 / 0.25), v_tol=max(V_TOL, 200 * max(K_TOL, 4e-12 / 0.25)))
+    else:
+        assert np.array_equal(ka, kb)
+        detour = (ka & L.KIND_MASK) == L.KIND_DETOUR
+        assert np.array_equal(na[~detour], nb[~detour]) and int(np.abs(na[detour] - nb[detour]).max()) <= 1
+    b.close()

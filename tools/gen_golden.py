@@ -490,8 +490,42 @@ def tier_mfp():
     return out
 
 
+def tier_fragile():
+    """The fields on which a count hinges on the last bit of a sine (profiles/r05_fragile_tally.txt: rectangles whose inset height is an exact
+    multiple of the working width, under rotation -- the library's fcpp_math.h and the oracle's libm disagree on 2 % of them): the REFERENCE
+    decides.  Per field: its vertices and start point, and the reference's own len(main path), len(headland path)."""
+    rows = []
+    for line in open(os.path.join(os.path.dirname(OUT.rstrip('/')), '..', 'profiles', 'r05_fragile_tally.txt')):
+        if not (line.startswith('MISMATCH') or line.startswith('FRAGILE-AGREE')):
+            continue
+        w = line.split()
+        k = w.index('verts')
+        v = [float.fromhex(x) for x in w[k + 1:k + 9]]
+        start = None
+        if 'start' in w:
+            j = w.index('start')
+            if w[j + 1] == '1':
+                start = (float.fromhex(w[j + 2]), float.fromhex(w[j + 3]))
+        rows.append((line.startswith('MISMATCH'), [(v[0], v[1]), (v[2], v[3]), (v[4], v[5]), (v[6], v[7])], start))
+    out = {'verts': [], 'start': [], 'mismatch': [], 'n_main': [], 'n_head': []}
+    for mism, verts, start in rows:
+        pl = quiet(mlp.TwoLayerPathPlannerV37, vehicle_params=mlp.VehicleParams(), field_vertices=verts, start_point=start)
+        res = quiet(pl.plan_complete_coverage)
+        out['verts'].append(verts)
+        out['start'].append(start if start is not None else (np.nan, np.nan))
+        out['mismatch'].append(int(mism))
+        out['n_main'].append(len(res['main_work']['path']))
+        out['n_head'].append(len(res['headland']['path']))
+    return {k: np.array(v) for k, v in out.items()}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if '--fragile-only' in sys.argv:
+        f = tier_fragile()
+        np.savez_compressed(os.path.join(OUT, 'golden_fragile.npz'), **f)
+        print('golden_fragile.npz:', len(f['n_main']), 'fields,', int(f['mismatch'].sum()), 'of them fields the library and the oracle disagree on')
+        return
     if '--mfp-only' in sys.argv:
         m = tier_mfp()
         np.savez_compressed(os.path.join(OUT, 'golden_mfp.npz'), **m)
@@ -516,6 +550,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, 'golden_plans.npz'), **b)
     np.savez_compressed(os.path.join(OUT, 'golden_cover.npz'), **tier_cover())
     np.savez_compressed(os.path.join(OUT, 'golden_mfp.npz'), **tier_mfp())
+    np.savez_compressed(os.path.join(OUT, 'golden_fragile.npz'), **tier_fragile())
 
     # --- the reference's own published pins (README_en.md:199-215, doc/V3.5.1:109-111)
     assert len(b['cfg1_500x200/main_path']) == 1256, len(b['cfg1_500x200/main_path'])
