@@ -119,6 +119,17 @@ __device__ __forceinline__ int wave_argmax(double f, int idx, double &wf)
     return wi;
 }
 
+// Diagnostic build only (-DFCPP_DIAG_GA: `make diag-ga`, tools/diag_ga.py; never shipped): 10 ns time stamps of the phases of ONE pair's
+// wavefront (pair 1000 of generation 250) and of the two bookkeeping workgroups of the same launch.
+#ifdef FCPP_DIAG_GA
+__device__ unsigned long long g_ga_stamps[48];
+#define GSTAMP(k) do { if (gen == 250 && pair == 1000 && lane == 0) g_ga_stamps[k] = wall_clock64(); } while (0)
+#define BSTAMP(k) do { if (gen == 249 && threadIdx.x == 0) g_ga_stamps[k] = wall_clock64(); } while (0)
+#else
+#define GSTAMP(k) do { } while (0)
+#define BSTAMP(k) do { } while (0)
+#endif
+
 // int32 words of a wavefront's LDS slice before its 2 x 64 tournament candidates: 4 n genes + 2 n presence bytes (one set per child),
 // rounded to 16 bytes
 #define GA_PAIR_LDS_HEAD(n) ((((size_t)(n) * 4 * sizeof(int32_t) + (size_t)(2 * (n)) + 15) / 16) * 4)
@@ -130,6 +141,7 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
     int32_t *const P[2] = { lds, lds + n }, *const Cc[2] = { lds + 2 * n, lds + 3 * n };
     unsigned char *const pres0 = reinterpret_cast<unsigned char *>(lds + 4 * n), *const pres1 = pres0 + n;
     const uint32_t k0 = (uint32_t)cfg.seed, k1 = (uint32_t)(cfg.seed >> 32);
+    GSTAMP(0);
     // (the crossover's presence marks are cleared now, long before they are needed; the slice is a multiple of 16 bytes)
     for (int w = lane; w < (2 * n + 3) / 4; w += 64) lds[4 * n + w] = 0;
     // The two tournaments (GA:189-194): k distinct candidates each, the FIRST maximum wins (np.argmax).
@@ -209,9 +221,11 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
         X = philox((uint32_t)gen, (uint32_t)pair, 3u, 0u, k0, k1);
         if (lane < 2) M = philox((uint32_t)gen, (uint32_t)pair, (uint32_t)(4 + lane), 0u, k0, k1);
     }
+    GSTAMP(1);
     const int32_t *p1g = cur + (int64_t)w0 * n, *p2g = cur + (int64_t)w1 * n;
     for (int i = lane; i < n; i += 64) { P[0][i] = p1g[i]; P[1][i] = p2g[i]; }
     wsync();
+    GSTAMP(2);
     if (unit(X.w[0], X.w[1]) < cfg.crossover_rate) {      // GA:207
         int i, j;
         two_positions(X.w[2], X.w[3], n, i, j);
@@ -221,6 +235,7 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
         for (int i = lane; i < n; i += 64) { Cc[0][i] = P[0][i]; Cc[1][i] = P[1][i]; }
         wsync();
     }
+    GSTAMP(3);
     if (lane < 2) {      // GA:246-250
         if (unit(M.w[0], M.w[1]) < cfg.mutation_rate) {
             int i, j;
@@ -262,6 +277,7 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
         for (; l < m; ++l) total += t[l];
         return total;
     };
+    GSTAMP(4);
     if (conv) return;                      // (the run has converged: nothing is written)
     if (nchunk <= 4) {
         double dd[2][4];
@@ -278,15 +294,18 @@ __device__ __forceinline__ void ga_pair(int lane, int pair, int32_t *lds, int *s
         for (int c = 0; c < 2; ++c)
             if (rowok[c]) for (int i = lane; i < n; i += 64) nxt[(int64_t)(2 * pair + c) * n + i] = Cc[c][i];
         wsync();                           // every lane has read its genes
+        GSTAMP(5);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int b = 0; b < 4; ++b) { const int k = 64 * b + lane; if (k < n) S[c * n + k] = dd[c][b]; }
         wsync();
+        GSTAMP(6);
         if (lane < 2 && (lane == 0 ? rowok[0] : rowok[1])) {
             const double t = sum_left_to_right(S + lane * n, n);
             nxt_dist[2 * pair + lane] = t; nxt_fit[2 * pair + lane] = 1.0 / (t + 1e-6);
         }
+        GSTAMP(7);
         return;
     }
     // long tours: child 0's terms go over the parents' genes, child 1's over them again once child 0's sum is taken (its terms would lie
@@ -427,29 +446,51 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
         __shared__ int q_i[GA_ELITE_CAND];
         __shared__ int q_n;
         const int E = cfg.elite_size;
+        __shared__ int q_rank[GA_ELITE_CAND];
         if (tid == 0) q_n = 0;
+        if (tid < GA_ELITE_CAND) q_rank[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < pop; i += SB) {
-            const double f = s_fit[i];
-            if (f > thr_prev || i >= pop - E) {
-                const int pos = atomicAdd(&q_n, 1);
-                if (pos < GA_ELITE_CAND) { q_f[pos] = f; q_i[pos] = i; }
+        // (the candidates of a wavefront take their places together: a ballot, one addition to the counter per wavefront -- a candidate a
+        // lane, each with an atomic of its own on the one counter, was a microsecond of serialised LDS atomics)
+        for (int i0 = 0; i0 < pop; i0 += SB) {
+            const int i = i0 + tid;
+            const double f = i < pop ? s_fit[i] : 0.0;
+            const bool is_c = i < pop && (f > thr_prev || i >= pop - E);
+            const unsigned long long m = __ballot(is_c);
+            if (m != 0ull) {
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&q_n, __popcll(m));
+                base = __shfl(base, 0);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (is_c && pos < GA_ELITE_CAND) { q_f[pos] = f; q_i[pos] = i; }
             }
         }
         __syncthreads();
         const int C = q_n;
         if (C >= E && C <= GA_ELITE_CAND) {
-            if (tid < C) {
-                const double f = q_f[tid];
-                const int i = q_i[tid];
-                int rank = 0;
-                for (int u = 0; u < C; ++u) {
+            // every candidate's rank = the candidates that precede it: the C x C comparisons spread over all 1024 threads (thread t: candidate
+            // t % Cp against every (SB / Cp)-th other), the partial counts met in LDS -- one candidate per thread walking all C others was
+            // C dependent LDS round trips, 2.5 of the role's 9.3 us (profiles/r05_ga_phases.txt)
+            int Cp = 1;
+            while (Cp < C) Cp <<= 1;                      // (a power of two <= 256: SB / Cp threads per candidate)
+            const int c = tid & (Cp - 1), part = tid / Cp, nparts = SB / Cp;
+            if (c < C) {
+                const double f = q_f[c];
+                const int i = q_i[c];
+                int cnt = 0;
+                for (int u = part; u < C; u += nparts) {
                     const double uf = q_f[u];
                     const int ui = q_i[u];
-                    rank += (uf > f || (uf == f && ui > i)) ? 1 : 0;
+                    cnt += (uf > f || (uf == f && ui > i)) ? 1 : 0;
                 }
-                if (rank < E) s_pick[rank] = i;
-                if (rank == E - 1 && !conv) state->elite_thr = f;
+                if (cnt) atomicAdd(&q_rank[c], cnt);
+            }
+            __syncthreads();
+            if (tid < C) {
+                const int rank = q_rank[tid];
+                if (rank < E) s_pick[rank] = q_i[tid];
+                if (rank == E - 1 && !conv) state->elite_thr = q_f[tid];
             }
             __syncthreads();
             if (conv) return;
@@ -594,16 +635,22 @@ __global__ __launch_bounds__(SB) void k_ga_generation(int n, int pop, const doub
     const int conv = __atomic_load_n(&state->converged, __ATOMIC_RELAXED);
     if (blockIdx.x == 0) {
         if (conv) return;
+        { const int gen_ = gen; (void)gen_; }
+        BSTAMP(16);
         ga_stats_elite<1>(dyn_lds, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen - 1, state, best_route, hist, 0);
+        BSTAMP(17);
         return;
     }
     if (blockIdx.x == 1) {
+        BSTAMP(18);
         ga_stats_elite<2>(dyn_lds, n, pop, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen - 1, state, best_route, hist, conv);
+        BSTAMP(19);
         return;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pair = (blockIdx.x - 2) * GA_PAIRS_PER_WG + wave;
     if (wave >= GA_PAIRS_PER_WG || pair >= pop / 2 || gen >= cfg.max_generations) return;
+    GSTAMP(8);
     ga_pair(lane, pair, reinterpret_cast<int32_t *>(dyn_lds) + (size_t)wave * pair_lds_ints, s_w[wave], n, pop, D, cur, cur_fit, nxt, nxt_fit,
             nxt_dist, cfg, gen, conv);
 }
@@ -684,3 +731,10 @@ int launch_ga_generation(hipStream_t st, int n, int pop, const double *D, const 
 }
 
 }  // namespace fcpp
+
+#ifdef FCPP_DIAG_GA
+extern "C" __attribute__((visibility("default"))) int fcpp_diag_ga_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fcpp::g_ga_stamps), sizeof(fcpp::g_ga_stamps));
+}
+#endif
