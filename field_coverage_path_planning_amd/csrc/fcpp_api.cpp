@@ -1076,6 +1076,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     // planner cuts it -- host-built and device-built tables stay equal byte for byte
     tc.closed_cut = opt->sample_spacing == 0.0 && opt->obstacle_mode == FCPP_OBSTACLES_FLAG && tc.wave_points == CUT_WAVE_LANES && !getenv("FCPP_WINDOW_CUT");
     tc.cut = make_cut_consts(*b->templates, false, turn_quiet, tc.wave_factor, tc.two_a, tc.u_cap, tc.c_line, tc.fence_margin, b->cst);
+    if (getenv("FCPP_DENSE_SPAN") && atoll(getenv("FCPP_DENSE_SPAN")) <= 0) tc.span_line_max = 64;          // (round 4's runs: the A/B)
     BatchTiler tiler;
     ImageLayout &lay = b->lay;
     rc = tiler.plan(b->hp, tc, obstacles, lay, err);

@@ -68,6 +68,12 @@ __global__ __launch_bounds__(64) void k_plan_fields(int64_t n, PlanConsts pc, co
 // time), neighbours come by lane moves inside the quad.  Every value is computed by the same float64 operations in the same order as in
 // plan_field_t (sums over the four vertices run 0, 1, 2, 3 on gathered values): the records are equal byte for byte to the host's
 // (tests/test_gpu_devplan.py), and FCPP_PLAN_SERIAL=1 keeps the one-thread kernel as the A/B.
+#ifdef FCPP_DIAG_TILE
+__device__ unsigned long long g_plan_stamps[16];
+#define PSTAMP(k) do { if (field == 1000 && (threadIdx.x & 15) == 0) g_plan_stamps[k] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
 namespace p16 {
 __device__ __forceinline__ double qget(double v, int k) { return __shfl(v, (int)((threadIdx.x & ~3u) | (unsigned)k)); }          // lane k of this lane's quad
 __device__ __forceinline__ int qgeti(int v, int k) { return __shfl(v, (int)((threadIdx.x & ~3u) | (unsigned)k)); }
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
     const int lane = threadIdx.x, l16 = lane & 15, i = lane & 3, lp = l16 >> 2;
     const int64_t field = (int64_t)blockIdx.x * 4 + (lane >> 4);
     if (field >= n) return;
+    PSTAMP(0);
     const fcpp_field f = fin[field];
     if (check_obstacles && l16 == 0 && (f.n_obstacles < 0 || f.obstacle_first < 0 || (f.n_obstacles > 0 && f.obstacle_first + f.n_obstacles > n_polys)))
         atomicMax(reinterpret_cast<unsigned long long *>(totals + PC_COLS + PF_BAD_OBSTACLES), (unsigned long long)gen);
@@ -144,6 +151,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         const bool convex = (pos == 0 || neg == 0) && (pos + neg) > 0;
         if (qballot(fin_i) != 0xFu || !convex) P16_FAIL(FCPP_EUNSUPPORTED);
     }
+    PSTAMP(1);
     // ---- __init__ (MLP:109-135, 137-163, 310, 322-343)
     const double bminx = qmin_seq(qx), bmaxx = qmax_seq(qx), bminy = qmin_seq(qy), bmaxy = qmax_seq(qy);
     const double L = f.from_vertices ? (bmaxx - bminx) : f.vx[1];
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         for (int k = 0; k < 4; ++k) { const double dk = qget(d, k); if (k == 0 || dk < best) { best = dk; sci = k; } }
     }
     if (w0) { in.start_corner = sci; }
+    PSTAMP(2);
     // ---- layer 1 frame (MLP:591-611, 670-718): mitre_of(q), inset by hw
     double acx, acy;
     const double sgn = area_centroid_q(qx, qy, i, acx, acy) > 0 ? 1.0 : -1.0;
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         const double ar = fabs(area_centroid_q(mqx, mqy, i, cx, cy));
         if (!ok || ar < 1.0) P16_FAIL(FCPP_EINVAL);
     }
+    PSTAMP(3);
     const double e0x = f.vx[1] - f.vx[0], e0y = f.vy[1] - f.vy[0];
     const double rot = (e0x == 0.0 && e0y == 0.0) ? 0.0 : atan2_fd(e0y, e0x);
     if (w0) { in.rotation_angle = rot; }
@@ -231,6 +241,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         if (sx > (min_x + max_x) / 2) start_from_right = 1;
     }
     if (w0) { in.reverse_order = reverse_order; in.start_from_right = start_from_right; }
+    PSTAMP(4);
     // ---- layer 1 sizes (MLP:736-739)
     const double lsx = min_x + R, lex = max_x - R;
     const double Pd = (max_y - min_y) / W;
@@ -254,6 +265,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
     if (w0) { df.P = (int32_t)P; df.n_line = (int32_t)n_line; df.n_turn = (int32_t)n_turn; }
     if (w0) { df.reverse_order = reverse_order; df.start_from_right = start_from_right; df.rotated = rotated; }
     if (w0) { df.turn_model = opt.turn_model; }
+    PSTAMP(5);
     // geofence half-planes: edge i
     double gex, gey, geo;
     {
@@ -270,6 +282,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
     if (w0) { df.eo[0] = geo0; df.eo[1] = geo1; df.eo[2] = geo2; df.eo[3] = geo3; }
 
     // ---- layer 2 (MLP:898-1084): quad lp = loop l0 + lp, lane i = side i of the loop (its straight, then the turn at its end)
+    PSTAMP(6);
     const int num_loops = (int)ceil(hw / W);
     if (w0) { in.n_loops = num_loops; }
     int64_t pos = n_main;
@@ -331,6 +344,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
             if (ds > 0) nr = n_for_length(rlen, ds);
             else { nr = (int64_t)(rlen / 0.5); if (nr < 10) nr = 10; }
         }
+        if (l0 == 0) PSTAMP(7);
         // the first failure in path order decides (rows of a chunk are loops in order, lanes of a quad sides in order); within a side the
         // order is inset (whole loop: its lane 0 first), counts, gap -- one code per lane, the lowest lane wins
         {
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         const int32_t prims_before = prims_incl - my_prims;
         const int64_t pts_chunk = ((int64_t)rgeti((int)(pts_incl >> 32), 15) << 32) | (uint32_t)rgeti((int)(pts_incl & 0xffffffff), 15);
         const int32_t prims_chunk = rgeti(prims_incl, 15);
+        if (l0 == 0) PSTAMP(8);
         const double sxp = qget(cx, sci), syp = qget(cy, sci);          // the loop's start point (a lane move: outside the branches of single lanes)
         if (act) {
             int64_t at = pos + pts_before;
@@ -402,6 +417,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
                 }
             }
         }
+        if (l0 == 0) PSTAMP(9);
         // what the row's lane 0 needs of this chunk: the reverse-fill counts (loop 0), the first and the last point of the headland
         if (l0 == 0) {
             const int my_nr = (add_rev && loop == 0) ? (int)nr : 0;
@@ -418,6 +434,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         pos += pts_chunk;
         prim_pos += prims_chunk;
     }
+    PSTAMP(10);
     if (w0) { in.n_reverse[0] = nrev0; in.n_reverse[1] = nrev1; in.n_reverse[2] = nrev2; in.n_reverse[3] = nrev3; }
     if (w0) { in.n_head = pos - n_main; }
     if (w0 && has_start) {   // MLP:437-441
@@ -450,6 +467,7 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
         if (w0) df.span_inside = all_in ? 1 : 0;
     }
     finish(pos, prim_pos, prim_pos);
+    PSTAMP(11);
 #undef P16_FAIL
 }
 
@@ -1402,6 +1420,10 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
 extern "C" __attribute__((visibility("default"))) int fcpp_diag_tile_stamps(unsigned long long *out)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_stamps), sizeof g_tile_stamps);
+}
+extern "C" __attribute__((visibility("default"))) int fcpp_diag_plan_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_plan_stamps), sizeof g_plan_stamps);
 }
 extern "C" __attribute__((visibility("default"))) int fcpp_diag_fill_stamps(unsigned long long *out)
 {

@@ -16,7 +16,7 @@ __device__ unsigned g_sparse_diag[SP_DIAG_SLOTS * 16];     // one row per wave t
 __device__ unsigned g_sparse_diag_next;
 __device__ int g_sparse_stop = 99;                         // leave sparse_tile2 after this section (instruction counts per section: rocprofv3 --pmc)
 template <class T> __device__ __forceinline__ void sp_pin(T &v) { asm volatile("" : "+v"(v)); }
-#define SP_STAMP_S(k, sval) do { int s_ = (int)(sval); asm volatile("" : "+s"(s_)); const unsigned long long t_now_ = __builtin_readcyclecounter(); \
+#define SP_STAMP_S(k, sval) do { int s_ = __builtin_amdgcn_readfirstlane((int)(sval)); asm volatile("" : "+s"(s_)); const unsigned long long t_now_ = __builtin_readcyclecounter(); \
                                 t_sec_[k] = (unsigned)(t_now_ - t_prev_) + (unsigned)(s_ & 0); t_prev_ = t_now_; } while (0)
 template <class T, class... R> __device__ __forceinline__ void sp_pin(T &v, R &...r) { sp_pin(v); sp_pin(r...); }
 // (the values a section produces go through an empty volatile asm, so the compiler can move their computation neither behind the

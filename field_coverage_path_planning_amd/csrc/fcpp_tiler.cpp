@@ -299,10 +299,10 @@ struct FieldTiler {
             // the line's last point: a skipped step; the jump back from the turn's end is too long to bind): all
             // complete passes (line + turn) form ONE quiet span, whatever the sampling.  The last line ends at the
             // seam to the headland layer: it is cut like any other straight, without a margin at its start.
-            // Dense sampling keeps lines and turns as runs of their own (cheaper per point: no pass decode); the span is for
-            // short lines -- the reference's own sampling has 2 points per line and 20 per turn.
+            // (Rounds 2-4 kept lines and turns as runs of their own at dense sampling -- no pass decode per point -- and the span for
+            // short lines only; TileConsts.span_line_max says where that still holds.)
             int64_t first_idx = 0;
-            const bool span = turn_quiet && P >= 2 && n_line - need1 < 64 && (P - 1) * per < (int64_t)0x7fffffff;
+            const bool span = turn_quiet && P >= 2 && n_line - need1 < (F.obs_count > 0 ? (int64_t)64 : tc.span_line_max) && (P - 1) * per < (int64_t)0x7fffffff;
             if (span) {
                 const int64_t S = (P - 1) * per;
                 emit_quiet(0, S, 4, 0, 0);
@@ -583,7 +583,8 @@ int BatchTiler::plan_impl(const HostPlan &hp, const TileConsts &tc, const fcpp_p
             const int k = (int)(fi - pb.f0);
             bt.tile0[k] = (int64_t)bt.tiles.size(); bt.w0[k] = (int64_t)bt.wtiles.size();
             const int64_t proto = hp.same_as.empty() ? -1 : hp.same_as[(size_t)fi];
-            if (proto >= 0) ft.copy_field(fi, proto);
+            // (equal fields may differ in their obstacles, which do not change the plan -- but whether the passes form a span: span_line_max)
+            if (proto >= 0 && (hp.fields[(size_t)fi].obs_count > 0) == (hp.fields[(size_t)proto].obs_count > 0)) ft.copy_field(fi, proto);
             else ft.tile_field(fi);
             bt.tile0[k + 1] = (int64_t)bt.tiles.size(); bt.w0[k + 1] = (int64_t)bt.wtiles.size();
             ft.derive_field(fi, k, bt.tile0[k], bt.tile0[k + 1]);

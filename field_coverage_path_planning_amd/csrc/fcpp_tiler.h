@@ -34,6 +34,12 @@ struct TileConsts {
     int64_t reduce_wg_max = 1024;             // statistic entries one workgroup reduces; beyond: 64 workgroups + join
     bool closed_cut = false;                  // reference sampling: the general stretch of a field with a closed-form span is cut by fcpp_cutfn.h (as the device planner cuts it)
     CutConsts cut = {};                       // ... with these constants (host copies of the templates and their chord tables)
+    // a field's complete passes (line + closed-form U-turn) form ONE span -- one run, one statistics entry, chunks decoded by (pass, offset) -- when
+    // its lines' quiet zones are shorter than span_line_max; fields with obstacles keep 64 (their lines and turns stay runs of their own: a line's
+    // chunks test the obstacles once per line, a span's chunks pair by pair -- cfg3: 0.36 vs 0.43 ms a step).  Round 5: unlimited for fields without
+    // obstacles, whatever the sampling -- 2P - 1 runs per field become one (cfg2 at 0.5 m: a 20 MB image -> 6 MB, the plan call 3.1 -> 2.4 ms,
+    // the step itself 1.23 -> 1.10 ms); FCPP_DENSE_SPAN=0 keeps round 4's runs for the A/B.
+    int64_t span_line_max = INT64_MAX;
     bool device_chunks = false;               // the chunk lists of k_plan_quiet are expanded on the device from chunk groups (fcpp_batch_create; false: written by the host, the checker)
 };
 

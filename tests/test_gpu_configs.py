@@ -207,10 +207,14 @@ def test_cfg4_ga_population_4096_vs_oracle():
     assert np.isnan(dd[7]) and np.isfinite(np.delete(dd, 7)).all()
 
 
-def test_one_path_with_more_than_4096_statistic_entries():
-    """A single field of 2900 passes: its path holds ~5800 closed-form runs plus the general tiles, more than a workgroup takes in
-    k_reduce_stats -- the sliced reduction (64 workgroups + join).  Whole path against the oracle, statistics included; mixed with
-    small fields so that every class of the reduction runs in one batch."""
+@pytest.mark.parametrize('runs', ['one run per line and turn', 'one span'])
+def test_one_path_with_more_than_4096_statistic_entries(runs, monkeypatch):
+    """A single field of 2900 passes.  With its lines and U-turns as runs of their own (rounds 2-4; FCPP_DENSE_SPAN=0, and still the rule
+    for fields with obstacles) its path holds ~5800 closed-form runs plus the general tiles, more than a workgroup takes in
+    k_reduce_stats -- the sliced reduction (64 workgroups + join); as round 5 cuts it, all complete passes are ONE span.  Whole path
+    against the oracle either way, statistics included; mixed with small fields so that every class of the reduction runs in one batch."""
+    if runs != 'one span':
+        monkeypatch.setenv('FCPP_DENSE_SPAN', '0')
     big = dict(L=120.0, H=9300.0)
     small = [dict(L=500.0, H=200.0), dict(L=260.0, H=140.0), dict(L=900.0, H=700.0)]
     for tm, sp in ((0, 0.1), (1, 0.2)):
@@ -239,5 +243,5 @@ def test_one_path_with_more_than_4096_statistic_entries():
         st0 = res0.stats()
         np.testing.assert_allclose(st0['main_len_m'], st['main_len_m'], rtol=1e-12)
         np.testing.assert_allclose(st0['head_time_s'], st['head_time_s'], rtol=1e-10)
-        assert batch.reduce_classes()[3] == 1            # the long path went through the sliced reduction
+        assert batch.reduce_classes()[3] == (0 if runs == 'one span' else 1)            # the long path went through the sliced reduction
         batch.close()

@@ -2,7 +2,7 @@
 """Diagnostic only: where the cycles of a wave tile go.  Needs the -DFCPP_DIAG_SPARSE build (`make -C field_coverage_path_planning_amd/csrc
 diag-sparse` -> build/libfcpp_diag_sparse.so), which records shader-clock cycles per section of sparse_tile2 (fcpp_sparse2_fn.h) for every
 wave tile.  A wavefront shares its SIMD with the others resident there, so a section's cycles are its share of the wave's life, not
-its instruction count.  Usage: FCPP_LIBRARY=build/libfcpp_diag_sparse.so python tools/diag_sparse.py [headline|cfg2_ref]"""
+its instruction count.  Usage: FCPP_LIBRARY=build/libfcpp_diag_sparse.so python tools/diag_sparse.py [headline|cfg2_ref|cfg5]"""
 import ctypes
 import os
 import sys
@@ -14,7 +14,8 @@ from field_coverage_path_planning_amd import _lib, engine as E, workloads as WL 
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'headline'
 table = {'headline': lambda: E.FieldTable.from_rectangles(WL.cfg1_batch(4096)),
-         'cfg2_ref': lambda: E.FieldTable.from_rectangles(WL.cfg2_rectangles())}[which]()
+         'cfg2_ref': lambda: E.FieldTable.from_rectangles(WL.cfg2_rectangles()),
+         'cfg5': lambda: E.FieldTable.from_vertices(WL.cfg5_parallelograms())}[which]()
 lib = _lib.load()
 fn = lib.fcpp_diag_sparse
 fn.argtypes = [ctypes.c_void_p, ctypes.c_longlong]

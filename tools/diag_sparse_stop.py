@@ -12,7 +12,8 @@ from field_coverage_path_planning_amd import _lib, engine as E, workloads as WL 
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'headline'
 table = {'headline': lambda: E.FieldTable.from_rectangles(WL.cfg1_batch(4096)),
-         'cfg2_ref': lambda: E.FieldTable.from_rectangles(WL.cfg2_rectangles())}[which]()
+         'cfg2_ref': lambda: E.FieldTable.from_rectangles(WL.cfg2_rectangles()),
+         'cfg5': lambda: E.FieldTable.from_vertices(WL.cfg5_parallelograms())}[which]()
 lib = _lib.load()
 lib.fcpp_diag_sparse_stop.argtypes = [ctypes.c_int]
 lib.fcpp_diag_sparse_stop.restype = ctypes.c_int

@@ -20,6 +20,9 @@ for r in range(5):
     out2 = (C.c_uint64 * 40)()
     L.load().fcpp_diag_fill_stamps(out2)
     fs = list(out2)
+    out3 = (C.c_uint64 * 16)()
+    L.load().fcpp_diag_plan_stamps(out3)
+    ps = list(out3)
     b.close()
 names = {0: 'entry', 1: 'field read', 2: 'staged', 36: 'cut done', 37: 'decisions', 38: 'counts written'}
 for k in range(4):
@@ -39,3 +42,12 @@ prev = fs[0]
 for k in sorted(fn):
     print(f'{fn[k]:36s} +{(fs[k] - prev) * 10:6d} ns   at {(fs[k] - fs[0]) * 10:6d} ns')
     prev = fs[k]
+
+print('the planner (k_plan_fields16) of the same field:')
+pn = {0: 'entry', 1: 'field read, convexity', 2: 'bounds, corner angles, shape, start corner', 3: 'mitres, inset by the headland width', 4: 'rotation (atan2, sincos), frame', 5: 'layer 1 sizes and record',
+      6: 'geofence half-planes', 7: 'loops 0-3: inset, corner exits, reverse fill', 8: 'failure vote, prefix over the row', 9: 'primitives written', 10: 'loop over', 11: 'record finished'}
+prev = ps[0]
+for k in sorted(pn):
+    if ps[k]:
+        print(f'{pn[k]:48s} +{(ps[k] - prev) * 10:6d} ns   at {(ps[k] - ps[0]) * 10:6d} ns')
+        prev = ps[k]

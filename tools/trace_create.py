@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A plan call end to end, repeated: wall time of create / alloc / run / sync, median over the repetitions after the first.
-Usage: python tools/trace_create.py [reps] [headline|cfg2_ref|cfg5|cfg1_clothoid]   (FCPP_NO_PIN=1: pageable field records)"""
+Usage: python tools/trace_create.py [reps] [headline|cfg2_ref|cfg2_0.5|cfg2_0.1|cfg3|cfg3_avoid|cfg5|cfg1_clothoid|cfg1_clothoid_dense]   (FCPP_NO_PIN=1: pageable field records)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,8 +11,17 @@ from field_coverage_path_planning_amd import workloads as WL
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 what = sys.argv[2] if len(sys.argv) > 2 else 'headline'
 opt = E.make_options()
-if what == 'cfg2_ref':
+if what in ('cfg2_ref', 'cfg2_0.5', 'cfg2_0.1'):
     table = E.FieldTable.from_rectangles(WL.cfg2_rectangles())
+    if what != 'cfg2_ref':
+        opt = E.make_options(1, float(what[5:]))
+elif what in ('cfg3', 'cfg3_avoid'):
+    (L_, H_), obst_ = WL.cfg3_field()
+    table = E.FieldTable.from_specs([E.FieldSpec(field_length=L_, field_width=H_, obstacles=obst_)])
+    opt = E.make_options(1, 0.05, avoid_obstacles=(what == 'cfg3_avoid'))
+elif what == 'cfg1_clothoid_dense':
+    table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (4096, 1)))
+    opt = E.make_options(1, 0.1)
 elif what == 'cfg5':
     table = E.FieldTable.from_vertices(WL.cfg5_parallelograms())
 else:
@@ -28,7 +37,6 @@ stream = torch.cuda.Stream()
 torch.cuda.set_stream(stream)
 rows = []
 batch = None
-one_call = os.environ.get('FCPP_ONE_CALL', '1') != '0'
 one_call = os.environ.get('FCPP_ONE_CALL', '1') != '0'
 for r in range(reps):
     if batch is not None:
