@@ -197,8 +197,11 @@ struct fcpp_ctx {
     size_t verify_scratch_cap = 0;
     int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values: the scans of the counting phase write them here
     int64_t plan_gen = 0;                           // generation number of the last counting phase (PlanFlag, fcpp_devplan.h)
-    hipEvent_t ev_plan = nullptr; bool ev_plan_set = false;
-    hipEvent_t ev_totals = nullptr;                 // behind the counting phase's last scan (a speculative setup waits for it, not for the stream)
+    // the stream the last device-side setup was enqueued on (its fill pass may still read the scratch): a setup on ANOTHER stream records
+    // ev_plan there and waits for it -- lazily, when that other stream shows up: an event recorded between two kernels of the plan call
+    // costs 5 us of device time between them (round 5: the three records of a plan call were 16 of its 158 us)
+    hipEvent_t ev_plan = nullptr; hipStream_t plan_stream = nullptr; bool plan_pending = false;
+    hipEvent_t ev_chunk[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // a large batch's counting pass in chunks beside its planner (launch_devplan_count)
     // the output arena (fcpp_ctx_reserve_outputs): ONE allocation of 4 x pitch + lane bytes; array k of every batch's outputs lies in lane k
     // (lanes `pitch` apart), placed first-fit among the live allocations of the lane -- all five arrays of an allocation at the same offset
     void *arena = nullptr; size_t arena_pitch = 0, arena_lane = 0;
@@ -250,9 +253,30 @@ struct fcpp_batch {
     void note_stream(hipStream_t s) { if (std::find(used_streams.begin(), used_streams.end(), s) == used_streams.end()) used_streams.push_back(s); }
     // the device-side setup returns with its last kernels still in the stream it was enqueued on: whoever reads the tables on ANOTHER stream
     // (a caller that re-binds the context's stream between create and run) waits for this event first
+    // (the event is recorded on the setup's stream when such a stream first shows up -- everything enqueued there so far, the setup included,
+    // lies before it -- not by the setup itself: see fcpp_ctx::ev_plan)
     hipStream_t setup_stream = nullptr;
+    bool setup_pending = false;
     hipEvent_t ev_setup = nullptr;
-    hipError_t wait_setup(hipStream_t s) const { return (ev_setup && s != setup_stream) ? hipStreamWaitEvent(s, ev_setup, 0) : hipSuccess; }
+    std::vector<hipStream_t> setup_seen;           // streams already ordered behind the setup
+    hipError_t wait_setup(hipStream_t s)
+    {
+        if (!setup_pending || s == setup_stream || std::find(setup_seen.begin(), setup_seen.end(), s) != setup_seen.end()) return hipSuccess;
+        if (!ev_setup) {
+            if (!ctx->ev_pool.empty()) { ev_setup = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+            else { const hipError_t e = hipEventCreateWithFlags(&ev_setup, hipEventDisableTiming); if (e != hipSuccess) return e; }
+        }
+        hipError_t e = hipEventRecord(ev_setup, setup_stream);
+        if (e != hipSuccess) {          // (the setup's stream is gone: whatever ran there has been drained or is drained now)
+            (void)hipGetLastError();
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) setup_pending = false;
+            return e;
+        }
+        e = hipStreamWaitEvent(s, ev_setup, 0);
+        if (e == hipSuccess) setup_seen.push_back(s);
+        return e;
+    }
     ~fcpp_batch() { for (hipEvent_t e : events) (void)hipEventDestroy(e); if (ev_setup) (void)hipEventDestroy(ev_setup); }
 };
 
@@ -413,7 +437,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->plan_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->plan_scratch); }
     if (c->arena) { (void)hipDeviceSynchronize(); (void)hipFree(c->arena); }
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
-    if (c->ev_totals) (void)hipEventDestroy(c->ev_totals);
+    for (hipEvent_t e : c->ev_chunk) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
     if (c->verify_scratch) (void)hipFree(c->verify_scratch);
@@ -673,6 +697,7 @@ double ms_since(std::chrono::steady_clock::time_point t0)
 }
 
 namespace {
+thread_local double g_trace_totals_ms = 0.0;      // (FCPP_TRACE_PLAN: when the last device setup saw its totals, ms since try_device_setup began)
 constexpr int kNotOnDevice = 1;      // try_device_setup: this batch is the host's (reason in err)
 
 // pointers of the fused pipeline's tables inside the slab
@@ -719,8 +744,12 @@ int take_slab(fcpp_ctx *c, fcpp_batch *b, std::string &err)
 // the context's planner scratch for n fields (grow-only), ordered behind the last fill pass that read it
 int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, DevPlanScratch &s, std::string &err)
 {
-    if (!c->ev_plan) DEVCHK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
-    if (c->ev_plan_set) DEVCHK(hipStreamWaitEvent(st, c->ev_plan, 0));       // (the previous batch's fill pass may still read the scratch)
+    if (c->plan_pending && c->plan_stream != st) {       // (the previous batch's fill pass, on another stream, may still read the scratch)
+        if (!c->ev_plan) DEVCHK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
+        if (hipEventRecord(c->ev_plan, c->plan_stream) == hipSuccess) DEVCHK(hipStreamWaitEvent(st, c->ev_plan, 0));
+        else { (void)hipGetLastError(); DEVCHK(hipDeviceSynchronize()); }        // (that stream is gone)
+        c->plan_pending = false;
+    }
     DevPlanScratch off;
     const size_t need = devplan_scratch_layout(n_fields, max_prims, &off);
     if (c->plan_scratch_cap < need) {
@@ -789,6 +818,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     if (pc.max_prims > DEVPLAN_PRIMS_CAP) { err = "too many headland loops for the device planner"; return kNotOnDevice; }
     hipStream_t st = c->stream;
     auto t0 = std::chrono::steady_clock::now();
+    const auto t_call = t0;
 
     // templates on the host (closed-form test); a fresh set is on its way back
     if (fresh_templates) { DEVCHK(hipStreamSynchronize(st)); fresh_templates = false; }
@@ -893,14 +923,16 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         bind_tables(b);
         if ((rc = upload_obstacles()) != FCPP_OK) return rc;
     }
-    int lrc = launch_devplan_count(st, n_fields, pc, tc, s, dev_fields, n_polys, obstacles != nullptr, tot);
+    if (!spec && c->side && !c->ev_chunk[0])
+        for (hipEvent_t &e : c->ev_chunk) DEVCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    tc.f0 = 0; tc.f1 = n_fields;
+    int lrc = launch_devplan_count(st, n_fields, pc, tc, s, dev_fields, n_polys, obstacles != nullptr, tot, spec ? nullptr : c->side, c->ev_chunk, 5);
     if (lrc) { (void)hipStreamSynchronize(st); err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }   // (drained: the caller's pinned records may still be read)
     if (spec) {
-        if (!c->ev_totals) DEVCHK(hipEventCreateWithFlags(&c->ev_totals, hipEventDisableTiming));
-        DEVCHK(hipEventRecord(c->ev_totals, st));
         if ((rc = launch_fill()) != FCPP_OK) { (void)hipStreamSynchronize(st); return rc; }
         // (the last scan has written the totals and the flags to `tot`, then the phase's generation number to tot[PX_DONE]: polled -- a word
-        // of the host's own pinned memory, there a microsecond after the kernel wrote it -- with the event as the fallback; the fill pass runs on)
+        // of the host's own pinned memory, there a microsecond after the kernel wrote it -- with the drained stream as the fallback; the fill pass
+        // runs on.  No event behind the scan: a record between two kernels holds the second one back by 5 us)
         {
             volatile int64_t *done = tot + PX_DONE;
             const auto t_poll = std::chrono::steady_clock::now();
@@ -909,8 +941,9 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
                 seen = *done == tc.gen;
                 if (!seen && (spin & 1023) == 1023 && ms_since(t_poll) > 2.0) break;
             }
-            if (!seen) DEVCHK(hipEventSynchronize(c->ev_totals));
+            if (!seen) DEVCHK(hipStreamSynchronize(st));
             std::atomic_thread_fence(std::memory_order_acquire);
+            g_trace_totals_ms = ms_since(t_call);
         }
     } else {
         DEVCHK(hipStreamSynchronize(st));
@@ -960,12 +993,8 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         if ((rc = launch_fill()) != FCPP_OK) return rc;
     }
     tm.image_bytes = (int64_t)((size_t)n_fields * sizeof(fcpp_field) + (lay.n_polys > 0 ? lay.seg - lay.obs_off : 0));
-    DEVCHK(hipEventRecord(c->ev_plan, st));
-    c->ev_plan_set = true;
-    if (!c->ev_pool.empty()) { b->ev_setup = c->ev_pool.back(); c->ev_pool.pop_back(); }
-    else DEVCHK(hipEventCreateWithFlags(&b->ev_setup, hipEventDisableTiming));
-    DEVCHK(hipEventRecord(b->ev_setup, st));
-    b->setup_stream = st;
+    c->plan_stream = st; c->plan_pending = true;
+    b->setup_stream = st; b->setup_pending = true;
     // fcpp_field_info stays on the device until somebody asks (fcpp_batch_info); the stream is NOT drained: a step enqueued next runs
     // right behind the setup
     b->info_dev = T.info;
@@ -1311,13 +1340,18 @@ int fcpp_batch_plan(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *op
     if (!batch || !x || !y || !kappa || !v || !fs) return fail(FCPP_EINVAL, "bad arguments");
     *batch = nullptr; *x = *y = *kappa = *v = nullptr; *fs = nullptr;
     fcpp_batch *b = nullptr;
+    static const bool trace = getenv("FCPP_TRACE_PLAN") != nullptr;      // (diagnostic: the host's side of a plan call, microseconds since its start, to stderr)
+    const auto t_begin = std::chrono::steady_clock::now();
     int rc = fcpp_batch_create(c, veh, opt, n_fields, fields, obstacles, &b);
     if (rc != FCPP_OK) return rc;
+    const double t_create = trace ? ms_since(t_begin) : 0.0;
     const int64_t total = b->hp.total_points;
     rc = fcpp_outputs_alloc(c, total, 0, x, y, kappa, v, fs);
+    const double t_alloc = trace ? ms_since(t_begin) : 0.0;
     if (rc == FCPP_OK) {
         if (!stats && b->slab) stats = reinterpret_cast<fcpp_field_stats *>(static_cast<unsigned char *>(b->slab) + b->lay.own_stats);
         rc = fcpp_batch_run(b, *x, *y, *kappa, *v, *fs, stats, 1);
+        if (trace) fprintf(stderr, "[fcpp] plan call: totals seen %.1f us, create returns %.1f, arrays %.1f, step enqueued %.1f\n", g_trace_totals_ms * 1e3, t_create * 1e3, t_alloc * 1e3, ms_since(t_begin) * 1e3);
         if (rc != FCPP_OK) { const std::string keep = g_err; (void)hipStreamSynchronize(c->stream); (void)fcpp_outputs_free(c, *x); g_err = keep; }
     }
     if (rc != FCPP_OK) {

@@ -51,6 +51,7 @@ struct DevTileConsts {
     double two_a, u_cap, c_line, fence_margin;
     int64_t reduce_wg_max;
     int64_t gen;                  // this counting phase's generation number (> 0)
+    int64_t f0, f1;               // counting pass: the fields [f0, f1) (launch_devplan_count sets them: a large batch is counted in chunks)
     CutConsts cut;                // the closed-form cut (fcpp_cutfn.h), templates and chord tables on the device
 };
 
@@ -94,8 +95,10 @@ static_assert(DEVPLAN_KEEP_ROWS >= DEVPLAN_KEEP_TILES, "the window cut keeps its
 // phase 1: plan + count.  Enqueues k_plan_fields, the scans and the counting pass; afterwards totals[] holds the sums and the flags, and so
 // does totals_host (pinned host memory the device can write, or null) once the stream has got there: the scans write it themselves.
 // fields: the records as the device reaches them (s.fields_in after a copy, or the caller's pinned memory).
+// side, ev[n_ev]: a second stream and events for the experiment FCPP_COUNT_CHUNKS (a large batch's counting pass in chunks beside its planner's:
+// measured slower, see launch_devplan_count); null / 0: one stream.
 int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, const fcpp_field *fields,
-                         int64_t n_polys, int check_obstacles, int64_t *totals_host);
+                         int64_t n_polys, int check_obstacles, int64_t *totals_host, hipStream_t side = nullptr, hipEvent_t *ev = nullptr, int n_ev = 0);
 // sizing only (fcpp_plan_points): k_plan_fields without primitives; counts[PC_POINTS][field] = points of the field
 int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s, const fcpp_field *fields);
 // phase 2: the tables.  `bases` / `totals` as phase 1 left them.

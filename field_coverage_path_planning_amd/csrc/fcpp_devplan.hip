@@ -99,14 +99,15 @@ __device__ __forceinline__ double area_centroid_q(double px, double py, int i, d
 }
 }  // namespace p16
 
+// (f0, f1: the fields [f0, f1) of the batch's n -- large batches are planned in chunks, launch_devplan_count)
 __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, const fcpp_field *__restrict__ fin, fcpp_field_info *__restrict__ info,
                                                       DevField *__restrict__ ftmp, DevPrim *__restrict__ ptmp, int64_t *__restrict__ counts,
-                                                      int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles, int64_t gen)
+                                                      int64_t *__restrict__ totals, int64_t n_polys, int check_obstacles, int64_t gen, int64_t f0, int64_t f1)
 {
     using namespace p16;
     const int lane = threadIdx.x, l16 = lane & 15, i = lane & 3, lp = l16 >> 2;
-    const int64_t field = (int64_t)blockIdx.x * 4 + (lane >> 4);
-    if (field >= n) return;
+    const int64_t field = f0 + (int64_t)blockIdx.x * 4 + (lane >> 4);
+    if (field >= f1) return;
     PSTAMP(0);
     const fcpp_field f = fin[field];
     if (check_obstacles && l16 == 0 && (f.n_obstacles < 0 || f.obstacle_first < 0 || (f.n_obstacles > 0 && f.obstacle_first + f.n_obstacles > n_polys)))
@@ -513,6 +514,19 @@ __device__ __forceinline__ int64_t wg_incl_scan(int64_t v, int64_t *lds /* 4 */,
     return v + pre;
 }
 
+// what depends on where a field's span lies in the batch arrays (pt_off): its 512-point chunks, whether its field's own workgroup can write
+// it (at most FUSED_SPAN_CHUNKS of them), the alternatives the host chooses between once it has the totals
+__device__ __forceinline__ void span_counts(int64_t pt_off, int64_t S, bool is_work, bool fuse_possible, int64_t &c_span, int64_t &c_span_f,
+                                            int64_t &c_work_span_pts, int64_t &c_unfusable)
+{
+    c_span = c_span_f = c_work_span_pts = c_unfusable = 0;
+    if (S <= 0) return;
+    const int64_t n_chunks = ((pt_off % TILE_POINTS) + S + TILE_POINTS - 1) / TILE_POINTS;
+    const bool fusable = is_work && n_chunks <= FUSED_SPAN_CHUNKS;
+    const int64_t fused = (fusable && fuse_possible) ? S : 0;
+    c_span = n_chunks; c_span_f = fused > 0 ? 0 : n_chunks; c_work_span_pts = fused; c_unfusable = (is_work && !fusable) ? 1 : 0;
+}
+
 // phase A: sums of blocks of 1024 fields; grid (blocks, columns)
 __global__ __launch_bounds__(256) void k_scan_block_sums(int64_t n, int c0, const int64_t *__restrict__ counts, int64_t *__restrict__ blk_sums, int64_t nblk)
 {
@@ -544,8 +558,10 @@ __global__ __launch_bounds__(256) void k_scan_block_bases(int c0, int64_t *__res
     if (threadIdx.x == 0) { totals[col] = carry; publish_total(totals, mirror, col, carry, with_flags && blockIdx.x == 0); if (with_flags) publish_done(totals, mirror, (int)gridDim.x, done_gen); }
 }
 // phase C: exclusive scan inside each block of 1024 fields + the block's base; grid (blocks, columns)
-__global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int64_t *__restrict__ counts, const int64_t *__restrict__ blk_sums,
-                                                    int64_t nblk, int64_t *__restrict__ bases)
+// derive: the column of the points also makes the columns that depend on the fields' point offsets (span_counts), from the offsets it has just
+// computed -- the counting pass of a large batch, run in chunks beside the planner, goes without them as a small batch's does
+__global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, int64_t *__restrict__ counts, const int64_t *__restrict__ blk_sums,
+                                                    int64_t nblk, int64_t *__restrict__ bases, int derive, int fuse_possible)
 {
     __shared__ int64_t lds[4];
     const int col = c0 + blockIdx.y;
@@ -556,20 +572,19 @@ __global__ __launch_bounds__(256) void k_scan_apply(int64_t n, int c0, const int
     int64_t tot;
     int64_t run = wg_incl_scan(s, lds, tot) - s + blk_sums[(int64_t)col * nblk + blockIdx.x];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { if (base + k < n) bases[(int64_t)col * n + base + k] = run; run += v[k]; }
-}
-
-// what depends on where a field's span lies in the batch arrays (pt_off): its 512-point chunks, whether its field's own workgroup can write
-// it (at most FUSED_SPAN_CHUNKS of them), the alternatives the host chooses between once it has the totals
-__device__ __forceinline__ void span_counts(int64_t pt_off, int64_t S, bool is_work, bool fuse_possible, int64_t &c_span, int64_t &c_span_f,
-                                            int64_t &c_work_span_pts, int64_t &c_unfusable)
-{
-    c_span = c_span_f = c_work_span_pts = c_unfusable = 0;
-    if (S <= 0) return;
-    const int64_t n_chunks = ((pt_off % TILE_POINTS) + S + TILE_POINTS - 1) / TILE_POINTS;
-    const bool fusable = is_work && n_chunks <= FUSED_SPAN_CHUNKS;
-    const int64_t fused = (fusable && fuse_possible) ? S : 0;
-    c_span = n_chunks; c_span_f = fused > 0 ? 0 : n_chunks; c_work_span_pts = fused; c_unfusable = (is_work && !fusable) ? 1 : 0;
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) {
+            bases[(int64_t)col * n + base + k] = run;
+            if (derive && col == PC_POINTS) {
+                const int64_t f = base + k;
+                int64_t c_span, c_span_f, c_wsp, c_unf;
+                span_counts(run, counts[(int64_t)PC_SPAN_PTS * n + f], counts[(int64_t)PC_WORK * n + f] != 0, fuse_possible != 0, c_span, c_span_f, c_wsp, c_unf);
+                counts[(int64_t)PC_SPAN * n + f] = c_span; counts[(int64_t)PC_SPAN_F * n + f] = c_span_f;
+                counts[(int64_t)PC_WORK_SPAN_PTS * n + f] = c_wsp; counts[(int64_t)PC_UNFUSABLE * n + f] = c_unf;
+            }
+        }
+        run += v[k];
+    }
 }
 
 // small batches: one workgroup of 1024 threads per column walks the fields in chunks of 4096 -- one launch instead of three, and one
@@ -665,7 +680,7 @@ int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch 
     }
     hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk);
     hipLaunchKernelGGL(k_scan_block_bases, dim3((unsigned)nc), dim3(256), 0, st, c0, s.blk_sums, nblk, s.totals, mirror, with_flags, done_gen);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk, s.bases);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nblk, (unsigned)nc), dim3(256), 0, st, n, c0, s.counts, s.blk_sums, nblk, s.bases, derive, fuse_possible);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -717,8 +732,8 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
 {
     __shared__ TileWaveLds<STAGE> lds_all[TW_WAVES];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int64_t field = (int64_t)blockIdx.x * TW_WAVES + wave;
-    if (field >= n) return;
+    const int64_t field = (FILL ? 0 : tc.f0) + (int64_t)blockIdx.x * TW_WAVES + wave;      // (the counting pass of a large batch runs in chunks: fields [f0, f1))
+    if (field >= (FILL ? n : tc.f1)) return;
     TSTAMP(0);
     FSTAMP(0);
     TileWaveLds<STAGE> &L = lds_all[wave];
@@ -1373,43 +1388,76 @@ __global__ void k_debug_math(int fn, int64_t n, const double *__restrict__ a, co
 }  // namespace
 
 int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, const fcpp_field *fields,
-                         int64_t n_polys, int check_obstacles, int64_t *totals_host)
+                         int64_t n_polys, int check_obstacles, int64_t *totals_host, hipStream_t side, hipEvent_t *ev, int n_ev)
 {
     if (n <= 0) return 0;
     // (sixteen lanes per field; FCPP_PLAN_SERIAL=1 -- read once -- keeps the one-thread-per-field kernel: the A/B and the checker of the two)
     // Sixteen lanes per field cut the latency of a plan (23 instead of 35 us for 4096 fields) and, four fields per wavefront, its stores are
     // denser (cfg5's 65 536 fields: 170 us against 230 for the one-thread kernel); FCPP_PLAN_SERIAL=1 keeps the latter (the A/B, the checker)
     static const bool plan_serial = getenv("FCPP_PLAN_SERIAL") != nullptr;
-    if (plan_serial)
-        hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
-                           n_polys, check_obstacles, 0, tc.gen);
-    else
-        hipLaunchKernelGGL(k_plan_fields16, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, st, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
-                           n_polys, check_obstacles, tc.gen);
-    // small batches: the counting pass goes without the fields' point offsets, ONE scan follows it (span_counts); large ones: a scan of
-    // points and primitives, the pass, a scan of its columns
+    static const bool one_stream = !(getenv("FCPP_COUNT_CHUNKS") != nullptr && atoi(getenv("FCPP_COUNT_CHUNKS")) >= 2);      // (the chunks: an experiment, see below)
+    // The counting pass goes without the fields' point offsets; what depends on them (span_counts) is derived by the scan that follows the
+    // pass: small batches ONE scan of one launch (k_scan_small), large ones the scan of the points (its apply kernel derives) and then the
+    // scan of the other columns.  (Rounds 4-5a scanned the points of a large batch BEFORE its pass.)
     const bool one_scan = (n + 1023) / 1024 <= 8;
     DevTileConsts tcc = tc;
-    tcc.no_bases = one_scan ? 1 : 0;
-    int rc = 0;
-    if (!one_scan) {
-        rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s, totals_host, 0);
-        if (rc) return rc;
-    }
+    tcc.no_bases = 1;
+    auto plan = [&](hipStream_t q, int64_t f0, int64_t f1) {
+        if (plan_serial) {
+            if (f0 == 0)
+                hipLaunchKernelGGL(k_plan_fields, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, q, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                                   n_polys, check_obstacles, 0, tc.gen);
+        } else
+            hipLaunchKernelGGL(k_plan_fields16, dim3((unsigned)((f1 - f0 + 3) / 4)), dim3(64), 0, q, n, pc, fields, s.info, s.fields_tmp, s.prims_tmp, s.counts, s.totals,
+                               n_polys, check_obstacles, tc.gen, f0, f1);
+    };
     // (more fields than one round of wavefronts takes -- 4 per SIMD x 1024 SIMDs with the primitives staged in LDS: they are not staged, five
     // wavefronts per SIMD instead of four; cfg5's 65 536 fields: plan + count 1.30 -> 1.07 ms)
-    if (n <= 4096)
-        hipLaunchKernelGGL((k_tile_fields<false, true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
-                           s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
-    else
-        hipLaunchKernelGGL((k_tile_fields<false, false>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
-                           s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
+    auto count = [&](hipStream_t q, int64_t f0, int64_t f1) {
+        tcc.f0 = f0; tcc.f1 = f1;
+        const unsigned grid = (unsigned)((f1 - f0 + TW_WAVES - 1) / TW_WAVES);
+        if (n <= 4096)
+            hipLaunchKernelGGL((k_tile_fields<false, true>), dim3(grid), dim3(64 * TW_WAVES), 0, q, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
+                               s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
+        else
+            hipLaunchKernelGGL((k_tile_fields<false, false>), dim3(grid), dim3(64 * TW_WAVES), 0, q, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
+                               s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
+    };
+    // Large batches in CHUNKS on two streams (FCPP_COUNT_CHUNKS=2..4; measured and NOT the default): the planner's first load is the transfer
+    // of the field records (128 bytes a field over PCIe: the kernel runs at the link's 50 GB/s), the counting pass of a chunk needs nothing but
+    // its own fields' plans -- beside the planner's next chunk instead of behind its last.  It loses: the planner reaches the link's rate only
+    // with the whole chip's wavefronts waiting on loads, and beside the counting pass it has half of them -- cfg5, four chunks: planner
+    // 60 + 66 + 76 + 85 us instead of 171, counting pass 106 + 86 + 76 + 71 instead of 249, the scans begin at 460 us instead of 421.
+    int n_chunks = 1;
+    if (!one_scan && !plan_serial && !one_stream && side && side != st && ev && n_ev >= 2) {
+        n_chunks = n_ev - 1 < 4 ? n_ev - 1 : 4;
+        if (const char *e = getenv("FCPP_COUNT_CHUNKS")) { const int c = atoi(e); if (c >= 2 && c <= n_ev - 1) n_chunks = c; }
+    }
+    if (n_chunks <= 1) { plan(st, 0, n); count(st, 0, n); }
+    else {
+        const int64_t per = (((n + n_chunks - 1) / n_chunks) + 3) / 4 * 4;      // (whole wavefronts of the planner, whole workgroups of the pass)
+        int used = 0;
+        for (int64_t f0 = 0; f0 < n; f0 += per, ++used) {
+            const int64_t f1 = f0 + per < n ? f0 + per : n;
+            plan(st, f0, f1);
+            hipError_t e = hipEventRecord(ev[used], st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, ev[used], 0);
+            if (e != hipSuccess) return (int)e;
+            count(side, f0, f1);
+        }
+        hipError_t e = hipEventRecord(ev[n_ev - 1], side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev[n_ev - 1], 0);
+        if (e != hipSuccess) return (int)e;
+    }
+    int rc = 0;
     if (one_scan) {
         rc = launch_scan(st, n, PC_POINTS, PC_COLS, s, totals_host, 1, 1, tc.fuse_spans, tc.speculative ? tc.gen : 0, tc.gen);
         if (rc) return rc;
         const hipError_t e1 = hipGetLastError();
         return e1 == hipSuccess ? 0 : (int)e1;
     }
+    rc = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s, totals_host, 0, 1, tc.fuse_spans);
+    if (rc) return rc;
     rc = launch_scan(st, n, PC_TILES, PC_COLS, s, totals_host, 1, 0, 0, 0, tc.gen);
     if (rc) return rc;
     const hipError_t e = hipGetLastError();

@@ -109,10 +109,19 @@ def test_speculative_and_exact_layouts_build_the_same_tables():
 
 
 def test_a_batch_beyond_the_one_scan_limit_equals_the_hosts():
-    """More than 8192 fields: the counting pass runs behind a scan of its own (points, primitives) and the three-kernel scans; at most
-    8192: one scan after the pass derives what depends on the spans' alignment.  Both against the host's tables."""
+    """More than 8192 fields: the counting pass, then the three-kernel scans -- the scan of the points derives what depends on the spans'
+    alignment; at most 8192: ONE scan of one launch after the pass.  Both against the host's tables -- and the experiment FCPP_COUNT_CHUNKS
+    (the counting pass in chunks on a second stream beside the planner's chunks; read once per process, so in a process of its own)."""
     V = WL.cfg5_parallelograms(9001)
     _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(), E.make_options()), 'cfg5 x 9001')
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from tests.test_gpu_devplan import _compare, _both; "
+            "from field_coverage_path_planning_amd import engine as E, workloads as WL; "
+            "_compare(*_both(E.FieldTable.from_vertices(WL.cfg5_parallelograms(9001)), E.make_vehicle(), E.make_options()), 'chunks'); print('chunks equal')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, FCPP_COUNT_CHUNKS='3'), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'chunks equal' in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
     _compare(*_both(E.FieldTable.from_vertices(V[:8192]), E.make_vehicle(), E.make_options()), 'cfg5 x 8192')
 
 

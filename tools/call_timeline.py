@@ -17,7 +17,8 @@ def short(n):
 calls, cur = [], None
 for r in rows:
     n = short(r['Kernel_Name'])
-    if n.startswith('k_plan_fields'):
+    # (a large batch's planner and counting pass run in chunks: a call begins with the first planner launch after a fill pass)
+    if n.startswith('k_plan_fields') and (cur is None or any(x[0].startswith('k_tile_fields<true') for x in cur)):
         cur = []
         calls.append(cur)
     if cur is not None:
