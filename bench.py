@@ -691,7 +691,7 @@ def main():
         # a few calls for the dense ones -- milliseconds each)
         sparse = e2e_reps >= 100
         rr = run_planner(E, torch, table, opt, steps, warmup, calibrate=calibrate, fence=fence, e2e_reps=min(e2e_reps, 20),
-                         fresh_steps=steps if sparse else 3, fresh_reps=REPS_SHORT if sparse else 3)
+                         fresh_steps=steps if sparse else 3, fresh_reps=REPS_SHORT if sparse else 5)
         cpu = None
         if rank == 0 and cpu_on and cpu_fn is not None:
             cpu = cpu_fn()
@@ -934,7 +934,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
     # ---- the job end to end, E2E_REPS times: sizing of all fields (every rank, threaded, no collective), this rank's fresh batch, its
     # output arrays, one step, the stats gathered on rank 0
     e2e, batch, bufs, res = [], None, None, None
-    for rep in range(4):
+    for rep in range(9):             # (the first is dropped: allocations; median of the other eight)
         if batch is not None:
             batch.close()
             batch = bufs = res = None

@@ -7,7 +7,7 @@ import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 d = json.load(open(os.path.join(REPO, 'profiles', f'{ROUND}_bench_detail.json')))
 cfg = {e['name']: e for e in d['configs']}
 
@@ -22,23 +22,25 @@ def sci(v):
 
 
 def row(e):
+    """plan call ms, fresh points/s, step ms, step frac"""
     rf = e.get('roofline') or {}
-    return g(e['ms_per_step']), sci(e['value']), g(rf.get('step_frac', 0.0), 3), g((e.get('end_to_end') or {}).get('ms', 0.0), 3)
+    ms_f = e.get('ms_fresh') or (e.get('end_to_end') or {}).get('ms', 0.0)
+    v_f = e.get('value_fresh') or (e.get('end_to_end') or {}).get('points_per_s', 0.0)
+    return g(ms_f), sci(v_f), g(e['ms_per_step']), g(rf.get('step_frac', 0.0), 3)
 
 
 sub = {}
 hk = d['roofline']['all_kernels_ms']['k_plan_sparse_fields']
-sub['H_MS'], sub['H_V'], sub['H_F'], sub['H_E'] = g(d['ms_per_step']), sci(d['value']), g(d['roofline']['step_frac'], 3), g(d['end_to_end']['ms'], 3)
+sub['H_MS'], sub['H_V'], sub['H_S'], sub['H_F'] = g(d['ms_per_step']), sci(d['value']), g(d['ms_step']), g(d['roofline']['step_frac'], 3)
 sub['H_K'] = f'{hk * 1e3:.1f} µs ({d["roofline"]["frac"]:.2f})'
-for key, name in (('C', 'cfg1_clothoid'), ('R', 'cfg2_ref'), ('5', 'cfg2_0.5'), ('1', 'cfg2_0.1'), ('3', 'cfg3'), ('A', 'cfg3_avoid'), ('P', 'cfg5')):
-    sub[key + '_MS'], sub[key + '_V'], sub[key + '_F'], sub[key + '_E'] = row(cfg[name])
+for key, name in (('C', 'cfg1_clothoid'), ('X', 'cfg1_x16384'), ('R', 'cfg2_ref'), ('5', 'cfg2_0.5'), ('1', 'cfg2_0.1'), ('D', 'cfg1_clothoid_dense'), ('3', 'cfg3'),
+                  ('A', 'cfg3_avoid'), ('P', 'cfg5')):
+    sub[key + '_MS'], sub[key + '_V'], sub[key + '_S'], sub[key + '_F'] = row(cfg[name])
 g4 = cfg['cfg4']
 sub['G_MS'], sub['G_V'] = g(g4.get('ms_total', g4.get('ms_per_step'))), sci(g4['value'])
 cb = d['cpu_baseline']
 sub['CPU'] = f'{sci(cb["value"])} ({sci(cb["single_core_value"])} on one thread)'
-al = json.load(open(os.path.join(REPO, 'profiles', f'{ROUND}_arena_live.json')))
-sub['ARENA'] = ', '.join(f'{k} {al["ms_solo"][k]:.3f} / {al["ms_all_alive"][k]:.3f}' for k in al['ms_solo']) + \
-    f' ms alone / with all three alive ({al["device_GiB_held_by_process"]} GiB held by the process)'
+sub['PYL'], sub['NPY'] = sci(cb['python_loops_value']), sci(cb['numpy_value'])
 tj = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json')))
 pts = {'k_plan_sparse_fields|cfg1': 6926336, 'k_plan_quiet_spans|cfg5': 240011750, 'k_plan_quiet|cfg2_0.1': None}
 tr = []

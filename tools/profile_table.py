@@ -9,7 +9,7 @@ import os
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 print(f"{'config':10s} {'kernel':34s} {'us':>8s} {'waves':>9s} {'VALU/w':>7s} {'SALU/w':>7s} {'SMEM/w':>7s} {'VMEMrd/w':>8s} {'LDS/w':>6s} {'cycles/w':>9s} {'wait%':>6s} {'VALUbusy%':>9s} {'waves/SIMD':>10s}")
-for path in sorted(glob.glob(os.path.join(REPO, 'profiles', os.environ.get('FCPP_ROUND', 'r04') + '_*_counters.csv'))):
+for path in sorted(glob.glob(os.path.join(REPO, 'profiles', os.environ.get('FCPP_ROUND', 'r05') + '_*_counters.csv'))):
     cfg = os.path.basename(path)[4:-13]
     rows = {(r['Kernel'], r['Counter']): float(r['MeanPerDispatch']) for r in csv.DictReader(open(path))}
     st = {r['Name']: float(r['AverageNs']) / 1e3 for r in csv.DictReader(open(path.replace('_counters', '_kernel_stats')))}
