@@ -218,7 +218,9 @@ def test_geofence_tolerances_vs_oracle():
 
 
 def test_fields_far_from_the_origin_vs_oracle():
-    """UTM-sized coordinates (~5e6 m, where a double resolves 1e-9 m): coordinates within 5e-8 m of the oracle, every integer equal, and the
+    """UTM-sized coordinates (~5e6 m, where a double resolves 9.3e-10 m): coordinates within 2 ulps (2e-9 m) of the oracle, speeds within
+    1e-8 km/h, curvatures within 2e-8 1/m (the three-point stencil amplifies a coordinate's rounding by 4 / ds^2) -- measured: 0 m,
+    5e-15 km/h, 1.4e-9 1/m; rounds 2-4 accepted 5e-8 m and 1e-4 km/h here --, every integer equal, and the
     geofence flags equal -- with the default tolerance exactly, with tolerance 0 wherever a point is farther than a micrometre from the
     boundary (ON it, rounding decides in the oracle as in the library).  The tiler's "inside by a margin" shortcut (DevWaveTile.inside,
     fcpp_tilefn.h: tiler_inside) scales its margin with the coordinates, so it cannot hide a flag here either."""
@@ -246,14 +248,15 @@ def test_fields_far_from_the_origin_vs_oracle():
             finally:
                 E.get_context().set_setup('auto')
             res = batch.run()
-            x, y, v, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.flagseg).view(np.uint32)
+            x, y, v, fs, kap = _np(res.x), _np(res.y), _np(res.v), _np(res.flagseg).view(np.uint32), _np(res.kappa)
             for i, of in enumerate(ofs):
                 rc, p = orc.plan_field(of, orc.Vehicle.make(DEFAULT_VP), orc.Options.make(geofence_tol=tol))
                 info = batch.info[i]
                 assert rc == info.status == 0 and (info.n_main, info.n_head, info.n_swaths) == (p.n_main, p.n_head, p.n_swaths)
                 sl = res.field_slice(i)
-                np.testing.assert_allclose(np.column_stack([x[sl], y[sl]]), p.xy, rtol=0, atol=5e-8)
-                np.testing.assert_allclose(v[sl], p.v, rtol=0, atol=1e-4)
+                np.testing.assert_allclose(np.column_stack([x[sl], y[sl]]), p.xy, rtol=0, atol=2e-9)
+                np.testing.assert_allclose(v[sl], p.v, rtol=0, atol=1e-8)
+                np.testing.assert_allclose(kap[sl], p.kappa, rtol=0, atol=2e-8)
                 kinds = ~np.uint32(L.FLAG_OUTSIDE)
                 assert np.array_equal(fs[sl] & kinds, p.flagseg & kinds)
                 # signed distance of every point to the nearest edge line (relative coordinates: no cancellation)
