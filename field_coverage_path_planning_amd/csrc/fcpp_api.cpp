@@ -807,7 +807,8 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         const int64_t small = e ? atoll(e) : 16;
         if (c->setup_mode == FCPP_SETUP_AUTO && n_fields < small) { err = "a handful of fields: set up by the host"; return kNotOnDevice; }
     }
-    if (opt.sample_spacing != 0.0) { err = "sample_spacing > 0 (the device planner takes the reference's sampling)"; return kNotOnDevice; }
+    const bool dense = opt.sample_spacing != 0.0;          // (round 5: span + quiet runs of the straights + general tiles, k_tile_fields' dense block)
+    if (dense && getenv("FCPP_DENSE_DEVICE") && atoi(getenv("FCPP_DENSE_DEVICE")) == 0) { err = "FCPP_DENSE_DEVICE=0: dense sampling set up by the host"; return kNotOnDevice; }
     if (opt.obstacle_mode != FCPP_OBSTACLES_FLAG) { err = "obstacle-aware swaths are planned on the host"; return kNotOnDevice; }
     if (tune_enabled()) { err = "FCPP_TUNE: the tuning knobs are the host tiler's"; return kNotOnDevice; }
     PlanConsts pc;
@@ -894,7 +895,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     auto launch_fill = [&]() -> int {
         bind_tables(b);
         T.fields = b->t.fields; T.prims = b->t.prims; T.tiles = b->t.tiles; T.wtiles = b->t.wave_tiles; T.general_ids = b->t.general_ids;
-        T.span_chunks = b->t.span_chunks; T.stat_ids = b->t.stat_ids; T.stat_first = b->t.stat_first; T.stat_run = b->t.stat_run;
+        T.span_chunks = b->t.span_chunks; T.chunks = b->t.chunks; T.stat_ids = b->t.stat_ids; T.stat_first = b->t.stat_first; T.stat_run = b->t.stat_run;
         T.red_paths = b->t.red_paths; T.field_work = b->t.field_work; T.field_packs = b->t.field_packs; T.open_wave_ids = b->t.open_wave_ids; T.seg = b->t.seg; T.seg_mask = b->t.seg_mask;
         T.partial = b->t.partial; T.field_junc = b->t.field_junc; T.work_totals = b->t.work_totals;
         T.info = reinterpret_cast<fcpp_field_info *>(static_cast<unsigned char *>(b->slab) + lay.info);
@@ -905,7 +906,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         return FCPP_OK;
     };
     const bool exact_only = getenv("FCPP_SETUP_EXACT") != nullptr;              // (the checker of the speculative layout: tests/test_gpu_devplan.py)
-    bool spec = (n_fields + 1023) / 1024 <= 8 && !exact_only;
+    bool spec = (n_fields + 1023) / 1024 <= 8 && !exact_only && !dense;
     if (spec) {
         common_layout(lay);
         const int64_t K = DEVPLAN_KEEP_TILES;
@@ -917,7 +918,9 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         if (lay.total_bytes > ((size_t)1 << 30)) spec = false;
     }
     tc.speculative = spec ? 1 : 0;
-    tc.closed_cut = getenv("FCPP_WINDOW_CUT") ? 0 : 1;          // (FCPP_WINDOW_CUT=1: round 4's cut on both sides -- the A/B of the two cuts)
+    tc.closed_cut = (getenv("FCPP_WINDOW_CUT") || dense) ? 0 : 1;          // (FCPP_WINDOW_CUT=1: round 4's cut on both sides -- the A/B of the two cuts)
+    tc.dense = dense ? 1 : 0;
+    tc.span_line_max = (getenv("FCPP_DENSE_SPAN") && atoll(getenv("FCPP_DENSE_SPAN")) <= 0) ? 64 : INT64_MAX;
     if (spec) {
         if ((rc = take_slab(c, b, err)) != FCPP_OK) return rc;
         bind_tables(b);
@@ -966,7 +969,8 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         l.n_span_chunks = fuse ? tot[PC_SPAN_F] : tot[PC_SPAN]; l.n_runs = tot[PC_RUNS];
         for (int k = 0; k < 4; ++k) l.n_red[k] = tot[PC_CLS0 + k];
         l.n_work[0] = tot[PC_WORK]; l.n_field_work = tot[PC_WORK]; l.n_open_wave = tot[PC_OPEN];
-        l.quiet_points = tot[PC_SPAN_PTS]; l.span_points = tot[PC_SPAN_PTS] - (fuse ? tot[PC_WORK_SPAN_PTS] : 0); l.work_span_points = fuse ? tot[PC_WORK_SPAN_PTS] : 0; l.chunk_points = 0; l.wave_points = tot[PC_WAVE_PTS];
+        l.quiet_points = tot[PC_SPAN_PTS] + tot[PC_CHUNK_PTS]; l.span_points = tot[PC_SPAN_PTS] - (fuse ? tot[PC_WORK_SPAN_PTS] : 0); l.work_span_points = fuse ? tot[PC_WORK_SPAN_PTS] : 0;
+        l.n_chunks = tot[PC_CHUNKS]; l.chunk_points = tot[PC_CHUNK_PTS]; l.wave_points = tot[PC_WAVE_PTS];
         l.work_wave_points = tot[PC_WORK_WAVE_PTS]; l.wave_inside = tot[PC_WAVE_INSIDE];
     };
     if (spec && tot[PC_COLS + PF_OVER_CAPACITY] != tc.gen) {

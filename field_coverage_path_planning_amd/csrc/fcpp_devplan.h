@@ -24,7 +24,9 @@ namespace fcpp {
 // columns of the per-field count table (counts[col][field]) and of its exclusive scan (bases[col][field]); totals[col] = sum
 enum PlanCol : int {
     PC_POINTS = 0, PC_PRIMS, PC_TILES, PC_WAVE, PC_GENERAL, PC_STAT, PC_SPAN, PC_WORK, PC_OPEN, PC_CLS0, PC_CLS1, PC_CLS2, PC_CLS3,
-    PC_RUNS, PC_SPAN_PTS, PC_WAVE_PTS, PC_WORK_WAVE_PTS, PC_WAVE_INSIDE, PC_WORK_SPAN_PTS, PC_SPAN_F, PC_UNFUSABLE, PC_COLS
+    PC_RUNS, PC_SPAN_PTS, PC_WAVE_PTS, PC_WORK_WAVE_PTS, PC_WAVE_INSIDE, PC_WORK_SPAN_PTS, PC_SPAN_F, PC_UNFUSABLE,
+    PC_CHUNKS, PC_CHUNK_PTS,      // dense sampling: chunk records / points of the quiet runs of straights (the last swath line, headland straights)
+    PC_COLS
 };
 // (PC_SPAN: span chunks when no span is fused; PC_SPAN_F: when every fusable span is; PC_UNFUSABLE: fields of field work whose span has too
 // many chunks to be fused -- the host fuses all or none, k_tile_fields<true> is told which: DevTileConsts.fuse_spans)
@@ -48,6 +50,8 @@ struct DevTileConsts {
     int32_t speculative;          // the tables are laid out by capacities: the counting pass and the scan watch them, the fill pass decides
                                   // the fusing of spans itself and does nothing when a flag of this generation is up
     int32_t closed_cut;           // the general stretches of fields with a closed-form span are cut in closed form (fcpp_cutfn.h); 0: by the window cut of round 4
+    int32_t dense;                // sample_spacing > 0: span of all complete passes + quiet runs of the straights + general tiles between them (k_tile_fields, "dense")
+    int64_t span_line_max;        // TileConsts.span_line_max
     double two_a, u_cap, c_line, fence_margin;
     int64_t reduce_wg_max;
     int64_t gen;                  // this counting phase's generation number (> 0)
@@ -73,7 +77,7 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *offsets_
 
 // the tables the fill pass writes (pointers into the batch's slab, laid out by the host from the totals)
 struct DevPlanTables {
-    DevField *fields; DevPrim *prims; DevTile *tiles; DevWaveTile *wtiles; int32_t *general_ids; DevTile *span_chunks;
+    DevField *fields; DevPrim *prims; DevTile *tiles; DevWaveTile *wtiles; int32_t *general_ids; DevTile *span_chunks; DevTile *chunks;
     int32_t *stat_ids; int64_t *stat_first, *stat_run; int32_t *red_paths; DevFieldWork *field_work; DevFieldPack *field_packs; int32_t *open_wave_ids;
     double *seg; int32_t *seg_mask;
     // what batch creation computes once from the tables (k_field_junctions, k_run_consts, k_work_totals on the host path), done by the
@@ -99,6 +103,8 @@ static_assert(DEVPLAN_KEEP_ROWS >= DEVPLAN_KEEP_TILES, "the window cut keeps its
 // measured slower, see launch_devplan_count); null / 0: one stream.
 int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const DevTileConsts &tc, const DevPlanScratch &s, const fcpp_field *fields,
                          int64_t n_polys, int check_obstacles, int64_t *totals_host, hipStream_t side = nullptr, hipEvent_t *ev = nullptr, int n_ev = 0);
+// (tc.dense: the counting pass needs the fields' point offsets -- the chunks of every quiet run lie on 512-point boundaries of the batch arrays --:
+// planner, scan of the points, pass, scan of the other columns)
 // sizing only (fcpp_plan_points): k_plan_fields without primitives; counts[PC_POINTS][field] = points of the field
 int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const DevPlanScratch &s, const fcpp_field *fields);
 // phase 2: the tables.  `bases` / `totals` as phase 1 left them.

@@ -755,7 +755,8 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
 
     // the field's counts (count pass) / positions (fill pass)
     int64_t c_tiles = 0, c_wave = 0, c_general = 0, c_stat = 0, c_span = 0, c_work = 0, c_open = 0, c_runs = 0, c_span_pts = 0, c_wave_pts = 0,
-            c_work_wave_pts = 0, c_wave_inside = 0, c_work_span_pts = 0, c_span_f = 0, c_unfusable = 0;
+            c_work_wave_pts = 0, c_wave_inside = 0, c_work_span_pts = 0, c_span_f = 0, c_unfusable = 0, c_chunks_out = 0, c_chunk_pts_out = 0;
+    bool dense_entries = false;          // (fill pass: the dense block has written the field's entries, slots and chunks itself -- all but the span's)
     int cls = 0;
     int64_t wave_base = 0, general_base = 0, stat_base = 0, span_base = 0, prim_base = 0;
     if (FILL) {
@@ -798,16 +799,122 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         const double line_step_len = fabs(F.line_step);
         const bool turn_quiet = tc.turn_quiet && F.n_turn == tc.nu && F.line_step > 0.0;
         const bool wave_ok = F.n_turn == tc.nu && (double)tc.wave_factor * tc.two_a * line_step_len >= tc.u_cap;
-        // (sample_spacing = 0: 2 points per line, 20 per headland straight -- no quiet zone anywhere; anything else is not this kernel's)
-        if (F.n_line >= 64 || prim_count > DEVPLAN_PRIMS_CAP) fallback = true;
+        // (sample_spacing = 0: 2 points per line, 20 per headland straight -- no quiet zone anywhere; dense sampling: the block below)
+        const bool dense = tc.dense != 0;
+        if ((!dense && F.n_line >= 64) || prim_count > (dense ? 62 : DEVPLAN_PRIMS_CAP)) fallback = true;
         int64_t pos = 0;
         const int64_t need1 = tiler_need_for(tc.c_line, line_step_len, tc.two_a);
         if (need1 >= 0 && per > 0 && gen_main > 0) {
-            const bool span = turn_quiet && P >= 2 && (int64_t)F.n_line - need1 < 64 && (P - 1) * per < (int64_t)0x7fffffff;
+            const bool span = turn_quiet && P >= 2 && (int64_t)F.n_line - need1 < (F.obs_count > 0 ? (int64_t)64 : tc.span_line_max) && (P - 1) * per < (int64_t)0x7fffffff;
             if (span) { S = (P - 1) * per; span_k = (S + (TILE_POINTS - 2) - 1) / (TILE_POINTS - 2); pos = S; }
         }
+        // ---- DENSE sampling (round 5; FieldTiler::tile_field + derive_field for a field whose complete passes form a span): behind the span the
+        // last swath line and every headland straight have a quiet zone of their own (a run: one tile, one statistics entry, chunks on
+        // 512-point boundaries of the batch arrays), the stretches between the zones are cut into general tiles.  The zones a lane each
+        // (lane 0: the last line, lane 1 + k: primitive k), the stretches a lane each, places by prefix sums over the lanes.  Not taken
+        // here (PF_FALLBACK: the host sets the batch up): fields without a span (obstacles, turns that are not closed form), samplings
+        // coarse enough for wave tiles (0.18 m and up at the default accelerations), more than 62 primitives.
+        int64_t n_quiet = 0, c_chunks = 0, c_chunk_pts = 0;
+        if (dense && !fallback) {
+            if (!(S > 0 && F.obs_count == 0 && !wave_ok && gen_main == F.n_main)) fallback = true;
+            else {
+                int64_t q_s = 0, q_n = 0;
+                int q_kind = 0, q_i0 = 0, q_o0 = 0;
+                bool valid = false;
+                if (lane == 0) {
+                    const int64_t Z = (int64_t)F.n_line - need1;          // (no margin at its start behind a span; need1 points before the seam to layer 2)
+                    if (Z >= 64) { valid = true; q_s = S; q_n = Z; q_kind = 1; q_i0 = (int)(P - 1); q_o0 = 0; }
+                } else if (lane - 1 < prim_count) {
+                    const DevPrim &pr = prims[lane - 1];
+                    if (pr.kind == PRIM_LINSPACE) {
+                        const double ms = pr.v_nom / 3.6;
+                        const int64_t need2 = tiler_need_for(ms * ms, sqrt(pr.a[4] * pr.a[4] + pr.a[5] * pr.a[5]), tc.two_a);
+                        const int64_t Z = (int64_t)pr.n - 2 * need2;
+                        if (need2 >= 0 && Z >= 64) { valid = true; q_s = pr.start + need2; q_n = Z; q_kind = 2; q_i0 = lane - 1; q_o0 = (int)need2; }
+                    }
+                }
+                const unsigned long long vm = __ballot(valid);
+                const int nq = __popcll(vm), rk = __popcll(vm & ((1ull << lane) - 1ull));
+                // the runs in path order (the window's bytes: this path cuts no wave tile)
+                int64_t *qs = reinterpret_cast<int64_t *>(L.d), *qn = qs + 64;
+                int32_t *qk = reinterpret_cast<int32_t *>(qn + 64), *qi = qk + 64, *qo = qi + 64;
+                static_assert(sizeof(L.d) >= 64 * (8 + 8 + 4 + 4 + 4), "the runs of a dense field fit the window's bytes");
+                if (valid) { qs[rk] = q_s; qn[rk] = q_n; qk[rk] = q_kind; qi[rk] = q_i0; qo[rk] = q_o0; }
+                wave_sync();
+                // stretch j = [end of run j - 1 (the span's for j = 0), start of run j (the path's end for j = nq))
+                int64_t a_j = 0, len_j = 0, ng_j = 0, z_j = 0, s_j = 0, J_j = 0;
+                if (lane <= nq) {
+                    a_j = lane == 0 ? S : qs[lane - 1] + qn[lane - 1];
+                    const int64_t b_j = lane == nq ? n_total : qs[lane];
+                    len_j = b_j > a_j ? b_j - a_j : 0;
+                    ng_j = (len_j + TILE_POINTS - 1) / TILE_POINTS;
+                }
+                if (lane < nq) {
+                    s_j = qs[lane]; z_j = qn[lane];
+                    J_j = (((pt_off + s_j) % TILE_POINTS) + z_j + TILE_POINTS - 1) / TILE_POINTS;
+                }
+                int64_t g_incl = ng_j, j_incl = J_j, z_sum = z_j;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int64_t u = __shfl_up(g_incl, o), w = __shfl_up(j_incl, o), zz = __shfl_up(z_sum, o);
+                    if (lane >= o) { g_incl += u; j_incl += w; z_sum += zz; }
+                }
+                const int64_t g_before = g_incl - ng_j, j_before = j_incl - J_j;
+                n_general = __shfl(g_incl, 63); c_chunks = __shfl(j_incl, 63); c_chunk_pts = __shfl(z_sum, 63);
+                n_quiet = nq;
+                if (FILL) {
+                    const int64_t chunk_base = base_of(PC_CHUNKS);
+                    // general tiles of stretch `lane`: near-equal, at most 512 points (emit_general); entries [1 + g_before + lane, + ng_j)
+                    if (lane <= nq && ng_j > 0) {
+                        const int64_t bs = len_j / ng_j, rem = len_j % ng_j;
+                        for (int64_t i = 0; i < ng_j; ++i) {
+                            const int64_t st = a_j + i * bs + (i < rem ? i : rem), cnt = bs + (i < rem ? 1 : 0);
+                            const int64_t e = stat_base + 1 + g_before + lane + i;
+                            const bool l1 = per > 0 && st < gen_main;
+                            DevTile t;
+                            t.field = (int32_t)field; t.start = st; t.count = (int32_t)cnt; t.quiet = 0; t.stat_tile = (int32_t)e;
+                            t.idx0 = l1 ? (int32_t)(st / per) : 0; t.off0 = l1 ? (int32_t)(st % per) : 0;
+                            T.tiles[e] = t;
+                            T.general_ids[general_base + g_before + i] = (int32_t)e;
+                            T.stat_ids[e] = (int32_t)e; T.stat_run[e] = 0;
+                            unsigned long long *slot = reinterpret_cast<unsigned long long *>(T.partial + e);
+                            for (int w = 0; w < 13; ++w) slot[w] = 0ull;
+                        }
+                    }
+                    // the runs: tile, entry, closed-form statistics, chunks
+                    if (lane < nq) {
+                        const int64_t e = stat_base + 1 + g_before + ng_j + lane;
+                        const int64_t cap = TILE_POINTS - 2, k = (z_j + cap - 1) / cap, bs = z_j / k, rem = z_j % k;
+                        DevTile t;
+                        t.field = (int32_t)field; t.start = s_j; t.count = (int32_t)(bs + (rem > 0 ? 1 : 0)); t.quiet = qk[lane]; t.stat_tile = 0;
+                        t.idx0 = qk[lane] == 2 ? (int32_t)(prim_index0 + qi[lane]) : qi[lane]; t.off0 = qo[lane];
+                        T.tiles[e] = t;
+                        T.stat_ids[e] = (int32_t)e; T.stat_run[e] = z_j;
+                        double2 junc = make_double2(0.0, 0.0);
+                        if (F.P >= 2 && F.n_line >= 2 && F.n_turn >= 1) junc.x = line_start_curvature(F, cst, 1, junc.y);
+                        FieldStatView fv;
+                        fv.n_line = F.n_line; fv.n_turn = F.n_turn; fv.reverse_order = F.reverse_order; fv.line_step = F.line_step; fv.n_main = F.n_main; fv.junc = junc;
+                        DevTile tl = t;
+                        tl.idx0 = qi[lane];                              // (the field's own primitives: `prims`)
+                        const DevRun run = { (int32_t)e, 0, z_j };
+                        TilePartial tp = quiet_run_partial(run, tl, fv, prims, cst);
+                        tp.n_viol = tp.n_outside = tp.n_in_obstacle = tp.n_adjusted = 0;
+                        T.partial[e] = tp;
+                        const int64_t g0r = pt_off + s_j;
+                        const int64_t c_first = (z_j < TILE_POINTS - (g0r % TILE_POINTS)) ? z_j : TILE_POINTS - (g0r % TILE_POINTS);
+                        for (int64_t j = 0; j < J_j; ++j) {
+                            const int64_t done = j == 0 ? 0 : c_first + (j - 1) * TILE_POINTS;
+                            DevTile ch = t;
+                            ch.start = s_j + done; ch.count = (int32_t)(j == 0 ? c_first : ((z_j - done < TILE_POINTS) ? z_j - done : TILE_POINTS));
+                            ch.stat_tile = (int32_t)e; ch.off0 = (int32_t)(t.off0 + done);
+                            T.chunks[chunk_base + j_before + j] = ch;
+                        }
+                    }
+                }
+            }
+        }
         const int64_t a = pos, b = n_total, G = b - a;
-        bool use_wave = wave_ok && G > 0 && !fallback;
+        bool use_wave = wave_ok && G > 0 && !fallback && !dense;
         bool refused = false;
         // the count pass has already decided whether the stretch takes wave tiles: the fill pass reads its verdict
         if (FILL && use_wave) {
@@ -1155,7 +1262,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             if (!refused) { n_wave = ordinal; c_wave_pts = wave_pts; c_wave_inside = inside_cnt; }
             TSTAMP(36);
         }
-        if (G > 0 && n_wave == 0 && !fallback) {
+        if (G > 0 && n_wave == 0 && !fallback && !dense) {
             // general tiles of at most 512 points, near-equal
             n_general = (G + TILE_POINTS - 1) / TILE_POINTS;
             if (FILL) {
@@ -1183,7 +1290,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         // ---- the span's tiles (near-equal, at most 510 points: the closed-form kernel stores aligned pairs) and its chunks on 512-point
         // boundaries of the batch arrays
         if (span_k > 0) {
-            c_runs = 1; c_span_pts = S;
+            c_runs = 1 + n_quiet; c_span_pts = S;
             const int64_t g0 = pt_off;                           // the span starts the path
             // (counting pass: fuse_spans = fusing is possible for this batch, both alternatives are counted; fill pass: the host's
             // decision -- all fields of field work have fusable spans, or nothing is fused)
@@ -1209,9 +1316,10 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                 }
             }
         }
-        c_tiles = (span_k > 0 ? 1 : 0) + n_wave + n_general;      // (the tile table holds one tile per statistics entry: of a span, the first)
+        c_tiles = (span_k > 0 ? 1 : 0) + n_wave + n_general + n_quiet;      // (the tile table holds one tile per statistics entry: of a span / a run, the first)
         c_wave = n_wave; c_general = n_general;
-        c_stat = (span_k > 0 ? 1 : 0) + n_wave + n_general;
+        c_stat = (span_k > 0 ? 1 : 0) + n_wave + n_general + n_quiet;
+        if (dense) { c_chunks_out = c_chunks; c_chunk_pts_out = c_chunk_pts; dense_entries = true; }
     }
     // ---- which kernel reduces the field: its own workgroup (k_plan_sparse_fields) or a class of k_reduce_stats
     const int64_t ne = c_stat;
@@ -1233,6 +1341,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             c[(int64_t)PC_CLS2 * n] = (!is_work && cls == 2) ? 1 : 0; c[(int64_t)PC_CLS3 * n] = (!is_work && cls == 3) ? 1 : 0;
             c[(int64_t)PC_RUNS * n] = c_runs; c[(int64_t)PC_SPAN_PTS * n] = c_span_pts; c[(int64_t)PC_WAVE_PTS * n] = c_wave_pts;
             c[(int64_t)PC_WORK_WAVE_PTS * n] = c_work_wave_pts; c[(int64_t)PC_WAVE_INSIDE * n] = c_wave_inside;
+            c[(int64_t)PC_CHUNKS * n] = c_chunks_out; c[(int64_t)PC_CHUNK_PTS * n] = c_chunk_pts_out;
         }
         TSTAMP(38);
         return;
@@ -1257,7 +1366,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
     FSTAMP(3);
     // entries in path order: the span's run, then the wave tiles / general tiles
     if (span_k > 0 && lane == 0) { T.stat_ids[stat_base] = (int32_t)stat_base; T.stat_run[stat_base] = S; }
-    {
+    if (!dense_entries) {
         const int64_t e0 = stat_base + (span_k > 0 ? 1 : 0), nt = n_wave + n_general;
         for (int64_t j = lane; j < nt; j += 64) { T.stat_ids[e0 + j] = (int32_t)(e0 + j); T.stat_run[e0 + j] = 0; }
     }
@@ -1344,7 +1453,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         // slots: entry 0 = the span's (when there is one), the others zero
         unsigned long long *slots = reinterpret_cast<unsigned long long *>(T.partial + stat_base);
         const unsigned long long *tpw = reinterpret_cast<const unsigned long long *>(&tp);
-        const int64_t nwords = c_stat * 13;
+        const int64_t nwords = dense_entries ? 13 : c_stat * 13;          // (dense: the span's slot; the dense block wrote the others)
         for (int64_t k = lane; k < nwords; k += 64) {
             unsigned long long v = 0;
             if (span_k > 0 && k < 13) {
@@ -1432,6 +1541,18 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
     if (!one_scan && !plan_serial && !one_stream && side && side != st && ev && n_ev >= 2) {
         n_chunks = n_ev - 1 < 4 ? n_ev - 1 : 4;
         if (const char *e = getenv("FCPP_COUNT_CHUNKS")) { const int c = atoi(e); if (c >= 2 && c <= n_ev - 1) n_chunks = c; }
+    }
+    if (tc.dense) {
+        // dense sampling: the chunks of every quiet run lie on 512-point boundaries of the batch arrays -- the pass needs the point offsets
+        plan(st, 0, n);
+        int rc0 = launch_scan(st, n, PC_POINTS, PC_PRIMS + 1, s, totals_host, 0);
+        if (rc0) return rc0;
+        tcc.no_bases = 0;
+        count(st, 0, n);
+        rc0 = launch_scan(st, n, PC_TILES, PC_COLS, s, totals_host, 1, 0, 0, 0, tc.gen);
+        if (rc0) return rc0;
+        const hipError_t e0 = hipGetLastError();
+        return e0 == hipSuccess ? 0 : (int)e0;
     }
     if (n_chunks <= 1) { plan(st, 0, n); count(st, 0, n); }
     else {

@@ -298,3 +298,18 @@ def test_one_call_plan_equals_create_alloc_run():
                     del E._contexts[0]
                     if saved is not None:
                         E._contexts[0] = saved
+
+
+def test_dense_sampling_tables_equal_the_hosts():
+    """Round 5: batches at dense sampling whose fields have no obstacles are set up on the device too -- the span of all complete passes, the
+    quiet zones of the last swath line and of the headland straights as runs with their chunks, general tiles between them -- and must
+    equal the host's tables byte for byte; a sampling coarse enough for wave tiles (0.5 m) is still the host's (setup_path says so)."""
+    R = WL.cfg2_rectangles()[:64]
+    V = WL.cfg5_parallelograms(48)
+    for tm, sp in ((1, 0.1), (0, 0.12), (1, 0.05)):
+        _compare(*_both(E.FieldTable.from_rectangles(R), E.make_vehicle(), E.make_options(tm, sp)), f'rectangles, turn model {tm}, {sp} m')
+    _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(), E.make_options(1, 0.1)), 'parallelograms, clothoid, 0.1 m')
+    _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(working_width=1.2), E.make_options(0, 0.15)), 'parallelograms, three headland loops, 0.15 m')
+    b = E.Batch(E.FieldTable.from_rectangles(R), E.make_vehicle(), E.make_options(1, 0.5))
+    assert b.setup_path() == 'host'
+    b.close()
