@@ -808,15 +808,229 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             const bool span = turn_quiet && P >= 2 && (int64_t)F.n_line - need1 < (F.obs_count > 0 ? (int64_t)64 : tc.span_line_max) && (P - 1) * per < (int64_t)0x7fffffff;
             if (span) { S = (P - 1) * per; span_k = (S + (TILE_POINTS - 2) - 1) / (TILE_POINTS - 2); pos = S; }
         }
+        // ---- the WINDOW cut of one general stretch [a, b) into wave tiles (FieldTiler::wave_tiles): the sparse field's one stretch (fields the
+        // closed-form cut does not take) and, round 5, every stretch of a dense field.  mode 0: counting pass of a sparse field (its first
+        // DEVPLAN_KEEP_TILES tiles kept), 1: its fill pass, 2: a dense field's counting pass (nothing written), 3: its fill pass; e_first / w_first:
+        // the stretch's first statistics entry / wave tile within the field.  -> tiles cut, or -1: the stretch is the general kernel's.
+        const double cap = tiler_halo_cap(tc.u_cap);
+        const int64_t n_main = F.n_main;
+        bool win_staged = false;
+        const DevPrim *wprims = prims;
+        const Pt2 *wtu = tc.tu, *wtc = tc.tc;
+        int32_t my_pstart = INT32_MAX;
+        auto stage_window = [&]() {
+            if (win_staged) return;
+            win_staged = true;
+            const bool lds_prims = STAGE && prim_count <= TW_LDS_PRIMS, lds_tmpl = STAGE && tc.nu + tc.nc <= TW_LDS_TMPL;
+            if (lds_prims && lds_tmpl) {
+                // the usual field: starts, records and templates requested together, then stored -- one round trip to memory, not three
+                static_assert(TW_LDS_PRIMS <= 64 && TW_LDS_TMPL <= 64 && TW_LDS_PRIMS * (sizeof(DevPrim) / 8) <= 6 * 64, "a lane each / six words a lane");
+                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(prims);
+                const int nw = prim_count * (int)(sizeof(DevPrim) / 8);
+                const int64_t st = lane < prim_count ? prims[lane].start : 0;
+                unsigned long long w6[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const int k = lane + 64 * j; w6[j] = k < nw ? src[k] : 0ull; }
+                Pt2 tp = { 0.0, 0.0 };
+                if (lane < tc.nu) tp = tc.tu[lane];
+                else if (lane < tc.nu + tc.nc) tp = tc.tc[lane - tc.nu];
+                if (lane < prim_count) L.pstart[lane] = (int32_t)(st - n_main);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const int k = lane + 64 * j; if (k < nw) L.prim_words[k] = w6[j]; }
+                if (lane < tc.nu + tc.nc) L.tmpl[lane] = tp;
+            } else {
+                for (int k = lane; k < prim_count; k += 64) L.pstart[k] = (int32_t)(prims[k].start - n_main);
+                if (lds_prims) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(prims);
+                    for (int k = lane; k < prim_count * (int)(sizeof(DevPrim) / 8); k += 64) L.prim_words[k] = src[k];
+                }
+                if (lds_tmpl) {
+                    for (int k = lane; k < tc.nu; k += 64) L.tmpl[k] = tc.tu[k];
+                    for (int k = lane; k < tc.nc; k += 64) L.tmpl[tc.nu + k] = tc.tc[k];
+                }
+            }
+            wprims = lds_prims ? reinterpret_cast<const DevPrim *>(L.prim_words) : prims;
+            wtu = lds_tmpl ? L.tmpl : tc.tu; wtc = lds_tmpl ? L.tmpl + tc.nu : tc.tc;
+            wave_sync();                                     // the starts (and the staged records) are in LDS
+            my_pstart = lane < prim_count ? L.pstart[lane] : INT32_MAX;       // (fields of at most 64 primitives: their starts, a lane each)
+            TSTAMP(2);
+        };
+        auto cut_stretch = [&](const int64_t a, const int64_t b, const int mode, const int64_t e_first, const int64_t w_first, int64_t &wave_pts,
+                               int64_t &inside_cnt) -> int64_t {
+            stage_window();
+            // the host evaluates the points [lo - 1, hi) of the stretch at once; here a window of TW_NW points slides along with the cut
+            // (a tile starting at s touches the points [s - 43, s + 171) at most), the points are the same function values wherever the
+            // window lies
+            const int64_t lo_all = (a - WAVE_HALO_MAX - 2 > 1) ? a - WAVE_HALO_MAX - 2 : 1;
+            const int64_t hi_all = (b + WAVE_HALO_MAX + 2 < n_total) ? b + WAVE_HALO_MAX + 2 : n_total;
+            int64_t win0 = 0, win1 = -1;                     // window = path points [win0, win1)
+            auto dist = [&](int64_t i) -> double { return L.d[i - win0 - 1]; };
+            auto prim_of = [&](int64_t i) -> int { return (int)L.pidx[i - win0]; };
+            const int WAVE_LANES = 128;
+            int64_t s = a;
+            int64_t ordinal = 0;
+            bool refused_l = false;
+            while (s < b) {
+                const int64_t need_lo = (s - WAVE_HALO_MAX - 3 > lo_all - 1) ? s - WAVE_HALO_MAX - 3 : lo_all - 1;
+                const int64_t need_hi = (s + WAVE_LANES + WAVE_HALO_MAX + 3 < hi_all) ? s + WAVE_LANES + WAVE_HALO_MAX + 3 : hi_all;
+                if (!(win0 <= need_lo && need_hi <= win1)) {
+                    // ---- the window's points, lane-parallel: step lengths, geofence margin, primitive of every point
+                    wave_sync();
+                    win0 = need_lo; win1 = (win0 + TW_NW < hi_all) ? win0 + TW_NW : hi_all;
+                    const int nwin = (int)(win1 - win0);
+                    double cx = 0.0, cy = 0.0;               // the previous round's last point
+                    for (int w_base = 0; w_base < nwin; w_base += 64) {
+                        const int w = w_base + lane;
+                        const bool valid = w < nwin;
+                        const int64_t i = win0 + (valid ? w : nwin - 1);
+                        double px = 0.0, py = 0.0;
+                        int pk = 0;
+#ifdef FCPP_DIAG_TILE
+#define WSTAMP(k) do { if (w_base == 128) TSTAMP(k); } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
+                        WSTAMP(24);
+                        const int64_t i_last = win0 + ((w_base + 63 < nwin) ? w_base + 63 : nwin - 1);      // (wave-uniform)
+                        if (i < gen_main) {
+                            int64_t idx, off;
+                            if (i_last < ((int64_t)1 << 31)) { const uint32_t q32 = (uint32_t)i / (uint32_t)per; idx = q32; off = (int64_t)((uint32_t)i - q32 * (uint32_t)per); }
+                            else { idx = i / per; off = i - idx * per; }
+                            tiler_point_main(F, wtu, idx, off, px, py);
+                        }
+                        if (i_last >= gen_main) {
+                            // layer 2: the primitives this round's points lie in, one after the other (wave-uniform: a handful per
+                            // round) -- every lane's primitive is the last one that starts at or before its point, as a search per lane finds it
+                            const int64_t i_first = win0 + w_base;
+                            const int32_t rel = (int32_t)(i - n_main);
+                            const int32_t rel_lo = i_first > n_main ? (int32_t)(i_first - n_main) : 0, rel_hi = (int32_t)(i_last - n_main);
+                            // every lane's primitive = the last one that starts at or before its point: the first point's by one ballot
+                            // over the starts (a lane each), the few that start inside the round counted in; fields of more than 64
+                            // primitives search per lane
+                            if (prim_count <= 64) {
+                                int k = __popcll(__ballot(my_pstart <= rel_lo)) - 1;
+                                if (k < 0) k = 0;
+                                pk = k;
+                                for (++k; k < prim_count; ++k) {
+                                    const int32_t st_k = __builtin_amdgcn_readlane(my_pstart, k);
+                                    if (st_k > rel_hi) break;
+                                    pk += rel >= st_k ? 1 : 0;
+                                }
+                            } else {
+                                int lo_k = 0, hi_k = prim_count - 1;
+                                while (lo_k < hi_k) { const int m = (lo_k + hi_k + 1) >> 1; if (L.pstart[m] <= rel) lo_k = m; else hi_k = m - 1; }
+                                pk = lo_k;
+                            }
+                            WSTAMP(25);
+                            if (i >= gen_main) {
+                                const DevPrim q = wprims[pk];
+                                tiler_point_prim(q, wtu, wtc, (int)(i - q.start), px, py);
+                            } else pk = 0;
+                        }
+                        WSTAMP(26);
+                        double qx = __shfl_up(px, 1), qy = __shfl_up(py, 1);
+                        if (lane == 0) { qx = cx; qy = cy; }
+                        cx = __shfl(px, 63); cy = __shfl(py, 63);
+                        if (valid) {
+                            if (w >= 1) { const double dx = px - qx, dy = py - qy; L.d[w - 1] = sqrt(dx * dx + dy * dy); }
+                            WSTAMP(27);
+                            L.pidx[w] = (uint8_t)pk;
+                            L.ins[w] = tiler_inside(F, px, py, tc.fence_margin) ? 1 : 0;
+                        }
+                        WSTAMP(28);
+                    }
+                    wave_sync();
+                }
+                // ---- one step of the greedy cut, wave-uniform
+                TSTAMP(3 + 4 * (int)ordinal);
+                const int Hb = tiler_back_halo(dist, s, tc.two_a, cap);
+                TSTAMP(4 + 4 * (int)ordinal);
+                if (Hb < 0) { refused_l = true; break; }
+                const int64_t cmax = (b - s < WAVE_LANES - Hb) ? b - s : WAVE_LANES - Hb;
+                const int64_t first0 = s - Hb;
+                const int pa0 = first0 + Hb + cmax - 1 >= gen_main ? prim_of(first0 > gen_main ? first0 : gen_main) : 0;
+                // the largest count whose forward halo still fits and whose points lie in at most nine primitives: candidates lane-parallel
+                int64_t c = 0;
+                int Hf = -1;
+                for (int64_t cb = 0; cb < cmax; cb += 64) {
+                    const int64_t cand = cmax - cb - lane;
+                    bool ok = false;
+                    int hf = -1;
+                    if (cand >= 1) {
+                        hf = tiler_fwd_halo(dist, s + cand - 1, n_total, tc.two_a, cap);
+                        ok = hf >= 0 && Hb + cand + hf <= WAVE_LANES;
+                        if (ok) { const int64_t last0 = s + cand - 1 + hf; if (last0 >= gen_main && prim_of(last0) - pa0 > 8) ok = false; }
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (m) {
+                        const int l0 = __builtin_ctzll(m);
+                        c = cmax - cb - l0;
+                        Hf = __shfl(hf, l0);
+                        break;
+                    }
+                }
+                if (c < (b - s < 8 ? b - s : 8)) { refused_l = true; break; }
+                TSTAMP(5 + 4 * (int)ordinal);
+                const int64_t first = s - Hb, last = s + c - 1 + Hf;
+                // every output point inside the geofence with the margin?
+                bool all_in = true;
+                for (int64_t o0 = 0; o0 < c; o0 += 64) {
+                    const int64_t o = o0 + lane;
+                    const bool bad = o < c && L.ins[s + o - win0] == 0;
+                    if (__ballot(bad)) all_in = false;
+                }
+                int pa = 0, pb = 0;
+                if (last >= gen_main) {
+                    const int64_t fl2 = first > gen_main ? first : gen_main;
+                    pa = prim_of(fl2); pb = prim_of(last);
+                    if (pb - pa > 8) { refused_l = true; break; }
+                    bool bad = false;
+                    for (int k = pa + 1; k <= pb; ++k) if (L.pstart[k] <= L.pstart[k - 1]) bad = true;
+                    if (bad) { refused_l = true; break; }
+                }
+                const bool wr_fill = mode == 1 || mode == 3, wr_keep = mode == 0 && ordinal < DEVPLAN_KEEP_TILES;
+                if ((wr_fill || wr_keep) && lane == 0) {
+                    // (count pass: indices relative to the field -- primitive 0 = the field's first, entry 0 = its first, out_base = first)
+                    const int64_t p_base = wr_fill ? prim_index0 : 0;
+                    DevTile t;
+                    t.field = (int32_t)field; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
+                    if (first < gen_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
+                    else { t.idx0 = (int32_t)(p_base + prim_of(first)); t.off0 = 0; }
+                    DevWaveTile wt;
+                    memset(&wt, 0, sizeof wt);
+                    wt.out_base = (wr_fill ? pt_off : 0) + first; wt.field = (int32_t)field;
+                    wt.tile = (int32_t)((wr_fill ? stat_base : 0) + e_first + ordinal);
+                    wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = all_in ? 1 : 0;
+                    wt.rel_main = clampi(gen_main - first); wt.rel_seam = clampi(n_main - first); wt.rel_last = clampi(n_total - 1 - first);
+                    wt.rel_zero = clampi(-first);
+                    wt.idx0 = t.idx0; wt.off0 = t.off0;
+                    for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
+                    if (last >= gen_main) {
+                        wt.p0 = (int32_t)(p_base + pa);
+                        wt.r0 = (int32_t)(first - (n_main + L.pstart[pa]));
+                        for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
+                    }
+                    if (wr_fill) { T.tiles[stat_base + e_first + ordinal] = t; T.wtiles[wave_base + w_first + ordinal] = wt; }
+                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_ROWS + ordinal] = wt; }
+                }
+                TSTAMP(6 + 4 * (int)ordinal);
+                inside_cnt += all_in ? 1 : 0;
+                wave_pts += c;
+                ++ordinal;
+                s += c;
+            }
+            return refused_l ? -1 : ordinal;
+        };
         // ---- DENSE sampling (round 5; FieldTiler::tile_field + derive_field for a field whose complete passes form a span): behind the span the
         // last swath line and every headland straight have a quiet zone of their own (a run: one tile, one statistics entry, chunks on
-        // 512-point boundaries of the batch arrays), the stretches between the zones are cut into general tiles.  The zones a lane each
-        // (lane 0: the last line, lane 1 + k: primitive k), the stretches a lane each, places by prefix sums over the lanes.  Not taken
-        // here (PF_FALLBACK: the host sets the batch up): fields without a span (obstacles, turns that are not closed form), samplings
-        // coarse enough for wave tiles (0.18 m and up at the default accelerations), more than 62 primitives.
+        // 512-point boundaries of the batch arrays); the stretches between the zones are cut into wave tiles (samplings coarse enough for
+        // them -- 0.18 m and up at the default accelerations -- by the window cut above, a stretch after the other; a stretch it refuses
+        // is the general kernel's, as on the host) or into general tiles.  The zones a lane each (lane 0: the last line, lane 1 + k:
+        // primitive k), the stretches a lane each, places by prefix sums over the lanes.  Not taken here (PF_FALLBACK: the host sets the
+        // batch up): fields without a span (obstacles, turns that are not closed form), more than 62 primitives, fields of field work.
         int64_t n_quiet = 0, c_chunks = 0, c_chunk_pts = 0;
         if (dense && !fallback) {
-            if (!(S > 0 && F.obs_count == 0 && !wave_ok && gen_main == F.n_main)) fallback = true;
+            if (!(S > 0 && F.obs_count == 0 && gen_main == F.n_main)) fallback = true;
             else {
                 int64_t q_s = 0, q_n = 0;
                 int q_kind = 0, q_i0 = 0, q_o0 = 0;
@@ -835,41 +1049,79 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                 }
                 const unsigned long long vm = __ballot(valid);
                 const int nq = __popcll(vm), rk = __popcll(vm & ((1ull << lane) - 1ull));
-                // the runs in path order (the window's bytes: this path cuts no wave tile)
-                int64_t *qs = reinterpret_cast<int64_t *>(L.d), *qn = qs + 64;
-                int32_t *qk = reinterpret_cast<int32_t *>(qn + 64), *qi = qk + 64, *qo = qi + 64;
-                static_assert(sizeof(L.d) >= 64 * (8 + 8 + 4 + 4 + 4), "the runs of a dense field fit the window's bytes");
-                if (valid) { qs[rk] = q_s; qn[rk] = q_n; qk[rk] = q_kind; qi[rk] = q_i0; qo[rk] = q_o0; }
-                wave_sync();
-                // stretch j = [end of run j - 1 (the span's for j = 0), start of run j (the path's end for j = nq))
-                int64_t a_j = 0, len_j = 0, ng_j = 0, z_j = 0, s_j = 0, J_j = 0;
-                if (lane <= nq) {
-                    a_j = lane == 0 ? S : qs[lane - 1] + qn[lane - 1];
-                    const int64_t b_j = lane == nq ? n_total : qs[lane];
-                    len_j = b_j > a_j ? b_j - a_j : 0;
-                    ng_j = (len_j + TILE_POINTS - 1) / TILE_POINTS;
+                // the runs in path order: through the window's bytes into the lanes (lane j: run j and the stretch in front of it)
+                int64_t s_j = 0, z_j = 0, a_j = 0, len_j = 0;
+                int k_j = 0, i_j = 0, o_j = 0;
+                {
+                    int64_t *qs = reinterpret_cast<int64_t *>(L.d), *qn = qs + 64;
+                    int32_t *qk = reinterpret_cast<int32_t *>(qn + 64), *qi = qk + 64, *qo = qi + 64;
+                    static_assert(sizeof(L.d) >= 64 * (8 + 8 + 4 + 4 + 4), "the runs of a dense field fit the window's bytes");
+                    wave_sync();
+                    if (valid) { qs[rk] = q_s; qn[rk] = q_n; qk[rk] = q_kind; qi[rk] = q_i0; qo[rk] = q_o0; }
+                    wave_sync();
+                    if (lane < nq) { s_j = qs[lane]; z_j = qn[lane]; k_j = qk[lane]; i_j = qi[lane]; o_j = qo[lane]; }
+                    // stretch j = [end of run j - 1 (the span's for j = 0), start of run j (the path's end for j = nq))
+                    if (lane <= nq) {
+                        a_j = lane == 0 ? S : qs[lane - 1] + qn[lane - 1];
+                        const int64_t b_j = lane == nq ? n_total : s_j;
+                        len_j = b_j > a_j ? b_j - a_j : 0;
+                    }
+                    wave_sync();                                      // (the window cut writes these bytes)
                 }
-                if (lane < nq) {
-                    s_j = qs[lane]; z_j = qn[lane];
-                    J_j = (((pt_off + s_j) % TILE_POINTS) + z_j + TILE_POINTS - 1) / TILE_POINTS;
+                int64_t ng_j = (len_j + TILE_POINTS - 1) / TILE_POINTS, nw_j = 0;       // general tiles of the stretch -- or its wave tiles
+                int64_t wave_pts = 0, inside_cnt = 0;
+                if (wave_ok) {
+                    // a stretch after the other, in path order.  The counting pass leaves its verdicts (bit j: stretch j is the general kernel's)
+                    // in the field's row of the kept-tile scratch; the fill pass cuts only the stretches that take wave tiles, whose records it
+                    // can therefore write as it goes
+                    unsigned long long *verdicts = reinterpret_cast<unsigned long long *>(keep_wtiles + field * DEVPLAN_KEEP_ROWS);
+                    unsigned long long refused_mask = FILL ? verdicts[0] : 0ull;
+                    int64_t e_run = 1, w_run = 0;
+                    for (int j = 0; j <= nq; ++j) {
+                        const int64_t a_s = __shfl(a_j, j), l_s = __shfl(len_j, j);
+                        int64_t t_s = (l_s + TILE_POINTS - 1) / TILE_POINTS;
+                        if (l_s > 0 && !((refused_mask >> j) & 1ull)) {
+                            const int64_t nt = cut_stretch(a_s, a_s + l_s, FILL ? 3 : 2, e_run, w_run, wave_pts, inside_cnt);
+                            if (nt >= 0) {
+                                if (lane == j) { nw_j = nt; ng_j = 0; }
+                                if (FILL)
+                                    for (int64_t i = lane; i < nt; i += 64) {
+                                        const int64_t e = stat_base + e_run + i;
+                                        T.stat_ids[e] = (int32_t)e; T.stat_run[e] = 0;
+                                        unsigned long long *slot = reinterpret_cast<unsigned long long *>(T.partial + e);
+                                        for (int w = 0; w < 13; ++w) slot[w] = 0ull;
+                                    }
+                                t_s = nt; w_run += nt;
+                            } else if (FILL) fallback = true;              // (cannot happen: the counting pass cut this stretch with the same code)
+                            else refused_mask |= 1ull << j;
+                        }
+                        e_run += t_s + 1;
+                    }
+                    if (!FILL && lane == 0) verdicts[0] = refused_mask;
                 }
-                int64_t g_incl = ng_j, j_incl = J_j, z_sum = z_j;
+                const int64_t t_j = lane <= nq ? nw_j + ng_j : 0;                  // entries of the stretch
+                int64_t J_j = 0;
+                if (lane < nq) J_j = (((pt_off + s_j) % TILE_POINTS) + z_j + TILE_POINTS - 1) / TILE_POINTS;
+                int64_t g_incl = lane <= nq ? ng_j : 0, w_incl = nw_j, j_incl = J_j, z_sum = z_j;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
-                    const int64_t u = __shfl_up(g_incl, o), w = __shfl_up(j_incl, o), zz = __shfl_up(z_sum, o);
-                    if (lane >= o) { g_incl += u; j_incl += w; z_sum += zz; }
+                    const int64_t u = __shfl_up(g_incl, o), v = __shfl_up(w_incl, o), w = __shfl_up(j_incl, o), zz = __shfl_up(z_sum, o);
+                    if (lane >= o) { g_incl += u; w_incl += v; j_incl += w; z_sum += zz; }
                 }
-                const int64_t g_before = g_incl - ng_j, j_before = j_incl - J_j;
-                n_general = __shfl(g_incl, 63); c_chunks = __shfl(j_incl, 63); c_chunk_pts = __shfl(z_sum, 63);
+                if (lane > nq) ng_j = 0;
+                const int64_t g_before = g_incl - ng_j, w_before = w_incl - nw_j, j_before = j_incl - J_j;
+                n_general = __shfl(g_incl, 63); n_wave = __shfl(w_incl, 63); c_chunks = __shfl(j_incl, 63); c_chunk_pts = __shfl(z_sum, 63);
+                c_wave_pts = wave_pts; c_wave_inside = inside_cnt;
                 n_quiet = nq;
-                if (FILL) {
+                const int64_t E_j = 1 + g_before + w_before + lane;                  // the stretch's first entry within the field
+                if (FILL && !fallback) {
                     const int64_t chunk_base = base_of(PC_CHUNKS);
-                    // general tiles of stretch `lane`: near-equal, at most 512 points (emit_general); entries [1 + g_before + lane, + ng_j)
+                    // general tiles of stretch `lane`: near-equal, at most 512 points (emit_general)
                     if (lane <= nq && ng_j > 0) {
                         const int64_t bs = len_j / ng_j, rem = len_j % ng_j;
                         for (int64_t i = 0; i < ng_j; ++i) {
                             const int64_t st = a_j + i * bs + (i < rem ? i : rem), cnt = bs + (i < rem ? 1 : 0);
-                            const int64_t e = stat_base + 1 + g_before + lane + i;
+                            const int64_t e = stat_base + E_j + i;
                             const bool l1 = per > 0 && st < gen_main;
                             DevTile t;
                             t.field = (int32_t)field; t.start = st; t.count = (int32_t)cnt; t.quiet = 0; t.stat_tile = (int32_t)e;
@@ -883,11 +1135,11 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                     }
                     // the runs: tile, entry, closed-form statistics, chunks
                     if (lane < nq) {
-                        const int64_t e = stat_base + 1 + g_before + ng_j + lane;
-                        const int64_t cap = TILE_POINTS - 2, k = (z_j + cap - 1) / cap, bs = z_j / k, rem = z_j % k;
+                        const int64_t e = stat_base + E_j + t_j;
+                        const int64_t capq = TILE_POINTS - 2, k = (z_j + capq - 1) / capq, bs = z_j / k, rem = z_j % k;
                         DevTile t;
-                        t.field = (int32_t)field; t.start = s_j; t.count = (int32_t)(bs + (rem > 0 ? 1 : 0)); t.quiet = qk[lane]; t.stat_tile = 0;
-                        t.idx0 = qk[lane] == 2 ? (int32_t)(prim_index0 + qi[lane]) : qi[lane]; t.off0 = qo[lane];
+                        t.field = (int32_t)field; t.start = s_j; t.count = (int32_t)(bs + (rem > 0 ? 1 : 0)); t.quiet = k_j; t.stat_tile = 0;
+                        t.idx0 = k_j == 2 ? (int32_t)(prim_index0 + i_j) : i_j; t.off0 = o_j;
                         T.tiles[e] = t;
                         T.stat_ids[e] = (int32_t)e; T.stat_run[e] = z_j;
                         double2 junc = make_double2(0.0, 0.0);
@@ -895,7 +1147,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                         FieldStatView fv;
                         fv.n_line = F.n_line; fv.n_turn = F.n_turn; fv.reverse_order = F.reverse_order; fv.line_step = F.line_step; fv.n_main = F.n_main; fv.junc = junc;
                         DevTile tl = t;
-                        tl.idx0 = qi[lane];                              // (the field's own primitives: `prims`)
+                        tl.idx0 = i_j;                                   // (the field's own primitives: `prims`)
                         const DevRun run = { (int32_t)e, 0, z_j };
                         TilePartial tp = quiet_run_partial(run, tl, fv, prims, cst);
                         tp.n_viol = tp.n_outside = tp.n_in_obstacle = tp.n_adjusted = 0;
@@ -915,11 +1167,10 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         }
         const int64_t a = pos, b = n_total, G = b - a;
         bool use_wave = wave_ok && G > 0 && !fallback && !dense;
-        bool refused = false;
         // the count pass has already decided whether the stretch takes wave tiles: the fill pass reads its verdict
         if (FILL && use_wave) {
             const int64_t cw = counts[(int64_t)PC_WAVE * n + field];
-            if (cw == 0) { use_wave = false; refused = true; }
+            if (cw == 0) use_wave = false;
             else if (cw <= DEVPLAN_KEEP_TILES || (tc.closed_cut != 0 && a == cut_span_points(F, tc.cut) && cut_applies(F, tc.cut, a))) {       // (a closed-form cut: every tile was kept)
                 // the counting pass kept this field's wave tiles: copy them, indices made batch-wide
                 use_wave = false;
@@ -1021,8 +1272,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                     if (__shfl(code, __builtin_ctzll(bad)) == 1) break;           // a halo too long: the general kernel's
                 }
             TSTAMP(13);
-            if (nt == 0) refused = true;
-            else {
+            if (nt != 0) {
                 // the last primitive that starts at or before point i >= n_main: the starts a lane each, one ballot per tile and question
                 const int32_t my_start = lane < prim_count ? (int32_t)(q.start - n_main) : INT32_MAX;
                 const int64_t first_l = s - Hb, last_l = s + c - 1 + Hf;
@@ -1065,201 +1315,9 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
             }
         }
         if (use_wave) {
-            const double cap = tiler_halo_cap(tc.u_cap);
-            // the host evaluates the points [lo - 1, hi) of the stretch at once; here a window of TW_NW points slides along with the cut
-            // (a tile starting at s touches the points [s - 43, s + 171) at most), the points are the same function values wherever the
-            // window lies
-            const int64_t lo_all = (a - WAVE_HALO_MAX - 2 > 1) ? a - WAVE_HALO_MAX - 2 : 1;
-            const int64_t hi_all = (b + WAVE_HALO_MAX + 2 < n_total) ? b + WAVE_HALO_MAX + 2 : n_total;
-            const int64_t n_main = F.n_main;
-            const bool lds_prims = STAGE && prim_count <= TW_LDS_PRIMS, lds_tmpl = STAGE && tc.nu + tc.nc <= TW_LDS_TMPL;
-            if (lds_prims && lds_tmpl) {
-                // the usual field: starts, records and templates requested together, then stored -- one round trip to memory, not three
-                static_assert(TW_LDS_PRIMS <= 64 && TW_LDS_TMPL <= 64 && TW_LDS_PRIMS * (sizeof(DevPrim) / 8) <= 6 * 64, "a lane each / six words a lane");
-                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(prims);
-                const int nw = prim_count * (int)(sizeof(DevPrim) / 8);
-                const int64_t st = lane < prim_count ? prims[lane].start : 0;
-                unsigned long long w6[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) { const int k = lane + 64 * j; w6[j] = k < nw ? src[k] : 0ull; }
-                Pt2 tp = { 0.0, 0.0 };
-                if (lane < tc.nu) tp = tc.tu[lane];
-                else if (lane < tc.nu + tc.nc) tp = tc.tc[lane - tc.nu];
-                if (lane < prim_count) L.pstart[lane] = (int32_t)(st - n_main);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) { const int k = lane + 64 * j; if (k < nw) L.prim_words[k] = w6[j]; }
-                if (lane < tc.nu + tc.nc) L.tmpl[lane] = tp;
-            } else {
-                for (int k = lane; k < prim_count; k += 64) L.pstart[k] = (int32_t)(prims[k].start - n_main);
-                if (lds_prims) {
-                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(prims);
-                    for (int k = lane; k < prim_count * (int)(sizeof(DevPrim) / 8); k += 64) L.prim_words[k] = src[k];
-                }
-                if (lds_tmpl) {
-                    for (int k = lane; k < tc.nu; k += 64) L.tmpl[k] = tc.tu[k];
-                    for (int k = lane; k < tc.nc; k += 64) L.tmpl[tc.nu + k] = tc.tc[k];
-                }
-            }
-            const DevPrim *const wprims = lds_prims ? reinterpret_cast<const DevPrim *>(L.prim_words) : prims;
-            const Pt2 *const wtu = lds_tmpl ? L.tmpl : tc.tu, *const wtc = lds_tmpl ? L.tmpl + tc.nu : tc.tc;
-            wave_sync();                                     // the starts (and the staged records) are in LDS
-            const int32_t my_pstart = lane < prim_count ? L.pstart[lane] : INT32_MAX;       // (fields of at most 64 primitives: their starts, a lane each)
-            TSTAMP(2);
-            int64_t win0 = 0, win1 = -1;                     // window = path points [win0, win1)
-            auto dist = [&](int64_t i) -> double { return L.d[i - win0 - 1]; };
-            auto prim_of = [&](int64_t i) -> int { return (int)L.pidx[i - win0]; };
-            const int WAVE_LANES = 128;
-            int64_t s = a;
-            int64_t ordinal = 0, wave_pts = 0, inside_cnt = 0;
-            while (s < b) {
-                const int64_t need_lo = (s - WAVE_HALO_MAX - 3 > lo_all - 1) ? s - WAVE_HALO_MAX - 3 : lo_all - 1;
-                const int64_t need_hi = (s + WAVE_LANES + WAVE_HALO_MAX + 3 < hi_all) ? s + WAVE_LANES + WAVE_HALO_MAX + 3 : hi_all;
-                if (!(win0 <= need_lo && need_hi <= win1)) {
-                    // ---- the window's points, lane-parallel: step lengths, geofence margin, primitive of every point
-                    wave_sync();
-                    win0 = need_lo; win1 = (win0 + TW_NW < hi_all) ? win0 + TW_NW : hi_all;
-                    const int nwin = (int)(win1 - win0);
-                    double cx = 0.0, cy = 0.0;               // the previous round's last point
-                    for (int w_base = 0; w_base < nwin; w_base += 64) {
-                        const int w = w_base + lane;
-                        const bool valid = w < nwin;
-                        const int64_t i = win0 + (valid ? w : nwin - 1);
-                        double px = 0.0, py = 0.0;
-                        int pk = 0;
-#ifdef FCPP_DIAG_TILE
-#define WSTAMP(k) do { if (w_base == 128) TSTAMP(k); } while (0)
-#else
-#define WSTAMP(k) do { } while (0)
-#endif
-                        WSTAMP(24);
-                        const int64_t i_last = win0 + ((w_base + 63 < nwin) ? w_base + 63 : nwin - 1);      // (wave-uniform)
-                        if (i < gen_main) {
-                            int64_t idx, off;
-                            if (i_last < ((int64_t)1 << 31)) { const uint32_t q32 = (uint32_t)i / (uint32_t)per; idx = q32; off = (int64_t)((uint32_t)i - q32 * (uint32_t)per); }
-                            else { idx = i / per; off = i - idx * per; }
-                            tiler_point_main(F, wtu, idx, off, px, py);
-                        }
-                        if (i_last >= gen_main) {
-                            // layer 2: the primitives this round's points lie in, one after the other (wave-uniform: a handful per
-                            // round) -- every lane's primitive is the last one that starts at or before its point, as a search per lane finds it
-                            const int64_t i_first = win0 + w_base;
-                            const int32_t rel = (int32_t)(i - n_main);
-                            const int32_t rel_lo = i_first > n_main ? (int32_t)(i_first - n_main) : 0, rel_hi = (int32_t)(i_last - n_main);
-                            // every lane's primitive = the last one that starts at or before its point: the first point's by one ballot
-                            // over the starts (a lane each), the few that start inside the round counted in; fields of more than 64
-                            // primitives search per lane
-                            if (prim_count <= 64) {
-                                int k = __popcll(__ballot(my_pstart <= rel_lo)) - 1;
-                                if (k < 0) k = 0;
-                                pk = k;
-                                for (++k; k < prim_count; ++k) {
-                                    const int32_t st_k = __builtin_amdgcn_readlane(my_pstart, k);
-                                    if (st_k > rel_hi) break;
-                                    pk += rel >= st_k ? 1 : 0;
-                                }
-                            } else {
-                                int lo_k = 0, hi_k = prim_count - 1;
-                                while (lo_k < hi_k) { const int m = (lo_k + hi_k + 1) >> 1; if (L.pstart[m] <= rel) lo_k = m; else hi_k = m - 1; }
-                                pk = lo_k;
-                            }
-                            WSTAMP(25);
-                            if (i >= gen_main) {
-                                const DevPrim q = wprims[pk];
-                                tiler_point_prim(q, wtu, wtc, (int)(i - q.start), px, py);
-                            } else pk = 0;
-                        }
-                        WSTAMP(26);
-                        double qx = __shfl_up(px, 1), qy = __shfl_up(py, 1);
-                        if (lane == 0) { qx = cx; qy = cy; }
-                        cx = __shfl(px, 63); cy = __shfl(py, 63);
-                        if (valid) {
-                            if (w >= 1) { const double dx = px - qx, dy = py - qy; L.d[w - 1] = sqrt(dx * dx + dy * dy); }
-                            WSTAMP(27);
-                            L.pidx[w] = (uint8_t)pk;
-                            L.ins[w] = tiler_inside(F, px, py, tc.fence_margin) ? 1 : 0;
-                        }
-                        WSTAMP(28);
-                    }
-                    wave_sync();
-                }
-                // ---- one step of the greedy cut, wave-uniform
-                TSTAMP(3 + 4 * (int)ordinal);
-                const int Hb = tiler_back_halo(dist, s, tc.two_a, cap);
-                TSTAMP(4 + 4 * (int)ordinal);
-                if (Hb < 0) { refused = true; break; }
-                const int64_t cmax = (b - s < WAVE_LANES - Hb) ? b - s : WAVE_LANES - Hb;
-                const int64_t first0 = s - Hb;
-                const int pa0 = first0 + Hb + cmax - 1 >= gen_main ? prim_of(first0 > gen_main ? first0 : gen_main) : 0;
-                // the largest count whose forward halo still fits and whose points lie in at most nine primitives: candidates lane-parallel
-                int64_t c = 0;
-                int Hf = -1;
-                for (int64_t cb = 0; cb < cmax; cb += 64) {
-                    const int64_t cand = cmax - cb - lane;
-                    bool ok = false;
-                    int hf = -1;
-                    if (cand >= 1) {
-                        hf = tiler_fwd_halo(dist, s + cand - 1, n_total, tc.two_a, cap);
-                        ok = hf >= 0 && Hb + cand + hf <= WAVE_LANES;
-                        if (ok) { const int64_t last0 = s + cand - 1 + hf; if (last0 >= gen_main && prim_of(last0) - pa0 > 8) ok = false; }
-                    }
-                    const unsigned long long m = __ballot(ok);
-                    if (m) {
-                        const int l0 = __builtin_ctzll(m);
-                        c = cmax - cb - l0;
-                        Hf = __shfl(hf, l0);
-                        break;
-                    }
-                }
-                if (c < (b - s < 8 ? b - s : 8)) { refused = true; break; }
-                TSTAMP(5 + 4 * (int)ordinal);
-                const int64_t first = s - Hb, last = s + c - 1 + Hf;
-                // every output point inside the geofence with the margin?
-                bool all_in = true;
-                for (int64_t o0 = 0; o0 < c; o0 += 64) {
-                    const int64_t o = o0 + lane;
-                    const bool bad = o < c && L.ins[s + o - win0] == 0;
-                    if (__ballot(bad)) all_in = false;
-                }
-                int pa = 0, pb = 0;
-                if (last >= gen_main) {
-                    const int64_t fl2 = first > gen_main ? first : gen_main;
-                    pa = prim_of(fl2); pb = prim_of(last);
-                    if (pb - pa > 8) { refused = true; break; }
-                    bool bad = false;
-                    for (int k = pa + 1; k <= pb; ++k) if (L.pstart[k] <= L.pstart[k - 1]) bad = true;
-                    if (bad) { refused = true; break; }
-                }
-                if ((FILL || ordinal < DEVPLAN_KEEP_TILES) && lane == 0) {
-                    // (count pass: indices relative to the field -- primitive 0 = the field's first, entry 0 = its first, out_base = first)
-                    const int64_t p_base = FILL ? prim_index0 : 0;
-                    DevTile t;
-                    t.field = (int32_t)field; t.count = (int32_t)c; t.start = s; t.quiet = 5; t.stat_tile = Hb | (Hf << 16);
-                    if (first < gen_main) { t.idx0 = (int32_t)(first / per); t.off0 = (int32_t)(first % per); }
-                    else { t.idx0 = (int32_t)(p_base + prim_of(first)); t.off0 = 0; }
-                    DevWaveTile wt;
-                    memset(&wt, 0, sizeof wt);
-                    wt.out_base = (FILL ? pt_off : 0) + first; wt.field = (int32_t)field;
-                    wt.tile = (int32_t)((FILL ? stat_base : 0) + (span_k > 0 ? 1 : 0) + ordinal);
-                    wt.count = (uint8_t)c; wt.hb = (uint8_t)Hb; wt.hf = (uint8_t)Hf; wt.inside = all_in ? 1 : 0;
-                    wt.rel_main = clampi(gen_main - first); wt.rel_seam = clampi(n_main - first); wt.rel_last = clampi(n_total - 1 - first);
-                    wt.rel_zero = clampi(-first);
-                    wt.idx0 = t.idx0; wt.off0 = t.off0;
-                    for (int k = 0; k < 8; ++k) wt.thr[k] = 255;
-                    if (last >= gen_main) {
-                        wt.p0 = (int32_t)(p_base + pa);
-                        wt.r0 = (int32_t)(first - (n_main + L.pstart[pa]));
-                        for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
-                    }
-                    if (FILL) { T.tiles[stat_base + (span_k > 0 ? 1 : 0) + ordinal] = t; T.wtiles[wave_base + ordinal] = wt; }
-                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_ROWS + ordinal] = wt; }
-                }
-                TSTAMP(6 + 4 * (int)ordinal);
-                inside_cnt += all_in ? 1 : 0;
-                wave_pts += c;
-                ++ordinal;
-                s += c;
-            }
-            if (!refused) { n_wave = ordinal; c_wave_pts = wave_pts; c_wave_inside = inside_cnt; }
+            int64_t wave_pts = 0, inside_cnt = 0;
+            const int64_t nt = cut_stretch(a, b, FILL ? 1 : 0, span_k > 0 ? 1 : 0, 0, wave_pts, inside_cnt);
+            if (nt >= 0) { n_wave = nt; c_wave_pts = wave_pts; c_wave_inside = inside_cnt; }
             TSTAMP(36);
         }
         if (G > 0 && n_wave == 0 && !fallback && !dense) {
@@ -1283,9 +1341,11 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         // a field whose general points are all in a few wave tiles is planned AND reduced by one workgroup (k_plan_sparse_fields), which
         // then writes the field's span too (fuse_spans): its chunks are not in k_plan_quiet's list
         {
-            const int64_t ne0 = (span_k > 0 ? 1 : 0) + n_wave + n_general;
+            const int64_t ne0 = (span_k > 0 ? 1 : 0) + n_wave + n_general + n_quiet;
             const int fw_max = tc.field_work_tiles < FIELD_WORK_TILES ? tc.field_work_tiles : FIELD_WORK_TILES;
             is_work = n_general == 0 && n_wave >= 1 && n_wave <= fw_max && ne0 <= FIELD_WORK_ENTRIES;
+            // (a dense field of field work -- few wave tiles, nothing general -- gets a pack and a fused span on the host: not built here)
+            if (dense && is_work) { is_work = false; fallback = true; }
         }
         // ---- the span's tiles (near-equal, at most 510 points: the closed-form kernel stores aligned pairs) and its chunks on 512-point
         // boundaries of the batch arrays

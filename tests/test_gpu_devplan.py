@@ -172,16 +172,20 @@ def test_fields_with_obstacle_polygons_flag_mode():
 
 
 def test_what_the_device_planner_does_not_take_goes_to_the_host():
+    """obstacle-aware swaths, and dense sampling of fields WITH obstacles (a run per line and turn); dense fields without obstacles are the
+    device's since round 5 (test_dense_sampling_tables_equal_the_hosts)"""
     ctx = E.get_context()
     t = E.FieldTable.from_rectangles(WL.cfg2_rectangles(64))
-    for opt in (E.make_options(1, 0.5), E.make_options(avoid_obstacles=True)):
-        b = E.Batch(t, E.make_vehicle(), opt)
+    sq = [[(40.0, 40.0), (50.0, 40.0), (50.0, 50.0), (40.0, 50.0)]]
+    t_obs = E.FieldTable.from_specs([E.FieldSpec(field_length=300.0 + 7 * k, field_width=200.0 + 3 * k, obstacles=sq) for k in range(24)])
+    for tab, opt in ((t_obs, E.make_options(1, 0.5)), (t, E.make_options(avoid_obstacles=True))):
+        b = E.Batch(tab, E.make_vehicle(), opt)
         assert b.setup_path() == 'host'
         b.close()
         ctx.set_setup('device')
         try:
             with pytest.raises(L.FcppError):
-                E.Batch(t, E.make_vehicle(), opt)
+                E.Batch(tab, E.make_vehicle(), opt)
         finally:
             ctx.set_setup('auto')
     b = E.Batch(t, E.make_vehicle(), E.make_options())
@@ -302,14 +306,19 @@ def test_one_call_plan_equals_create_alloc_run():
 
 def test_dense_sampling_tables_equal_the_hosts():
     """Round 5: batches at dense sampling whose fields have no obstacles are set up on the device too -- the span of all complete passes, the
-    quiet zones of the last swath line and of the headland straights as runs with their chunks, general tiles between them -- and must
-    equal the host's tables byte for byte; a sampling coarse enough for wave tiles (0.5 m) is still the host's (setup_path says so)."""
+    quiet zones of the last swath line and of the headland straights as runs with their chunks, and between them general tiles (fine
+    samplings) or wave tiles cut by the window cut, a stretch after the other (0.18 m and coarser) -- and must equal the host's tables
+    byte for byte.  Fields with obstacles keep a run per line and turn: the host's (setup_path says so)."""
     R = WL.cfg2_rectangles()[:64]
     V = WL.cfg5_parallelograms(48)
-    for tm, sp in ((1, 0.1), (0, 0.12), (1, 0.05)):
+    for tm, sp in ((1, 0.1), (0, 0.12), (1, 0.05), (1, 0.5), (0, 0.25), (1, 1.7)):
         _compare(*_both(E.FieldTable.from_rectangles(R), E.make_vehicle(), E.make_options(tm, sp)), f'rectangles, turn model {tm}, {sp} m')
     _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(), E.make_options(1, 0.1)), 'parallelograms, clothoid, 0.1 m')
+    _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(), E.make_options(1, 0.5)), 'parallelograms, clothoid, 0.5 m')
     _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(working_width=1.2), E.make_options(0, 0.15)), 'parallelograms, three headland loops, 0.15 m')
-    b = E.Batch(E.FieldTable.from_rectangles(R), E.make_vehicle(), E.make_options(1, 0.5))
+    _compare(*_both(E.FieldTable.from_vertices(V), E.make_vehicle(working_width=1.2), E.make_options(0, 0.4)), 'parallelograms, three headland loops, 0.4 m')
+    (L_, H_), obst = WL.cfg3_field()
+    b = E.Batch([E.FieldSpec(field_length=L_ / 10, field_width=H_ / 10 + k, obstacles=[[(20.0, 20.0), (30.0, 20.0), (30.0, 30.0), (20.0, 30.0)]]) for k in range(20)],
+                E.make_vehicle(), E.make_options(1, 0.1))
     assert b.setup_path() == 'host'
     b.close()
