@@ -185,7 +185,17 @@ struct fcpp_ctx {
     // up to kStageMax; larger images go through a pageable buffer), and the last destroyed batch's device allocation is kept for the
     // next one (up to kSpareMax): a caller that plans batch after batch allocates nothing after the first
     void *stage = nullptr; size_t stage_cap = 0;
-    hipEvent_t ev_stage = nullptr; bool ev_stage_set = false;    // behind the last asynchronous copy out of `stage` (the device-side setup's obstacle table)
+    // the stream of the last asynchronous copy out of `stage`: whoever writes that memory next drains it first (a caller that plans batch
+    // after batch has drained it long before: a query; no event -- a record between two kernels holds the second back by 5 us)
+    hipStream_t stage_stream = nullptr; bool stage_busy = false;
+    hipError_t stage_wait()
+    {
+        if (!stage_busy) return hipSuccess;
+        stage_busy = false;
+        hipError_t e = hipStreamSynchronize(stage_stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipDeviceSynchronize(); }      // (that stream is gone)
+        return e;
+    }
     void *spare = nullptr; size_t spare_cap = 0;
     std::shared_ptr<TemplateSet> templates;         // the last batch's turn templates
     fcpp_setup_times last_setup = {};
@@ -431,7 +441,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     free_paths_cache(c);
-    if (c->ev_stage) { if (c->ev_stage_set) (void)hipEventSynchronize(c->ev_stage); (void)hipEventDestroy(c->ev_stage); }
+    (void)c->stage_wait();
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->spare) (void)hipFree(c->spare);
     if (c->plan_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->plan_scratch); }
@@ -867,12 +877,12 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     auto upload_obstacles = [&]() -> int {
         if (lay.n_polys <= 0) return FCPP_OK;
         // (the obstacle region of the image -- it alone, offsets rebased -- through the context's pinned staging memory, pageable when that
-        // cannot be had; the copy out of the staging memory is asynchronous: ev_stage orders the next writer of that memory behind it)
+        // cannot be had; the copy out of the staging memory is asynchronous: the next writer of that memory drains this stream first)
         const size_t o0 = lay.obs_off, o1 = lay.seg, nb = o1 - o0;
         std::vector<unsigned char> tmp;
         unsigned char *img = nullptr;
         if (nb <= kStageMax) {
-            if (c->ev_stage_set) { DEVCHK(hipEventSynchronize(c->ev_stage)); c->ev_stage_set = false; }
+            DEVCHK(c->stage_wait());
             if (c->stage_cap < nb) {
                 if (c->stage) { (void)hipHostFree(c->stage); c->stage = nullptr; c->stage_cap = 0; }
                 if (hipHostMalloc(&c->stage, nb + nb / 4, hipHostMallocDefault) == hipSuccess) c->stage_cap = nb + nb / 4;
@@ -885,9 +895,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         DEVCHK(hipMemcpyAsync(static_cast<unsigned char *>(b->slab) + o0, img, nb, hipMemcpyHostToDevice, st));
         if (!tmp.empty()) DEVCHK(hipStreamSynchronize(st));
         else {
-            if (!c->ev_stage) DEVCHK(hipEventCreateWithFlags(&c->ev_stage, hipEventDisableTiming));
-            DEVCHK(hipEventRecord(c->ev_stage, st));
-            c->ev_stage_set = true;
+            c->stage_stream = st; c->stage_busy = true;
         }
         return FCPP_OK;
     };
@@ -1136,7 +1144,7 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
     unsigned char *img = nullptr;
     std::vector<unsigned char> pageable;
     if (lay.upload_bytes <= kStageMax) {
-        if (c->ev_stage_set) { HIPCHK(hipEventSynchronize(c->ev_stage)); c->ev_stage_set = false; }
+        HIPCHK(c->stage_wait());
         if (c->stage_cap < lay.upload_bytes) {
             if (c->stage) { (void)hipHostFree(c->stage); c->stage = nullptr; c->stage_cap = 0; }
             const size_t want = std::min(kStageMax, std::max<size_t>(lay.upload_bytes + lay.upload_bytes / 4, (size_t)1 << 20));
@@ -1169,7 +1177,11 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
         LAUNCHCHK(launch_run_consts(st, lay.n_stat, b->t.stat_ids, b->t.stat_run, b->t.tiles, b->t.fields, b->t.prims, b->cst, b->t.partial));
         LAUNCHCHK(launch_work_totals(st, lay.n_field_work, b->t.field_work, b->t.stat_run, b->t.partial, b->t.work_totals));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    // The stream is NOT drained when the image went through the context's pinned staging memory (round 5; as the device-side setup leaves it):
+    // a step enqueued next runs right behind the copy and the setup kernels, a consumer on another stream is ordered behind them (wait_setup),
+    // the staging memory's next writer drains this stream first (stage_wait).  A pageable image is freed on return: drained.
+    if (!pageable.empty() || lay.upload_bytes == 0) HIPCHK(hipStreamSynchronize(st));
+    else { c->stage_stream = st; c->stage_busy = true; b->setup_stream = st; b->setup_pending = true; }
     tm.h2d_ms = ms_since(t0);
     tm.total_ms = ms_since(t_begin);
     c->last_setup = tm;
