@@ -19,6 +19,8 @@ elif what in ('cfg3', 'cfg3_avoid'):
     (L_, H_), obst_ = WL.cfg3_field()
     table = E.FieldTable.from_specs([E.FieldSpec(field_length=L_, field_width=H_, obstacles=obst_)])
     opt = E.make_options(1, 0.05, avoid_obstacles=(what == 'cfg3_avoid'))
+elif what.startswith('n') and what[1:].isdigit():          # n<k>: k fields of 500 x 200 m (the small-batch rule: FCPP_SMALL_BATCH)
+    table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (int(what[1:]), 1)) + np.arange(int(what[1:]))[:, None] * 0.37)
 elif what == 'cfg1_clothoid_dense':
     table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (4096, 1)))
     opt = E.make_options(1, 0.1)
