@@ -71,7 +71,7 @@ struct DevPlanScratch {
     // the counting pass keeps the first DEVPLAN_KEEP_TILES wave tiles of every field (records with field-relative indices): the fill pass
     // copies and rebases them instead of cutting the field again (fields with more are cut again)
     DevTile *keep_tiles;          // n x DEVPLAN_KEEP_ROWS
-    DevWaveTile *keep_wtiles;     // n x DEVPLAN_KEEP_ROWS
+    DevWaveTile *keep_wtiles;     // n x DEVPLAN_KEEP_WROWS
 };
 size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *offsets_as_pointers /* offsets from 0, cast to pointers */);
 
@@ -92,6 +92,10 @@ constexpr int DEVPLAN_PRIMS_CAP = 255;
 constexpr int DEVPLAN_KEEP_TILES = 8;
 constexpr int DEVPLAN_KEEP_ROWS = CUT_TILES_MAX;      // rows per field of the kept-tile arrays: every tile of a closed-form cut is kept (the fill pass never cuts such a field again)
 static_assert(DEVPLAN_KEEP_ROWS >= DEVPLAN_KEEP_TILES, "the window cut keeps its first DEVPLAN_KEEP_TILES tiles in the same rows");
+// rows per field of the kept WAVE-tile array: one more, whose 64 bytes hold a dense field's wave tiles per stretch (byte j: stretch j; 255: the
+// stretch is the general kernel's) -- the counting pass's verdicts, read by the fill pass
+constexpr int DEVPLAN_KEEP_WROWS = DEVPLAN_KEEP_ROWS + 1;
+static_assert(sizeof(DevWaveTile) == 64, "a row of the kept wave tiles holds the 64 stretches' bytes");
 
 // Small batches (at most 8192 fields) are counted WITHOUT the fields' point offsets: what depends on a span's alignment in the batch arrays
 // -- its chunk count, hence whether its field's workgroup can write it (PC_SPAN, PC_SPAN_F, PC_WORK_SPAN_PTS, PC_UNFUSABLE) -- is derived by the

@@ -23,7 +23,7 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
     o->bases = reinterpret_cast<int64_t *>(take(nn * PC_COLS * sizeof(int64_t)));
     o->blk_sums = reinterpret_cast<int64_t *>(take(nblk * PC_COLS * sizeof(int64_t)));
     o->keep_tiles = reinterpret_cast<DevTile *>(take(nn * DEVPLAN_KEEP_ROWS * sizeof(DevTile)));
-    o->keep_wtiles = reinterpret_cast<DevWaveTile *>(take(nn * DEVPLAN_KEEP_ROWS * sizeof(DevWaveTile)));
+    o->keep_wtiles = reinterpret_cast<DevWaveTile *>(take(nn * DEVPLAN_KEEP_WROWS * sizeof(DevWaveTile)));
     return off;
 }
 
@@ -988,7 +988,10 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                     for (int k = pa + 1; k <= pb; ++k) if (L.pstart[k] <= L.pstart[k - 1]) bad = true;
                     if (bad) { refused_l = true; break; }
                 }
-                const bool wr_fill = mode == 1 || mode == 3, wr_keep = mode == 0 && ordinal < DEVPLAN_KEEP_TILES;
+                // (kept by the counting pass, indices relative to the field: a sparse field's first DEVPLAN_KEEP_TILES tiles, a dense field's first
+                // DEVPLAN_KEEP_ROWS over all its stretches -- row = the tile's number within the field)
+                const bool wr_fill = mode == 1 || mode == 3;
+                const bool wr_keep = (mode == 0 && ordinal < DEVPLAN_KEEP_TILES) || (mode == 2 && w_first + ordinal < DEVPLAN_KEEP_ROWS);
                 if ((wr_fill || wr_keep) && lane == 0) {
                     // (count pass: indices relative to the field -- primitive 0 = the field's first, entry 0 = its first, out_base = first)
                     const int64_t p_base = wr_fill ? prim_index0 : 0;
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                         for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
                     }
                     if (wr_fill) { T.tiles[stat_base + e_first + ordinal] = t; T.wtiles[wave_base + w_first + ordinal] = wt; }
-                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_ROWS + ordinal] = wt; }
+                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + w_first + ordinal] = t; keep_wtiles[field * DEVPLAN_KEEP_WROWS + w_first + ordinal] = wt; }
                 }
                 TSTAMP(6 + 4 * (int)ordinal);
                 inside_cnt += all_in ? 1 : 0;
@@ -1071,33 +1074,71 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                 int64_t ng_j = (len_j + TILE_POINTS - 1) / TILE_POINTS, nw_j = 0;       // general tiles of the stretch -- or its wave tiles
                 int64_t wave_pts = 0, inside_cnt = 0;
                 if (wave_ok) {
-                    // a stretch after the other, in path order.  The counting pass leaves its verdicts (bit j: stretch j is the general kernel's)
-                    // in the field's row of the kept-tile scratch; the fill pass cuts only the stretches that take wave tiles, whose records it
-                    // can therefore write as it goes
-                    unsigned long long *verdicts = reinterpret_cast<unsigned long long *>(keep_wtiles + field * DEVPLAN_KEEP_ROWS);
-                    unsigned long long refused_mask = FILL ? verdicts[0] : 0ull;
-                    int64_t e_run = 1, w_run = 0;
-                    for (int j = 0; j <= nq; ++j) {
-                        const int64_t a_s = __shfl(a_j, j), l_s = __shfl(len_j, j);
-                        int64_t t_s = (l_s + TILE_POINTS - 1) / TILE_POINTS;
-                        if (l_s > 0 && !((refused_mask >> j) & 1ull)) {
-                            const int64_t nt = cut_stretch(a_s, a_s + l_s, FILL ? 3 : 2, e_run, w_run, wave_pts, inside_cnt);
-                            if (nt >= 0) {
-                                if (lane == j) { nw_j = nt; ng_j = 0; }
-                                if (FILL)
-                                    for (int64_t i = lane; i < nt; i += 64) {
-                                        const int64_t e = stat_base + e_run + i;
-                                        T.stat_ids[e] = (int32_t)e; T.stat_run[e] = 0;
-                                        unsigned long long *slot = reinterpret_cast<unsigned long long *>(T.partial + e);
-                                        for (int w = 0; w < 13; ++w) slot[w] = 0ull;
-                                    }
-                                t_s = nt; w_run += nt;
-                            } else if (FILL) fallback = true;              // (cannot happen: the counting pass cut this stretch with the same code)
-                            else refused_mask |= 1ull << j;
+                    // a stretch after the other, in path order.  The counting pass keeps the field's first DEVPLAN_KEEP_ROWS wave tiles (indices and
+                    // entries relative to the field) and, in the row behind them, a byte per stretch: its wave tiles, or 255 -- the general
+                    // kernel's, as the host decides.  The fill pass copies the kept tiles (a lane each); a field with more cuts again, only the
+                    // stretches that take wave tiles, whose records it can therefore write as it goes
+                    unsigned char *verdicts = reinterpret_cast<unsigned char *>(keep_wtiles + field * DEVPLAN_KEEP_WROWS + DEVPLAN_KEEP_ROWS);
+                    unsigned long long refused_mask = 0ull;
+                    bool recut = true;
+                    if (FILL) {
+                        // what the counting pass found: wave tiles per stretch (a lane each).  A field whose wave tiles were all kept is not cut again
+                        const int vb = lane <= nq ? (int)verdicts[lane] : 0;
+                        refused_mask = __ballot(vb == 255);
+                        if (lane <= nq && vb != 255 && len_j > 0) { nw_j = vb; ng_j = 0; }
+                        int64_t tot = nw_j;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+                        recut = tot > DEVPLAN_KEEP_ROWS;
+                        if (!recut) {
+                            if (lane < tot) {
+                                DevTile t = keep_tiles[field * DEVPLAN_KEEP_ROWS + lane];
+                                DevWaveTile wt = keep_wtiles[field * DEVPLAN_KEEP_WROWS + lane];
+                                const int64_t first = wt.out_base;                       // (kept relative to the field)
+                                const int nl = (int)wt.hb + wt.count + wt.hf;
+                                if (first >= gen_main) { t.idx0 += (int32_t)prim_index0; wt.idx0 = t.idx0; }
+                                if (wt.rel_main < nl) wt.p0 += (int32_t)prim_index0;     // the tile holds points of layer 2
+                                wt.out_base = pt_off + first;
+                                const int64_t e = stat_base + wt.tile;                   // (kept: the entry within the field)
+                                wt.tile = (int32_t)e;
+                                T.tiles[e] = t;
+                                T.wtiles[wave_base + lane] = wt;
+                                T.stat_ids[e] = (int32_t)e; T.stat_run[e] = 0;
+                                unsigned long long *slot = reinterpret_cast<unsigned long long *>(T.partial + e);
+                                for (int w = 0; w < 13; ++w) slot[w] = 0ull;
+                            }
                         }
-                        e_run += t_s + 1;
                     }
-                    if (!FILL && lane == 0) verdicts[0] = refused_mask;
+                    int64_t e_run = 1, w_run = 0;
+                    if (recut) {
+                        if (FILL && lane <= nq) { nw_j = 0; ng_j = (len_j + TILE_POINTS - 1) / TILE_POINTS; }
+                        for (int j = 0; j <= nq; ++j) {
+                            const int64_t a_s = __shfl(a_j, j), l_s = __shfl(len_j, j);
+                            int64_t t_s = (l_s + TILE_POINTS - 1) / TILE_POINTS;
+                            if (l_s > 0 && !((refused_mask >> j) & 1ull)) {
+                                const int64_t nt = cut_stretch(a_s, a_s + l_s, FILL ? 3 : 2, e_run, w_run, wave_pts, inside_cnt);
+                                if (nt >= 0) {
+                                    if (lane == j) { nw_j = nt; ng_j = 0; }
+                                    if (FILL)
+                                        for (int64_t i = lane; i < nt; i += 64) {
+                                            const int64_t e = stat_base + e_run + i;
+                                            T.stat_ids[e] = (int32_t)e; T.stat_run[e] = 0;
+                                            unsigned long long *slot = reinterpret_cast<unsigned long long *>(T.partial + e);
+                                            for (int w = 0; w < 13; ++w) slot[w] = 0ull;
+                                        }
+                                    t_s = nt; w_run += nt;
+                                } else if (FILL) fallback = true;              // (cannot happen: the counting pass cut this stretch with the same code)
+                                else refused_mask |= 1ull << j;
+                            }
+                            e_run += t_s + 1;
+                        }
+                    }
+                    if (!FILL && lane <= nq) {
+                        // (a stretch of 255 wave tiles or more: not representable in its byte -- 20 000 points without a quiet zone: the host's)
+                        if (nw_j >= 255) fallback = true;
+                        verdicts[lane] = ((refused_mask >> lane) & 1ull) ? (unsigned char)255 : (unsigned char)nw_j;
+                    }
+                    fallback = __ballot(fallback) != 0ull;
                 }
                 const int64_t t_j = lane <= nq ? nw_j + ng_j : 0;                  // entries of the stretch
                 int64_t J_j = 0;
@@ -1177,7 +1218,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                 n_wave = cw;
                 if (lane < cw) {
                     DevTile t = keep_tiles[field * DEVPLAN_KEEP_ROWS + lane];
-                    DevWaveTile wt = keep_wtiles[field * DEVPLAN_KEEP_ROWS + lane];
+                    DevWaveTile wt = keep_wtiles[field * DEVPLAN_KEEP_WROWS + lane];
                     const int64_t first = wt.out_base;                       // (kept relative to the field)
                     const int nl = (int)wt.hb + wt.count + wt.hf;
                     if (first >= gen_main) { t.idx0 += (int32_t)prim_index0; wt.idx0 = t.idx0; }
@@ -1308,7 +1349,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
                         for (int k = pa + 1; k <= pb; ++k) wt.thr[k - pa - 1] = (uint8_t)(n_main + L.pstart[k] - first);
                     }
                     if (FILL) { T.tiles[stat_base + (span_k > 0 ? 1 : 0) + lane] = t; T.wtiles[wave_base + lane] = wt; }
-                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + lane] = t; keep_wtiles[field * DEVPLAN_KEEP_ROWS + lane] = wt; }
+                    else { keep_tiles[field * DEVPLAN_KEEP_ROWS + lane] = t; keep_wtiles[field * DEVPLAN_KEEP_WROWS + lane] = wt; }
                 }
                 n_wave = nt; c_wave_pts = wave_pts; c_wave_inside = inside_cnt;
                 TSTAMP(14);
