@@ -939,25 +939,22 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
     tc.f0 = 0; tc.f1 = n_fields;
     int lrc = launch_devplan_count(st, n_fields, pc, tc, s, dev_fields, n_polys, obstacles != nullptr, tot, spec ? nullptr : c->side, c->ev_chunk, 5);
     if (lrc) { (void)hipStreamSynchronize(st); err = std::string("launch_devplan_count: ") + hipGetErrorString((hipError_t)lrc); return FCPP_EHIP; }   // (drained: the caller's pinned records may still be read)
-    if (spec) {
-        if ((rc = launch_fill()) != FCPP_OK) { (void)hipStreamSynchronize(st); return rc; }
-        // (the last scan has written the totals and the flags to `tot`, then the phase's generation number to tot[PX_DONE]: polled -- a word
-        // of the host's own pinned memory, there a microsecond after the kernel wrote it -- with the drained stream as the fallback; the fill pass
-        // runs on.  No event behind the scan: a record between two kernels holds the second one back by 5 us)
-        {
-            volatile int64_t *done = tot + PX_DONE;
-            const auto t_poll = std::chrono::steady_clock::now();
-            bool seen = false;
-            for (int spin = 0; !seen; ++spin) {
-                seen = *done == tc.gen;
-                if (!seen && (spin & 1023) == 1023 && ms_since(t_poll) > 2.0) break;
-            }
-            if (!seen) DEVCHK(hipStreamSynchronize(st));
-            std::atomic_thread_fence(std::memory_order_acquire);
-            g_trace_totals_ms = ms_since(t_call);
+    if (spec && (rc = launch_fill()) != FCPP_OK) { (void)hipStreamSynchronize(st); return rc; }
+    // (the last scan has written the totals and the flags to `tot`, then the phase's generation number to tot[PX_DONE]: polled -- a word
+    // of the host's own pinned memory, there a microsecond after the kernel wrote it -- with the drained stream as the fallback; a speculative
+    // fill pass runs on.  No event behind the scan: a record between two kernels holds the second one back by 5 us.  Batches laid out from
+    // their totals poll as well: nothing else is in the stream, and the poll sees the word ~10 us before a drained stream reports)
+    {
+        volatile int64_t *done = tot + PX_DONE;
+        const auto t_poll = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (int spin = 0; !seen; ++spin) {
+            seen = *done == tc.gen;
+            if (!seen && (spin & 1023) == 1023 && ms_since(t_poll) > 2.0) break;
         }
-    } else {
-        DEVCHK(hipStreamSynchronize(st));
+        if (!seen) DEVCHK(hipStreamSynchronize(st));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        g_trace_totals_ms = ms_since(t_call);
     }
     tm.host_plan_ms = ms_since(t0);          // (the plan and the counting pass, on the device)
     if (tot[PC_COLS + PF_BAD_OBSTACLES] == tc.gen) { err = "field obstacle range outside the polygon table"; return FCPP_ESIZE; }
