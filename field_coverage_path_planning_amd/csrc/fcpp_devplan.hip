@@ -724,7 +724,10 @@ struct TileWaveLds {
 
 __device__ __forceinline__ int32_t clampi(int64_t v) { return (int32_t)(v < -2 ? -2 : (v > ((int64_t)1 << 30) ? ((int64_t)1 << 30) : v)); }
 
-template <bool FILL, bool STAGE>
+// DENSE: the instance for batches at dense sampling (the dense block and the window cut; no closed-form cut) -- an instance of its own so that
+// the sparse instances keep their registers (with the dense block compiled in, the counting pass of large batches went from 79 to 108
+// vector registers: four wavefronts per SIMD instead of six)
+template <bool FILL, bool STAGE, bool DENSE = false>
 __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, DevTileConsts tc, DevConst cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
                                                               fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
                                                               const int64_t *__restrict__ bases, int64_t *__restrict__ totals,
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         const bool turn_quiet = tc.turn_quiet && F.n_turn == tc.nu && F.line_step > 0.0;
         const bool wave_ok = F.n_turn == tc.nu && (double)tc.wave_factor * tc.two_a * line_step_len >= tc.u_cap;
         // (sample_spacing = 0: 2 points per line, 20 per headland straight -- no quiet zone anywhere; dense sampling: the block below)
-        const bool dense = tc.dense != 0;
+        constexpr bool dense = DENSE;
         if ((!dense && F.n_line >= 64) || prim_count > (dense ? 62 : DEVPLAN_PRIMS_CAP)) fallback = true;
         int64_t pos = 0;
         const int64_t need1 = tiler_need_for(tc.c_line, line_step_len, tc.two_a);
@@ -1239,7 +1242,7 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
         // ---- round 5: the general stretch of a field with a closed-form span is cut IN CLOSED FORM (fcpp_cutfn.h, the function the host
         // tiler runs): the step lengths the halos are sized from are the primitives' own steps and the distances between their end points
         // -- the primitives a lane each, then the tiles of a candidate cut a lane each -- no point of the stretch is evaluated
-        if (!FILL && use_wave && tc.closed_cut != 0 && a == cut_span_points(F, tc.cut) && cut_applies(F, tc.cut, a)) {
+        if (!DENSE && !FILL && use_wave && tc.closed_cut != 0 && a == cut_span_points(F, tc.cut) && cut_applies(F, tc.cut, a)) {
             use_wave = false;
             const int64_t n_main = F.n_main;
             TSTAMP(10);
@@ -1626,7 +1629,10 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
     auto count = [&](hipStream_t q, int64_t f0, int64_t f1) {
         tcc.f0 = f0; tcc.f1 = f1;
         const unsigned grid = (unsigned)((f1 - f0 + TW_WAVES - 1) / TW_WAVES);
-        if (n <= 4096)
+        if (tc.dense)
+            hipLaunchKernelGGL((k_tile_fields<false, true, true>), dim3(grid), dim3(64 * TW_WAVES), 0, q, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
+                               s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
+        else if (n <= 4096)
             hipLaunchKernelGGL((k_tile_fields<false, true>), dim3(grid), dim3(64 * TW_WAVES), 0, q, n, tcc, DevConst(), s.fields_tmp, s.prims_tmp,
                                s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, DevPlanTables());
         else
@@ -1713,8 +1719,12 @@ int launch_devplan_points(hipStream_t st, int64_t n, const PlanConsts &pc, const
 int launch_devplan_fill(hipStream_t st, int64_t n, const DevTileConsts &tc, const DevConst &cst, const DevPlanScratch &s, const DevPlanTables &t)
 {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL((k_tile_fields<true, true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, cst, s.fields_tmp, s.prims_tmp,
-                       s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, t);
+    if (tc.dense)
+        hipLaunchKernelGGL((k_tile_fields<true, true, true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, cst, s.fields_tmp, s.prims_tmp,
+                           s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, t);
+    else
+        hipLaunchKernelGGL((k_tile_fields<true, true>), dim3((unsigned)((n + TW_WAVES - 1) / TW_WAVES)), dim3(64 * TW_WAVES), 0, st, n, tc, cst, s.fields_tmp, s.prims_tmp,
+                           s.info, s.counts, s.bases, s.totals, s.keep_tiles, s.keep_wtiles, t);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
