@@ -185,6 +185,9 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
         int dq1 = (int)(a1 / uper), off1 = (int)(a1 - (unsigned)dq1 * uper);
 #pragma unroll
         for (int k = 0; k < TILE_POINTS / 128; ++k) {
+            // (a round = 128 points; a chunk that ends before this round -- the first and the last chunk of a span, a third of the headline's
+            // -- skips it: wave-uniform.  Rounds 2-4 ran all four rounds of every chunk, storing nothing in the ones beyond its end.)
+            if (k > 0 && 128 * k - odd >= cnt) break;
             const int j = 2 * (lane + 64 * k) - odd;
             const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;
             double px0, py0, k0, v0, px1, py1, k1, v1;
@@ -253,6 +256,7 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
         };
 #pragma unroll
         for (int k = 0; k < TILE_POINTS / 128; ++k) {
+            if (k > 0 && 128 * k - odd >= cnt) break;          // (the chunk ends before this round)
             const int j = 2 * (lane + 64 * k) - odd;
             const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;
             double px0, py0, k0, px1, py1, k1;
@@ -321,8 +325,9 @@ __device__ __forceinline__ void quiet_tile(const DevTile &tl, const DevField *__
         const double bminx = fmin(ex0, ex1), bmaxx = fmax(ex0, ex1), bminy = fmin(ey0, ey1), bmaxy = fmax(ey0, ey1);
 #pragma unroll
         for (int k = 0; k < TILE_POINTS / 128; ++k) {
+            if (k > 0 && 128 * k - odd >= cnt) break;          // (the chunk ends before this round: wave-uniform)
             const int j = 2 * (lane + 64 * k) - odd;
-            const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;     // (no early exit: the obstacle test below is wave-wide)
+            const bool has0 = j >= 0 && j < cnt, has1 = j + 1 < cnt;     // (no exit of single lanes: the obstacle test below is wave-wide)
             double px0, py0, px1, py1;
             lin(tl.off0 + j, px0, py0);
             lin(tl.off0 + j + 1, px1, py1);
