@@ -178,14 +178,16 @@ def test_what_the_device_planner_does_not_take_goes_to_the_host():
     t = E.FieldTable.from_rectangles(WL.cfg2_rectangles(64))
     sq = [[(40.0, 40.0), (50.0, 40.0), (50.0, 50.0), (40.0, 50.0)]]
     t_obs = E.FieldTable.from_specs([E.FieldSpec(field_length=300.0 + 7 * k, field_width=200.0 + 3 * k, obstacles=sq) for k in range(24)])
-    for tab, opt in ((t_obs, E.make_options(1, 0.5)), (t, E.make_options(avoid_obstacles=True))):
-        b = E.Batch(tab, E.make_vehicle(), opt)
+    # (ten headland loops = 83 primitives per field: more than the dense block's lane each)
+    for tab, opt, veh in ((t_obs, E.make_options(1, 0.5), E.make_vehicle()), (t, E.make_options(avoid_obstacles=True), E.make_vehicle()),
+                          (t, E.make_options(0, 0.3), E.make_vehicle(working_width=0.8))):
+        b = E.Batch(tab, veh, opt)
         assert b.setup_path() == 'host'
         b.close()
         ctx.set_setup('device')
         try:
             with pytest.raises(L.FcppError):
-                E.Batch(tab, E.make_vehicle(), opt)
+                E.Batch(tab, veh, opt)
         finally:
             ctx.set_setup('auto')
     b = E.Batch(t, E.make_vehicle(), E.make_options())
