@@ -40,9 +40,12 @@ torch.cuda.set_stream(stream)
 rows = []
 batch = None
 one_call = os.environ.get('FCPP_ONE_CALL', '1') != '0'
+closes = []
 for r in range(reps):
     if batch is not None:
+        tc0 = time.perf_counter()
         batch.close()
+        closes.append((time.perf_counter() - tc0) * 1e3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if one_call:
@@ -62,4 +65,4 @@ for r in range(reps):
 a = np.array(rows[1:])
 med = np.median(a, axis=0)
 print(("one call " if one_call else "three calls ") + "%s: median ms: create %.4f alloc %.4f run_enqueue %.4f sync %.4f total %.4f" % ((what,) + tuple(med)))
-print("setup_times", batch.setup_times(), 'points', batch.total_points)
+print("setup_times", batch.setup_times(), 'points', batch.total_points, 'close() of the previous batch, median ms: %.4f' % float(np.median(closes)))
