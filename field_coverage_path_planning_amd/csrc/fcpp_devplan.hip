@@ -727,11 +727,11 @@ __device__ __forceinline__ int32_t clampi(int64_t v) { return (int32_t)(v < -2 ?
 // DENSE: the instance for batches at dense sampling (the dense block and the window cut; no closed-form cut) -- an instance of its own so that
 // the sparse instances keep their registers (with the dense block compiled in, the counting pass of large batches went from 79 to 108
 // vector registers: four wavefronts per SIMD instead of six)
-template <bool FILL, bool STAGE, bool DENSE = false>
-__global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, DevTileConsts tc, DevConst cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
-                                                              fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
-                                                              const int64_t *__restrict__ bases, int64_t *__restrict__ totals,
-                                                              DevTile *__restrict__ keep_tiles, DevWaveTile *__restrict__ keep_wtiles, DevPlanTables T)
+template <bool FILL, bool STAGE, bool DENSE>
+__device__ __forceinline__ void tile_fields_body(int64_t n, const DevTileConsts &tc, const DevConst &cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
+                                                 fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
+                                                 const int64_t *__restrict__ bases, int64_t *__restrict__ totals,
+                                                 DevTile *__restrict__ keep_tiles, DevWaveTile *__restrict__ keep_wtiles, const DevPlanTables &T)
 {
     __shared__ TileWaveLds<STAGE> lds_all[TW_WAVES];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1587,6 +1587,17 @@ __global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, Dev
     }
     FSTAMP(7);
 }
+
+template <bool FILL, bool STAGE, bool DENSE = false>
+__global__ __launch_bounds__(64 * TW_WAVES, 4) void k_tile_fields(int64_t n, DevTileConsts tc, DevConst cst, const DevField *__restrict__ ftmp, const DevPrim *__restrict__ ptmp,
+                                                              fcpp_field_info *__restrict__ info, int64_t *__restrict__ counts,
+                                                              const int64_t *__restrict__ bases, int64_t *__restrict__ totals,
+                                                              DevTile *__restrict__ keep_tiles, DevWaveTile *__restrict__ keep_wtiles, DevPlanTables T)
+{
+    tile_fields_body<FILL, STAGE, DENSE>(n, tc, cst, ftmp, ptmp, info, counts, bases, totals, keep_tiles, keep_wtiles, T);
+}
+// (Measured and not kept: the fill pass of a large batch held to six wavefronts per SIMD -- 85 registers, 225 spilled, the primitives not staged:
+// cfg5 390 instead of 235 us.)
 
 __global__ void k_debug_math(int fn, int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o0, double *__restrict__ o1)
 {
