@@ -463,9 +463,10 @@ def compact_line(out):
     for e in out.get('configs', []):
         rr = e.get('roofline') or {}
         cpu = e.get('cpu_baseline') or {}
+        dev = (e.get('setup_ms') or {}).get('device_setup')
         rows[e['name']] = [_r(e.get('ms_fresh'), 4), _r(e.get('value_fresh'), 4), _r(e.get('ms_per_step', e.get('ms_total')), 5),
-                           _r(rr.get('step_frac', rr.get('frac')), 3), _r(cpu.get('value'), 4)]
-    c['configs'] = {'columns': ['ms_plan_call', 'value_plan_call', 'ms_step', 'step_frac', 'cpu_baseline_value'], **rows}
+                           _r(rr.get('step_frac', rr.get('frac')), 3), _r(cpu.get('value'), 4), None if dev is None else ('device' if dev else 'host')]
+    c['configs'] = {'columns': ['ms_plan_call', 'value_plan_call', 'ms_step', 'step_frac', 'cpu_baseline_value', 'setup'], **rows}
     line = json.dumps(c, separators=(',', ':'))
     for drop in ('per_rank_points_per_s', 'configs'):          # (never needed so far: a guard, not a plan)
         if len(line) <= COMPACT_LIMIT:

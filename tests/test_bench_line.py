@@ -30,7 +30,7 @@ def _fake_out(n_configs=12):
            'cpu_baseline': {'value': 3.3e7, 'unit': 'points/s', 'cores': 16, 'kind': 'port', 'single_core_value': 5e6, 'sample': 's' * 600,
                             'python_loops_value': 3.2e4, 'numpy_value': 3.9e6, 'python_cores': 1, 'python_sample': 'p' * 300}}
     out['configs'] = [{'name': f'cfg_with_a_long_name_{k}', 'workload': 'v' * 500, 'ms_per_step': 1.9255567982327193, 'value': 141933305343.59515,
-                       'ms_fresh': 2.7701, 'value_fresh': 98660000000.0,
+                       'ms_fresh': 2.7701, 'value_fresh': 98660000000.0, 'setup_ms': {'device_setup': k % 2},
                        'roofline': bench.roofline_of(r, None), 'end_to_end': dict(e2e), 'cpu_baseline': {'value': 33199297.29, 'sample': 'q' * 300}} for k in range(n_configs)]
     return out
 
@@ -59,6 +59,8 @@ def test_compact_line_is_short_and_complete():
     assert d['vs_baseline'] is None and len(d['config']['workload']) <= 200
     assert d['value_clothoid'] == 4.0e10 and d['frac_clothoid'] == 0.54
     assert len(d['configs']) == 13 and d['configs']['columns'][:3] == ['ms_plan_call', 'value_plan_call', 'ms_step']
+    # ... and where every configuration's batch was set up (round 5: dense sampling on the device too)
+    assert d['configs']['columns'][-1] == 'setup' and d['configs']['cfg_with_a_long_name_1'][-1] == 'device' and d['configs']['cfg_with_a_long_name_2'][-1] == 'host'
     # every region is K steps between two fences; their number, the first one's own value and the spread ride along
     assert d['timed_regions'] == {'n': 25, 'reported': 'median', 'first_ms': 0.0563, 'min_ms': 0.0545, 'max_ms': 0.0594}
     assert 'turn' in d['config']['workload'].lower() or d['config']['turn_model']
