@@ -176,9 +176,10 @@ int fcpp_ctx_destroy(fcpp_ctx *ctx);
 int fcpp_ctx_set_stream(fcpp_ctx *ctx, void *hip_stream); /* a hipStream_t; NULL = HIP's default stream.  A new context starts on a private non-blocking stream */
 int fcpp_ctx_synchronize(fcpp_ctx *ctx);
 /* Where the setup of a batch runs (fcpp_batch_create: every field's __init__ and O(1) decisions, MLP:63-107, 591-668, 898-1084, and the
- * cut of its path into kernel work).  FCPP_SETUP_AUTO: on the DEVICE for batches at the reference's own sampling (sample_spacing = 0,
- * obstacle_mode = FLAG) -- only the fcpp_field records go up, fcpp_field_info comes back -- and on the host's cores otherwise (dense
- * sampling, obstacle-aware swaths, fields beyond the device planner's limits).  _HOST: always on the host (the checker of the device
+ * cut of its path into kernel work).  FCPP_SETUP_AUTO: on the DEVICE for batches of 16 fields and more with obstacle_mode = FLAG -- at the
+ * reference's own sampling (sample_spacing = 0) and, since round 5, at any uniform sampling when no field of the batch has obstacles;
+ * only the fcpp_field records go up, fcpp_field_info comes back -- and on the host's cores otherwise (obstacle-aware swaths, dense
+ * sampling of fields with obstacles, fields beyond the device planner's limits, a handful of fields).  _HOST: always on the host (the checker of the device
  * path: both build the same tables, byte for byte).  _DEVICE: batches the device planner does not take fail with FCPP_EUNSUPPORTED.
  * The environment variable FCPP_SETUP=host|device sets the initial mode of new contexts. */
 enum { FCPP_SETUP_AUTO = 0, FCPP_SETUP_HOST = 1, FCPP_SETUP_DEVICE = 2 };
