@@ -202,7 +202,13 @@ struct fcpp_ctx {
     // device-side setup (fcpp_devplan.h): FCPP_SETUP_AUTO / _HOST / _DEVICE; its scratch (grow-only) and a small pinned block for the
     // totals that come back in the middle of it
     int setup_mode = FCPP_SETUP_AUTO;
-    void *plan_scratch = nullptr; size_t plan_scratch_cap = 0;
+    // (up to FOUR scratch allocations, one per stream that sets batches up: a caller that plans batch k + 1 on a second stream while batch k's step
+    // still runs on the first -- the sustained rate of bench.py -- must not wait for that step because its fill pass shared the scratch)
+    struct PlanSlot { void *p = nullptr; size_t cap = 0; hipStream_t stream = nullptr; bool pending = false; uint64_t tick = 0; };
+    static constexpr int kPlanSlots = 4;
+    PlanSlot plan_slots[kPlanSlots];
+    uint64_t plan_tick = 0;
+    int plan_cur = 0;                               // the slot of the setup in progress / of the last one
     void *verify_scratch = nullptr;                 // sliced reduction of the standalone operators' long paths (reduce_paths)
     size_t verify_scratch_cap = 0;
     int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values: the scans of the counting phase write them here
@@ -210,7 +216,7 @@ struct fcpp_ctx {
     // the stream the last device-side setup was enqueued on (its fill pass may still read the scratch): a setup on ANOTHER stream records
     // ev_plan there and waits for it -- lazily, when that other stream shows up: an event recorded between two kernels of the plan call
     // costs 5 us of device time between them (round 5: the three records of a plan call were 16 of its 158 us)
-    hipEvent_t ev_plan = nullptr; hipStream_t plan_stream = nullptr; bool plan_pending = false;
+    hipEvent_t ev_plan = nullptr;
     hipEvent_t ev_chunk[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };      // a large batch's counting pass in chunks beside its planner (launch_devplan_count)
     // the output arena (fcpp_ctx_reserve_outputs): ONE allocation of 4 x pitch + lane bytes; array k of every batch's outputs lies in lane k
     // (lanes `pitch` apart), placed first-fit among the live allocations of the lane -- all five arrays of an allocation at the same offset
@@ -444,7 +450,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     (void)c->stage_wait();
     if (c->stage) (void)hipHostFree(c->stage);
     if (c->spare) (void)hipFree(c->spare);
-    if (c->plan_scratch) { (void)hipDeviceSynchronize(); (void)hipFree(c->plan_scratch); }
+    for (auto &sl : c->plan_slots) if (sl.p) { (void)hipDeviceSynchronize(); (void)hipFree(sl.p); sl.p = nullptr; }
     if (c->arena) { (void)hipDeviceSynchronize(); (void)hipFree(c->arena); }
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     for (hipEvent_t e : c->ev_chunk) if (e) (void)hipEventDestroy(e);
@@ -754,25 +760,33 @@ int take_slab(fcpp_ctx *c, fcpp_batch *b, std::string &err)
 // the context's planner scratch for n fields (grow-only), ordered behind the last fill pass that read it
 int plan_scratch(fcpp_ctx *c, int64_t n_fields, int max_prims, hipStream_t st, DevPlanScratch &s, std::string &err)
 {
-    if (c->plan_pending && c->plan_stream != st) {       // (the previous batch's fill pass, on another stream, may still read the scratch)
+    // the slot: this stream's, else an unused one, else the one used longest ago -- ordered behind whatever another stream left in it
+    int k = -1;
+    for (int i = 0; i < fcpp_ctx::kPlanSlots; ++i) if (c->plan_slots[i].p && c->plan_slots[i].stream == st) k = i;
+    if (k < 0) for (int i = 0; i < fcpp_ctx::kPlanSlots; ++i) if (!c->plan_slots[i].p) { k = i; break; }
+    if (k < 0) { k = 0; for (int i = 1; i < fcpp_ctx::kPlanSlots; ++i) if (c->plan_slots[i].tick < c->plan_slots[k].tick) k = i; }
+    fcpp_ctx::PlanSlot &sl = c->plan_slots[k];
+    if (sl.pending && sl.stream != st) {       // (that batch's fill pass, on another stream, may still read the scratch)
         if (!c->ev_plan) DEVCHK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming));
-        if (hipEventRecord(c->ev_plan, c->plan_stream) == hipSuccess) DEVCHK(hipStreamWaitEvent(st, c->ev_plan, 0));
+        if (hipEventRecord(c->ev_plan, sl.stream) == hipSuccess) DEVCHK(hipStreamWaitEvent(st, c->ev_plan, 0));
         else { (void)hipGetLastError(); DEVCHK(hipDeviceSynchronize()); }        // (that stream is gone)
-        c->plan_pending = false;
+        sl.pending = false;
     }
+    sl.stream = st; sl.tick = ++c->plan_tick;
+    c->plan_cur = k;
     DevPlanScratch off;
     const size_t need = devplan_scratch_layout(n_fields, max_prims, &off);
-    if (c->plan_scratch_cap < need) {
-        if (c->plan_scratch) { DEVCHK(hipDeviceSynchronize()); (void)hipFree(c->plan_scratch); c->plan_scratch = nullptr; c->plan_scratch_cap = 0; }
+    if (sl.cap < need) {
+        if (sl.p) { DEVCHK(hipDeviceSynchronize()); (void)hipFree(sl.p); sl.p = nullptr; sl.cap = 0; }
         const size_t want = need + need / 4;
-        if (hipMalloc(&c->plan_scratch, want) != hipSuccess) { (void)hipGetLastError(); err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
-        c->plan_scratch_cap = want;
+        if (hipMalloc(&sl.p, want) != hipSuccess) { (void)hipGetLastError(); sl.p = nullptr; err = "out of device memory for the planner's scratch"; return FCPP_ENOMEM; }
+        sl.cap = want;
         // (the flags live at the start of the allocation and are never cleared again: they hold generation numbers)
-        DEVCHK(hipMemsetAsync(c->plan_scratch, 0, PLAN_TOTALS * sizeof(int64_t), st));
+        DEVCHK(hipMemsetAsync(sl.p, 0, PLAN_TOTALS * sizeof(int64_t), st));
     }
     if (!c->plan_totals_host)
         { DEVCHK(hipHostMalloc((void **)&c->plan_totals_host, PLAN_TOTALS * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent)); memset(c->plan_totals_host, 0, PLAN_TOTALS * sizeof(int64_t)); }
-    unsigned char *sb = static_cast<unsigned char *>(c->plan_scratch);
+    unsigned char *sb = static_cast<unsigned char *>(sl.p);
     s.fields_in = reinterpret_cast<fcpp_field *>(sb + (size_t)off.fields_in); s.info = reinterpret_cast<fcpp_field_info *>(sb + (size_t)off.info);
     s.fields_tmp = reinterpret_cast<DevField *>(sb + (size_t)off.fields_tmp); s.prims_tmp = reinterpret_cast<DevPrim *>(sb + (size_t)off.prims_tmp);
     s.counts = reinterpret_cast<int64_t *>(sb + (size_t)off.counts); s.bases = reinterpret_cast<int64_t *>(sb + (size_t)off.bases);
@@ -1002,7 +1016,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         if ((rc = launch_fill()) != FCPP_OK) return rc;
     }
     tm.image_bytes = (int64_t)((size_t)n_fields * sizeof(fcpp_field) + (lay.n_polys > 0 ? lay.seg - lay.obs_off : 0));
-    c->plan_stream = st; c->plan_pending = true;
+    c->plan_slots[c->plan_cur].pending = true;
     b->setup_stream = st; b->setup_pending = true;
     // fcpp_field_info stays on the device until somebody asks (fcpp_batch_info); the stream is NOT drained: a step enqueued next runs
     // right behind the setup
@@ -1475,8 +1489,9 @@ int fcpp_batch_destroy(fcpp_batch *b)
     fcpp_ctx *c = b->ctx;
     (void)hipSetDevice(c->device);
     // (the tables may become the next batch's: nothing that reads them may still be running -- on whichever streams this batch ran)
+    // (every stream the batch was created, stepped or read on is noted in used_streams; the context's CURRENT stream is not drained for its own
+    // sake: it may be another batch's -- a caller with two plan calls in flight on two streams would wait for the other call's step here)
     for (hipStream_t s : b->used_streams) (void)hipStreamSynchronize(s);
-    (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (b->slab) {      // the larger of this allocation and the context's spare stays for the next batch
         if (b->slab_bytes <= kSpareMax && b->slab_bytes > c->spare_cap) {

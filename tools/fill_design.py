@@ -32,6 +32,7 @@ def row(e):
 sub = {}
 hk = d['roofline']['all_kernels_ms']['k_plan_sparse_fields']
 sub['H_MS'], sub['H_V'], sub['H_S'], sub['H_F'] = g(d['ms_per_step']), sci(d['value']), g(d['ms_step']), g(d['roofline']['step_frac'], 3)
+sub['SUS_MS'], sub['SUS_V'] = g(d.get('ms_sustained', 0.0)), sci(d.get('value_sustained', 0.0))
 sub['H_K'] = f'{hk * 1e3:.1f} µs ({d["roofline"]["frac"]:.2f})'
 for key, name in (('C', 'cfg1_clothoid'), ('X', 'cfg1_x16384'), ('R', 'cfg2_ref'), ('5', 'cfg2_0.5'), ('1', 'cfg2_0.1'), ('D', 'cfg1_clothoid_dense'), ('3', 'cfg3'),
                   ('A', 'cfg3_avoid'), ('P', 'cfg5')):
