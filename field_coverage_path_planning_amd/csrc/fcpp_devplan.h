@@ -1,13 +1,18 @@
 // fcpp_devplan.h -- the setup of a batch ON THE DEVICE (fcpp_devplan.hip): what fcpp_host.cpp (one field's plan) and fcpp_tiler.cpp (its
-// path cut into kernel work) do on the host's cores, done by the GPU for batches at the reference's own sampling -- the plan call of the
-// reference, plan_complete_coverage (MLP:387-465), plans a NEW field every time, so the setup belongs on the clock and off the host.
+// path cut into kernel work) do on the host's cores, done by the GPU -- the plan call of the reference, plan_complete_coverage
+// (MLP:387-465), plans a NEW field every time, so the setup belongs on the clock and off the host.  Batches with obstacle_mode = FLAG: at the
+// reference's own sampling (rounds 4-5) and at dense sampling when no field has obstacles (round 5).
 //
-//   k_plan_fields      one thread per field: fcpp_planfn.h (the same source the host runs) -> fcpp_field_info, DevField, its primitives
-//   k_scan_*           exclusive scans over the fields of the per-field counts (points, primitives; then tiles, wave tiles, entries, ...)
-//   k_tile_fields<0>   one wavefront per field: the tiler's cut at sparse sampling (span of whole passes + wave tiles with halos sized
-//                      from the path's own step lengths), counting its records
-//   k_tile_fields<1>   the same cut again, records written at their scanned positions: the tables of ImageLayout, equal byte for byte
-//                      to what BatchTiler::fill writes on the host (tests/test_gpu_devplan.py)
+//   k_plan_fields16    sixteen lanes per field, four fields per wavefront: fcpp_planfn.h's plan function restated lane-parallel, the same
+//                      float64 operations in the same order -> fcpp_field_info, DevField, its primitives (k_plan_fields: the one-thread
+//                      original, FCPP_PLAN_SERIAL=1 and fcpp_plan_points)
+//   k_tile_fields<0>   one wavefront per field, the tiler's cut, counting its records.  Sparse sampling: span of whole passes + the general
+//                      stretch cut in closed form (fcpp_cutfn.h) or by the window cut; dense sampling (the DENSE instance): span + a lane per
+//                      quiet zone (last line, headland straights) + a lane per stretch between them (general tiles, or wave tiles by the
+//                      window cut, a stretch after the other)
+//   k_scan_*           exclusive scans over the fields of the per-field counts; the totals go to the host's pinned memory (polled)
+//   k_tile_fields<1>   the records written at their scanned positions: the tables of ImageLayout, equal byte for byte to what BatchTiler::fill
+//                      writes on the host (tests/test_gpu_devplan.py)
 // Only the 128-byte fcpp_field records go to the device and the totals (one small copy) and fcpp_field_info come back.
 #pragma once
 #include <hip/hip_runtime_api.h>
