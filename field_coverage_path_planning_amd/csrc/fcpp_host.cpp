@@ -111,6 +111,12 @@ int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c
             if (!isfinite(v)) { err = "vehicle parameters and options must be finite"; return FCPP_EINVAL; }
         if (W < 1e-6 || R < 1e-6 || (ds > 0 && ds < 1e-9)) { err = "working width, turn radius or sample spacing too small"; return FCPP_EINVAL; }
     }
+    // (the same vehicle and options as the last call of this thread -- a caller that plans batch after batch: the constants below, with
+    // the clothoid's 257-sample extents and its Fresnel evaluations, cost 5-10 us, and a plan call asks for them twice)
+    struct Prepared { fcpp_vehicle veh; fcpp_options opt; PlanConsts c; TurnTemplates tt; bool valid = false; };
+    static thread_local Prepared last;
+    if (last.valid && memcmp(&last.veh, &veh, sizeof veh) == 0 && memcmp(&last.opt, &opt, sizeof opt) == 0) { c = last.c; tt = last.tt; return FCPP_OK; }
+    last.valid = false;
     memset(&c, 0, sizeof c);
     c.veh = veh; c.opt = opt; c.W = W; c.R = R; c.ds = ds;
     c.clip = opt.obstacle_mode == FCPP_OBSTACLES_AVOID;
@@ -179,6 +185,7 @@ int plan_prepare(const fcpp_vehicle &veh, const fcpp_options &opt, PlanConsts &c
         c.uturn_dx = c.Re_pi * my; c.uturn_h = c.Re_pi * mx;
     }
     tt.c_end = c.cloth ? sh_half.T * c.Re_half : kHalfPi; tt.c_step = lin_step(0.0, tt.c_end, tt.nc); tt.c_Re = c.Re_half;
+    last.veh = veh; last.opt = opt; last.c = c; last.tt = tt; last.valid = true;
     return FCPP_OK;
 }
 
