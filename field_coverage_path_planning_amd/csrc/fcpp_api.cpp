@@ -1378,7 +1378,9 @@ int fcpp_batch_plan(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *op
     if (rc == FCPP_OK) {
         if (!stats && b->slab) stats = reinterpret_cast<fcpp_field_stats *>(static_cast<unsigned char *>(b->slab) + b->lay.own_stats);
         rc = fcpp_batch_run(b, *x, *y, *kappa, *v, *fs, stats, 1);
-        if (trace) fprintf(stderr, "[fcpp] plan call: totals seen %.1f us, create returns %.1f, arrays %.1f, step enqueued %.1f\n", g_trace_totals_ms * 1e3, t_create * 1e3, t_alloc * 1e3, ms_since(t_begin) * 1e3);
+        if (trace) fprintf(stderr, "[fcpp] plan call: entered at %.1f us (CLOCK_MONOTONIC mod 1 s), totals seen %.1f us, create returns %.1f, arrays %.1f, step enqueued %.1f\n",
+                           (double)(std::chrono::duration_cast<std::chrono::nanoseconds>(t_begin.time_since_epoch()).count() % 1000000000ll) / 1e3,
+                           g_trace_totals_ms * 1e3, t_create * 1e3, t_alloc * 1e3, ms_since(t_begin) * 1e3);
         if (rc != FCPP_OK) { const std::string keep = g_err; (void)hipStreamSynchronize(c->stream); (void)fcpp_outputs_free(c, *x); g_err = keep; }
     }
     if (rc != FCPP_OK) {

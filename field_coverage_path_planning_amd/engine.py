@@ -453,14 +453,15 @@ class Batch:
         self._info = None
         self._token = object()
         self._last_mode = 1
-        dev = torch.device('cuda', self.ctx.device)
         self.ctx.bind_stream()
         h = C.c_void_p()
         ptrs = [C.c_void_p() for _ in range(5)]
         tot = C.c_int64()
-        # (no statistics records of ours: the batch's own, inside its device allocation -- nothing is allocated in front of the call)
+        # (no statistics records of ours: the batch's own, inside its device allocation -- nothing is allocated in front of the call, and
+        # whatever Python can do behind it -- the device object, the tensors over the arrays -- is done while the device works)
         L.check(self.lib.fcpp_batch_plan(self.ctx.handle, C.byref(self.vehicle), C.byref(self.options), self.n_fields, arr, C.byref(polys),
                                          None, C.byref(h), *[C.byref(q) for q in ptrs], C.byref(tot)))
+        dev = torch.device('cuda', self.ctx.device)
         self.handle = h
         self.total_points = n = tot.value
         sp = C.c_void_p()
