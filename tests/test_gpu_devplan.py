@@ -324,3 +324,33 @@ def test_dense_sampling_tables_equal_the_hosts():
                 E.make_vehicle(), E.make_options(1, 0.1))
     assert b.setup_path() == 'host'
     b.close()
+
+
+@pytest.mark.parametrize('seed', [21, 22, 23])
+def test_random_fields_at_dense_sampling_tables_equal_the_hosts(seed):
+    """Random quadrilaterals of every shape class (some too small to plan: they raise on both paths alike), start / end points, three
+    vehicles (one, two and four headland loops), both turn models and ring orders, samplings on both sides of the wave-tile limit: the
+    device's dense setup against the host's tables, byte for byte, and a step's results bit for bit."""
+    rng = np.random.default_rng(seed)
+    n = 96
+    V = np.empty((n, 4, 2))
+    for k in range(n):
+        w, h = rng.uniform(90, 380, 2)
+        q = np.array([[0, 0], [w, 0], [w, h], [0, h]], dtype=np.float64)
+        kind = rng.integers(0, 3)
+        if kind == 1:
+            q[2:, 0] += rng.uniform(-0.35, 0.35) * h
+        elif kind == 2:
+            q += rng.uniform(-0.08, 0.08, (4, 2)) * min(w, h)
+        rot = rng.uniform(-np.pi, np.pi) if kind else 0.0
+        V[k] = q @ np.array([[np.cos(rot), np.sin(rot)], [-np.sin(rot), np.cos(rot)]]) + rng.uniform(-50, 50, 2) * (kind > 0)
+    V[::31] *= 0.01
+    starts = np.where(rng.random((n, 1)) < 0.5, rng.uniform(0, 300, (n, 2)), np.nan)
+    ends = np.where(rng.random((n, 1)) < 0.5, rng.uniform(0, 300, (n, 2)), np.nan)
+    table = E.FieldTable.from_vertices(V, start_points=starts, end_points=ends)
+    vehicles = [E.make_vehicle(), E.make_vehicle(working_width=2.0, min_turn_radius=5.0), E.make_vehicle(working_width=1.0, min_turn_radius=4.0)]
+    veh = vehicles[seed % len(vehicles)]
+    for tm, ring, sp in ((0, 0, 0.12), (1, 1, 0.5), (1, 0, 0.2), (0, 1, 0.8)):
+        bd, bh = _both(table, veh, E.make_options(tm, sp, ring_order=ring))
+        assert (bd.info.array['status'] != 0).any() and (bd.info.array['status'] == 0).any()
+        _compare(bd, bh, f'seed {seed} turn model {tm} ring {ring} spacing {sp}')
