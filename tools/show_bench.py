@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Print the figures of a bench.py JSON line as a table: headline and every entry of `configs`.   show_bench.py <bench.json>"""
+"""Print the figures of a bench.py JSON line (or of bench_detail.json) as a table: headline and every entry of `configs`.
+    show_bench.py <bench.json>"""
 import json
 import sys
 
@@ -20,5 +21,16 @@ def show(e, name):
 
 
 show(d, 'HEADLINE')
-for e in d.get('configs', []):
-    show(e, e['name'])
+for k in ('value_step', 'ms_step', 'value_sustained', 'ms_sustained', 'value_clothoid'):
+    if d.get(k) is not None:
+        print(f"{'':22s} {k} = {d[k]:.5g}")
+cfgs = d.get('configs', [])
+if isinstance(cfgs, dict):                    # the compact line: a row per configuration under `columns`
+    cols = cfgs.get('columns', [])
+    print(f"{'':22s} " + ' '.join(f'{c:>18s}' for c in cols))
+    for name, row in cfgs.items():
+        if name != 'columns':
+            print(f'{name:22s} ' + ' '.join(f'{(v if v is not None else "-"):>18.5g}' if isinstance(v, (int, float)) else f'{str(v if v is not None else "-"):>18s}' for v in row))
+else:
+    for e in cfgs:
+        show(e, e['name'])
