@@ -36,13 +36,32 @@ int main(int argc, char **argv)
     }
     int64_t zero = 0;
     fcpp_polys polys = { 0, &zero, nullptr, nullptr };
+    // cfg3a: ONE 5000 x 2000 m field with 32 eight-gon obstacles on a jittered 8 x 4 grid, obstacle-aware swaths (cfg3_avoid of bench.py)
+    std::vector<int64_t> offs(1, 0);
+    std::vector<double> ox, oy;
+    if (what == "cfg3a") {
+        fields.resize(1);
+        fcpp_field f = {};
+        f.vx[1] = 5000; f.vx[2] = 5000; f.vy[2] = 2000; f.vy[3] = 2000;
+        f.obstacle_first = 0; f.n_obstacles = 32;
+        fields[0] = f;
+        opt.obstacle_mode = FCPP_OBSTACLES_AVOID;
+        for (int gy = 0; gy < 4; ++gy)
+            for (int gx = 0; gx < 8; ++gx) {
+                const double cx = (gx + 0.5) * 5000 / 8 + U(-100, 100), cy = (gy + 0.5) * 2000 / 4 + U(-100, 100), r = U(10, 40);
+                for (int k = 0; k < 8; ++k) { ox.push_back(cx + r * cos(k * 0.7853981633974483)); oy.push_back(cy + r * sin(k * 0.7853981633974483)); }
+                offs.push_back((int64_t)ox.size());
+            }
+        polys = { 32, offs.data(), ox.data(), oy.data() };
+    }
+    const int n_run = (int)fields.size();
     double best[4] = { 1e30, 1e30, 1e30, 1e30 };
     ImageLayout lay;
     for (int rep = 0; rep < 9; ++rep) {
         HostPlan hp;
         std::string err;
         double t0 = now_ms();
-        int rc = build_host_plan(veh, opt, n, fields.data(), &polys, true, hp, err);
+        int rc = build_host_plan(veh, opt, n_run, fields.data(), &polys, true, hp, err);
         if (rc != FCPP_OK) { fprintf(stderr, "build_host_plan: %s\n", err.c_str()); return 1; }
         double t1 = now_ms();
         const TurnTemplates &tt = hp.tt;
