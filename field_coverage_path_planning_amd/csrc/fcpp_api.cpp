@@ -928,7 +928,7 @@ int try_device_setup(fcpp_ctx *c, fcpp_batch *b, int64_t n_fields, const fcpp_fi
         return FCPP_OK;
     };
     const bool exact_only = getenv("FCPP_SETUP_EXACT") != nullptr;              // (the checker of the speculative layout: tests/test_gpu_devplan.py)
-    bool spec = (n_fields + 1023) / 1024 <= 8 && !exact_only && !dense;
+    bool spec = (n_fields + 1023) / 1024 <= devplan_small_blocks() && !exact_only && !dense;
     if (spec) {
         common_layout(lay);
         const int64_t K = DEVPLAN_KEEP_TILES;

@@ -78,6 +78,7 @@ struct DevPlanScratch {
     DevTile *keep_tiles;          // n x DEVPLAN_KEEP_ROWS
     DevWaveTile *keep_wtiles;     // n x DEVPLAN_KEEP_WROWS
 };
+int64_t devplan_small_blocks();
 size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *offsets_as_pointers /* offsets from 0, cast to pointers */);
 
 // the tables the fill pass writes (pointers into the batch's slab, laid out by the host from the totals)

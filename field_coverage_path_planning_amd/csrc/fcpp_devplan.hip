@@ -27,6 +27,14 @@ size_t devplan_scratch_layout(int64_t n, int max_prims, DevPlanScratch *o)
     return off;
 }
 
+// blocks of 1024 fields up to which a batch is "small": ONE scan launch (a workgroup per column walks the fields in chunks of 4096) and
+// -- fcpp_api.cpp -- the speculative capacity layout.  FCPP_SMALL_BLOCKS (read once) for the A/B.
+int64_t devplan_small_blocks()
+{
+    static const int64_t v = [] { const char *e = getenv("FCPP_SMALL_BLOCKS"); const int64_t x = e ? atoll(e) : 8; return x < 1 ? 1 : (x > 128 ? 128 : x); }();
+    return v;
+}
+
 namespace {
 
 // ---- k_plan_fields: one thread per field, the host's own plan function ----------------------------------------------------------------
@@ -673,7 +681,7 @@ int launch_scan(hipStream_t st, int64_t n, int c0, int c1, const DevPlanScratch 
 {
     const int64_t nblk = (n + 1023) / 1024;
     const int nc = c1 - c0;
-    if (nblk <= 8) {
+    if (nblk <= devplan_small_blocks()) {
         hipLaunchKernelGGL(k_scan_small, dim3((unsigned)nc), dim3(1024), 0, st, n, c0, s.counts, s.bases, s.totals, mirror, with_flags, derive, fuse_possible, spec_gen, done_gen);
         const hipError_t e0 = hipGetLastError();
         return e0 == hipSuccess ? 0 : (int)e0;
@@ -1623,7 +1631,7 @@ int launch_devplan_count(hipStream_t st, int64_t n, const PlanConsts &pc, const 
     // The counting pass goes without the fields' point offsets; what depends on them (span_counts) is derived by the scan that follows the
     // pass: small batches ONE scan of one launch (k_scan_small), large ones the scan of the points (its apply kernel derives) and then the
     // scan of the other columns.  (Rounds 4-5a scanned the points of a large batch BEFORE its pass.)
-    const bool one_scan = (n + 1023) / 1024 <= 8;
+    const bool one_scan = (n + 1023) / 1024 <= devplan_small_blocks();
     DevTileConsts tcc = tc;
     tcc.no_bases = 1;
     auto plan = [&](hipStream_t q, int64_t f0, int64_t f1) {

@@ -21,6 +21,8 @@ elif what in ('cfg3', 'cfg3_avoid'):
     opt = E.make_options(1, 0.05, avoid_obstacles=(what == 'cfg3_avoid'))
 elif what.startswith('n') and what[1:].isdigit():          # n<k>: k fields of 500 x 200 m (the small-batch rule: FCPP_SMALL_BATCH)
     table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (int(what[1:]), 1)) + np.arange(int(what[1:]))[:, None] * 0.37)
+elif what.startswith('x') and what[1:].isdigit():          # x<k>: k copies of the 500 x 200 m field (cfg1_x16384 of bench.py)
+    table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (int(what[1:]), 1)))
 elif what == 'cfg1_clothoid_dense':
     table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (4096, 1)))
     opt = E.make_options(1, 0.1)
