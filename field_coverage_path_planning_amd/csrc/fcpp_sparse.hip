@@ -30,13 +30,18 @@ __global__ __launch_bounds__(64 * SP_WAVES) void k_plan_sparse(const DevWaveTile
                                                                const DevField *__restrict__ fields, const DevPrim *__restrict__ prims,
                                                                DevConst cst, DevObstacles obs, double *__restrict__ xo, double *__restrict__ yo,
                                                                double *__restrict__ ko, double *__restrict__ vo, uint32_t *__restrict__ fso,
-                                                               TilePartial *__restrict__ partial)
+                                                               TilePartial *__restrict__ partial, int xcd_map)
 {
     __shared__ double obs_lds[SP_WAVES][2 * OBS_LDS_VERTS];
     __shared__ double atab[ATAN_TAB_DOUBLES];
     __shared__ double plds[SP_WAVES][TILE_PRIMS_LDS];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int64_t slot = (int64_t)blockIdx.x * SP_WAVES + wave;
+    // XCD-aware order (round 5): workgroups go round robin to the chip's eight XCDs, each with an L2 of its own, and the tiles of ONE field
+    // -- five on cfg5, side by side in the list -- read the same field record and primitives: workgroup b takes the slots of position
+    // (b mod 8) x (grid / 8) + b / 8, so that every XCD walks one contiguous eighth of the list and a field's records are fetched into one
+    // L2 instead of five (the grid is a multiple of eight: launch_plan_sparse)
+    const unsigned bid = xcd_map ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t slot = (int64_t)bid * SP_WAVES + wave;
     if (slot >= n_wtiles) return;
     atan_tab_stage(atab);
     const DevWaveTile wt = wtiles[ids ? (int64_t)ids[slot] : slot];      // (ids: the wave tiles of the fields k_plan_sparse_fields does not take)
@@ -271,12 +276,14 @@ int launch_plan_sparse(hipStream_t st, int64_t n_wtiles, const DevWaveTile *wtil
     if (n_wtiles <= 0) return 0;
     const bool two = points_per_lane == 2;
     const int wpb_k = tune_int("FCPP_SPARSE_WPB", 0);         // (FCPP_TUNE=1 only: 2 or 4 wave tiles per workgroup, tools/ab_knob.py)
+    static const int xcd_map = getenv("FCPP_XCD_MAP") ? atoi(getenv("FCPP_XCD_MAP")) : 1;       // (0: workgroup b takes slot b -- the A/B)
+    auto grid8 = [&](int64_t per) { const int64_t g = (n_wtiles + per - 1) / per; return dim3((unsigned)(xcd_map ? (g + 7) / 8 * 8 : g)); };
     if (wpb_k == 2 || (wpb_k != 4 && n_wtiles >= (two ? 65536 : 131072))) {
-        if (two) FCPP_LAUNCH((k_plan_sparse<2, 2>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
-        else FCPP_LAUNCH((k_plan_sparse<2, 1>), dim3((unsigned)((n_wtiles + 1) / 2)), dim3(128), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        if (two) FCPP_LAUNCH((k_plan_sparse<2, 2>), grid8(2), dim3(128), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial, xcd_map);
+        else FCPP_LAUNCH((k_plan_sparse<2, 1>), grid8(2), dim3(128), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial, xcd_map);
     } else {
-        if (two) FCPP_LAUNCH((k_plan_sparse<4, 2>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
-        else FCPP_LAUNCH((k_plan_sparse<4, 1>), dim3((unsigned)((n_wtiles + 3) / 4)), dim3(256), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial);
+        if (two) FCPP_LAUNCH((k_plan_sparse<4, 2>), grid8(4), dim3(256), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial, xcd_map);
+        else FCPP_LAUNCH((k_plan_sparse<4, 1>), grid8(4), dim3(256), 0, st, wtiles, ids, n_wtiles, fields, prims, cst, obs, x, y, kappa, v, fs, partial, xcd_map);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
