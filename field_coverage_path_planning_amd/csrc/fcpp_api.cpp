@@ -1972,10 +1972,12 @@ int fcpp_gather(fcpp_ctx *c, void *nccl_comm, int rank, int world, int root, int
 // ---- diagnostics (tests) -------------------------------------------------------------------------------------------------------------
 int fcpp_debug_math(int fn, int64_t n, const double *a, const double *b, double *out0, double *out1)
 {
-    if (fn < 0 || fn > 3 || n < 0 || (n > 0 && (!a || !out0)) || ((fn == 1 || fn == 3) && n > 0 && !b) || (fn == 0 && n > 0 && !out1))
+    if (fn < 0 || fn > 5 || n < 0 || (n > 0 && (!a || !out0)) || ((fn == 1 || fn == 3 || fn == 5) && n > 0 && !b) || ((fn == 0 || fn == 4) && n > 0 && !out1))
         return fail(FCPP_EINVAL, "bad arguments");
     for (int64_t i = 0; i < n; ++i) {
         if (fn == 0) fc_sincos(a[i], out0[i], out1[i]);
+        else if (fn == 4) fc_sincos_cr(a[i], out0[i], out1[i]);
+        else if (fn == 5) out0[i] = fc_atan2_cr(a[i], b[i]);
         else if (fn == 1) out0[i] = atan2_fd(a[i], b[i]);
         else if (fn == 2) out0[i] = fc_acos(a[i]);
         else out0[i] = fc_hypot(a[i], b[i]);
@@ -1985,7 +1987,7 @@ int fcpp_debug_math(int fn, int64_t n, const double *a, const double *b, double 
 
 int fcpp_debug_math_dev(fcpp_ctx *c, int fn, int64_t n, const double *a, const double *b, double *out0, double *out1)
 {
-    if (!c || fn < 0 || fn > 3 || n < 0) return fail(FCPP_EINVAL, "bad arguments");
+    if (!c || fn < 0 || fn > 5 || n < 0) return fail(FCPP_EINVAL, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     LAUNCHCHK(launch_debug_math(c->stream, fn, n, a, b, out0, out1));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -230,12 +230,12 @@ __global__ __launch_bounds__(64) void k_plan_fields16(int64_t n, PlanConsts pc, 
     }
     PSTAMP(3);
     const double e0x = f.vx[1] - f.vx[0], e0y = f.vy[1] - f.vy[0];
-    const double rot = (e0x == 0.0 && e0y == 0.0) ? 0.0 : atan2_fd(e0y, e0x);
+    const double rot = (e0x == 0.0 && e0y == 0.0) ? 0.0 : fc_atan2_cr(e0y, e0x);          // (correctly rounded: fcpp_math.h, round 5)
     if (w0) { in.rotation_angle = rot; }
     const bool rotated = fabs(rot) > 0.01;
     if (w0) { in.rotated = rotated; }
     double rc, rs;
-    fc_sincos(rot, rs, rc);
+    fc_sincos_cr(rot, rs, rc);
     double ccx = 0, ccy = 0, sx = f.start_x, sy = f.start_y;
     double rqx = mqx, rqy = mqy;
     if (rotated) {
@@ -1612,6 +1612,8 @@ __global__ void k_debug_math(int fn, int64_t n, const double *__restrict__ a, co
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (fn == 0) { double s, c; fc_sincos(a[i], s, c); o0[i] = s; o1[i] = c; }
+    else if (fn == 4) { double s, c; fc_sincos_cr(a[i], s, c); o0[i] = s; o1[i] = c; }
+    else if (fn == 5) o0[i] = fc_atan2_cr(a[i], b[i]);
     else if (fn == 1) o0[i] = atan2_fd(a[i], b[i]);
     else if (fn == 2) o0[i] = fc_acos(a[i]);
     else o0[i] = fc_hypot(a[i], b[i]);

@@ -452,7 +452,7 @@ struct HostSink {
         const int64_t P = fr.P, n_turn = fr.n_turn;
         boxes.clear(); gpoly.clear();
         double rc, rs;
-        fc_sincos(rot, rs, rc);
+        fc_sincos_cr(rot, rs, rc);
         fr_rotated = rotated; fr_c = rc; fr_s = rs; fr_cx = ccx; fr_cy = ccy;
         const double ca = rc, sa = -rs;
         bool bad_obs = f.n_obstacles < 0 || (f.n_obstacles > 0 && (!polys || f.obstacle_first < 0 || f.obstacle_first + f.n_obstacles > polys->n_polys));

@@ -260,12 +260,12 @@ FCPP_HD int64_t plan_field_t(const PlanConsts &pc, const fcpp_field &f, fcpp_fie
     mitre_of(q, mit);
     if (!inset(q, mit, hw, mq) || abs_area(mq) < 1.0) FCPP_FAIL(FCPP_EINVAL);
     const double e0x = q.x[1] - q.x[0], e0y = q.y[1] - q.y[0];
-    const double rot = (e0x == 0.0 && e0y == 0.0) ? 0.0 : atan2_fd(e0y, e0x);
+    const double rot = (e0x == 0.0 && e0y == 0.0) ? 0.0 : fc_atan2_cr(e0y, e0x);          // (correctly rounded: fcpp_math.h, round 5)
     in.rotation_angle = rot;
     const bool rotated = fabs(rot) > 0.01;
     in.rotated = rotated;
     double rc, rs;                       // cos / sin of +rot; the frame of layer 1 is reached with -rot: (rc, -rs)
-    fc_sincos(rot, rs, rc);
+    fc_sincos_cr(rot, rs, rc);
     double ccx = 0, ccy = 0, sx = f.start_x, sy = f.start_y;
     Quad rq = mq;
     if (rotated) {
