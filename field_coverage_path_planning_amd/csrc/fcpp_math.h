@@ -147,12 +147,21 @@ FCPP_HD double fc_atan2_cr(double y, double x)
     return a0 + (num.hi + num.lo) / den;
 }
 
-// acos(c) for c in [-1, 1] through the one atan2 of the library: atan2(sqrt((1 - c)(1 + c)), c)
+// acos(c) for c in [-1, 1] through the one atan2 of the library: atan2(sqrt((1 - c)(1 + c)), c), < 2 ulp.  The planner compares the corner
+// angles of a field with 60 degrees (MLP:1043) and with 90 +- 1 degrees (MLP:224-235); a field drawn with such a corner (c = 0.5 to the
+// last bit) must fall on the side the reference's acos puts it, so within 1e-6 degrees of those three values the estimate takes ONE Newton
+// step on cos(a) - c with the cosine and sine of the estimate in double-double, which makes it the correctly rounded acos there.
 FCPP_HD double fc_acos(double c)
 {
     if (c >= 1.0) return 0.0;
     if (c <= -1.0) return 3.14159265358979311600e+00;
-    return atan2_fd(sqrt((1.0 - c) * (1.0 + c)), c);
+    const double a0 = atan2_fd(sqrt((1.0 - c) * (1.0 + c)), c);
+    const double deg = a0 * (180.0 / 3.14159265358979311600e+00);
+    if (!(fabs(deg - 60.0) < 1e-6 || fabs(deg - 89.0) < 1e-6 || fabs(deg - 91.0) < 1e-6)) return a0;
+    DD S, C;
+    sincos_dd(a0, S, C);
+    const DD num = dd_add(C, DD{ -c, 0.0 });
+    return a0 + (num.hi + num.lo) / S.hi;
 }
 
 // sqrt(x^2 + y^2) for field-sized operands (no scaling: neither overflow nor underflow can occur for coordinates in metres), correctly

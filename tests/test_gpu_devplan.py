@@ -65,7 +65,9 @@ def test_shared_math_device_equals_host_bit_for_bit():
     lib = L.load()
     ctx = E.get_context()
     rng = np.random.default_rng(3)
-    a = np.concatenate([rng.uniform(-np.pi, np.pi, 100000), rng.uniform(-1, 1, 100000), rng.uniform(-1e4, 1e4, 50000), [0.0, 1.0, -1.0]])
+    a = np.concatenate([rng.uniform(-np.pi, np.pi, 100000), rng.uniform(-1, 1, 100000), rng.uniform(-1e4, 1e4, 50000), [0.0, 1.0, -1.0],
+                        0.5 + rng.uniform(-1.5e-8, 1.5e-8, 2000), np.cos(np.deg2rad(89.0)) + rng.uniform(-1.5e-8, 1.5e-8, 2000),   # (fc_acos's refined windows)
+                        np.cos(np.deg2rad(91.0)) + rng.uniform(-1.5e-8, 1.5e-8, 2000), 0.5 + np.arange(-20, 21) * 2.0 ** -53])
     b = rng.uniform(-1e3, 1e3, a.size)
     for fn in range(6):          # (4, 5: the rotation's correctly rounded sine / cosine and angle, round 5)
         arg = np.clip(a, -1, 1) if fn == 2 else a

@@ -354,3 +354,30 @@ def test_counts_that_hinge_on_the_last_bit_of_a_sine_the_reference_decides():
     assert int((o_main != ref_main).sum()) <= 4                       # the oracle: the reference's count on 86 of 90
     assert int((l_main != ref_main).sum()) <= 6                       # the library: on 85 of 90 (round 4: 34)
     assert int((l_main != o_main).sum()) <= 2                         # ... and the oracle's count on 89
+
+
+def test_a_corner_of_exactly_sixty_degrees_the_reverse_fill_decision():
+    """tests/golden/golden_fragile.npz c60_* (tools/gen_golden.py --fragile-only; 25 fields of tools/fragile_tally.sh's class 4,
+    profiles/r05_fragile_tally_corner60.txt): parallelograms DRAWN with a corner of 60 degrees, rotated.  MLP:1043 fills a corner in reverse
+    when its angle is `>= 60`, the angle being degrees(arccos(c)) with c = 0.5 to the last bit or two (MLP:165-192) -- so the decision is the
+    last bit of an arccos.  The library's fc_acos is the correctly rounded arccos in that window since round 5 (csrc/fcpp_math.h; 21 % of such
+    fields differed from the oracle's libm acos before, none of 240 000 now).  The reference run HERE is not a fixed point to aim at on
+    these fields: numpy 2.2's float64 arccos loop on this CPU differs from libm on 9 % of arguments (arccos(0.5) comes out one ulp low:
+    59.99999999999999 degrees, libm and the exact value give 60.00000000000001) and its BLAS dot product fuses the multiply-add, so the
+    fixture's counts are those of ONE platform; the library and the oracle agree with each other on all 25 and with that run on 15, and
+    where they differ the library has the reverse fill (more headland points), never fewer."""
+    from field_coverage_path_planning_amd import engine as E
+    g = np.load(os.path.join(GOLDEN, 'golden_fragile.npz'))
+    V, st, ref_main, ref_head = g['c60_verts'], g['c60_start'], g['c60_n_main'], g['c60_n_head']
+    assert len(V) == 25
+    o_main, o_head = [], []
+    for k in range(len(V)):
+        rc, p = orc.plan_field(orc.make_field(verts=[tuple(x) for x in V[k]], start=None if np.isnan(st[k, 0]) else tuple(st[k])))
+        assert rc == 0
+        o_main.append(p.n_main)
+        o_head.append(p.n_head)
+    info = E.plan_count(E.FieldTable.from_vertices(V, start_points=st), E.make_vehicle(), E.make_options())
+    l_main, l_head = np.array([i.n_main for i in info]), np.array([i.n_head for i in info])
+    assert np.array_equal(l_main, np.array(o_main)) and np.array_equal(l_head, np.array(o_head))
+    assert np.array_equal(l_main, ref_main)                           # layer 1 is not in question
+    assert int((l_head == ref_head).sum()) >= 15 and (l_head >= ref_head).all()

@@ -70,3 +70,27 @@ def test_rotation_functions_are_correctly_rounded():
     assert _call(5, np.array([0.0]), np.array([500.0]))[0][0] == 0.0 and _call(5, np.array([3.0]), np.array([0.0]))[0][0] == np.pi / 2
     h, _ = _call(3, y, xx)
     assert np.array_equal(h, np.array([float(mpmath.sqrt(mpmath.mpf(float(p)) ** 2 + mpmath.mpf(float(q)) ** 2)) for p, q in zip(y, xx)]))
+
+
+def test_corner_angle_is_correctly_rounded_where_a_decision_hangs_on_it():
+    """fc_acos within 1e-6 degrees of 60, 89 and 91 degrees (MLP:1043 the reverse fill of a corner of 60 degrees and more; MLP:224-235 the
+    rectangle test): the correctly rounded acos, so that a field DRAWN with a corner of exactly 60 degrees falls on the reference's side."""
+    mpmath = __import__('pytest').importorskip('mpmath')
+    mpmath.mp.prec = 300
+    rng = np.random.default_rng(12)
+    cs = []
+    for deg in (60.0, 89.0, 91.0, 120.0):
+        c0 = np.cos(np.deg2rad(deg))
+        cs.append(np.nextafter(c0, 1.0) + np.arange(-40, 41) * np.spacing(c0))
+        if deg != 120.0:
+            cs.append(c0 + rng.uniform(-1.5e-8, 1.5e-8, 300))
+    c = np.concatenate(cs + [np.array([0.5, -0.5])])
+    a, _ = _call(2, c)
+    want = np.array([float(mpmath.acos(mpmath.mpf(float(v)))) for v in c])
+    near = np.zeros(c.size, bool)
+    for deg in (60.0, 89.0, 91.0):
+        near |= np.abs(np.degrees(want) - deg) < 0.9e-6
+    assert near.sum() > 800
+    assert np.array_equal(a[near], want[near])
+    assert _ulps(a, want).max() <= 2.0
+    assert a[-2] * (180.0 / np.pi) >= 60.0                   # acos(0.5) in degrees: the platform's 60.00000000000001

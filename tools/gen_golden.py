@@ -516,6 +516,24 @@ def tier_fragile():
         out['mismatch'].append(int(mism))
         out['n_main'].append(len(res['main_work']['path']))
         out['n_head'].append(len(res['headland']['path']))
+    # a corner of exactly 60 degrees (MLP:1043 `>= 60` on arccos's last bit): tools/fragile_tally.sh's class 4, a sample of its fields
+    c60 = {'c60_verts': [], 'c60_start': [], 'c60_n_main': [], 'c60_n_head': []}
+    for line in open(os.path.join(os.path.dirname(OUT.rstrip('/')), '..', 'profiles', 'r05_fragile_tally_corner60.txt')):
+        if not line.startswith('CORNER60'):
+            continue
+        w = line.split()
+        k = w.index('verts')
+        v = [float.fromhex(x) for x in w[k + 1:k + 9]]
+        j = w.index('start')
+        start = (float.fromhex(w[j + 2]), float.fromhex(w[j + 3])) if w[j + 1] == '1' else None
+        verts = [(v[0], v[1]), (v[2], v[3]), (v[4], v[5]), (v[6], v[7])]
+        pl = quiet(mlp.TwoLayerPathPlannerV37, vehicle_params=mlp.VehicleParams(), field_vertices=verts, start_point=start)
+        res = quiet(pl.plan_complete_coverage)
+        c60['c60_verts'].append(verts)
+        c60['c60_start'].append(start if start is not None else (np.nan, np.nan))
+        c60['c60_n_main'].append(len(res['main_work']['path']))
+        c60['c60_n_head'].append(len(res['headland']['path']))
+    out.update(c60)
     return {k: np.array(v) for k, v in out.items()}
 
 

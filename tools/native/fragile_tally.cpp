@@ -45,7 +45,7 @@ int main(int argc, char **argv)
         for (int64_t i = 0; i < n; ++i) {
             fcpp_field f;
             memset(&f, 0, sizeof f);
-            const int cls = (int)(i % 4);        // 0, 1: rotated parallelogram (cfg5's distribution); 2: quadrilateral; 3: exact-multiple height under rotation
+            const int cls = (int)(i % 5);        // 0, 1: rotated parallelogram (cfg5's distribution); 2: quadrilateral; 3: exact-multiple height under rotation; 4: a corner of exactly 60 degrees under rotation (MLP:1043: the reverse fill of a corner of 60 degrees and more)
             double qx[4], qy[4];
             if (cls <= 1) {
                 const double b = U(100, 1000), h = U(100, 1000), ang = U(M_PI / 3, 2 * M_PI / 3), sx = h / tan(ang);
@@ -55,13 +55,17 @@ int main(int argc, char **argv)
                 const double b = U(100, 900), h = U(100, 700), m = 0.12 * (b < h ? b : h);
                 const double x[4] = { U(-m, m), b + U(-m, m), b + U(-m, m), U(-m, m) }, y[4] = { U(-m, m), U(-m, m), h + U(-m, m), h + U(-m, m) };
                 memcpy(qx, x, sizeof x); memcpy(qy, y, sizeof y);
+            } else if (cls == 4) {
+                const double b = U(100, 1000), h = U(100, 1000), sx = h / 1.7320508075688772;          // tan(60 degrees)
+                const double x[4] = { 0, b, b + sx, sx }, y[4] = { 0, 0, h, h };
+                memcpy(qx, x, sizeof x); memcpy(qy, y, sizeof y);
             } else {
-                const int k = 1 + (int)((i / 4) % 399);              // H - 2R = k W exactly in real arithmetic
+                const int k = 1 + (int)((i / 5) % 399);              // H - 2R = k W exactly in real arithmetic
                 const double b = U(100, 1000), h = 2 * veh.min_turn_radius + k * veh.working_width;
                 const double x[4] = { 0, b, b, 0 }, y[4] = { 0, 0, h, h };
                 memcpy(qx, x, sizeof x); memcpy(qy, y, sizeof y);
             }
-            const double rot = U(-M_PI / 4, M_PI / 4), c = cos(rot), s = sin(rot), tx = cls == 3 ? U(-50, 50) : 0.0, ty = cls == 3 ? U(-50, 50) : 0.0;
+            const double rot = U(-M_PI / 4, M_PI / 4), c = cos(rot), s = sin(rot), tx = cls >= 3 ? U(-50, 50) : 0.0, ty = cls >= 3 ? U(-50, 50) : 0.0;
             for (int k = 0; k < 4; ++k) { f.vx[k] = qx[k] * c - qy[k] * s + tx; f.vy[k] = qx[k] * s + qy[k] * c + ty; }
             f.from_vertices = 1;
             if (rng() & 1) { f.has_start = 1; f.start_x = U(0, 400); f.start_y = U(0, 400); }
@@ -87,7 +91,7 @@ int main(int argc, char **argv)
     }
     // the oracle, field by field on `threads` threads
     std::atomic<int64_t> next(0), mism(0), refused_both(0), status_diff(0), frag_mism(0);
-    int64_t mism_cls[4] = { 0, 0, 0, 0 }, frag_cls[4] = { 0, 0, 0, 0 }, n_cls[4] = { 0, 0, 0, 0 };
+    int64_t mism_cls[5] = { 0, 0, 0, 0, 0 }, frag_cls[5] = { 0, 0, 0, 0, 0 }, n_cls[5] = { 0, 0, 0, 0, 0 };
     std::mutex mu;
     std::vector<std::string> lines;
     auto work = [&]() {
@@ -120,9 +124,15 @@ int main(int argc, char **argv)
                          rc, rc ? 0 : p.n_swaths, rc ? 0LL : (long long)p.n_main, rc ? 0LL : (long long)p.n_head, p.n_reverse[0], p.n_reverse[1], p.n_reverse[2], p.n_reverse[3],
                          f.vx[0], f.vy[0], f.vx[1], f.vy[1], f.vx[2], f.vy[2], f.vx[3], f.vy[3], f.has_start, f.start_x, f.start_y);
                 lines.push_back(buf);
-            } else if (fragile[(size_t)i] && lines.size() < 4000 && cases[(size_t)i].cls == 3 && (i / 4) % 37 == 0) {
+            } else if (fragile[(size_t)i] && lines.size() < 4000 && cases[(size_t)i].cls == 3 && (i / 5) % 37 == 0) {
                 char buf[400];
                 snprintf(buf, sizeof buf, "FRAGILE-AGREE field %lld swaths %d | verts %a %a %a %a %a %a %a %a", (long long)i, in.n_swaths, f.vx[0], f.vy[0], f.vx[1], f.vy[1], f.vx[2], f.vy[2], f.vx[3], f.vy[3]);
+                lines.push_back(buf);
+            }
+            if (!bad && cases[(size_t)i].cls == 4 && fragile[(size_t)i] && (i / 5) % 4000 == 0) {      // a sample for tests/golden (tools/gen_golden.py: the reference decides)
+                char buf[400];
+                snprintf(buf, sizeof buf, "CORNER60 field %lld head %lld rev %d %d %d %d | verts %a %a %a %a %a %a %a %a start %d %a %a", (long long)i, (long long)in.n_head,
+                         in.n_reverse[0], in.n_reverse[1], in.n_reverse[2], in.n_reverse[3], f.vx[0], f.vy[0], f.vx[1], f.vy[1], f.vx[2], f.vy[2], f.vx[3], f.vy[3], f.has_start, f.start_x, f.start_y);
                 lines.push_back(buf);
             }
             if (rc == 0) orc_plan_free(&p);
@@ -135,8 +145,8 @@ int main(int argc, char **argv)
     for (unsigned char c : fragile) nfrag += c;
     printf("fields %lld seed %llu: mismatches %lld (status %lld) ; fragile by the library's own count (swaths or reverse-fill points change under a scaling by 1 +- 2^-40) %lld, of them mismatching %lld ; refused by both %lld\n",
            (long long)n, (unsigned long long)seed, (long long)mism.load(), (long long)status_diff.load(), (long long)nfrag, (long long)frag_mism.load(), (long long)refused_both.load());
-    const char *names[4] = { "rotated parallelograms", "rotated parallelograms", "quadrilaterals", "exact-multiple heights under rotation" };
-    for (int c = 1; c < 4; ++c)
+    const char *names[5] = { "rotated parallelograms", "rotated parallelograms", "quadrilaterals", "exact-multiple heights under rotation", "a corner of exactly 60 degrees" };
+    for (int c = 1; c < 5; ++c)
         printf("  %-40s fields %lld fragile %lld mismatches %lld\n", names[c], (long long)(n_cls[c] + (c == 1 ? n_cls[0] : 0)), (long long)(frag_cls[c] + (c == 1 ? frag_cls[0] : 0)), (long long)(mism_cls[c] + (c == 1 ? mism_cls[0] : 0)));
     for (const auto &l : lines) puts(l.c_str());
     return 0;
