@@ -4,9 +4,10 @@
 One "step" = one PLAN CALL of the reference for a whole batch: plan_complete_coverage (MLP:387-465) sets a NEW field up and generates its
 path in one call, and so does a step here (round 5) -- `engine.Batch.plan(table)` = fcpp_batch_plan: the batch's setup on the device, its
 output arrays, the whole hot path (sample every path point, curvature, curvature clamp, forward/backward speed sweeps, a_lat / geofence /
-obstacle validation, per-field metrics) -- and the stream drained; the field records (128 B per field) lie in pinned host memory and are
-read by the device where they lie.  `value` / `ms_per_step`: the median of REPS_SHORT regions of K such calls, each region bracketed by
-barrier + synchronize.
+obstacle validation, per-field metrics) -- and the stream drained; the field records (128 B per field) are RESIDENT IN DEVICE MEMORY when the
+region starts (engine.FieldTable.to_device(): inputs in HBM, as the tier's measurement rule has them; the same call on records in pinned host
+memory, read by the device across PCIe where they lie, rides along as `ms_pinned_records` / `value_pinned_records`).  `value` / `ms_per_step`:
+the median of REPS_SHORT regions of K such calls, each region bracketed by barrier + synchronize.
 
 `value_step` / `ms_step` is what rounds 1-4 reported as `value`: the hot path re-run on a batch that is already set up (the kernels alone,
 inputs resident in HBM) -- the figure the kernels' roofline fractions refer to.  `end_to_end` (diagnostic) splits a plan call made through
@@ -157,6 +158,7 @@ def fresh_regions(E, torch, table, veh, opt, steps, reps, fence, after_call=None
     """`reps` regions of `steps` FRESH plan calls (engine.Batch.plan: fcpp_batch_plan + the stream drained; the previous call's batch and
     arrays are released inside the region, as a caller in a loop releases them) -> (seconds per region, points per call)"""
     dts, batch, res, n_points, k = [], None, None, 0, 0
+    drain = torch.cuda.current_stream().synchronize
     for _ in range(max(1, reps)):
         fence()
         t0 = time.perf_counter()
@@ -168,7 +170,7 @@ def fresh_regions(E, torch, table, veh, opt, steps, reps, fence, after_call=None
             if after_call:
                 after_call(k, res)
             k += 1
-            torch.cuda.synchronize()
+            drain()                     # (the call's stream drained: 2.5 us less than torch.cuda.synchronize(), which waits for every stream of the device)
         fence()
         dts.append(time.perf_counter() - t0)
         n_points = batch.total_points
@@ -208,7 +210,7 @@ def sustained_regions(E, torch, table, veh, opt, steps, reps, fence):
 
 
 def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=None, after_step=None, stats_of=None, reps=REPS, e2e_reps=5,
-                fresh_steps=0, fresh_reps=0, after_fresh=None):
+                fresh_steps=0, fresh_reps=0, after_fresh=None, records='device', pinned_too=False):
     """-> dict(points, ms_per_step, kernels {name: ms}, dominant kernel + its points, end_to_end, batch, bufs, res).
 
     1. the plan call end to end, e2e_reps times: a fresh batch from `table` (engine.FieldTable), its output arrays, one step, the stream
@@ -223,8 +225,13 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     fence = fence or torch.cuda.synchronize
     veh = E.make_vehicle()
     e2e, batch, bufs = [], None, None
-    if hasattr(table, 'pin'):
-        table.pin()       # (the field records in pinned host memory, as a caller that builds its tables in place keeps them: the device reads them where they lie)
+    # the field records: resident in DEVICE memory when the timed regions start (records='device', round 5b: FieldTable.to_device() -- inputs in
+    # HBM), or in pinned host memory, read by the device across PCIe where they lie ('pinned': rounds 4-5a).  The host paths of the library
+    # (cfg3's single field, AVOID mode) copy device records back first -- inside the call, on the clock.
+    if records == 'device' and hasattr(table, 'to_device'):
+        table.to_device()
+    elif hasattr(table, 'pin'):
+        table.pin()
     for rep in range(max(1, e2e_reps)):
         if batch is not None:
             batch.close()
@@ -263,7 +270,14 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
         fw, _ = fresh_regions(E, torch, table, veh, opt, min(fresh_steps, 5), 1, fence)          # (warm-up: the arena, the spare allocations)
         fdts, fpts = fresh_regions(E, torch, table, veh, opt, fresh_steps, fresh_reps or reps, fence, after_fresh)
         assert fpts == n_points
-        fresh = {'dts': fdts, 'steps': fresh_steps, 'ms_per_call': median(fdts) / fresh_steps * 1e3}
+        fresh = {'dts': fdts, 'steps': fresh_steps, 'ms_per_call': median(fdts) / fresh_steps * 1e3, 'records': records}
+        if pinned_too and records == 'device':
+            # the same regions with the records in pinned host memory (rounds 4-5a's `value`)
+            import numpy as np
+            tp = E.FieldTable(np.array(table.rec), table.poly_offsets, table.poly_x, table.poly_y).pin()
+            fresh_regions(E, torch, tp, veh, opt, min(fresh_steps, 5), 1, fence)
+            pdts, _ = fresh_regions(E, torch, tp, veh, opt, fresh_steps, fresh_reps or reps, fence)
+            fresh['pinned_ms_per_call'] = median(pdts) / fresh_steps * 1e3
     warm = e2e[1:] or e2e                 # (the first repetition of a process pays the context's pinned staging memory and the allocator)
     mid = sorted(warm, key=lambda r: r['ms'])[(len(warm) - 1) // 2]
     end_to_end = {'ms': mid['ms'], 'points_per_s': n_points / (mid['ms'] * 1e-3), 'create_ms': mid['create_ms'],
@@ -271,8 +285,8 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
                   'first_ms': e2e[0]['ms'], 'all_ms': [round(r['ms'], 3) for r in e2e[:16]], 'reps': len(e2e),
                   'what': 'fresh batch in a warm context: engine.Batch(table) [fcpp_batch_create: the setup, on the device where the device planner '
                           'takes the batch, else host plan + tiler + image + one H2D copy] + output arrays + one step + stream drained; the field '
-                          'records in pinned host memory (FieldTable.pin(): read by the device where they lie; pageable_ms: the same call on '
-                          'pageable records); median of the repetitions after the first; the reference times this call (plan_complete_coverage, MLP:387-465)'}
+                          'records ' + ('resident in device memory (FieldTable.to_device())' if records == 'device' else 'in pinned host memory (FieldTable.pin(): read by the device where they lie)') +
+                          '; pageable_ms: the same call on pageable records; median of the repetitions after the first; the reference times this call (plan_complete_coverage, MLP:387-465)'}
     if pageable_ms is not None:
         end_to_end['pageable_ms'] = pageable_ms
     res = None
@@ -465,7 +479,8 @@ def compact_line(out):
         'metric': out['metric'], 'value': _r(out['value'], 7), 'unit': out['unit'], 'n_gpus': out['n_gpus'], 'steps': out['steps'], 'warmup': out['warmup'],
         'ms_per_step': _r(out['ms_per_step'], 6), 'higher_is_better': True, 'scaling': out['scaling'], 'vs_baseline': out.get('vs_baseline'),
         'vs_baseline_of': out.get('vs_baseline_of'), 'dtype': 'f64', 'data': 'synthetic',
-        'step': 'one plan call (fcpp_batch_plan: setup on the device + output arrays + the hot path) + stream drained',
+        'step': 'one plan call (fcpp_batch_plan: setup on the device + output arrays + the hot path) + stream drained; field records resident in HBM',
+        'ms_pinned_records': _r(out.get('ms_pinned_records'), 5), 'value_pinned_records': _r(out.get('value_pinned_records'), 5),
         'value_step': _r(out.get('value_step'), 6), 'ms_step': _r(out.get('ms_step'), 5),
         'value_sustained': _r(out.get('value_sustained'), 5), 'ms_sustained': _r(out.get('ms_sustained'), 5),
         'config': {'workload': cfg['workload'][:200], 'turn_model': cfg['turn_model'], 'points_per_gpu_step': cfg['points_per_gpu_step'],
@@ -653,11 +668,11 @@ def main():
 
     r = run_planner(E, torch, E.FieldTable.from_rectangles(LH1), E.make_options(), args.steps, args.warmup, mode=args.mode, fence=fence_headline,
                     after_step=count_and_gather, stats_of=stats_slot if use_dist else None, e2e_reps=50, fresh_steps=args.steps, fresh_reps=REPS_SHORT,
-                    after_fresh=after_fresh)
+                    after_fresh=after_fresh, pinned_too=(world == 1))
     sustained = None
     if world == 1:
         t_h = E.FieldTable.from_rectangles(LH1)
-        t_h.pin()
+        t_h.to_device()
         sustained = median(sustained_regions(E, torch, t_h, E.make_vehicle(), E.make_options(), args.steps, REPS_SHORT, fence_headline))
     dt = allmax(r['dt'])
     fresh_dt = allmax(median(r['fresh']['dts']))
@@ -681,12 +696,14 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'step': 'one plan call of the reference for the whole batch (plan_complete_coverage, MLP:387-465: a NEW field set up and its path generated): '
                     'engine.Batch.plan(table) = fcpp_batch_plan (the setup on the device, the output arrays from the context\'s arena, the hot path) + the stream drained; '
-                    'field records in pinned host memory, read by the device where they lie',
+                    'field records resident in device memory when the region starts (FieldTable.to_device(); ms_pinned_records: the same call on records in pinned host memory)',
             'timed_region': {'reps': len(r['fresh']['dts']), 'steps_per_rep': args.steps, 'ms_per_step_each_rep': [round(d / args.steps * 1e3, 5) for d in r['fresh']['dts']],
                              'reported': 'median'},
             # the hot path on the batch that is set up (rounds 1-4's `value`): K steps per region, the kernels alone
             'value_step': total_points * args.steps / dt, 'ms_step': dt / args.steps * 1e3, 'timed_region_step': timed_region_of(r),
             'end_to_end_frac': BYTES_PER_POINT * r['points'] / (fresh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            **({'ms_pinned_records': r['fresh']['pinned_ms_per_call'], 'value_pinned_records': r['points'] / (r['fresh']['pinned_ms_per_call'] * 1e-3)}
+               if r['fresh'].get('pinned_ms_per_call') else {}),
             # two plan calls in flight on two streams: the sustained fresh-batch rate, reported as such
             **({'value_sustained': total_points * args.steps / sustained, 'ms_sustained': sustained / args.steps * 1e3,
                 'sustained': 'fresh plan calls alternating between two streams, batch k + 1 set up while batch k\'s step runs; not `value`'} if sustained else {}),
@@ -968,7 +985,7 @@ def run_cfg5(E, S, WL, torch, dist, np, rank, world, dev, cdev, fence, allmax, s
     """cfg5: 65 536 parallelograms through sharding.plan_sharded -- one block of fields per rank, cut on the analytic point counts."""
     V = WL.cfg5_parallelograms()
     t0 = time.perf_counter()
-    table = E.FieldTable.from_vertices(V).pin()        # (records in pinned host memory: the device reads them where they lie)
+    table = E.FieldTable.from_vertices(V).to_device()        # (records resident in device memory; the ranks' blocks are contiguous slices of them)
     t_table = (time.perf_counter() - t0) * 1e3
     veh, opt = E.make_vehicle(), E.make_options()
     # ---- the job end to end, E2E_REPS times: sizing of all fields (every rank, threaded, no collective), this rank's fresh batch, its

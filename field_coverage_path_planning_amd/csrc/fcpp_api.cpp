@@ -615,6 +615,25 @@ int fcpp_memcpy_d2h(fcpp_ctx *c, void *dst, const void *src, int64_t bytes)
     return FCPP_OK;
 }
 
+namespace {
+// Field records that live in DEVICE memory (round 5: a table kept on the GPU -- engine.FieldTable.to_device(), a caller whose fields are
+// made there -- is read by the device-side setup where it lies, like pinned records, without crossing PCIe): the HOST paths (host plan,
+// fcpp_plan_count, a batch the device planner hands back) read a copy.  -> `host` = fields, or copy.data()
+int host_fields(const fcpp_field *fields, int64_t n_fields, std::vector<fcpp_field> &copy, const fcpp_field *&host)
+{
+    host = fields;
+    if (n_fields <= 0 || !fields) return FCPP_OK;
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, fields) != hipSuccess) { (void)hipGetLastError(); return FCPP_OK; }      // (pageable memory, or no GPU at all)
+    if (at.type != hipMemoryTypeDevice) return FCPP_OK;
+    try { copy.resize((size_t)n_fields); } catch (const std::bad_alloc &) { return fail(FCPP_ENOMEM, "out of host memory"); }
+    HIPCHK(hipMemcpy(copy.data(), fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyDeviceToHost));
+    host = copy.data();
+    return FCPP_OK;
+}
+}  // namespace
+
 int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
                     const fcpp_polys *obstacles, fcpp_field_info *info_out)
 {
@@ -622,7 +641,10 @@ int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_
         return fail(FCPP_EINVAL, "bad arguments");
     HostPlan hp;
     std::string err;
-    int rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, false, hp, err);
+    std::vector<fcpp_field> fcopy;
+    int rc = host_fields(fields, n_fields, fcopy, fields);
+    if (rc != FCPP_OK) return rc;
+    rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, false, hp, err);
     if (rc != FCPP_OK) return fail(rc, err);
     if (n_fields) memcpy(info_out, hp.info.data(), (size_t)n_fields * sizeof(fcpp_field_info));
     return FCPP_OK;
@@ -649,6 +671,8 @@ int fcpp_plan_points(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *o
                            pc.max_prims <= DEVPLAN_PRIMS_CAP && !tune_enabled();
     if (!on_device) {
         HostPlan hp;
+        std::vector<fcpp_field> fcopy;
+        if ((rc = host_fields(fields, n_fields, fcopy, fields)) != FCPP_OK) return rc;
         rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, false, hp, err);
         if (rc != FCPP_OK) return fail(rc, err);
         for (int64_t i = 0; i < n_fields; ++i) points_out[i] = hp.info[(size_t)i].n_main + hp.info[(size_t)i].n_head;
@@ -809,8 +833,11 @@ int device_fields(const fcpp_field *fields, int64_t n_fields, hipStream_t st, co
         dev = static_cast<const fcpp_field *>(dp);
         return FCPP_OK;
     }
+    // (records in DEVICE memory: read where they lie when they are this context's device's, copied from the peer otherwise)
+    int cur = -1;
+    if (at.type == hipMemoryTypeDevice && hipGetDevice(&cur) == hipSuccess && at.device == cur) { dev = fields; return FCPP_OK; }
     (void)hipGetLastError();          // (pageable memory: "invalid value" on some runtimes, hipMemoryTypeUnregistered on others)
-    DEVCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), hipMemcpyHostToDevice, st));
+    DEVCHK(hipMemcpyAsync(s.fields_in, fields, (size_t)n_fields * sizeof(fcpp_field), at.type == hipMemoryTypeDevice ? hipMemcpyDefault : hipMemcpyHostToDevice, st));
     dev = s.fields_in;
     return FCPP_OK;
 }
@@ -1085,7 +1112,10 @@ int fcpp_batch_create(fcpp_ctx *c, const fcpp_vehicle *veh, const fcpp_options *
 
     // ---- 2. host plan: __init__ + the O(1) decisions of every field, blocks of fields side by side (fcpp_host.cpp)
     t0 = std::chrono::steady_clock::now();
-    int rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, true, b->hp, err);
+    std::vector<fcpp_field> fcopy;             // (records in device memory: the host plans a copy)
+    int rc = host_fields(fields, n_fields, fcopy, fields);
+    if (rc != FCPP_OK) { if (fresh) (void)hipStreamSynchronize(st); return rc; }
+    rc = build_host_plan(*veh, *opt, n_fields, fields, obstacles, true, b->hp, err);
     if (rc != FCPP_OK) { if (fresh) (void)hipStreamSynchronize(st); return fail(rc, err); }
     tm.host_plan_ms = ms_since(t0);
 

@@ -149,6 +149,7 @@ class FieldTable:
 
     def __init__(self, rec, poly_offsets=None, poly_x=None, poly_y=None):
         self._cargs = None
+        self._dev = None            # the records' copy in device memory after to_device() (a torch uint8 tensor)
         self.rec = rec
         self._pinned = None         # the pinned buffer the records live in after pin()
         self.poly_offsets = np.zeros(1, dtype=np.int64) if poly_offsets is None else np.ascontiguousarray(poly_offsets, dtype=np.int64)
@@ -164,6 +165,7 @@ class FieldTable:
     def rec(self, value):
         self._rec = value
         self._cargs = None          # (the pointers c_args() made are another array's)
+        self._dev = None            # (and so is the copy on the device)
 
     def __len__(self):
         return int(self.rec.shape[0])
@@ -173,6 +175,11 @@ class FieldTable:
             raise TypeError('a FieldTable is sliced, not indexed')
         t = FieldTable(self.rec[sl], self.poly_offsets, self.poly_x, self.poly_y)
         t._pinned = self._pinned    # (a slice of pinned records is pinned, and keeps the buffer alive)
+        if self._dev is not None:   # (a contiguous slice of a table on the device is on the device)
+            lo, hi, step = sl.indices(len(self))
+            if step == 1:
+                sz = _field_dtype().itemsize
+                t._dev = self._dev[lo * sz:max(lo, hi) * sz]
         return t
 
     def pin(self):
@@ -186,6 +193,20 @@ class FieldTable:
             rec = buf.numpy().view(dt)[:n]
             rec[...] = self.rec
             self.rec, self._pinned, self._cargs = rec, buf, None
+        return self
+
+    def to_device(self, device=None):
+        """Copies the records into DEVICE memory (once; needs a GPU): fcpp_batch_plan / fcpp_batch_create / fcpp_plan_points then read them
+        where they lie -- nothing crosses PCIe in front of the plan call's first kernel (the headline's 512 KB of records were ~10 us of
+        it), as for a table whose fields are made on the GPU.  `rec` stays the host's copy (slicing, sharding): records written in place
+        afterwards are NOT seen by the library until to_device() is called again on a table with a new `rec`.  The host paths of the library
+        (a handful of fields, AVOID mode, FCPP_SETUP=host) copy the records back first.  -> self"""
+        if self._dev is None:
+            torch = _torch()
+            rec = np.ascontiguousarray(self.rec)
+            dev = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+            self._dev = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev)
+            self._cargs = None
         return self
 
     @staticmethod
@@ -265,6 +286,10 @@ class FieldTable:
         rec = self.rec if contiguous else np.ascontiguousarray(self.rec)
         polys = L.Polys(len(self.poly_offsets) - 1, self.poly_offsets.ctypes.data_as(L.c_i64_p), self.poly_x.ctypes.data_as(L.c_double_p),
                         self.poly_y.ctypes.data_as(L.c_double_p))
+        if self._dev is not None:
+            cargs = (C.cast(C.c_void_p(self._dev.data_ptr()), C.POINTER(L.Field)), polys, [self._dev, self.poly_offsets, self.poly_x, self.poly_y])
+            self._cargs = cargs
+            return cargs
         cargs = (C.cast(C.c_void_p(rec.ctypes.data), C.POINTER(L.Field)), polys, [rec, self.poly_offsets, self.poly_x, self.poly_y])
         if contiguous:
             self._cargs = cargs

@@ -219,9 +219,14 @@ int fcpp_plan_count(const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_
  * only the field records go up, 8 bytes per field come back), else on the host's cores like fcpp_plan_count.  Synchronises. */
 int fcpp_plan_points(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields, const fcpp_field *fields,
                      const fcpp_polys *obstacles, int64_t *points_out);
-/* Same setup, plus the per-field descriptors and the kernels' work lists on the device.  `fields` is host memory, read only during the
- * call.  Records in PINNED host memory (hipHostMalloc / hipHostRegister, a torch tensor with pin_memory) are read by the device-side setup
- * where they lie -- no copy goes before its first kernel (fcpp_plan_points likewise); pageable records are copied to the device first. */
+/* Same setup, plus the per-field descriptors and the kernels' work lists on the device.  `fields` is read only during the call; it may be
+ *   - DEVICE memory (round 5; engine.FieldTable.to_device(), a caller whose field table lives on the GPU): the device-side setup reads the
+ *     records where they lie, nothing crosses PCIe in front of its first kernel (the headline's plan call 0.145 -> 0.138 ms); the writes that
+ *     made the records must be ordered before the context's stream.  Records on another device are copied over.  The library's host paths
+ *     (fewer than 16 fields, AVOID mode, FCPP_SETUP_HOST, fcpp_plan_count) copy them back first;
+ *   - PINNED host memory (hipHostMalloc / hipHostRegister, a torch tensor with pin_memory): read by the device-side setup across PCIe where
+ *     they lie -- no copy goes before its first kernel (fcpp_plan_points likewise);
+ *   - pageable host memory: copied to the device first. */
 int fcpp_batch_create(fcpp_ctx *ctx, const fcpp_vehicle *veh, const fcpp_options *opt, int64_t n_fields,
                       const fcpp_field *fields, const fcpp_polys *obstacles, fcpp_batch **batch);
 int fcpp_batch_info(const fcpp_batch *batch, fcpp_field_info *info_out /* n_fields, may be NULL */,

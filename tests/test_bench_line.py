@@ -21,7 +21,7 @@ def _fake_out(n_configs=12):
     e2e = {'ms': 0.19, 'points_per_s': 3.6e10, 'create_ms': 0.13, 'setup_ms': {'host_plan': 0.1}, 'what': 'x' * 400}
     out = {'metric': bench.METRIC, 'value': 4.2e10, 'unit': 'points/s', 'n_gpus': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 0.165, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'step': 'one plan call ' + 'y' * 300,
-           'value_step': 1.08e11, 'ms_step': 0.0641, 'value_sustained': 6.0e10, 'ms_sustained': 0.1155, 'end_to_end_frac': 36 * 6926336 / 0.165e-3 / 8e12,
+           'value_step': 1.08e11, 'ms_step': 0.0641, 'value_sustained': 6.0e10, 'ms_sustained': 0.1155, 'ms_pinned_records': 0.1741, 'value_pinned_records': 3.98e10, 'end_to_end_frac': 36 * 6926336 / 0.165e-3 / 8e12,
            'value_end_to_end': 3.6e10, 'end_to_end': e2e,
            'config': {'workload': 'w' * 700, 'turn_model': 'arc (reference, pinned)', 'points_per_gpu_step': r['points'], 'fields_per_gpu': 4096, 'setup': 'device'},
            'timed_region': {'reps': 25, 'steps_per_rep': 20, 'ms_per_step_each_rep': [0.0563, 0.0565, 0.0594] + [0.0545] * 22, 'reported': 'median'},
@@ -44,6 +44,8 @@ def test_compact_line_is_short_and_complete():
     assert d['value'] == 4.2e10 and d['ms_per_step'] == 0.165 and d['value_step'] == 1.08e11 and d['ms_step'] == 0.0641 and d['step'].startswith('one plan call')
     # ... and the sustained rate of two plan calls in flight, under its own name
     assert d['value_sustained'] == 6.0e10 and d['ms_sustained'] == 0.1155
+    # `value` has the field records resident in HBM; the same call on records in pinned host memory rides along (round 5b)
+    assert d['ms_pinned_records'] == 0.1741 and d['value_pinned_records'] == 3.98e10 and 'HBM' in d['step']
     rf = d['roofline']
     # the dominant kernel: its own launch duration and fraction, and what bounds it (the wave-tile kernels: float64 vector issue)
     assert rf['kernel'] == 'k_plan_sparse_fields' and rf['bound'] == 'valu_f64' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0

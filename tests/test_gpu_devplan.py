@@ -356,3 +356,60 @@ def test_random_fields_at_dense_sampling_tables_equal_the_hosts(seed):
         bd, bh = _both(table, veh, E.make_options(tm, sp, ring_order=ring))
         assert (bd.info.array['status'] != 0).any() and (bd.info.array['status'] == 0).any()
         _compare(bd, bh, f'seed {seed} turn model {tm} ring {ring} spacing {sp}')
+
+
+def test_field_records_in_device_memory_equal_host_records():
+    """Round 5: a FieldTable kept in DEVICE memory (FieldTable.to_device(): fcpp_batch_plan / fcpp_batch_create / fcpp_plan_points read the
+    records where they lie, nothing crosses PCIe before the first kernel) plans bit for bit what the same table in pageable and in pinned host
+    memory plans -- on the device path (a batch), on the host paths that copy the records back (a handful of fields, FCPP_SETUP=host, AVOID
+    mode), for a contiguous slice (a shard), and for the sizing calls."""
+    import torch
+    rng = np.random.default_rng(77)
+    LH = rng.uniform(100.0, 900.0, size=(700, 2))
+    LH[5] = (15.0, 200.0)                                   # a field that raises
+    veh = E.make_vehicle()
+
+    def bits(t):
+        return t.view(torch.int64) if t.dtype == torch.float64 else t
+
+    def planned(table, opt):
+        b, r = E.Batch.plan(table, veh, opt)
+        torch.cuda.synchronize()
+        out = [bits(t).clone() for t in (r.x, r.y, r.kappa, r.v, r.flagseg, r.stats_raw)], b.setup_path(), bytes(b.info.array.tobytes())
+        b.close()
+        return out
+
+    ctx = E.get_context()
+    for opt in (E.make_options(), E.make_options(1, 0.5)):
+        host = E.FieldTable.from_rectangles(LH)
+        pinned = E.FieldTable.from_rectangles(LH).pin()
+        dev = E.FieldTable.from_rectangles(LH).to_device()
+        assert dev._dev is not None and dev._dev.is_cuda and dev.c_args()[0] is not None
+        want, path, info = planned(host, opt)
+        assert path == 'device'
+        for t in (pinned, dev):
+            got, p, i = planned(t, opt)
+            assert p == 'device' and i == info
+            assert all(torch.equal(a, b) for a, b in zip(got, want))
+        # a shard of the table on the device is on the device; a handful of fields goes to the host, which reads a copy
+        for sl in (slice(100, 431), slice(3, 9)):
+            w, pw, iw = planned(host[sl], opt)
+            g, pg, ig = planned(dev[sl], opt)
+            assert dev[sl]._dev is not None and pg == pw and ig == iw and all(torch.equal(a, b) for a, b in zip(g, w))
+        assert planned(dev[3:9], opt)[1] == 'host'
+        ctx.set_setup('host')
+        try:
+            g, pg, ig = planned(dev, opt)
+            w, pw, iw = planned(host, opt)
+        finally:
+            ctx.set_setup('auto')
+        assert pg == pw == 'host' and ig == iw and all(torch.equal(a, b) for a, b in zip(g, w))
+        assert np.array_equal(E.plan_points(dev, veh, opt), E.plan_points(host, veh, opt))
+        assert bytes(E.plan_count(dev, veh, opt).array.tobytes()) == bytes(E.plan_count(host, veh, opt).array.tobytes())
+    # AVOID mode is planned on the host: records (and obstacle ranges) from the device copy
+    specs = [E.FieldSpec(field_length=400.0 + 10 * k, field_width=220.0, obstacles=[[(150.0, 100.0), (170.0, 100.0), (170.0, 112.0), (150.0, 112.0)]])
+             for k in range(20)]
+    opt = E.make_options(avoid_obstacles=True)
+    w, pw, iw = planned(E.FieldTable.from_specs(specs), opt)
+    g, pg, ig = planned(E.FieldTable.from_specs(specs).to_device(), opt)
+    assert pg == pw == 'host' and ig == iw and all(torch.equal(a, b) for a, b in zip(g, w))

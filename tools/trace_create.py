@@ -32,7 +32,9 @@ else:
     table = E.FieldTable.from_rectangles(np.tile(np.array([[500.0, 200.0]]), (4096, 1)))
     if what == 'cfg1_clothoid':
         opt = E.make_options(1, 0.0)
-if not os.environ.get('FCPP_NO_PIN'):
+if os.environ.get('FCPP_RECORDS') == 'device':          # (the records in device memory: FieldTable.to_device())
+    table.to_device()
+elif not os.environ.get('FCPP_NO_PIN'):
     table.pin()
 if os.environ.get('FCPP_ARENA', '1') != '0':
     E.get_context().reserve_outputs(lane_gib=24.0, pitch_gib=24.0)
