@@ -228,9 +228,17 @@ def run_planner(E, torch, table, opt, steps, warmup, mode=1, calibrate=0, fence=
     # the field records: resident in DEVICE memory when the timed regions start (records='device', round 5b: FieldTable.to_device() -- inputs in
     # HBM), or in pinned host memory, read by the device across PCIe where they lie ('pinned': rounds 4-5a).  The host paths of the library
     # (cfg3's single field, AVOID mode) copy device records back first -- inside the call, on the clock.
+    # A batch the HOST sets up (cfg3's single field, AVOID mode) keeps its records in pinned host memory: the host plans them, a table on the
+    # device would be copied back first (30-40 us of every call, measured: cfg3 0.442 -> 0.480 ms).
     if records == 'device' and hasattr(table, 'to_device'):
-        table.to_device()
-    elif hasattr(table, 'pin'):
+        probe = E.Batch(table, veh, opt)
+        on_device = probe.setup_path() == 'device'
+        probe.close()
+        if on_device:
+            table.to_device()
+        else:
+            records = 'pinned'
+    if records != 'device' and hasattr(table, 'pin'):
         table.pin()
     for rep in range(max(1, e2e_reps)):
         if batch is not None:
@@ -427,6 +435,7 @@ def config_entry(name, workload, r, cpu=None, extra=None, traffic_key=None):
          'quiet_points': r['quiet_points'], 'general_points': r['general_points'], 'roofline': roofline_of(r, traffic_key or name), 'cpu_baseline': cpu}
     if r.get('fresh'):
         e['ms_fresh'] = r['fresh']['ms_per_call']
+        e['records'] = r['fresh'].get('records')          # (where the field records lay: 'device' = resident in HBM, 'pinned' = host memory the device reads / the host plans)
         e['value_fresh'] = r['points'] / (r['fresh']['ms_per_call'] * 1e-3)
         e['fresh_region'] = {'reps': len(r['fresh']['dts']), 'calls_per_rep': r['fresh']['steps'],
                              'ms_per_call_each_rep': [round(d / r['fresh']['steps'] * 1e3, 5) for d in r['fresh']['dts']], 'reported': 'median',

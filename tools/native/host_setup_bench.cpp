@@ -57,7 +57,8 @@ int main(int argc, char **argv)
     const int n_run = (int)fields.size();
     double best[4] = { 1e30, 1e30, 1e30, 1e30 };
     ImageLayout lay;
-    for (int rep = 0; rep < 9; ++rep) {
+    const int n_reps = getenv("REPS") ? atoi(getenv("REPS")) : 9;
+    for (int rep = 0; rep < n_reps; ++rep) {
         HostPlan hp;
         std::string err;
         double t0 = now_ms();
