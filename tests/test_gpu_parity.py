@@ -4,6 +4,8 @@
 Tolerances (float64): coordinates 1e-9 m (the bar in BASELINE.json is 1e-6 m), curvature 1e-9 1/m,
 speeds 1e-9 km/h at the reference's sampling; integers (counts, swath indices, flags) exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -92,6 +94,8 @@ def _compare_with_oracle(specs, ofields, veh_arr, opt_kw, xy_tol=XY_TOL, k_tol=K
 
 def _compare_with_oracle_mode(mode, specs, ofields, veh_arr, opt_kw, xy_tol, k_tol, v_tol):
     o = E.make_options(**opt_kw)
+    if os.environ.get('FCPP_FUZZ_RECORDS') == 'device':          # (tools/fuzz_parity.py: the field records resident in device memory)
+        specs = E.as_table(specs).to_device()
     batch = E.Batch(specs, _veh(veh_arr), o)
     res = batch.run(mode=mode)
     x, y, v, k, fs = _np(res.x), _np(res.y), _np(res.v), _np(res.kappa), _np(res.flagseg).view(np.uint32)
