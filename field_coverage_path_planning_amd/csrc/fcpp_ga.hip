@@ -620,16 +620,23 @@ __global__ __launch_bounds__(SB) void k_ga_stats_elite(int n, int pop, const int
 // (generation index gen; GA_PAIRS_PER_WG wavefronts = pairs per workgroup).  The two roles read the same population and write
 // disjoint rows, so they need no order between them; a generation then costs the longer role, not the sum of two launches.
 // stats_gen == -2: no bookkeeping role (never used); pairs_gen < 0: no children (the final population's statistics).
-static constexpr int GA_PAIRS_PER_WG = 8;       // of the workgroup's 16 wavefronts (the others leave at once): 2048 pairs = 256 workgroups, one per compute unit, two
-                                                // pair wavefronts per SIMD -- with sixteen pairs per workgroup half the chip idled while four wavefronts shared every SIMD of the other half
+static constexpr int GA_PAIRS_PER_WG = 8;       // of the workgroup's 16 wavefronts (the others leave at once): two pair wavefronts per SIMD -- with sixteen pairs per
+                                                // workgroup half the chip idled while four wavefronts shared every SIMD of the other half
+// Round 5b: ALL workgroups of a launch resident at once.  The kernel holds 98 vector registers -- four wavefronts per SIMD, so a compute unit takes
+// ONE workgroup of 1024 threads, and a pair workgroup's eight idle wavefronts free nothing a sixteen-wavefront workgroup could use.  2048 pairs as 256
+// workgroups of 8 + the two single roles = 258 workgroups on 256 compute units: the last two waited for a compute unit to drain, and the launch took two
+// roles' time (11.5 us for roles of at most 5.2).  The pairs are now spread over (compute units - 2) workgroups, 8 or 9 of them each (at most
+// GA_PAIRS_MAX; more pairs than that: 8 per workgroup and as many workgroups as it takes, as before): workgroup b takes the pairs
+// [b base + min(b, extra), ...) with base = pairs / workgroups, extra = pairs % workgroups.
+static constexpr int GA_PAIRS_MAX = 16;
 __global__ __launch_bounds__(SB) void k_ga_generation(int n, int pop, const double *__restrict__ D, const int32_t *__restrict__ cur,
                                                       const double *__restrict__ cur_fit, const double *__restrict__ cur_dist,
                                                       int32_t *__restrict__ nxt, double *__restrict__ nxt_fit, double *__restrict__ nxt_dist,
-                                                      fcpp_ga_config cfg, int gen, int pair_lds_ints, GaState *__restrict__ state,
-                                                      int32_t *__restrict__ best_route, double *__restrict__ hist)
+                                                      fcpp_ga_config cfg, int gen, int pair_lds_ints, int pairs_base, int pairs_extra,
+                                                      GaState *__restrict__ state, int32_t *__restrict__ best_route, double *__restrict__ hist)
 {
     extern __shared__ double dyn_lds[];
-    __shared__ int s_w[GA_PAIRS_PER_WG][2];
+    __shared__ int s_w[GA_PAIRS_MAX][2];
     // (the children of the generation in which convergence is found go to the buffer that is not the result; the pairs and the elites
     // ask for the flag first and look at it last, before anything is written: its round trip runs beside their own loads)
     const int conv = __atomic_load_n(&state->converged, __ATOMIC_RELAXED);
@@ -648,8 +655,10 @@ __global__ __launch_bounds__(SB) void k_ga_generation(int n, int pop, const doub
         return;
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pair = (blockIdx.x - 2) * GA_PAIRS_PER_WG + wave;
-    if (wave >= GA_PAIRS_PER_WG || pair >= pop / 2 || gen >= cfg.max_generations) return;
+    const int b = (int)blockIdx.x - 2;
+    const int mine = pairs_base + (b < pairs_extra ? 1 : 0);                       // this workgroup's pairs, a wavefront each
+    const int pair = b * pairs_base + (b < pairs_extra ? b : pairs_extra) + wave;
+    if (wave >= mine || pair >= pop / 2 || gen >= cfg.max_generations) return;
     GSTAMP(8);
     ga_pair(lane, pair, reinterpret_cast<int32_t *>(dyn_lds) + (size_t)wave * pair_lds_ints, s_w[wave], n, pop, D, cur, cur_fit, nxt, nxt_fit,
             nxt_dist, cfg, gen, conv);
@@ -712,6 +721,29 @@ int launch_ga_stats_elite(hipStream_t st, int n, int pop, const int32_t *cur, co
 // lds ints of one pair: 4 n genes + n presence bytes, rounded to 16 bytes
 static inline size_t ga_pair_lds_ints(int n) { return GA_PAIR_LDS_HEAD(n) + 128; }
 
+// how a launch spreads pop / 2 pairs over its workgroups: -> pair workgroups; base / extra as k_ga_generation reads them; per_wg = the most pairs of one
+static unsigned ga_pair_groups(int n, int pop, int &base, int &extra, int &per_wg)
+{
+    static const int n_cu = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); cu = 0; }
+        return cu;
+    }();
+    const int pairs = pop / 2;
+    int groups = n_cu > 2 ? n_cu - 2 : 0;
+    if (groups > pairs) groups = pairs;
+    const int most = groups > 0 ? (pairs + groups - 1) / groups : 0;
+    if (groups <= 0 || most > GA_PAIRS_MAX || most < GA_PAIRS_PER_WG || ga_pair_lds_ints(n) * sizeof(int32_t) * (size_t)most > 60 * 1024) {
+        // (too many pairs for one round of workgroups -- or tours too long for that many pairs' LDS --, or so few that eight a workgroup already fit:
+        // eight per workgroup)
+        groups = (pairs + GA_PAIRS_PER_WG - 1) / GA_PAIRS_PER_WG;
+        base = GA_PAIRS_PER_WG; extra = 0; per_wg = GA_PAIRS_PER_WG;
+        return (unsigned)groups;
+    }
+    base = pairs / groups; extra = pairs % groups; per_wg = base + (extra ? 1 : 0);
+    return (unsigned)groups;
+}
+
 bool ga_generation_fits(int n, int pop)
 {
     return pop <= GA_LDS_POP && ga_pair_lds_ints(n) * sizeof(int32_t) * GA_PAIRS_PER_WG <= 60 * 1024;
@@ -722,10 +754,11 @@ int launch_ga_generation(hipStream_t st, int n, int pop, const double *D, const 
                          int32_t *best_route, double *hist)
 {
     const size_t pl = ga_pair_lds_ints(n);
-    const size_t lds = std::max(pl * sizeof(int32_t) * GA_PAIRS_PER_WG, (size_t)pop * sizeof(double));
-    const unsigned blocks = (unsigned)((pop / 2 + GA_PAIRS_PER_WG - 1) / GA_PAIRS_PER_WG) + 2u;
+    int base = 0, extra = 0, per_wg = 0;
+    const unsigned blocks = ga_pair_groups(n, pop, base, extra, per_wg) + 2u;
+    const size_t lds = std::max(pl * sizeof(int32_t) * (size_t)per_wg, (size_t)pop * sizeof(double));
     hipLaunchKernelGGL(k_ga_generation, dim3(blocks), dim3(SB), lds, st, n, pop, D, cur, cur_fit, cur_dist, nxt, nxt_fit, nxt_dist, cfg, gen,
-                       (int)pl, state, best_route, hist);
+                       (int)pl, base, extra, state, best_route, hist);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
