@@ -212,6 +212,7 @@ struct fcpp_ctx {
     void *verify_scratch = nullptr;                 // sliced reduction of the standalone operators' long paths (reduce_paths)
     size_t verify_scratch_cap = 0;
     int64_t *plan_totals_host = nullptr;            // pinned, PC_COLS + PF_COUNT values: the scans of the counting phase write them here
+    unsigned long long *ga_mirror = nullptr;        // pinned, one word: (converged << 32) | generations of the running fcpp_ga_evolve (GaState::mirror)
     int64_t plan_gen = 0;                           // generation number of the last counting phase (PlanFlag, fcpp_devplan.h)
     // the stream the last device-side setup was enqueued on (its fill pass may still read the scratch): a setup on ANOTHER stream records
     // ev_plan there and waits for it -- lazily, when that other stream shows up: an event recorded between two kernels of the plan call
@@ -456,6 +457,7 @@ int fcpp_ctx_destroy(fcpp_ctx *c)
     for (hipEvent_t e : c->ev_chunk) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->plan_totals_host) (void)hipHostFree(c->plan_totals_host);
+    if (c->ga_mirror) (void)hipHostFree(c->ga_mirror);
     if (c->verify_scratch) (void)hipFree(c->verify_scratch);
     c->templates.reset();
     delete c;
@@ -1797,6 +1799,17 @@ int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const doub
     HIPCHK(fd.alloc((size_t)pop * 4));
     HIPCHK(state.alloc(1));
     HIPCHK(hipMemsetAsync(state.p, 0, sizeof(GaState), st));
+    // the run's progress in a word of pinned memory the bookkeeping role writes (GaState::mirror): followed without draining the stream
+    if (!c->ga_mirror && hipHostMalloc((void **)&c->ga_mirror, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { c->ga_mirror = nullptr; (void)hipGetLastError(); }
+    volatile unsigned long long *mir = c->ga_mirror;
+    void *mirror_dp = nullptr;                      // (the word as the device addresses it; lives until the copy below has read it)
+    if (mir) {
+        *mir = 0ull;
+        if (hipHostGetDevicePointer(&mirror_dp, c->ga_mirror, 0) == hipSuccess && mirror_dp) {
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<unsigned char *>(state.p) + offsetof(GaState, mirror), &mirror_dp, sizeof mirror_dp, hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));       // (once per run, in front of its first launch)
+        } else { mir = nullptr; (void)hipGetLastError(); }
+    }
     {   // the initial population must consist of permutations: the kernels index D and their LDS marks by gene
         DevBuf<int32_t> bad;
         int32_t hb = 0;
@@ -1819,6 +1832,20 @@ int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const doub
             const int a = g & 1, b = a ^ 1;
             LAUNCHCHK(launch_ga_generation(st, n, pop, D, buf[a], fit[a], dist[a], buf[b], fit[b], dist[b], *cfg, g, state.p, best_route, hist));
             if ((g & 31) == 31) {                      // the kernel is a no-op once converged; stop launching it
+                // Round 5b: the check is PIPELINED.  The bookkeeping role of launch L leaves `generations` = L in the mirror word, so the
+                // host waits -- on that word, not on the stream -- only until launch g - 63 is through: two blocks of 32 launches are in
+                // flight at most, the device never runs dry at a check (it used to: a copy back and a drained stream every 32 generations,
+                // ~20 us of idle device each = 0.5 us of a generation's 10), and a converged run is noticed within 64 launches (no-ops by then).
+                if (mir) {
+                    const auto t_wait = std::chrono::steady_clock::now();
+                    bool seen = false;
+                    for (int spin = 0; !seen; ++spin) {
+                        const unsigned long long w = *mir;
+                        seen = (w >> 32) != 0 || (long long)(w & 0xffffffffull) >= (long long)g - 63;
+                        if (!seen && (spin & 4095) == 4095 && ms_since(t_wait) > 2000.0) break;
+                    }
+                    if (seen) { if ((*mir >> 32) != 0) break; continue; }
+                }
                 HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (h.converged) break;

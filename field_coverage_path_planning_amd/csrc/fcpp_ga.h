@@ -16,6 +16,10 @@ struct GaState {
     // fitness of the last (elite_size-th) elite of the previous generation: elitism carries the elites over, so the elites of the
     // next population are among its last elite_size rows and the members strictly above this value (0 before the first selection: everybody)
     double elite_thr;
+    // round 5b: a word of the host's pinned memory (or null) the bookkeeping role writes after every generation it completes --
+    // (converged << 32) | generations, one 8-byte store -- so that fcpp_ga_evolve follows the run without a copy command or a drained
+    // stream between the generations' launches (it used to drain the stream every 32 generations: a bubble of ~20 us each time)
+    unsigned long long *mirror;
 };
 
 constexpr int GA_MAX_NODES = 2048;

@@ -425,6 +425,9 @@ __device__ __forceinline__ void ga_stats_elite(double *s_fit, int n, int pop, co
             if (state->gwi >= cfg.convergence_threshold) { state->converged = 1; stop = 1; }                              // GA:110-113
         }
         s_copy = copy; s_stop = stop;
+        if (state->mirror)
+            __hip_atomic_store(state->mirror, ((unsigned long long)(unsigned)state->converged << 32) | (unsigned long long)(unsigned)state->generations,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     if (s_copy >= 0)
