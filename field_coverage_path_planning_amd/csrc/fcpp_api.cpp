@@ -1824,6 +1824,18 @@ int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const doub
     double *fit[2] = { fd.p, fd.p + 2 * (size_t)pop }, *dist[2] = { fd.p + pop, fd.p + 3 * (size_t)pop };
     LAUNCHCHK(launch_ga_fitness(st, n, pop, D, routes, dist[0], fit[0], 0));                       // GA:64
     GaState h = {};
+    // the pipelined convergence check (round 5b): has the bookkeeping of generation g - 63 been done (mirror word: generations >= g - 63)?
+    // -> 1: the run has converged, 0: go on, -1: no mirror word / not seen within 2 s (the caller falls back to a copy back + drained stream)
+    auto follow = [&](int g) -> int {
+        if (!mir) return -1;
+        const auto t_wait = std::chrono::steady_clock::now();
+        for (int spin = 0;; ++spin) {
+            const unsigned long long w = *mir;
+            if ((w >> 32) != 0) return 1;
+            if ((long long)(w & 0xffffffffull) >= (long long)g - 63) return 0;
+            if ((spin & 4095) == 4095 && ms_since(t_wait) > 2000.0) return -1;
+        }
+    };
     if (ga_generation_fits(n, pop)) {
         // One launch per generation (k_ga_generation): the population in buffer a -> its statistics and elites (the bookkeeping of
         // generation g - 1) and its children (generation g) at once; the launch after the last generation only evaluates the final
@@ -1836,16 +1848,9 @@ int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const doub
                 // host waits -- on that word, not on the stream -- only until launch g - 63 is through: two blocks of 32 launches are in
                 // flight at most, the device never runs dry at a check (it used to: a copy back and a drained stream every 32 generations,
                 // ~20 us of idle device each = 0.5 us of a generation's 10), and a converged run is noticed within 64 launches (no-ops by then).
-                if (mir) {
-                    const auto t_wait = std::chrono::steady_clock::now();
-                    bool seen = false;
-                    for (int spin = 0; !seen; ++spin) {
-                        const unsigned long long w = *mir;
-                        seen = (w >> 32) != 0 || (long long)(w & 0xffffffffull) >= (long long)g - 63;
-                        if (!seen && (spin & 4095) == 4095 && ms_since(t_wait) > 2000.0) break;
-                    }
-                    if (seen) { if ((*mir >> 32) != 0) break; continue; }
-                }
+                const int f = follow(g);
+                if (f == 1) break;
+                if (f == 0) continue;
                 HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
                 if (h.converged) break;
@@ -1880,7 +1885,10 @@ int fcpp_ga_evolve(fcpp_ctx *c, int32_t n, const fcpp_ga_config *cfg, const doub
         HIPCHK(hipStreamWaitEvent(sd, ev.p[g & 1], 0));                 // the children of population g are in b
         LAUNCHCHK(launch_ga_stats_elite(sd, n, pop, buf[b], fit[b], dist[b], buf[a], fit[a], dist[a], *cfg, g, state.p, best_route, hist));
         HIPCHK(hipEventRecord(ev.s[g & 1], sd));
-        if ((g & 31) == 31) {                          // the kernels are no-ops once converged; stop launching them
+        if ((g & 31) == 31) {                          // the kernels are no-ops once converged; stop launching them (pipelined check, as above)
+            const int f = follow(g);
+            if (f == 1) break;
+            if (f == 0) continue;
             HIPCHK(hipMemcpyAsync(&h, state.p, sizeof h, hipMemcpyDeviceToHost, sd));
             HIPCHK(hipStreamSynchronize(sd));
             if (h.converged) break;
